@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py -- text-line images/sec (fwd + CTC + bwd + all-reduce + update) of the MI355X hot path.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N>1 is launched as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  one rank per GPU; ranks shard the minibatch (independent lines, no data-path collective) and
+  all-reduce the 135,883-float gradient buffer over RCCL before the identical update (weak scaling:
+  64 lines per GPU).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[2]/[3]): uw3-500 OCR shape -- BiLSTM(100) on 48-px lines,
+83 classes, T=200 frames, transcripts of 25 labels, minibatch = 64 lines per GPU, synthetic
+inputs (clip(N(0.2,0.3),0,1) smoothed along t), reference LCG init (seed 0.222, negbiased).
+A step = one pass of the hot path over one minibatch whose frames are already resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NI, NH, NC = 48, 100, 83
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TFS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+# algorithmic bytes per cell-step of the fused gate kernels
+BYTES_PER_CELL_STEP = {"lstm_fwd": 44.0, "lstm_bwd": 56.0}
+
+
+def synth_batch(rng, bs, T, ragged):
+    Ts = [int(t) for t in (rng.integers(150, 251, bs) if ragged else [T] * bs)]
+    xs = []
+    for t in Ts:
+        x = np.clip(rng.normal(0.2, 0.3, (t + 2, NI)), 0, 1)
+        xs.append(((x[:-2] + x[1:-1] + x[2:]) / 3.0).astype(np.float32))
+    labels = [rng.integers(1, NC, 25).astype(np.int32) for _ in Ts]
+    return Ts, np.concatenate(xs, 0), labels
+
+
+def cpu_baseline(params, seconds_target=12.0):
+    """The oracle (CPU restatement of the reference's Eigen path, `kind: port`) timed on this box's
+    host cores on a bounded sample of the same workload: fwd+CTC+bwd of T=200 lines, OpenMP over
+    lines (the generous 'Eigen/OpenMP' figure) and single-threaded."""
+    from oracle.oracle import Oracle, OracleNet
+    ora = Oracle("f32")
+    net = OracleNet(ora, NI, NH, NC, init=False)
+    net.set_params(params)
+    rng = np.random.default_rng(123)
+    cores = os.cpu_count() or 1
+    nlines = max(8, cores)
+    Ts, x, labels = synth_batch(rng, nlines, 200, False)
+    offs = np.concatenate([[0], np.cumsum(Ts)])
+    loffs = np.concatenate([[0], np.cumsum([len(l) for l in labels])])
+    lab = np.concatenate(labels)
+    t1 = net.bench_lines(x, offs, lab, loffs, nthreads=1, reps=1)       # also warms the page cache
+    single = nlines / t1
+    reps = max(1, int(seconds_target * single * min(cores, 4) / nlines))
+    tn = net.bench_lines(x, offs, lab, loffs, nthreads=cores, reps=reps)
+    multi = nlines * reps / tn
+    use_multi = multi >= single
+    return {
+        "value": round(multi if use_multi else single, 2), "unit": "lines/s",
+        "cores": cores if use_multi else 1, "kind": "port",
+        "sample": "%d lines x %d reps of T=200 fwd+CTC+bwd, OpenMP over lines on %d threads "
+                  "(%.1f lines/s); single thread %.1f lines/s; gcc -O3 -march=native" %
+                  (nlines, reps, cores, multi, single),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--minibatch", type=int, default=64, help="lines per GPU")
+    ap.add_argument("--T", type=int, default=200)
+    ap.add_argument("--ragged", action="store_true", help="T ~ U{150..250} instead of fixed T")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from clstm_amd import abi
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Network
+    from clstm_amd.parallel import Trainer
+
+    lib = abi.load()   # raises if the HIP extension is missing -- there is no fallback path
+    lib.call("clstm_set_stream", torch.cuda.current_stream().cuda_stream)
+    params_h = init_params(NI, NH, NC, seed=0.222)
+    nparams = params_h.size
+    dev = torch.device("cuda", local_rank)
+    params = torch.from_numpy(params_h).to(dev)
+    derivs = torch.zeros(nparams, device=dev)
+    grads = torch.zeros(nparams, device=dev)
+    net = Network(NI, NH, NC, lib=lib, params=params, derivs=derivs, grads=grads)
+    net.params_changed()
+    net.setLearningRate(1e-4, 0.9)
+    trainer = Trainer(net, grads_tensor=grads)
+
+    # synthetic minibatches resident in HBM before the timed region (a small rotating pool)
+    rng = np.random.default_rng(1000 + rank)
+    pool = []
+    for _ in range(4):
+        Ts, x, labels = synth_batch(rng, args.minibatch, args.T, args.ragged)
+        pool.append((Ts, torch.from_numpy(x).to(dev), labels))
+
+    def step(i):
+        Ts, xd, labels = pool[i % len(pool)]
+        trainer.step_device(Ts, xd, labels)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    lines_total = args.minibatch * world * args.steps
+    value = lines_total / dt
+
+    # per-kernel device time (HIP events on the library's stream) for the roofline object
+    kern = {}
+    roofline = None
+    if rank == 0 and args.profile_steps > 0:
+        net.enable_timing(True)
+        net.reset_timing()
+        frames = 0
+        for i in range(args.profile_steps):
+            step(i)
+            frames += sum(pool[i % len(pool)][0])
+        torch.cuda.synchronize()
+        for name in ("gemm_gates_x", "lstm_fwd", "gemm_softmax", "softmax_norm", "ctc_align",
+                     "gemm_softmax_dx", "gemm_softmax_dw", "lstm_bwd", "gemm_gates_dw", "gemm_gates_dx",
+                     "sgd_update"):
+            ms, n = net.kernel_time_ms(name)
+            if n:
+                kern[name] = {"ms_per_step": round(ms / args.profile_steps, 4), "launches_per_step": n / args.profile_steps}
+        net.enable_timing(False)
+        dom = max(("lstm_fwd", "lstm_bwd"), key=lambda k: kern.get(k, {"ms_per_step": 0})["ms_per_step"])
+        if dom in kern:
+            frames_per_launch = frames / args.profile_steps
+            byts = BYTES_PER_CELL_STEP[dom] * 2 * NH * frames_per_launch      # 2 directions x 100 cells
+            sec = kern[dom]["ms_per_step"] * 1e-3 / kern[dom]["launches_per_step"]
+            ach = byts / sec / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "avg_launch_ms": round(sec * 1e3, 4),
+                        "note": "latency-bound persistent recurrence: %d workgroups (lines x directions) on 256 CUs; "
+                                "recurrent FMA rate %.2f TFLOP/s of %.1f f32 peak" %
+                                (2 * args.minibatch, 8.0 * NH * NH * 2 * frames_per_launch / 2 / sec / 1e12,
+                                 F32_MFMA_PEAK_TFS)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(params_h)
+
+    if rank == 0:
+        out = {
+            "metric": "text-line images/sec (fwd+bwd+CTC), 100-unit BiLSTM H=48 T~200",
+            "value": round(value, 2), "unit": "lines/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "uw3-500 OCR shape: BiLSTM(100) H=48 nc=83, T=%s, L=25, minibatch=%d lines/GPU "
+                                   "(BASELINE.json configs[2]; x%d GPUs = configs[3] sharding), fwd+CTC+bwd+allreduce+update"
+                                   % ("U{150..250}" if args.ragged else args.T, args.minibatch, world),
+                       "minibatch_per_gpu": args.minibatch, "global_minibatch": args.minibatch * world,
+                       "parallelism": "dp%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

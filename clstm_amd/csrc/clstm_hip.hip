@@ -1,0 +1,797 @@
+// clstm_hip.hip -- host orchestration + C ABI (include/clstm_abi.h) of the MI355X hot path.
+//
+// The fused network mirrors Stacked{Parallel{NPLSTM, Reversed{NPLSTM}} x L, SoftmaxLayer}
+// (clstm_prefab.cc:52-109, clstm.cc:391-656) on packed minibatches of text lines:
+//   forward : per layer  G = W_x.x + b   (one MFMA GEMM over every frame of the minibatch)
+//                        lstm_fwd_kernel (persistent recurrence, one workgroup per line x dir)
+//             softmax    Z = W1.[h_f;h_r] + b (MFMA GEMM) ; limexp / column normalise
+//   CTC     : ctc_align_kernel (one workgroup per line), deltas = aligned - Z
+//   backward: softmax dX (MFMA GEMM), dW1 (split-K MFMA GEMM over frames)
+//             per layer lstm_bwd_kernel ; dW = delta.[1;x;h_prev]^T (split-K MFMA GEMM) ;
+//             dX = W_x^T.delta (MFMA GEMM, only where a consumer exists)
+//   update  : k_update on the flat reference-layout buffers, then re-pack kernel weights.
+// Stacked/Parallel/Reversed never copy: they are pointer hand-offs and index arithmetic.
+#include "../../include/clstm_abi.h"
+#include "ctc.h"
+#include "devintrin.h"
+#include "gemm_mfma.h"
+#include "lstm_seq.h"
+#include "ops.h"
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace clstm {
+
+static thread_local std::string g_err;
+static thread_local hipStream_t g_stream = nullptr;
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+#define HIPCHECK(expr)                                                                       \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      throw Error(std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                  ":" + std::to_string(__LINE__) + ")");                                     \
+  } while (0)
+#define REQUIRE(cond, msg)                    \
+  do {                                        \
+    if (!(cond)) throw Error(std::string(msg)); \
+  } while (0)
+#define ABI_BEGIN try {
+#define ABI_END                         \
+  return 0;                             \
+  }                                     \
+  catch (const std::exception& e) {     \
+    g_err = e.what();                   \
+    return 1;                           \
+  }                                     \
+  catch (...) {                         \
+    g_err = "unknown error";            \
+    return 1;                           \
+  }
+
+static inline int nblocks(size_t n, int bs = 256) {
+  size_t b = (n + bs - 1) / bs;
+  if (b < 1) b = 1;
+  if (b > 4096) b = 4096;
+  return (int)b;
+}
+static void check_launch() { HIPCHECK(hipGetLastError()); }
+
+template <class T>
+struct DevBuf {  // grow-only device buffer
+  T* p = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (p) HIPCHECK(hipFree(p));
+    p = nullptr;
+    size_t want = n + n / 4 + 64;
+    HIPCHECK(hipMalloc((void**)&p, want * sizeof(T)));
+    HIPCHECK(hipMemset(p, 0, want * sizeof(T)));
+    cap = want;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// ---- GEMM operand functors ---------------------------------------------------------------------
+struct RowMajorA {  // A(r,k) = p[r*ld + k]
+  const float* p; long long ld;
+  DEVMFN float operator()(int r, int k) const { return p[(long long)r * ld + k]; }
+};
+struct RowMajorB {  // B(k,c) = p[k*ld + c]
+  const float* p; long long ld;
+  DEVMFN float operator()(int k, int c) const { return p[(long long)k * ld + c]; }
+};
+struct TransB {     // B(k,c) = p[c*ld + k]
+  const float* p; long long ld;
+  DEVMFN float operator()(int k, int c) const { return p[(long long)c * ld + k]; }
+};
+struct TransA {     // A(r,k) = p[k*ld + r]
+  const float* p; long long ld;
+  DEVMFN float operator()(int r, int k) const { return p[(long long)k * ld + r]; }
+};
+struct StoreBias {  // out[r*ld + c] = val + bias[c]
+  float* out; long long ld; const float* bias;
+  DEVMFN void operator()(int r, int c, float v, int) const { out[(long long)r * ld + c] = v + bias[c]; }
+};
+struct StorePlain {
+  float* out; long long ld;
+  DEVMFN void operator()(int r, int c, float v, int) const { out[(long long)r * ld + c] = v; }
+};
+struct StorePartial {  // split-K slabs [z][R][Cn]
+  float* out; int R, Cn;
+  DEVMFN void operator()(int r, int c, float v, int z) const { out[((long long)z * R + r) * Cn + c] = v; }
+};
+// A(j, tok) of the weight-gradient products: rows of [1 ; x_tok ; h_prev(tok)]  -- the `source`
+// vector of forward_stack_delay (clstm_compute.cc:377-397) without materialising it.
+struct SourceT {
+  const float* x; long long ldx; int ni;
+  const float* h; long long ldh; int hofs;  // h_prev(tok)[k] = h[prev[tok]*ldh + hofs + k]
+  const int* prev;                          // -1 at the first step of a line
+  DEVMFN float operator()(int j, int tok) const {
+    if (j == 0) return 1.0f;
+    if (j <= ni) return x[(long long)tok * ldx + (j - 1)];
+    const int p = prev[tok];
+    return p < 0 ? 0.0f : h[(long long)p * ldh + hofs + (j - 1 - ni)];
+  }
+};
+struct OnesAndRowsT {  // A(j, tok) = [1 ; h_tok] for the softmax dW
+  const float* h; long long ldh;
+  DEVMFN float operator()(int j, int tok) const { return j == 0 ? 1.0f : h[(long long)tok * ldh + (j - 1)]; }
+};
+
+static const int kNK4Table[] = {1, 2, 4, 7, 8};
+static int pick_nk4(int no) {
+  int need = ((no + 3) / 4 + 3) / 4;
+  for (int v : kNK4Table)
+    if (v >= need) return v;
+  return -1;
+}
+template <int NK4>
+static void launch_fwd(const LstmSeqArgs& a, int bs, int nthreads, hipStream_t s) {
+  const size_t smem = 2 * 4 * (size_t)lstm_qstride(NK4) * sizeof(float);
+  CLSTM_LAUNCH((lstm_fwd_kernel<NK4>), dim3(bs, a.ndir), dim3(nthreads), smem, s, a);
+}
+template <int NK4>
+static void launch_bwd(const LstmSeqArgs& a, int bs, int nthreads, hipStream_t s) {
+  const size_t smem = 2 * 16 * (size_t)lstm_qstride(NK4) * sizeof(float);
+  CLSTM_LAUNCH((lstm_bwd_kernel<NK4>), dim3(bs, a.ndir), dim3(nthreads), smem, s, a);
+}
+static void launch_lstm(bool fwd, int nk4, const LstmSeqArgs& a, int bs, int nthreads, hipStream_t s) {
+  switch (nk4) {
+#define CASE_(N) case N: if (fwd) launch_fwd<N>(a, bs, nthreads, s); else launch_bwd<N>(a, bs, nthreads, s); break;
+    CASE_(1) CASE_(2) CASE_(4) CASE_(7) CASE_(8)
+#undef CASE_
+    default: throw Error("unsupported nhidden for the register-resident recurrence");
+  }
+  check_launch();
+}
+
+// ---- per-kernel device timing (bench.py roofline) ---------------------------------------------
+#ifndef CLSTM_HIP_EMU
+struct Timing {
+  bool on = false;
+  struct Rec { std::string name; hipEvent_t a, b; };
+  std::vector<Rec> pending;
+  std::map<std::string, std::pair<double, int>> acc;
+  void begin(const char* name, hipStream_t s) {
+    if (!on) return;
+    Rec r; r.name = name;
+    HIPCHECK(hipEventCreate(&r.a)); HIPCHECK(hipEventCreate(&r.b));
+    HIPCHECK(hipEventRecord(r.a, s));
+    pending.push_back(r);
+  }
+  void end(hipStream_t s) {
+    if (!on) return;
+    HIPCHECK(hipEventRecord(pending.back().b, s));
+  }
+  void collect(hipStream_t s) {
+    if (pending.empty()) return;
+    HIPCHECK(hipStreamSynchronize(s));
+    for (auto& r : pending) {
+      float ms = 0;
+      HIPCHECK(hipEventElapsedTime(&ms, r.a, r.b));
+      auto& e = acc[r.name];
+      e.first += ms; e.second += 1;
+      (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    pending.clear();
+  }
+};
+#else
+struct Timing {
+  bool on = false;
+  std::map<std::string, std::pair<double, int>> acc;
+  void begin(const char*, hipStream_t) {}
+  void end(hipStream_t) {}
+  void collect(hipStream_t) {}
+};
+#endif
+
+struct Layer {
+  int ni, no, nk4, nthreads;
+  PackDesc pd;
+  float *Wt = nullptr, *bias = nullptr, *Rf = nullptr, *Rb = nullptr;
+  long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
+  DevBuf<float> G, C, H, D, dH;
+};
+
+struct Net {
+  clstm_net_desc desc;
+  int ndir;
+  std::vector<Layer> L;
+  int sm_ni = 0;
+  long long sm_off = 0;
+  int nparams = 0;
+  float *v = nullptr, *d = nullptr, *g = nullptr;
+  bool own_v = false, own_d = false, own_g = false;
+  float lr = 1e-4f, mom = 0.9f, gclip = 100.0f;
+  bool packed_dirty = true;
+  bool want_dx0 = false;
+  // batch
+  int bs = 0;
+  long long N = 0;
+  std::vector<int> line_off_h;
+  DevBuf<int> line_off, prev0, prev1;
+  DevBuf<float> X, Z, Dz, dX0, partial, aligned, tmp;
+  // ctc / decode
+  DevBuf<int> states, state_off, dec_idx, dec_cls, dec_loc, dec_cnt;
+  DevBuf<float> dec_val, lat;
+  DevBuf<long long> lat_off;
+  Timing timing;
+
+  hipStream_t stream() const { return g_stream; }
+
+  void build(const clstm_net_desc& ds, float* pv, float* pd, float* pg) {
+    desc = ds;
+    REQUIRE(ds.nlayers >= 1 && ds.nlayers <= CLSTM_MAX_LAYERS, "nlayers out of range");
+    REQUIRE(ds.ninput > 0 && ds.nclasses >= 2, "bad ninput/nclasses (Softmax requires no>=2, clstm.cc:399)");
+    ndir = ds.unidirectional ? 1 : 2;
+    static const int blockidx[4] = {2, 1, 3, 0};  // slot gi,gf,go,ci -> alphabetical WCI,WGF,WGI,WGO
+    long long off = 0;
+    int ni = ds.ninput;
+    L.resize(ds.nlayers);
+    for (int l = 0; l < ds.nlayers; l++) {
+      Layer& y = L[l];
+      y.ni = ni;
+      y.no = ds.nhidden[l];
+      REQUIRE(y.no > 0, "nhidden must be positive");
+      y.nk4 = pick_nk4(y.no);
+      REQUIRE(y.nk4 > 0, "nhidden > 128 is not supported by the register-resident recurrence yet");
+      y.nthreads = 64 * ((y.no + 15) / 16);
+      const long long blk = (long long)y.no * (1 + y.ni + y.no);
+      y.pd.ni = y.ni; y.pd.no = y.no; y.pd.ndir = ndir; y.pd.nk4 = y.nk4; y.pd.nthreads = y.nthreads;
+      for (int dir = 0; dir < ndir; dir++) {
+        for (int s = 0; s < 4; s++) y.pd.p_off[dir][s] = off + blockidx[s] * blk;
+        off += 4 * blk;
+      }
+      if (ndir == 1) for (int s = 0; s < 4; s++) y.pd.p_off[1][s] = y.pd.p_off[0][s];
+      ni = ndir * y.no;
+    }
+    sm_ni = ni;
+    sm_off = off;
+    off += (long long)ds.nclasses * (1 + sm_ni);
+    nparams = (int)off;
+    auto own = [&](float*& dst, float* given, bool& flag) {
+      if (given) { dst = given; flag = false; }
+      else {
+        HIPCHECK(hipMalloc((void**)&dst, (size_t)nparams * sizeof(float)));
+        HIPCHECK(hipMemset(dst, 0, (size_t)nparams * sizeof(float)));
+        flag = true;
+      }
+    };
+    own(v, pv, own_v); own(d, pd, own_d); own(g, pg, own_g);
+    for (auto& y : L) {
+      const int M = ndir * 4 * y.no, KQP = 4 * y.nk4;
+      HIPCHECK(hipMalloc((void**)&y.Wt, (size_t)y.ni * M * sizeof(float)));
+      HIPCHECK(hipMalloc((void**)&y.bias, (size_t)M * sizeof(float)));
+      HIPCHECK(hipMalloc((void**)&y.Rf, (size_t)ndir * 4 * KQP * y.nthreads * sizeof(float)));
+      HIPCHECK(hipMalloc((void**)&y.Rb, (size_t)ndir * 4 * KQP * y.nthreads * sizeof(float)));
+      HIPCHECK(hipMalloc((void**)&y.moff, (size_t)M * sizeof(long long)));
+      std::vector<long long> mo(M);
+      for (int m = 0; m < M; m++) {
+        const int dir = m / (4 * y.no), c = (m % (4 * y.no)) >> 2, s = m & 3;
+        mo[m] = y.pd.p_off[dir][s] + c;
+      }
+      HIPCHECK(hipMemcpy(y.moff, mo.data(), (size_t)M * sizeof(long long), hipMemcpyHostToDevice));
+    }
+    packed_dirty = true;
+  }
+  ~Net() {
+    for (auto& y : L) {
+      (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff);
+      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release();
+    }
+    if (own_v) (void)hipFree(v);
+    if (own_d) (void)hipFree(d);
+    if (own_g) (void)hipFree(g);
+    line_off.release(); prev0.release(); prev1.release(); X.release(); Z.release(); Dz.release();
+    dX0.release(); partial.release(); aligned.release(); tmp.release(); states.release();
+    state_off.release(); dec_idx.release(); dec_cls.release(); dec_loc.release(); dec_cnt.release();
+    dec_val.release(); lat.release(); lat_off.release();
+  }
+
+  void repack() {
+    if (!packed_dirty) return;
+    hipStream_t s = stream();
+    for (auto& y : L) {
+      const int M = ndir * 4 * y.no, KQP = 4 * y.nk4;
+      CLSTM_LAUNCH(k_pack_wx, dim3(nblocks((size_t)(1 + y.ni) * M)), dim3(256), 0, s, (const float*)v, y.Wt, y.bias, y.pd);
+      const size_t nr = (size_t)ndir * 4 * KQP * y.nthreads;
+      CLSTM_LAUNCH(k_pack_rf, dim3(nblocks(nr)), dim3(256), 0, s, (const float*)v, y.Rf, y.pd);
+      CLSTM_LAUNCH(k_pack_rb, dim3(nblocks(nr)), dim3(256), 0, s, (const float*)v, y.Rb, y.pd);
+    }
+    check_launch();
+    packed_dirty = false;
+  }
+
+  void set_batch(const int* T_h, int nb) {
+    REQUIRE(nb > 0, "empty batch");
+    bs = nb;
+    line_off_h.assign(nb + 1, 0);
+    for (int b = 0; b < nb; b++) {
+      REQUIRE(T_h[b] >= 0, "negative line length");
+      line_off_h[b + 1] = line_off_h[b] + T_h[b];
+    }
+    N = line_off_h[nb];
+    REQUIRE(N > 0, "batch has no frames");
+    std::vector<int> p0(N), p1(N);
+    for (int b = 0; b < nb; b++)
+      for (int t = line_off_h[b]; t < line_off_h[b + 1]; t++) {
+        p0[t] = (t > line_off_h[b]) ? t - 1 : -1;           // h_{t-1} of the forward NPLSTM
+        p1[t] = (t + 1 < line_off_h[b + 1]) ? t + 1 : -1;   // previous own-step of the reversed one
+      }
+    line_off.reserve(nb + 1); prev0.reserve(N); prev1.reserve(N);
+    hipStream_t s = stream();
+    HIPCHECK(hipMemcpyAsync(line_off.p, line_off_h.data(), (nb + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(prev0.p, p0.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(prev1.p, p1.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipStreamSynchronize(s));  // host vectors go out of scope
+    X.reserve((size_t)N * desc.ninput);
+    for (auto& y : L) {
+      y.G.reserve((size_t)N * ndir * 4 * y.no);
+      y.C.reserve((size_t)N * ndir * y.no);
+      y.H.reserve((size_t)N * ndir * y.no);
+      y.D.reserve((size_t)N * ndir * 4 * y.no);
+      y.dH.reserve((size_t)N * ndir * y.no);
+    }
+    Z.reserve((size_t)N * desc.nclasses);
+    Dz.reserve((size_t)N * desc.nclasses);
+  }
+
+  const float* layer_input(int l) const { return l == 0 ? X.p : L[l - 1].H.p; }
+
+  void forward() {
+    REQUIRE(N > 0, "set_batch first");
+    repack();
+    hipStream_t s = stream();
+    for (int l = 0; l < (int)L.size(); l++) {
+      Layer& y = L[l];
+      const int M = ndir * 4 * y.no;
+      timing.begin("gemm_gates_x", s);
+      gemm_f32<GEMM_KC, GEMM_MC>(s, RowMajorA{layer_input(l), y.ni}, RowMajorB{y.Wt, M},
+                                 StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
+      timing.end(s);
+      check_launch();
+      LstmSeqArgs a{};
+      a.Rpk = y.Rf; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = nullptr; a.D = nullptr;
+      a.line_off = line_off.p; a.no = y.no; a.ndir = ndir;
+      timing.begin("lstm_fwd", s);
+      launch_lstm(true, y.nk4, a, bs, y.nthreads, s);
+      timing.end(s);
+    }
+    const int nc = desc.nclasses;
+    const float* W1 = v + sm_off;
+    timing.begin("gemm_softmax", s);
+    gemm_f32<GEMM_KC, GEMM_MC>(s, RowMajorA{L.back().H.p, sm_ni}, RowMajorB{W1 + nc, nc},
+                               StoreBias{Z.p, nc, W1}, (int)N, nc, sm_ni);
+    timing.end(s);
+    check_launch();
+    timing.begin("softmax_norm", s);
+    CLSTM_LAUNCH(k_softmax_norm, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Z.p, nc, (size_t)N);
+    timing.end(s);
+    check_launch();
+  }
+
+  int pick_split(int R, int Cn) const {
+    const long long tiles = (long long)((R + 63) / 64) * ((Cn + 63) / 64);
+    long long want = (768 + tiles - 1) / tiles;
+    const long long maxs = (N + 63) / 64;
+    if (want > maxs) want = maxs;
+    if (want > 64) want = 64;
+    if (want < 1) want = 1;
+    return (int)want;
+  }
+
+  void backward() {
+    REQUIRE(N > 0, "set_batch first");
+    repack();
+    hipStream_t s = stream();
+    const int nc = desc.nclasses;
+    const float* W1 = v + sm_off;
+    HIPCHECK(hipMemsetAsync(g, 0, (size_t)nparams * sizeof(float), s));
+    // SoftmaxLayer::backward (clstm.cc:411-417): x.d = W^T z.d ; W.d += z.d [1;x]^T
+    Layer& top = L.back();
+    timing.begin("gemm_softmax_dx", s);
+    gemm_f32<GEMM_KC, GEMM_KC>(s, RowMajorA{Dz.p, nc}, TransB{W1 + nc, nc}, StorePlain{top.dH.p, sm_ni},
+                               (int)N, sm_ni, nc);
+    timing.end(s);
+    {
+      const int R = 1 + sm_ni, Cn = nc, ns = pick_split(R, Cn);
+      partial.reserve((size_t)ns * R * Cn);
+      timing.begin("gemm_softmax_dw", s);
+      gemm_f32<GEMM_MC, GEMM_MC>(s, OnesAndRowsT{top.H.p, sm_ni}, RowMajorB{Dz.p, nc},
+                                 StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns);
+      CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns, R, Cn,
+                   g, (const long long*)nullptr, (long long)sm_off, nc);
+      timing.end(s);
+    }
+    check_launch();
+    for (int l = (int)L.size() - 1; l >= 0; l--) {
+      Layer& y = L[l];
+      const int M = ndir * 4 * y.no;
+      LstmSeqArgs a{};
+      a.Rpk = y.Rb; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = y.dH.p; a.D = y.D.p;
+      a.line_off = line_off.p; a.no = y.no; a.ndir = ndir;
+      timing.begin("lstm_bwd", s);
+      launch_lstm(false, y.nk4, a, bs, y.nthreads, s);
+      timing.end(s);
+      // W.d += delta [1; x_t; h_{t-1}]^T for the four gates of each direction
+      const int R = 1 + y.ni + y.no, Cn = 4 * y.no, ns = pick_split(R, Cn * ndir);
+      partial.reserve((size_t)ns * R * Cn);
+      timing.begin("gemm_gates_dw", s);
+      for (int dir = 0; dir < ndir; dir++) {
+        SourceT src{layer_input(l), y.ni, y.ni, y.H.p, (long long)ndir * y.no, dir * y.no,
+                    dir == 0 ? prev0.p : prev1.p};
+        gemm_f32<GEMM_MC, GEMM_MC>(s, src, RowMajorB{y.D.p + (size_t)dir * 4 * y.no, M},
+                                   StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns);
+        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns, R, Cn,
+                     g, (const long long*)(y.moff + (size_t)dir * 4 * y.no), 0LL, y.no);
+      }
+      timing.end(s);
+      check_launch();
+      // input deltas: x.d = sum_dir W_x^T delta (Parallel::backward sums both subs, clstm.cc:538-541)
+      float* dx = nullptr;
+      if (l > 0) dx = L[l - 1].dH.p;
+      else if (want_dx0) { dX0.reserve((size_t)N * y.ni); dx = dX0.p; }
+      if (dx) {
+        timing.begin("gemm_gates_dx", s);
+        gemm_f32<GEMM_KC, GEMM_KC>(s, RowMajorA{y.D.p, M}, TransB{y.Wt, M}, StorePlain{dx, y.ni}, (int)N,
+                                   y.ni, M);
+        timing.end(s);
+        check_launch();
+      }
+    }
+  }
+
+  void update() {
+    hipStream_t s = stream();
+    timing.begin("sgd_update", s);
+    CLSTM_LAUNCH(k_update, dim3(nblocks(nparams)), dim3(256), 0, s, v, d, (const float*)g, (size_t)nparams, lr, mom, gclip);
+    timing.end(s);
+    check_launch();
+    packed_dirty = true;
+  }
+};
+
+// CTC on an arbitrary packed batch (used by the net and by the stand-alone ABI entry)
+struct CtcWorkspace {
+  DevBuf<int> line_off, states, state_off;
+  DevBuf<float> lat;
+  DevBuf<long long> lat_off;
+};
+static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* aligned, int nc,
+                    const int* line_off_h, const int* states_h, const int* state_off_h, int bs,
+                    hipStream_t s) {
+  REQUIRE(bs > 0, "empty batch");
+  std::vector<long long> lo(bs + 1, 0);
+  for (int b = 0; b < bs; b++) {
+    const long long T = line_off_h[b + 1] - line_off_h[b], S = state_off_h[b + 1] - state_off_h[b];
+    REQUIRE(T >= 0 && S >= 0, "bad offsets");
+    REQUIRE(S <= 64 * CTC_RMAX, "more than 512 target states per line is not supported");
+    lo[b + 1] = lo[b] + 3 * T * S;
+  }
+  const int ns = state_off_h[bs];
+  for (int i = 0; i < ns; i++) REQUIRE(states_h[i] >= 0 && states_h[i] < nc, "target class out of range");
+  w.line_off.reserve(bs + 1); w.state_off.reserve(bs + 1); w.states.reserve(ns > 0 ? ns : 1);
+  w.lat_off.reserve(bs + 1); w.lat.reserve((size_t)(lo[bs] > 0 ? lo[bs] : 1));
+  HIPCHECK(hipMemcpyAsync(w.line_off.p, line_off_h, (bs + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(w.state_off.p, state_off_h, (bs + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+  if (ns > 0) HIPCHECK(hipMemcpyAsync(w.states.p, states_h, ns * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(w.lat_off.p, lo.data(), (bs + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  CtcArgs a{};
+  a.P = probs; a.Dz = deltas; a.aligned = aligned; a.line_off = w.line_off.p; a.states = w.states.p;
+  a.state_off = w.state_off.p; a.lat = w.lat.p; a.lat_off = w.lat_off.p; a.nc = nc;
+  CLSTM_LAUNCH(ctc_align_kernel, dim3(bs), dim3(CTC_THREADS), 0, s, a);
+  check_launch();
+}
+struct DecodeWorkspace {
+  DevBuf<int> line_off, idx, cls, loc, cnt;
+  DevBuf<float> val;
+};
+static void run_decode(DecodeWorkspace& w, const float* probs, int nc, const int* line_off_h, int bs,
+                       int* classes_h, int* locs_h, int* counts_h, hipStream_t s) {
+  const int N = line_off_h[bs];
+  REQUIRE(bs > 0 && N > 0, "empty batch");
+  w.line_off.reserve(bs + 1); w.idx.reserve(N); w.val.reserve(N); w.cls.reserve(N); w.loc.reserve(N); w.cnt.reserve(bs);
+  HIPCHECK(hipMemcpyAsync(w.line_off.p, line_off_h, (bs + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+  CLSTM_LAUNCH(argmax_kernel, dim3((N + 255) / 256), dim3(256), 0, s, probs, w.idx.p, w.val.p, N, nc);
+  CLSTM_LAUNCH(decode_kernel, dim3(bs), dim3(64), 0, s, (const int*)w.idx.p, (const float*)w.val.p,
+               (const int*)w.line_off.p, w.cls.p, w.loc.p, w.cnt.p);
+  check_launch();
+  HIPCHECK(hipMemcpyAsync(counts_h, w.cnt.p, bs * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (classes_h) HIPCHECK(hipMemcpyAsync(classes_h, w.cls.p, N * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (locs_h) HIPCHECK(hipMemcpyAsync(locs_h, w.loc.p, N * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+}
+
+static thread_local CtcWorkspace* g_ctc_ws = nullptr;
+static thread_local DecodeWorkspace* g_dec_ws = nullptr;
+
+}  // namespace clstm
+
+using namespace clstm;
+struct clstm_net {
+  Net net;
+  CtcWorkspace ctc;
+  DecodeWorkspace dec;
+};
+
+#define EW(kernel, len, ...) \
+  CLSTM_LAUNCH(kernel, dim3(nblocks(len)), dim3(256), 0, g_stream, __VA_ARGS__); check_launch();
+
+extern "C" {
+
+const char* clstm_last_error(void) { return g_err.c_str(); }
+int clstm_abi_version(void) { return 1; }
+int clstm_set_stream(void* s) { g_stream = (hipStream_t)s; return 0; }
+int clstm_synchronize(void) { ABI_BEGIN HIPCHECK(hipStreamSynchronize(g_stream)); ABI_END }
+
+// ---- per-op entry points -------------------------------------------------------------------------
+int clstm_forward_nonlin0(float* y, int len, int nl) { ABI_BEGIN EW(k_forward_nonlin0, len, y, (size_t)len, nl) ABI_END }
+int clstm_backward_nonlin0(const float* yv, float* yd, int len, int nl) { ABI_BEGIN EW(k_backward_nonlin0, len, yv, yd, (size_t)len, nl) ABI_END }
+int clstm_forward_nonlin(float* y, const float* x, int len, int nl) { ABI_BEGIN EW(k_forward_nonlin, len, y, x, (size_t)len, nl) ABI_END }
+int clstm_backward_nonlin(const float* yv, const float* yd, float* xd, int len, int nl) { ABI_BEGIN EW(k_backward_nonlin, len, yv, yd, xd, (size_t)len, nl) ABI_END }
+int clstm_forward_lin1(float* y, const float* W, const float* x, int n, int m, int bs) {
+  ABI_BEGIN EW(k_forward_lin1, (size_t)n * bs, y, W, x, n, m, bs, -1) ABI_END
+}
+int clstm_backward_lin1(const float* yd, const float* W, float* Wd, const float* x, float* xd, int n, int m, int bs) {
+  ABI_BEGIN
+  EW(k_backward_lin1_dx, (size_t)(m - 1) * bs, yd, W, xd, n, m, bs, 0)
+  EW(k_backward_lin1_dw, (size_t)n * m, yd, Wd, x, n, m, bs)
+  ABI_END
+}
+int clstm_forward_full1(float* y, const float* W, const float* x, int n, int m, int bs, int nl) {
+  ABI_BEGIN
+  REQUIRE(nl >= 0 && nl <= 4, "bad nonlinearity code (clstm_compute.cc:147 aborts)");
+  EW(k_forward_lin1, (size_t)n * bs, y, W, x, n, m, bs, nl)
+  ABI_END
+}
+int clstm_backward_full1(const float* yv, float* yd, const float* W, float* Wd, const float* x, float* xd,
+                         int n, int m, int bs, int nl) {
+  ABI_BEGIN
+  REQUIRE(nl >= 0 && nl <= 4, "bad nonlinearity code");
+  EW(k_backward_nonlin0, (size_t)n * bs, yv, yd, (size_t)n * bs, nl)
+  EW(k_backward_lin1_dx, (size_t)(m - 1) * bs, (const float*)yd, W, xd, n, m, bs, 0)
+  EW(k_backward_lin1_dw, (size_t)n * m, (const float*)yd, Wd, x, n, m, bs)
+  ABI_END
+}
+int clstm_forward_softmax(float* z, const float* W, const float* x, int n, int m, int bs) {
+  ABI_BEGIN
+  REQUIRE(n >= 2, "Softmax requires n>=2 (clstm_compute.cc:328)");
+  EW(k_forward_lin1, (size_t)n * bs, z, W, x, n, m, bs, -1)
+  CLSTM_LAUNCH(k_softmax_norm, dim3((bs + 3) / 4), dim3(256), 0, g_stream, z, n, (size_t)bs);
+  check_launch();
+  ABI_END
+}
+int clstm_backward_softmax(const float* zd, const float* W, float* Wd, const float* x, float* xd, int n, int m, int bs) {
+  ABI_BEGIN
+  EW(k_backward_lin1_dx, (size_t)(m - 1) * bs, zd, W, xd, n, m, bs, 1)
+  EW(k_backward_lin1_dw, (size_t)n * m, zd, Wd, x, n, m, bs)
+  ABI_END
+}
+int clstm_forward_stack(float* z, const float* x, const float* y, int nx, int ny, int bs) {
+  ABI_BEGIN REQUIRE(y != nullptr, "null operand"); EW(k_stack, (size_t)(nx + ny) * bs, z, x, y, nx, ny, bs) ABI_END
+}
+int clstm_backward_stack(const float* zd, float* xd, float* yd, int nx, int ny, int bs) {
+  ABI_BEGIN REQUIRE(yd != nullptr, "null operand"); EW(k_unstack_add, (size_t)(nx + ny) * bs, zd, xd, yd, nx, ny, bs) ABI_END
+}
+int clstm_forward_stack_delay(float* z, const float* x, const float* ylast, int nx, int ny, int bs) {
+  ABI_BEGIN EW(k_stack, (size_t)(nx + ny) * bs, z, x, ylast, nx, ny, bs) ABI_END
+}
+int clstm_backward_stack_delay(const float* zd, float* xd, float* ylastd, int nx, int ny, int bs) {
+  ABI_BEGIN EW(k_unstack_add, (size_t)(nx + ny) * bs, zd, xd, ylastd, nx, ny, bs) ABI_END
+}
+int clstm_forward_reverse(float* y, const float* x, int rows, int bs, int N) {
+  ABI_BEGIN EW(k_forward_reverse, (size_t)rows * bs * 2 * N, y, x, (size_t)rows * bs * 2, N) ABI_END
+}
+int clstm_backward_reverse(const float* y, float* x, int rows, int bs, int N) {
+  ABI_BEGIN EW(k_backward_reverse, (size_t)rows * bs * N, y, x, (size_t)rows * bs, N) ABI_END
+}
+int clstm_forward_statemem(float* st, const float* ci, const float* gi, const float* last, const float* gf, int len) {
+  ABI_BEGIN EW(k_forward_statemem, len, st, ci, gi, last, gf, (size_t)len) ABI_END
+}
+int clstm_backward_statemem(const float* sd, const float* ci, float* cid, const float* gi, float* gid,
+                            const float* last, float* lastd, const float* gf, float* gfd, int len) {
+  ABI_BEGIN EW(k_backward_statemem, len, sd, ci, cid, gi, gid, last, lastd, gf, gfd, (size_t)len) ABI_END
+}
+int clstm_forward_nonlingate(float* out, const float* st, const float* go, int len, int nl) {
+  ABI_BEGIN EW(k_forward_nonlingate, len, out, st, go, (size_t)len, nl) ABI_END
+}
+int clstm_backward_nonlingate(const float* outd, const float* st, float* std_, const float* go, float* god, int len, int nl) {
+  ABI_BEGIN EW(k_backward_nonlingate, len, outd, st, std_, go, god, (size_t)len, nl) ABI_END
+}
+int clstm_clip_gradient(float* d, int len, float clip) {
+  ABI_BEGIN
+  if (clip >= 1e6f) return 0;  // clstm_compute.cc:554
+  REQUIRE(clip > 0, "clip must be positive (clstm_compute.cc:555)");
+  EW(k_clip, len, d, (size_t)len, clip)
+  ABI_END
+}
+int clstm_sgd_update(float* v, float* d, int len, float lr, float mom) { ABI_BEGIN EW(k_sgd, len, v, d, (size_t)len, lr, mom) ABI_END }
+
+// ---- CTC ------------------------------------------------------------------------------------------
+int clstm_mktargets(int* states_h, const int* transcript_h, int L) {
+  for (int t = 0; t < 2 * L + 1; t++) states_h[t] = (t % 2 == 1) ? transcript_h[(t - 1) / 2] : 0;
+  return 0;
+}
+int clstm_ctc_align_batch(const float* probs, float* deltas, float* aligned, int nc, const int* line_off_h,
+                          const int* states_h, const int* state_off_h, int bs) {
+  ABI_BEGIN
+  if (!g_ctc_ws) g_ctc_ws = new CtcWorkspace();
+  run_ctc(*g_ctc_ws, probs, deltas, aligned, nc, line_off_h, states_h, state_off_h, bs, g_stream);
+  ABI_END
+}
+int clstm_trivial_decode_batch(const float* probs, int nc, const int* line_off_h, int bs, int* classes_h,
+                               int* locs_h, int* counts_h) {
+  ABI_BEGIN
+  if (!g_dec_ws) g_dec_ws = new DecodeWorkspace();
+  run_decode(*g_dec_ws, probs, nc, line_off_h, bs, classes_h, locs_h, counts_h, g_stream);
+  ABI_END
+}
+
+// ---- fused network ----------------------------------------------------------------------------------
+int clstm_net_nparams_for(const clstm_net_desc* ds) {
+  long long total = 0;
+  int ni = ds->ninput;
+  const int nd = ds->unidirectional ? 1 : 2;
+  for (int l = 0; l < ds->nlayers; l++) {
+    const int no = ds->nhidden[l];
+    total += (long long)nd * 4 * no * (ni + no + 1);
+    ni = nd * no;
+  }
+  total += (long long)ds->nclasses * (ni + 1);
+  return (int)total;
+}
+int clstm_net_create(clstm_net** out, const clstm_net_desc* ds, float* pv, float* pd, float* pg) {
+  ABI_BEGIN
+  REQUIRE(out && ds, "null argument");
+  clstm_net* h = new clstm_net();
+  try { h->net.build(*ds, pv, pd, pg); } catch (...) { delete h; throw; }
+  *out = h;
+  ABI_END
+}
+int clstm_net_destroy(clstm_net* h) { ABI_BEGIN delete h; ABI_END }
+int clstm_net_nparams(clstm_net* h) { return h->net.nparams; }
+int clstm_net_buffers(clstm_net* h, float** v, float** d, float** g) {
+  if (v) *v = h->net.v;
+  if (d) *d = h->net.d;
+  if (g) *g = h->net.g;
+  return 0;
+}
+static void copy_h2d(float* dst, const float* src, size_t n) {
+  HIPCHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyHostToDevice, g_stream));
+  HIPCHECK(hipStreamSynchronize(g_stream));
+}
+static void copy_d2h(float* dst, const float* src, size_t n) {
+  HIPCHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, g_stream));
+  HIPCHECK(hipStreamSynchronize(g_stream));
+}
+int clstm_net_set_params_h(clstm_net* h, const float* p) { ABI_BEGIN copy_h2d(h->net.v, p, h->net.nparams); h->net.packed_dirty = true; ABI_END }
+int clstm_net_get_params_h(clstm_net* h, float* p) { ABI_BEGIN copy_d2h(p, h->net.v, h->net.nparams); ABI_END }
+int clstm_net_set_derivs_h(clstm_net* h, const float* p) { ABI_BEGIN copy_h2d(h->net.d, p, h->net.nparams); ABI_END }
+int clstm_net_get_derivs_h(clstm_net* h, float* p) { ABI_BEGIN copy_d2h(p, h->net.d, h->net.nparams); ABI_END }
+int clstm_net_get_grads_h(clstm_net* h, float* p) { ABI_BEGIN copy_d2h(p, h->net.g, h->net.nparams); ABI_END }
+int clstm_net_params_changed(clstm_net* h) { h->net.packed_dirty = true; return 0; }
+int clstm_net_set_learning_rate(clstm_net* h, float lr, float mom) { h->net.lr = lr; h->net.mom = mom; return 0; }
+int clstm_net_set_gradient_clip(clstm_net* h, float c) {
+  ABI_BEGIN REQUIRE(c > 0, "clip must be positive"); h->net.gclip = c; ABI_END
+}
+int clstm_net_set_batch(clstm_net* h, const int* T_h, int bs) { ABI_BEGIN h->net.set_batch(T_h, bs); ABI_END }
+int clstm_net_set_inputs_h(clstm_net* h, const float* x) {
+  ABI_BEGIN REQUIRE(h->net.N > 0, "set_batch first"); copy_h2d(h->net.X.p, x, (size_t)h->net.N * h->net.desc.ninput); ABI_END
+}
+int clstm_net_set_inputs_d(clstm_net* h, const float* x) {
+  ABI_BEGIN
+  REQUIRE(h->net.N > 0, "set_batch first");
+  HIPCHECK(hipMemcpyAsync(h->net.X.p, x, (size_t)h->net.N * h->net.desc.ninput * sizeof(float), hipMemcpyDeviceToDevice, g_stream));
+  ABI_END
+}
+int clstm_net_forward(clstm_net* h) { ABI_BEGIN h->net.forward(); ABI_END }
+int clstm_net_outputs(clstm_net* h, float** p, float** d) {
+  if (p) *p = h->net.Z.p;
+  if (d) *d = h->net.Dz.p;
+  return 0;
+}
+int clstm_net_get_outputs_h(clstm_net* h, float* p) { ABI_BEGIN copy_d2h(p, h->net.Z.p, (size_t)h->net.N * h->net.desc.nclasses); ABI_END }
+int clstm_net_set_output_deltas_h(clstm_net* h, const float* p) { ABI_BEGIN copy_h2d(h->net.Dz.p, p, (size_t)h->net.N * h->net.desc.nclasses); ABI_END }
+int clstm_net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* aligned_h) {
+  ABI_BEGIN
+  Net& n = h->net;
+  REQUIRE(n.N > 0, "set_batch first");
+  std::vector<int> soff(n.bs + 1, 0), states;
+  int lpos = 0;
+  for (int b = 0; b < n.bs; b++) {
+    const int L = L_h[b];
+    REQUIRE(L >= 0, "negative transcript length");
+    states.resize(soff[b] + 2 * L + 1);
+    clstm_mktargets(states.data() + soff[b], labels_h + lpos, L);
+    for (int i = 0; i < L; i++) REQUIRE(labels_h[lpos + i] != 0, "transcript contains the blank class (Codec::encode asserts c != 0, clstm.cc:232)");
+    lpos += L;
+    soff[b + 1] = soff[b] + 2 * L + 1;
+  }
+  float* al = nullptr;
+  if (aligned_h) { n.aligned.reserve((size_t)n.N * n.desc.nclasses); al = n.aligned.p; }
+  n.timing.begin("ctc_align", g_stream);
+  run_ctc(h->ctc, n.Z.p, n.Dz.p, al, n.desc.nclasses, n.line_off_h.data(), states.data(), soff.data(), n.bs, g_stream);
+  n.timing.end(g_stream);
+  if (aligned_h) copy_d2h(aligned_h, al, (size_t)n.N * n.desc.nclasses);
+  ABI_END
+}
+int clstm_net_backward(clstm_net* h) { ABI_BEGIN h->net.backward(); ABI_END }
+int clstm_net_enable_input_deltas(clstm_net* h, int on) { h->net.want_dx0 = on != 0; return 0; }
+int clstm_net_get_input_deltas_h(clstm_net* h, float* dx) {
+  ABI_BEGIN
+  REQUIRE(h->net.want_dx0 && h->net.dX0.p, "input deltas not enabled / no backward yet");
+  copy_d2h(dx, h->net.dX0.p, (size_t)h->net.N * h->net.desc.ninput);
+  ABI_END
+}
+int clstm_net_update(clstm_net* h) { ABI_BEGIN h->net.update(); ABI_END }
+int clstm_net_decode(clstm_net* h, int* cls, int* locs, int* cnt) {
+  ABI_BEGIN
+  Net& n = h->net;
+  REQUIRE(n.N > 0, "set_batch first");
+  run_decode(h->dec, n.Z.p, n.desc.nclasses, n.line_off_h.data(), n.bs, cls, locs, cnt, g_stream);
+  ABI_END
+}
+int clstm_net_get_state_h(clstm_net* h, int layer, int dir, int which, float* out) {
+  ABI_BEGIN
+  Net& n = h->net;
+  REQUIRE(layer >= 0 && layer < (int)n.L.size() && dir >= 0 && dir < n.ndir && which >= 0 && which <= 9, "bad state selector");
+  Layer& y = n.L[layer];
+  n.tmp.reserve((size_t)n.N * y.no);
+  const float* src = which < 4 ? y.G.p : which == 4 ? y.C.p : which == 5 ? y.H.p : y.D.p;
+  const int slot = which < 4 ? which : which >= 6 ? which - 6 : -1;
+  CLSTM_LAUNCH(k_gather_state, dim3(nblocks((size_t)n.N * y.no)), dim3(256), 0, g_stream, src, n.tmp.p, (size_t)n.N, y.no, n.ndir, dir, slot);
+  check_launch();
+  copy_d2h(out, n.tmp.p, (size_t)n.N * y.no);
+  ABI_END
+}
+int clstm_net_enable_timing(clstm_net* h, int on) { h->net.timing.on = on != 0; return 0; }
+int clstm_net_kernel_time_ms(clstm_net* h, const char* name, double* total_ms, int* launches) {
+  ABI_BEGIN
+  h->net.timing.collect(g_stream);
+  auto it = h->net.timing.acc.find(name);
+  if (it == h->net.timing.acc.end()) { *total_ms = 0; *launches = 0; }
+  else { *total_ms = it->second.first; *launches = it->second.second; }
+  ABI_END
+}
+int clstm_net_reset_timing(clstm_net* h) { ABI_BEGIN h->net.timing.collect(g_stream); h->net.timing.acc.clear(); ABI_END }
+
+// ---- diagnostics ----------------------------------------------------------------------------------
+int clstm_debug_lane_ops(float* out) {
+  ABI_BEGIN
+  CLSTM_LAUNCH(k_debug_lane_ops, dim3(1), dim3(64), 0, g_stream, out);
+  check_launch();
+  ABI_END
+}
+int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R, int Cn, int K, int nsplit) {
+  ABI_BEGIN
+  static thread_local DevBuf<float>* part = nullptr;
+  if (mode == 0) gemm_f32<GEMM_KC, GEMM_MC>(g_stream, RowMajorA{A, K}, RowMajorB{B, Cn}, StorePlain{Cm, Cn}, R, Cn, K);
+  else if (mode == 1) gemm_f32<GEMM_KC, GEMM_KC>(g_stream, RowMajorA{A, K}, TransB{B, K}, StorePlain{Cm, Cn}, R, Cn, K);
+  else if (mode == 2) {
+    if (!part) part = new DevBuf<float>();
+    if (nsplit < 1) nsplit = 1;
+    part->reserve((size_t)nsplit * R * Cn);
+    HIPCHECK(hipMemsetAsync(Cm, 0, (size_t)R * Cn * sizeof(float), g_stream));
+    gemm_f32<GEMM_MC, GEMM_MC>(g_stream, TransA{A, R}, RowMajorB{B, Cn}, StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
+    CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream, (const float*)part->p, nsplit,
+                 R, Cn, Cm, (const long long*)nullptr, 0LL, Cn);
+  } else throw Error("bad mode");
+  check_launch();
+  ABI_END
+}
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+// ops.h -- element-wise / small kernels: the 1:1 per-op side of the C ABI
+// (clstm_compute.h:72-103 operators on the BiLSTM+CTC path), softmax normalisation,
+// the fused clip+SGD update and the weight re-packing for the sequence kernels.
+#pragma once
+#include "devintrin.h"
+
+namespace clstm {
+
+enum { LIN = 0, SIG = 1, TANH = 2, RELU = 3, LOGMAG = 4 };  // clstm_compute.h:10-14
+
+DEVFN float nonlin_fwd(float x, int nl) {  // clstm_compute.cc:113-129
+  switch (nl) {
+    case SIG: return sigmoid_dev(x);
+    case TANH: return tanh_dev(x);
+    case RELU: return x > 0.0f ? x : 0.0f;
+    case LOGMAG: return logf(fabsf(x) + 1.0f) * ((x < 0.0f ? 1.0f : 0.0f) * -2.0f + 1.0f);
+    default: return x;
+  }
+}
+DEVFN float nonlin_deriv(float y, int nl) {  // f'(x) expressed through y=f(x), :152-167
+  switch (nl) {
+    case SIG: return y * (-y + 1.0f);
+    case TANH: return -y * y + 1.0f;
+    case RELU: return y > 0.0f ? 1.0f : 0.0f;
+    case LOGMAG: return expf(-fabsf(y));
+    default: return 1.0f;
+  }
+}
+
+#define CLSTM_GRID_STRIDE(i, n) \
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(n); i += (size_t)gridDim.x * blockDim.x)
+
+__global__ void k_forward_nonlin0(float* y, size_t len, int nl) {
+  CLSTM_GRID_STRIDE(i, len) y[i] = nonlin_fwd(y[i], nl);
+}
+__global__ void k_backward_nonlin0(const float* yv, float* yd, size_t len, int nl) {
+  CLSTM_GRID_STRIDE(i, len) yd[i] = nonlin_deriv(yv[i], nl) * yd[i];
+}
+__global__ void k_forward_nonlin(float* y, const float* x, size_t len, int nl) {
+  CLSTM_GRID_STRIDE(i, len) y[i] = nonlin_fwd(x[i], nl);
+}
+__global__ void k_backward_nonlin(const float* yv, const float* yd, float* xd, size_t len, int nl) {
+  CLSTM_GRID_STRIDE(i, len) xd[i] += nonlin_deriv(yv[i], nl) * yd[i];
+}
+// y(i,b) = sum_k W(i,1+k) x(k,b) + W(i,0); optional nonlinearity (full1) -- per-op path only
+__global__ void k_forward_lin1(float* y, const float* W, const float* x, int n, int m, int bs, int nl) {
+  CLSTM_GRID_STRIDE(e, (size_t)n * bs) {
+    const int i = e % n, b = e / n;
+    const int nx = m - 1;
+    float acc = 0.0f;
+    for (int k = 0; k < nx; k++) acc += W[i + (size_t)n * (1 + k)] * x[k + (size_t)nx * b];
+    acc += W[i];
+    y[e] = nl >= 0 ? nonlin_fwd(acc, nl) : acc;
+  }
+}
+// x.d(k,b) (+)= sum_i W(i,1+k) y.d(i,b)
+__global__ void k_backward_lin1_dx(const float* yd, const float* W, float* xd, int n, int m, int bs, int assign) {
+  const int nx = m - 1;
+  CLSTM_GRID_STRIDE(e, (size_t)nx * bs) {
+    const int k = e % nx, b = e / nx;
+    float acc = 0.0f;
+    for (int i = 0; i < n; i++) acc += W[i + (size_t)n * (1 + k)] * yd[i + (size_t)n * b];
+    xd[e] = assign ? acc : xd[e] + acc;
+  }
+}
+// W.d(i,j) += sum_b y.d(i,b) * [1 ; x](j,b)
+__global__ void k_backward_lin1_dw(const float* yd, float* Wd, const float* x, int n, int m, int bs) {
+  const int nx = m - 1;
+  CLSTM_GRID_STRIDE(e, (size_t)n * m) {
+    const int i = e % n, j = e / n;
+    float acc = 0.0f;
+    for (int b = 0; b < bs; b++) acc += yd[i + (size_t)n * b] * (j == 0 ? 1.0f : x[(j - 1) + (size_t)nx * b]);
+    Wd[e] += acc;
+  }
+}
+// z = limexp(z) / colsum  (no max-subtraction, clstm_compute.cc:333-339). One wave per column.
+DEVFN float limexp_dev(float x) {  // tensor.h:78-82
+  if (x < -30.0f) return (float)exp(-30.0);
+  if (x > 30.0f) return (float)exp(30.0);
+  return expf(x);
+}
+__global__ __launch_bounds__(256) void k_softmax_norm(float* z, int n, size_t cols) {
+  const int lane = threadIdx.x & 63;
+  const size_t col = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const bool ok = col < cols;   // keep whole waves alive for the wave reduction
+  float* p = z + (ok ? col : 0) * n;
+  float s = 0.0f;
+  for (int i = lane; i < n; i += 64) {
+    const float e = limexp_dev(p[i]);
+    if (ok) p[i] = e;
+    s += e;
+  }
+  s = wave_sum(s);
+  if (ok)
+    for (int i = lane; i < n; i += 64) p[i] = p[i] / s;
+}
+__global__ void k_stack(float* z, const float* x, const float* y, int nx, int ny, int bs) {
+  CLSTM_GRID_STRIDE(e, (size_t)(nx + ny) * bs) {
+    const int i = e % (nx + ny), b = e / (nx + ny);
+    z[e] = i < nx ? x[i + (size_t)nx * b] : (y ? y[(i - nx) + (size_t)ny * b] : 0.0f);
+  }
+}
+__global__ void k_unstack_add(const float* z, float* x, float* y, int nx, int ny, int bs) {
+  CLSTM_GRID_STRIDE(e, (size_t)(nx + ny) * bs) {
+    const int i = e % (nx + ny), b = e / (nx + ny);
+    if (i < nx) x[i + (size_t)nx * b] += z[e];
+    else if (y) y[(i - nx) + (size_t)ny * b] += z[e];
+  }
+}
+// Sequence blocks: dims (rows, bs, 2, N) -- batches.h:79-86
+__global__ void k_forward_reverse(float* y, const float* x, size_t step, int N) {
+  CLSTM_GRID_STRIDE(e, step * N) {
+    const size_t t = e / step, r = e % step;
+    y[(size_t)(N - 1 - t) * step + r] = x[e];  // step = rows*bs*2: copies v and d planes
+  }
+}
+__global__ void k_backward_reverse(const float* y, float* x, size_t plane, int N) {
+  CLSTM_GRID_STRIDE(e, plane * N) {
+    const size_t t = e / plane, r = e % plane;
+    x[(size_t)(N - 1 - t) * 2 * plane + plane + r] += y[t * 2 * plane + plane + r];
+  }
+}
+__global__ void k_forward_statemem(float* st, const float* ci, const float* gi, const float* last,
+                                   const float* gf, size_t len) {
+  CLSTM_GRID_STRIDE(i, len) {
+    float c = ci[i] * gi[i];
+    if (last) c += gf[i] * last[i];
+    st[i] = c;
+  }
+}
+__global__ void k_backward_statemem(const float* sd, const float* ci, float* cid, const float* gi, float* gid,
+                                    const float* last, float* lastd, const float* gf, float* gfd, size_t len) {
+  CLSTM_GRID_STRIDE(i, len) {
+    const float d = sd[i];
+    if (last) { lastd[i] += d * gf[i]; gfd[i] += d * last[i]; }
+    gid[i] += d * ci[i];
+    cid[i] += d * gi[i];
+  }
+}
+__global__ void k_forward_nonlingate(float* out, const float* st, const float* go, size_t len, int nl) {
+  CLSTM_GRID_STRIDE(i, len) out[i] = nonlin_fwd(st[i], nl) * go[i];
+}
+__global__ void k_backward_nonlingate(const float* outd, const float* st, float* std_, const float* go,
+                                      float* god, size_t len, int nl) {
+  CLSTM_GRID_STRIDE(i, len) {
+    const float t = nonlin_fwd(st[i], nl);
+    god[i] += t * outd[i];
+    std_[i] += nonlin_deriv(t, nl) * (go[i] * outd[i]);
+  }
+}
+__global__ void k_clip(float* d, size_t len, float clip) {
+  CLSTM_GRID_STRIDE(i, len) d[i] = fmaxf(-clip, fminf(clip, d[i]));
+}
+__global__ void k_sgd(float* v, float* d, size_t len, float lr, float mom) {
+  CLSTM_GRID_STRIDE(i, len) {
+    const float di = d[i];
+    v[i] += di * lr;
+    d[i] = di * mom;
+  }
+}
+// fused: d += g ; clip ; v += lr*d ; d *= mom    (clstm.cc:201-217 on the flat buffers)
+__global__ void k_update(float* v, float* d, const float* g, size_t len, float lr, float mom, float clip) {
+  CLSTM_GRID_STRIDE(i, len) {
+    float di = d[i] + g[i];
+    if (clip < 1e6f) di = fmaxf(-clip, fminf(clip, di));
+    v[i] += di * lr;
+    d[i] = di * mom;
+  }
+}
+
+// ---- weight packing for the sequence kernels ---------------------------------------------------
+struct PackDesc {
+  long long p_off[2][4];  // flat offsets of (dir, slot) blocks; slot 0 gi,1 gf,2 go,3 ci
+  int ni, no, ndir, nk4, nthreads;
+};
+// Wt[k][m] (k < ni, m = dir*4no + 4*cell + slot) and bias[m] for the hoisted input GEMM
+__global__ void k_pack_wx(const float* v, float* Wt, float* bias, PackDesc p) {
+  const int M = p.ndir * 4 * p.no;
+  CLSTM_GRID_STRIDE(e, (size_t)(1 + p.ni) * M) {
+    const int j = e / M, m = e % M;
+    const int dir = m / (4 * p.no), c = (m % (4 * p.no)) >> 2, s = m & 3;
+    const float x = v[p.p_off[dir][s] + c + (size_t)p.no * j];
+    if (j == 0) bias[m] = x;
+    else Wt[(size_t)(j - 1) * M + m] = x;
+  }
+}
+// forward recurrence registers: Rf[dir][(g*KQP + kk)][tid] = R_g[cell][q*KQP + kk]
+__global__ void k_pack_rf(const float* v, float* Rf, PackDesc p) {
+  const int KQP = 4 * p.nk4;
+  const size_t per_dir = (size_t)4 * KQP * p.nthreads;
+  CLSTM_GRID_STRIDE(e, per_dir * p.ndir) {
+    const int dir = e / per_dir;
+    const size_t r = e % per_dir;
+    const int tid = r % p.nthreads, gk = r / p.nthreads;
+    const int g = gk / KQP, kk = gk % KQP;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cell = wave * 16 + (lane >> 2), q = lane & 3;
+    const int k = q * KQP + kk;
+    float x = 0.0f;
+    if (cell < p.no && k < p.no) x = v[p.p_off[dir][g] + cell + (size_t)p.no * (1 + p.ni + k)];
+    Rf[e] = x;
+  }
+}
+// backward recurrence registers: Rb[dir][(i*SLP + pp)][tid] = R_g[j][4*kg + i], (g,j) = pair js*SL+pp
+__global__ void k_pack_rb(const float* v, float* Rb, PackDesc p) {
+  const int SLP = 4 * p.nk4;
+  const int SL = (4 * p.no + 15) / 16;
+  const size_t per_dir = (size_t)4 * SLP * p.nthreads;
+  CLSTM_GRID_STRIDE(e, per_dir * p.ndir) {
+    const int dir = e / per_dir;
+    const size_t r = e % per_dir;
+    const int tid = r % p.nthreads, ip = r / p.nthreads;
+    const int i = ip / SLP, pp = ip % SLP;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int kcell = 4 * (wave * 4 + (lane >> 4)) + i;
+    const int js = lane & 15;
+    const int pr = js * SL + pp;
+    float x = 0.0f;
+    if (pp < SL && pr < 4 * p.no && kcell < p.no) {
+      const int g = pr / p.no, j = pr % p.no;
+      x = v[p.p_off[dir][g] + j + (size_t)p.no * (1 + p.ni + kcell)];
+    }
+    Rb[e] = x;
+  }
+}
+// g[off(c) + rs*r] += sum_z partial[z][r][c]   (deterministic split-K reduction + row scatter)
+__global__ void k_reduce_scatter(const float* partial, int nsplit, int R, int Cn, float* g,
+                                 const long long* moff, long long base, int rs) {
+  CLSTM_GRID_STRIDE(e, (size_t)R * Cn) {
+    const int r = e / Cn, c = e % Cn;
+    float s = 0.0f;
+    for (int z = 0; z < nsplit; z++) s += partial[(size_t)z * R * Cn + e];
+    const long long o = (moff ? moff[c] : base + c) + (long long)rs * r;
+    g[o] += s;
+  }
+}
+// diagnostics: the cross-lane primitives applied to the lane index (tests/test_intrinsics.py)
+__global__ void k_debug_lane_ops(float* out) {
+  const int lane = threadIdx.x & 63;
+  const float x = (float)lane;
+  out[0 * 64 + lane] = quad_xor1(x);
+  out[1 * 64 + lane] = quad_xor2(x);
+  out[2 * 64 + lane] = quad_bcast<0>(x);
+  out[3 * 64 + lane] = quad_bcast<1>(x);
+  out[4 * 64 + lane] = quad_bcast<2>(x);
+  out[5 * 64 + lane] = quad_bcast<3>(x);
+  out[6 * 64 + lane] = row_ror<1>(x);
+  out[7 * 64 + lane] = row_ror<4>(x);
+  out[8 * 64 + lane] = row_ror<8>(x);
+}
+// gather one NPLSTM state plane into [N][no] for the parity tests
+__global__ void k_gather_state(const float* src, float* out, size_t N, int no, int ndir, int dir, int slot) {
+  CLSTM_GRID_STRIDE(e, N * no) {
+    const size_t n = e / no;
+    const int c = e % no;
+    out[e] = slot < 0 ? src[(n * ndir + dir) * no + c] : src[(n * ndir + dir) * 4 * no + c * 4 + slot];
+  }
+}
+
+}  // namespace clstm

@@ -1,0 +1,63 @@
+"""Data-parallel training step: each GPU owns an independent shard of the minibatch's text lines
+and the fresh gradient sum is all-reduced (RCCL over xGMI; gloo in the CPU tests) before the
+identical update on every rank.
+
+Reference precedent: share_deltas (clstm.cc:731-744) sums Params.d over in-process replicas.
+Params.d also carries the momentum (clstm_compute.cc:560-563), so summing it over R replicas
+would count mom*d_prev R times; here only the separate fresh-gradient buffer `grads` crosses
+GPUs and `derivs += grads` happens inside the update kernel, which keeps the single-process
+semantics  d = mom*d_prev + sum_b g_b  for any world size.
+"""
+import numpy as np
+
+
+class Trainer:
+    """CLSTMOCR::train (clstmhl.h:201-223) for a minibatch of lines, optionally data-parallel."""
+
+    def __init__(self, net, grads_tensor=None, process_group=None):
+        self.net = net
+        self.grads = grads_tensor          # torch tensor aliasing the net's grads buffer
+        self.pg = process_group
+        self.dist = None
+        if grads_tensor is not None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.dist = dist
+
+    def world_size(self):
+        return self.dist.get_world_size(self.pg) if self.dist else 1
+
+    def allreduce_grads(self):
+        if self.dist is not None and self.world_size() > 1:
+            self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM, group=self.pg)
+
+    def fwdbwd(self, lines, transcripts):
+        self.net.set_inputs(lines)
+        self.net.forward()
+        self.net.ctc(transcripts)
+        self.net.backward()
+
+    def step_device(self, T, x_dev, transcripts):
+        """One training step on inputs already resident in HBM (x_dev: [sum T, ninput])."""
+        net = self.net
+        net.set_batch(T)
+        net.set_inputs_device(x_dev)
+        net.forward()
+        net.ctc(transcripts)
+        net.backward()
+        self.allreduce_grads()
+        net.update()
+
+    def train(self, lines, transcripts):
+        self.fwdbwd(lines, transcripts)
+        out = self.net.decode()
+        self.allreduce_grads()
+        self.net.update()
+        return out
+
+
+def shard(items, rank, world):
+    """Contiguous shard of a minibatch for this rank (B/R lines per GPU)."""
+    n = len(items)
+    per = (n + world - 1) // world
+    return items[rank * per:min(n, (rank + 1) * per)]

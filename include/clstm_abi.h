@@ -1,0 +1,196 @@
+/*
+ * clstm_abi.h -- C ABI of libclstm_hip.so: the MI355X (gfx950) backing of clstm's hot path.
+ *
+ * This is the drop-in boundary for tmbdev/clstm's per-timestep LSTM forward/backward compute
+ * and CTC alignment.  Everything is `extern "C"`, plain pointers and sizes; no C++ or torch
+ * types.  All `float*` arguments are DEVICE pointers (hipMalloc / torch.cuda memory) unless the
+ * parameter name ends in `_h` (HOST pointer).  All matrices are column-major exactly as the
+ * reference's Tensor2 (tensor.h:252,288): element (i, b) of a (rows x cols) batch is
+ * ptr[i + rows*b]; a Params matrix W is (no x (1+ni)) with the bias in column 0
+ * (tensor.h:263-264).  Functions return 0 on success, non-zero on error;
+ * clstm_last_error() returns the message (the reference throws `const char*`, SConstruct:43).
+ * Kernels are enqueued on the stream set with clstm_set_stream() (default: the null stream);
+ * calls are asynchronous unless stated otherwise.  Handles are not thread-safe (the reference
+ * is single-threaded and not re-entrant, batches.cc:11, clstm_compute.cc:47).
+ *
+ * Two granularities, as SURVEY.md §8(b) requires:
+ *  (1) per-op entry points, 1:1 with the DEFGENERIC operator list of clstm_compute.h:72-103
+ *      that lies on the 1-D BiLSTM+CTC path (what `clstm_compute.cc` would call per timestep);
+ *  (2) fused sequence-level entry points (`clstm_net_*`): what the INetwork layers
+ *      (clstm.cc NPLSTM/Parallel/Reversed/Stacked/SoftmaxLayer), ctc.cc and sgd_update actually
+ *      use for a whole minibatch of text lines.
+ */
+#ifndef CLSTM_ABI_H_
+#define CLSTM_ABI_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* nonlinearity codes: clstm_compute.h:10-14 */
+enum { CLSTM_LIN = 0, CLSTM_SIG = 1, CLSTM_TANH = 2, CLSTM_RELU = 3, CLSTM_LOGMAG = 4 };
+
+const char* clstm_last_error(void);
+int clstm_abi_version(void);
+/* stream for every subsequent call on this host thread (a hipStream_t passed as void*) */
+int clstm_set_stream(void* hip_stream);
+int clstm_synchronize(void);
+
+/* ------------------------------------------------------------------------------------------
+ * (1) per-op entry points.  `n`/`m` are the Params dims (rows, cols incl. bias column),
+ *     `bs` the batch columns, `len` = rows*bs element counts.
+ * ---------------------------------------------------------------------------------------- */
+/* forward_nonlin0 / backward_nonlin0   clstm_compute.cc:209-229 / :247-267 */
+int clstm_forward_nonlin0(float* y_v, int len, int nl);
+int clstm_backward_nonlin0(const float* y_v, float* y_d, int len, int nl);
+/* forward_nonlin / backward_nonlin     clstm_compute.cc:130-150 / :168-188 */
+int clstm_forward_nonlin(float* y_v, const float* x_v, int len, int nl);
+int clstm_backward_nonlin(const float* y_v, const float* y_d, float* x_d, int len, int nl);
+/* forward_lin1 / backward_lin1         clstm_compute.cc:275-293 / :294-304 */
+int clstm_forward_lin1(float* y_v, const float* W_v, const float* x_v, int n, int m, int bs);
+int clstm_backward_lin1(const float* y_d, const float* W_v, float* W_d, const float* x_v, float* x_d,
+                        int n, int m, int bs);
+/* forward_full1 / backward_full1       clstm_compute.cc:308-314 / :316-320 */
+int clstm_forward_full1(float* y_v, const float* W_v, const float* x_v, int n, int m, int bs, int nl);
+int clstm_backward_full1(const float* y_v, float* y_d, const float* W_v, float* W_d, const float* x_v,
+                         float* x_d, int n, int m, int bs, int nl);
+/* forward_softmax / backward_softmax   clstm_compute.cc:324-345 / :346-356 */
+int clstm_forward_softmax(float* z_v, const float* W_v, const float* x_v, int n, int m, int bs);
+int clstm_backward_softmax(const float* z_d, const float* W_v, float* W_d, const float* x_v,
+                           float* x_d, int n, int m, int bs);
+/* forward_stack / backward_stack       clstm_compute.cc:360-367 / :368-373 */
+int clstm_forward_stack(float* z_v, const float* x_v, const float* y_v, int nx, int ny, int bs);
+int clstm_backward_stack(const float* z_d, float* x_d, float* y_d, int nx, int ny, int bs);
+/* forward_stack_delay / backward_stack_delay  clstm_compute.cc:377-397 / :398-410
+ * ylast_* = y[last].v / y[last].d, or NULL when last < 0 */
+int clstm_forward_stack_delay(float* z_v, const float* x_v, const float* ylast_v, int nx, int ny, int bs);
+int clstm_backward_stack_delay(const float* z_d, float* x_d, float* ylast_d, int nx, int ny, int bs);
+/* forward_reverse / backward_reverse   clstm_compute.cc:414-417 / :418-421
+ * on raw Sequence blocks (batches.h:79-86): dims (rows, bs, 2, N); forward copies v AND d */
+int clstm_forward_reverse(float* y_seq, const float* x_seq, int rows, int bs, int N);
+int clstm_backward_reverse(const float* y_seq, float* x_seq, int rows, int bs, int N);
+/* forward_statemem / backward_statemem clstm_compute.cc:504-508 / :509-515 (last_* NULL if last<0) */
+int clstm_forward_statemem(float* state_v, const float* ci_v, const float* gi_v, const float* last_v,
+                           const float* gf_v, int len);
+int clstm_backward_statemem(const float* state_d, const float* ci_v, float* ci_d, const float* gi_v,
+                            float* gi_d, const float* last_v, float* last_d, const float* gf_v,
+                            float* gf_d, int len);
+/* forward_nonlingate / backward_nonlingate  clstm_compute.cc:530-537 / :539-547 (no heap temp) */
+int clstm_forward_nonlingate(float* out_v, const float* state_v, const float* go_v, int len, int nl);
+int clstm_backward_nonlingate(const float* out_d, const float* state_v, float* state_d,
+                              const float* go_v, float* go_d, int len, int nl);
+/* clip_gradient / sgd_update           clstm_compute.cc:553-558 / :560-563 */
+int clstm_clip_gradient(float* d, int len, float clip);
+int clstm_sgd_update(float* v, float* d, int len, float lr, float mom);
+
+/* ------------------------------------------------------------------------------------------
+ * CTC on packed line batches.  A "line batch" is bs text lines packed frame-major:
+ * line b owns frames [line_off[b], line_off[b+1]) of a [N][nc] array (nc contiguous).
+ * ---------------------------------------------------------------------------------------- */
+/* ctc_align_targets(Sequence&, Sequence&, Classes&)  ctc.cc:136-146 (and :57-134), batched.
+ * probs/deltas/aligned: DEVICE [N][nc]; aligned may be NULL.  deltas = aligned - probs
+ * (clstmhl.h:211-212).  line_off_h[bs+1], states_h (one class per target state, packed),
+ * state_off_h[bs+1]: HOST.  Synchronous with respect to the host arrays (they are copied). */
+int clstm_ctc_align_batch(const float* probs, float* deltas, float* aligned, int nc,
+                          const int* line_off_h, const int* states_h, const int* state_off_h, int bs);
+/* mktargets  ctc.cc:148-157: 2L+1 state classes, blank (0) on even positions.  HOST arrays. */
+int clstm_mktargets(int* states_h, const int* transcript_h, int L);
+/* trivial_decode  ctc.cc:159-190 (+ argmax tensor.h:357-366), batched.  probs DEVICE [N][nc];
+ * classes_h/locs_h HOST [N] (line b's result starts at line_off[b]); counts_h HOST [bs].
+ * Blocking. */
+int clstm_trivial_decode_batch(const float* probs, int nc, const int* line_off_h, int bs,
+                               int* classes_h, int* locs_h, int* counts_h);
+
+/* ------------------------------------------------------------------------------------------
+ * (2) fused network: Stacked{ Parallel{NPLSTM, Reversed{NPLSTM}} x nlayers, SoftmaxLayer }
+ *     = prefab "bidi" / "bidi2" (clstm_prefab.cc:52-68, 86-109); unidirectional = "lstm1".
+ * ---------------------------------------------------------------------------------------- */
+typedef struct clstm_net clstm_net;
+#define CLSTM_MAX_LAYERS 4
+typedef struct {
+  int nlayers;                    /* BiLSTM layers (1 = bidi, 2 = bidi2) */
+  int unidirectional;             /* 1: Stacked{NPLSTM, Softmax} (lstm1) */
+  int ninput;                     /* features per frame (48 for OCR lines) */
+  int nhidden[CLSTM_MAX_LAYERS];  /* NPLSTM units per direction */
+  int nclasses;                   /* softmax outputs */
+} clstm_net_desc;
+
+/* Number of floats of the flat parameter buffer: exactly n_params() (clstm.cc:852-857) in
+ * walk_params order (clstm.cc:59-62): per NPLSTM WCI,WGF,WGI,WGO (std::map order), forward
+ * before reversed, layers in order, softmax W1 last; each Params block column-major. */
+int clstm_net_nparams_for(const clstm_net_desc* desc);
+/* params_d / derivs_d / grads_d: caller-owned DEVICE buffers of nparams floats (the analogue of
+ * share_params, clstm.cc:859-870), or NULL to let the library allocate.
+ *   params = Params.v ; derivs = Params.d (gradient + carried momentum, clstm_compute.cc:560-563);
+ *   grads  = this step's fresh minibatch gradient sum (what data-parallel ranks all-reduce). */
+int clstm_net_create(clstm_net** out, const clstm_net_desc* desc, float* params_d, float* derivs_d,
+                     float* grads_d);
+int clstm_net_destroy(clstm_net* net);
+int clstm_net_nparams(clstm_net* net);
+int clstm_net_buffers(clstm_net* net, float** params_d, float** derivs_d, float** grads_d);
+/* get_params/set_params/get_derivs/set_derivs (clstm.cc:872-917): HOST buffers, blocking. */
+int clstm_net_set_params_h(clstm_net* net, const float* params_h);
+int clstm_net_get_params_h(clstm_net* net, float* params_h);
+int clstm_net_set_derivs_h(clstm_net* net, const float* derivs_h);
+int clstm_net_get_derivs_h(clstm_net* net, float* derivs_h);
+int clstm_net_get_grads_h(clstm_net* net, float* grads_h);
+/* must be called after writing the params buffer directly on the device */
+int clstm_net_params_changed(clstm_net* net);
+/* INetwork::setLearningRate (clstm.cc:158-161) + gradient_clip attr (clstm.cc:204) */
+int clstm_net_set_learning_rate(clstm_net* net, float lr, float momentum);
+int clstm_net_set_gradient_clip(clstm_net* net, float clip);
+
+/* Declare the next minibatch: bs lines of T_h[b] frames each (HOST).  N = sum T. */
+int clstm_net_set_batch(clstm_net* net, const int* T_h, int bs);
+/* set_inputs (clstm.cc:684-690): x [N][ninput], frame-major, feature contiguous. */
+int clstm_net_set_inputs_h(clstm_net* net, const float* x_h);
+int clstm_net_set_inputs_d(clstm_net* net, const float* x_d);
+/* net->forward() */
+int clstm_net_forward(clstm_net* net);
+/* net->outputs: DEVICE pointer to [N][nclasses] softmax outputs / their deltas (.d plane) */
+int clstm_net_outputs(clstm_net* net, float** probs_d, float** deltas_d);
+int clstm_net_get_outputs_h(clstm_net* net, float* probs_h);
+int clstm_net_set_output_deltas_h(clstm_net* net, const float* deltas_h);
+/* CLSTMOCR::fwdbwd CTC leg (clstmhl.h:207-212): mktargets + ctc_align_targets + deltas for
+ * every line of the batch.  labels_h packed transcripts, L_h[bs] lengths (HOST).
+ * aligned_h (HOST, [N][nc]) may be NULL. */
+int clstm_net_ctc(clstm_net* net, const int* labels_h, const int* L_h, float* aligned_h);
+/* net->backward(): accumulates this minibatch's gradient sum into grads (zeroed first). */
+int clstm_net_backward(clstm_net* net);
+/* input deltas of the first layer are only computed if enabled (nothing on the OCR path reads
+ * them; the gradient tests do). */
+int clstm_net_enable_input_deltas(clstm_net* net, int on);
+int clstm_net_get_input_deltas_h(clstm_net* net, float* dx_h);
+/* sgd_update(Network) (clstm.cc:201-217) on the flat buffers:
+ *   derivs += grads ; derivs = clip(derivs, +-gradient_clip) ; params += lr*derivs ;
+ *   derivs *= momentum.   (lr is NOT normalised, see SURVEY.md §7 "lr normalisation".) */
+int clstm_net_update(clstm_net* net);
+/* trivial_decode of every line; HOST outputs as clstm_trivial_decode_batch.  Blocking. */
+int clstm_net_decode(clstm_net* net, int* classes_h, int* locs_h, int* counts_h);
+/* internal NPLSTM state for parity tests: which = 0 gi,1 gf,2 go,3 ci,4 state,5 output h,
+ * 6 gate delta gi,7 gf,8 go,9 ci (pre-activation deltas after backward_nonlin0).
+ * dir 0 = forward NPLSTM, 1 = the NPLSTM inside Reversed.  out_h: HOST [N][nhidden] in FRAME
+ * order (i.e. already un-reversed).  Blocking. */
+int clstm_net_get_state_h(clstm_net* net, int layer, int dir, int which, float* out_h);
+/* name and average device time (ms, hipEvent-timed on the library's stream) of the most
+ * recent forward/backward kernels -- used by bench.py for the roofline object.
+ * Enable with clstm_net_enable_timing(net, 1). */
+int clstm_net_enable_timing(clstm_net* net, int on);
+int clstm_net_kernel_time_ms(clstm_net* net, const char* kernel_name, double* total_ms, int* launches);
+int clstm_net_reset_timing(clstm_net* net);
+
+/* ------------------------------------------------------------------------------------------
+ * diagnostics (used by tests/ to pin the hardware lane layouts the kernels rely on)
+ * ---------------------------------------------------------------------------------------- */
+/* out: DEVICE [9][64] floats; row k = op k applied to the lane index:
+ * 0 quad_xor1, 1 quad_xor2, 2..5 quad_bcast<0..3>, 6 row_ror<1>, 7 row_ror<4>, 8 row_ror<8> */
+int clstm_debug_lane_ops(float* out);
+/* C = A.B through the MFMA GEMM used by the hoisted products.  mode 0 "NN": A [R][K] row-major,
+ * B [K][Cn] row-major; mode 1 "NT": A [R][K], B given as [Cn][K]; mode 2 "TN": A given as [K][R],
+ * B [K][Cn] (split over K into nsplit slabs, reduced deterministically).  C [R][Cn] row-major. */
+int clstm_debug_gemm(int mode, const float* A, const float* B, float* C, int R, int Cn, int K, int nsplit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLSTM_ABI_H_ */

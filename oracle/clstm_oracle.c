@@ -224,12 +224,16 @@ void ora_backward_nonlin(const Float *yv, const Float *yd, Float *xd, int len, i
 
 /* y.v = W[:,1:] . x.v  then  += W[:,0] broadcast  (clstm_compute.cc:275-293) */
 void ora_forward_lin1(Float *yv, const Float *W, const Float *xv, int n, int m, int bs) {
+  /* Loop order is i-inner (contiguous columns of W) so the compiler vectorises it like Eigen's
+   * contraction kernels do; every y(i,b) still accumulates its products in k order. */
   int nx = m - 1;
   for (int b = 0; b < bs; b++) {
-    for (int i = 0; i < n; i++) {
-      Float acc = 0;
-      for (int k = 0; k < nx; k++) acc += W[i + (size_t)n * (1 + k)] * xv[k + (size_t)nx * b];
-      yv[i + (size_t)n * b] = acc;
+    Float *y = yv + (size_t)n * b;
+    for (int i = 0; i < n; i++) y[i] = 0;
+    for (int k = 0; k < nx; k++) {
+      const Float xk = xv[k + (size_t)nx * b];
+      const Float *w = W + (size_t)n * (1 + k);
+      for (int i = 0; i < n; i++) y[i] += w[i] * xk;
     }
   }
   for (int b = 0; b < bs; b++)
@@ -241,16 +245,27 @@ void ora_backward_lin1(const Float *yd, const Float *W, Float *Wd, const Float *
   int nx = m - 1;
   for (int b = 0; b < bs; b++)
     for (int k = 0; k < nx; k++) {
+      const Float *w = W + (size_t)n * (1 + k);
+      const Float *y = yd + (size_t)n * b;
       Float acc = 0;
-      for (int i = 0; i < n; i++) acc += W[i + (size_t)n * (1 + k)] * yd[i + (size_t)n * b];
+#pragma omp simd reduction(+ : acc)
+      for (int i = 0; i < n; i++) acc += w[i] * y[i];
       xd[k + (size_t)nx * b] += acc;
     }
-  for (int k = 0; k < nx; k++)
-    for (int i = 0; i < n; i++) {
-      Float acc = 0;
-      for (int b = 0; b < bs; b++) acc += yd[i + (size_t)n * b] * xv[k + (size_t)nx * b];
-      Wd[i + (size_t)n * (1 + k)] += acc;
+  if (bs == 1) { /* rank-1 update, the online-SGD case */
+    for (int k = 0; k < nx; k++) {
+      const Float xk = xv[k];
+      Float *wd = Wd + (size_t)n * (1 + k);
+      for (int i = 0; i < n; i++) wd[i] += yd[i] * xk;
     }
+  } else {
+    for (int k = 0; k < nx; k++)
+      for (int i = 0; i < n; i++) {
+        Float acc = 0;
+        for (int b = 0; b < bs; b++) acc += yd[i + (size_t)n * b] * xv[k + (size_t)nx * b];
+        Wd[i + (size_t)n * (1 + k)] += acc;
+      }
+  }
   for (int i = 0; i < n; i++) {
     Float acc = 0;
     for (int b = 0; b < bs; b++) acc += yd[i + (size_t)n * b];

@@ -22,3 +22,13 @@ def ora32():
 def ora64():
     from oracle.oracle import Oracle
     return Oracle("f64")
+
+
+def _backend_params():
+    return ["emu", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(scope="session", params=_backend_params())
+def backend(request):
+    from common import Backend
+    return Backend(request.param)

@@ -1,0 +1,152 @@
+// hip_emu.h -- TEST-ONLY host-thread emulator of the handful of HIP/gfx950 primitives that
+// clstm_amd/csrc uses (see devintrin.h).  It lets the CPU test-suite (-m "not gpu") execute
+// the real kernel sources -- one OS thread per GPU thread, blocks run one after another --
+// to validate indexing, LDS hand-offs and barrier placement where no GPU is available.
+// MFMA / DPP lane layouts follow /opt/skills/guides/cdna_hip_programming.md §3 and the LLVM
+// DppCtrl table; they are assumptions of the emulator, re-checked on hardware by
+// tests/test_gpu_intrinsics.py.  Never built into, or loaded by, the product library.
+#pragma once
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+extern thread_local uint3_emu threadIdx, blockIdx;
+extern thread_local dim3 blockDim, gridDim;
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(n ? n : 1, 1); return 0; }
+inline hipError_t hipFree(void* p) { free(p); return 0; }
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __restrict__
+#define DEVFN static inline
+#define DEVMFN inline
+
+struct f32x4 {
+  float v[4];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+struct float4 { float x, y, z, w; };
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+// ---- block / wave runtime -----------------------------------------------------------
+struct EmuBlock {
+  pthread_barrier_t block_bar;
+  std::vector<pthread_barrier_t> wave_bar;
+  std::vector<float> xf;   // [wave][64][8] exchange slots
+  char* smem;
+};
+extern thread_local EmuBlock* emu_blk;
+inline void __syncthreads() { pthread_barrier_wait(&emu_blk->block_bar); }
+inline int emu_lane() { return threadIdx.x & 63; }
+inline int emu_wave() { return threadIdx.x >> 6; }
+inline void emu_wave_sync() { pthread_barrier_wait(&emu_blk->wave_bar[emu_wave()]); }
+inline float* emu_slot(int lane, int k = 0) { return &emu_blk->xf[((size_t)emu_wave() * 64 + lane) * 8 + k]; }
+
+inline float wave_shfl(float x, int src) {
+  *emu_slot(emu_lane()) = x;
+  emu_wave_sync();
+  float r = *emu_slot(src & 63);
+  emu_wave_sync();
+  return r;
+}
+inline int wave_shfl_i(int x, int src) {
+  float f; memcpy(&f, &x, 4);
+  f = wave_shfl(f, src);
+  int r; memcpy(&r, &f, 4);
+  return r;
+}
+inline float wave_shfl_up1(float x) { int l = emu_lane(); return wave_shfl(x, l == 0 ? 0 : l - 1); }
+inline float quad_xor1(float x) { return wave_shfl(x, emu_lane() ^ 1); }
+inline float quad_xor2(float x) { return wave_shfl(x, emu_lane() ^ 2); }
+template <int I> inline float quad_bcast(float x) { return wave_shfl(x, (emu_lane() & ~3) | I); }
+template <int N> inline float row_ror(float x) {
+  // DPP row_ror:N -- lane i of a 16-lane row receives the value of lane (i+N)%16 of that row
+  int l = emu_lane();
+  return wave_shfl(x, (l & ~15) | ((l + N) & 15));
+}
+inline float wave_max(float x) { for (int m = 32; m >= 1; m >>= 1) x = fmaxf(x, wave_shfl(x, emu_lane() ^ m)); return x; }
+inline float wave_sum(float x) { for (int m = 32; m >= 1; m >>= 1) x += wave_shfl(x, emu_lane() ^ m); return x; }
+
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=(l>>4)*4+r][col=l&15]
+inline f32x4 mfma16x16x4(float a, float b, f32x4 c) {
+  int l = emu_lane();
+  *emu_slot(l, 0) = a;
+  *emu_slot(l, 1) = b;
+  emu_wave_sync();
+  f32x4 d = c;
+  for (int r = 0; r < 4; r++) {
+    int row = (l >> 4) * 4 + r, col = l & 15;
+    float acc = c[r];
+    for (int k = 0; k < 4; k++) acc = fmaf(*emu_slot(k * 16 + row, 0), *emu_slot(k * 16 + col, 1), acc);
+    d[r] = acc;
+  }
+  emu_wave_sync();
+  return d;
+}
+inline float fast_exp(float x) { return expf(x); }
+inline float fast_rcp(float x) { return 1.0f / x; }
+template <typename T> inline T* dyn_smem() { return reinterpret_cast<T*>(emu_blk->smem); }
+
+template <typename K, typename... Args>
+void emu_launch(K kernel, dim3 grid, dim3 block, size_t smem, Args... args) {
+  const unsigned nthreads = block.x * block.y * block.z;
+  if (nthreads % 64 != 0) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }
+  for (unsigned bz = 0; bz < grid.z; bz++)
+    for (unsigned by = 0; by < grid.y; by++)
+      for (unsigned bx = 0; bx < grid.x; bx++) {
+        EmuBlock blk;
+        pthread_barrier_init(&blk.block_bar, nullptr, nthreads);
+        blk.wave_bar.resize(nthreads / 64);
+        for (auto& w : blk.wave_bar) pthread_barrier_init(&w, nullptr, 64);
+        blk.xf.assign((size_t)nthreads * 8, 0.f);
+        std::vector<char> sm(smem + 16, 0);
+        blk.smem = sm.data();
+        std::vector<std::thread> th;
+        th.reserve(nthreads);
+        for (unsigned t = 0; t < nthreads; t++)
+          th.emplace_back([&, t]() {
+            emu_blk = &blk;
+            threadIdx = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+            blockIdx = {bx, by, bz};
+            blockDim = block;
+            gridDim = grid;
+            kernel(args...);
+          });
+        for (auto& t : th) t.join();
+        pthread_barrier_destroy(&blk.block_bar);
+        for (auto& w : blk.wave_bar) pthread_barrier_destroy(&w);
+      }
+}
+#define CLSTM_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  emu_launch(kernel, dim3(grid), dim3(block), smem, __VA_ARGS__)

@@ -1,0 +1,83 @@
+"""world_size-2 data-parallel step on CPU: gloo all-reduce of the fresh-gradient buffer, the
+kernels running through the host emulator.  Checks (a) both ranks end bit-identical, (b) the
+result equals the single-process oracle minibatch over ALL lines, including the second step where
+the carried momentum (Params.d, clstm_compute.cc:560-563) must NOT be multiplied by the replica
+count (the share_deltas artefact, clstm.cc:731-744 / SURVEY.md §8e)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NI, NH, NC = 4, 5, 4
+
+
+def make_data(step):
+    from common import synth_lines
+    rng = np.random.default_rng(100 + step)
+    T = [5, 3, 4, 6]
+    lines = synth_lines(rng, T, NI)
+    trs = [rng.integers(1, NC, 2).astype(np.int32) for _ in T]
+    return lines, trs
+
+
+def worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Network
+    from clstm_amd.parallel import Trainer, shard
+    from common import emu_lib
+    lib = emu_lib()
+    p0 = init_params(NI, NH, NC, seed=0.222) * 30
+    params = torch.from_numpy(p0.copy())
+    derivs = torch.zeros_like(params)
+    grads = torch.zeros_like(params)
+    net = Network(NI, NH, NC, lib=lib, params=params, derivs=derivs, grads=grads)
+    net.params_changed()
+    net.setLearningRate(5e-2, 0.9)
+    tr = Trainer(net, grads_tensor=grads)
+    assert tr.world_size() == world
+    for step in range(2):
+        lines, trs = make_data(step)
+        tr.train(shard(lines, rank, world), shard(trs, rank, world))
+    np.save(os.path.join(outdir, "params_%d.npy" % rank), params.numpy())
+    np.save(os.path.join(outdir, "derivs_%d.npy" % rank), derivs.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_matches_single_process(tmp_path, ora32):
+    import torch.multiprocessing as mp
+    from common import assert_close, emu_lib
+    from clstm_amd.init import init_params
+    from oracle.oracle import OracleNet
+    emu_lib()                                   # build once, before the workers race for it
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p = [np.load(tmp_path / ("params_%d.npy" % r)) for r in range(2)]
+    d = [np.load(tmp_path / ("derivs_%d.npy" % r)) for r in range(2)]
+    assert np.array_equal(p[0], p[1]) and np.array_equal(d[0], d[1])     # replicas stay identical
+    ref = OracleNet(ora32, NI, NH, NC, init=False)
+    ref.set_params(init_params(NI, NH, NC, seed=0.222) * 30)
+    ref.set_lr(5e-2, 0.9)
+    for step in range(2):
+        lines, trs = make_data(step)
+        for x, t in zip(lines, trs):
+            ref.set_inputs(x); ref.forward(); ref.ctc_deltas(t); ref.backward()
+        ref.update()
+    assert_close(p[0], ref.get_params(), rtol=2e-5, atol=2e-7, what="params after 2 DP steps")
+    assert_close(d[0], ref.get_derivs(), rtol=5e-4, atol=2e-6, what="momentum buffer after 2 DP steps")
+
+
+def test_shard_covers_everything():
+    from clstm_amd.parallel import shard
+    items = list(range(11))
+    for world in (1, 2, 3, 4, 8):
+        got = sum((shard(items, r, world) for r in range(world)), [])
+        assert got == items

@@ -1,0 +1,54 @@
+"""Pins the hardware facts the kernels rely on: DPP lane-move encodings, the f32 MFMA
+fragment layout (through the GEMM with asymmetric operands, cdna guide §3 "A=I-check with
+ASYMMETRIC B") and the device activation functions.  'emu' checks the emulator's model of them,
+'hip' (-m gpu) checks the silicon -- both must agree with the same expectations."""
+import numpy as np
+import pytest
+
+from clstm_amd.abi import ptr
+from common import assert_close
+
+
+def test_lane_ops(backend):
+    out = backend.zeros((9, 64))
+    backend.lib.call("clstm_debug_lane_ops", ptr(out))
+    got = backend.down(out)
+    lane = np.arange(64)
+    want = np.stack([lane ^ 1, lane ^ 2, (lane & ~3) | 0, (lane & ~3) | 1, (lane & ~3) | 2, (lane & ~3) | 3,
+                     (lane & ~15) | ((lane + 1) & 15), (lane & ~15) | ((lane + 4) & 15),
+                     (lane & ~15) | ((lane + 8) & 15)]).astype(np.float32)
+    # row_ror all-reduce only needs SOME rotation by N within the row: accept either direction
+    for k in range(6):
+        assert np.array_equal(got[k], want[k]), k
+    for k, n in ((6, 1), (7, 4), (8, 8)):
+        alt = ((lane & ~15) | ((lane - n) & 15)).astype(np.float32)
+        assert np.array_equal(got[k], want[k]) or np.array_equal(got[k], alt), k
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("R,Cn,K,ns", [(64, 64, 16, 1), (70, 45, 37, 1), (149, 400, 333, 5), (5, 3, 2, 1),
+                                       (130, 83, 200, 3)])
+def test_gemm_modes(backend, mode, R, Cn, K, ns):
+    if backend.kind == "emu" and R * Cn > 20000:
+        pytest.skip("big tile counts only on the GPU")
+    rng = np.random.default_rng(R * 1000 + Cn)
+    A = rng.normal(size=(R, K)).astype(np.float32)
+    B = rng.normal(size=(K, Cn)).astype(np.float32)
+    want = A.astype(np.float64) @ B.astype(np.float64)
+    Ad = backend.up(A if mode != 2 else A.T)
+    Bd = backend.up(B if mode != 1 else B.T)
+    Cd = backend.zeros((R, Cn))
+    backend.lib.call("clstm_debug_gemm", mode, ptr(Ad), ptr(Bd), ptr(Cd), R, Cn, K, ns if mode == 2 else 1)
+    got = backend.down(Cd)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    assert (np.abs(got - want) <= 2e-6 * scale + 1e-6).all()
+
+
+def test_device_activations(backend):
+    # sigmoid_dev / tanh_dev (devintrin.h) through forward_nonlin0 over a wide sweep
+    x = np.concatenate([np.linspace(-40, 40, 4001), np.linspace(-0.6, 0.6, 2001), [0.0, 1e-8, -1e-8, 1e-3]])
+    x = x.astype(np.float32)
+    for nl, f in ((1, lambda v: 1 / (1 + np.exp(-v))), (2, np.tanh)):
+        y = backend.up(x)
+        backend.lib.call("clstm_forward_nonlin0", ptr(y), x.size, nl)
+        assert_close(backend.down(y), f(x.astype(np.float64)), rtol=2e-6, atol=1e-30, what="nl %d" % nl)

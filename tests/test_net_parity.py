@@ -1,0 +1,153 @@
+"""Parity of the fused network path (clstm_net_* ABI) against the oracle.
+
+Every test runs twice: backend 'emu' executes the real kernel sources on CPU threads
+(-m "not gpu"), backend 'hip' is the parity test proper on an MI355X through the C ABI (-m gpu).
+Tolerances: 1e-4 relative on activations (BASELINE.json north_star), CTC argmax decodes exact."""
+import numpy as np
+import pytest
+
+from common import assert_close, oracle_minibatch, synth_lines
+from oracle.oracle import OracleNet
+
+STATES = ("gi", "gf", "go", "ci", "state", "outputs")
+DELTAS = ("d_gi", "d_gf", "d_go", "d_ci")
+
+
+def run_case(backend, ora32, ni, nh, nc, T, uni=False, scale=30.0, seed=1, lr=1e-2, check_dx=False):
+    from clstm_amd.net import Network
+    rng = np.random.default_rng(seed)
+    nhl = nh if isinstance(nh, list) else [nh]
+    dirs = (0,) if uni else (0, 1)
+    ref = OracleNet(ora32, ni, nh, nc, unidirectional=uni, seed=0.222)
+    params = ref.get_params() * scale
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+    skeys = [(l, d, w) for l in range(len(nhl)) for d in dirs for w in STATES + DELTAS]
+    want = oracle_minibatch(ora32, OracleNet, params, ni, nh, nc, lines, trs, unidirectional=uni,
+                            states=skeys, lr=lr, mom=0.9)
+    net = Network(ni, nh, nc, unidirectional=uni, lib=backend.lib)
+    net.set_params(params)
+    net.setLearningRate(lr, 0.9)
+    if check_dx:
+        net.enable_input_deltas(True)
+    net.set_inputs(lines)
+    net.forward()
+    got = net.split(net.outputs())
+    for b in range(len(T)):
+        assert_close(got[b], want["outputs"][b], what="softmax outputs line %d" % b)
+    for k in skeys:
+        if k[2] in STATES:
+            s = net.split(net.state(*k))
+            for b in range(len(T)):
+                assert_close(s[b], want["states"][k][b], what="state %s line %d" % (k, b))
+    dec = net.decode()
+    for b in range(len(T)):
+        assert dec[b].tolist() == want["decode"][b].tolist()       # bit-exact decode
+    al = net.split(net.ctc(trs, want_aligned=True))
+    for b in range(len(T)):
+        assert_close(al[b], want["aligned"][b], rtol=1e-4, atol=1e-6, what="aligned line %d" % b)
+    net.backward()
+    for k in skeys:
+        if k[2] in DELTAS:
+            s = net.split(net.state(*k))
+            for b in range(len(T)):
+                assert_close(s[b], want["states"][k][b], rtol=3e-4, atol=1e-7, what="delta %s line %d" % (k, b))
+    assert_close(net.get_grads(), want["derivs"], rtol=3e-4, atol=2e-6, what="minibatch gradient")
+    net.update()
+    want["net"].update()
+    assert_close(net.get_params(), want["net"].get_params(), rtol=1e-5, atol=1e-7, what="params after update")
+    assert_close(net.get_derivs(), want["net"].get_derivs(), rtol=3e-4, atol=2e-6, what="momentum buffer")
+    return net, want
+
+
+@pytest.mark.parametrize("ni,nh,nc,T", [
+    (5, 6, 4, [5, 3]),            # one wave, two ragged lines
+    (7, 20, 5, [4]),              # two waves, second partially filled
+    (3, 33, 6, [3, 1, 2]),        # NK4=4 instantiation, a 1-frame line
+])
+def test_bidi_small(backend, ora32, ni, nh, nc, T):
+    run_case(backend, ora32, ni, nh, nc, T)
+
+
+def test_bidi_uw3_shape_short(backend, ora32):
+    # the uw3 architecture (48 -> 2x100 -> 83), short lines so the CPU emulation stays fast
+    T = [4, 2] if backend.kind == "emu" else [40, 23, 31]
+    run_case(backend, ora32, 48, 100, 83, T, scale=10.0)
+
+
+def test_bidi2_stacked(backend, ora32):
+    # two stacked BiLSTM layers: exercises the inter-layer dX GEMM (Stacked::backward clstm.cc:440-454)
+    run_case(backend, ora32, 4, [6, 5], 4, [4, 3], scale=30.0)
+
+
+def test_lstm1_unidirectional(backend, ora32):
+    run_case(backend, ora32, 3, 4, 3, [6], uni=True)
+
+
+def test_second_step_momentum(backend, ora32):
+    """d doubles as gradient + carried momentum (clstm_compute.cc:560-563): after the first
+    update, d = mom*d_prev must be carried into the second minibatch exactly once."""
+    from clstm_amd.net import Network
+    ni, nh, nc = 4, 5, 4
+    rng = np.random.default_rng(3)
+    ref = OracleNet(ora32, ni, nh, nc, seed=0.222)
+    params = ref.get_params() * 30
+    ref.set_params(params)
+    ref.set_lr(5e-2, 0.9)
+    net = Network(ni, nh, nc, lib=backend.lib)
+    net.set_params(params)
+    net.setLearningRate(5e-2, 0.9)
+    for step in range(3):
+        lines = synth_lines(rng, [5, 4], ni)
+        trs = [rng.integers(1, nc, 2).astype(np.int32) for _ in lines]
+        for x, tr in zip(lines, trs):            # reference: both lines accumulate into d, one update
+            ref.set_inputs(x); ref.forward(); ref.ctc_deltas(tr); ref.backward()
+        ref.update()
+        net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward(); net.update()
+        assert_close(net.get_params(), ref.get_params(), rtol=2e-5, atol=2e-7, what="params step %d" % step)
+        assert_close(net.get_derivs(), ref.get_derivs(), rtol=5e-4, atol=2e-6, what="derivs step %d" % step)
+
+
+def test_input_deltas_and_explicit_output_deltas(backend, ora32):
+    """set_targets-style deltas (clstm.cc:142-150) instead of CTC; also checks the first layer's
+    input deltas (Parallel::backward sums both directions, clstm.cc:538-541)."""
+    from clstm_amd.net import Network
+    ni, nh, nc, T = 5, 7, 4, 6
+    rng = np.random.default_rng(5)
+    ref = OracleNet(ora32, ni, nh, nc, seed=0.222)
+    params = ref.get_params() * 30
+    ref.set_params(params)
+    x = synth_lines(rng, [T], ni)[0]
+    y = np.abs(rng.normal(size=(T, nc))).astype(np.float32)
+    y /= y.sum(-1, keepdims=True)
+    ref.set_inputs(x)
+    out = ref.forward()[:, 0, :]
+    ref.set_targets(y[:, None, :])
+    ref.backward()
+    net = Network(ni, nh, nc, lib=backend.lib)
+    net.set_params(params)
+    net.enable_input_deltas(True)
+    net.set_inputs([x])
+    net.forward()
+    o = net.outputs()
+    assert_close(o, out, what="outputs")
+    net.set_output_deltas(y - o)
+    net.backward()
+    assert_close(net.input_deltas(), ref.input_deltas()[:, 0, :], rtol=3e-4, atol=1e-7, what="input deltas")
+    assert_close(net.get_grads(), ref.get_derivs(), rtol=3e-4, atol=2e-6, what="gradient")
+
+
+def test_errors_are_reported(backend):
+    from clstm_amd.abi import ClstmError
+    from clstm_amd.net import Network
+    net = Network(4, 5, 3, lib=backend.lib)
+    with pytest.raises(ClstmError):
+        net.forward()                              # no batch yet
+    with pytest.raises(ClstmError):
+        Network(4, 500, 3, lib=backend.lib)        # beyond the register-resident recurrence
+    net.set_inputs([np.zeros((3, 4), np.float32)])
+    net.forward()
+    with pytest.raises(ClstmError):
+        net.ctc([[0]])                             # blank inside a transcript (clstm.cc:232)
+    with pytest.raises(ClstmError):
+        net.ctc([[7]])                             # class out of range
