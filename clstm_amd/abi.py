@@ -90,6 +90,7 @@ _SIGS = {
     "clstm_net_kernel_time_ms": [_P, C.c_char_p, _P, _P],
     "clstm_net_reset_timing": [_P],
     "clstm_debug_lane_ops": [_P],
+    "clstm_debug_ctc_cycles": [_P],
     "clstm_debug_gemm": [_I, _P, _P, _P, _I, _I, _I, _I],
 }
 # functions whose int return value is a result, not a status

@@ -18,6 +18,8 @@
 #include "lstm_seq.h"
 #include "ops.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -139,15 +141,15 @@ static int pick_nk4(int no) {
 }
 template <int NK4>
 static void launch_fwd(const LstmSeqArgs& a, int bs, int nthreads, hipStream_t s) {
-  const size_t smem = 2 * 4 * (size_t)lstm_qstride(NK4) * sizeof(float);
+  const size_t smem = (2 * 4 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
   CLSTM_LAUNCH((lstm_fwd_kernel<NK4>), dim3(bs, a.ndir), dim3(nthreads), smem, s, a);
 }
 template <int NK4>
 static void launch_bwd(const LstmSeqArgs& a, int bs, int nthreads, hipStream_t s) {
-  const size_t smem = 2 * 16 * (size_t)lstm_qstride(NK4) * sizeof(float);
+  const size_t smem = (2 * 16 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
   CLSTM_LAUNCH((lstm_bwd_kernel<NK4>), dim3(bs, a.ndir), dim3(nthreads), smem, s, a);
 }
-static void launch_lstm(bool fwd, int nk4, const LstmSeqArgs& a, int bs, int nthreads, hipStream_t s) {
+static void launch_lstm(bool fwd, int nk4, LstmSeqArgs a, int bs, int nthreads, hipStream_t s) {
   switch (nk4) {
 #define CASE_(N) case N: if (fwd) launch_fwd<N>(a, bs, nthreads, s); else launch_bwd<N>(a, bs, nthreads, s); break;
     CASE_(1) CASE_(2) CASE_(4) CASE_(7) CASE_(8)
@@ -464,8 +466,11 @@ struct Net {
   }
 };
 
+static thread_local long long* g_last_ctc_prof = nullptr;
 // CTC on an arbitrary packed batch (used by the net and by the stand-alone ABI entry)
 struct CtcWorkspace {
+  DevBuf<long long> prof;
+  DevBuf<double> tables;
   DevBuf<int> line_off, states, state_off;
   DevBuf<float> lat;
   DevBuf<long long> lat_off;
@@ -478,7 +483,7 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
   for (int b = 0; b < bs; b++) {
     const long long T = line_off_h[b + 1] - line_off_h[b], S = state_off_h[b + 1] - state_off_h[b];
     REQUIRE(T >= 0 && S >= 0, "bad offsets");
-    REQUIRE(S <= 64 * CTC_RMAX, "more than 512 target states per line is not supported");
+    REQUIRE(S <= CTC_GROUP * CTC_RMAX, "more than 512 target states per line is not supported");
     lo[b + 1] = lo[b] + 3 * T * S;
   }
   const int ns = state_off_h[bs];
@@ -493,7 +498,33 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
   CtcArgs a{};
   a.P = probs; a.Dz = deltas; a.aligned = aligned; a.line_off = w.line_off.p; a.states = w.states.p;
   a.state_off = w.state_off.p; a.lat = w.lat.p; a.lat_off = w.lat_off.p; a.nc = nc;
-  CLSTM_LAUNCH(ctc_align_kernel, dim3(bs), dim3(CTC_THREADS), 0, s, a);
+  w.prof.reserve(8); a.prof = w.prof.p; g_last_ctc_prof = w.prof.p;
+  if (!w.tables.p) {
+    w.tables.reserve(160);
+    std::vector<double> tb(160);
+    for (int i = 0; i < 32; i++) tb[i] = CTC_EXP2_32[i];
+    for (int i = 0; i < 64; i++) { tb[32 + i] = CTC_LOG_INVC[i]; tb[96 + i] = CTC_LOG_LOGC[i]; }
+    HIPCHECK(hipMemcpy(w.tables.p, tb.data(), 160 * sizeof(double), hipMemcpyHostToDevice));
+  }
+  a.tables = w.tables.p;
+  int smax = 1;
+  for (int b = 0; b < bs; b++) smax = std::max(smax, state_off_h[b + 1] - state_off_h[b]);
+  a.smax = smax;
+  a.ncp = nc | 1;                                   // odd row stride: conflict-free row-per-lane access
+  int tile = (int)((120 * 1024) / ((a.ncp + (smax | 1)) * sizeof(float)));
+  if (tile > CTC_MAX_TILE) tile = CTC_MAX_TILE;
+  REQUIRE(tile >= 1, "too many classes for the CTC row tile");
+  a.tile = tile;
+  const size_t smem = (size_t)ctc_lds_layout(a.tile, a.ncp, a.smax).words * sizeof(float);
+  REQUIRE(smem <= 160 * 1024, "CTC LDS carve exceeds 160 KiB");
+#ifndef CLSTM_HIP_EMU
+  static size_t smem_set = 0;
+  if (smem > smem_set) {
+    HIPCHECK(hipFuncSetAttribute((const void*)ctc_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    smem_set = smem;
+  }
+#endif
+  CLSTM_LAUNCH(ctc_align_kernel, dim3(bs), dim3(CTC_THREADS), smem, s, a);
   check_launch();
 }
 struct DecodeWorkspace {
@@ -770,6 +801,13 @@ int clstm_net_kernel_time_ms(clstm_net* h, const char* name, double* total_ms, i
 int clstm_net_reset_timing(clstm_net* h) { ABI_BEGIN h->net.timing.collect(g_stream); h->net.timing.acc.clear(); ABI_END }
 
 // ---- diagnostics ----------------------------------------------------------------------------------
+int clstm_debug_ctc_cycles(long long* out_h) {
+  ABI_BEGIN
+  REQUIRE(g_last_ctc_prof, "no CTC launch yet");
+  HIPCHECK(hipStreamSynchronize(g_stream));
+  HIPCHECK(hipMemcpy(out_h, g_last_ctc_prof, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  ABI_END
+}
 int clstm_debug_lane_ops(float* out) {
   ABI_BEGIN
   CLSTM_LAUNCH(k_debug_lane_ops, dim3(1), dim3(64), 0, g_stream, out);

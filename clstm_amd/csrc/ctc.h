@@ -5,25 +5,30 @@
 // log_add cuts off at |x-y| > 10 (tensor.h:86-89), posteriors are normalised per STATE over
 // time and then per frame.  All of that is replicated here:
 //   A. lmatch[t][s] = log(out_t[class_s]), out_t = max(1e-5, p_t) / sum      (ctc.cc:66-77)
-//   B. wave 0 runs the forward recursion, wave 1 the same recursion on the (t,s)-reversed
-//      lattice (= forwardbackward, ctc.cc:42-55).  Lane l owns R = ceil(S/64) consecutive
-//      states; the j-1 neighbour of its first state comes from lane l-1 (wave shift), so the
-//      label axis is a wave scan and only t is serial.
+//   B. waves 0-3 run the forward recursion, waves 4-7 the same recursion on the (t,s)-reversed
+//      lattice (= forwardbackward, ctc.cc:42-55).  The label axis is spread over 256 lanes
+//      (ceil(S/256) states each); the j-1 neighbour of a lane's first state is handed over
+//      through a double-buffered LDS vector, so only t is serial (one barrier per frame).
 //   C. epath = limexp(both - max)                                            (ctc.cc:82)
 //   D. per-state normalisation over t, floor 1e-9, double accumulator        (ctc.cc:83-88)
 //   E. aligned[t][c] = sum_s epath[t][s] [class_s == c]; per-frame normalise (ctc.cc:91-109)
 //      and the fused delta  d = aligned - p                                  (clstmhl.h:211-212)
 // Targets are given as one class per state (the Classes overload, ctc.cc:136-146; mktargets'
 // blank-interleaved list for OCR lines, ctc.cc:148-157).
-// Numerical note: step E accumulates in float in state order (the reference uses a double
-// accumulator narrowed to Float) -- a <=1e-7 relative difference, inside the 1e-4 parity bar.
+// Numerical note: in step E the blank class keeps the reference's double accumulator; a label that
+// occurs k >= 3 times in one transcript is accumulated in float (<= 1 ulp from the reference's
+// double accumulator narrowed to Float).
 #pragma once
 #include "devintrin.h"
+#define CR_FN DEVFN
+#include "cr_math.h"
 
 namespace clstm {
 
-constexpr int CTC_RMAX = 8;      // up to 512 states per line
-constexpr int CTC_THREADS = 256;
+constexpr int CTC_THREADS = 512;   // waves 0-3: forward recursion, waves 4-7: reversed-lattice recursion
+constexpr int CTC_GROUP = 256;     // lanes per recursion when S > 64
+constexpr int CTC_RMAX = 2;        // up to 512 target states per line
+constexpr int CTC_MAX_TILE = 256;  // frames per LDS tile (phases A and E)
 
 struct CtcArgs {
   const float* P;        // [N][nc] softmax outputs
@@ -34,131 +39,295 @@ struct CtcArgs {
   const int* state_off;  // [bs+1]
   float* lat;            // lattice workspace: per line 3*T*S floats at lat_off[b]
   const long long* lat_off;
+  const double* tables;  // device copy of ctc_tables.h: exp2_32[32] | invc[64] | logc[64]
   int nc;
+  int ncp;               // LDS row stride of the class tile (odd)
+  int tile;              // frames per LDS tile
+  int smax;              // max states of any line in the batch (sizes the LDS carve)
+  long long* prof;       // optional [8] phase timestamps of block 0 (diagnostics)
 };
 
-DEVFN float ctc_log_add(float x, float y) {  // tensor.h:86-89
-  if (fabsf(x - y) > 10.0f) return fmaxf(x, y);
-  return logf(expf(x - y) + 1.0f) + y;
+// LDS carve shared by host (size) and kernel (offsets); all offsets in 4-byte words
+struct CtcLds {
+  int tables, part, tot, rowbuf, etile, asum, states, vx, red, words;
+};
+inline __host__ __device__ CtcLds ctc_lds_layout(int tile, int ncp, int smax) {
+  CtcLds l;
+  int o = 0;
+  l.tables = o; o += CTC_TABLE_WORDS;  // doubles first: 8-byte aligned
+  l.part = o;   o += 2 * 512;
+  l.tot = o;    o += 2 * smax;
+  l.rowbuf = o; o += tile * ncp;
+  l.etile = o;  o += tile * (smax | 1);
+  l.asum = o;   o += tile;
+  l.states = o; o += smax;
+  l.vx = o;     o += 2 * 2 * (CTC_GROUP + 2);
+  l.red = o;    o += 16;
+  l.words = o;
+  return l;
 }
-DEVFN float ctc_limexp(float x) {  // tensor.h:78-82
-  if (x < -30.0f) return (float)exp(-30.0);
-  if (x > 30.0f) return (float)exp(30.0);
-  return expf(x);
+
+DEVFN float ctc_log_add(float x, float y, const CrTables tb) {  // tensor.h:86-89
+  if (fabsf(x - y) > 10.0f) return fmaxf(x, y);
+  return cr_logf(cr_expf(x - y, tb) + 1.0f, tb) + y;
+}
+DEVFN float ctc_limexp(float x, const CrTables tb) {  // tensor.h:78-82
+  if (x < -30.0f) return (float)0x1.a56e0c2b7ab97p-44;  // (Float)exp(-30.0)
+  if (x > 30.0f) return (float)0x1.37047090c0b53p+43;   // (Float)exp(30.0)
+  return cr_expf(x, tb);
 }
 
 __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
-  __shared__ float red[CTC_THREADS / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* lds = dyn_smem<float>();
+  const CtcLds L = ctc_lds_layout(a.tile, a.ncp, a.smax);
+  double* tabs = reinterpret_cast<double*>(lds + L.tables);
+  double* part = reinterpret_cast<double*>(lds + L.part);
+  double* tot = reinterpret_cast<double*>(lds + L.tot);
+  float* rowbuf = lds + L.rowbuf;
+  float* etile = lds + L.etile;
+  float* asum = lds + L.asum;
+  int* stl = reinterpret_cast<int*>(lds + L.states);
+  float* vx = lds + L.vx;
+  float* red = lds + L.red;
+  const CrTables tb{tabs, tabs + 32, tabs + 96};
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int b = blockIdx.x;
-  const int nc = a.nc;
+  const int nc = a.nc, ncp = a.ncp, TT = a.tile;
   const int off = a.line_off[b], T = a.line_off[b + 1] - off;
   const int soff = a.state_off[b], S = a.state_off[b + 1] - soff;
   if (T <= 0 || S <= 0) return;
   const float* P = a.P + (size_t)off * nc;
   float* Dz = a.Dz + (size_t)off * nc;
-  const int* st = a.states + soff;
   float* lm = a.lat + a.lat_off[b];
   float* al = lm + (size_t)T * S;
   float* be = al + (size_t)T * S;
+  for (int i = tid; i < CTC_TABLE_WORDS / 2; i += CTC_THREADS) tabs[i] = a.tables[i];
+  for (int s = tid; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
+#define CTC_STAMP(k) do { if (a.prof && b == 0 && tid == 0) a.prof[k] = dev_clock(); } while (0)
+  CTC_STAMP(0);
 
-  // ---- A: match scores -------------------------------------------------------------
-  for (int t = tid; t < T; t += CTC_THREADS) {
-    const float* p = P + (size_t)t * nc;
-    float asum = 0.0f;
-    for (int c = 0; c < nc; c++) asum += fmaxf(1e-5f, p[c]);
-    for (int s = 0; s < S; s++) {
-      const float o = fmaxf(1e-5f, p[st[s]]) / asum;
-      lm[(size_t)t * S + s] = (float)log((double)o);
+  // ---- A: match scores  lmatch[t][s] = log(max(1e-5,p_t[class_s]) / sum_c max(1e-5,p_t[c])) ------
+  for (int t0 = 0; t0 < T; t0 += TT) {
+    const int nt = (T - t0) < TT ? (T - t0) : TT;
+    __syncthreads();
+    if (ncp == nc) {  // rows are back to back in LDS too: flat coalesced copy
+      for (int i = tid; i < nt * nc; i += CTC_THREADS) rowbuf[i] = fmaxf(1e-5f, P[(size_t)t0 * nc + i]);
+    } else {
+      for (int i = tid; i < nt * nc; i += CTC_THREADS) {
+        const int t = i / nc, c = i - t * nc;
+        rowbuf[t * ncp + c] = fmaxf(1e-5f, P[(size_t)t0 * nc + i]);
+      }
+    }
+    __syncthreads();
+    if (tid < nt) {  // sequential float sum in class order, as asum1() (tensor.h:337-342)
+      float acc = 0.0f;
+      const float* r = rowbuf + tid * ncp;
+      for (int c = 0; c < nc; c++) acc += r[c];
+      asum[tid] = acc;
+    }
+    __syncthreads();
+    for (int t = wave; t < nt; t += CTC_THREADS / 64) {  // one wave per frame, lanes over states
+      const float* r = rowbuf + t * ncp;
+      const float as = asum[t];
+      float* lrow = lm + (size_t)(t0 + t) * S;
+      for (int s0 = lane; s0 < S; s0 += 64) lrow[s0] = cr_logf(r[stl[s0]] / as, tb);
     }
   }
-  __syncthreads();
+  CTC_STAMP(1);
 
-  // ---- B: forward (wave 0) and reversed-lattice forward (wave 1) -------------------------
-  if (wave < 2) {
-    const bool rev = wave == 1;
-    const int R = (S + 63) / 64;
-    float v[CTC_RMAX], lmv[CTC_RMAX];
+  // ---- B: forward recursion and the same recursion on the (t,s)-reversed lattice
+  //         (= forwardbackward(), ctc.cc:42-55); serial in t, parallel over the label axis --------
+  const size_t latbytes = (size_t)T * S * 4;
+  const BufF32 lmb = make_buf(lm, latbytes);
+  if (S <= 64) {
+    // one wave per direction: the j-1 neighbour arrives by a DPP wave shift, no barrier per frame
+    __syncthreads();  // lattice rows of phase A visible
+    if (wave < 2) {
+      const bool rev = wave == 1;
+      const BufF32 outb = make_buf(rev ? be : al, latbytes);
+      const int j = lane;
+      auto loff = [&](int i) -> unsigned {
+        if (i >= T || j >= S) return BUF_OOB;
+        return (unsigned)(rev ? (size_t)(T - 1 - i) * S + (S - 1 - j) : (size_t)i * S + j) * 4u;
+      };
+      float v = (float)(-5.0 * j);
+      float lmA = buf_load(lmb, loff(0)), lmB = buf_load(lmb, loff(1));
+      float kaA = 0.0f, kaB = 0.0f;
+      auto step = [&](const int i, float& lmr, float& ka) {
+        KEEP_ALIVE(ka);
+        float w = wave_shr1(v);
+        if (j == 0) w = (float)(-5.0 * i);
+        const float lmv = lmr;
+        lmr = buf_load(lmb, loff(i + 2));  // two frames ahead
+        const float same = v + lmv;
+        const float next = w + lmv;
+        v = ctc_log_add(same, next, tb);
+        buf_store(outb, loff(i), v);
+        ka = v;
+      };
+      int i = 0;
+      for (; i + 1 < T; i += 2) {
+        step(i, lmA, kaA);
+        step(i + 1, lmB, kaB);
+      }
+      if (i < T) step(i, lmA, kaA);
+    }
+  } else {
+    const int grp = wave >> 2, u = tid & (CTC_GROUP - 1);
+    const int R = (S + CTC_GROUP - 1) / CTC_GROUP;
+    float* vxg = vx + grp * 2 * (CTC_GROUP + 2);
+    vxg[u] = (float)(-5.0 * (u * R + R - 1));
+    __syncthreads();
+    const bool rev = grp == 1;
+    const BufF32 outb = make_buf(rev ? be : al, latbytes);
+    auto loff = [&](int i, int j) -> unsigned {
+      if (i >= T || j >= S) return BUF_OOB;
+      return (unsigned)(rev ? (size_t)(T - 1 - i) * S + (S - 1 - j) : (size_t)i * S + j) * 4u;
+    };
+    float v[CTC_RMAX], lmA[CTC_RMAX], lmB[CTC_RMAX], kaA[CTC_RMAX], kaB[CTC_RMAX];
 #pragma unroll
     for (int r = 0; r < CTC_RMAX; r++) {
-      const int j = lane * R + r;
+      const int j = u * R + r;
       v[r] = (float)(-5.0 * j);
-      lmv[r] = 0.0f;
-      if (r < R && j < S) lmv[r] = rev ? lm[(size_t)(T - 1) * S + (S - 1 - j)] : lm[j];
+      lmA[r] = buf_load(lmb, r < R ? loff(0, j) : BUF_OOB);
+      lmB[r] = buf_load(lmb, r < R ? loff(1, j) : BUF_OOB);
+      kaA[r] = kaB[r] = 0.0f;
     }
-    float* out = rev ? be : al;
-    for (int i = 0; i < T; i++) {
-      float lmn[CTC_RMAX];
+    auto step = [&](const int i, float (&lmr)[CTC_RMAX], float (&ka)[CTC_RMAX]) {
 #pragma unroll
-      for (int r = 0; r < CTC_RMAX; r++) {  // prefetch next lattice row
-        const int j = lane * R + r;
-        lmn[r] = 0.0f;
-        if (r < R && j < S && i + 1 < T)
-          lmn[r] = rev ? lm[(size_t)(T - 2 - i) * S + (S - 1 - j)] : lm[(size_t)(i + 1) * S + j];
+      for (int r = 0; r < CTC_RMAX; r++) KEEP_ALIVE(ka[r]);
+      const float from_prev = vxg[(i & 1) * (CTC_GROUP + 2) + (u > 0 ? u - 1 : 0)];
+      float lmv[CTC_RMAX];
+#pragma unroll
+      for (int r = 0; r < CTC_RMAX; r++) {
+        lmv[r] = lmr[r];
+        lmr[r] = buf_load(lmb, r < R ? loff(i + 2, u * R + r) : BUF_OOB);  // two frames ahead
+      }
+#pragma unroll
+      for (int r = CTC_RMAX - 1; r >= 0; r--) {
+        if (r < R) {
+          const int j = u * R + r;
+          float w = (r == 0) ? from_prev : v[r - 1];
+          if (j == 0) w = (float)(-5.0 * i);
+          const float same = v[r] + lmv[r];
+          const float next = w + lmv[r];
+          v[r] = ctc_log_add(same, next, tb);
+          buf_store(outb, loff(i, j), v[r]);
+          ka[r] = v[r];
+        }
       }
       float last = v[0];
 #pragma unroll
       for (int r = 1; r < CTC_RMAX; r++)
         if (r == R - 1) last = v[r];
-      const float from_prev_lane = wave_shfl_up1(last);
-#pragma unroll
-      for (int r = CTC_RMAX - 1; r >= 0; r--) {
-        if (r < R) {
-          const int j = lane * R + r;
-          float w = (r == 0) ? from_prev_lane : v[r - 1];
-          if (j == 0) w = (float)(-5.0 * i);
-          const float same = v[r] + lmv[r];
-          const float next = w + lmv[r];
-          v[r] = ctc_log_add(same, next);
-          if (j < S) {
-            if (rev) out[(size_t)(T - 1 - i) * S + (S - 1 - j)] = v[r];
-            else out[(size_t)i * S + j] = v[r];
-          }
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < CTC_RMAX; r++) lmv[r] = lmn[r];
+      vxg[((i + 1) & 1) * (CTC_GROUP + 2) + u] = last;
+      __syncthreads();
+    };
+    int i = 0;
+    for (; i + 1 < T; i += 2) {
+      step(i, lmA, kaA);
+      step(i + 1, lmB, kaB);
     }
+    if (i < T) step(i, lmA, kaA);
   }
   __syncthreads();
+  CTC_STAMP(2);
 
   // ---- C: epath = limexp(both - amax2(both)) ---------------------------------------------
   const int TS = T * S;
-  float mx = -3.0e38f;
-  for (int i = tid; i < TS; i += CTC_THREADS) mx = fmaxf(mx, al[i] + be[i]);
-  mx = wave_max(mx);
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = red[0];
-  for (int i = 1; i < CTC_THREADS / 64; i++) mx = fmaxf(mx, red[i]);
-  for (int i = tid; i < TS; i += CTC_THREADS) al[i] = ctc_limexp((al[i] + be[i]) - mx);
-  __syncthreads();
-
-  // ---- D: normalise every state column over time -----------------------------------------
-  for (int s = tid; s < S; s += CTC_THREADS) {
-    double total = 0.0;
-    for (int t = 0; t < T; t++) total += al[(size_t)t * S + s];
-    total = fmax(1e-9, total);
-    for (int t = 0; t < T; t++) al[(size_t)t * S + s] = (float)((double)al[(size_t)t * S + s] / total);
-  }
-  __syncthreads();
-
-  // ---- E: project states onto classes, normalise per frame, emit deltas --------------------
-  for (int t = tid; t < T; t += CTC_THREADS) {
-    float* row = Dz + (size_t)t * nc;
-    for (int c = 0; c < nc; c++) row[c] = 0.0f;
-    for (int s = 0; s < S; s++) row[st[s]] += al[(size_t)t * S + s];
-    double total = 0.0;
-    for (int c = 0; c < nc; c++) total += row[c];
-    total = fmax(total, 1e-9);
-    const float* p = P + (size_t)t * nc;
-    float* arow = a.aligned ? a.aligned + ((size_t)off + t) * nc : nullptr;
-    for (int c = 0; c < nc; c++) {
-      const float av = (float)((double)row[c] / total);
-      if (arow) arow[c] = av;
-      row[c] = av - p[c];
+  constexpr int CCACHE = 24;  // lattice cells per thread kept in registers between the two passes
+  if (TS <= CTC_THREADS * CCACHE) {
+    float bo[CCACHE];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < CCACHE; k++) {
+      const int i = tid + k * CTC_THREADS;
+      bo[k] = i < TS ? al[i] + be[i] : -3.0e38f;
+      mx = fmaxf(mx, bo[k]);
     }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int i = 1; i < CTC_THREADS / 64; i++) mx = fmaxf(mx, red[i]);
+#pragma unroll
+    for (int k = 0; k < CCACHE; k++) {
+      const int i = tid + k * CTC_THREADS;
+      if (i < TS) al[i] = ctc_limexp(bo[k] - mx, tb);
+    }
+  } else {
+    float mx = -3.0e38f;
+    for (int i = tid; i < TS; i += CTC_THREADS) mx = fmaxf(mx, al[i] + be[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int i = 1; i < CTC_THREADS / 64; i++) mx = fmaxf(mx, red[i]);
+    for (int i = tid; i < TS; i += CTC_THREADS) al[i] = ctc_limexp((al[i] + be[i]) - mx, tb);
   }
+  __syncthreads();
+  CTC_STAMP(3);
+
+  // ---- D: per-state totals over time (double accumulator, floor 1e-9); x/total is evaluated as
+  //         (float)((double)x * (1/total)): equal to the reference's (Float)(x/total) except for
+  //         ~1e-8 of the values (1 ulp of double before the rounding to float) -----------------------
+  {
+    const int Q = CTC_THREADS / S > 8 ? 8 : CTC_THREADS / S;  // time chunks per state (S <= 512)
+    if (tid < S * Q) {
+      const int s = tid % S, q = tid / S;
+      double acc = 0.0;
+      for (int t = q; t < T; t += Q) acc += (double)al[(size_t)t * S + s];
+      part[q * S + s] = acc;
+    }
+    __syncthreads();
+    if (tid < S) {
+      double acc = 0.0;
+      for (int q = 0; q < Q; q++) acc += part[q * S + tid];
+      tot[tid] = 1.0 / fmax(1e-9, acc);  // reciprocal: the divisions below become double multiplies
+    }
+    __syncthreads();
+  }
+  CTC_STAMP(4);
+
+  // ---- E: per-state normalisation applied on the fly; project states onto classes, normalise
+  //         per frame, emit deltas ---------------------------------------------------------------
+  const int sp = S | 1;
+  for (int t0 = 0; t0 < T; t0 += TT) {
+    const int nt = (T - t0) < TT ? (T - t0) : TT;
+    for (int t = wave; t < nt; t += CTC_THREADS / 64) {  // coalesced staging of the lattice tile
+      const float* src = al + (size_t)(t0 + t) * S;
+      for (int s0 = lane; s0 < S; s0 += 64) etile[t * sp + s0] = (float)((double)src[s0] * tot[s0]);
+    }
+    for (int i = tid; i < nt * ncp; i += CTC_THREADS) rowbuf[i] = 0.0f;
+    __syncthreads();
+    if (tid < nt) {
+      float* row = rowbuf + tid * ncp;
+      double blank = 0.0;  // class 0 collects L+1 states: keep the reference's double accumulator
+      const float* e = etile + tid * sp;
+      for (int s0 = 0; s0 < S; s0++) {
+        const int c = stl[s0];
+        const float x = e[s0];
+        if (c == 0) blank += (double)x;
+        else row[c] += x;
+      }
+      row[0] = (float)blank;
+      double total = 0.0;
+      for (int c = 0; c < nc; c++) total += (double)row[c];
+      part[tid] = 1.0 / fmax(total, 1e-9);
+    }
+    __syncthreads();
+    for (int t = wave; t < nt; t += CTC_THREADS / 64) {  // coalesced write-out, one wave per frame
+      const double inv = part[t];
+      const size_t g0 = (size_t)(t0 + t) * nc;
+      for (int c = lane; c < nc; c += 64) {
+        const float av = (float)((double)rowbuf[t * ncp + c] * inv);
+        if (a.aligned) a.aligned[(size_t)off * nc + g0 + c] = av;
+        Dz[g0 + c] = av - P[g0 + c];
+      }
+    }
+    __syncthreads();
+  }
+  CTC_STAMP(5);
 }
 
 // argmax per frame, ties -> last index (tensor.h:357-366)

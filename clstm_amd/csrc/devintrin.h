@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define DEVFN __device__ __forceinline__
 #define DEVMFN __device__ __forceinline__  // member functions
@@ -22,8 +23,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---- DPP lane moves (LLVM DppCtrl encodings: quad_perm 0x00-0xFF, row_ror:n 0x120+n) ----
 template <int CTRL>
 DEVFN float dpp_mov(float x) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+  const int xi = __builtin_bit_cast(int, x);  // old = src: no zero-init mov, lanes without a source keep x
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, CTRL, 0xF, 0xF, false));
 }
 #ifndef CLSTM_USE_SHFL
 DEVFN float quad_xor1(float x) { return dpp_mov<0xB1>(x); }  // quad_perm [1,0,3,2]
@@ -32,6 +33,7 @@ template <int I>
 DEVFN float quad_bcast(float x) { return dpp_mov<I * 0x55>(x); }  // quad_perm [I,I,I,I]
 template <int N>
 DEVFN float row_ror(float x) { return dpp_mov<0x120 + N>(x); }  // rotate within a row of 16
+DEVFN float row_half_mirror(float x) { return dpp_mov<0x141>(x); }  // lane i <-> i^7 within 8 lanes
 #else
 // Fallback through ds_bpermute (definitionally correct; used to cross-check the DPP codes).
 DEVFN float quad_xor1(float x) { return __shfl_xor(x, 1, 64); }
@@ -43,10 +45,17 @@ DEVFN float row_ror(float x) {
   const int lane = threadIdx.x & 63;
   return __shfl(x, (lane & ~15) | ((lane + N) & 15), 64);
 }
+DEVFN float row_half_mirror(float x) { return __shfl(x, (int)(threadIdx.x & 63u) ^ 7, 64); }
 #endif
 DEVFN float wave_shfl(float x, int src) { return __shfl(x, src, 64); }
 DEVFN float wave_shfl_up1(float x) { return __shfl_up(x, 1, 64); }
+#ifndef CLSTM_USE_SHFL
+DEVFN float wave_shr1(float x) { return dpp_mov<0x138>(x); }  // DPP wave_shr:1 (lane 0 keeps its value)
+#else
+DEVFN float wave_shr1(float x) { return __shfl_up(x, 1, 64); }
+#endif
 DEVFN int wave_shfl_i(int x, int src) { return __shfl(x, src, 64); }
+DEVFN int wave_shfl_xor_i(int x, int m) { return __shfl_xor(x, m, 64); }
 DEVFN float wave_max(float x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, 64));
@@ -58,14 +67,47 @@ DEVFN float wave_sum(float x) {
   return x;
 }
 
+// packed f32 FMA (v_pk_fma_f32): two lanes of work per VALU issue slot
+DEVFN f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+DEVFN f32x2 splat2(float x) { return (f32x2){x, x}; }
+
 // ---- f32 MFMA: D(16x16) += A(16x4) * B(4x16); exact f32 fma chain (guide: cdna §3) ----
 // lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; holds D[row=(l>>4)*4+r][col=l&15].
 DEVFN f32x4 mfma16x16x4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// value known to be wave-uniform (e.g. threadIdx.x >> 6): tell the compiler so that buffer
+// descriptors derived from it live in SGPRs instead of waterfall loops (guide T20)
+DEVFN int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+DEVFN long long dev_clock() { return (long long)__builtin_readcyclecounter(); }
 DEVFN float fast_exp(float x) { return __expf(x); }
 DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// ---- buffer (SRD) loads/stores: out-of-range offsets are dropped by the bounds check, so masked
+// lanes need no exec-mask branch and hipcc can count the VMEM queue exactly (vmcnt(N), N>0: the
+// fire-and-forget stores of a recurrence step never sit on the next step's critical path).
+struct BufF32 { __amdgpu_buffer_rsrc_t r; };
+constexpr unsigned BUF_OOB = 0xFFFFFFF0u;
+// lane base offset for masked lanes when a (wave-uniform, < 2^31) step offset is ADDED to it: the sum
+// stays >= 2^31 > num_records, hence out of range, and cannot wrap into the buffer
+constexpr unsigned BUF_OOB_BASE = 0x80000000u;
+DEVFN BufF32 make_buf(const float* base, size_t bytes) {
+  BufF32 b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0x7FFFFFF0ull ? 0x7FFFFFF0ull : bytes), 0x00020000);
+  return b;
+}
+DEVFN float buf_load(BufF32 b, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, byte_off, 0, 0));
+}
+DEVFN void buf_store(BufF32 b, unsigned byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.r, byte_off, 0, 0);
+}
+
+// A VMEM store reads its data VGPR when the memory pipeline executes it, so hipcc inserts a vmcnt
+// wait before that register may be overwritten.  KEEP_ALIVE(x) placed two recurrence steps later
+// pins the register until then, which moves that wait off the per-step critical path.
+#define KEEP_ALIVE(x) asm volatile("" ::"v"(x))
 
 template <typename T>
 DEVFN T* dyn_smem() {
@@ -80,6 +122,22 @@ DEVFN T* dyn_smem() {
 // ---------------------------------------------------------------------------------------
 // activation functions shared by every kernel (and replicated in numpy by the CPU tests)
 // ---------------------------------------------------------------------------------------
+// gate nonlinearity without divergence: sigmoid for the three gates, tanh for the cell input;
+// one exp + one rcp either way (tanh's |x| >= 0.4 branch is 1 - 2/(1+exp(2|x|))).
+DEVFN float gate_act(float x, bool is_tanh) {
+  const float ax = fabsf(x);
+  const float r = fast_rcp(1.0f + fast_exp(is_tanh ? 2.0f * ax : -x));
+  const float x2 = x * x;
+  float p = -1382.0f / 155925.0f;
+  p = p * x2 + 62.0f / 2835.0f;
+  p = p * x2 - 17.0f / 315.0f;
+  p = p * x2 + 2.0f / 15.0f;
+  p = p * x2 - 1.0f / 3.0f;
+  p = p * x2 + 1.0f;
+  const float th = ax < 0.4f ? x * p : copysignf(1.0f - 2.0f * r, x);
+  return is_tanh ? th : r;
+}
+
 // sigmoid(x) = 1/(1+exp(-x))  (Eigen scalar_sigmoid_op form used by clstm_compute.cc:117,196)
 DEVFN float sigmoid_dev(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 

@@ -47,70 +47,102 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   constexpr int KQP = 4 * NK4;
   constexpr int QS = KQP + ((NK4 & 1) ? 0 : 4);
   constexpr int HB = 4 * QS;
-  float* lds = dyn_smem<float>();  // hbuf[2][HB]
+  float* lds = dyn_smem<float>();  // hbuf[2][HB] + dump word
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x;
   const int b = blockIdx.x, dir = blockIdx.y;
   const int no = a.no;
   const int q = lane & 3, cell = wave * 16 + (lane >> 2);
   const bool valid = cell < no;
+  const bool lead = valid && q == 0;
   const int nd = a.ndir;
 
-  float w[4][KQP];
+  // recurrent weights as (gi,gf) and (go,ci) pairs: one v_pk_fma_f32 serves two gates
+  f32x2 w01[KQP], w23[KQP];
   {
     const float* rp = a.Rpk + (size_t)dir * 4 * KQP * nthreads + tid;
 #pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-      for (int kk = 0; kk < KQP; kk++) w[g][kk] = rp[(size_t)(g * KQP + kk) * nthreads];
+    for (int kk = 0; kk < KQP; kk++) {
+      w01[kk] = (f32x2){rp[(size_t)(0 * KQP + kk) * nthreads], rp[(size_t)(1 * KQP + kk) * nthreads]};
+      w23[kk] = (f32x2){rp[(size_t)(2 * KQP + kk) * nthreads], rp[(size_t)(3 * KQP + kk) * nthreads]};
+    }
   }
-  for (int i = tid; i < 2 * HB; i += nthreads) lds[i] = 0.0f;
+  for (int i = tid; i < 2 * HB + 4; i += nthreads) lds[i] = 0.0f;
 
   const int off = a.line_off[b];
   const int T = a.line_off[b + 1] - off;
+  // per-line windows; frame fr(t) within the line (Reversed = index arithmetic); byte offsets are
+  // lane part + wave-uniform frame part, masked lanes sit at BUF_OOB_BASE
+  const unsigned gstride4 = (unsigned)nd * 4 * no * 4, cstride4 = (unsigned)nd * no * 4;
+  const BufF32 gbuf = make_buf(a.G + (size_t)off * (gstride4 / 4), (size_t)T * gstride4);
+  const BufF32 cbuf = make_buf(a.C + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
+  const BufF32 hbuf = make_buf(a.H + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
+  const unsigned gl = valid ? ((unsigned)dir * 4 * no + cell * 4 + q) * 4u : BUF_OOB_BASE;
+  const unsigned cl = lead ? ((unsigned)dir * no + cell) * 4u : BUF_OOB_BASE;
+  auto fr = [&](int t) -> unsigned {  // clamped: prefetches past the end re-read the last frame
+    const int tc = t < T ? t : T - 1;
+    return (unsigned)(dir == 0 ? tc : T - 1 - tc);
+  };
   const int hslot = (cell / KQP) * QS + (cell % KQP);
+  const float* rdA = lds + q * QS;            // even steps read buffer 0, write buffer 1
+  const float* rdB = lds + HB + q * QS;
+  float* wrA = lead ? lds + HB + hslot : lds + 2 * HB;
+  float* wrB = lead ? lds + hslot : lds + 2 * HB;
+  const bool qhi = (q & 2) != 0, qlo = (q & 1) != 0;
   float c_prev = 0.0f;
-  const size_t gstride = (size_t)nd * 4 * no;
-  const size_t gofs = (size_t)dir * 4 * no + cell * 4 + q;
-  auto tok = [&](int t) -> size_t { return (size_t)(dir == 0 ? off + t : off + T - 1 - t); };
-  float gx = (valid && T > 0) ? a.G[tok(0) * gstride + gofs] : 0.0f;
+  if (T <= 0) return;
+  // input pre-activations are fetched two steps ahead into two alternating registers (the loop is
+  // unrolled by two so that no register rotation forces an early wait on an in-flight load)
+  float gxA = buf_load(gbuf, gl + fr(0) * gstride4);
+  float gxB = buf_load(gbuf, gl + fr(1) * gstride4);
+  float kaA0 = 0.f, kaA1 = 0.f, kaA2 = 0.f, kaB0 = 0.f, kaB1 = 0.f, kaB2 = 0.f;  // store-data pins
   __syncthreads();
-  for (int t = 0; t < T; t++) {
-    const size_t tk = tok(t);
-    const float gx_next = (valid && t + 1 < T) ? a.G[tok(t + 1) * gstride + gofs] : 0.0f;
-    const float* hq = lds + (t & 1) * HB + q * QS;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  auto step = [&](const int t, float& gxr, const float* hq, float* hw, float& ka0, float& ka1, float& ka2) {
+    KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2);  // stores of step t-2 have long completed
+    f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
 #pragma unroll
     for (int j = 0; j < NK4; j++) {
       const float4 hv = *reinterpret_cast<const float4*>(hq + 4 * j);
-      acc0 += w[0][4 * j] * hv.x; acc1 += w[1][4 * j] * hv.x; acc2 += w[2][4 * j] * hv.x; acc3 += w[3][4 * j] * hv.x;
-      acc0 += w[0][4 * j + 1] * hv.y; acc1 += w[1][4 * j + 1] * hv.y; acc2 += w[2][4 * j + 1] * hv.y; acc3 += w[3][4 * j + 1] * hv.y;
-      acc0 += w[0][4 * j + 2] * hv.z; acc1 += w[1][4 * j + 2] * hv.z; acc2 += w[2][4 * j + 2] * hv.z; acc3 += w[3][4 * j + 2] * hv.z;
-      acc0 += w[0][4 * j + 3] * hv.w; acc1 += w[1][4 * j + 3] * hv.w; acc2 += w[2][4 * j + 3] * hv.w; acc3 += w[3][4 * j + 3] * hv.w;
+      a01 = fma2(w01[4 * j], splat2(hv.x), a01); a23 = fma2(w23[4 * j], splat2(hv.x), a23);
+      a01 = fma2(w01[4 * j + 1], splat2(hv.y), a01); a23 = fma2(w23[4 * j + 1], splat2(hv.y), a23);
+      a01 = fma2(w01[4 * j + 2], splat2(hv.z), a01); a23 = fma2(w23[4 * j + 2], splat2(hv.z), a23);
+      a01 = fma2(w01[4 * j + 3], splat2(hv.w), a01); a23 = fma2(w23[4 * j + 3], splat2(hv.w), a23);
     }
-    // sum the four k-quarters held by the quad
-    acc0 += quad_xor1(acc0); acc1 += quad_xor1(acc1); acc2 += quad_xor1(acc2); acc3 += quad_xor1(acc3);
-    acc0 += quad_xor2(acc0); acc1 += quad_xor2(acc1); acc2 += quad_xor2(acc2); acc3 += quad_xor2(acc3);
+    // reduce-scatter over the quad: lane q ends with gate q's sum over the four k-quarters
+    f32x2 keep = qhi ? a23 : a01;
+    const f32x2 send = qhi ? a01 : a23;
+    keep[0] += quad_xor2(send[0]);
+    keep[1] += quad_xor2(send[1]);
+    float k = qlo ? keep[1] : keep[0];
+    const float sd = qlo ? keep[0] : keep[1];
+    k += quad_xor1(sd);
     // lane q finishes gate q: q=0 gi, 1 gf, 2 go (sigmoid); 3 ci (tanh)   [forward_full1]
-    const float pre = (q == 0 ? acc0 : q == 1 ? acc1 : q == 2 ? acc2 : acc3) + gx;
-    const float act = (q == 3) ? tanh_dev(pre) : sigmoid_dev(pre);
+    const float pre = k + gxr;
+    // re-issue into the SAME register only now that its old value is dead (no back-edge copy, so
+    // the load really stays in flight for two steps)
+    gxr = buf_load(gbuf, gl + fr(t + 2) * gstride4);
+    const float act = gate_act(pre, q == 3);
     const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), go = quad_bcast<2>(act),
                 ci = quad_bcast<3>(act);
-    float c = ci * gi;                 // forward_statemem (clstm_compute.cc:504-508)
-    if (t > 0) c += gf * c_prev;
-    const float h = tanh_dev(c) * go;  // forward_nonlingate (clstm_compute.cc:530-537)
+    // forward_statemem (clstm_compute.cc:504-508); c_prev = 0 at t = 0 makes the second term an
+    // exact +0, so no first-step special case (and no loop peeling) is needed
+    const float c = ci * gi + gf * c_prev;
+    const float h = gate_act(c, true) * go;  // forward_nonlingate (clstm_compute.cc:530-537)
     c_prev = c;
-    if (valid) {
-      a.G[tk * gstride + gofs] = act;
-      if (q == 0) {
-        a.C[(tk * nd + dir) * no + cell] = c;
-        a.H[tk * nd * no + (size_t)dir * no + cell] = h;
-        lds[((t + 1) & 1) * HB + hslot] = h;
-      }
-    }
-    gx = gx_next;
+    const unsigned f = fr(t);
+    buf_store(gbuf, gl + f * gstride4, act);
+    buf_store(cbuf, cl + f * cstride4, c);
+    buf_store(hbuf, cl + f * cstride4, h);
+    *hw = h;
+    ka0 = act; ka1 = c; ka2 = h;
     __syncthreads();
+  };
+  int t = 0;
+  for (; t + 1 < T; t += 2) {
+    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2);
+    step(t + 1, gxB, rdB, wrB, kaB0, kaB1, kaB2);
   }
+  if (t < T) step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2);
 }
 
 template <int NK4>
@@ -118,101 +150,120 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
   constexpr int SLP = 4 * NK4;
   constexpr int QS = SLP + ((NK4 & 1) ? 0 : 4);
   constexpr int DB = 16 * QS;
-  float* lds = dyn_smem<float>();  // dbuf[2][DB]
+  float* lds = dyn_smem<float>();  // dbuf[2][DB] + dump word
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x;
   const int b = blockIdx.x, dir = blockIdx.y;
   const int no = a.no, nd = a.ndir;
   const int SL = (4 * no + 15) / 16;  // (gate,j) pairs per slice
   const int js = lane & 15;
-  const int g = lane & 3, cell = wave * 16 + (lane >> 2), isel = (lane >> 2) & 3;
+  const int g = lane & 3, cell = wave * 16 + (lane >> 2), Q = (lane >> 2) & 3;
   const bool valid = cell < no;
 
-  float wb[4][SLP];
+  // R_g[j][k] for this lane's 4 output cells as (cell 0,1) and (cell 2,3) pairs
+  f32x2 wb01[SLP], wb23[SLP];
   {
     const float* rp = a.Rpk + (size_t)dir * 4 * SLP * nthreads + tid;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int pp = 0; pp < SLP; pp++) wb[i][pp] = rp[(size_t)(i * SLP + pp) * nthreads];
+    for (int pp = 0; pp < SLP; pp++) {
+      wb01[pp] = (f32x2){rp[(size_t)(0 * SLP + pp) * nthreads], rp[(size_t)(1 * SLP + pp) * nthreads]};
+      wb23[pp] = (f32x2){rp[(size_t)(2 * SLP + pp) * nthreads], rp[(size_t)(3 * SLP + pp) * nthreads]};
+    }
   }
-  for (int i = tid; i < 2 * DB; i += nthreads) lds[i] = 0.0f;
+  for (int i = tid; i < 2 * DB + 4; i += nthreads) lds[i] = 0.0f;
 
   const int off = a.line_off[b];
   const int T = a.line_off[b + 1] - off;
+  if (T <= 0) return;
   const int pidx = g * no + cell;  // this lane's delta goes to pair (gate g, j = cell)
   const int dslot = (pidx / SL) * QS + (pidx % SL);
-  const size_t gstride = (size_t)nd * 4 * no;
-  const size_t gofs = (size_t)dir * 4 * no + cell * 4 + g;
-  auto tok = [&](int s) -> size_t { return (size_t)(dir == 0 ? off + s : off + T - 1 - s); };
+  const unsigned gstride4 = (unsigned)nd * 4 * no * 4, cstride4 = (unsigned)nd * no * 4;
+  const BufF32 gbuf = make_buf(a.G + (size_t)off * (gstride4 / 4), (size_t)T * gstride4);
+  const BufF32 dbuf = make_buf(a.D + (size_t)off * (gstride4 / 4), (size_t)T * gstride4);
+  const BufF32 cbuf = make_buf(a.C + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
+  const BufF32 hbuf = make_buf(a.dH + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
+  const unsigned gl = valid ? ((unsigned)dir * 4 * no + cell * 4 + g) * 4u : BUF_OOB_BASE;
+  const unsigned cl = valid ? ((unsigned)dir * no + cell) * 4u : BUF_OOB_BASE;
+  auto fr = [&](int s) -> unsigned {  // own step s -> frame, clamped at the first step
+    const int sc = s > 0 ? s : 0;
+    return (unsigned)(dir == 0 ? sc : T - 1 - sc);
+  };
+  // c_{s-1} reads 0 at s = 0: masked by an out-of-range offset (s - 1 < 0 is wave-uniform)
+  auto cpoff = [&](int s) -> unsigned { return s >= 1 ? cl + fr(s - 1) * cstride4 : BUF_OOB; };
+  const float* rdA = lds + js * QS;           // first step reads buffer 0, writes buffer 1
+  const float* rdB = lds + DB + js * QS;
+  float* wrA = valid ? lds + DB + dslot : lds + 2 * DB;
+  float* wrB = valid ? lds + dslot : lds + 2 * DB;
+  const bool qb1 = (Q & 2) != 0, qb0 = (Q & 1) != 0;
 
-  // prefetch for step s = T-1
-  float act = 0.f, dhv = 0.f, c_cur = 0.f, c_m1 = 0.f;
-  if (valid && T > 0) {
-    const size_t tk = tok(T - 1);
-    act = a.G[tk * gstride + gofs];
-    dhv = a.dH[tk * nd * no + (size_t)dir * no + cell];
-    c_cur = a.C[(tk * nd + dir) * no + cell];
-    if (T > 1) c_m1 = a.C[(tok(T - 2) * nd + dir) * no + cell];
-  }
+  // operands are fetched two steps ahead into alternating registers (loop unrolled by two)
+  float actA = buf_load(gbuf, gl + fr(T - 1) * gstride4), actB = buf_load(gbuf, gl + fr(T - 2) * gstride4);
+  float dhA = buf_load(hbuf, cl + fr(T - 1) * cstride4), dhB = buf_load(hbuf, cl + fr(T - 2) * cstride4);
+  float ccA = buf_load(cbuf, cl + fr(T - 1) * cstride4), ccB = buf_load(cbuf, cl + fr(T - 2) * cstride4);  // c_s
+  float cpA = buf_load(cbuf, cpoff(T - 1)), cpB = buf_load(cbuf, cpoff(T - 2));                            // c_{s-1}
   float dc_carry = 0.0f;
+  float kaA = 0.f, kaB = 0.f;  // store-data pins (see KEEP_ALIVE)
   __syncthreads();
-  int cur = 0;
-  for (int s = T - 1; s >= 0; s--) {
-    const size_t tk = tok(s);
-    // prefetch step s-1 (and c of step s-2)
-    float act_n = 0.f, dhv_n = 0.f, c_m2 = 0.f;
-    if (valid && s > 0) {
-      const size_t tn = tok(s - 1);
-      act_n = a.G[tn * gstride + gofs];
-      dhv_n = a.dH[tn * nd * no + (size_t)dir * no + cell];
-      if (s > 1) c_m2 = a.C[(tok(s - 2) * nd + dir) * no + cell];
-    }
+  auto step = [&](const int s, float& actr, float& dhr, float& ccr, float& cpr, const float* dq, float* dw,
+                  float& ka) {
+    KEEP_ALIVE(ka);
     // dh_rec[k] = sum_{g,j} R_g[j][k] * delta_g[j](s+1)      [backward_lin1 recurrent half +
     //                                                         backward_stack_delay, :294-304,:398-410]
-    const float* dq = lds + cur * DB + js * QS;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
 #pragma unroll
     for (int j = 0; j < NK4; j++) {
       const float4 dv = *reinterpret_cast<const float4*>(dq + 4 * j);
-      acc0 += wb[0][4 * j] * dv.x; acc1 += wb[1][4 * j] * dv.x; acc2 += wb[2][4 * j] * dv.x; acc3 += wb[3][4 * j] * dv.x;
-      acc0 += wb[0][4 * j + 1] * dv.y; acc1 += wb[1][4 * j + 1] * dv.y; acc2 += wb[2][4 * j + 1] * dv.y; acc3 += wb[3][4 * j + 1] * dv.y;
-      acc0 += wb[0][4 * j + 2] * dv.z; acc1 += wb[1][4 * j + 2] * dv.z; acc2 += wb[2][4 * j + 2] * dv.z; acc3 += wb[3][4 * j + 2] * dv.z;
-      acc0 += wb[0][4 * j + 3] * dv.w; acc1 += wb[1][4 * j + 3] * dv.w; acc2 += wb[2][4 * j + 3] * dv.w; acc3 += wb[3][4 * j + 3] * dv.w;
+      a01 = fma2(wb01[4 * j], splat2(dv.x), a01); a23 = fma2(wb23[4 * j], splat2(dv.x), a23);
+      a01 = fma2(wb01[4 * j + 1], splat2(dv.y), a01); a23 = fma2(wb23[4 * j + 1], splat2(dv.y), a23);
+      a01 = fma2(wb01[4 * j + 2], splat2(dv.z), a01); a23 = fma2(wb23[4 * j + 2], splat2(dv.z), a23);
+      a01 = fma2(wb01[4 * j + 3], splat2(dv.w), a01); a23 = fma2(wb23[4 * j + 3], splat2(dv.w), a23);
     }
-    // all-reduce over the 16 slices of the row
-    acc0 += row_ror<8>(acc0); acc1 += row_ror<8>(acc1); acc2 += row_ror<8>(acc2); acc3 += row_ror<8>(acc3);
-    acc0 += row_ror<4>(acc0); acc1 += row_ror<4>(acc1); acc2 += row_ror<4>(acc2); acc3 += row_ror<4>(acc3);
-    acc0 += row_ror<2>(acc0); acc1 += row_ror<2>(acc1); acc2 += row_ror<2>(acc2); acc3 += row_ror<2>(acc3);
-    acc0 += row_ror<1>(acc0); acc1 += row_ror<1>(acc1); acc2 += row_ror<1>(acc2); acc3 += row_ror<1>(acc3);
-    const float dh_rec = isel == 0 ? acc0 : isel == 1 ? acc1 : isel == 2 ? acc2 : acc3;
+    // reduce-scatter over the row of 16 slices: the quad of cell Q ends with dh_rec of that cell.
+    // ror:8 pairs quad Q with Q^2, half_mirror pairs Q with Q^1 (slice j with 3-j, which the
+    // quad sum below makes irrelevant).
+    f32x2 keep = qb1 ? a23 : a01;
+    const f32x2 send = qb1 ? a01 : a23;
+    keep[0] += row_ror<8>(send[0]);
+    keep[1] += row_ror<8>(send[1]);
+    float k = qb0 ? keep[1] : keep[0];
+    const float sd = qb0 ? keep[0] : keep[1];
+    k += row_half_mirror(sd);
+    k += quad_xor1(k);
+    k += quad_xor2(k);
+    const float dh_rec = k;
 
-    const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), go = quad_bcast<2>(act),
-                ci = quad_bcast<3>(act);
-    const float dh = dhv + dh_rec;             // out[s].d, clstm.cc:626-628 + :646
-    const float th = tanh_dev(c_cur);          // backward_nonlingate recomputes tanh(state)
+    const float gi = quad_bcast<0>(actr), gf = quad_bcast<1>(actr), go = quad_bcast<2>(actr),
+                ci = quad_bcast<3>(actr);
+    // backward_nonlin0 in place (clstm_compute.cc:231-267): y(1-y) for SIG, 1-y^2 for TANH
+    const float deriv = g == 3 ? (-actr * actr + 1.0f) : actr * (-actr + 1.0f);
+    const float dh = dhr + dh_rec;             // out[s].d, clstm.cc:626-628 + :646
+    const float c_s = ccr, c_m1 = cpr;
+    // operands of step s-2 are re-issued into the same registers once their old values are dead
+    actr = buf_load(gbuf, gl + fr(s - 2) * gstride4);
+    dhr = buf_load(hbuf, cl + fr(s - 2) * cstride4);
+    ccr = buf_load(cbuf, cl + fr(s - 2) * cstride4);
+    cpr = buf_load(cbuf, cpoff(s - 2));
+    const float th = gate_act(c_s, true);      // backward_nonlingate recomputes tanh(state)
     const float d_go = th * dh;                //   go.d += t * out.d
     const float dc = dc_carry + (-th * th + 1.0f) * (go * dh);  // state.d += (1-t^2) * (go*out.d)
-    float d_gf = 0.0f;
-    if (s > 0) {                               // backward_statemem (clstm_compute.cc:509-515)
-      dc_carry = dc * gf;
-      d_gf = dc * c_m1;
-    }
+    // backward_statemem (clstm_compute.cc:509-515); at s = 0 c_m1 reads 0 (out of range), which
+    // reproduces "gf.d untouched when last < 0"
+    dc_carry = dc * gf;
+    const float d_gf = dc * c_m1;
     const float d_gi = dc * ci, d_ci = dc * gi;
-    // backward_nonlin0 in place (clstm_compute.cc:231-267): y(1-y) for SIG, 1-y^2 for TANH
-    float delta;
-    if (g == 0) delta = gi * (-gi + 1.0f) * d_gi;
-    else if (g == 1) delta = gf * (-gf + 1.0f) * d_gf;
-    else if (g == 2) delta = go * (-go + 1.0f) * d_go;
-    else delta = (-ci * ci + 1.0f) * d_ci;
-    if (valid) {
-      a.D[tk * gstride + gofs] = delta;
-      lds[(cur ^ 1) * DB + dslot] = delta;
-    }
-    act = act_n; dhv = dhv_n; c_cur = c_m1; c_m1 = c_m2;
-    cur ^= 1;
+    const float dsel = g == 0 ? d_gi : g == 1 ? d_gf : g == 2 ? d_go : d_ci;
+    const float delta = deriv * dsel;
+    buf_store(dbuf, gl + fr(s) * gstride4, delta);
+    *dw = delta;
+    ka = delta;
     __syncthreads();
+  };
+  int s = T - 1;
+  for (; s >= 1; s -= 2) {
+    step(s, actA, dhA, ccA, cpA, rdA, wrA, kaA);
+    step(s - 1, actB, dhB, ccB, cpB, rdB, wrB, kaB);
   }
+  if (s == 0) step(0, actA, dhA, ccA, cpA, rdA, wrA, kaA);
 }
 
 }  // namespace clstm

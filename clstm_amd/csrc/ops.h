@@ -247,6 +247,8 @@ __global__ void k_debug_lane_ops(float* out) {
   out[6 * 64 + lane] = row_ror<1>(x);
   out[7 * 64 + lane] = row_ror<4>(x);
   out[8 * 64 + lane] = row_ror<8>(x);
+  out[9 * 64 + lane] = row_half_mirror(x);
+  out[10 * 64 + lane] = wave_shr1(x);
 }
 // gather one NPLSTM state plane into [N][no] for the parity tests
 __global__ void k_gather_state(const float* src, float* out, size_t N, int no, int ndir, int dir, int slot) {

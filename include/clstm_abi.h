@@ -182,12 +182,15 @@ int clstm_net_reset_timing(clstm_net* net);
 /* ------------------------------------------------------------------------------------------
  * diagnostics (used by tests/ to pin the hardware lane layouts the kernels rely on)
  * ---------------------------------------------------------------------------------------- */
-/* out: DEVICE [9][64] floats; row k = op k applied to the lane index:
- * 0 quad_xor1, 1 quad_xor2, 2..5 quad_bcast<0..3>, 6 row_ror<1>, 7 row_ror<4>, 8 row_ror<8> */
+/* out: DEVICE [11][64] floats; row k = op k applied to the lane index:
+ * 0 quad_xor1, 1 quad_xor2, 2..5 quad_bcast<0..3>, 6 row_ror<1>, 7 row_ror<4>, 8 row_ror<8>,
+ * 9 row_half_mirror, 10 wave_shr1 */
 int clstm_debug_lane_ops(float* out);
 /* C = A.B through the MFMA GEMM used by the hoisted products.  mode 0 "NN": A [R][K] row-major,
  * B [K][Cn] row-major; mode 1 "NT": A [R][K], B given as [Cn][K]; mode 2 "TN": A given as [K][R],
  * B [K][Cn] (split over K into nsplit slabs, reduced deterministically).  C [R][Cn] row-major. */
+/* shader-clock timestamps of the last CTC launch's block 0 after phases A..E (HOST [8]) */
+int clstm_debug_ctc_cycles(long long* out_h);
 int clstm_debug_gemm(int mode, const float* A, const float* B, float* C, int R, int Cn, int K, int nsplit);
 
 #ifdef __cplusplus

@@ -11,8 +11,24 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _cpu_stamp():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                import hashlib
+                return hashlib.md5(line.encode()).hexdigest()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def build(force=False):
-    """Compile the oracle with gcc (oracle/Makefile)."""
+    """Compile the oracle with gcc (oracle/Makefile).  Built with -march=native, so a library
+    that travelled from another host (the build container -> the GPU box) is rebuilt."""
+    stamp_file = os.path.join(_HERE, "build", ".cpu_stamp")
+    stamp = _cpu_stamp()
+    if not (os.path.exists(stamp_file) and open(stamp_file).read() == stamp):
+        force = True
     need = force or not all(
         os.path.exists(os.path.join(_HERE, "build", f"liboracle_{s}.so")) for s in ("f32", "f64"))
     if not need:
@@ -20,7 +36,11 @@ def build(force=False):
         need = any(os.path.getmtime(os.path.join(_HERE, "build", f"liboracle_{s}.so")) < src
                    for s in ("f32", "f64"))
     if need:
+        if force:
+            subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+        with open(stamp_file, "w") as f:
+            f.write(stamp)
 
 
 class Oracle:

@@ -1,0 +1,23 @@
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from clstm_amd import abi
+from clstm_amd.abi import ptr
+lib = abi.load()
+rng = np.random.default_rng(0)
+for (T, L, nc, bs) in [(200, 25, 83, 64), (200, 25, 83, 1), (400, 80, 83, 16)]:
+    probs = rng.random((bs * T, nc)).astype(np.float32) ** 3
+    probs /= probs.sum(1, keepdims=True)
+    S = 2 * L + 1
+    states = np.zeros(bs * S, np.int32); states[1::2] = 0
+    st = []
+    for b in range(bs):
+        tr = rng.integers(1, nc, L); s = np.zeros(S, np.int32); s[1::2] = tr; st.append(s)
+    states = np.concatenate(st)
+    loff = (np.arange(bs + 1) * T).astype(np.int32); soff = (np.arange(bs + 1) * S).astype(np.int32)
+    P = torch.from_numpy(probs).cuda(); D = torch.zeros_like(P)
+    for it in range(3):
+        lib.call("clstm_ctc_align_batch", ptr(P), ptr(D), None, nc, ptr(loff), ptr(states), ptr(soff), bs)
+    cyc = np.zeros(8, np.int64)
+    lib.call("clstm_debug_ctc_cycles", ptr(cyc))
+    d = np.diff(cyc[:6])
+    print("T=%d S=%d bs=%d phases A,B,C,D,E cycles:" % (T, S, bs), d.tolist(), "total", int(cyc[5]-cyc[0]))

@@ -13,10 +13,15 @@ RTOL = 1e-4
 ATOL = 2e-6
 
 
-def assert_close(a, b, rtol=RTOL, atol=ATOL, what=""):
+def assert_close(a, b, rtol=RTOL, atol=ATOL, what="", scale_atol=0.0):
+    """|a-b| <= atol + scale_atol*max|b| + rtol*|b|.  `scale_atol` is for quantities that are sums
+    with cancellation (deltas, gradients): float32 summation-order noise is relative to the
+    magnitude of the terms (~ the largest entries), not of each small result."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     assert a.shape == b.shape, (what, a.shape, b.shape)
+    if scale_atol:
+        atol = atol + scale_atol * float(np.abs(b).max()) if b.size else atol
     err = np.abs(a - b) - (atol + rtol * np.abs(b))
     if not (err <= 0).all():
         i = np.unravel_index(np.argmax(err), err.shape)

@@ -48,6 +48,7 @@ inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 #define __launch_bounds__(...)
 #define __shared__ static
 #define __restrict__
+#define hipFuncSetAttribute(...) 0
 #define DEVFN static inline
 #define DEVMFN inline
 
@@ -57,6 +58,9 @@ struct f32x4 {
   const float& operator[](int i) const { return v[i]; }
 };
 struct float4 { float x, y, z, w; };
+typedef float f32x2 __attribute__((vector_size(8)));
+inline f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return a * b + c; }
+inline f32x2 splat2(float x) { return (f32x2){x, x}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
 // ---- block / wave runtime -----------------------------------------------------------
@@ -86,7 +90,9 @@ inline int wave_shfl_i(int x, int src) {
   int r; memcpy(&r, &f, 4);
   return r;
 }
+inline int wave_shfl_xor_i(int x, int m) { return wave_shfl_i(x, emu_lane() ^ m); }
 inline float wave_shfl_up1(float x) { int l = emu_lane(); return wave_shfl(x, l == 0 ? 0 : l - 1); }
+inline float wave_shr1(float x) { return wave_shfl_up1(x); }
 inline float quad_xor1(float x) { return wave_shfl(x, emu_lane() ^ 1); }
 inline float quad_xor2(float x) { return wave_shfl(x, emu_lane() ^ 2); }
 template <int I> inline float quad_bcast(float x) { return wave_shfl(x, (emu_lane() & ~3) | I); }
@@ -95,6 +101,7 @@ template <int N> inline float row_ror(float x) {
   int l = emu_lane();
   return wave_shfl(x, (l & ~15) | ((l + N) & 15));
 }
+inline float row_half_mirror(float x) { return wave_shfl(x, emu_lane() ^ 7); }
 inline float wave_max(float x) { for (int m = 32; m >= 1; m >>= 1) x = fmaxf(x, wave_shfl(x, emu_lane() ^ m)); return x; }
 inline float wave_sum(float x) { for (int m = 32; m >= 1; m >>= 1) x += wave_shfl(x, emu_lane() ^ m); return x; }
 
@@ -114,8 +121,17 @@ inline f32x4 mfma16x16x4(float a, float b, f32x4 c) {
   emu_wave_sync();
   return d;
 }
+inline int wave_uniform(int x) { return x; }
+inline long long dev_clock() { return 0; }
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
+#define KEEP_ALIVE(x) (void)(x)
+struct BufF32 { float* base; size_t bytes; };
+constexpr unsigned BUF_OOB = 0xFFFFFFF0u;
+constexpr unsigned BUF_OOB_BASE = 0x80000000u;
+inline BufF32 make_buf(const float* base, size_t bytes) { return BufF32{const_cast<float*>(base), bytes}; }
+inline float buf_load(BufF32 b, unsigned off) { return ((size_t)off + 4 <= b.bytes) ? b.base[off / 4] : 0.0f; }
+inline void buf_store(BufF32 b, unsigned off, float v) { if ((size_t)off + 4 <= b.bytes) b.base[off / 4] = v; }
 template <typename T> inline T* dyn_smem() { return reinterpret_cast<T*>(emu_blk->smem); }
 
 template <typename K, typename... Args>

@@ -72,7 +72,7 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path, ora32):
             ref.set_inputs(x); ref.forward(); ref.ctc_deltas(t); ref.backward()
         ref.update()
     assert_close(p[0], ref.get_params(), rtol=2e-5, atol=2e-7, what="params after 2 DP steps")
-    assert_close(d[0], ref.get_derivs(), rtol=5e-4, atol=2e-6, what="momentum buffer after 2 DP steps")
+    assert_close(d[0], ref.get_derivs(), rtol=1e-4, atol=1e-9, scale_atol=2e-4, what="momentum buffer after 2 DP steps")
 
 
 def test_shard_covers_everything():

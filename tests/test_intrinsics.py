@@ -10,7 +10,7 @@ from common import assert_close
 
 
 def test_lane_ops(backend):
-    out = backend.zeros((9, 64))
+    out = backend.zeros((11, 64))
     backend.lib.call("clstm_debug_lane_ops", ptr(out))
     got = backend.down(out)
     lane = np.arange(64)
@@ -20,6 +20,8 @@ def test_lane_ops(backend):
     # row_ror all-reduce only needs SOME rotation by N within the row: accept either direction
     for k in range(6):
         assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got[9], (lane ^ 7).astype(np.float32))            # row_half_mirror
+    assert np.array_equal(got[10][1:], lane[:-1].astype(np.float32))        # wave_shr:1 (lane 0 unspecified)
     for k, n in ((6, 1), (7, 4), (8, 8)):
         alt = ((lane & ~15) | ((lane - n) & 15)).astype(np.float32)
         assert np.array_equal(got[k], want[k]) or np.array_equal(got[k], alt), k

@@ -51,12 +51,12 @@ def run_case(backend, ora32, ni, nh, nc, T, uni=False, scale=30.0, seed=1, lr=1e
         if k[2] in DELTAS:
             s = net.split(net.state(*k))
             for b in range(len(T)):
-                assert_close(s[b], want["states"][k][b], rtol=3e-4, atol=1e-7, what="delta %s line %d" % (k, b))
-    assert_close(net.get_grads(), want["derivs"], rtol=3e-4, atol=2e-6, what="minibatch gradient")
+                assert_close(s[b], want["states"][k][b], rtol=1e-4, atol=1e-9, scale_atol=1e-4, what="delta %s line %d" % (k, b))
+    assert_close(net.get_grads(), want["derivs"], rtol=1e-4, atol=1e-9, scale_atol=1e-4, what="minibatch gradient")
     net.update()
     want["net"].update()
     assert_close(net.get_params(), want["net"].get_params(), rtol=1e-5, atol=1e-7, what="params after update")
-    assert_close(net.get_derivs(), want["net"].get_derivs(), rtol=3e-4, atol=2e-6, what="momentum buffer")
+    assert_close(net.get_derivs(), want["net"].get_derivs(), rtol=1e-4, atol=1e-9, scale_atol=1e-4, what="momentum buffer")
     return net, want
 
 
@@ -105,7 +105,7 @@ def test_second_step_momentum(backend, ora32):
         ref.update()
         net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward(); net.update()
         assert_close(net.get_params(), ref.get_params(), rtol=2e-5, atol=2e-7, what="params step %d" % step)
-        assert_close(net.get_derivs(), ref.get_derivs(), rtol=5e-4, atol=2e-6, what="derivs step %d" % step)
+        assert_close(net.get_derivs(), ref.get_derivs(), rtol=1e-4, atol=1e-9, scale_atol=2e-4, what="derivs step %d" % step)
 
 
 def test_input_deltas_and_explicit_output_deltas(backend, ora32):
@@ -133,8 +133,8 @@ def test_input_deltas_and_explicit_output_deltas(backend, ora32):
     assert_close(o, out, what="outputs")
     net.set_output_deltas(y - o)
     net.backward()
-    assert_close(net.input_deltas(), ref.input_deltas()[:, 0, :], rtol=3e-4, atol=1e-7, what="input deltas")
-    assert_close(net.get_grads(), ref.get_derivs(), rtol=3e-4, atol=2e-6, what="gradient")
+    assert_close(net.input_deltas(), ref.input_deltas()[:, 0, :], rtol=1e-4, atol=1e-9, scale_atol=1e-4, what="input deltas")
+    assert_close(net.get_grads(), ref.get_derivs(), rtol=1e-4, atol=1e-9, scale_atol=1e-4, what="gradient")
 
 
 def test_errors_are_reported(backend):
