@@ -205,7 +205,8 @@ struct Layer {
   PackDesc pd;
   float *Wt = nullptr, *bias = nullptr, *Rf = nullptr, *Rb = nullptr;
   long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
-  DevBuf<float> G, C, H, D, dH;
+  DevBuf<float> G, C, H, D, dH, S;
+  int lds = 0;
 };
 
 struct Net {
@@ -225,7 +226,7 @@ struct Net {
   long long N = 0;
   std::vector<int> line_off_h;
   DevBuf<int> line_off, prev0, prev1;
-  DevBuf<float> X, Z, Dz, dX0, partial, aligned, tmp;
+  DevBuf<float> X, Z, Dz, dX0, partial, aligned, tmp, Ssm;
   // ctc / decode
   DevBuf<int> states, state_off, dec_idx, dec_cls, dec_loc, dec_cnt;
   DevBuf<float> dec_val, lat;
@@ -251,6 +252,7 @@ struct Net {
       y.nk4 = pick_nk4(y.no);
       REQUIRE(y.nk4 > 0, "nhidden > 128 is not supported by the register-resident recurrence yet");
       y.nthreads = 64 * ((y.no + 15) / 16);
+      y.lds = 1 + y.ni + y.no;
       const long long blk = (long long)y.no * (1 + y.ni + y.no);
       y.pd.ni = y.ni; y.pd.no = y.no; y.pd.ndir = ndir; y.pd.nk4 = y.nk4; y.pd.nthreads = y.nthreads;
       for (int dir = 0; dir < ndir; dir++) {
@@ -292,13 +294,13 @@ struct Net {
   ~Net() {
     for (auto& y : L) {
       (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff);
-      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release();
+      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release();
     }
     if (own_v) (void)hipFree(v);
     if (own_d) (void)hipFree(d);
     if (own_g) (void)hipFree(g);
     line_off.release(); prev0.release(); prev1.release(); X.release(); Z.release(); Dz.release();
-    dX0.release(); partial.release(); aligned.release(); tmp.release(); states.release();
+    dX0.release(); partial.release(); aligned.release(); tmp.release(); Ssm.release(); states.release();
     state_off.release(); dec_idx.release(); dec_cls.release(); dec_loc.release(); dec_cnt.release();
     dec_val.release(); lat.release(); lat_off.release();
   }
@@ -346,7 +348,9 @@ struct Net {
       y.H.reserve((size_t)N * ndir * y.no);
       y.D.reserve((size_t)N * ndir * 4 * y.no);
       y.dH.reserve((size_t)N * ndir * y.no);
+      y.S.reserve((size_t)N * ndir * y.lds + GEMM_TN_ROWS);
     }
+    Ssm.reserve((size_t)N * (1 + sm_ni) + GEMM_TN_ROWS);
     Z.reserve((size_t)N * desc.nclasses);
     Dz.reserve((size_t)N * desc.nclasses);
   }
@@ -365,15 +369,22 @@ struct Net {
                                  StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
       timing.end(s);
       check_launch();
+      timing.begin("build_source", s);
+      CLSTM_LAUNCH(k_build_source, dim3(nblocks((size_t)N * (1 + y.ni))), dim3(256), 0, s, y.S.p, layer_input(l),
+                   (size_t)N, y.ni, y.ni, y.lds, ndir, (long long)N * y.lds);
+      timing.end(s);
       LstmSeqArgs a{};
       a.Rpk = y.Rf; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = nullptr; a.D = nullptr;
       a.line_off = line_off.p; a.no = y.no; a.ndir = ndir;
+      a.S = y.S.p; a.lds = y.lds; a.sofs = 1 + y.ni; a.sdir = (long long)N * y.lds;
       timing.begin("lstm_fwd", s);
       launch_lstm(true, y.nk4, a, bs, y.nthreads, s);
       timing.end(s);
     }
     const int nc = desc.nclasses;
     const float* W1 = v + sm_off;
+    CLSTM_LAUNCH(k_build_source, dim3(nblocks((size_t)N * (1 + sm_ni))), dim3(256), 0, s, Ssm.p,
+                 (const float*)L.back().H.p, (size_t)N, sm_ni, sm_ni, 1 + sm_ni, 1, 0LL);
     timing.begin("gemm_softmax", s);
     gemm_f32<GEMM_KC, GEMM_MC>(s, RowMajorA{L.back().H.p, sm_ni}, RowMajorB{W1 + nc, nc},
                                StoreBias{Z.p, nc, W1}, (int)N, nc, sm_ni);
@@ -385,10 +396,11 @@ struct Net {
     check_launch();
   }
 
+  // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
   int pick_split(int R, int Cn) const {
-    const long long tiles = (long long)((R + 63) / 64) * ((Cn + 63) / 64);
+    const long long tiles = (long long)((R + GEMM_BT - 1) / GEMM_BT) * ((Cn + GEMM_BT - 1) / GEMM_BT);
     long long want = (768 + tiles - 1) / tiles;
-    const long long maxs = (N + 63) / 64;
+    const long long maxs = (N + 63) / 64;   // at least 64 frames per slab
     if (want > maxs) want = maxs;
     if (want > 64) want = 64;
     if (want < 1) want = 1;
@@ -412,8 +424,8 @@ struct Net {
       const int R = 1 + sm_ni, Cn = nc, ns = pick_split(R, Cn);
       partial.reserve((size_t)ns * R * Cn);
       timing.begin("gemm_softmax_dw", s);
-      gemm_f32<GEMM_MC, GEMM_MC>(s, OnesAndRowsT{top.H.p, sm_ni}, RowMajorB{Dz.p, nc},
-                                 StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns);
+      gemm_f32<GEMM_MC, GEMM_MC>(s, TransA{Ssm.p, 1 + sm_ni}, RowMajorB{Dz.p, nc}, StorePartial{partial.p, R, Cn},
+                                 R, Cn, (int)N, ns);
       CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns, R, Cn,
                    g, (const long long*)nullptr, (long long)sm_off, nc);
       timing.end(s);
@@ -429,14 +441,13 @@ struct Net {
       launch_lstm(false, y.nk4, a, bs, y.nthreads, s);
       timing.end(s);
       // W.d += delta [1; x_t; h_{t-1}]^T for the four gates of each direction
-      const int R = 1 + y.ni + y.no, Cn = 4 * y.no, ns = pick_split(R, Cn * ndir);
+      const int R = 1 + y.ni + y.no, Cn = 4 * y.no, ns = pick_split(R, Cn);
       partial.reserve((size_t)ns * R * Cn);
       timing.begin("gemm_gates_dw", s);
       for (int dir = 0; dir < ndir; dir++) {
-        SourceT src{layer_input(l), y.ni, y.ni, y.H.p, (long long)ndir * y.no, dir * y.no,
-                    dir == 0 ? prev0.p : prev1.p};
-        gemm_f32<GEMM_MC, GEMM_MC>(s, src, RowMajorB{y.D.p + (size_t)dir * 4 * y.no, M},
-                                   StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns);
+        gemm_f32<GEMM_MC, GEMM_MC>(s, TransA{y.S.p + (size_t)dir * N * y.lds, y.lds},
+                                   RowMajorB{y.D.p + (size_t)dir * 4 * y.no, M}, StorePartial{partial.p, R, Cn}, R,
+                                   Cn, (int)N, ns);
         CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns, R, Cn,
                      g, (const long long*)(y.moff + (size_t)dir * 4 * y.no), 0LL, y.no);
       }
@@ -825,6 +836,14 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     part->reserve((size_t)nsplit * R * Cn);
     HIPCHECK(hipMemsetAsync(Cm, 0, (size_t)R * Cn * sizeof(float), g_stream));
     gemm_f32<GEMM_MC, GEMM_MC>(g_stream, TransA{A, R}, RowMajorB{B, Cn}, StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
+    CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream, (const float*)part->p, nsplit,
+                 R, Cn, Cm, (const long long*)nullptr, 0LL, Cn);
+  } else if (mode == 3) {
+    if (!part) part = new DevBuf<float>();
+    if (nsplit < 1) nsplit = 1;
+    part->reserve((size_t)nsplit * R * Cn);
+    HIPCHECK(hipMemsetAsync(Cm, 0, (size_t)R * Cn * sizeof(float), g_stream));
+    gemm_tn_direct(g_stream, A, R, B, Cn, StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream, (const float*)part->p, nsplit,
                  R, Cn, Cm, (const long long*)nullptr, 0LL, Cn);
   } else throw Error("bad mode");

@@ -115,4 +115,94 @@ inline void gemm_f32(hipStream_t stream, FA fa, FB fb, FE fe, int R, int Cn, int
                R, Cn, K, ksplit);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight-gradient form: out(r, c) = sum_{k in split} A[k*lda + r] * B[k*ldb + c] with a LONG
+// contraction (k = every frame of the minibatch) and a small output (a Params matrix).  Both operands
+// are frame-major arrays, contiguous along their output index -- exactly the f32 MFMA fragment order
+// (16 consecutive rows / columns for 4 consecutive k) -- so every lane loads its fragments straight
+// from global memory (L1/L2-served 64-byte segments): no LDS, no barriers.  Loads are unconditional
+// buffer loads: the descriptor ends at the slab's last frame, so k >= kend reads 0; rows / columns
+// past R / Cn read finite neighbouring data whose products land in outputs that are never stored.
+// The next k-step's fragments are fetched into a second register set while the current 20 MFMAs
+// issue (loop unrolled by two, no register moves).
+// Workgroup = 2x2 waves, wave tile = 5x4 MFMA tiles (80x64), workgroup tile 160 x 128.
+// blockIdx.z = split-K slab; slabs are reduced deterministically by k_reduce_scatter.
+constexpr int GEMM_TN_TR = 5, GEMM_TN_TC = 4;
+constexpr int GEMM_TN_ROWS = 2 * GEMM_TN_TR * 16, GEMM_TN_COLS = 2 * GEMM_TN_TC * 16;
+
+template <class FE>
+__global__ __launch_bounds__(256) void gemm_tn_direct_kernel(const float* A, int lda, const float* B, int ldb,
+                                                             FE fe, int R, int Cn, int K, int ksplit) {
+  constexpr int TR = GEMM_TN_TR, TC = GEMM_TN_TC;
+  const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r0 = blockIdx.y * GEMM_TN_ROWS + wr * TR * 16;
+  const int c0 = blockIdx.x * GEMM_TN_COLS + wc * TC * 16;
+  const int z = blockIdx.z;
+  const int kbeg = z * ksplit;
+  const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
+  const int fi = lane & 15, fk = lane >> 4;
+  // descriptors start at the slab's first frame and end at its last one
+  const BufF32 abuf = make_buf(A + (size_t)kbeg * lda, kend > kbeg ? (size_t)(kend - kbeg) * lda * 4 : 0);
+  const BufF32 bbuf = make_buf(B + (size_t)kbeg * ldb, kend > kbeg ? (size_t)(kend - kbeg) * ldb * 4 : 0);
+  const unsigned aoff = ((unsigned)fk * lda + r0 + fi) * 4u, boff = ((unsigned)fk * ldb + c0 + fi) * 4u;
+  const unsigned astep = 4u * lda * 4u, bstep = 4u * ldb * 4u;  // 4 frames per k-step
+
+  f32x4 acc[TR][TC];
+#pragma unroll
+  for (int i = 0; i < TR; i++)
+#pragma unroll
+    for (int j = 0; j < TC; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+
+  float aA[TR], bA[TC], aB[TR], bB[TC];
+  auto load = [&](unsigned step, float (&av)[TR], float (&bv)[TC]) {
+#pragma unroll
+    for (int i = 0; i < TR; i++) av[i] = buf_load(abuf, aoff + step * astep + 64u * i);
+#pragma unroll
+    for (int j = 0; j < TC; j++) bv[j] = buf_load(bbuf, boff + step * bstep + 64u * j);
+  };
+  auto mma = [&](const float (&av)[TR], const float (&bv)[TC]) {
+#pragma unroll
+    for (int i = 0; i < TR; i++)
+#pragma unroll
+      for (int j = 0; j < TC; j++) acc[i][j] = mfma16x16x4(av[i], bv[j], acc[i][j]);
+  };
+  const unsigned nsteps = kend > kbeg ? (unsigned)(kend - kbeg + 3) / 4 : 0;
+  load(0, aA, bA);
+  unsigned st = 0;
+  for (; st + 1 < nsteps; st += 2) {
+    load(st + 1, aB, bB);
+    mma(aA, bA);
+    load(st + 2, aA, bA);  // past the slab: reads 0
+    mma(aB, bB);
+  }
+  if (st < nsteps) mma(aA, bA);
+#pragma unroll
+  for (int i = 0; i < TR; i++)
+#pragma unroll
+    for (int j = 0; j < TC; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = r0 + i * 16 + (lane >> 4) * 4 + q;
+        const int c = c0 + j * 16 + (lane & 15);
+        if (r < R && c < Cn) fe(r, c, acc[i][j][q], z);
+      }
+}
+
+// A: [K][lda] (rows r < R used), B: [K][ldb] (columns c < Cn used).  The arrays must extend at least
+// GEMM_TN_ROWS / GEMM_TN_COLS floats past the last used row start only in the sense of "readable or
+// past the end of the slab": reads beyond the slab return 0, reads inside it hit finite data.
+template <class FE>
+inline void gemm_tn_direct(hipStream_t stream, const float* A, int lda, const float* B, int ldb, FE fe, int R,
+                           int Cn, int K, int nsplit) {
+  if (R <= 0 || Cn <= 0) return;
+  if (nsplit < 1) nsplit = 1;
+  int ksplit = (K + nsplit - 1) / nsplit;
+  ksplit = ((ksplit + 7) / 8) * 8;
+  dim3 grid((Cn + GEMM_TN_COLS - 1) / GEMM_TN_COLS, (R + GEMM_TN_ROWS - 1) / GEMM_TN_ROWS, nsplit);
+  CLSTM_LAUNCH((gemm_tn_direct_kernel<FE>), grid, dim3(256), 0, stream, A, lda, B, ldb, fe, R, Cn, K, ksplit);
+}
+
 }  // namespace clstm

@@ -38,6 +38,9 @@ struct LstmSeqArgs {
   const int* line_off;  // [bs+1] first token of each line
   int no;
   int ndir;             // 2 (bidirectional) or 1 (forward only, "lstm1")
+  float* S;             // [ndir][N][lds] source rows [1 | x_t | h_{t-1}] for the weight-gradient GEMM;
+  int lds, sofs;        //   the forward pass deposits h_{t-1} at column sofs = 1 + ni of the NEXT step's row
+  long long sdir;       //   floats between the two directions' S arrays
 };
 
 constexpr int lstm_qstride(int nk4) { return 4 * nk4 + ((nk4 & 1) ? 0 : 4); }
@@ -77,8 +80,11 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   const BufF32 gbuf = make_buf(a.G + (size_t)off * (gstride4 / 4), (size_t)T * gstride4);
   const BufF32 cbuf = make_buf(a.C + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
   const BufF32 hbuf = make_buf(a.H + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
+  const unsigned sstride4 = (unsigned)a.lds * 4;
+  const BufF32 sbuf = make_buf(a.S + (size_t)dir * a.sdir + (size_t)off * a.lds, (size_t)T * sstride4);
   const unsigned gl = valid ? ((unsigned)dir * 4 * no + cell * 4 + q) * 4u : BUF_OOB_BASE;
   const unsigned cl = lead ? ((unsigned)dir * no + cell) * 4u : BUF_OOB_BASE;
+  const unsigned sl = lead ? ((unsigned)a.sofs + cell) * 4u : BUF_OOB_BASE;
   auto fr = [&](int t) -> unsigned {  // clamped: prefetches past the end re-read the last frame
     const int tc = t < T ? t : T - 1;
     return (unsigned)(dir == 0 ? tc : T - 1 - tc);
@@ -96,6 +102,7 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   float gxA = buf_load(gbuf, gl + fr(0) * gstride4);
   float gxB = buf_load(gbuf, gl + fr(1) * gstride4);
   float kaA0 = 0.f, kaA1 = 0.f, kaA2 = 0.f, kaB0 = 0.f, kaB1 = 0.f, kaB2 = 0.f;  // store-data pins
+  buf_store(sbuf, sl + fr(0) * sstride4, 0.0f);  // h_{-1} = 0 (forward_stack_delay, last < 0)
   __syncthreads();
   auto step = [&](const int t, float& gxr, const float* hq, float* hw, float& ka0, float& ka1, float& ka2) {
     KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2);  // stores of step t-2 have long completed
@@ -133,6 +140,8 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     buf_store(gbuf, gl + f * gstride4, act);
     buf_store(cbuf, cl + f * cstride4, c);
     buf_store(hbuf, cl + f * cstride4, h);
+    // h_t is the recurrent part of the NEXT step's source row (dropped after the last step)
+    buf_store(sbuf, t + 1 < T ? sl + fr(t + 1) * sstride4 : BUF_OOB, h);
     *hw = h;
     ka0 = act; ka1 = c; ka2 = h;
     __syncthreads();

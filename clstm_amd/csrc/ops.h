@@ -223,6 +223,16 @@ __global__ void k_pack_rb(const float* v, float* Rb, PackDesc p) {
     Rb[e] = x;
   }
 }
+// S[dir][n][0] = 1, S[dir][n][1..ni] = x_n for every direction: the non-recurrent part of the source
+// rows [1 | x_t | h_{t-1}] (forward_stack_delay + the bias column of Params, tensor.h:263-264)
+__global__ void k_build_source(float* S, const float* x, size_t N, int ni, int ldx, int lds, int ndir, long long sdir) {
+  CLSTM_GRID_STRIDE(e, N * (size_t)(1 + ni)) {
+    const size_t n = e / (1 + ni);
+    const int j = e % (1 + ni);
+    const float v = j == 0 ? 1.0f : x[n * ldx + (j - 1)];
+    for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = v;
+  }
+}
 // g[off(c) + rs*r] += sum_z partial[z][r][c]   (deterministic split-K reduction + row scatter)
 __global__ void k_reduce_scatter(const float* partial, int nsplit, int R, int Cn, float* g,
                                  const long long* moff, long long base, int rs) {

@@ -27,7 +27,7 @@ def test_lane_ops(backend):
         assert np.array_equal(got[k], want[k]) or np.array_equal(got[k], alt), k
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("R,Cn,K,ns", [(64, 64, 16, 1), (70, 45, 37, 1), (149, 400, 333, 5), (5, 3, 2, 1),
                                        (130, 83, 200, 3)])
 def test_gemm_modes(backend, mode, R, Cn, K, ns):
@@ -37,10 +37,10 @@ def test_gemm_modes(backend, mode, R, Cn, K, ns):
     A = rng.normal(size=(R, K)).astype(np.float32)
     B = rng.normal(size=(K, Cn)).astype(np.float32)
     want = A.astype(np.float64) @ B.astype(np.float64)
-    Ad = backend.up(A if mode != 2 else A.T)
+    Ad = backend.up(A if mode < 2 else A.T)
     Bd = backend.up(B if mode != 1 else B.T)
     Cd = backend.zeros((R, Cn))
-    backend.lib.call("clstm_debug_gemm", mode, ptr(Ad), ptr(Bd), ptr(Cd), R, Cn, K, ns if mode == 2 else 1)
+    backend.lib.call("clstm_debug_gemm", mode, ptr(Ad), ptr(Bd), ptr(Cd), R, Cn, K, ns if mode >= 2 else 1)
     got = backend.down(Cd)
     scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
     assert (np.abs(got - want) <= 2e-6 * scale + 1e-6).all()
