@@ -19,6 +19,7 @@
 #include "ops.h"
 
 #include <algorithm>
+#include <cstring>
 #include <cstdlib>
 #include <map>
 #include <stdexcept>
@@ -85,6 +86,39 @@ struct DevBuf {  // grow-only device buffer
   }
 };
 
+// Pinned host staging ring: small per-minibatch host arrays (line offsets, CTC target states) are
+// copied here and DMA'd asynchronously, so declaring a batch never drains the stream and the host
+// can run ahead of the GPU.  A slot is reused only after the copy recorded on it has completed.
+struct PinnedRing {
+  static const int SLOTS = 8;
+  void* h[SLOTS] = {};
+  size_t cap[SLOTS] = {};
+  hipEvent_t ev[SLOTS] = {};
+  bool busy[SLOTS] = {};
+  int cur = 0;
+  void* acquire(size_t bytes) {
+    cur = (cur + 1) % SLOTS;
+    if (busy[cur]) { HIPCHECK(hipEventSynchronize(ev[cur])); busy[cur] = false; }
+    if (cap[cur] < bytes) {
+      if (h[cur]) (void)hipHostFree(h[cur]);
+      cap[cur] = bytes * 2 + 256;
+      HIPCHECK(hipHostMalloc(&h[cur], cap[cur]));
+    }
+    return h[cur];
+  }
+  void commit(hipStream_t s) {
+    if (!ev[cur]) HIPCHECK(hipEventCreateWithFlags(&ev[cur], hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(ev[cur], s));
+    busy[cur] = true;
+  }
+  ~PinnedRing() {
+    for (int i = 0; i < SLOTS; i++) {
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+      if (h[i]) (void)hipHostFree(h[i]);
+    }
+  }
+};
+
 // ---- GEMM operand functors ---------------------------------------------------------------------
 struct RowMajorA {  // A(r,k) = p[r*ld + k]
   const float* p; long long ld;
@@ -114,24 +148,6 @@ struct StorePartial {  // split-K slabs [z][R][Cn]
   float* out; int R, Cn;
   DEVMFN void operator()(int r, int c, float v, int z) const { out[((long long)z * R + r) * Cn + c] = v; }
 };
-// A(j, tok) of the weight-gradient products: rows of [1 ; x_tok ; h_prev(tok)]  -- the `source`
-// vector of forward_stack_delay (clstm_compute.cc:377-397) without materialising it.
-struct SourceT {
-  const float* x; long long ldx; int ni;
-  const float* h; long long ldh; int hofs;  // h_prev(tok)[k] = h[prev[tok]*ldh + hofs + k]
-  const int* prev;                          // -1 at the first step of a line
-  DEVMFN float operator()(int j, int tok) const {
-    if (j == 0) return 1.0f;
-    if (j <= ni) return x[(long long)tok * ldx + (j - 1)];
-    const int p = prev[tok];
-    return p < 0 ? 0.0f : h[(long long)p * ldh + hofs + (j - 1 - ni)];
-  }
-};
-struct OnesAndRowsT {  // A(j, tok) = [1 ; h_tok] for the softmax dW
-  const float* h; long long ldh;
-  DEVMFN float operator()(int j, int tok) const { return j == 0 ? 1.0f : h[(long long)tok * ldh + (j - 1)]; }
-};
-
 static const int kNK4Table[] = {1, 2, 4, 7, 8};
 static int pick_nk4(int no) {
   int need = ((no + 3) / 4 + 3) / 4;
@@ -225,7 +241,8 @@ struct Net {
   int bs = 0;
   long long N = 0;
   std::vector<int> line_off_h;
-  DevBuf<int> line_off, prev0, prev1;
+  DevBuf<int> line_off;
+  PinnedRing ring;
   DevBuf<float> X, Z, Dz, dX0, partial, aligned, tmp, Ssm;
   // ctc / decode
   DevBuf<int> states, state_off, dec_idx, dec_cls, dec_loc, dec_cnt;
@@ -299,7 +316,7 @@ struct Net {
     if (own_v) (void)hipFree(v);
     if (own_d) (void)hipFree(d);
     if (own_g) (void)hipFree(g);
-    line_off.release(); prev0.release(); prev1.release(); X.release(); Z.release(); Dz.release();
+    line_off.release(); X.release(); Z.release(); Dz.release();
     dX0.release(); partial.release(); aligned.release(); tmp.release(); Ssm.release(); states.release();
     state_off.release(); dec_idx.release(); dec_cls.release(); dec_loc.release(); dec_cnt.release();
     dec_val.release(); lat.release(); lat_off.release();
@@ -329,18 +346,12 @@ struct Net {
     }
     N = line_off_h[nb];
     REQUIRE(N > 0, "batch has no frames");
-    std::vector<int> p0(N), p1(N);
-    for (int b = 0; b < nb; b++)
-      for (int t = line_off_h[b]; t < line_off_h[b + 1]; t++) {
-        p0[t] = (t > line_off_h[b]) ? t - 1 : -1;           // h_{t-1} of the forward NPLSTM
-        p1[t] = (t + 1 < line_off_h[b + 1]) ? t + 1 : -1;   // previous own-step of the reversed one
-      }
-    line_off.reserve(nb + 1); prev0.reserve(N); prev1.reserve(N);
+    line_off.reserve(nb + 1);
     hipStream_t s = stream();
-    HIPCHECK(hipMemcpyAsync(line_off.p, line_off_h.data(), (nb + 1) * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(prev0.p, p0.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(prev1.p, p1.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHECK(hipStreamSynchronize(s));  // host vectors go out of scope
+    int* stage = (int*)ring.acquire((nb + 1) * sizeof(int));
+    memcpy(stage, line_off_h.data(), (nb + 1) * sizeof(int));
+    HIPCHECK(hipMemcpyAsync(line_off.p, stage, (nb + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    ring.commit(s);
     X.reserve((size_t)N * desc.ninput);
     for (auto& y : L) {
       y.G.reserve((size_t)N * ndir * 4 * y.no);
@@ -416,20 +427,21 @@ struct Net {
     HIPCHECK(hipMemsetAsync(g, 0, (size_t)nparams * sizeof(float), s));
     // SoftmaxLayer::backward (clstm.cc:411-417): x.d = W^T z.d ; W.d += z.d [1;x]^T
     Layer& top = L.back();
-    timing.begin("gemm_softmax_dx", s);
-    gemm_f32<GEMM_KC, GEMM_KC>(s, RowMajorA{Dz.p, nc}, TransB{W1 + nc, nc}, StorePlain{top.dH.p, sm_ni},
-                               (int)N, sm_ni, nc);
-    timing.end(s);
-    {
+    {  // (a side stream for this GEMM was measured on MI355X: no gain -- the recurrence workgroups it would
+       // overlap with slow down by as much -- so everything stays on one stream)
       const int R = 1 + sm_ni, Cn = nc, ns = pick_split(R, Cn);
       partial.reserve((size_t)ns * R * Cn);
       timing.begin("gemm_softmax_dw", s);
-      gemm_f32<GEMM_MC, GEMM_MC>(s, TransA{Ssm.p, 1 + sm_ni}, RowMajorB{Dz.p, nc}, StorePartial{partial.p, R, Cn},
-                                 R, Cn, (int)N, ns);
+      gemm_f32<GEMM_MC, GEMM_MC>(s, TransA{Ssm.p, 1 + sm_ni}, RowMajorB{Dz.p, nc}, StorePartial{partial.p, R, Cn}, R,
+                                 Cn, (int)N, ns);
       CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns, R, Cn,
                    g, (const long long*)nullptr, (long long)sm_off, nc);
       timing.end(s);
     }
+    timing.begin("gemm_softmax_dx", s);
+    gemm_f32<GEMM_KC, GEMM_KC>(s, RowMajorA{Dz.p, nc}, TransB{W1 + nc, nc}, StorePlain{top.dH.p, sm_ni},
+                               (int)N, sm_ni, nc);
+    timing.end(s);
     check_launch();
     for (int l = (int)L.size() - 1; l >= 0; l--) {
       Layer& y = L[l];
@@ -480,6 +492,7 @@ struct Net {
 static thread_local long long* g_last_ctc_prof = nullptr;
 // CTC on an arbitrary packed batch (used by the net and by the stand-alone ABI entry)
 struct CtcWorkspace {
+  PinnedRing ring;
   DevBuf<long long> prof;
   DevBuf<double> tables;
   DevBuf<int> line_off, states, state_off;
@@ -501,11 +514,20 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
   for (int i = 0; i < ns; i++) REQUIRE(states_h[i] >= 0 && states_h[i] < nc, "target class out of range");
   w.line_off.reserve(bs + 1); w.state_off.reserve(bs + 1); w.states.reserve(ns > 0 ? ns : 1);
   w.lat_off.reserve(bs + 1); w.lat.reserve((size_t)(lo[bs] > 0 ? lo[bs] : 1));
-  HIPCHECK(hipMemcpyAsync(w.line_off.p, line_off_h, (bs + 1) * sizeof(int), hipMemcpyHostToDevice, s));
-  HIPCHECK(hipMemcpyAsync(w.state_off.p, state_off_h, (bs + 1) * sizeof(int), hipMemcpyHostToDevice, s));
-  if (ns > 0) HIPCHECK(hipMemcpyAsync(w.states.p, states_h, ns * sizeof(int), hipMemcpyHostToDevice, s));
-  HIPCHECK(hipMemcpyAsync(w.lat_off.p, lo.data(), (bs + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
-  HIPCHECK(hipStreamSynchronize(s));
+  {  // one pinned slot: [lat_off (bs+1 x i64) | line_off | state_off | states]
+    const size_t nlo = (size_t)(bs + 1) * sizeof(long long), nio = (size_t)(bs + 1) * sizeof(int);
+    const size_t nst = (size_t)(ns > 0 ? ns : 1) * sizeof(int);
+    char* stage = (char*)w.ring.acquire(nlo + 2 * nio + nst);
+    memcpy(stage, lo.data(), nlo);
+    memcpy(stage + nlo, line_off_h, nio);
+    memcpy(stage + nlo + nio, state_off_h, nio);
+    if (ns > 0) memcpy(stage + nlo + 2 * nio, states_h, (size_t)ns * sizeof(int));
+    HIPCHECK(hipMemcpyAsync(w.lat_off.p, stage, nlo, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(w.line_off.p, stage + nlo, nio, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(w.state_off.p, stage + nlo + nio, nio, hipMemcpyHostToDevice, s));
+    if (ns > 0) HIPCHECK(hipMemcpyAsync(w.states.p, stage + nlo + 2 * nio, (size_t)ns * sizeof(int), hipMemcpyHostToDevice, s));
+    w.ring.commit(s);
+  }
   CtcArgs a{};
   a.P = probs; a.Dz = deltas; a.aligned = aligned; a.line_off = w.line_off.p; a.states = w.states.p;
   a.state_off = w.state_off.p; a.lat = w.lat.p; a.lat_off = w.lat_off.p; a.nc = nc;

@@ -37,6 +37,18 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStrea
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+typedef int hipEvent_t;
+#define hipEventDisableTiming 0
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { *e = 1; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+#define hipStreamNonBlocking 0
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, int) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, int) { return 0; }
+inline hipError_t hipHostMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return 0; }
+inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
