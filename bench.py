@@ -165,13 +165,22 @@ def main():
                 kern[name] = {"ms_per_step": round(ms / args.profile_steps, 4), "launches_per_step": n / args.profile_steps}
         net.enable_timing(False)
         dom = max(("lstm_fwd", "lstm_bwd"), key=lambda k: kern.get(k, {"ms_per_step": 0})["ms_per_step"])
+        traffic = None
+        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload only)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01.json")))
+            if (pmc["workload"]["minibatch_per_gpu"] == args.minibatch and pmc["workload"]["T"] == args.T
+                    and not args.ragged and dom in pmc["kernels"]):
+                traffic = pmc["kernels"][dom]["hbm_bytes"]
+        except Exception:
+            traffic = None
         if dom in kern:
             frames_per_launch = frames / args.profile_steps
             byts = BYTES_PER_CELL_STEP[dom] * 2 * NH * frames_per_launch      # 2 directions x 100 cells
             sec = kern[dom]["ms_per_step"] * 1e-3 / kern[dom]["launches_per_step"]
             ach = byts / sec / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "algorithmic_bytes": int(byts),
                         "avg_launch_ms": round(sec * 1e3, 4),
                         "note": "latency-bound persistent recurrence: %d workgroups (lines x directions) on 256 CUs; "
                                 "recurrent FMA rate %.2f TFLOP/s of %.1f f32 peak" %

@@ -38,4 +38,11 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" 
 tail -3 "$OUT/rocprof.log"
 find "$OUT/prof" -name "*kernel_stats*" | head -2 | while read f; do echo "--- $f"; head -25 "$f"; done
 find "$OUT/prof" -name "*kernel_trace*" -size +20M -delete
+echo "=== rocprofv3 PMC passes (HBM traffic): FETCH_SIZE, WRITE_SIZE in separate runs"
+for CNT in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_$CNT" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/rocprof_$CNT.log" 2>&1
+  tail -2 "$OUT/rocprof_$CNT.log"
+  python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_$CNT" $CNT > "$OUT/pmc_${CNT}_summary.txt" 2>&1; cat "$OUT/pmc_${CNT}_summary.txt"
+  find "$OUT/pmc_$CNT" -name "*.csv" -size +8M -delete
+done
 echo "=== done"
