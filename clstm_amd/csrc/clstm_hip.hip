@@ -120,22 +120,6 @@ struct PinnedRing {
 };
 
 // ---- GEMM operand functors ---------------------------------------------------------------------
-struct RowMajorA {  // A(r,k) = p[r*ld + k]
-  const float* p; long long ld;
-  DEVMFN float operator()(int r, int k) const { return p[(long long)r * ld + k]; }
-};
-struct RowMajorB {  // B(k,c) = p[k*ld + c]
-  const float* p; long long ld;
-  DEVMFN float operator()(int k, int c) const { return p[(long long)k * ld + c]; }
-};
-struct TransB {     // B(k,c) = p[c*ld + k]
-  const float* p; long long ld;
-  DEVMFN float operator()(int k, int c) const { return p[(long long)c * ld + k]; }
-};
-struct TransA {     // A(r,k) = p[k*ld + r]
-  const float* p; long long ld;
-  DEVMFN float operator()(int r, int k) const { return p[(long long)k * ld + r]; }
-};
 struct StoreBias {  // out[r*ld + c] = val + bias[c]
   float* out; long long ld; const float* bias;
   DEVMFN void operator()(int r, int c, float v, int) const { out[(long long)r * ld + c] = v + bias[c]; }
@@ -359,9 +343,9 @@ struct Net {
       y.H.reserve((size_t)N * ndir * y.no);
       y.D.reserve((size_t)N * ndir * 4 * y.no);
       y.dH.reserve((size_t)N * ndir * y.no);
-      y.S.reserve((size_t)N * ndir * y.lds + GEMM_TN_ROWS);
+      y.S.reserve((size_t)N * ndir * y.lds + 64);
     }
-    Ssm.reserve((size_t)N * (1 + sm_ni) + GEMM_TN_ROWS);
+    Ssm.reserve((size_t)N * (1 + sm_ni) + 64);
     Z.reserve((size_t)N * desc.nclasses);
     Dz.reserve((size_t)N * desc.nclasses);
   }
@@ -376,7 +360,7 @@ struct Net {
       Layer& y = L[l];
       const int M = ndir * 4 * y.no;
       timing.begin("gemm_gates_x", s);
-      gemm_f32<GEMM_KC, GEMM_MC>(s, RowMajorA{layer_input(l), y.ni}, RowMajorB{y.Wt, M},
+      gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), y.ni, N), gemm_mc(y.Wt, M, y.ni, 0),
                                  StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
       timing.end(s);
       check_launch();
@@ -397,7 +381,7 @@ struct Net {
     CLSTM_LAUNCH(k_build_source, dim3(nblocks((size_t)N * (1 + sm_ni))), dim3(256), 0, s, Ssm.p,
                  (const float*)L.back().H.p, (size_t)N, sm_ni, sm_ni, 1 + sm_ni, 1, 0LL);
     timing.begin("gemm_softmax", s);
-    gemm_f32<GEMM_KC, GEMM_MC>(s, RowMajorA{L.back().H.p, sm_ni}, RowMajorB{W1 + nc, nc},
+    gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(L.back().H.p, sm_ni, N), gemm_mc(W1 + nc, nc, sm_ni, 0),
                                StoreBias{Z.p, nc, W1}, (int)N, nc, sm_ni);
     timing.end(s);
     check_launch();
@@ -410,7 +394,8 @@ struct Net {
   // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
   int pick_split(int R, int Cn) const {
     const long long tiles = (long long)((R + GEMM_BT - 1) / GEMM_BT) * ((Cn + GEMM_BT - 1) / GEMM_BT);
-    long long want = (768 + tiles - 1) / tiles;
+    static const long long target = getenv("CLSTM_SPLIT_TARGET") ? atoll(getenv("CLSTM_SPLIT_TARGET")) : 768;
+    long long want = (target + tiles - 1) / tiles;
     const long long maxs = (N + 63) / 64;   // at least 64 frames per slab
     if (want > maxs) want = maxs;
     if (want > 64) want = 64;
@@ -432,14 +417,14 @@ struct Net {
       const int R = 1 + sm_ni, Cn = nc, ns = pick_split(R, Cn);
       partial.reserve((size_t)ns * R * Cn);
       timing.begin("gemm_softmax_dw", s);
-      gemm_f32<GEMM_MC, GEMM_MC>(s, TransA{Ssm.p, 1 + sm_ni}, RowMajorB{Dz.p, nc}, StorePartial{partial.p, R, Cn}, R,
-                                 Cn, (int)N, ns);
+      gemm_f32<GEMM_MC, GEMM_MC>(s, gemm_mc(Ssm.p, 1 + sm_ni, N), gemm_mc(Dz.p, nc, N), StorePartial{partial.p, R, Cn},
+                                 R, Cn, (int)N, ns);
       CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns, R, Cn,
                    g, (const long long*)nullptr, (long long)sm_off, nc);
       timing.end(s);
     }
     timing.begin("gemm_softmax_dx", s);
-    gemm_f32<GEMM_KC, GEMM_KC>(s, RowMajorA{Dz.p, nc}, TransB{W1 + nc, nc}, StorePlain{top.dH.p, sm_ni},
+    gemm_f32<GEMM_KC, GEMM_KC>(s, gemm_kc(Dz.p, nc, N), gemm_kc(W1 + nc, nc, sm_ni, 0), StorePlain{top.dH.p, sm_ni},
                                (int)N, sm_ni, nc);
     timing.end(s);
     check_launch();
@@ -457,9 +442,9 @@ struct Net {
       partial.reserve((size_t)ns * R * Cn);
       timing.begin("gemm_gates_dw", s);
       for (int dir = 0; dir < ndir; dir++) {
-        gemm_f32<GEMM_MC, GEMM_MC>(s, TransA{y.S.p + (size_t)dir * N * y.lds, y.lds},
-                                   RowMajorB{y.D.p + (size_t)dir * 4 * y.no, M}, StorePartial{partial.p, R, Cn}, R,
-                                   Cn, (int)N, ns);
+        gemm_f32<GEMM_MC, GEMM_MC>(s, gemm_mc(y.S.p + (size_t)dir * N * y.lds, y.lds, N),
+                                   gemm_mc(y.D.p + (size_t)dir * 4 * y.no, M, N, 0), StorePartial{partial.p, R, Cn},
+                                   R, Cn, (int)N, ns);
         CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns, R, Cn,
                      g, (const long long*)(y.moff + (size_t)dir * 4 * y.no), 0LL, y.no);
       }
@@ -471,7 +456,7 @@ struct Net {
       else if (want_dx0) { dX0.reserve((size_t)N * y.ni); dx = dX0.p; }
       if (dx) {
         timing.begin("gemm_gates_dx", s);
-        gemm_f32<GEMM_KC, GEMM_KC>(s, RowMajorA{y.D.p, M}, TransB{y.Wt, M}, StorePlain{dx, y.ni}, (int)N,
+        gemm_f32<GEMM_KC, GEMM_KC>(s, gemm_kc(y.D.p, M, N), gemm_kc(y.Wt, M, y.ni, 0), StorePlain{dx, y.ni}, (int)N,
                                    y.ni, M);
         timing.end(s);
         check_launch();
@@ -850,22 +835,15 @@ int clstm_debug_lane_ops(float* out) {
 int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R, int Cn, int K, int nsplit) {
   ABI_BEGIN
   static thread_local DevBuf<float>* part = nullptr;
-  if (mode == 0) gemm_f32<GEMM_KC, GEMM_MC>(g_stream, RowMajorA{A, K}, RowMajorB{B, Cn}, StorePlain{Cm, Cn}, R, Cn, K);
-  else if (mode == 1) gemm_f32<GEMM_KC, GEMM_KC>(g_stream, RowMajorA{A, K}, TransB{B, K}, StorePlain{Cm, Cn}, R, Cn, K);
+  // user arrays are exact-size: no slack, the descriptor ends at the last element
+  if (mode == 0) gemm_f32<GEMM_KC, GEMM_MC>(g_stream, gemm_kc(A, K, R, 0), gemm_mc(B, Cn, K, 0), StorePlain{Cm, Cn}, R, Cn, K);
+  else if (mode == 1) gemm_f32<GEMM_KC, GEMM_KC>(g_stream, gemm_kc(A, K, R, 0), gemm_kc(B, K, Cn, 0), StorePlain{Cm, Cn}, R, Cn, K);
   else if (mode == 2) {
     if (!part) part = new DevBuf<float>();
     if (nsplit < 1) nsplit = 1;
     part->reserve((size_t)nsplit * R * Cn);
     HIPCHECK(hipMemsetAsync(Cm, 0, (size_t)R * Cn * sizeof(float), g_stream));
-    gemm_f32<GEMM_MC, GEMM_MC>(g_stream, TransA{A, R}, RowMajorB{B, Cn}, StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
-    CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream, (const float*)part->p, nsplit,
-                 R, Cn, Cm, (const long long*)nullptr, 0LL, Cn);
-  } else if (mode == 3) {
-    if (!part) part = new DevBuf<float>();
-    if (nsplit < 1) nsplit = 1;
-    part->reserve((size_t)nsplit * R * Cn);
-    HIPCHECK(hipMemsetAsync(Cm, 0, (size_t)R * Cn * sizeof(float), g_stream));
-    gemm_tn_direct(g_stream, A, R, B, Cn, StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
+    gemm_f32<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream, (const float*)part->p, nsplit,
                  R, Cn, Cm, (const long long*)nullptr, 0LL, Cn);
   } else throw Error("bad mode");

@@ -100,6 +100,10 @@ DEVFN BufF32 make_buf(const float* base, size_t bytes) {
 DEVFN float buf_load(BufF32 b, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, byte_off, 0, 0));
 }
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+DEVFN f32x4 buf_load4(BufF32 b, unsigned byte_off) {  // 16 bytes, dword alignment suffices
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, byte_off, 0, 0));
+}
 DEVFN void buf_store(BufF32 b, unsigned byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.r, byte_off, 0, 0);
 }
@@ -122,37 +126,29 @@ DEVFN T* dyn_smem() {
 // ---------------------------------------------------------------------------------------
 // activation functions shared by every kernel (and replicated in numpy by the CPU tests)
 // ---------------------------------------------------------------------------------------
-// gate nonlinearity without divergence: sigmoid for the three gates, tanh for the cell input;
-// one exp + one rcp either way (tanh's |x| >= 0.4 branch is 1 - 2/(1+exp(2|x|))).
-DEVFN float gate_act(float x, bool is_tanh) {
-  const float ax = fabsf(x);
-  const float r = fast_rcp(1.0f + fast_exp(is_tanh ? 2.0f * ax : -x));
-  const float x2 = x * x;
-  float p = -1382.0f / 155925.0f;
-  p = p * x2 + 62.0f / 2835.0f;
-  p = p * x2 - 17.0f / 315.0f;
-  p = p * x2 + 2.0f / 15.0f;
-  p = p * x2 - 1.0f / 3.0f;
-  p = p * x2 + 1.0f;
-  const float th = ax < 0.4f ? x * p : copysignf(1.0f - 2.0f * r, x);
-  return is_tanh ? th : r;
+// tanh(x) = (e-1)/(e+1), e = exp(2x) (native v_exp_f32 / v_rcp_f32), x clamped to +-15 so e stays
+// finite; below |x| = 0.01 the cancellation in e-1 would cost more than ~6e-6 relative, there
+// x - x^3/3 is exact to 1e-9.  Worst-case relative error ~6e-6 (at |x| = 0.01), 3e-7 for |x| > 0.2:
+// well inside the 1e-4 activation bar, and less than half the instructions of a polynomial/exp
+// hybrid on the per-timestep critical path.
+DEVFN float tanh_dev(float x) {
+  const float xc = fminf(fmaxf(x, -15.0f), 15.0f);
+  const float e = fast_exp(2.0f * xc);
+  const float big = (e - 1.0f) * fast_rcp(e + 1.0f);
+  const float small = xc - xc * xc * xc * (1.0f / 3.0f);
+  return fabsf(xc) < 0.01f ? small : big;
 }
 
 // sigmoid(x) = 1/(1+exp(-x))  (Eigen scalar_sigmoid_op form used by clstm_compute.cc:117,196)
 DEVFN float sigmoid_dev(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 
-// tanh: odd Taylor polynomial (through x^11) below 0.4, 1 - 2/(1+exp(2|x|)) above; ~5e-7 relative.
-DEVFN float tanh_dev(float x) {
-  const float ax = fabsf(x);
-  const float x2 = x * x;
-  float p = -1382.0f / 155925.0f;
-  p = p * x2 + 62.0f / 2835.0f;
-  p = p * x2 - 17.0f / 315.0f;
-  p = p * x2 + 2.0f / 15.0f;
-  p = p * x2 - 1.0f / 3.0f;
-  p = p * x2 + 1.0f;
-  const float small = x * p;
-  const float r = fast_rcp(1.0f + fast_exp(2.0f * ax));
-  const float big = copysignf(1.0f - 2.0f * r, x);
-  return ax < 0.4f ? small : big;
+// gate nonlinearity without divergence: sigmoid for the three gates, tanh for the cell input;
+// one exp + one rcp either way.
+DEVFN float gate_act(float x, bool is_tanh) {
+  const float xc = fminf(fmaxf(x, -15.0f), 15.0f);
+  const float e = fast_exp(is_tanh ? 2.0f * xc : -x);
+  const float r = fast_rcp(1.0f + e);
+  const float small = xc - xc * xc * xc * (1.0f / 3.0f);
+  const float th = fabsf(xc) < 0.01f ? small : (e - 1.0f) * r;
+  return is_tanh ? th : r;
 }

@@ -188,8 +188,7 @@ int clstm_net_reset_timing(clstm_net* net);
 int clstm_debug_lane_ops(float* out);
 /* C = A.B through the MFMA GEMM used by the hoisted products.  mode 0 "NN": A [R][K] row-major,
  * B [K][Cn] row-major; mode 1 "NT": A [R][K], B given as [Cn][K]; mode 2 "TN": A given as [K][R],
- * B [K][Cn] (split over K into nsplit slabs, reduced deterministically); mode 3: as mode 2 through
- * the LDS-free direct-fragment kernel used for the weight gradients.  C [R][Cn] row-major. */
+ * B [K][Cn] (split over K into nsplit slabs, reduced deterministically).  C [R][Cn] row-major. */
 /* shader-clock timestamps of the last CTC launch's block 0 after phases A..E (HOST [8]) */
 int clstm_debug_ctc_cycles(long long* out_h);
 int clstm_debug_gemm(int mode, const float* A, const float* B, float* C, int R, int Cn, int K, int nsplit);

@@ -143,6 +143,7 @@ constexpr unsigned BUF_OOB = 0xFFFFFFF0u;
 constexpr unsigned BUF_OOB_BASE = 0x80000000u;
 inline BufF32 make_buf(const float* base, size_t bytes) { return BufF32{const_cast<float*>(base), bytes}; }
 inline float buf_load(BufF32 b, unsigned off) { return ((size_t)off + 4 <= b.bytes) ? b.base[off / 4] : 0.0f; }
+inline f32x4 buf_load4(BufF32 b, unsigned off) { f32x4 r; for (int i = 0; i < 4; i++) r[i] = buf_load(b, off + 4 * i); return r; }
 inline void buf_store(BufF32 b, unsigned off, float v) { if ((size_t)off + 4 <= b.bytes) b.base[off / 4] = v; }
 template <typename T> inline T* dyn_smem() { return reinterpret_cast<T*>(emu_blk->smem); }
 

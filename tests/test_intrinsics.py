@@ -27,7 +27,7 @@ def test_lane_ops(backend):
         assert np.array_equal(got[k], want[k]) or np.array_equal(got[k], alt), k
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("R,Cn,K,ns", [(64, 64, 16, 1), (70, 45, 37, 1), (149, 400, 333, 5), (5, 3, 2, 1),
                                        (130, 83, 200, 3)])
 def test_gemm_modes(backend, mode, R, Cn, K, ns):
@@ -53,4 +53,4 @@ def test_device_activations(backend):
     for nl, f in ((1, lambda v: 1 / (1 + np.exp(-v))), (2, np.tanh)):
         y = backend.up(x)
         backend.lib.call("clstm_forward_nonlin0", ptr(y), x.size, nl)
-        assert_close(backend.down(y), f(x.astype(np.float64)), rtol=2e-6, atol=1e-30, what="nl %d" % nl)
+        assert_close(backend.down(y), f(x.astype(np.float64)), rtol=1e-5, atol=1e-30, what="nl %d" % nl)
