@@ -110,8 +110,17 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   for (int t0 = 0; t0 < T; t0 += TT) {
     const int nt = (T - t0) < TT ? (T - t0) : TT;
     __syncthreads();
-    if (ncp == nc) {  // rows are back to back in LDS too: flat coalesced copy
-      for (int i = tid; i < nt * nc; i += CTC_THREADS) rowbuf[i] = fmaxf(1e-5f, P[(size_t)t0 * nc + i]);
+    if (ncp == nc) {  // rows are back to back in LDS too: flat coalesced copy, 4 loads in flight
+      const float* src = P + (size_t)t0 * nc;
+      const int n = nt * nc;
+      for (int i0 = tid; i0 < n; i0 += 4 * CTC_THREADS) {
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = (i0 + u * CTC_THREADS < n) ? src[i0 + u * CTC_THREADS] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (i0 + u * CTC_THREADS < n) rowbuf[i0 + u * CTC_THREADS] = fmaxf(1e-5f, x[u]);
+      }
     } else {
       for (int i = tid; i < nt * nc; i += CTC_THREADS) {
         const int t = i / nc, c = i - t * nc;
@@ -126,11 +135,22 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
       asum[tid] = acc;
     }
     __syncthreads();
-    for (int t = wave; t < nt; t += CTC_THREADS / 64) {  // one wave per frame, lanes over states
-      const float* r = rowbuf + t * ncp;
-      const float as = asum[t];
-      float* lrow = lm + (size_t)(t0 + t) * S;
-      for (int s0 = lane; s0 < S; s0 += 64) lrow[s0] = cr_logf(r[stl[s0]] / as, tb);
+    for (int s0 = lane; s0 < S; s0 += 64) {  // lanes over states, one wave per frame, 4 frames in flight
+      const int cls = stl[s0];
+      for (int t = wave; t < nt; t += 4 * (CTC_THREADS / 64)) {
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int tu = t + u * (CTC_THREADS / 64);
+          o[u] = tu < nt ? rowbuf[tu * ncp + cls] / asum[tu] : 1.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int tu = t + u * (CTC_THREADS / 64);
+          const float l = cr_logf(o[u], tb);
+          if (tu < nt) lm[(size_t)(t0 + tu) * S + s0] = l;
+        }
+      }
     }
   }
   CTC_STAMP(1);
@@ -146,23 +166,27 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
       const bool rev = wave == 1;
       const BufF32 outb = make_buf(rev ? be : al, latbytes);
       const int j = lane;
-      auto loff = [&](int i) -> unsigned {
-        if (i >= T || j >= S) return BUF_OOB;
-        return (unsigned)(rev ? (size_t)(T - 1 - i) * S + (S - 1 - j) : (size_t)i * S + j) * 4u;
+      // lattice cell of (step i, state j): byte offset = lane part + wave-uniform frame part;
+      // masked lanes (j >= S) sit at BUF_OOB_BASE, prefetches past the end re-read the last frame
+      const unsigned lanepart = j < S ? (unsigned)(rev ? S - 1 - j : j) * 4u : BUF_OOB_BASE;
+      const unsigned rowbytes = (unsigned)S * 4u;
+      auto frame = [&](int i) -> unsigned {
+        const int ic = i < T ? i : T - 1;
+        return (unsigned)(rev ? T - 1 - ic : ic) * rowbytes;
       };
-      float v = (float)(-5.0 * j);
-      float lmA = buf_load(lmb, loff(0)), lmB = buf_load(lmb, loff(1));
+      float v = -5.0f * (float)j;            // skip * j, exact in float
+      float lmA = buf_load(lmb, lanepart + frame(0)), lmB = buf_load(lmb, lanepart + frame(1));
       float kaA = 0.0f, kaB = 0.0f;
       auto step = [&](const int i, float& lmr, float& ka) {
         KEEP_ALIVE(ka);
         float w = wave_shr1(v);
-        if (j == 0) w = (float)(-5.0 * i);
+        if (j == 0) w = -5.0f * (float)i;    // skip * i
         const float lmv = lmr;
-        lmr = buf_load(lmb, loff(i + 2));  // two frames ahead
         const float same = v + lmv;
         const float next = w + lmv;
+        lmr = buf_load(lmb, lanepart + frame(i + 2));  // two frames ahead
         v = ctc_log_add(same, next, tb);
-        buf_store(outb, loff(i), v);
+        buf_store(outb, lanepart + frame(i), v);
         ka = v;
       };
       int i = 0;
@@ -294,9 +318,21 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   const int sp = S | 1;
   for (int t0 = 0; t0 < T; t0 += TT) {
     const int nt = (T - t0) < TT ? (T - t0) : TT;
-    for (int t = wave; t < nt; t += CTC_THREADS / 64) {  // coalesced staging of the lattice tile
-      const float* src = al + (size_t)(t0 + t) * S;
-      for (int s0 = lane; s0 < S; s0 += 64) etile[t * sp + s0] = (float)((double)src[s0] * tot[s0]);
+    for (int s0 = lane; s0 < S; s0 += 64) {  // coalesced staging of the lattice tile, 4 frames in flight
+      const double it = tot[s0];
+      for (int t = wave; t < nt; t += 4 * (CTC_THREADS / 64)) {
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int tu = t + u * (CTC_THREADS / 64);
+          x[u] = tu < nt ? al[(size_t)(t0 + tu) * S + s0] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int tu = t + u * (CTC_THREADS / 64);
+          if (tu < nt) etile[tu * sp + s0] = (float)((double)x[u] * it);
+        }
+      }
     }
     for (int i = tid; i < nt * ncp; i += CTC_THREADS) rowbuf[i] = 0.0f;
     __syncthreads();
@@ -316,13 +352,24 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
       part[tid] = 1.0 / fmax(total, 1e-9);
     }
     __syncthreads();
-    for (int t = wave; t < nt; t += CTC_THREADS / 64) {  // coalesced write-out, one wave per frame
-      const double inv = part[t];
-      const size_t g0 = (size_t)(t0 + t) * nc;
-      for (int c = lane; c < nc; c += 64) {
-        const float av = (float)((double)rowbuf[t * ncp + c] * inv);
-        if (a.aligned) a.aligned[(size_t)off * nc + g0 + c] = av;
-        Dz[g0 + c] = av - P[g0 + c];
+    for (int c = lane; c < nc; c += 64) {  // coalesced write-out, one wave per frame, 4 frames in flight
+      for (int t = wave; t < nt; t += 4 * (CTC_THREADS / 64)) {
+        float p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int tu = t + u * (CTC_THREADS / 64);
+          p[u] = tu < nt ? P[(size_t)(t0 + tu) * nc + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int tu = t + u * (CTC_THREADS / 64);
+          if (tu < nt) {
+            const float av = (float)((double)rowbuf[tu * ncp + c] * part[tu]);
+            const size_t g0 = (size_t)(t0 + tu) * nc + c;
+            if (a.aligned) a.aligned[(size_t)off * nc + g0] = av;
+            Dz[g0] = av - p[u];
+          }
+        }
       }
     }
     __syncthreads();
