@@ -1,0 +1,192 @@
+// clstmhl.h -- CLSTMOCR (clstmhl.h:146-272) and Codec (clstm.h:82-93, clstm.cc:219-263) on top of the
+// C ABI of libclstm_hip.so.  Same members and call order as the reference: measure/normalize ->
+// set_inputs -> forward -> mktargets/ctc_align_targets -> backward -> trivial_decode -> sgd_update.
+// The host holds only small arrays (the line image, transcripts, decodes); all network arithmetic
+// runs on the MI355X.
+#pragma once
+#include "model.h"
+#include "normalizer.h"
+#include "png_io.h"
+
+namespace clstmhost {
+
+typedef vector<int> Classes;
+
+inline void chk(int rc, const char* what) {
+  if (rc) fail(string(what) + ": " + clstm_last_error());
+}
+
+struct Codec {
+  vector<int> codec;
+  std::map<int, int> encoder;
+  int size() const { return (int)codec.size(); }
+  void set(const vector<int>& a) {
+    codec = a;
+    encoder.clear();
+    for (int i = 0; i < (int)codec.size(); i++) encoder.insert(std::make_pair(codec[i], i));
+  }
+  void encode(Classes& cs, const ustring& s) const {  // clstm.cc:226-236 (asserts become errors)
+    cs.clear();
+    for (char32_t ch : s) {
+      auto it = encoder.find((int)ch);
+      if (it == encoder.end()) fail("character not in codec: U+" + std::to_string((unsigned)ch));
+      if (it->second == 0) fail("transcript maps to class 0 (reserved for blank)");
+      cs.push_back(it->second);
+    }
+  }
+  ustring decode(const Classes& cs) const {
+    ustring s;
+    for (int c : cs) s.push_back((char32_t)codec.at(c));
+    return s;
+  }
+  void build(const vector<string>& fnames, const ustring& extra = U"") {  // clstm.cc:246-267
+    std::set<int> codes;
+    codes.insert(0);
+    for (char32_t c : extra) codes.insert((int)c);
+    for (auto& fname : fnames) {
+      std::ifstream stream(fname);
+      string line;
+      while (getline(stream, line)) {
+        if (line.substr(0, 1) == "#") continue;
+        if (line.size() == 0) continue;
+        for (char32_t c : utf8_to_utf32(line)) codes.insert((int)c);
+      }
+    }
+    set(vector<int>(codes.begin(), codes.end()));
+  }
+};
+
+// trivial_decode (ctc.cc:159-190) on a host matrix [T][nc]; used for the "ALN" report line only
+inline void trivial_decode_host(Classes& cs, const float* out, int T, int nc) {
+  cs.clear();
+  float mv = 0;
+  int mc = -1;
+  for (int t = 0; t < T; t++) {
+    const float* p = out + (size_t)t * nc;
+    int index = -1;
+    float best = p[0];
+    for (int i = 0; i < nc; i++) {
+      if (p[i] < best) continue;
+      index = i;
+      best = p[i];
+    }
+    if (index == 0) {
+      if (mc != -1 && mc != 0) cs.push_back(mc);
+      mv = 0;
+      mc = -1;
+      continue;
+    }
+    if (best > mv) { mv = best; mc = index; }
+  }
+}
+
+struct CharPrediction { int i, x; char32_t c; float p; };
+
+struct CLSTMOCR {
+  Model model;
+  Codec codec;
+  CenterNormalizer normalizer;
+  clstm_net* net = nullptr;
+  int target_height = 48;
+  int nclasses = -1;
+  Image image;
+  vector<float> aligned;  // [T][nclasses] of the last fwdbwd
+  int T = 0;
+
+  ~CLSTMOCR() { if (net) clstm_net_destroy(net); }
+  void attach() {  // device network from the host model
+    if (net) { clstm_net_destroy(net); net = nullptr; }
+    chk(clstm_net_create(&net, &model.desc, nullptr, nullptr, nullptr), "clstm_net_create");
+    chk(clstm_net_set_params_h(net, model.params.data()), "clstm_net_set_params_h");
+    nclasses = model.desc.nclasses;
+    target_height = model.desc.ninput;
+    normalizer.target_height = target_height;
+    codec.set(model.codec);
+    const float lr = atof(attr_get("learning_rate", "1e-4").c_str());
+    const float mom = atof(attr_get("momentum", "0.9").c_str());
+    chk(clstm_net_set_learning_rate(net, lr, mom), "clstm_net_set_learning_rate");
+  }
+  string attr_get(const string& k, const string& dflt) const {
+    auto it = model.attr.find(k);
+    return it == model.attr.end() ? dflt : it->second;
+  }
+  void setLearningRate(float lr, float mom) {  // INetwork::setLearningRate, clstm.cc:158-161
+    model.attr["learning_rate"] = std::to_string((double)lr);   // String(double) = std::to_string
+    model.attr["momentum"] = std::to_string((double)mom);
+    if (net) chk(clstm_net_set_learning_rate(net, lr, mom), "clstm_net_set_learning_rate");
+  }
+  void createBidi(const vector<int>& codec_, int nhidden) {  // clstmhl.h:191-200
+    LCG lcg;
+    model.create("bidi", target_height, (int)codec_.size(), nhidden, 0, lcg);
+    model.codec = codec_;
+    attach();
+  }
+  void load(const string& fname) {  // clstmhl.h:157-175
+    model.load(fname);
+    attach();
+  }
+  void save(const string& fname) {
+    chk(clstm_net_get_params_h(net, model.params.data()), "clstm_net_get_params_h");
+    model.save(fname);
+  }
+  void set_line(const Image& raw) {  // measure / normalize / set_inputs, clstmhl.h:202-205
+    normalizer.measure(raw);
+    normalizer.normalize(image, raw);
+    T = image.w;
+    chk(clstm_net_set_batch(net, &T, 1), "clstm_net_set_batch");
+    chk(clstm_net_set_inputs_h(net, image.d.data()), "clstm_net_set_inputs_h");  // image(t,i) is frame-major
+  }
+  Classes decode_outputs(vector<int>* where = nullptr) {
+    vector<int> cls(T), loc(T);
+    int cnt = 0;
+    chk(clstm_net_decode(net, cls.data(), loc.data(), &cnt), "clstm_net_decode");
+    cls.resize(cnt);
+    if (where) where->assign(loc.begin(), loc.begin() + cnt);
+    return cls;
+  }
+  ustring fwdbwd(const Image& raw, const ustring& target) {  // clstmhl.h:201-217
+    set_line(raw);
+    chk(clstm_net_forward(net), "clstm_net_forward");
+    Classes transcript;
+    codec.encode(transcript, target);
+    const int L = (int)transcript.size();
+    aligned.resize((size_t)T * nclasses);
+    chk(clstm_net_ctc(net, transcript.data(), &L, aligned.data()), "clstm_net_ctc");
+    chk(clstm_net_backward(net), "clstm_net_backward");
+    return codec.decode(decode_outputs());
+  }
+  void update() { chk(clstm_net_update(net), "clstm_net_update"); }
+  ustring train(const Image& raw, const ustring& target) {
+    ustring r = fwdbwd(raw, target);
+    update();
+    return r;
+  }
+  string aligned_utf8() {  // clstmhl.h:224-229
+    Classes cs;
+    trivial_decode_host(cs, aligned.data(), T, nclasses);
+    return utf32_to_utf8(codec.decode(cs));
+  }
+  ustring predict(const Image& raw, vector<int>* where = nullptr) {  // clstmhl.h:233-242
+    set_line(raw);
+    chk(clstm_net_forward(net), "clstm_net_forward");
+    return codec.decode(decode_outputs(where));
+  }
+  string predict_utf8(const Image& raw) { return utf32_to_utf8(predict(raw)); }
+  void get_outputs(Image& out) {  // [T][nclasses]
+    out.resize(T, nclasses);
+    chk(clstm_net_get_outputs_h(net, out.d.data()), "clstm_net_get_outputs_h");
+  }
+  void predict(vector<CharPrediction>& preds, const Image& raw) {  // clstmhl.h:243-262
+    vector<int> where;
+    set_line(raw);
+    chk(clstm_net_forward(net), "clstm_net_forward");
+    Classes cs = decode_outputs(&where);
+    Image out;
+    get_outputs(out);
+    preds.clear();
+    for (int i = 0; i < (int)cs.size(); i++)
+      preds.push_back(CharPrediction{i, where[i], (char32_t)codec.codec[cs[i]], out(where[i], cs[i])});
+  }
+};
+
+}  // namespace clstmhost

@@ -1,0 +1,118 @@
+// clstmocrtrain -- the reference's OCR training driver (clstmocrtrain.cc:97-224) on the MI355X path:
+// same arguments, environment variables, stdout lines and model files; one text line per update.
+#include "clstmhl.h"
+using namespace clstmhost;
+
+struct Dataset {  // clstmocrtrain.cc:56-76
+  vector<string> fnames;
+  ustring charsep = utf8_to_utf32(getsenv("charsep", ""));
+  int size() { return (int)fnames.size(); }
+  void readFileList(const string& file_list) { read_lines(fnames, file_list); }
+  void getCodec(Codec& codec) {
+    vector<string> gtnames;
+    for (auto& s : fnames) gtnames.push_back(basename_noext(s) + ".gt.txt");
+    codec.build(gtnames, charsep);
+  }
+  ustring separate_chars(const ustring& s) {
+    if (charsep.empty()) return s;
+    ustring r;
+    for (size_t i = 0; i < s.size(); i++) {
+      if (i > 0) r.push_back(charsep[0]);
+      r.push_back(s[i]);
+    }
+    return r;
+  }
+  void readSample(Image& raw, ustring& gt, int index) {
+    const string& fname = fnames[index];
+    gt = separate_chars(utf8_to_utf32(read_text(basename_noext(fname) + ".gt.txt")));
+    read_png(raw, fname);
+    for (float& v : raw.d) v = -v + 1.0f;  // raw = 1 - raw: ink = 1 (clstmocrtrain.cc:73)
+  }
+};
+
+static int print_usage(char** argv) {
+  std::cerr << "Usage: [VAR=VAL...] " << argv[0] << " TRAININGLIST [TESTLIST]\n"
+            << "  Variables: load save_name nhidden lrate momentum target_height ntrain start charsep\n"
+            << "             report_time test_every report_every save_every params   (clstmocrtrain.cc:99-115)\n";
+  return EXIT_FAILURE;
+}
+
+static int main1(int argc, char** argv) {
+  if (argc < 2 || argc > 3 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) return print_usage(argv);
+  int ntrain = getienv("ntrain", 10000000);
+  string save_name = getsenv("save_name", "_ocr");
+  int report_time = getienv("report_time", 0);
+  Dataset trainingset, testset;
+  trainingset.readFileList(argv[1]);
+  if (trainingset.size() <= 0) fail("empty training list");
+  if (argc > 2) testset.readFileList(argv[2]);
+  std::cout << "got " << trainingset.size() << " files, " << testset.size() << " tests" << std::endl;
+  string load_name = getsenv("load", "");
+  CLSTMOCR clstm;
+  if (load_name != "") {
+    clstm.load(load_name);
+  } else {
+    Codec codec;
+    trainingset.getCodec(codec);
+    std::cout << "got " << codec.size() << " classes" << std::endl;
+    clstm.target_height = int(getrenv("target_height", 48));
+    clstm.createBidi(codec.codec, getienv("nhidden", 100));
+    clstm.setLearningRate(getdenv("lrate", 1e-4), getdenv("momentum", 0.9));
+  }
+  double test_error = 9999.0, best_error = 1e38;
+  double start_time = now();
+  int start = atoi(clstm.attr_get("trial", std::to_string(getienv("start", -1))).c_str()) + 1;
+  if (start > 0) std::cout << "start " << start << std::endl;
+  Trigger test_trigger(getienv("test_every", 10000), -1, start);
+  test_trigger.skip0();
+  Trigger save_trigger(getienv("save_every", 10000), ntrain, start);
+  save_trigger.enable(save_name != "").skip0();
+  Trigger report_trigger(getienv("report_every", 100), ntrain, start);
+  for (int trial = start; trial < ntrain; trial++) {
+    int sample = lrand48() % trainingset.size();
+    Image raw;
+    ustring gt;
+    trainingset.readSample(raw, gt, sample);
+    ustring pred = clstm.train(raw, gt);
+    if (report_trigger(trial)) {
+      std::cout << trial << std::endl;
+      std::cout << "TRU " << utf32_to_utf8(gt) << std::endl;
+      std::cout << "ALN " << clstm.aligned_utf8() << std::endl;
+      std::cout << "OUT " << utf32_to_utf8(pred) << std::endl;
+      if (trial > 0 && report_time) std::cout << "steptime " << (now() - start_time) / report_trigger.since() << std::endl;
+      start_time = now();
+    }
+    if (test_trigger(trial) && testset.size() > 0) {
+      double count = 0.0, errors = 0.0;
+      for (int test = 0; test < testset.size(); test++) {
+        Image traw;
+        ustring tgt;
+        testset.readSample(traw, tgt, test);
+        ustring tpred = clstm.predict(traw);
+        count += tgt.size();
+        errors += levenshtein(tpred, tgt);
+      }
+      test_error = errors / count;
+      std::cout << "ERROR " << trial << " " << test_error << "     " << errors << " " << count << std::endl;
+      if (test_error < best_error) {
+        best_error = test_error;
+        string fname = save_name + ".clstm";
+        std::cout << "saving best performing network so far " << fname << " error rate:  " << best_error << std::endl;
+        clstm.model.attr["trial"] = std::to_string(trial);
+        clstm.save(fname);
+      }
+    }
+    if (save_trigger(trial) && save_trigger.enabled) {
+      string fname = save_name + "-" + std::to_string(trial) + ".clstm";
+      std::cout << "saving " << fname << std::endl;
+      clstm.model.attr["trial"] = std::to_string(trial);
+      clstm.save(fname);
+    }
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  try { return main1(argc, argv); }
+  catch (const std::exception& e) { std::cerr << "FATAL: " << e.what() << std::endl; return 1; }
+}

