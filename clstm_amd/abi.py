@@ -108,6 +108,13 @@ class Lib:
                 "HIP extension not built: %s is missing (no CPU fallback exists; build it with "
                 "`make -C clstm_amd/csrc` or __graft_entry__.build())" % path)
         self.path = path
+        # PyTorch-ROCm bundles its own HIP runtime; if libclstm_hip.so pulled /opt/rocm's copy into the
+        # process first, torch would later find the GPU "unavailable".  Let torch load its runtime first.
+        if os.path.basename(path).startswith("libclstm_hip"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         self.dll = C.CDLL(path)
         self.dll.clstm_last_error.restype = C.c_char_p
         self.dll.clstm_last_error.argtypes = []
