@@ -189,4 +189,91 @@ struct CLSTMOCR {
   }
 };
 
+// CLSTMText (clstmhl.h:24-144): text in, text out through the same BiLSTM + CTC path; characters are
+// one-hot frames separated by `neps` all-zero frames (setInputs, clstmhl.h:83-100).
+struct CLSTMText {
+  Model model;
+  Codec codec, icodec;
+  clstm_net* net = nullptr;
+  int nclasses = -1, iclasses = -1;
+  int neps = 3;  // the reference never overrides it: maybe_load() shadows the member (clstmhl.h:53)
+  vector<float> frames, aligned;
+  int T = 0;
+  ~CLSTMText() { if (net) clstm_net_destroy(net); }
+  void attach() {
+    if (net) { clstm_net_destroy(net); net = nullptr; }
+    chk(clstm_net_create(&net, &model.desc, nullptr, nullptr, nullptr), "clstm_net_create");
+    chk(clstm_net_set_params_h(net, model.params.data()), "clstm_net_set_params_h");
+    nclasses = model.desc.nclasses;
+    iclasses = model.desc.ninput;
+    codec.set(model.codec);
+    icodec.set(model.icodec);
+    auto get = [&](const char* k, const char* d) { auto it = model.attr.find(k); return it == model.attr.end() ? string(d) : it->second; };
+    chk(clstm_net_set_learning_rate(net, atof(get("learning_rate", "1e-4").c_str()), atof(get("momentum", "0.9").c_str())),
+        "clstm_net_set_learning_rate");
+  }
+  void setLearningRate(float lr, float mom) {
+    model.attr["learning_rate"] = std::to_string((double)lr);
+    model.attr["momentum"] = std::to_string((double)mom);
+    if (net) chk(clstm_net_set_learning_rate(net, lr, mom), "clstm_net_set_learning_rate");
+  }
+  void createBidi(const vector<int>& icodec_, const vector<int>& codec_, int nhidden) {  // clstmhl.h:70-82
+    LCG lcg;
+    model.create("bidi", (int)icodec_.size(), (int)codec_.size(), nhidden, 0, lcg);
+    model.attr["neps"] = std::to_string(neps);
+    model.icodec = icodec_;
+    model.codec = codec_;
+    attach();
+  }
+  void load(const string& fname) { model.load(fname); attach(); }
+  void save(const string& fname) {
+    chk(clstm_net_get_params_h(net, model.params.data()), "clstm_net_get_params_h");
+    model.save(fname);
+  }
+  void setInputs(const ustring& s) {
+    Classes cs;
+    icodec.encode(cs, s);
+    T = (int)cs.size() * (neps + 1) + neps;
+    frames.assign((size_t)T * iclasses, 0.0f);
+    int index = neps;
+    for (int c : cs) {
+      frames[(size_t)index * iclasses + c] = 1.0f;
+      index += neps + 1;
+    }
+    chk(clstm_net_set_batch(net, &T, 1), "clstm_net_set_batch");
+    chk(clstm_net_set_inputs_h(net, frames.data()), "clstm_net_set_inputs_h");
+  }
+  ustring decode_outputs() {
+    vector<int> cls(T), loc(T);
+    int cnt = 0;
+    chk(clstm_net_decode(net, cls.data(), loc.data(), &cnt), "clstm_net_decode");
+    cls.resize(cnt);
+    return codec.decode(cls);
+  }
+  ustring train(const ustring& in, const ustring& target) {  // clstmhl.h:103-117
+    setInputs(in);
+    chk(clstm_net_forward(net), "clstm_net_forward");
+    Classes transcript;
+    codec.encode(transcript, target);
+    const int L = (int)transcript.size();
+    aligned.resize((size_t)T * nclasses);
+    chk(clstm_net_ctc(net, transcript.data(), &L, aligned.data()), "clstm_net_ctc");
+    chk(clstm_net_backward(net), "clstm_net_backward");
+    ustring out = decode_outputs();   // decode before the update, as the reference's outputs are
+    chk(clstm_net_update(net), "clstm_net_update");
+    return out;
+  }
+  ustring predict(const ustring& in) {
+    setInputs(in);
+    chk(clstm_net_forward(net), "clstm_net_forward");
+    return decode_outputs();
+  }
+  string predict_utf8(const string& in) { return utf32_to_utf8(predict(utf8_to_utf32(in))); }
+  string aligned_utf8() {
+    Classes cs;
+    trivial_decode_host(cs, aligned.data(), T, nclasses);
+    return utf32_to_utf8(codec.decode(cs));
+  }
+};
+
 }  // namespace clstmhost

@@ -31,7 +31,7 @@ struct LCG {
 struct Model {
   clstm_net_desc desc{};
   vector<float> params;  // flat, walk_params order
-  vector<int> codec;
+  vector<int> codec, icodec;
   std::map<string, string> attr;  // top-level attributes (kind, learning_rate, momentum, trial, ...)
 
   int ndir() const { return desc.unidirectional ? 1 : 2; }
@@ -106,6 +106,7 @@ struct Model {
     top.ninput = desc.ninput;
     top.noutput = desc.nclasses;
     top.codec = codec;
+    top.icodec = icodec;
     for (auto& kv : attr) {
       if (kv.first == "name" || kv.first == "ninput" || kv.first == "noutput") continue;
       top.attribute.emplace_back(kv.first, kv.second);
@@ -192,6 +193,7 @@ struct Model {
     }
     params_of(&params[off], weight(sm, "W1"), desc.nclasses, ni + 1);
     codec = top.codec;
+    icodec = top.icodec;
     attr.clear();
     for (auto& kv : top.attribute) attr[kv.first] = kv.second;
   }

@@ -77,3 +77,22 @@ def test_fixture_online_sgd_matches_oracle(tmp_path, ora32):
         net.ctc([tr]); net.backward(); net.update()
         assert got_dec == want_dec, "decode differs at step %d" % step
         assert_close(net.get_params(), ref.get_params(), rtol=1e-4, atol=1e-9, scale_atol=1e-4, what="params step %d" % step)
+
+
+@pytest.mark.gpu
+def test_reference_cli_test_filter(tmp_path):
+    """test-filter.sh:5-9: clstmfiltertrain learns 'hello' -> 'hello' in 1001 iterations (lrate 1e-2),
+    clstmfilter with _filter-1000.clstm prints hello.  (run-cmu is the same path on misc/cmu-*.txt.)"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "clstm_amd", "host"), "-s", "all"])
+    txt = tmp_path / "_filter.txt"
+    txt.write_text("hello\thello\n")
+    env = dict(os.environ, hidden="20", ntrain="1001", neps="0", report_every="200", save_every="1000", lrate="1e-2",
+               save_name=str(tmp_path / "_filter"))
+    r = subprocess.run([os.path.join(BIN, "clstmfiltertrain"), str(txt)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "INP hello" in r.stdout
+    model = tmp_path / "_filter-1000.clstm"
+    assert model.exists()
+    r2 = subprocess.run([os.path.join(BIN, "clstmfilter"), str(txt)], env=dict(os.environ, load=str(model)),
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and "hello" in r2.stdout.split("\n")
