@@ -311,10 +311,9 @@ struct Net {
     hipStream_t s = stream();
     for (auto& y : L) {
       const int M = ndir * 4 * y.no, KQP = 4 * y.nk4;
-      CLSTM_LAUNCH(k_pack_wx, dim3(nblocks((size_t)(1 + y.ni) * M)), dim3(256), 0, s, (const float*)v, y.Wt, y.bias, y.pd);
       const size_t nr = (size_t)ndir * 4 * KQP * y.nthreads;
-      CLSTM_LAUNCH(k_pack_rf, dim3(nblocks(nr)), dim3(256), 0, s, (const float*)v, y.Rf, y.pd);
-      CLSTM_LAUNCH(k_pack_rb, dim3(nblocks(nr)), dim3(256), 0, s, (const float*)v, y.Rb, y.pd);
+      CLSTM_LAUNCH(k_pack_layer, dim3(nblocks((size_t)(1 + y.ni) * M + 2 * nr)), dim3(256), 0, s, (const float*)v, y.Wt,
+                   y.bias, y.Rf, y.Rb, y.pd);
     }
     check_launch();
     packed_dirty = false;
@@ -392,8 +391,8 @@ struct Net {
   }
 
   // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
-  int pick_split(int R, int Cn) const {
-    const long long tiles = (long long)((R + GEMM_BT - 1) / GEMM_BT) * ((Cn + GEMM_BT - 1) / GEMM_BT);
+  int pick_split(int R, int Cn, int nbatch = 1) const {
+    const long long tiles = (long long)((R + GEMM_BT - 1) / GEMM_BT) * ((Cn + GEMM_BT - 1) / GEMM_BT) * nbatch;
     static const long long target = getenv("CLSTM_SPLIT_TARGET") ? atoll(getenv("CLSTM_SPLIT_TARGET")) : 768;
     long long want = (target + tiles - 1) / tiles;
     const long long maxs = (N + 63) / 64;   // at least 64 frames per slab
@@ -409,7 +408,7 @@ struct Net {
     hipStream_t s = stream();
     const int nc = desc.nclasses;
     const float* W1 = v + sm_off;
-    HIPCHECK(hipMemsetAsync(g, 0, (size_t)nparams * sizeof(float), s));
+    // every entry of g is assigned by exactly one reduce below: no clearing pass
     // SoftmaxLayer::backward (clstm.cc:411-417): x.d = W^T z.d ; W.d += z.d [1;x]^T
     Layer& top = L.back();
     {  // (a side stream for this GEMM was measured on MI355X: no gain -- the recurrence workgroups it would
@@ -419,7 +418,7 @@ struct Net {
       timing.begin("gemm_softmax_dw", s);
       gemm_f32<GEMM_MC, GEMM_MC>(s, gemm_mc(Ssm.p, 1 + sm_ni, N), gemm_mc(Dz.p, nc, N), StorePartial{partial.p, R, Cn},
                                  R, Cn, (int)N, ns);
-      CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns, R, Cn,
+      CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns, 1, R, Cn,
                    g, (const long long*)nullptr, (long long)sm_off, nc);
       timing.end(s);
     }
@@ -438,16 +437,15 @@ struct Net {
       launch_lstm(false, y.nk4, a, bs, y.nthreads, s);
       timing.end(s);
       // W.d += delta [1; x_t; h_{t-1}]^T for the four gates of each direction
-      const int R = 1 + y.ni + y.no, Cn = 4 * y.no, ns = pick_split(R, Cn);
-      partial.reserve((size_t)ns * R * Cn);
+      // (both directions in one batched launch: half the slabs per direction fill the chip)
+      const int R = 1 + y.ni + y.no, Cn = 4 * y.no, ns = pick_split(R, Cn, ndir);
+      partial.reserve((size_t)ndir * ns * R * Cn);
       timing.begin("gemm_gates_dw", s);
-      for (int dir = 0; dir < ndir; dir++) {
-        gemm_f32<GEMM_MC, GEMM_MC>(s, gemm_mc(y.S.p + (size_t)dir * N * y.lds, y.lds, N),
-                                   gemm_mc(y.D.p + (size_t)dir * 4 * y.no, M, N, 0), StorePartial{partial.p, R, Cn},
-                                   R, Cn, (int)N, ns);
-        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns, R, Cn,
-                     g, (const long long*)(y.moff + (size_t)dir * 4 * y.no), 0LL, y.no);
-      }
+      gemm_f32<GEMM_MC, GEMM_MC>(s, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
+                                 gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
+                                 StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns, ndir);
+      CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)ndir * R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns,
+                   ndir, R, Cn, g, (const long long*)y.moff, 0LL, y.no);
       timing.end(s);
       check_launch();
       // input deltas: x.d = sum_dir W_x^T delta (Parallel::backward sums both subs, clstm.cc:538-541)
@@ -480,9 +478,8 @@ struct CtcWorkspace {
   PinnedRing ring;
   DevBuf<long long> prof;
   DevBuf<double> tables;
-  DevBuf<int> line_off, states, state_off;
+  DevBuf<char> meta;
   DevBuf<float> lat;
-  DevBuf<long long> lat_off;
 };
 static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* aligned, int nc,
                     const int* line_off_h, const int* states_h, const int* state_off_h, int bs,
@@ -497,25 +494,24 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
   }
   const int ns = state_off_h[bs];
   for (int i = 0; i < ns; i++) REQUIRE(states_h[i] >= 0 && states_h[i] < nc, "target class out of range");
-  w.line_off.reserve(bs + 1); w.state_off.reserve(bs + 1); w.states.reserve(ns > 0 ? ns : 1);
-  w.lat_off.reserve(bs + 1); w.lat.reserve((size_t)(lo[bs] > 0 ? lo[bs] : 1));
-  {  // one pinned slot: [lat_off (bs+1 x i64) | line_off | state_off | states]
-    const size_t nlo = (size_t)(bs + 1) * sizeof(long long), nio = (size_t)(bs + 1) * sizeof(int);
-    const size_t nst = (size_t)(ns > 0 ? ns : 1) * sizeof(int);
+  w.lat.reserve((size_t)(lo[bs] > 0 ? lo[bs] : 1));
+  // one pinned slot, one device block, one copy: [lat_off (bs+1 x i64) | line_off | state_off | states]
+  const size_t nlo = (size_t)(bs + 1) * sizeof(long long), nio = (size_t)(bs + 1) * sizeof(int);
+  const size_t nst = (size_t)(ns > 0 ? ns : 1) * sizeof(int);
+  w.meta.reserve(nlo + 2 * nio + nst);
+  {
     char* stage = (char*)w.ring.acquire(nlo + 2 * nio + nst);
     memcpy(stage, lo.data(), nlo);
     memcpy(stage + nlo, line_off_h, nio);
     memcpy(stage + nlo + nio, state_off_h, nio);
     if (ns > 0) memcpy(stage + nlo + 2 * nio, states_h, (size_t)ns * sizeof(int));
-    HIPCHECK(hipMemcpyAsync(w.lat_off.p, stage, nlo, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(w.line_off.p, stage + nlo, nio, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(w.state_off.p, stage + nlo + nio, nio, hipMemcpyHostToDevice, s));
-    if (ns > 0) HIPCHECK(hipMemcpyAsync(w.states.p, stage + nlo + 2 * nio, (size_t)ns * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(w.meta.p, stage, nlo + 2 * nio + nst, hipMemcpyHostToDevice, s));
     w.ring.commit(s);
   }
   CtcArgs a{};
-  a.P = probs; a.Dz = deltas; a.aligned = aligned; a.line_off = w.line_off.p; a.states = w.states.p;
-  a.state_off = w.state_off.p; a.lat = w.lat.p; a.lat_off = w.lat_off.p; a.nc = nc;
+  a.P = probs; a.Dz = deltas; a.aligned = aligned; a.line_off = (const int*)(w.meta.p + nlo);
+  a.states = (const int*)(w.meta.p + nlo + 2 * nio); a.state_off = (const int*)(w.meta.p + nlo + nio);
+  a.lat = w.lat.p; a.lat_off = (const long long*)w.meta.p; a.nc = nc;
   w.prof.reserve(8); a.prof = w.prof.p; g_last_ctc_prof = w.prof.p;
   if (!w.tables.p) {
     w.tables.reserve(160);
@@ -842,10 +838,9 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     if (!part) part = new DevBuf<float>();
     if (nsplit < 1) nsplit = 1;
     part->reserve((size_t)nsplit * R * Cn);
-    HIPCHECK(hipMemsetAsync(Cm, 0, (size_t)R * Cn * sizeof(float), g_stream));
     gemm_f32<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream, (const float*)part->p, nsplit,
-                 R, Cn, Cm, (const long long*)nullptr, 0LL, Cn);
+                 1, R, Cn, Cm, (const long long*)nullptr, 0LL, Cn);
   } else throw Error("bad mode");
   check_launch();
   ABI_END

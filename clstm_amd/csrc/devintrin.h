@@ -101,6 +101,13 @@ DEVFN float buf_load(BufF32 b, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, byte_off, 0, 0));
 }
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+DEVFN f32x2 buf_load2(BufF32 b, unsigned byte_off) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b.r, byte_off, 0, 0));
+}
+DEVFN void buf_store2(BufF32 b, unsigned byte_off, f32x2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, v), b.r, byte_off, 0, 0);
+}
 DEVFN f32x4 buf_load4(BufF32 b, unsigned byte_off) {  // 16 bytes, dword alignment suffices
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, byte_off, 0, 0));
 }
@@ -112,6 +119,9 @@ DEVFN void buf_store(BufF32 b, unsigned byte_off, float v) {
 // wait before that register may be overwritten.  KEEP_ALIVE(x) placed two recurrence steps later
 // pins the register until then, which moves that wait off the per-step critical path.
 #define KEEP_ALIVE(x) asm volatile("" ::"v"(x))
+// instruction-scheduling fence: nothing is moved across it (keeps load issue order = source order)
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define KEEP_ALIVE2(x) asm volatile("" ::"v"(x))
 
 template <typename T>
 DEVFN T* dyn_smem() {

@@ -17,9 +17,10 @@
 // neighbouring finite data whose products land in outputs that are never stored, accesses past the
 // array end are dropped by the descriptor's bounds check, and the k tail is masked by four selects.
 // MC tiles go to LDS with one ds_write_b128, KC tiles are transposed by four ds_write_b32.  The
-// next tile's global loads fly under the MFMAs.
-// blockIdx.z = split-K slab; the epilogue functor receives it (deterministic slab reduction in
-// ops.h:k_reduce_scatter).
+// global loads of the next GEMM_PF tiles fly under the MFMAs.
+// blockIdx.z = batch * nsplit + split-K slab; operand pointers advance by `bstride` floats per batch
+// entry (the two directions of a BiLSTM layer share one launch); the epilogue functor receives
+// blockIdx.z (deterministic slab reduction in ops.h:k_reduce_scatter).
 #pragma once
 #include "devintrin.h"
 
@@ -29,16 +30,18 @@ enum { GEMM_KC = 0, GEMM_MC = 1 };
 constexpr int GEMM_BT = 64;   // tile rows / cols
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_LD = 80;
+constexpr int GEMM_PF = 3;   // k-tiles prefetched in registers
 
 struct GemmOperand {
   const float* p;
   int ld;
   long long elems;  // floats readable from p (array extent; may include up to 3 floats of slack)
+  long long bstride;  // floats between batch entries (0: shared by all batch entries)
 };
 
 template <int AMODE, int BMODE, class FE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
-                                                       int K, int ksplit) {
+                                                       int K, int ksplit, int nsplit) {
   __shared__ __attribute__((aligned(16))) float As[GEMM_BK * GEMM_LD];
   __shared__ __attribute__((aligned(16))) float Bs[GEMM_BK * GEMM_LD];
   const int tid = threadIdx.x;
@@ -46,7 +49,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperan
   const int wm = wave >> 1, wn = wave & 1;
   const int r0 = blockIdx.y * GEMM_BT, c0 = blockIdx.x * GEMM_BT;
   const int z = blockIdx.z;
-  const int kbeg = z * ksplit;
+  const int batch = z / nsplit;
+  const int kbeg = (z - batch * nsplit) * ksplit;
   const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
 
   // staging coordinates of this thread's float4:
@@ -56,17 +60,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperan
   const int a_k = AMODE == GEMM_KC ? (tid & 3) * 4 : (tid >> 4);
   const int b_mn = BMODE == GEMM_KC ? (tid >> 2) : (tid & 15) * 4;
   const int b_k = BMODE == GEMM_KC ? (tid & 3) * 4 : (tid >> 4);
-  const BufF32 abuf = make_buf(A.p, (size_t)A.elems * 4);
-  const BufF32 bbuf = make_buf(B.p, (size_t)B.elems * 4);
+  const BufF32 abuf = make_buf(A.p + batch * A.bstride, (size_t)(A.elems - batch * A.bstride) * 4);
+  const BufF32 bbuf = make_buf(B.p + batch * B.bstride, (size_t)(B.elems - batch * B.bstride) * 4);
   const unsigned a_base = AMODE == GEMM_KC ? (unsigned)(r0 + a_mn) * A.ld + a_k : (unsigned)a_k * A.ld + r0 + a_mn;
   const unsigned b_base = BMODE == GEMM_KC ? (unsigned)(c0 + b_mn) * B.ld + b_k : (unsigned)b_k * B.ld + c0 + b_mn;
   const unsigned a_kstep = AMODE == GEMM_KC ? 1u : (unsigned)A.ld, b_kstep = BMODE == GEMM_KC ? 1u : (unsigned)B.ld;
 
-  f32x4 ra, rb;
-  auto load_tile = [&](int k0) {
-    ra = buf_load4(abuf, (a_base + (unsigned)k0 * a_kstep) * 4u);
-    rb = buf_load4(bbuf, (b_base + (unsigned)k0 * b_kstep) * 4u);
-    // frames / contraction indices past the slab hold real data (next slab, next row): mask them
+  // Loads are issued unconditionally (tiles past the slab get an out-of-range offset, which the
+  // descriptor drops without touching memory): with a fixed number of loads per phase the compiler
+  // can count vmcnt exactly instead of draining the queue at every control-flow join.
+  auto load_tile = [&](int k0, f32x4& ra, f32x4& rb) {
+    const bool live = k0 < kend;
+    ra = buf_load4(abuf, live ? (a_base + (unsigned)k0 * a_kstep) * 4u : BUF_OOB);
+    rb = buf_load4(bbuf, live ? (b_base + (unsigned)k0 * b_kstep) * 4u : BUF_OOB);
+  };
+  // frames / contraction indices past the slab hold real data (next slab, next row): zero them.  Done
+  // when the tile is staged, not when it is loaded -- touching the registers earlier would put a
+  // vmcnt wait right behind the load and serialise the prefetch.
+  auto mask_tile = [&](int k0, f32x4& ra, f32x4& rb) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       ra[i] = (k0 + a_k + (AMODE == GEMM_KC ? i : 0) < kend) ? ra[i] : 0.0f;
@@ -82,37 +93,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperan
 #pragma unroll
       for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
 
+  // GEMM_PF k-tiles are in flight in registers: a tile's global loads are issued GEMM_PF iterations
+  // before it is staged, which covers the ~2000-cycle HBM latency with MFMA work of the same workgroup
+  // (the grids here are only 1-3 workgroups per CU, so there is little inter-workgroup overlap to lean on)
+  f32x4 ra[GEMM_PF], rb[GEMM_PF];
+#pragma unroll
+  for (int p = 0; p < GEMM_PF; p++) {
+    load_tile(kbeg + p * GEMM_BK, ra[p], rb[p]);
+    SCHED_FENCE();   // same issue order as inside the loop, so the vmcnt at the loop head stays exact
+  }
   const int fk = lane >> 4, fi = lane & 15;
-  if (kbeg < kend) load_tile(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
-    if (AMODE == GEMM_KC) {
+  for (int kb = kbeg; kb < kend; kb += GEMM_PF * GEMM_BK) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) As[(a_k + i) * GEMM_LD + a_mn] = ra[i];
-    } else {
-      *reinterpret_cast<f32x4*>(&As[a_k * GEMM_LD + a_mn]) = ra;
-    }
-    if (BMODE == GEMM_KC) {
+    for (int p = 0; p < GEMM_PF; p++) {
+      const int k0 = kb + p * GEMM_BK;   // phases past the slab multiply zeros (no early exit: the
+                                         // straight-line body keeps the accumulators and vmcnt exact)
+      mask_tile(k0, ra[p], rb[p]);
+      if (AMODE == GEMM_KC) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) Bs[(b_k + i) * GEMM_LD + b_mn] = rb[i];
-    } else {
-      *reinterpret_cast<f32x4*>(&Bs[b_k * GEMM_LD + b_mn]) = rb;
-    }
-    __syncthreads();
-    if (k0 + GEMM_BK < kend) load_tile(k0 + GEMM_BK);  // global loads fly under the MFMAs
-#pragma unroll
-    for (int kk = 0; kk < GEMM_BK; kk += 4) {
-      float af[2], bf[2];
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        af[i] = As[(kk + fk) * GEMM_LD + wm * 32 + i * 16 + fi];
-        bf[i] = Bs[(kk + fk) * GEMM_LD + wn * 32 + i * 16 + fi];
+        for (int i = 0; i < 4; i++) As[(a_k + i) * GEMM_LD + a_mn] = ra[p][i];
+      } else {
+        *reinterpret_cast<f32x4*>(&As[a_k * GEMM_LD + a_mn]) = ra[p];
       }
+      if (BMODE == GEMM_KC) {
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 4; i++) Bs[(b_k + i) * GEMM_LD + b_mn] = rb[p][i];
+      } else {
+        *reinterpret_cast<f32x4*>(&Bs[b_k * GEMM_LD + b_mn]) = rb[p];
+      }
+      __syncthreads();
+      load_tile(k0 + GEMM_PF * GEMM_BK, ra[p], rb[p]);
+      SCHED_FENCE();
 #pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = mfma16x16x4(af[i], bf[j], acc[i][j]);
+      for (int kk = 0; kk < GEMM_BK; kk += 4) {
+        float af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          af[i] = As[(kk + fk) * GEMM_LD + wm * 32 + i * 16 + fi];
+          bf[i] = Bs[(kk + fk) * GEMM_LD + wn * 32 + i * 16 + fi];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = mfma16x16x4(af[i], bf[j], acc[i][j]);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -129,21 +155,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperan
 // Operand constructors.  `slack` floats after the array may be read (and are multiplied into outputs
 // that are never stored): library-owned buffers are over-allocated, so 3 is always safe for them.
 inline GemmOperand gemm_kc(const float* p, int ld, long long rows, int slack = 3) {
-  return GemmOperand{p, ld, rows * (long long)ld + slack};
+  return GemmOperand{p, ld, rows * (long long)ld + slack, 0};
 }
 inline GemmOperand gemm_mc(const float* p, int ld, long long frames, int slack = 3) {
-  return GemmOperand{p, ld, frames * (long long)ld + slack};
+  return GemmOperand{p, ld, frames * (long long)ld + slack, 0};
+}
+// batch entry b reads from p + b*bstride; `elems` must cover the last entry
+inline GemmOperand gemm_batched(GemmOperand o, long long bstride, int nbatch) {
+  o.elems += bstride * (nbatch - 1);
+  o.bstride = bstride;
+  return o;
 }
 
 template <int AMODE, int BMODE, class FE>
-inline void gemm_f32(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int nsplit = 1) {
+inline void gemm_f32(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int nsplit = 1,
+                     int nbatch = 1) {
   if (R <= 0 || Cn <= 0) return;
   if (nsplit < 1) nsplit = 1;
   int ksplit = (K + nsplit - 1) / nsplit;
-  ksplit = ((ksplit + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
-  if (ksplit < GEMM_BK) ksplit = GEMM_BK;
-  dim3 grid((Cn + GEMM_BT - 1) / GEMM_BT, (R + GEMM_BT - 1) / GEMM_BT, nsplit);
-  CLSTM_LAUNCH((gemm_f32_kernel<AMODE, BMODE, FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit);
+  const int kq = nsplit > 1 ? GEMM_PF * GEMM_BK : GEMM_BK;   // whole pipeline rounds per slab
+  ksplit = ((ksplit + kq - 1) / kq) * kq;
+  if (ksplit < kq) ksplit = kq;
+  dim3 grid((Cn + GEMM_BT - 1) / GEMM_BT, (R + GEMM_BT - 1) / GEMM_BT, nsplit * nbatch);
+  CLSTM_LAUNCH((gemm_f32_kernel<AMODE, BMODE, FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
 }
 
 }  // namespace clstm

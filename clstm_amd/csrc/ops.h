@@ -173,54 +173,58 @@ struct PackDesc {
   long long p_off[2][4];  // flat offsets of (dir, slot) blocks; slot 0 gi,1 gf,2 go,3 ci
   int ni, no, ndir, nk4, nthreads;
 };
-// Wt[k][m] (k < ni, m = dir*4no + 4*cell + slot) and bias[m] for the hoisted input GEMM
-__global__ void k_pack_wx(const float* v, float* Wt, float* bias, PackDesc p) {
+// One launch repacks a layer's parameters after every update:
+//   Wt[k][m] (k < ni, m = dir*4no + 4*cell + slot) and bias[m] for the hoisted input GEMM,
+//   Rf[dir][(g*KQP + kk)][tid] = R_g[cell][q*KQP + kk]          forward recurrence registers,
+//   Rb[dir][(i*SLP + pp)][tid] = R_g[j][4*kg + i], (g,j) = pair js*SL+pp   backward recurrence registers.
+DEVFN void pack_wx(size_t e, const float* v, float* Wt, float* bias, const PackDesc& p) {
   const int M = p.ndir * 4 * p.no;
-  CLSTM_GRID_STRIDE(e, (size_t)(1 + p.ni) * M) {
-    const int j = e / M, m = e % M;
-    const int dir = m / (4 * p.no), c = (m % (4 * p.no)) >> 2, s = m & 3;
-    const float x = v[p.p_off[dir][s] + c + (size_t)p.no * j];
-    if (j == 0) bias[m] = x;
-    else Wt[(size_t)(j - 1) * M + m] = x;
-  }
+  const int j = e / M, m = e % M;
+  const int dir = m / (4 * p.no), c = (m % (4 * p.no)) >> 2, s = m & 3;
+  const float x = v[p.p_off[dir][s] + c + (size_t)p.no * j];
+  if (j == 0) bias[m] = x;
+  else Wt[(size_t)(j - 1) * M + m] = x;
 }
-// forward recurrence registers: Rf[dir][(g*KQP + kk)][tid] = R_g[cell][q*KQP + kk]
-__global__ void k_pack_rf(const float* v, float* Rf, PackDesc p) {
+DEVFN void pack_rf(size_t e, const float* v, float* Rf, const PackDesc& p) {
   const int KQP = 4 * p.nk4;
   const size_t per_dir = (size_t)4 * KQP * p.nthreads;
-  CLSTM_GRID_STRIDE(e, per_dir * p.ndir) {
-    const int dir = e / per_dir;
-    const size_t r = e % per_dir;
-    const int tid = r % p.nthreads, gk = r / p.nthreads;
-    const int g = gk / KQP, kk = gk % KQP;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int cell = wave * 16 + (lane >> 2), q = lane & 3;
-    const int k = q * KQP + kk;
-    float x = 0.0f;
-    if (cell < p.no && k < p.no) x = v[p.p_off[dir][g] + cell + (size_t)p.no * (1 + p.ni + k)];
-    Rf[e] = x;
-  }
+  const int dir = e / per_dir;
+  const size_t r = e % per_dir;
+  const int tid = r % p.nthreads, gk = r / p.nthreads;
+  const int g = gk / KQP, kk = gk % KQP;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int cell = wave * 16 + (lane >> 2), q = lane & 3;
+  const int k = q * KQP + kk;
+  float x = 0.0f;
+  if (cell < p.no && k < p.no) x = v[p.p_off[dir][g] + cell + (size_t)p.no * (1 + p.ni + k)];
+  Rf[e] = x;
 }
-// backward recurrence registers: Rb[dir][(i*SLP + pp)][tid] = R_g[j][4*kg + i], (g,j) = pair js*SL+pp
-__global__ void k_pack_rb(const float* v, float* Rb, PackDesc p) {
+DEVFN void pack_rb(size_t e, const float* v, float* Rb, const PackDesc& p) {
   const int SLP = 4 * p.nk4;
   const int SL = (4 * p.no + 15) / 16;
   const size_t per_dir = (size_t)4 * SLP * p.nthreads;
-  CLSTM_GRID_STRIDE(e, per_dir * p.ndir) {
-    const int dir = e / per_dir;
-    const size_t r = e % per_dir;
-    const int tid = r % p.nthreads, ip = r / p.nthreads;
-    const int i = ip / SLP, pp = ip % SLP;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int kcell = 4 * (wave * 4 + (lane >> 4)) + i;
-    const int js = lane & 15;
-    const int pr = js * SL + pp;
-    float x = 0.0f;
-    if (pp < SL && pr < 4 * p.no && kcell < p.no) {
-      const int g = pr / p.no, j = pr % p.no;
-      x = v[p.p_off[dir][g] + j + (size_t)p.no * (1 + p.ni + kcell)];
-    }
-    Rb[e] = x;
+  const int dir = e / per_dir;
+  const size_t r = e % per_dir;
+  const int tid = r % p.nthreads, ip = r / p.nthreads;
+  const int i = ip / SLP, pp = ip % SLP;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int kcell = 4 * (wave * 4 + (lane >> 4)) + i;
+  const int js = lane & 15;
+  const int pr = js * SL + pp;
+  float x = 0.0f;
+  if (pp < SL && pr < 4 * p.no && kcell < p.no) {
+    const int g = pr / p.no, j = pr % p.no;
+    x = v[p.p_off[dir][g] + j + (size_t)p.no * (1 + p.ni + kcell)];
+  }
+  Rb[e] = x;
+}
+__global__ void k_pack_layer(const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p) {
+  const size_t nwx = (size_t)(1 + p.ni) * p.ndir * 4 * p.no;
+  const size_t nr = (size_t)p.ndir * 4 * 4 * p.nk4 * p.nthreads;
+  CLSTM_GRID_STRIDE(e, nwx + 2 * nr) {
+    if (e < nwx) pack_wx(e, v, Wt, bias, p);
+    else if (e < nwx + nr) pack_rf(e - nwx, v, Rf, p);
+    else pack_rb(e - nwx - nr, v, Rb, p);
   }
 }
 // S[dir][n][0] = 1, S[dir][n][1..ni] = x_n for every direction: the non-recurrent part of the source
@@ -233,15 +237,27 @@ __global__ void k_build_source(float* S, const float* x, size_t N, int ni, int l
     for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = v;
   }
 }
-// g[off(c) + rs*r] += sum_z partial[z][r][c]   (deterministic split-K reduction + row scatter)
-__global__ void k_reduce_scatter(const float* partial, int nsplit, int R, int Cn, float* g,
+// g[off(b, c) + rs*r] = sum_z partial[b*nsplit + z][r][c]   (deterministic split-K reduction + row scatter;
+// every parameter is produced by exactly one (b, r, c), so this assigns and g needs no clearing)
+__global__ void k_reduce_scatter(const float* partial, int nsplit, int nbatch, int R, int Cn, float* g,
                                  const long long* moff, long long base, int rs) {
-  CLSTM_GRID_STRIDE(e, (size_t)R * Cn) {
-    const int r = e / Cn, c = e % Cn;
-    float s = 0.0f;
-    for (int z = 0; z < nsplit; z++) s += partial[(size_t)z * R * Cn + e];
-    const long long o = (moff ? moff[c] : base + c) + (long long)rs * r;
-    g[o] += s;
+  const size_t RC = (size_t)R * Cn;
+  CLSTM_GRID_STRIDE(e, RC * nbatch) {
+    const int b = e / RC;
+    const int rc = e - b * RC;
+    const int r = rc / Cn, c = rc % Cn;
+    const float* p = partial + (size_t)b * nsplit * RC + rc;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int z = 0;
+    for (; z + 4 <= nsplit; z += 4) {   // four independent loads in flight, fixed summation order
+      s0 += p[(size_t)z * RC];
+      s1 += p[(size_t)(z + 1) * RC];
+      s2 += p[(size_t)(z + 2) * RC];
+      s3 += p[(size_t)(z + 3) * RC];
+    }
+    for (; z < nsplit; z++) s0 += p[(size_t)z * RC];
+    const long long o = (moff ? moff[(size_t)b * Cn + c] : base + c) + (long long)rs * r;
+    g[o] = (s0 + s1) + (s2 + s3);
   }
 }
 // diagnostics: the cross-lane primitives applied to the lane index (tests/test_intrinsics.py)

@@ -1,6 +1,6 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd "$ROOT"; OUT="$ROOT/gpurun_out/abl"; mkdir -p "$OUT"
-for D in 0 1 2 3 4 7; do
+for D in "$@"; do
   CLSTM_DBG=$D timeout 300 python bench.py --no-cpu-baseline --steps 10 --warmup 3 > "$OUT/b$D.json" 2>/dev/null
   python - <<PY
 import json

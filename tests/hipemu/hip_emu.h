@@ -138,13 +138,17 @@ inline long long dev_clock() { return 0; }
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 #define KEEP_ALIVE(x) (void)(x)
+#define SCHED_FENCE() ((void)0)
 struct BufF32 { float* base; size_t bytes; };
 constexpr unsigned BUF_OOB = 0xFFFFFFF0u;
 constexpr unsigned BUF_OOB_BASE = 0x80000000u;
 inline BufF32 make_buf(const float* base, size_t bytes) { return BufF32{const_cast<float*>(base), bytes}; }
 inline float buf_load(BufF32 b, unsigned off) { return ((size_t)off + 4 <= b.bytes) ? b.base[off / 4] : 0.0f; }
 inline f32x4 buf_load4(BufF32 b, unsigned off) { f32x4 r; for (int i = 0; i < 4; i++) r[i] = buf_load(b, off + 4 * i); return r; }
+inline f32x2 buf_load2(BufF32 b, unsigned off) { f32x2 r; r[0] = buf_load(b, off); r[1] = buf_load(b, off + 4); return r; }
 inline void buf_store(BufF32 b, unsigned off, float v) { if ((size_t)off + 4 <= b.bytes) b.base[off / 4] = v; }
+inline void buf_store2(BufF32 b, unsigned off, f32x2 v) { buf_store(b, off, v[0]); buf_store(b, off + 4, v[1]); }
+#define KEEP_ALIVE2(x) (void)(x)
 template <typename T> inline T* dyn_smem() { return reinterpret_cast<T*>(emu_blk->smem); }
 
 template <typename K, typename... Args>
