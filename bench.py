@@ -25,6 +25,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 NI, NH, NC = 48, 100, 83
+LABELS = 25
+# --config b2: BASELINE.json configs[4] shape (2 x BiLSTM(512), H=64, T~400, 100 classes, 50 labels), f32
+CONFIGS = {"b1": dict(ni=48, nh=[100], nc=83, T=200, L=25),
+           "b2": dict(ni=64, nh=[512, 512], nc=100, T=400, L=50)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 # algorithmic bytes per cell-step of the fused gate kernels
@@ -37,7 +41,7 @@ def synth_batch(rng, bs, T, ragged):
     for t in Ts:
         x = np.clip(rng.normal(0.2, 0.3, (t + 2, NI)), 0, 1)
         xs.append(((x[:-2] + x[1:-1] + x[2:]) / 3.0).astype(np.float32))
-    labels = [rng.integers(1, NC, 25).astype(np.int32) for _ in Ts]
+    labels = [rng.integers(1, NC, LABELS).astype(np.int32) for _ in Ts]
     return Ts, np.concatenate(xs, 0), labels
 
 
@@ -77,11 +81,21 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--minibatch", type=int, default=64, help="lines per GPU")
-    ap.add_argument("--T", type=int, default=200)
+    ap.add_argument("--T", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="b1")
     ap.add_argument("--ragged", action="store_true", help="T ~ U{150..250} instead of fixed T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
     args = ap.parse_args()
+    global NI, NH, NC, LABELS
+    cfg = CONFIGS[args.config]
+    NI, NH, NC, LABELS = cfg["ni"], cfg["nh"], cfg["nc"], cfg["L"]
+    if args.T is None:
+        args.T = cfg["T"]
+    nh_list = list(NH)
+    NH = NH[0] if len(NH) == 1 else NH
+    if args.config != "b1":
+        args.no_cpu_baseline = True     # the bounded CPU sample is defined for the headline workload only
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,18 +189,21 @@ def main():
         except Exception:
             traffic = None
         if dom in kern:
-            frames_per_launch = frames / args.profile_steps
-            byts = BYTES_PER_CELL_STEP[dom] * 2 * NH * frames_per_launch      # 2 directions x 100 cells
-            sec = kern[dom]["ms_per_step"] * 1e-3 / kern[dom]["launches_per_step"]
+            frames_per_step = frames / args.profile_steps
+            cells = 2 * sum(nh_list)                                           # directions x cells, all layers
+            byts = BYTES_PER_CELL_STEP[dom] * cells * frames_per_step         # per minibatch, all layers
+            sec = kern[dom]["ms_per_step"] * 1e-3                              # same scope
+            nl = kern[dom]["launches_per_step"]
             ach = byts / sec / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "algorithmic_bytes": int(byts),
-                        "avg_launch_ms": round(sec * 1e3, 4),
-                        "note": "latency-bound persistent recurrence: %d workgroups (lines x directions) on 256 CUs; "
-                                "recurrent FMA rate %.2f TFLOP/s of %.1f f32 peak" %
-                                (2 * args.minibatch, 8.0 * NH * NH * 2 * frames_per_launch / 2 / sec / 1e12,
-                                 F32_MFMA_PEAK_TFS)}
+                        "algorithmic_bytes": int(byts / nl),
+                        "avg_launch_ms": round(sec / nl * 1e3, 4),
+                        "note": "latency-bound recurrence (%s); recurrent matmul rate %.2f TFLOP/s of %.1f f32 peak" %
+                                ("persistent, %d workgroups (lines x directions) on 256 CUs" % (2 * args.minibatch)
+                                 if max(nh_list) <= 128 else "lock-step, one MFMA launch per time step",
+                                 16.0 * sum(h * h for h in nh_list) * frames_per_step / sec / 1e12
+                                 * (1.0 if dom == "lstm_fwd" else 1.0), F32_MFMA_PEAK_TFS)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -194,14 +211,19 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "text-line images/sec (fwd+bwd+CTC), 100-unit BiLSTM H=48 T~200",
+            "metric": "text-line images/sec (fwd+bwd+CTC), 100-unit BiLSTM H=48 T~200" if args.config == "b1" else
+                      "text-line images/sec (fwd+bwd+CTC), 2xBiLSTM(512) H=64 T~400 (f32)",
             "value": round(value, 2), "unit": "lines/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "uw3-500 OCR shape: BiLSTM(100) H=48 nc=83, T=%s, L=25, minibatch=%d lines/GPU "
-                                   "(BASELINE.json configs[2]; x%d GPUs = configs[3] sharding), fwd+CTC+bwd+allreduce+update"
-                                   % ("U{150..250}" if args.ragged else args.T, args.minibatch, world),
+            "config": {"workload": ("uw3-500 OCR shape: BiLSTM(100) H=48 nc=83, T=%s, L=25, minibatch=%d lines/GPU "
+                                    "(BASELINE.json configs[2]; x%d GPUs = configs[3] sharding), fwd+CTC+bwd+allreduce+update"
+                                    % ("U{150..250}" if args.ragged else args.T, args.minibatch, world))
+                                   if args.config == "b1" else
+                                   ("stacked 2xBiLSTM(512) H=64 nc=100, T=%s, L=50, minibatch=%d lines/GPU x%d GPUs "
+                                    "(BASELINE.json configs[4] shape, f32), fwd+CTC+bwd+allreduce+update"
+                                    % (args.T, args.minibatch, world)),
                        "minibatch_per_gpu": args.minibatch, "global_minibatch": args.minibatch * world,
                        "parallelism": "dp%d" % world},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,

@@ -16,6 +16,7 @@
 #include "devintrin.h"
 #include "gemm_mfma.h"
 #include "lstm_seq.h"
+#include "lstm_wide.h"
 #include "ops.h"
 
 #include <algorithm>
@@ -159,6 +160,30 @@ static void launch_lstm(bool fwd, int nk4, LstmSeqArgs a, int bs, int nthreads, 
   check_launch();
 }
 
+// lock-step recurrence: one launch per time step (lstm_wide.h)
+static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, hipStream_t s) {
+  REQUIRE((double)a.N * a.ndir * 4 * a.no * 4 < 2147483000.0,
+          "minibatch too large for the lock-step recurrence (frames x 4 x nhidden x ndir x 4 B must stay below 2 GiB)");
+  const int no = a.no;
+  if (fwd) {
+    const int mt = a.bs > 32 ? 4 : a.bs > 16 ? 2 : 1;
+    const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mt - 1) / (16 * mt));
+    for (int t = 0; t < tmax; t++) {
+      a.step = t;
+      if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step<4>, grid, dim3(256), 0, s, a);
+      else if (mt == 2) CLSTM_LAUNCH(lstm_wide_fwd_step<2>, grid, dim3(256), 0, s, a);
+      else CLSTM_LAUNCH(lstm_wide_fwd_step<1>, grid, dim3(256), 0, s, a);
+    }
+  } else {
+    const dim3 grid((no + 15) / 16, a.ndir, (a.bs + 15) / 16);
+    for (int t = 0; t < tmax; t++) {
+      a.step = t;
+      CLSTM_LAUNCH(lstm_wide_bwd_step, grid, dim3(256), 0, s, a);
+    }
+  }
+  check_launch();
+}
+
 // ---- per-kernel device timing (bench.py roofline) ---------------------------------------------
 #ifndef CLSTM_HIP_EMU
 struct Timing {
@@ -202,8 +227,12 @@ struct Timing {
 
 struct Layer {
   int ni, no, nk4, nthreads;
+  bool wide = false;          // lock-step recurrence (lstm_wide.h) instead of the register-resident one
+  int kpf = 0, kpb = 0;
+  long long nwf = 0, nwb = 0;
   PackDesc pd;
-  float *Wt = nullptr, *bias = nullptr, *Rf = nullptr, *Rb = nullptr;
+  float *Wt = nullptr, *bias = nullptr, *Rf = nullptr, *Rb = nullptr, *Rwf = nullptr, *Rwb = nullptr;
+  DevBuf<float> dCc;
   long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
   DevBuf<float> G, C, H, D, dH, S;
   int lds = 0;
@@ -222,7 +251,7 @@ struct Net {
   bool packed_dirty = true;
   bool want_dx0 = false;
   // batch
-  int bs = 0;
+  int bs = 0, tmax = 0;
   long long N = 0;
   std::vector<int> line_off_h;
   DevBuf<int> line_off;
@@ -251,11 +280,13 @@ struct Net {
       y.no = ds.nhidden[l];
       REQUIRE(y.no > 0, "nhidden must be positive");
       y.nk4 = pick_nk4(y.no);
-      REQUIRE(y.nk4 > 0, "nhidden > 128 is not supported by the register-resident recurrence yet");
-      y.nthreads = 64 * ((y.no + 15) / 16);
+      const bool force_wide = getenv("CLSTM_FORCE_WIDE") && atoi(getenv("CLSTM_FORCE_WIDE")) != 0;
+      y.wide = y.nk4 < 0 || force_wide;
+      if (y.wide) y.nk4 = 1;
+      y.nthreads = y.wide ? 64 : 64 * ((y.no + 15) / 16);
       y.lds = 1 + y.ni + y.no;
       const long long blk = (long long)y.no * (1 + y.ni + y.no);
-      y.pd.ni = y.ni; y.pd.no = y.no; y.pd.ndir = ndir; y.pd.nk4 = y.nk4; y.pd.nthreads = y.nthreads;
+      y.pd.ni = y.ni; y.pd.no = y.no; y.pd.ndir = ndir; y.pd.nk4 = y.nk4; y.pd.nthreads = y.wide ? 0 : y.nthreads;
       for (int dir = 0; dir < ndir; dir++) {
         for (int s = 0; s < 4; s++) y.pd.p_off[dir][s] = off + blockidx[s] * blk;
         off += 4 * blk;
@@ -280,8 +311,16 @@ struct Net {
       const int M = ndir * 4 * y.no, KQP = 4 * y.nk4;
       HIPCHECK(hipMalloc((void**)&y.Wt, (size_t)y.ni * M * sizeof(float)));
       HIPCHECK(hipMalloc((void**)&y.bias, (size_t)M * sizeof(float)));
-      HIPCHECK(hipMalloc((void**)&y.Rf, (size_t)ndir * 4 * KQP * y.nthreads * sizeof(float)));
-      HIPCHECK(hipMalloc((void**)&y.Rb, (size_t)ndir * 4 * KQP * y.nthreads * sizeof(float)));
+      if (y.wide) {
+        y.kpf = wide_kp_fwd(y.no); y.kpb = wide_kp_bwd(y.no);
+        y.nwf = (long long)ndir * ((y.no + 3) / 4) * 16 * y.kpf;
+        y.nwb = (long long)ndir * ((y.no + 15) / 16) * 16 * y.kpb;
+        HIPCHECK(hipMalloc((void**)&y.Rwf, (size_t)(y.nwf + 4) * sizeof(float)));
+        HIPCHECK(hipMalloc((void**)&y.Rwb, (size_t)(y.nwb + 4) * sizeof(float)));
+      } else {
+        HIPCHECK(hipMalloc((void**)&y.Rf, (size_t)ndir * 4 * KQP * y.nthreads * sizeof(float)));
+        HIPCHECK(hipMalloc((void**)&y.Rb, (size_t)ndir * 4 * KQP * y.nthreads * sizeof(float)));
+      }
       HIPCHECK(hipMalloc((void**)&y.moff, (size_t)M * sizeof(long long)));
       std::vector<long long> mo(M);
       for (int m = 0; m < M; m++) {
@@ -295,6 +334,7 @@ struct Net {
   ~Net() {
     for (auto& y : L) {
       (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff);
+      (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); y.dCc.release();
       y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release();
     }
     if (own_v) (void)hipFree(v);
@@ -311,7 +351,10 @@ struct Net {
     hipStream_t s = stream();
     for (auto& y : L) {
       const int M = ndir * 4 * y.no, KQP = 4 * y.nk4;
-      const size_t nr = (size_t)ndir * 4 * KQP * y.nthreads;
+      const size_t nr = y.wide ? 0 : (size_t)ndir * 4 * KQP * y.nthreads;
+      if (y.wide)
+        CLSTM_LAUNCH(k_pack_wide, dim3(nblocks((size_t)(y.nwf + y.nwb))), dim3(256), 0, s, (const float*)v, y.Rwf, y.Rwb,
+                     y.pd, y.kpf, y.kpb);
       CLSTM_LAUNCH(k_pack_layer, dim3(nblocks((size_t)(1 + y.ni) * M + 2 * nr)), dim3(256), 0, s, (const float*)v, y.Wt,
                    y.bias, y.Rf, y.Rb, y.pd);
     }
@@ -329,6 +372,8 @@ struct Net {
     }
     N = line_off_h[nb];
     REQUIRE(N > 0, "batch has no frames");
+    tmax = 0;
+    for (int b = 0; b < nb; b++) tmax = std::max(tmax, T_h[b]);
     line_off.reserve(nb + 1);
     hipStream_t s = stream();
     int* stage = (int*)ring.acquire((nb + 1) * sizeof(int));
@@ -351,6 +396,17 @@ struct Net {
 
   const float* layer_input(int l) const { return l == 0 ? X.p : L[l - 1].H.p; }
 
+  LstmWideArgs wide_args(Layer& y, bool fwd) {
+    LstmWideArgs w{};
+    w.Rw = fwd ? y.Rwf : y.Rwb; w.rw_elems = fwd ? y.nwf : y.nwb;
+    w.G = y.G.p; w.C = y.C.p; w.H = y.H.p; w.dH = y.dH.p; w.D = y.D.p;
+    y.dCc.reserve((size_t)bs * ndir * y.no);
+    w.dC = y.dCc.p; w.line_off = line_off.p; w.S = y.S.p; w.sdir = (long long)N * y.lds; w.N = N;
+    w.lds = y.lds; w.sofs = 1 + y.ni; w.no = y.no; w.ndir = ndir; w.bs = bs;
+    w.kp = fwd ? y.kpf : y.kpb;
+    return w;
+  }
+
   void forward() {
     REQUIRE(N > 0, "set_batch first");
     repack();
@@ -372,7 +428,8 @@ struct Net {
       a.line_off = line_off.p; a.no = y.no; a.ndir = ndir;
       a.S = y.S.p; a.lds = y.lds; a.sofs = 1 + y.ni; a.sdir = (long long)N * y.lds;
       timing.begin("lstm_fwd", s);
-      launch_lstm(true, y.nk4, a, bs, y.nthreads, s);
+      if (y.wide) launch_lstm_wide(true, wide_args(y, true), tmax, s);
+      else launch_lstm(true, y.nk4, a, bs, y.nthreads, s);
       timing.end(s);
     }
     const int nc = desc.nclasses;
@@ -434,7 +491,8 @@ struct Net {
       a.Rpk = y.Rb; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = y.dH.p; a.D = y.D.p;
       a.line_off = line_off.p; a.no = y.no; a.ndir = ndir;
       timing.begin("lstm_bwd", s);
-      launch_lstm(false, y.nk4, a, bs, y.nthreads, s);
+      if (y.wide) launch_lstm_wide(false, wide_args(y, false), tmax, s);
+      else launch_lstm(false, y.nk4, a, bs, y.nthreads, s);
       timing.end(s);
       // W.d += delta [1; x_t; h_{t-1}]^T for the four gates of each direction
       // (both directions in one batched launch: half the slabs per direction fill the chip)

@@ -1,0 +1,253 @@
+// lstm_wide.h -- NPLSTM recurrence for hidden sizes whose recurrent weights do not fit the
+// register file of one workgroup (no > 128; BASELINE config "2 x BiLSTM(512)").
+//
+// Same arithmetic as lstm_seq.h (GenericNPLSTM::forward / ::backward, clstm.cc:600-653), different
+// parallelisation: the minibatch's lines advance in lock-step, one launch per time step, and the
+// recurrent product of a step is a (lines x no) . (no x 4no) MFMA GEMM spread over the whole chip
+// instead of a per-line mat-vec:
+//
+//   forward  step s : pre[m][cell,g] = G_x[frame_m(s)][cell,g] + sum_k h[frame_m(s-1)][k] R_g[cell][k]
+//   backward step s : dh_rec[m][k]   = sum_{g,j} delta_g[frame_m(s+1)][j] R_g[j][k]
+//
+// A workgroup owns a 16-column tile of the product (forward: 4 cells x 4 gates, so the gate
+// nonlinearities and the c/h update of those cells fuse into its epilogue; backward: 16 cells) for
+// 16*MT lines.  Its four waves split the contraction range (split-K, v_mfma_f32_16x16x4_f32 fed
+// straight from 16-byte buffer loads: lane (i, kq) loads four consecutive k of row i, and MFMA e of
+// a group uses element e of both operands' float4 -- the k permutation is the same on both sides),
+// partial tiles are summed through LDS, and thread (line, cell) finishes the step.
+//
+// Lines of different length simply drop out (their rows read as zeros through an out-of-range
+// buffer offset and their epilogue is skipped).  `Reversed` is index arithmetic as in lstm_seq.h.
+// Weights are repacked k-contiguous and zero-padded (ops.h:k_pack_wide), so operand rows may run
+// past `no` into neighbouring finite data without masking.
+#pragma once
+#include "devintrin.h"
+
+namespace clstm {
+
+struct LstmWideArgs {
+  const float* Rw;      // fwd: [dir][ceil(no/4)][16 = cell_local*4+gate][kp]   R_g[cell][k]
+                        // bwd: [dir][ceil(no/16)][16 = cell k][kp]             R_g[j][k] at kk = 4*j+g
+  long long rw_elems;
+  float* G;             // [N][nd][no][4]  pre-activations in, activations out (forward)
+  float* C;             // [N][nd][no]
+  float* H;             // [N][nd*no]
+  const float* dH;      // [N][nd*no]      (backward)
+  float* D;             // [N][nd][no][4]  gate pre-activation deltas (backward)
+  float* dC;            // [bs][nd][no]    carried state delta dc_{s+1} * gf_{s+1} (backward)
+  const int* line_off;  // [bs+1]
+  float* S;             // [nd][N][lds] source rows (see lstm_seq.h)
+  long long sdir;
+  long long N;          // frames in the batch (array extents)
+  int lds, sofs;
+  int no, ndir, bs;
+  int kp;               // padded contraction length, multiple of 64
+  int step;             // lock-step index: forward own step s = step, backward own step s = T-1-step
+};
+
+constexpr int WIDE_LDW = 20;  // LDS row stride of a partial tile (16 columns + pad, float4-aligned)
+constexpr int WIDE_PF = 4;    // 16-k groups in flight per wave
+
+// acc[i] += A_i(16 rows x kslice) . B(kslice x 16 cols) for this wave's quarter of the contraction,
+// then the four waves' partial tiles are left in red[wave][row][col] (caller syncs).
+template <int MT>
+DEVFN void wide_tile(const BufF32 abuf, const unsigned (&arow)[MT], const BufF32 bbuf, const unsigned brow,
+                     const int kp, float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int kw = kp >> 2;                 // contraction range of one wave (multiple of 16)
+  const int ngroups = kw >> 4;
+  const unsigned klane = (unsigned)(wave * kw + 4 * (lane >> 4)) * 4u;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[i][q] = 0.0f;
+  f32x4 ra[WIDE_PF][MT], rb[WIDE_PF];
+  // unconditional issue (groups past the end get out-of-range offsets): exact vmcnt, see gemm_mfma.h
+  auto load_group = [&](int g, f32x4 (&a)[MT], f32x4& b) {
+    const bool live = g < ngroups;
+    const unsigned ko = klane + (unsigned)g * 64u;
+#pragma unroll
+    for (int i = 0; i < MT; i++) a[i] = buf_load4(abuf, live ? arow[i] + ko : BUF_OOB);
+    b = buf_load4(bbuf, live ? brow + ko : BUF_OOB);
+  };
+#pragma unroll
+  for (int p = 0; p < WIDE_PF; p++) {
+    load_group(p, ra[p], rb[p]);
+    SCHED_FENCE();
+  }
+  for (int g0 = 0; g0 < ngroups; g0 += WIDE_PF) {
+#pragma unroll
+    for (int p = 0; p < WIDE_PF; p++) {
+      f32x4 av[MT];
+#pragma unroll
+      for (int i = 0; i < MT; i++) av[i] = ra[p][i];
+      const f32x4 bv = rb[p];
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int i = 0; i < MT; i++) acc[i] = mfma16x16x4(av[i][e], bv[e], acc[i]);
+      load_group(g0 + p + WIDE_PF, ra[p], rb[p]);
+      SCHED_FENCE();
+    }
+  }
+  // D layout: lane holds rows (lane>>4)*4 + q, column lane&15
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * WIDE_LDW + (lane & 15)] = acc[i][q];
+}
+
+// ---- forward: one time step of every line ------------------------------------------------------
+// grid (ceil(no/4), ndir, ceil(bs / 16MT)), 256 threads
+template <int MT>
+__global__ __launch_bounds__(256) void lstm_wide_fwd_step(LstmWideArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[4 * MT * 16 * WIDE_LDW];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int cg = blockIdx.x, dir = blockIdx.y, zb = blockIdx.z;
+  const int no = a.no, nd = a.ndir, sg = a.step;
+  const int ncg = (no + 3) >> 2;
+
+  unsigned arow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++) {
+    const int m = (zb * MT + i) * 16 + (lane & 15);
+    arow[i] = BUF_OOB_BASE;
+    if (m < a.bs) {
+      const int off = a.line_off[m], T = a.line_off[m + 1] - off;
+      if (sg >= 1 && sg < T) {
+        const int fprev = dir == 0 ? sg - 1 : T - sg;   // frame of own step s-1
+        arow[i] = (unsigned)(((long long)(off + fprev) * nd + dir) * no) * 4u;
+      }
+    }
+  }
+  const BufF32 abuf = make_buf(a.H, (size_t)a.N * nd * no * 4);
+  const BufF32 bbuf = make_buf(a.Rw, (size_t)a.rw_elems * 4);
+  const unsigned brow = (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp) * 4u;
+
+  // epilogue role of this thread: (line, cell); its operands are requested before the MFMA loop so
+  // that their HBM latency hides under it (masked threads read nothing: out-of-range offsets)
+  const int ml = tid >> 2, cl = tid & 3;
+  const int line = zb * MT * 16 + ml, cell = cg * 4 + cl;
+  bool live = ml < MT * 16 && line < a.bs && cell < no;
+  int off = 0, T = 0;
+  if (live) {
+    off = a.line_off[line];
+    T = a.line_off[line + 1] - off;
+    live = sg < T;
+  }
+  const long long n = off + (dir == 0 ? sg : T - 1 - sg);
+  const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
+  const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
+  const unsigned goff = live ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB;
+  const f32x4 gx = buf_load4(gbuf, goff);
+  const float c_prev = buf_load(cbuf, live && sg >= 1
+      ? (unsigned)((((long long)(off + (dir == 0 ? sg - 1 : T - sg)) * nd + dir) * no + cell) * 4) : BUF_OOB);
+
+  wide_tile<MT>(abuf, arow, bbuf, brow, a.kp, red);
+  __syncthreads();
+
+  // fused forward_full1 x4 + forward_statemem + forward_nonlingate for (line, cell)
+  if (!live) return;
+  f32x4 k;
+#pragma unroll
+  for (int q = 0; q < 4; q++) k[q] = 0.0f;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(&red[((w * MT + (ml >> 4)) * 16 + (ml & 15)) * WIDE_LDW + cl * 4]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) k[q] += p[q];
+  }
+  const float gi = gate_act(k[0] + gx[0], false), gf = gate_act(k[1] + gx[1], false),
+              go = gate_act(k[2] + gx[2], false), ci = gate_act(k[3] + gx[3], true);
+  const float c = ci * gi + gf * c_prev;      // c_prev reads 0 at the first step
+  const float h = gate_act(c, true) * go;
+  f32x4 act;
+  act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
+  *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
+  a.C[(n * nd + dir) * no + cell] = c;
+  a.H[n * (nd * no) + dir * no + cell] = h;
+  float* srow = a.S + (size_t)dir * a.sdir;
+  if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;                      // h_{-1} = 0
+  if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+}
+
+// ---- backward: one time step of every line -------------------------------------------------------
+// grid (ceil(no/16), ndir, ceil(bs/16)), 256 threads
+__global__ __launch_bounds__(256) void lstm_wide_bwd_step(LstmWideArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * WIDE_LDW];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ct = blockIdx.x, dir = blockIdx.y, zb = blockIdx.z;
+  const int no = a.no, nd = a.ndir, sg = a.step;
+  const int nct = (no + 15) >> 4;
+
+  unsigned arow[1];
+  {
+    const int m = zb * 16 + (lane & 15);
+    arow[0] = BUF_OOB_BASE;
+    if (m < a.bs) {
+      const int off = a.line_off[m], T = a.line_off[m + 1] - off;
+      if (sg >= 1 && sg < T) {
+        const int fnext = dir == 0 ? T - sg : sg - 1;   // frame of own step s+1, s = T-1-sg
+        arow[0] = (unsigned)(((long long)(off + fnext) * nd + dir) * 4 * no) * 4u;
+      }
+    }
+  }
+  const BufF32 abuf = make_buf(a.D, (size_t)a.N * nd * 4 * no * 4);
+  const BufF32 bbuf = make_buf(a.Rw, (size_t)a.rw_elems * 4);
+  const unsigned brow = (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp) * 4u;
+
+  // epilogue operands of thread (line, cell), requested ahead of the MFMA loop
+  const int ml = tid >> 4, c16 = tid & 15;
+  const int line = zb * 16 + ml, cell = ct * 16 + c16;
+  bool live = line < a.bs && cell < no;
+  int off = 0, T = 0;
+  if (live) {
+    off = a.line_off[line];
+    T = a.line_off[line + 1] - off;
+    live = sg < T;
+  }
+  const int s = T - 1 - sg;
+  const long long n = off + (dir == 0 ? s : sg);
+  const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
+  const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
+  const BufF32 hbuf = make_buf(a.dH, (size_t)a.N * nd * no * 4);
+  const BufF32 dcbuf = make_buf(a.dC, (size_t)a.bs * nd * no * 4);
+  const unsigned coff = (unsigned)(((n * nd + dir) * no + cell) * 4);
+  const f32x4 act = buf_load4(gbuf, live ? coff * 4u : BUF_OOB);
+  const float dh_in = buf_load(hbuf, live ? (unsigned)((n * (nd * no) + dir * no + cell) * 4) : BUF_OOB);
+  const float c_s = buf_load(cbuf, live ? coff : BUF_OOB);
+  const float c_m1 = buf_load(cbuf, live && s >= 1       // c_{s-1}; 0 at s = 0 ("gf.d untouched when last < 0")
+      ? (unsigned)((((long long)(off + (dir == 0 ? s - 1 : sg + 1)) * nd + dir) * no + cell) * 4) : BUF_OOB);
+  const unsigned dcoff = (unsigned)((((long long)line * nd + dir) * no + cell) * 4);
+  const float dc_carry = buf_load(dcbuf, live && sg >= 1 ? dcoff : BUF_OOB);
+
+  wide_tile<1>(abuf, arow, bbuf, brow, a.kp, red);
+  __syncthreads();
+
+  if (!live) return;
+  float dh_rec = 0.0f;
+#pragma unroll
+  for (int w = 0; w < 4; w++) dh_rec += red[(w * 16 + ml) * WIDE_LDW + c16];
+  const float gi = act[0], gf = act[1], go = act[2], ci = act[3];
+  const float dh = dh_in + dh_rec;           // out[s].d, clstm.cc:626-628 + :646
+  const float th = gate_act(c_s, true);      // backward_nonlingate recomputes tanh(state)
+  const float d_go = th * dh;
+  const float dc = dc_carry + (-th * th + 1.0f) * (go * dh);
+  a.dC[dcoff / 4] = dc * gf;                 // backward_statemem (clstm_compute.cc:509-515)
+  const float d_gf = dc * c_m1;
+  const float d_gi = dc * ci, d_ci = dc * gi;
+  f32x4 dl;                                  // backward_nonlin0: y(1-y) for SIG, 1-y^2 for TANH
+  dl[0] = (gi * (-gi + 1.0f)) * d_gi;
+  dl[1] = (gf * (-gf + 1.0f)) * d_gf;
+  dl[2] = (go * (-go + 1.0f)) * d_go;
+  dl[3] = (-ci * ci + 1.0f) * d_ci;
+  *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
+}
+
+// contraction padding of the packed weights
+inline int wide_kp_fwd(int no) { return ((no + 63) / 64) * 64; }
+inline int wide_kp_bwd(int no) { return ((4 * no + 63) / 64) * 64; }
+
+}  // namespace clstm

@@ -227,6 +227,29 @@ __global__ void k_pack_layer(const float* v, float* Wt, float* bias, float* Rf, 
     else pack_rb(e - nwx - nr, v, Rb, p);
   }
 }
+// k-contiguous, zero-padded recurrent weights of the lock-step recurrence (lstm_wide.h):
+//   Rwf[dir][cg][j = cl*4+g][k] = R_g[4cg+cl][k]          (kpf floats per row)
+//   Rwb[dir][ct][c][kk = 4j+g]  = R_g[j][16ct+c]          (kpb floats per row)
+__global__ void k_pack_wide(const float* v, float* Rwf, float* Rwb, PackDesc p, int kpf, int kpb) {
+  const int ncg = (p.no + 3) / 4, nct = (p.no + 15) / 16;
+  const size_t nf = (size_t)p.ndir * ncg * 16 * kpf, nb = (size_t)p.ndir * nct * 16 * kpb;
+  CLSTM_GRID_STRIDE(e, nf + nb) {
+    if (e < nf) {
+      const int k = e % kpf;
+      const size_t r = e / kpf;
+      const int j = r % 16, cg = (r / 16) % ncg, dir = r / ((size_t)16 * ncg);
+      const int cell = cg * 4 + (j >> 2), g = j & 3;
+      Rwf[e] = (cell < p.no && k < p.no) ? v[p.p_off[dir][g] + cell + (size_t)p.no * (1 + p.ni + k)] : 0.0f;
+    } else {
+      const size_t eb = e - nf;
+      const int kk = eb % kpb;
+      const size_t r = eb / kpb;
+      const int c = r % 16, ct = (r / 16) % nct, dir = r / ((size_t)16 * nct);
+      const int kcell = ct * 16 + c, j = kk >> 2, g = kk & 3;
+      Rwb[eb] = (kcell < p.no && j < p.no) ? v[p.p_off[dir][g] + j + (size_t)p.no * (1 + p.ni + kcell)] : 0.0f;
+    }
+  }
+}
 // S[dir][n][0] = 1, S[dir][n][1..ni] = x_n for every direction: the non-recurrent part of the source
 // rows [1 | x_t | h_{t-1}] (forward_stack_delay + the bias column of Params, tensor.h:263-264)
 __global__ void k_build_source(float* S, const float* x, size_t N, int ni, int ldx, int lds, int ndir, long long sdir) {

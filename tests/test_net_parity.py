@@ -75,6 +75,29 @@ def test_bidi_uw3_shape_short(backend, ora32):
     run_case(backend, ora32, 48, 100, 83, T, scale=10.0)
 
 
+@pytest.mark.parametrize("ni,nh,nc,T", [
+    (5, 6, 4, [5, 3, 1]),                 # forced: partial cell group, ragged lines dropping out of lock-step
+    (4, [7, 5], 4, [4, 6]),               # forced: two stacked layers
+    (6, 21, 5, [3] * 18 + [5]),           # forced: 19 lines -> two 16-line blocks (MT = 2 forward tile)
+])
+def test_lockstep_recurrence_forced(backend, ora32, monkeypatch, ni, nh, nc, T):
+    # the lock-step (one launch per time step, MFMA) recurrence of lstm_wide.h on sizes the
+    # register-resident kernels also handle
+    monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
+    run_case(backend, ora32, ni, nh, nc, T)
+
+
+def test_lockstep_recurrence_nhidden_over_128(backend, ora32):
+    # nhidden > 128 takes the lock-step path by itself (BASELINE config 2 x BiLSTM(512) shape family)
+    T = [3, 2] if backend.kind == "emu" else [37, 50, 11]
+    run_case(backend, ora32, 8, 132, 7, T, scale=10.0)
+
+
+def test_lockstep_unidirectional(backend, ora32, monkeypatch):
+    monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
+    run_case(backend, ora32, 4, 9, 5, [6, 2], uni=True)
+
+
 def test_bidi2_stacked(backend, ora32):
     # two stacked BiLSTM layers: exercises the inter-layer dX GEMM (Stacked::backward clstm.cc:440-454)
     run_case(backend, ora32, 4, [6, 5], 4, [4, 3], scale=30.0)
@@ -144,7 +167,7 @@ def test_errors_are_reported(backend):
     with pytest.raises(ClstmError):
         net.forward()                              # no batch yet
     with pytest.raises(ClstmError):
-        Network(4, 500, 3, lib=backend.lib)        # beyond the register-resident recurrence
+        Network(4, 0, 3, lib=backend.lib)          # nhidden must be positive
     net.set_inputs([np.zeros((3, 4), np.float32)])
     net.forward()
     with pytest.raises(ClstmError):
