@@ -28,6 +28,7 @@ namespace clstm {
 constexpr int CTC_THREADS = 512;   // waves 0-3: forward recursion, waves 4-7: reversed-lattice recursion
 constexpr int CTC_GROUP = 256;     // lanes per recursion when S > 64
 constexpr int CTC_RMAX = 2;        // up to 512 target states per line
+constexpr int CTC_MLP = 8;         // independent global loads a thread keeps in flight in the streaming phases
 constexpr int CTC_MAX_TILE = 256;  // frames per LDS tile (phases A and E)
 
 struct CtcArgs {
@@ -110,15 +111,15 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   for (int t0 = 0; t0 < T; t0 += TT) {
     const int nt = (T - t0) < TT ? (T - t0) : TT;
     __syncthreads();
-    if (ncp == nc) {  // rows are back to back in LDS too: flat coalesced copy, 4 loads in flight
+    if (ncp == nc) {  // rows are back to back in LDS too: flat coalesced copy, CTC_MLP loads in flight
       const float* src = P + (size_t)t0 * nc;
       const int n = nt * nc;
-      for (int i0 = tid; i0 < n; i0 += 4 * CTC_THREADS) {
-        float x[4];
+      for (int i0 = tid; i0 < n; i0 += CTC_MLP * CTC_THREADS) {
+        float x[CTC_MLP];
 #pragma unroll
-        for (int u = 0; u < 4; u++) x[u] = (i0 + u * CTC_THREADS < n) ? src[i0 + u * CTC_THREADS] : 0.0f;
+        for (int u = 0; u < CTC_MLP; u++) x[u] = (i0 + u * CTC_THREADS < n) ? src[i0 + u * CTC_THREADS] : 0.0f;
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < CTC_MLP; u++)
           if (i0 + u * CTC_THREADS < n) rowbuf[i0 + u * CTC_THREADS] = fmaxf(1e-5f, x[u]);
       }
     } else {
@@ -318,17 +319,17 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   const int sp = S | 1;
   for (int t0 = 0; t0 < T; t0 += TT) {
     const int nt = (T - t0) < TT ? (T - t0) : TT;
-    for (int s0 = lane; s0 < S; s0 += 64) {  // coalesced staging of the lattice tile, 4 frames in flight
+    for (int s0 = lane; s0 < S; s0 += 64) {  // coalesced staging of the lattice tile, CTC_MLP frames in flight
       const double it = tot[s0];
-      for (int t = wave; t < nt; t += 4 * (CTC_THREADS / 64)) {
-        float x[4];
+      for (int t = wave; t < nt; t += CTC_MLP * (CTC_THREADS / 64)) {
+        float x[CTC_MLP];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < CTC_MLP; u++) {
           const int tu = t + u * (CTC_THREADS / 64);
           x[u] = tu < nt ? al[(size_t)(t0 + tu) * S + s0] : 0.0f;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < CTC_MLP; u++) {
           const int tu = t + u * (CTC_THREADS / 64);
           if (tu < nt) etile[tu * sp + s0] = (float)((double)x[u] * it);
         }
@@ -352,16 +353,16 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
       part[tid] = 1.0 / fmax(total, 1e-9);
     }
     __syncthreads();
-    for (int c = lane; c < nc; c += 64) {  // coalesced write-out, one wave per frame, 4 frames in flight
-      for (int t = wave; t < nt; t += 4 * (CTC_THREADS / 64)) {
-        float p[4];
+    for (int c = lane; c < nc; c += 64) {  // coalesced write-out, one wave per frame, CTC_MLP frames in flight
+      for (int t = wave; t < nt; t += CTC_MLP * (CTC_THREADS / 64)) {
+        float p[CTC_MLP];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < CTC_MLP; u++) {
           const int tu = t + u * (CTC_THREADS / 64);
           p[u] = tu < nt ? P[(size_t)(t0 + tu) * nc + c] : 0.0f;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < CTC_MLP; u++) {
           const int tu = t + u * (CTC_THREADS / 64);
           if (tu < nt) {
             const float av = (float)((double)rowbuf[tu * ncp + c] * part[tu]);

@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Copy the judged summaries of one scripts/gpu_round.sh run from gpurun_out/<tag>/ into profiles/
+(prefix r<NN>_) and rebuild profiles/pmc_r<NN>.json (HBM bytes per launch of the main kernels).
+
+usage: python scripts/collect_profiles.py <tag> <NN>"""
+import json, os, re, shutil, sys
+
+tag, rnd = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+pre = "r%s_" % rnd
+for name in ("bench_default.json", "bench_mb1.json", "bench_mb16.json", "bench_mb256.json", "bench_mb1024.json",
+             "bench_ragged.json", "bench_b2.json", "host.txt", "pmc_FETCH_SIZE_summary.txt", "pmc_WRITE_SIZE_summary.txt"):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, pre + name))
+p = os.path.join(src, "prof", "bench_kernel_stats.csv")
+if os.path.exists(p):
+    shutil.copy(p, os.path.join(dst, pre + "bench_kernel_stats.csv"))
+
+
+def summary(counter):
+    out = {}
+    for line in open(os.path.join(src, "pmc_%s_summary.txt" % counter)):
+        m = re.match(r"(.*?)\s+launches\s+(\d+)\s+avg\s+([\d.]+)", line)
+        if m:
+            out[m.group(1).strip()] = float(m.group(3))
+    return out
+
+
+fe, wr = summary("FETCH_SIZE"), summary("WRITE_SIZE")
+names = {"lstm_fwd": "void clstm::lstm_fwd_kernel<7>", "lstm_bwd": "void clstm::lstm_bwd_kernel<7>",
+         "ctc_align": "clstm::ctc_align_kernel", "sgd_update": "clstm::k_update",
+         "gemm_dw (all split-K launches, avg)": "void clstm::gemm_f32_kernel<1, 1, clstm::StorePartial>",
+         "gemm_gates_x / gemm_softmax (avg)": "void clstm::gemm_f32_kernel<0, 1, clstm::StoreBias>"}
+kern = {}
+for k, full in names.items():
+    if full in fe and full in wr:
+        kern[k] = {"fetch_kib": fe[full], "write_kib": wr[full],
+                   "hbm_bytes": int(round((2.0 * fe[full] + wr[full]) * 1024))}
+doc = {
+    "_comment": "HBM traffic per launch from rocprofv3 PMC passes (profiles/%spmc_*_summary.txt), bench.py default "
+                "workload (minibatch 64, T=200, BiLSTM(100)). FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE "
+                "counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM) -> reads are doubled; WRITE_SIZE is exact. "
+                "Calibration in the same run: sgd_update reads 3 x 135883 x 4 B = 1,630,596 B and writes "
+                "2 x 135883 x 4 B = 1,087,064 B." % pre,
+    "workload": {"minibatch_per_gpu": 64, "T": 200},
+    "kernels": kern,
+}
+json.dump(doc, open(os.path.join(dst, "pmc_r%s.json" % rnd), "w"), indent=1)
+print(json.dumps(kern, indent=1))
