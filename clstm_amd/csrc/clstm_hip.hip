@@ -236,6 +236,9 @@ struct Layer {
   long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
   DevBuf<float> G, C, H, D, dH, S;
   int lds = 0;
+  int ldh = 0, hofs = 4;      // H rows: [pad pad pad 1 | h_dir0 | h_dir1], h at column hofs (16-byte aligned)
+  float* hrow() const { return H.p + hofs; }            // h block of frame 0
+  float* srow() const { return H.p + hofs - 1; }        // [1 | h] = the next layer's / softmax's source row
 };
 
 struct Net {
@@ -252,11 +255,13 @@ struct Net {
   bool want_dx0 = false;
   // batch
   int bs = 0, tmax = 0;
+  bool src0_ready = false;    // layer 0's source rows [1 | x] already written by set_inputs_d
   long long N = 0;
   std::vector<int> line_off_h;
   DevBuf<int> line_off;
   PinnedRing ring;
-  DevBuf<float> X, Z, Dz, dX0, partial, aligned, tmp, Ssm;
+  DevBuf<float> X, Z, Dz, dX0, partial, partial_sm, aligned, tmp;
+  ReduceDesc sm_red{};
   // ctc / decode
   DevBuf<int> states, state_off, dec_idx, dec_cls, dec_loc, dec_cnt;
   DevBuf<float> dec_val, lat;
@@ -285,6 +290,7 @@ struct Net {
       if (y.wide) y.nk4 = 1;
       y.nthreads = y.wide ? 64 : 64 * ((y.no + 15) / 16);
       y.lds = 1 + y.ni + y.no;
+      y.ldh = ((y.hofs + ndir * y.no + 3) / 4) * 4;
       const long long blk = (long long)y.no * (1 + y.ni + y.no);
       y.pd.ni = y.ni; y.pd.no = y.no; y.pd.ndir = ndir; y.pd.nk4 = y.nk4; y.pd.nthreads = y.wide ? 0 : y.nthreads;
       for (int dir = 0; dir < ndir; dir++) {
@@ -341,7 +347,7 @@ struct Net {
     if (own_d) (void)hipFree(d);
     if (own_g) (void)hipFree(g);
     line_off.release(); X.release(); Z.release(); Dz.release();
-    dX0.release(); partial.release(); aligned.release(); tmp.release(); Ssm.release(); states.release();
+    dX0.release(); partial.release(); partial_sm.release(); aligned.release(); tmp.release(); states.release();
     state_off.release(); dec_idx.release(); dec_cls.release(); dec_loc.release(); dec_cnt.release();
     dec_val.release(); lat.release(); lat_off.release();
   }
@@ -374,6 +380,7 @@ struct Net {
     REQUIRE(N > 0, "batch has no frames");
     tmax = 0;
     for (int b = 0; b < nb; b++) tmax = std::max(tmax, T_h[b]);
+    src0_ready = false;
     line_off.reserve(nb + 1);
     hipStream_t s = stream();
     int* stage = (int*)ring.acquire((nb + 1) * sizeof(int));
@@ -384,17 +391,24 @@ struct Net {
     for (auto& y : L) {
       y.G.reserve((size_t)N * ndir * 4 * y.no);
       y.C.reserve((size_t)N * ndir * y.no);
-      y.H.reserve((size_t)N * ndir * y.no);
+      {
+        const size_t cap0 = y.H.cap;
+        y.H.reserve((size_t)N * y.ldh + 64);
+        if (y.H.cap != cap0) {
+          const size_t rows = y.H.cap / y.ldh;
+          CLSTM_LAUNCH(k_fill_col0, dim3(nblocks(rows)), dim3(256), 0, s, y.H.p, rows, y.ldh, y.hofs - 1);
+        }
+      }
       y.D.reserve((size_t)N * ndir * 4 * y.no);
       y.dH.reserve((size_t)N * ndir * y.no);
       y.S.reserve((size_t)N * ndir * y.lds + 64);
     }
-    Ssm.reserve((size_t)N * (1 + sm_ni) + 64);
     Z.reserve((size_t)N * desc.nclasses);
     Dz.reserve((size_t)N * desc.nclasses);
   }
 
-  const float* layer_input(int l) const { return l == 0 ? X.p : L[l - 1].H.p; }
+  const float* layer_input(int l) const { return l == 0 ? X.p : L[l - 1].hrow(); }
+  int layer_input_ld(int l) const { return l == 0 ? desc.ninput : L[l - 1].ldh; }
 
   LstmWideArgs wide_args(Layer& y, bool fwd) {
     LstmWideArgs w{};
@@ -402,7 +416,7 @@ struct Net {
     w.G = y.G.p; w.C = y.C.p; w.H = y.H.p; w.dH = y.dH.p; w.D = y.D.p;
     y.dCc.reserve((size_t)bs * ndir * y.no);
     w.dC = y.dCc.p; w.line_off = line_off.p; w.S = y.S.p; w.sdir = (long long)N * y.lds; w.N = N;
-    w.lds = y.lds; w.sofs = 1 + y.ni; w.no = y.no; w.ndir = ndir; w.bs = bs;
+    w.lds = y.lds; w.sofs = 1 + y.ni; w.ldh = y.ldh; w.hofs = y.hofs; w.no = y.no; w.ndir = ndir; w.bs = bs;
     w.kp = fwd ? y.kpf : y.kpb;
     return w;
   }
@@ -415,17 +429,18 @@ struct Net {
       Layer& y = L[l];
       const int M = ndir * 4 * y.no;
       timing.begin("gemm_gates_x", s);
-      gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), y.ni, N), gemm_mc(y.Wt, M, y.ni, 0),
+      gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N), gemm_mc(y.Wt, M, y.ni, 0),
                                  StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
       timing.end(s);
       check_launch();
       timing.begin("build_source", s);
+      if (l > 0 || !src0_ready)
       CLSTM_LAUNCH(k_build_source, dim3(nblocks((size_t)N * (1 + y.ni))), dim3(256), 0, s, y.S.p, layer_input(l),
-                   (size_t)N, y.ni, y.ni, y.lds, ndir, (long long)N * y.lds);
+                   (size_t)N, y.ni, layer_input_ld(l), y.lds, ndir, (long long)N * y.lds);
       timing.end(s);
       LstmSeqArgs a{};
       a.Rpk = y.Rf; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = nullptr; a.D = nullptr;
-      a.line_off = line_off.p; a.no = y.no; a.ndir = ndir;
+      a.line_off = line_off.p; a.no = y.no; a.ndir = ndir; a.ldh = y.ldh; a.hofs = y.hofs;
       a.S = y.S.p; a.lds = y.lds; a.sofs = 1 + y.ni; a.sdir = (long long)N * y.lds;
       timing.begin("lstm_fwd", s);
       if (y.wide) launch_lstm_wide(true, wide_args(y, true), tmax, s);
@@ -434,10 +449,9 @@ struct Net {
     }
     const int nc = desc.nclasses;
     const float* W1 = v + sm_off;
-    CLSTM_LAUNCH(k_build_source, dim3(nblocks((size_t)N * (1 + sm_ni))), dim3(256), 0, s, Ssm.p,
-                 (const float*)L.back().H.p, (size_t)N, sm_ni, sm_ni, 1 + sm_ni, 1, 0LL);
+    // the top layer's output rows are [1 | h]: they ARE the softmax layer's source rows
     timing.begin("gemm_softmax", s);
-    gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(L.back().H.p, sm_ni, N), gemm_mc(W1 + nc, nc, sm_ni, 0),
+    gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(L.back().hrow(), L.back().ldh, N), gemm_mc(W1 + nc, nc, sm_ni, 0),
                                StoreBias{Z.p, nc, W1}, (int)N, nc, sm_ni);
     timing.end(s);
     check_launch();
@@ -471,13 +485,13 @@ struct Net {
     {  // (a side stream for this GEMM was measured on MI355X: no gain -- the recurrence workgroups it would
        // overlap with slow down by as much -- so everything stays on one stream)
       const int R = 1 + sm_ni, Cn = nc, ns = pick_split(R, Cn);
-      partial.reserve((size_t)ns * R * Cn);
+      partial_sm.reserve((size_t)ns * R * Cn);
       timing.begin("gemm_softmax_dw", s);
-      gemm_f32<GEMM_MC, GEMM_MC>(s, gemm_mc(Ssm.p, 1 + sm_ni, N), gemm_mc(Dz.p, nc, N), StorePartial{partial.p, R, Cn},
+      gemm_f32<GEMM_MC, GEMM_MC>(s, gemm_mc(top.srow(), top.ldh, N), gemm_mc(Dz.p, nc, N), StorePartial{partial_sm.p, R, Cn},
                                  R, Cn, (int)N, ns);
-      CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns, 1, R, Cn,
-                   g, (const long long*)nullptr, (long long)sm_off, nc);
       timing.end(s);
+      // its slabs are reduced together with the top layer's weight-gradient slabs below
+      sm_red = ReduceDesc{partial_sm.p, nullptr, (long long)sm_off, ns, 1, R, Cn, nc};
     }
     timing.begin("gemm_softmax_dx", s);
     gemm_f32<GEMM_KC, GEMM_KC>(s, gemm_kc(Dz.p, nc, N), gemm_kc(W1 + nc, nc, sm_ni, 0), StorePlain{top.dH.p, sm_ni},
@@ -502,8 +516,13 @@ struct Net {
       gemm_f32<GEMM_MC, GEMM_MC>(s, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
                                  gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
                                  StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns, ndir);
-      CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)ndir * R * Cn)), dim3(256), 0, s, (const float*)partial.p, ns,
-                   ndir, R, Cn, g, (const long long*)y.moff, 0LL, y.no);
+      {
+        const ReduceDesc gates{partial.p, y.moff, 0LL, ns, ndir, R, Cn, y.no};
+        ReduceDesc extra{};   // empty unless this is the top layer
+        if (l == (int)L.size() - 1) extra = sm_red;
+        const size_t work = (size_t)ndir * R * Cn + (size_t)extra.R * extra.Cn * extra.nbatch;
+        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, s, gates, extra, g);
+      }
       timing.end(s);
       check_launch();
       // input deltas: x.d = sum_dir W_x^T delta (Parallel::backward sums both subs, clstm.cc:538-541)
@@ -793,12 +812,21 @@ int clstm_net_set_gradient_clip(clstm_net* h, float c) {
 }
 int clstm_net_set_batch(clstm_net* h, const int* T_h, int bs) { ABI_BEGIN h->net.set_batch(T_h, bs); ABI_END }
 int clstm_net_set_inputs_h(clstm_net* h, const float* x) {
-  ABI_BEGIN REQUIRE(h->net.N > 0, "set_batch first"); copy_h2d(h->net.X.p, x, (size_t)h->net.N * h->net.desc.ninput); ABI_END
+  ABI_BEGIN
+  REQUIRE(h->net.N > 0, "set_batch first");
+  copy_h2d(h->net.X.p, x, (size_t)h->net.N * h->net.desc.ninput);
+  h->net.src0_ready = false;
+  ABI_END
 }
 int clstm_net_set_inputs_d(clstm_net* h, const float* x) {
   ABI_BEGIN
-  REQUIRE(h->net.N > 0, "set_batch first");
-  HIPCHECK(hipMemcpyAsync(h->net.X.p, x, (size_t)h->net.N * h->net.desc.ninput * sizeof(float), hipMemcpyDeviceToDevice, g_stream));
+  Net& n = h->net;
+  REQUIRE(n.N > 0, "set_batch first");
+  Layer& y = n.L[0];
+  CLSTM_LAUNCH(k_ingest, dim3(nblocks((size_t)n.N * (1 + y.ni))), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni,
+               y.lds, n.ndir, (long long)n.N * y.lds);
+  check_launch();
+  n.src0_ready = true;
   ABI_END
 }
 int clstm_net_forward(clstm_net* h) { ABI_BEGIN h->net.forward(); ABI_END }
@@ -854,9 +882,13 @@ int clstm_net_get_state_h(clstm_net* h, int layer, int dir, int which, float* ou
   REQUIRE(layer >= 0 && layer < (int)n.L.size() && dir >= 0 && dir < n.ndir && which >= 0 && which <= 9, "bad state selector");
   Layer& y = n.L[layer];
   n.tmp.reserve((size_t)n.N * y.no);
-  const float* src = which < 4 ? y.G.p : which == 4 ? y.C.p : which == 5 ? y.H.p : y.D.p;
+  const float* src = which < 4 ? y.G.p : which == 4 ? y.C.p : y.D.p;
   const int slot = which < 4 ? which : which >= 6 ? which - 6 : -1;
-  CLSTM_LAUNCH(k_gather_state, dim3(nblocks((size_t)n.N * y.no)), dim3(256), 0, g_stream, src, n.tmp.p, (size_t)n.N, y.no, n.ndir, dir, slot);
+  if (which == 5)
+    CLSTM_LAUNCH(k_gather_rows, dim3(nblocks((size_t)n.N * y.no)), dim3(256), 0, g_stream, (const float*)(y.hrow() + dir * y.no),
+                 n.tmp.p, (size_t)n.N, y.no, y.ldh);
+  else
+    CLSTM_LAUNCH(k_gather_state, dim3(nblocks((size_t)n.N * y.no)), dim3(256), 0, g_stream, src, n.tmp.p, (size_t)n.N, y.no, n.ndir, dir, slot);
   check_launch();
   copy_d2h(out, n.tmp.p, (size_t)n.N * y.no);
   ABI_END
@@ -897,8 +929,8 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     if (nsplit < 1) nsplit = 1;
     part->reserve((size_t)nsplit * R * Cn);
     gemm_f32<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
-    CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream, (const float*)part->p, nsplit,
-                 1, R, Cn, Cm, (const long long*)nullptr, 0LL, Cn);
+    CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
+                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm);
   } else throw Error("bad mode");
   check_launch();
   ABI_END

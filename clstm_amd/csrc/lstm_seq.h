@@ -32,7 +32,10 @@ struct LstmSeqArgs {
   const float* Rpk;     // packed recurrent weights for this pass: [dir][16*NK4][nthreads]
   float* G;             // [N][2][4*no]  fwd: in pre-activation (x part + bias), out activation
   float* C;             // [N][2][no]    cell state
-  float* H;             // [N][2*no]     outputs (dir d at column d*no) = Parallel's stacked output
+  float* H;             // [N][ldh]      outputs: column hofs-1 holds the constant 1 (bias input of the
+                        //               next layer / softmax), dir d at column hofs + d*no = Parallel's stacked
+                        //               output; hofs = 4 keeps the h block of a row 16-byte aligned
+  int ldh, hofs;
   const float* dH;      // [N][2*no]     bwd: delta on H            (backward only)
   float* D;             // [N][2][4*no]  bwd: gate pre-activation deltas (backward only)
   const int* line_off;  // [bs+1] first token of each line
@@ -79,12 +82,14 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   const unsigned gstride4 = (unsigned)nd * 4 * no * 4, cstride4 = (unsigned)nd * no * 4;
   const BufF32 gbuf = make_buf(a.G + (size_t)off * (gstride4 / 4), (size_t)T * gstride4);
   const BufF32 cbuf = make_buf(a.C + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
-  const BufF32 hbuf = make_buf(a.H + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
+  const unsigned hstride4 = (unsigned)a.ldh * 4;
+  const BufF32 hbuf = make_buf(a.H + (size_t)off * a.ldh, (size_t)T * hstride4);
   const unsigned sstride4 = (unsigned)a.lds * 4;
   const BufF32 sbuf = make_buf(a.S + (size_t)dir * a.sdir + (size_t)off * a.lds, (size_t)T * sstride4);
   const unsigned gl = valid ? ((unsigned)dir * 4 * no + cell * 4 + q) * 4u : BUF_OOB_BASE;
   const unsigned cl = lead ? ((unsigned)dir * no + cell) * 4u : BUF_OOB_BASE;
   const unsigned sl = lead ? ((unsigned)a.sofs + cell) * 4u : BUF_OOB_BASE;
+  const unsigned hl = lead ? ((unsigned)a.hofs + (unsigned)dir * no + cell) * 4u : BUF_OOB_BASE;
   auto fr = [&](int t) -> unsigned {  // clamped: prefetches past the end re-read the last frame
     const int tc = t < T ? t : T - 1;
     return (unsigned)(dir == 0 ? tc : T - 1 - tc);
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     const unsigned f = fr(t);
     buf_store(gbuf, gl + f * gstride4, act);
     buf_store(cbuf, cl + f * cstride4, c);
-    buf_store(hbuf, cl + f * cstride4, h);
+    buf_store(hbuf, hl + f * hstride4, h);
     // h_t is the recurrent part of the NEXT step's source row (dropped after the last step)
     buf_store(sbuf, t + 1 < T ? sl + fr(t + 1) * sstride4 : BUF_OOB, h);
     *hw = h;

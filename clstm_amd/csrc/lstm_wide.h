@@ -31,7 +31,7 @@ struct LstmWideArgs {
   long long rw_elems;
   float* G;             // [N][nd][no][4]  pre-activations in, activations out (forward)
   float* C;             // [N][nd][no]
-  float* H;             // [N][nd*no]
+  float* H;             // [N][ldh]        [.. 1 | h_dir0 | h_dir1], h at column hofs
   const float* dH;      // [N][nd*no]      (backward)
   float* D;             // [N][nd][no][4]  gate pre-activation deltas (backward)
   float* dC;            // [bs][nd][no]    carried state delta dc_{s+1} * gf_{s+1} (backward)
@@ -39,7 +39,7 @@ struct LstmWideArgs {
   float* S;             // [nd][N][lds] source rows (see lstm_seq.h)
   long long sdir;
   long long N;          // frames in the batch (array extents)
-  int lds, sofs;
+  int lds, sofs, ldh, hofs;
   int no, ndir, bs;
   int kp;               // padded contraction length, multiple of 64
   int step;             // lock-step index: forward own step s = step, backward own step s = T-1-step
@@ -118,11 +118,11 @@ __global__ __launch_bounds__(256) void lstm_wide_fwd_step(LstmWideArgs a) {
       const int off = a.line_off[m], T = a.line_off[m + 1] - off;
       if (sg >= 1 && sg < T) {
         const int fprev = dir == 0 ? sg - 1 : T - sg;   // frame of own step s-1
-        arow[i] = (unsigned)(((long long)(off + fprev) * nd + dir) * no) * 4u;
+        arow[i] = (unsigned)((long long)(off + fprev) * a.ldh + a.hofs + dir * no) * 4u;
       }
     }
   }
-  const BufF32 abuf = make_buf(a.H, (size_t)a.N * nd * no * 4);
+  const BufF32 abuf = make_buf(a.H, (size_t)a.N * a.ldh * 4);
   const BufF32 bbuf = make_buf(a.Rw, (size_t)a.rw_elems * 4);
   const unsigned brow = (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp) * 4u;
 
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void lstm_wide_fwd_step(LstmWideArgs a) {
   act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
   *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
   a.C[(n * nd + dir) * no + cell] = c;
-  a.H[n * (nd * no) + dir * no + cell] = h;
+  a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
   float* srow = a.S + (size_t)dir * a.sdir;
   if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;                      // h_{-1} = 0
   if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;

@@ -262,25 +262,36 @@ __global__ void k_build_source(float* S, const float* x, size_t N, int ni, int l
 }
 // g[off(b, c) + rs*r] = sum_z partial[b*nsplit + z][r][c]   (deterministic split-K reduction + row scatter;
 // every parameter is produced by exactly one (b, r, c), so this assigns and g needs no clearing)
-__global__ void k_reduce_scatter(const float* partial, int nsplit, int nbatch, int R, int Cn, float* g,
-                                 const long long* moff, long long base, int rs) {
-  const size_t RC = (size_t)R * Cn;
-  CLSTM_GRID_STRIDE(e, RC * nbatch) {
-    const int b = e / RC;
-    const int rc = e - b * RC;
-    const int r = rc / Cn, c = rc % Cn;
-    const float* p = partial + (size_t)b * nsplit * RC + rc;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int z = 0;
-    for (; z + 4 <= nsplit; z += 4) {   // four independent loads in flight, fixed summation order
-      s0 += p[(size_t)z * RC];
-      s1 += p[(size_t)(z + 1) * RC];
-      s2 += p[(size_t)(z + 2) * RC];
-      s3 += p[(size_t)(z + 3) * RC];
-    }
-    for (; z < nsplit; z++) s0 += p[(size_t)z * RC];
-    const long long o = (moff ? moff[(size_t)b * Cn + c] : base + c) + (long long)rs * r;
-    g[o] = (s0 + s1) + (s2 + s3);
+struct ReduceDesc {
+  const float* partial;
+  const long long* moff;
+  long long base;
+  int nsplit, nbatch, R, Cn, rs;
+};
+DEVFN void reduce_scatter_one(const ReduceDesc& d, size_t e, float* g) {
+  const size_t RC = (size_t)d.R * d.Cn;
+  const int b = e / RC;
+  const int rc = e - b * RC;
+  const int r = rc / d.Cn, c = rc % d.Cn;
+  const float* p = d.partial + (size_t)b * d.nsplit * RC + rc;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int z = 0;
+  for (; z + 4 <= d.nsplit; z += 4) {   // four independent loads in flight, fixed summation order
+    s0 += p[(size_t)z * RC];
+    s1 += p[(size_t)(z + 1) * RC];
+    s2 += p[(size_t)(z + 2) * RC];
+    s3 += p[(size_t)(z + 3) * RC];
+  }
+  for (; z < d.nsplit; z++) s0 += p[(size_t)z * RC];
+  const long long o = (d.moff ? d.moff[(size_t)b * d.Cn + c] : d.base + c) + (long long)d.rs * r;
+  g[o] = (s0 + s1) + (s2 + s3);
+}
+// up to two slab sets per launch (the softmax layer's weight gradient rides with the top LSTM layer's)
+__global__ void k_reduce_scatter(ReduceDesc d0, ReduceDesc d1, float* g) {
+  const size_t n0 = (size_t)d0.R * d0.Cn * d0.nbatch, n1 = (size_t)d1.R * d1.Cn * d1.nbatch;
+  CLSTM_GRID_STRIDE(e, n0 + n1) {
+    if (e < n0) reduce_scatter_one(d0, e, g);
+    else reduce_scatter_one(d1, e - n0, g);
   }
 }
 // diagnostics: the cross-lane primitives applied to the lane index (tests/test_intrinsics.py)
@@ -298,6 +309,31 @@ __global__ void k_debug_lane_ops(float* out) {
   out[8 * 64 + lane] = row_ror<8>(x);
   out[9 * 64 + lane] = row_half_mirror(x);
   out[10 * 64 + lane] = wave_shr1(x);
+}
+// device-resident input frames: one pass copies them into the net's input block AND lays down the
+// first layer's source rows (replaces a D2D memcpy followed by k_build_source)
+__global__ void k_ingest(const float* x, float* X, float* S, size_t N, int ni, int lds, int ndir, long long sdir) {
+  CLSTM_GRID_STRIDE(e, N * (size_t)(1 + ni)) {
+    const size_t n = e / (1 + ni);
+    const int j = e % (1 + ni);
+    float v = 1.0f;
+    if (j > 0) {
+      v = x[n * ni + (j - 1)];
+      X[n * ni + (j - 1)] = v;
+    }
+    for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = v;
+  }
+}
+// constant-1 column of the output rows [1 | h] (written when the buffer grows; rows never move)
+__global__ void k_fill_col0(float* H, size_t rows, int ld, int col) {
+  CLSTM_GRID_STRIDE(e, rows) H[e * ld + col] = 1.0f;
+}
+// gather rows of a strided plane: out[n][c] = src[n*ld + c]
+__global__ void k_gather_rows(const float* src, float* out, size_t N, int no, int ld) {
+  CLSTM_GRID_STRIDE(e, N * no) {
+    const size_t n = e / no;
+    out[e] = src[n * ld + (e % no)];
+  }
 }
 // gather one NPLSTM state plane into [N][no] for the parity tests
 __global__ void k_gather_state(const float* src, float* out, size_t N, int no, int ndir, int dir, int slot) {

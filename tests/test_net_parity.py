@@ -174,3 +174,29 @@ def test_errors_are_reported(backend):
         net.ctc([[0]])                             # blank inside a transcript (clstm.cc:232)
     with pytest.raises(ClstmError):
         net.ctc([[7]])                             # class out of range
+
+
+def test_device_resident_inputs_match_host_inputs(backend, ora32):
+    # clstm_net_set_inputs_d (frames already in device memory: one pass copies them and lays down the first
+    # layer's source rows) must give the same gradient as the host-buffer entry point
+    from clstm_amd.net import Network
+    rng = np.random.default_rng(5)
+    ni, nh, nc, T = 6, 9, 5, [5, 2, 4]
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+    grads = []
+    for device in (False, True):
+        net = Network(ni, nh, nc, lib=backend.lib)
+        net.set_params(params)
+        if device:
+            xd = backend.up(np.concatenate(lines, 0))
+            net.set_batch(T)
+            net.set_inputs_device(xd)
+        else:
+            net.set_inputs(lines)
+        net.forward()
+        net.ctc(trs)
+        net.backward()
+        grads.append(net.get_grads().copy())
+    assert np.array_equal(grads[0], grads[1])
