@@ -115,6 +115,48 @@ DEVFN void buf_store(BufF32 b, unsigned byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.r, byte_off, 0, 0);
 }
 
+// ---- device-scope (sc1) accesses and the grid barrier of the cooperative kernels (lstm_wide.h) ----
+// Data produced and consumed by DIFFERENT workgroups of one launch: per-XCD L2s are not coherent with
+// each other, so such stores are written through (sc1) and such loads ask at device scope (sc1); the
+// barrier then needs no cache maintenance (guide: in-launch hand-off, sc1 variant).
+DEVFN f32x4 buf_load4_dev(BufF32 b, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, byte_off, 0, 16));
+}
+DEVFN void buf_store_dev(BufF32 b, unsigned byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.r, byte_off, 0, 16);
+}
+DEVFN void buf_store4_dev(BufF32 b, unsigned byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b.r, byte_off, 0, 16);
+}
+constexpr int GRID_WATCHDOG_SPINS = 1 << 21;   // ~seconds of polling before a stuck barrier is reported
+// All workgroups of a cooperative launch meet here.  sync[0]: ticket counter (target = arrivals expected
+// so far), sync[1]: watchdog flag.  Returns false (uniformly within the workgroup) once any workgroup has
+// given up waiting; the caller leaves the kernel.
+DEVFN bool grid_barrier(int* sync, int target, int* lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's sc1 stores have been written through
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0, bad = 0;
+    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // relaxed polling
+      if ((++spins & 255) == 0) {   // the watchdog flag is looked at rarely: the poll stays one load per turn
+        bad = __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (spins > GRID_WATCHDOG_SPINS) bad = 1;
+        if (bad) break;
+      }
+    }
+    if (bad) __hip_atomic_store(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *lds_flag = bad;
+  }
+  __syncthreads();
+  return *lds_flag == 0;
+}
+#define CLSTM_LAUNCH_COOP(kernel, grid, block, smem, stream, argstruct)                                  \
+  do {                                                                                                   \
+    void* coop_args_[] = {(void*)&(argstruct)};                                                          \
+    HIPCHECK(hipLaunchCooperativeKernel((const void*)(kernel), grid, block, coop_args_, smem, (hipStream_t)(stream))); \
+  } while (0)
+
 // A VMEM store reads its data VGPR when the memory pipeline executes it, so hipcc inserts a vmcnt
 // wait before that register may be overwritten.  KEEP_ALIVE(x) placed two recurrence steps later
 // pins the register until then, which moves that wait off the per-step critical path.

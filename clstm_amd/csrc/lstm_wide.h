@@ -43,70 +43,97 @@ struct LstmWideArgs {
   int no, ndir, bs;
   int kp;               // padded contraction length, multiple of 64
   int step;             // lock-step index: forward own step s = step, backward own step s = T-1-step
+  int tmax;             // cooperative kernels: number of lock-steps (longest line)
+  int* sync;            // cooperative kernels: [0] barrier ticket counter (zeroed per launch), [1] watchdog flag
 };
 
 constexpr int WIDE_LDW = 20;  // LDS row stride of a partial tile (16 columns + pad, float4-aligned)
-constexpr int WIDE_PF = 4;    // 16-k groups in flight per wave
+constexpr int WIDE_PF = 4;    // 16-k groups in flight per wave, per-step kernels (8 measured slower: 200 VGPRs)
+constexpr int WIDE_PF_COOP = 8;  // cooperative kernels: all groups of a 512-cell layer in flight at once
+constexpr int WIDE_WPAD = 4;  // LDS weight rows are kp + 4 floats: 16 rows x b128 reads cover all banks once
 
 // acc[i] += A_i(16 rows x kslice) . B(kslice x 16 cols) for this wave's quarter of the contraction,
 // then the four waves' partial tiles are left in red[wave][row][col] (caller syncs).
-template <int MT>
+// COOP = false: B rows come from global memory (bbuf/brow), A rows by plain loads (per-step launches).
+// COOP = true : B rows are resident in LDS (wl, row stride kp + WIDE_WPAD), A rows were written by OTHER
+//               workgroups of the same launch -> device-scope (sc1) loads.
+template <int MT, int NT, bool COOP>
 DEVFN void wide_tile(const BufF32 abuf, const unsigned (&arow)[MT], const BufF32 bbuf, const unsigned brow,
-                     const int kp, float* red) {
+                     const float* wl, const int kp, float* red) {
+  constexpr int PF = COOP ? WIDE_PF_COOP : WIDE_PF;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int kw = kp >> 2;                 // contraction range of one wave (multiple of 16)
   const int ngroups = kw >> 4;
   const unsigned klane = (unsigned)(wave * kw + 4 * (lane >> 4)) * 4u;
-  f32x4 acc[MT];
+  f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; i++)
 #pragma unroll
-    for (int q = 0; q < 4; q++) acc[i][q] = 0.0f;
-  f32x4 ra[WIDE_PF][MT], rb[WIDE_PF];
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+  f32x4 ra[PF][MT], rb[PF][NT];
   // unconditional issue (groups past the end get out-of-range offsets): exact vmcnt, see gemm_mfma.h
-  auto load_group = [&](int g, f32x4 (&a)[MT], f32x4& b) {
+  auto load_group = [&](int g, f32x4 (&a)[MT], f32x4 (&b)[NT]) {
     const bool live = g < ngroups;
     const unsigned ko = klane + (unsigned)g * 64u;
 #pragma unroll
-    for (int i = 0; i < MT; i++) a[i] = buf_load4(abuf, live ? arow[i] + ko : BUF_OOB);
-    b = buf_load4(bbuf, live ? brow + ko : BUF_OOB);
-  };
+    for (int i = 0; i < MT; i++)
+      a[i] = COOP ? buf_load4_dev(abuf, live ? arow[i] + ko : BUF_OOB) : buf_load4(abuf, live ? arow[i] + ko : BUF_OOB);
+    if (!COOP) {
 #pragma unroll
-  for (int p = 0; p < WIDE_PF; p++) {
+      for (int j = 0; j < NT; j++) b[j] = buf_load4(bbuf, live ? brow + (unsigned)j * 16u * (unsigned)kp * 4u + ko : BUF_OOB);
+    }
+  };
+  const int ldw = kp + WIDE_WPAD;
+  const float* wrow = COOP ? wl + (lane & 15) * ldw + (klane >> 2) : nullptr;
+#pragma unroll
+  for (int p = 0; p < PF; p++) {
     load_group(p, ra[p], rb[p]);
     SCHED_FENCE();
   }
-  for (int g0 = 0; g0 < ngroups; g0 += WIDE_PF) {
+  for (int g0 = 0; g0 < ngroups; g0 += PF) {
 #pragma unroll
-    for (int p = 0; p < WIDE_PF; p++) {
-      f32x4 av[MT];
+    for (int p = 0; p < PF; p++) {
+      f32x4 av[MT], bv[NT];
 #pragma unroll
       for (int i = 0; i < MT; i++) av[i] = ra[p][i];
-      const f32x4 bv = rb[p];
+      if (COOP) {  // groups past the end multiply zero A rows: any in-range weight group will do
+        const int g = g0 + p < ngroups ? g0 + p : ngroups - 1;
+#pragma unroll
+        for (int j = 0; j < NT; j++) bv[j] = *reinterpret_cast<const f32x4*>(wrow + j * 16 * ldw + g * 16);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NT; j++) bv[j] = rb[p][j];
+      }
 #pragma unroll
       for (int e = 0; e < 4; e++)
 #pragma unroll
-        for (int i = 0; i < MT; i++) acc[i] = mfma16x16x4(av[i][e], bv[e], acc[i]);
-      load_group(g0 + p + WIDE_PF, ra[p], rb[p]);
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+          for (int j = 0; j < NT; j++) acc[i][j] = mfma16x16x4(av[i][e], bv[j][e], acc[i][j]);
+      load_group(g0 + p + PF, ra[p], rb[p]);
       SCHED_FENCE();
     }
   }
-  // D layout: lane holds rows (lane>>4)*4 + q, column lane&15
+  // D layout: lane holds rows (lane>>4)*4 + q, column lane&15; red row stride NT*16 + 4
+  constexpr int LDR = NT * 16 + 4;
 #pragma unroll
   for (int i = 0; i < MT; i++)
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * WIDE_LDW + (lane & 15)] = acc[i][q];
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * LDR + j * 16 + (lane & 15)] = acc[i][j][q];
 }
 
-// ---- forward: one time step of every line ------------------------------------------------------
-// grid (ceil(no/4), ndir, ceil(bs / 16MT)), 256 threads
-template <int MT>
-__global__ __launch_bounds__(256) void lstm_wide_fwd_step(LstmWideArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[4 * MT * 16 * WIDE_LDW];
+// ---- forward: one time step of 16*MT lines for one (cell group, direction) ------------------------
+// loff: line offsets (global for the per-step launch, an LDS copy in the cooperative kernel)
+template <int MT, bool COOP>
+DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, const int dir, const int zb,
+                         const int* loff, const float* wl, float* red) {
   const int tid = threadIdx.x, lane = tid & 63;
-  const int cg = blockIdx.x, dir = blockIdx.y, zb = blockIdx.z;
-  const int no = a.no, nd = a.ndir, sg = a.step;
+  const int no = a.no, nd = a.ndir;
   const int ncg = (no + 3) >> 2;
 
   unsigned arow[MT];
@@ -115,7 +142,7 @@ __global__ __launch_bounds__(256) void lstm_wide_fwd_step(LstmWideArgs a) {
     const int m = (zb * MT + i) * 16 + (lane & 15);
     arow[i] = BUF_OOB_BASE;
     if (m < a.bs) {
-      const int off = a.line_off[m], T = a.line_off[m + 1] - off;
+      const int off = loff[m], T = loff[m + 1] - off;
       if (sg >= 1 && sg < T) {
         const int fprev = dir == 0 ? sg - 1 : T - sg;   // frame of own step s-1
         arow[i] = (unsigned)((long long)(off + fprev) * a.ldh + a.hofs + dir * no) * 4u;
@@ -133,8 +160,8 @@ __global__ __launch_bounds__(256) void lstm_wide_fwd_step(LstmWideArgs a) {
   bool live = ml < MT * 16 && line < a.bs && cell < no;
   int off = 0, T = 0;
   if (live) {
-    off = a.line_off[line];
-    T = a.line_off[line + 1] - off;
+    off = loff[line];
+    T = loff[line + 1] - off;
     live = sg < T;
   }
   const long long n = off + (dir == 0 ? sg : T - 1 - sg);
@@ -142,44 +169,55 @@ __global__ __launch_bounds__(256) void lstm_wide_fwd_step(LstmWideArgs a) {
   const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
   const unsigned goff = live ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB;
   const f32x4 gx = buf_load4(gbuf, goff);
+  // c_{s-1} was written by this very thread one step ago (same (line, cell) role), so a plain load is
+  // coherent in the cooperative kernel as well
   const float c_prev = buf_load(cbuf, live && sg >= 1
       ? (unsigned)((((long long)(off + (dir == 0 ? sg - 1 : T - sg)) * nd + dir) * no + cell) * 4) : BUF_OOB);
 
-  wide_tile<MT>(abuf, arow, bbuf, brow, a.kp, red);
+  wide_tile<MT, 1, COOP>(abuf, arow, bbuf, brow, wl, a.kp, red);
   __syncthreads();
 
   // fused forward_full1 x4 + forward_statemem + forward_nonlingate for (line, cell)
-  if (!live) return;
-  f32x4 k;
+  if (live) {
+    f32x4 k;
 #pragma unroll
-  for (int q = 0; q < 4; q++) k[q] = 0.0f;
+    for (int q = 0; q < 4; q++) k[q] = 0.0f;
 #pragma unroll
-  for (int w = 0; w < 4; w++) {
-    const f32x4 p = *reinterpret_cast<const f32x4*>(&red[((w * MT + (ml >> 4)) * 16 + (ml & 15)) * WIDE_LDW + cl * 4]);
+    for (int w = 0; w < 4; w++) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(&red[((w * MT + (ml >> 4)) * 16 + (ml & 15)) * WIDE_LDW + cl * 4]);
 #pragma unroll
-    for (int q = 0; q < 4; q++) k[q] += p[q];
+      for (int q = 0; q < 4; q++) k[q] += p[q];
+    }
+    const float gi = gate_act(k[0] + gx[0], false), gf = gate_act(k[1] + gx[1], false),
+                go = gate_act(k[2] + gx[2], false), ci = gate_act(k[3] + gx[3], true);
+    const float c = ci * gi + gf * c_prev;      // c_prev reads 0 at the first step
+    const float h = gate_act(c, true) * go;
+    f32x4 act;
+    act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
+    *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
+    a.C[(n * nd + dir) * no + cell] = c;
+    // h_t is next step's A operand of every workgroup of this direction
+    if (COOP) buf_store_dev(abuf, (unsigned)(n * a.ldh + a.hofs + dir * no + cell) * 4u, h);
+    else a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
+    float* srow = a.S + (size_t)dir * a.sdir;
+    if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;                      // h_{-1} = 0
+    if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
   }
-  const float gi = gate_act(k[0] + gx[0], false), gf = gate_act(k[1] + gx[1], false),
-              go = gate_act(k[2] + gx[2], false), ci = gate_act(k[3] + gx[3], true);
-  const float c = ci * gi + gf * c_prev;      // c_prev reads 0 at the first step
-  const float h = gate_act(c, true) * go;
-  f32x4 act;
-  act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
-  *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
-  a.C[(n * nd + dir) * no + cell] = c;
-  a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
-  float* srow = a.S + (size_t)dir * a.sdir;
-  if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;                      // h_{-1} = 0
-  if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
 }
 
-// ---- backward: one time step of every line -------------------------------------------------------
-// grid (ceil(no/16), ndir, ceil(bs/16)), 256 threads
-__global__ __launch_bounds__(256) void lstm_wide_bwd_step(LstmWideArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * WIDE_LDW];
+// per-step launch: grid (ceil(no/4), ndir, ceil(bs / 16MT)), 256 threads
+template <int MT>
+__global__ __launch_bounds__(256) void lstm_wide_fwd_step(LstmWideArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[4 * MT * 16 * WIDE_LDW];
+  wide_fwd_tile<MT, false>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);
+}
+
+// ---- backward: one time step of 16 lines for one (16-cell tile, direction) ------------------------
+template <bool COOP>
+DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, const int dir, const int zb,
+                         const int* loff, const float* wl, float* red) {
   const int tid = threadIdx.x, lane = tid & 63;
-  const int ct = blockIdx.x, dir = blockIdx.y, zb = blockIdx.z;
-  const int no = a.no, nd = a.ndir, sg = a.step;
+  const int no = a.no, nd = a.ndir;
   const int nct = (no + 15) >> 4;
 
   unsigned arow[1];
@@ -187,7 +225,7 @@ __global__ __launch_bounds__(256) void lstm_wide_bwd_step(LstmWideArgs a) {
     const int m = zb * 16 + (lane & 15);
     arow[0] = BUF_OOB_BASE;
     if (m < a.bs) {
-      const int off = a.line_off[m], T = a.line_off[m + 1] - off;
+      const int off = loff[m], T = loff[m + 1] - off;
       if (sg >= 1 && sg < T) {
         const int fnext = dir == 0 ? T - sg : sg - 1;   // frame of own step s+1, s = T-1-sg
         arow[0] = (unsigned)(((long long)(off + fnext) * nd + dir) * 4 * no) * 4u;
@@ -204,8 +242,8 @@ __global__ __launch_bounds__(256) void lstm_wide_bwd_step(LstmWideArgs a) {
   bool live = line < a.bs && cell < no;
   int off = 0, T = 0;
   if (live) {
-    off = a.line_off[line];
-    T = a.line_off[line + 1] - off;
+    off = loff[line];
+    T = loff[line + 1] - off;
     live = sg < T;
   }
   const int s = T - 1 - sg;
@@ -221,29 +259,186 @@ __global__ __launch_bounds__(256) void lstm_wide_bwd_step(LstmWideArgs a) {
   const float c_m1 = buf_load(cbuf, live && s >= 1       // c_{s-1}; 0 at s = 0 ("gf.d untouched when last < 0")
       ? (unsigned)((((long long)(off + (dir == 0 ? s - 1 : sg + 1)) * nd + dir) * no + cell) * 4) : BUF_OOB);
   const unsigned dcoff = (unsigned)((((long long)line * nd + dir) * no + cell) * 4);
-  const float dc_carry = buf_load(dcbuf, live && sg >= 1 ? dcoff : BUF_OOB);
+  const float dc_carry = buf_load(dcbuf, live && sg >= 1 ? dcoff : BUF_OOB);   // own write of the previous step
 
-  wide_tile<1>(abuf, arow, bbuf, brow, a.kp, red);
+  wide_tile<1, 1, COOP>(abuf, arow, bbuf, brow, wl, a.kp, red);
   __syncthreads();
 
-  if (!live) return;
-  float dh_rec = 0.0f;
+  if (live) {
+    float dh_rec = 0.0f;
 #pragma unroll
-  for (int w = 0; w < 4; w++) dh_rec += red[(w * 16 + ml) * WIDE_LDW + c16];
-  const float gi = act[0], gf = act[1], go = act[2], ci = act[3];
-  const float dh = dh_in + dh_rec;           // out[s].d, clstm.cc:626-628 + :646
-  const float th = gate_act(c_s, true);      // backward_nonlingate recomputes tanh(state)
-  const float d_go = th * dh;
-  const float dc = dc_carry + (-th * th + 1.0f) * (go * dh);
-  a.dC[dcoff / 4] = dc * gf;                 // backward_statemem (clstm_compute.cc:509-515)
-  const float d_gf = dc * c_m1;
-  const float d_gi = dc * ci, d_ci = dc * gi;
-  f32x4 dl;                                  // backward_nonlin0: y(1-y) for SIG, 1-y^2 for TANH
-  dl[0] = (gi * (-gi + 1.0f)) * d_gi;
-  dl[1] = (gf * (-gf + 1.0f)) * d_gf;
-  dl[2] = (go * (-go + 1.0f)) * d_go;
-  dl[3] = (-ci * ci + 1.0f) * d_ci;
-  *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
+    for (int w = 0; w < 4; w++) dh_rec += red[(w * 16 + ml) * WIDE_LDW + c16];
+    const float gi = act[0], gf = act[1], go = act[2], ci = act[3];
+    const float dh = dh_in + dh_rec;           // out[s].d, clstm.cc:626-628 + :646
+    const float th = gate_act(c_s, true);      // backward_nonlingate recomputes tanh(state)
+    const float d_go = th * dh;
+    const float dc = dc_carry + (-th * th + 1.0f) * (go * dh);
+    a.dC[dcoff / 4] = dc * gf;                 // backward_statemem (clstm_compute.cc:509-515)
+    const float d_gf = dc * c_m1;
+    const float d_gi = dc * ci, d_ci = dc * gi;
+    f32x4 dl;                                  // backward_nonlin0: y(1-y) for SIG, 1-y^2 for TANH
+    dl[0] = (gi * (-gi + 1.0f)) * d_gi;
+    dl[1] = (gf * (-gf + 1.0f)) * d_gf;
+    dl[2] = (go * (-go + 1.0f)) * d_go;
+    dl[3] = (-ci * ci + 1.0f) * d_ci;
+    // the deltas are next step's A operand of every workgroup of this direction
+    if (COOP) buf_store4_dev(abuf, coff * 4u, dl);
+    else *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
+  }
+}
+
+// per-step launch: grid (ceil(no/16), ndir, ceil(bs/16)), 256 threads
+__global__ __launch_bounds__(256) void lstm_wide_bwd_step(LstmWideArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * WIDE_LDW];
+  wide_bwd_tile<false>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);
+}
+
+// ---- cooperative persistent variants -----------------------------------------------------------------
+// ONE launch walks all time steps: every workgroup keeps its 16 weight rows in LDS for the whole
+// sequence, and the steps are separated by a grid-wide barrier instead of a kernel boundary.  All
+// workgroups must be co-resident (launched with hipLaunchCooperativeKernel, grid <= CU count).
+// Cross-workgroup data (h_t forward, the gate deltas backward) travels by device-scope (sc1) stores and
+// loads, so the barrier itself needs no cache maintenance: drain the stores, one relaxed agent-scope
+// ticket, relaxed polling (guide: "in-launch hand-off", sc1 variant).  The poll loop carries a watchdog:
+// a workgroup that waits longer than ~seconds raises sync[1] and every workgroup leaves, so a scheduling
+// accident surfaces as an error instead of a hung GPU.
+struct CoopLds {
+  int weights, red, loff, flag, words;
+};
+// nrows weight rows resident per workgroup, ncols = columns of its partial tile
+inline __host__ __device__ CoopLds coop_lds_layout(int kp, int nrows, int ncols, int bs) {
+  CoopLds l;
+  int o = 0;
+  l.weights = o; o += nrows * (kp + WIDE_WPAD);
+  l.red = o;     o += 4 * 16 * (ncols + 4);
+  l.loff = o;    o += ((bs + 1 + 3) / 4) * 4;
+  l.flag = o;    o += 4;
+  l.words = o;
+  return l;
+}
+// weight rows [row0, row0 + nrows) of the packed array (rows >= rows_total read as zero) and the line
+// offsets, once per launch
+DEVFN void coop_stage(const LstmWideArgs& a, const float* wbase, long long row0, long long rows_total, int nrows,
+                      float* wl, int* loff) {
+  const int tid = threadIdx.x;
+  const int k4 = a.kp >> 2;
+  for (int i = tid; i < nrows * k4; i += 256) {
+    const int row = i / k4, c4 = i - row * k4;
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = 0.0f;
+    if (row0 + row < rows_total) v = *reinterpret_cast<const f32x4*>(wbase + (size_t)(row0 + row) * a.kp + c4 * 4);
+    *reinterpret_cast<f32x4*>(wl + row * (a.kp + WIDE_WPAD) + c4 * 4) = v;
+  }
+  for (int i = tid; i <= a.bs; i += 256) loff[i] = a.line_off[i];
+  __syncthreads();
+}
+
+// Cooperative forward tile: 16 lines x (16 cells x 4 gates).  Compared with the per-step kernel's
+// 64 lines x 4 cells it quarters the h_{t-1} bytes a workgroup pulls per step (32 KB at no = 512) --
+// those come at the cross-XCD per-workgroup rate -- and instead keeps 64 weight rows (132 KB) in LDS.
+DEVFN void coop_fwd_tile(const LstmWideArgs& a, const int sg, const int ct, const int dir, const int zb,
+                         const int* loff, const float* wl, float* red) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int no = a.no, nd = a.ndir;
+  unsigned arow[1];
+  {
+    const int m = zb * 16 + (lane & 15);
+    arow[0] = BUF_OOB_BASE;
+    if (m < a.bs) {
+      const int off = loff[m], T = loff[m + 1] - off;
+      if (sg >= 1 && sg < T) {
+        const int fprev = dir == 0 ? sg - 1 : T - sg;   // frame of own step s-1
+        arow[0] = (unsigned)((long long)(off + fprev) * a.ldh + a.hofs + dir * no) * 4u;
+      }
+    }
+  }
+  const BufF32 abuf = make_buf(a.H, (size_t)a.N * a.ldh * 4);
+  const int ml = tid >> 4, c16 = tid & 15;
+  const int line = zb * 16 + ml, cell = ct * 16 + c16;
+  bool live = line < a.bs && cell < no;
+  int off = 0, T = 0;
+  if (live) {
+    off = loff[line];
+    T = loff[line + 1] - off;
+    live = sg < T;
+  }
+  const long long n = off + (dir == 0 ? sg : T - 1 - sg);
+  const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
+  const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
+  const f32x4 gx = buf_load4(gbuf, live ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB);
+  const float c_prev = buf_load(cbuf, live && sg >= 1    // own write of the previous step
+      ? (unsigned)((((long long)(off + (dir == 0 ? sg - 1 : T - sg)) * nd + dir) * no + cell) * 4) : BUF_OOB);
+
+  wide_tile<1, 4, true>(abuf, arow, abuf, 0u, wl, a.kp, red);
+  __syncthreads();
+
+  if (live) {
+    f32x4 k;
+#pragma unroll
+    for (int q = 0; q < 4; q++) k[q] = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {   // columns of cell c16: cell group c16>>2, slot (c16&3)*4 + gate
+      const f32x4 p = *reinterpret_cast<const f32x4*>(&red[(w * 16 + ml) * 68 + c16 * 4]);
+#pragma unroll
+      for (int q = 0; q < 4; q++) k[q] += p[q];
+    }
+    const float gi = gate_act(k[0] + gx[0], false), gf = gate_act(k[1] + gx[1], false),
+                go = gate_act(k[2] + gx[2], false), ci = gate_act(k[3] + gx[3], true);
+    const float c = ci * gi + gf * c_prev;
+    const float h = gate_act(c, true) * go;
+    f32x4 act;
+    act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
+    *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
+    a.C[(n * nd + dir) * no + cell] = c;
+    buf_store_dev(abuf, (unsigned)(n * a.ldh + a.hofs + dir * no + cell) * 4u, h);   // next step's A operand
+    float* srow = a.S + (size_t)dir * a.sdir;
+    if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;                      // h_{-1} = 0
+    if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+  }
+}
+
+// grid (ceil(no/16), ndir, zsplit), 256 threads; workgroup z walks line blocks z, z + zsplit, ...
+__global__ __launch_bounds__(256) void lstm_coop_fwd(LstmWideArgs a) {
+  float* smem = dyn_smem<float>();
+  const CoopLds L = coop_lds_layout(a.kp, 64, 64, a.bs);
+  float* wl = smem + L.weights;
+  float* red = smem + L.red;
+  int* loff = reinterpret_cast<int*>(smem + L.loff);
+  const int ct = blockIdx.x, dir = blockIdx.y;
+  const int ncg = (a.no + 3) >> 2;
+  // packed rows of cell groups 4ct .. 4ct+3 of this direction (16 rows each: cell_local*4 + gate)
+  coop_stage(a, a.Rw + (size_t)dir * ncg * 16 * a.kp, (long long)ct * 64, (long long)ncg * 16, 64, wl, loff);
+  const int nzb = (a.bs + 15) / 16;
+  const int nwg = gridDim.x * gridDim.y * gridDim.z;
+  for (int sg = 0; sg < a.tmax; sg++) {
+    for (int zb = blockIdx.z; zb < nzb; zb += gridDim.z) {
+      coop_fwd_tile(a, sg, ct, dir, zb, loff, wl, red);
+      if (zb + (int)gridDim.z < nzb) __syncthreads();   // partial tiles are reused by the next line block
+    }
+    if (sg + 1 < a.tmax && !grid_barrier(a.sync, (sg + 1) * nwg, reinterpret_cast<int*>(smem + L.flag))) return;
+  }
+}
+
+// grid (ceil(no/16), ndir, zsplit), 256 threads; workgroup z walks line blocks z, z + zsplit, ...
+__global__ __launch_bounds__(256) void lstm_coop_bwd(LstmWideArgs a) {
+  float* smem = dyn_smem<float>();
+  const CoopLds L = coop_lds_layout(a.kp, 16, 16, a.bs);
+  float* wl = smem + L.weights;
+  float* red = smem + L.red;
+  int* loff = reinterpret_cast<int*>(smem + L.loff);
+  const int ct = blockIdx.x, dir = blockIdx.y;
+  const int nct = (a.no + 15) >> 4;
+  coop_stage(a, a.Rw + (size_t)dir * nct * 16 * a.kp, (long long)ct * 16, (long long)nct * 16, 16, wl, loff);
+  const int nzb = (a.bs + 15) / 16;
+  const int nwg = gridDim.x * gridDim.y * gridDim.z;
+  for (int sg = 0; sg < a.tmax; sg++) {
+    for (int zb = blockIdx.z; zb < nzb; zb += gridDim.z) {
+      wide_bwd_tile<true>(a, sg, ct, dir, zb, loff, wl, red);
+      if (zb + (int)gridDim.z < nzb) __syncthreads();
+    }
+    if (sg + 1 < a.tmax && !grid_barrier(a.sync, (sg + 1) * nwg, reinterpret_cast<int*>(smem + L.flag))) return;
+  }
 }
 
 // contraction padding of the packed weights

@@ -8,6 +8,7 @@
 #pragma once
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -149,7 +150,69 @@ inline f32x2 buf_load2(BufF32 b, unsigned off) { f32x2 r; r[0] = buf_load(b, off
 inline void buf_store(BufF32 b, unsigned off, float v) { if ((size_t)off + 4 <= b.bytes) b.base[off / 4] = v; }
 inline void buf_store2(BufF32 b, unsigned off, f32x2 v) { buf_store(b, off, v[0]); buf_store(b, off + 4, v[1]); }
 #define KEEP_ALIVE2(x) (void)(x)
+inline f32x4 buf_load4_dev(BufF32 b, unsigned off) { return buf_load4(b, off); }
+inline void buf_store_dev(BufF32 b, unsigned off, float v) { buf_store(b, off, v); }
+inline void buf_store4_dev(BufF32 b, unsigned off, f32x4 v) { for (int i = 0; i < 4; i++) buf_store(b, off + 4 * i, v[i]); }
 template <typename T> inline T* dyn_smem() { return reinterpret_cast<T*>(emu_blk->smem); }
+
+// grid barrier of the cooperative kernels: blocks of an emu_launch_coop run concurrently
+inline bool grid_barrier(int* sync, int target, int* lds_flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __atomic_fetch_add(sync, 1, __ATOMIC_SEQ_CST);
+    long spins = 0;
+    int bad = 0;
+    while (__atomic_load_n(sync, __ATOMIC_SEQ_CST) < target) {
+      sched_yield();
+      bad = __atomic_load_n(sync + 1, __ATOMIC_SEQ_CST);
+      if (++spins > 200000000L) bad = 1;
+      if (bad) break;
+    }
+    if (bad) __atomic_store_n(sync + 1, 1, __ATOMIC_SEQ_CST);
+    *lds_flag = bad;
+  }
+  __syncthreads();
+  return *lds_flag == 0;
+}
+
+// cooperative launch: ALL blocks live at once (needed by grid_barrier); only for small test grids
+template <typename K, typename A>
+void emu_launch_coop(K kernel, dim3 grid, dim3 block, size_t smem, A arg) {
+  const unsigned nthreads = block.x * block.y * block.z;
+  const unsigned nblocks = grid.x * grid.y * grid.z;
+  if (nthreads % 64 != 0) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }
+  if ((size_t)nblocks * nthreads > 20000) { fprintf(stderr, "emu: cooperative grid too large for the emulator\n"); abort(); }
+  std::vector<EmuBlock> blks(nblocks);
+  std::vector<std::vector<char>> sms(nblocks);
+  std::vector<std::thread> th;
+  th.reserve((size_t)nblocks * nthreads);
+  for (unsigned b = 0; b < nblocks; b++) {
+    EmuBlock& blk = blks[b];
+    pthread_barrier_init(&blk.block_bar, nullptr, nthreads);
+    blk.wave_bar.resize(nthreads / 64);
+    for (auto& w : blk.wave_bar) pthread_barrier_init(&w, nullptr, 64);
+    blk.xf.assign((size_t)nthreads * 8, 0.f);
+    sms[b].assign(smem + 16, 0);
+    blk.smem = sms[b].data();
+  }
+  for (unsigned b = 0; b < nblocks; b++)
+    for (unsigned t = 0; t < nthreads; t++)
+      th.emplace_back([&, b, t]() {
+        emu_blk = &blks[b];
+        threadIdx = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+        blockIdx = {b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y)};
+        blockDim = block;
+        gridDim = grid;
+        kernel(arg);
+      });
+  for (auto& t : th) t.join();
+  for (auto& blk : blks) {
+    pthread_barrier_destroy(&blk.block_bar);
+    for (auto& w : blk.wave_bar) pthread_barrier_destroy(&w);
+  }
+}
+#define CLSTM_LAUNCH_COOP(kernel, grid, block, smem, stream, argstruct) \
+  emu_launch_coop(kernel, dim3(grid), dim3(block), smem, argstruct)
 
 template <typename K, typename... Args>
 void emu_launch(K kernel, dim3 grid, dim3 block, size_t smem, Args... args) {

@@ -80,10 +80,12 @@ def test_bidi_uw3_shape_short(backend, ora32):
     (4, [7, 5], 4, [4, 6]),               # forced: two stacked layers
     (6, 21, 5, [3] * 18 + [5]),           # forced: 19 lines -> two 16-line blocks (MT = 2 forward tile)
 ])
-def test_lockstep_recurrence_forced(backend, ora32, monkeypatch, ni, nh, nc, T):
-    # the lock-step (one launch per time step, MFMA) recurrence of lstm_wide.h on sizes the
-    # register-resident kernels also handle
+@pytest.mark.parametrize("coop", [True, False], ids=["cooperative", "per_step_launch"])
+def test_lockstep_recurrence_forced(backend, ora32, monkeypatch, ni, nh, nc, T, coop):
+    # the lock-step MFMA recurrence of lstm_wide.h on sizes the register-resident kernels also handle:
+    # once as ONE cooperative launch with grid barriers, once as one launch per time step
     monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
+    monkeypatch.setenv("CLSTM_COOP", "1" if coop else "0")
     run_case(backend, ora32, ni, nh, nc, T)
 
 
