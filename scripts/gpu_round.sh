@@ -45,4 +45,13 @@ for CNT in FETCH_SIZE WRITE_SIZE; do
   python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_$CNT" $CNT > "$OUT/pmc_${CNT}_summary.txt" 2>&1; cat "$OUT/pmc_${CNT}_summary.txt"
   find "$OUT/pmc_$CNT" -name "*.csv" -size +8M -delete
 done
+echo "=== rocprofv3 PMC pass: MFMA busy cycles (north star: MFMA utilisation of the batched gate GEMMs)"
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_MFMA" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/rocprof_MFMA.log" 2>&1
+tail -2 "$OUT/rocprof_MFMA.log"
+for CNT in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_MFMA" $CNT > "$OUT/pmc_${CNT}_summary.txt" 2>&1; head -8 "$OUT/pmc_${CNT}_summary.txt"
+done
+find "$OUT/pmc_MFMA" -name "*.csv" -size +8M -delete
+echo "=== bench 2xBiLSTM(512) shape (f32)"
+timeout 600 python bench.py --config b2 --steps 5 --warmup 2 --profile-steps 2 > "$OUT/bench_b2.json" 2> "$OUT/bench_b2.err"; cut -c1-300 "$OUT/bench_b2.json"
 echo "=== done"
