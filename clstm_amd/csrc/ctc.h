@@ -136,20 +136,25 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
       asum[tid] = acc;
     }
     __syncthreads();
-    for (int s0 = lane; s0 < S; s0 += 64) {  // lanes over states, one wave per frame, 4 frames in flight
-      const int cls = stl[s0];
-      for (int t = wave; t < nt; t += 4 * (CTC_THREADS / 64)) {
+    // (frame, state) pairs flattened over all threads (states need not be a multiple of the wave); the
+    // pair of the next element follows incrementally (no integer division in the loop)
+    {
+      const int dq = CTC_THREADS / S, dr = CTC_THREADS - dq * S;
+      int tq = tid / S, sq = tid - tq * S;
+      for (int i0 = tid; i0 < nt * S; i0 += 4 * CTC_THREADS) {
         float o[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int tu = t + u * (CTC_THREADS / 64);
-          o[u] = tu < nt ? rowbuf[tu * ncp + cls] / asum[tu] : 1.0f;
+          const bool in = i0 + u * CTC_THREADS < nt * S;
+          o[u] = in ? rowbuf[tq * ncp + stl[sq]] / asum[tq] : 1.0f;
+          tq += dq; sq += dr;
+          if (sq >= S) { sq -= S; tq++; }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int tu = t + u * (CTC_THREADS / 64);
+          const int i = i0 + u * CTC_THREADS;
           const float l = cr_logf(o[u], tb);
-          if (tu < nt) lm[(size_t)(t0 + tu) * S + s0] = l;
+          if (i < nt * S) lm[(size_t)t0 * S + i] = l;
         }
       }
     }
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
         const int c = stl[s0];
         const float x = e[s0];
         if (c == 0) blank += (double)x;
-        else row[c] += x;
+        else row[c] += x;   // (ds_add_f32 instead was measured 40 % slower for this phase)
       }
       row[0] = (float)blank;
       double total = 0.0;
