@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--minibatch", type=int, default=64, help="lines per GPU")
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="b1")
+    ap.add_argument("--bf16-gemm", action="store_true",
+                    help="hoisted gate GEMMs with bf16 inputs / f32 accumulation (not the parity path)")
     ap.add_argument("--ragged", action="store_true", help="T ~ U{150..250} instead of fixed T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
@@ -127,6 +129,8 @@ def main():
     net = Network(NI, NH, NC, lib=lib, params=params, derivs=derivs, grads=grads)
     net.params_changed()
     net.setLearningRate(1e-4, 0.9)
+    if args.bf16_gemm:
+        net.set_gemm_precision(1)
     trainer = Trainer(net, grads_tensor=grads)
 
     # synthetic minibatches resident in HBM before the timed region (a small rotating pool)
@@ -215,7 +219,8 @@ def main():
                       "text-line images/sec (fwd+bwd+CTC), 2xBiLSTM(512) H=64 T~400 (f32)",
             "value": round(value, 2), "unit": "lines/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (hoisted gate GEMMs: bf16 in, f32 accumulate)" if args.bf16_gemm else "f32",
             "data": "synthetic",
             "config": {"workload": ("uw3-500 OCR shape: BiLSTM(100) H=48 nc=83, T=%s, L=25, minibatch=%d lines/GPU "
                                     "(BASELINE.json configs[2]; x%d GPUs = configs[3] sharding), fwd+CTC+bwd+allreduce+update"

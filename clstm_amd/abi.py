@@ -75,6 +75,7 @@ _SIGS = {
     "clstm_net_set_batch": [_P, _P, _I],
     "clstm_net_set_inputs_h": [_P, _P],
     "clstm_net_set_inputs_d": [_P, _P],
+    "clstm_net_set_gemm_precision": [_P, _I],
     "clstm_net_forward": [_P],
     "clstm_net_outputs": [_P, _P, _P],
     "clstm_net_get_outputs_h": [_P, _P],

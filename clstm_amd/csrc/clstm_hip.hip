@@ -15,6 +15,7 @@
 #include "ctc.h"
 #include "devintrin.h"
 #include "gemm_mfma.h"
+#include "gemm_bf16.h"
 #include "lstm_seq.h"
 #include "lstm_wide.h"
 #include "ops.h"
@@ -295,6 +296,7 @@ struct Layer {
   long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
   DevBuf<float> G, C, H, D, dH, S;
   int lds = 0;
+  int wt_slack = 32;          // floats past Wt a vectorised staging load may touch
   int ldh = 0, hofs = 4;      // H rows: [pad pad pad 1 | h_dir0 | h_dir1], h at column hofs (16-byte aligned)
   float* hrow() const { return H.p + hofs; }            // h block of frame 0
   float* srow() const { return H.p + hofs - 1; }        // [1 | h] = the next layer's / softmax's source row
@@ -311,6 +313,7 @@ struct Net {
   bool own_v = false, own_d = false, own_g = false;
   float lr = 1e-4f, mom = 0.9f, gclip = 100.0f;
   bool packed_dirty = true;
+  bool bf16_gemm = getenv("CLSTM_BF16_GEMM") && atoi(getenv("CLSTM_BF16_GEMM")) != 0;  // hoisted gate GEMMs: bf16 in, f32 accumulate
   bool want_dx0 = false;
   // batch
   int bs = 0, tmax = 0;
@@ -375,7 +378,8 @@ struct Net {
     own(v, pv, own_v); own(d, pd, own_d); own(g, pg, own_g);
     for (auto& y : L) {
       const int M = ndir * 4 * y.no, KQP = 4 * y.nk4;
-      HIPCHECK(hipMalloc((void**)&y.Wt, (size_t)y.ni * M * sizeof(float)));
+      HIPCHECK(hipMalloc((void**)&y.Wt, ((size_t)y.ni * M + y.wt_slack) * sizeof(float)));
+      HIPCHECK(hipMemset(y.Wt, 0, ((size_t)y.ni * M + y.wt_slack) * sizeof(float)));
       HIPCHECK(hipMalloc((void**)&y.bias, (size_t)M * sizeof(float)));
       if (y.wide) {
         y.kpf = wide_kp_fwd(y.no); y.kpb = wide_kp_bwd(y.no);
@@ -469,6 +473,7 @@ struct Net {
 
   const float* layer_input(int l) const { return l == 0 ? X.p : L[l - 1].hrow(); }
   int layer_input_ld(int l) const { return l == 0 ? desc.ninput : L[l - 1].ldh; }
+  int layer_input_slack(int l) const { return 32; }   // X and H are over-allocated by >= 64 floats
 
   LstmWideArgs wide_args(Layer& y, bool fwd) {
     LstmWideArgs w{};
@@ -489,8 +494,12 @@ struct Net {
       Layer& y = L[l];
       const int M = ndir * 4 * y.no;
       timing.begin("gemm_gates_x", s);
-      gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N), gemm_mc(y.Wt, M, y.ni, 0),
-                                 StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
+      if (bf16_gemm)
+        gemm_bf16<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N, layer_input_slack(l)),
+                                    gemm_mc(y.Wt, M, y.ni, y.wt_slack), StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
+      else
+        gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N), gemm_mc(y.Wt, M, y.ni, 0),
+                                   StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
       timing.end(s);
       check_launch();
       timing.begin("build_source", s);
@@ -573,9 +582,14 @@ struct Net {
       const int R = 1 + y.ni + y.no, Cn = 4 * y.no, ns = pick_split(R, Cn, ndir);
       partial.reserve((size_t)ndir * ns * R * Cn);
       timing.begin("gemm_gates_dw", s);
-      gemm_f32<GEMM_MC, GEMM_MC>(s, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
-                                 gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
-                                 StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns, ndir);
+      if (bf16_gemm)
+        gemm_bf16<GEMM_MC, GEMM_MC>(s, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
+                                    gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
+                                    StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns, ndir);
+      else
+        gemm_f32<GEMM_MC, GEMM_MC>(s, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
+                                   gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
+                                   StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns, ndir);
       {
         const ReduceDesc gates{partial.p, y.moff, 0LL, ns, ndir, R, Cn, y.no};
         ReduceDesc extra{};   // empty unless this is the top layer
@@ -591,8 +605,12 @@ struct Net {
       else if (want_dx0) { dX0.reserve((size_t)N * y.ni); dx = dX0.p; }
       if (dx) {
         timing.begin("gemm_gates_dx", s);
-        gemm_f32<GEMM_KC, GEMM_KC>(s, gemm_kc(y.D.p, M, N), gemm_kc(y.Wt, M, y.ni, 0), StorePlain{dx, y.ni}, (int)N,
-                                   y.ni, M);
+        if (bf16_gemm)
+          gemm_bf16<GEMM_KC, GEMM_KC>(s, gemm_kc(y.D.p, M, N, 32), gemm_kc(y.Wt, M, y.ni, y.wt_slack), StorePlain{dx, y.ni},
+                                      (int)N, y.ni, M);
+        else
+          gemm_f32<GEMM_KC, GEMM_KC>(s, gemm_kc(y.D.p, M, N), gemm_kc(y.Wt, M, y.ni, 0), StorePlain{dx, y.ni}, (int)N,
+                                     y.ni, M);
         timing.end(s);
         check_launch();
       }
@@ -953,6 +971,12 @@ int clstm_net_get_state_h(clstm_net* h, int layer, int dir, int which, float* ou
   copy_d2h(out, n.tmp.p, (size_t)n.N * y.no);
   ABI_END
 }
+int clstm_net_set_gemm_precision(clstm_net* h, int mode) {
+  ABI_BEGIN
+  REQUIRE(mode == 0 || mode == 1, "gemm precision: 0 = f32 (exact), 1 = bf16 inputs with f32 accumulation");
+  h->net.bf16_gemm = mode == 1;
+  ABI_END
+}
 int clstm_net_enable_timing(clstm_net* h, int on) { h->net.timing.on = on != 0; return 0; }
 int clstm_net_kernel_time_ms(clstm_net* h, const char* name, double* total_ms, int* launches) {
   ABI_BEGIN
@@ -989,6 +1013,15 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     if (nsplit < 1) nsplit = 1;
     part->reserve((size_t)nsplit * R * Cn);
     gemm_f32<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
+    CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
+                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm);
+  } else if (mode == 10) gemm_bf16<GEMM_KC, GEMM_MC>(g_stream, gemm_kc(A, K, R, 0), gemm_mc(B, Cn, K, 0), StorePlain{Cm, Cn}, R, Cn, K);
+  else if (mode == 11) gemm_bf16<GEMM_KC, GEMM_KC>(g_stream, gemm_kc(A, K, R, 0), gemm_kc(B, K, Cn, 0), StorePlain{Cm, Cn}, R, Cn, K);
+  else if (mode == 12) {
+    if (!part) part = new DevBuf<float>();
+    if (nsplit < 1) nsplit = 1;
+    part->reserve((size_t)nsplit * R * Cn);
+    gemm_bf16<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
                  (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm);
   } else throw Error("bad mode");

@@ -77,6 +77,27 @@ DEVFN f32x4 mfma16x16x4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- bf16 MFMA (gemm_bf16.h): D(16x16) += A(16x32) * B(32x16), f32 accumulate ----
+// lane l supplies 8 bf16 of row/column l&15; the k slots of lane group l>>4 are paired A-to-B by the
+// hardware, so any slot->k assignment is valid as long as both operands use the same one.
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+DEVFN u16x8 bf16_pack8(const float (&x)[8]) {   // round to nearest even (v_cvt_pk_bf16_f32)
+  bf16x8_t v;
+#pragma unroll
+  for (int i = 0; i < 8; i++) v[i] = (__bf16)x[i];
+  return __builtin_bit_cast(u16x8, v);
+}
+DEVFN unsigned bf16_pack2(float lo, float hi) {
+  bf16x2_t v;
+  v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+DEVFN f32x4 mfma16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
 // value known to be wave-uniform (e.g. threadIdx.x >> 6): tell the compiler so that buffer
 // descriptors derived from it live in SGPRs instead of waterfall loops (guide T20)
 DEVFN int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

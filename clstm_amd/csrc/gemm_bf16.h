@@ -1,0 +1,153 @@
+// gemm_bf16.h -- the hoisted gate GEMMs with bf16 inputs and f32 accumulation
+// (v_mfma_f32_16x16x32_bf16; BASELINE config "2 x BiLSTM(512), bf16 MFMA").  Opt-in
+// (clstm_net_set_gemm_precision): the default path is the exact-f32 kernel of gemm_mfma.h.
+//
+// Same interface and tile decomposition as gemm_f32_kernel (affine KC / MC operands in f32 memory,
+// 64x64 output tile, 2x2 waves x 2x2 MFMA tiles, split-K / batch in blockIdx.z, XCD-aware tile order,
+// register prefetch with exact vmcnt), different inner product:
+//   * BK = 32; operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) WHILE they are staged, and live in
+//     LDS as [mn][k] with k contiguous (row stride 40 halfs = 80 B: a fragment is one conflict-free
+//     ds_read_b128 of 8 bf16);
+//   * KC operands (k contiguous in memory): a thread converts 8 consecutive k of one row -> one
+//     ds_write_b128;  MC operands (mn contiguous): a thread loads 4 mn at k and at k+1 and writes four
+//     packed (k, k+1) pairs -> ds_write_b32, which is the transpose;
+//   * lane (i, kb) feeds the MFMA with k = 8 kb .. 8 kb + 7 of row i for BOTH operands; the instruction's
+//     internal k order is irrelevant because A and B use the same slot assignment.
+// One 32-k block costs a wave 4 ds_read_b128 + 4 MFMAs (~70 cycles) instead of 16 ds_read_b32 + 32 f32
+// MFMAs (1024 cycles); the kernel is then bound by the global->LDS staging of its 64x64 tiles.
+#pragma once
+#include "gemm_mfma.h"
+
+namespace clstm {
+
+constexpr int GB_BK = 32;
+constexpr int GB_LDH = 40;   // halfs per LDS row
+constexpr int GB_PF = 3;     // k-tiles prefetched in registers
+
+template <int AMODE, int BMODE, class FE>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
+                                                        int K, int ksplit, int nsplit) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[GEMM_BT * GB_LDH];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[GEMM_BT * GB_LDH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int bx, by, z;   // XCD-aware tile order, see gemm_mfma.h
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = lin & 7u, idx = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = (int)(v % gx);
+    by = (int)((v / gx) % gy);
+    z = (int)(v / (gx * gy));
+  }
+  const int r0 = by * GEMM_BT, c0 = bx * GEMM_BT;
+  const int batch = z / nsplit;
+  const int kbeg = (z - batch * nsplit) * ksplit;
+  const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
+
+  // staging unit of this thread (two float4 per operand per k-tile):
+  //   KC: row tid>>2, k = (tid&3)*8 .. +7          (second float4 = +4 floats)
+  //   MC: mn = (tid&15)*4 .. +3, k = (tid>>4)*2, +1 (second float4 = +ld floats)
+  const int a_mn = AMODE == GEMM_KC ? (tid >> 2) : (tid & 15) * 4;
+  const int a_k = AMODE == GEMM_KC ? (tid & 3) * 8 : (tid >> 4) * 2;
+  const int b_mn = BMODE == GEMM_KC ? (tid >> 2) : (tid & 15) * 4;
+  const int b_k = BMODE == GEMM_KC ? (tid & 3) * 8 : (tid >> 4) * 2;
+  const BufF32 abuf = make_buf(A.p + batch * A.bstride, (size_t)(A.elems - batch * A.bstride) * 4);
+  const BufF32 bbuf = make_buf(B.p + batch * B.bstride, (size_t)(B.elems - batch * B.bstride) * 4);
+  const unsigned a_base = AMODE == GEMM_KC ? (unsigned)(r0 + a_mn) * A.ld + a_k : (unsigned)a_k * A.ld + r0 + a_mn;
+  const unsigned b_base = BMODE == GEMM_KC ? (unsigned)(c0 + b_mn) * B.ld + b_k : (unsigned)b_k * B.ld + c0 + b_mn;
+  const unsigned a_kstep = AMODE == GEMM_KC ? 1u : (unsigned)A.ld, b_kstep = BMODE == GEMM_KC ? 1u : (unsigned)B.ld;
+  const unsigned a_second = AMODE == GEMM_KC ? 4u : (unsigned)A.ld, b_second = BMODE == GEMM_KC ? 4u : (unsigned)B.ld;
+
+  f32x4 ra[GB_PF][2], rb[GB_PF][2];
+  auto load_tile = [&](int k0, f32x4 (&a)[2], f32x4 (&b)[2]) {   // unconditional issue, see gemm_mfma.h
+    const bool live = k0 < kend;
+    const unsigned ao = (a_base + (unsigned)k0 * a_kstep) * 4u, bo = (b_base + (unsigned)k0 * b_kstep) * 4u;
+    a[0] = buf_load4(abuf, live ? ao : BUF_OOB);
+    a[1] = buf_load4(abuf, live ? ao + a_second * 4u : BUF_OOB);
+    b[0] = buf_load4(bbuf, live ? bo : BUF_OOB);
+    b[1] = buf_load4(bbuf, live ? bo + b_second * 4u : BUF_OOB);
+  };
+  // round to bf16 and store k-contiguous; contraction indices past the slab are zeroed here
+  auto stage = [&](const int MODE, unsigned short* S, const int mn, const int kk, const int k0, const f32x4 (&r)[2]) {
+    if (MODE == GEMM_KC) {
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) x[i] = (k0 + kk + i < kend) ? r[i >> 2][i & 3] : 0.0f;
+      *reinterpret_cast<u16x8*>(&S[mn * GB_LDH + kk]) = bf16_pack8(x);
+    } else {
+      const bool l0 = k0 + kk < kend, l1 = k0 + kk + 1 < kend;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        *reinterpret_cast<unsigned*>(&S[(mn + i) * GB_LDH + kk]) = bf16_pack2(l0 ? r[0][i] : 0.0f, l1 ? r[1][i] : 0.0f);
+    }
+  };
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+
+#pragma unroll
+  for (int p = 0; p < GB_PF; p++) {
+    load_tile(kbeg + p * GB_BK, ra[p], rb[p]);
+    SCHED_FENCE();
+  }
+  const int fk = lane >> 4, fi = lane & 15;
+  for (int kb = kbeg; kb < kend; kb += GB_PF * GB_BK) {
+#pragma unroll
+    for (int p = 0; p < GB_PF; p++) {
+      const int k0 = kb + p * GB_BK;   // phases past the slab multiply zeros
+      stage(AMODE, As, a_mn, a_k, k0, ra[p]);
+      stage(BMODE, Bs, b_mn, b_k, k0, rb[p]);
+      __syncthreads();
+      load_tile(k0 + GB_PF * GB_BK, ra[p], rb[p]);
+      SCHED_FENCE();
+      u16x8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        af[i] = *reinterpret_cast<const u16x8*>(&As[(wm * 32 + i * 16 + fi) * GB_LDH + fk * 8]);
+        bf[i] = *reinterpret_cast<const u16x8*>(&Bs[(wn * 32 + i * 16 + fi) * GB_LDH + fk * 8]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = mfma16x16x32_bf16(af[i], bf[j], acc[i][j]);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = r0 + wm * 32 + i * 16 + (lane >> 4) * 4 + q;
+        const int c = c0 + wn * 32 + j * 16 + (lane & 15);
+        if (r < R && c < Cn) fe(r, c, acc[i][j][q], z);
+      }
+}
+
+// Operand slack: the second float4 of a KC row may run 7 floats past the row end (library buffers carry
+// >= 64 floats of slack; exact-size user arrays get a descriptor that ends at the last element).
+template <int AMODE, int BMODE, class FE>
+inline void gemm_bf16(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int nsplit = 1,
+                      int nbatch = 1) {
+  if (R <= 0 || Cn <= 0) return;
+  if (nsplit < 1) nsplit = 1;
+  int ksplit = (K + nsplit - 1) / nsplit;
+  const int kq = nsplit > 1 ? GB_PF * GB_BK : GB_BK;
+  ksplit = ((ksplit + kq - 1) / kq) * kq;
+  if (ksplit < kq) ksplit = kq;
+  dim3 grid((Cn + GEMM_BT - 1) / GEMM_BT, (R + GEMM_BT - 1) / GEMM_BT, nsplit * nbatch);
+  CLSTM_LAUNCH((gemm_bf16_kernel<AMODE, BMODE, FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+}
+
+}  // namespace clstm

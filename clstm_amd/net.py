@@ -88,6 +88,11 @@ class Network:
     def setLearningRate(self, lr, momentum):          # INetwork::setLearningRate clstm.cc:158
         self.lib.call("clstm_net_set_learning_rate", self.h, float(lr), float(momentum))
 
+    def set_gemm_precision(self, mode):
+        """0: exact f32 MFMA (default, the parity path); 1: bf16 inputs / f32 accumulation for the hoisted
+        gate GEMMs (BASELINE config '2 x BiLSTM(512), bf16 MFMA')."""
+        self.lib.call("clstm_net_set_gemm_precision", self.h, int(mode))
+
     def set_gradient_clip(self, clip):
         self.lib.call("clstm_net_set_gradient_clip", self.h, float(clip))
 

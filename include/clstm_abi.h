@@ -126,6 +126,11 @@ int clstm_net_nparams_for(const clstm_net_desc* desc);
 int clstm_net_create(clstm_net** out, const clstm_net_desc* desc, float* params_d, float* derivs_d,
                      float* grads_d);
 int clstm_net_destroy(clstm_net* net);
+/* Precision of the hoisted gate GEMMs (W_x.x for all frames, the weight-gradient and input-delta GEMMs):
+ *   0 (default) exact f32 MFMA -- the parity path (1e-4 on activations);
+ *   1           bf16 inputs, f32 accumulation (v_mfma_f32_16x16x32_bf16) -- what BASELINE config
+ *               "2 x BiLSTM(512), bf16 MFMA" names; the recurrence, softmax and CTC stay f32. */
+int clstm_net_set_gemm_precision(clstm_net* net, int mode);
 int clstm_net_nparams(clstm_net* net);
 int clstm_net_buffers(clstm_net* net, float** params_d, float** derivs_d, float** grads_d);
 /* get_params/set_params/get_derivs/set_derivs (clstm.cc:872-917): HOST buffers, blocking. */
@@ -188,7 +193,8 @@ int clstm_net_reset_timing(clstm_net* net);
 int clstm_debug_lane_ops(float* out);
 /* C = A.B through the MFMA GEMM used by the hoisted products.  mode 0 "NN": A [R][K] row-major,
  * B [K][Cn] row-major; mode 1 "NT": A [R][K], B given as [Cn][K]; mode 2 "TN": A given as [K][R],
- * B [K][Cn] (split over K into nsplit slabs, reduced deterministically).  C [R][Cn] row-major. */
+ * B [K][Cn] (split over K into nsplit slabs, reduced deterministically).  C [R][Cn] row-major.
+ * Modes 10/11/12: the same three layouts through the bf16-input kernel (gemm_bf16.h). */
 /* shader-clock timestamps of the last CTC launch's block 0 after phases A..E (HOST [8]) */
 int clstm_debug_ctc_cycles(long long* out_h);
 int clstm_debug_gemm(int mode, const float* A, const float* B, float* C, int R, int Cn, int K, int nsplit);

@@ -80,7 +80,7 @@ inline float4 make_float4(float x, float y, float z, float w) { return float4{x,
 struct EmuBlock {
   pthread_barrier_t block_bar;
   std::vector<pthread_barrier_t> wave_bar;
-  std::vector<float> xf;   // [wave][64][8] exchange slots
+  std::vector<float> xf;   // [wave][64][16] exchange slots
   char* smem;
 };
 extern thread_local EmuBlock* emu_blk;
@@ -88,7 +88,7 @@ inline void __syncthreads() { pthread_barrier_wait(&emu_blk->block_bar); }
 inline int emu_lane() { return threadIdx.x & 63; }
 inline int emu_wave() { return threadIdx.x >> 6; }
 inline void emu_wave_sync() { pthread_barrier_wait(&emu_blk->wave_bar[emu_wave()]); }
-inline float* emu_slot(int lane, int k = 0) { return &emu_blk->xf[((size_t)emu_wave() * 64 + lane) * 8 + k]; }
+inline float* emu_slot(int lane, int k = 0) { return &emu_blk->xf[((size_t)emu_wave() * 64 + lane) * 16 + k]; }
 
 inline float wave_shfl(float x, int src) {
   *emu_slot(emu_lane()) = x;
@@ -129,6 +129,36 @@ inline f32x4 mfma16x16x4(float a, float b, f32x4 c) {
     int row = (l >> 4) * 4 + r, col = l & 15;
     float acc = c[r];
     for (int k = 0; k < 4; k++) acc = fmaf(*emu_slot(k * 16 + row, 0), *emu_slot(k * 16 + col, 1), acc);
+    d[r] = acc;
+  }
+  emu_wave_sync();
+  return d;
+}
+// bf16 helpers + v_mfma_f32_16x16x32_bf16 (slot j of lane group kb pairs A with B; see devintrin.h)
+struct alignas(16) u16x8 {
+  unsigned short v[8];
+  unsigned short& operator[](int i) { return v[i]; }
+  const unsigned short& operator[](int i) const { return v[i]; }
+};
+inline unsigned short emu_f2bf(float x) {
+  uint32_t u; memcpy(&u, &x, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40);   // quiet NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);                                                   // round to nearest even
+  return (unsigned short)(u >> 16);
+}
+inline float emu_bf2f(unsigned short h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+inline u16x8 bf16_pack8(const float (&x)[8]) { u16x8 r; for (int i = 0; i < 8; i++) r[i] = emu_f2bf(x[i]); return r; }
+inline unsigned bf16_pack2(float lo, float hi) { return (unsigned)emu_f2bf(lo) | ((unsigned)emu_f2bf(hi) << 16); }
+inline f32x4 mfma16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
+  int l = emu_lane();
+  for (int j = 0; j < 8; j++) { *emu_slot(l, j) = emu_bf2f(a[j]); *emu_slot(l, 8 + j) = emu_bf2f(b[j]); }
+  emu_wave_sync();
+  f32x4 d = c;
+  for (int r = 0; r < 4; r++) {
+    int row = (l >> 4) * 4 + r, col = l & 15;
+    float acc = c[r];
+    for (int kb = 0; kb < 4; kb++)
+      for (int j = 0; j < 8; j++) acc = fmaf(*emu_slot(kb * 16 + row, j), *emu_slot(kb * 16 + col, 8 + j), acc);
     d[r] = acc;
   }
   emu_wave_sync();
@@ -191,7 +221,7 @@ void emu_launch_coop(K kernel, dim3 grid, dim3 block, size_t smem, A arg) {
     pthread_barrier_init(&blk.block_bar, nullptr, nthreads);
     blk.wave_bar.resize(nthreads / 64);
     for (auto& w : blk.wave_bar) pthread_barrier_init(&w, nullptr, 64);
-    blk.xf.assign((size_t)nthreads * 8, 0.f);
+    blk.xf.assign((size_t)nthreads * 16, 0.f);
     sms[b].assign(smem + 16, 0);
     blk.smem = sms[b].data();
   }
@@ -225,7 +255,7 @@ void emu_launch(K kernel, dim3 grid, dim3 block, size_t smem, Args... args) {
         pthread_barrier_init(&blk.block_bar, nullptr, nthreads);
         blk.wave_bar.resize(nthreads / 64);
         for (auto& w : blk.wave_bar) pthread_barrier_init(&w, nullptr, 64);
-        blk.xf.assign((size_t)nthreads * 8, 0.f);
+        blk.xf.assign((size_t)nthreads * 16, 0.f);
         std::vector<char> sm(smem + 16, 0);
         blk.smem = sm.data();
         std::vector<std::thread> th;

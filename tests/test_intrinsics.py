@@ -46,6 +46,33 @@ def test_gemm_modes(backend, mode, R, Cn, K, ns):
     assert (np.abs(got - want) <= 2e-6 * scale + 1e-6).all()
 
 
+@pytest.mark.parametrize("mode", [10, 11, 12])
+@pytest.mark.parametrize("R,Cn,K,ns", [(64, 64, 32, 1), (70, 45, 37, 1), (149, 400, 333, 5), (5, 3, 2, 1),
+                                       (130, 83, 200, 3)])
+def test_gemm_bf16_modes(backend, mode, R, Cn, K, ns):
+    """bf16-input / f32-accumulate GEMM (gemm_bf16.h): exact against a float64 product of the SAME inputs
+    rounded to bf16 (asymmetric random operands, so a transposed fragment would show)."""
+    if backend.kind == "emu" and R * Cn > 20000:
+        pytest.skip("big tile counts only on the GPU")
+    rng = np.random.default_rng(R * 1000 + Cn + 7)
+    A = rng.normal(size=(R, K)).astype(np.float32)
+    B = rng.normal(size=(K, Cn)).astype(np.float32)
+
+    def bf16(x):   # round to nearest even on the upper 16 bits
+        u = x.view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+    want = bf16(A).astype(np.float64) @ bf16(B).astype(np.float64)
+    m = mode - 10
+    Ad = backend.up(A if m < 2 else A.T)
+    Bd = backend.up(B if m != 1 else B.T)
+    Cd = backend.zeros((R, Cn))
+    backend.lib.call("clstm_debug_gemm", mode, ptr(Ad), ptr(Bd), ptr(Cd), R, Cn, K, ns if m >= 2 else 1)
+    got = backend.down(Cd)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    assert (np.abs(got - want) <= 2e-6 * scale + 1e-6).all()
+
+
 def test_device_activations(backend):
     # sigmoid_dev / tanh_dev (devintrin.h) through forward_nonlin0 over a wide sweep
     x = np.concatenate([np.linspace(-40, 40, 4001), np.linspace(-0.6, 0.6, 2001), [0.0, 1e-8, -1e-8, 1e-3]])

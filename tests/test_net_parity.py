@@ -203,3 +203,29 @@ def test_device_resident_inputs_match_host_inputs(backend, ora32):
         net.backward()
         grads.append(net.get_grads().copy())
     assert np.array_equal(grads[0], grads[1])
+
+
+def test_bf16_gate_gemms_track_the_f32_path(backend, ora32):
+    """clstm_net_set_gemm_precision(1): bf16 inputs / f32 accumulation for the hoisted gate GEMMs.  Not a
+    parity mode -- stated tolerance: softmax outputs within 2e-2 absolute of the oracle, decodes equal on
+    this well-separated case, gradient within 5 % of its largest entry."""
+    from clstm_amd.net import Network
+    rng = np.random.default_rng(21)
+    ni, nh, nc, T = 12, [20, 16], 6, [9, 5, 7]
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+    want = oracle_minibatch(ora32, OracleNet, params, ni, nh, nc, lines, trs, states=[], lr=1e-3, mom=0.9)
+    net = Network(ni, nh, nc, lib=backend.lib)
+    net.set_params(params)
+    net.set_gemm_precision(1)
+    net.set_inputs(lines)
+    net.forward()
+    got = net.split(net.outputs())
+    for b in range(len(T)):
+        assert np.abs(got[b] - want["outputs"][b]).max() < 2e-2
+    net.ctc(trs)
+    net.backward()
+    g, w = net.get_grads(), want["derivs"]
+    assert np.abs(g - w).max() < 5e-2 * np.abs(w).max()
+    assert not np.array_equal(g, w)          # the switch really changed the arithmetic
