@@ -53,5 +53,5 @@ for CNT in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
 done
 find "$OUT/pmc_MFMA" -name "*.csv" -size +8M -delete
 echo "=== bench 2xBiLSTM(512) shape (f32)"
-timeout 600 python bench.py --config b2 --steps 5 --warmup 2 --profile-steps 2 > "$OUT/bench_b2.json" 2> "$OUT/bench_b2.err"; cut -c1-300 "$OUT/bench_b2.json"
+timeout 600 python "$ROOT/bench.py" --config b2 --steps 5 --warmup 2 --profile-steps 2 > "$OUT/bench_b2.json" 2> "$OUT/bench_b2.err"; cut -c1-300 "$OUT/bench_b2.json"
 echo "=== done"
