@@ -324,6 +324,7 @@ struct Net {
   PinnedRing ring;
   DevBuf<float> X, Z, Dz, dX0, partial, partial_sm, aligned, tmp;
   ReduceDesc sm_red{};
+  DevBuf<long long> lstm_prof;  // diagnostics build only
   DevBuf<int> coop_sync;      // grid-barrier ticket counter + watchdog flag of the cooperative recurrence
   // ctc / decode
   DevBuf<int> states, state_off, dec_idx, dec_cls, dec_loc, dec_cnt;
@@ -411,7 +412,7 @@ struct Net {
     if (own_d) (void)hipFree(d);
     if (own_g) (void)hipFree(g);
     line_off.release(); X.release(); Z.release(); Dz.release();
-    dX0.release(); partial.release(); partial_sm.release(); coop_sync.release(); aligned.release(); tmp.release(); states.release();
+    dX0.release(); partial.release(); partial_sm.release(); coop_sync.release(); lstm_prof.release(); aligned.release(); tmp.release(); states.release();
     state_off.release(); dec_idx.release(); dec_cls.release(); dec_loc.release(); dec_cnt.release();
     dec_val.release(); lat.release(); lat_off.release();
   }
@@ -511,6 +512,9 @@ struct Net {
       a.Rpk = y.Rf; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = nullptr; a.D = nullptr;
       a.line_off = line_off.p; a.no = y.no; a.ndir = ndir; a.ldh = y.ldh; a.hofs = y.hofs;
       a.S = y.S.p; a.lds = y.lds; a.sofs = 1 + y.ni; a.sdir = (long long)N * y.lds;
+#ifdef CLSTM_LSTM_PROF
+      lstm_prof.reserve(64); a.prof = lstm_prof.p;
+#endif
       timing.begin("lstm_fwd", s);
       if (y.wide) launch_lstm_wide(true, wide_args(y, true), tmax, coop_sync, s);
       else launch_lstm(true, y.nk4, a, bs, y.nthreads, s);
@@ -996,6 +1000,14 @@ int clstm_debug_ctc_cycles(long long* out_h) {
   HIPCHECK(hipMemcpy(out_h, g_last_ctc_prof, 8 * sizeof(long long), hipMemcpyDeviceToHost));
   ABI_END
 }
+#ifdef CLSTM_LSTM_PROF
+int clstm_debug_lstm_cycles(clstm_net* h, long long* out_h) {   // diagnostics build only (not in the product ABI)
+  ABI_BEGIN
+  HIPCHECK(hipStreamSynchronize(g_stream));
+  HIPCHECK(hipMemcpy(out_h, h->net.lstm_prof.p, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  ABI_END
+}
+#endif
 int clstm_debug_lane_ops(float* out) {
   ABI_BEGIN
   CLSTM_LAUNCH(k_debug_lane_ops, dim3(1), dim3(64), 0, g_stream, out);

@@ -44,6 +44,7 @@ struct LstmSeqArgs {
   float* S;             // [ndir][N][lds] source rows [1 | x_t | h_{t-1}] for the weight-gradient GEMM;
   int lds, sofs;        //   the forward pass deposits h_{t-1} at column sofs = 1 + ni of the NEXT step's row
   long long sdir;       //   floats between the two directions' S arrays
+  long long* prof;      // diagnostics build (-DCLSTM_LSTM_PROF) only: [8 waves][8] summed phase cycles of workgroup 0
 };
 
 constexpr int lstm_qstride(int nk4) { return 4 * nk4 + ((nk4 & 1) ? 0 : 4); }
@@ -109,9 +110,22 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   float kaA0 = 0.f, kaA1 = 0.f, kaA2 = 0.f, kaB0 = 0.f, kaB1 = 0.f, kaB2 = 0.f;  // store-data pins
   buf_store(sbuf, sl + fr(0) * sstride4, 0.0f);  // h_{-1} = 0 (forward_stack_delay, last < 0)
   __syncthreads();
+  // diagnostics build only: per-phase cycle stamps (scripts/gpu_lstmprof.py).  Each stamp costs ~60 cycles
+  // and drains lgkmcnt, so the instrumented step is ~25 % longer than the real one.
+#ifdef CLSTM_LSTM_PROF
+  long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long pt = 0;
+#define LSTM_STAMP(k) do { long long now_; SCHED_FENCE(); \
+                           asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+                           SCHED_FENCE(); pacc[k] += now_ - pt; pt = now_; } while (0)
+  asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(pt) :: "memory");
+#else
+#define LSTM_STAMP(k) do {} while (0)
+#endif
   auto step = [&](const int t, float& gxr, const float* hq, float* hw, float& ka0, float& ka1, float& ka2) {
     KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2);  // stores of step t-2 have long completed
     f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
+    LSTM_STAMP(0);   // loop overhead since the barrier
 #pragma unroll
     for (int j = 0; j < NK4; j++) {
       const float4 hv = *reinterpret_cast<const float4*>(hq + 4 * j);
@@ -120,6 +134,7 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
       a01 = fma2(w01[4 * j + 2], splat2(hv.z), a01); a23 = fma2(w23[4 * j + 2], splat2(hv.z), a23);
       a01 = fma2(w01[4 * j + 3], splat2(hv.w), a01); a23 = fma2(w23[4 * j + 3], splat2(hv.w), a23);
     }
+    LSTM_STAMP(1);   // LDS reads + FMAs
     // reduce-scatter over the quad: lane q ends with gate q's sum over the four k-quarters
     f32x2 keep = qhi ? a23 : a01;
     const f32x2 send = qhi ? a01 : a23;
@@ -130,6 +145,7 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     k += quad_xor1(sd);
     // lane q finishes gate q: q=0 gi, 1 gf, 2 go (sigmoid); 3 ci (tanh)   [forward_full1]
     const float pre = k + gxr;
+    LSTM_STAMP(2);   // quad reduce + wait for the prefetched pre-activation
     // re-issue into the SAME register only now that its old value is dead (no back-edge copy, so
     // the load really stays in flight for two steps)
     gxr = buf_load(gbuf, gl + fr(t + 2) * gstride4);
@@ -138,9 +154,11 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
                 ci = quad_bcast<3>(act);
     // forward_statemem (clstm_compute.cc:504-508); c_prev = 0 at t = 0 makes the second term an
     // exact +0, so no first-step special case (and no loop peeling) is needed
+    LSTM_STAMP(3);   // gate nonlinearity + quad broadcast
     const float c = ci * gi + gf * c_prev;
     const float h = gate_act(c, true) * go;  // forward_nonlingate (clstm_compute.cc:530-537)
     c_prev = c;
+    LSTM_STAMP(4);   // state update + tanh(c)
     const unsigned f = fr(t);
     buf_store(gbuf, gl + f * gstride4, act);
     buf_store(cbuf, cl + f * cstride4, c);
@@ -149,7 +167,9 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     buf_store(sbuf, t + 1 < T ? sl + fr(t + 1) * sstride4 : BUF_OOB, h);
     *hw = h;
     ka0 = act; ka1 = c; ka2 = h;
+    LSTM_STAMP(5);   // stores + LDS write issued
     __syncthreads();
+    LSTM_STAMP(6);   // barrier
   };
   int t = 0;
   for (; t + 1 < T; t += 2) {
@@ -157,6 +177,10 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     step(t + 1, gxB, rdB, wrB, kaB0, kaB1, kaB2);
   }
   if (t < T) step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2);
+#ifdef CLSTM_LSTM_PROF
+  if (a.prof && b == 0 && dir == 0 && lane == 0)
+    for (int k = 0; k < 8; k++) a.prof[wave * 8 + k] = pacc[k];
+#endif
 }
 
 template <int NK4>
