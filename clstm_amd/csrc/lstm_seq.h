@@ -108,7 +108,15 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   float gxA = buf_load(gbuf, gl + fr(0) * gstride4);
   float gxB = buf_load(gbuf, gl + fr(1) * gstride4);
   float kaA0 = 0.f, kaA1 = 0.f, kaA2 = 0.f, kaB0 = 0.f, kaB1 = 0.f, kaB2 = 0.f;  // store-data pins
+  unsigned kbA0 = 0, kbA1 = 0, kbA2 = 0, kbA3 = 0, kbB0 = 0, kbB1 = 0, kbB2 = 0, kbB3 = 0;  // store-offset pins
   buf_store(sbuf, sl + fr(0) * sstride4, 0.0f);  // h_{-1} = 0 (forward_stack_delay, last < 0)
+  // Touch every value loaded so far HERE.  hipcc otherwise places the wait for the weight loads at their
+  // first use inside the time loop -- a static s_waitcnt vmcnt(3) at the top of every step, sized for the
+  // first iteration, which in steady state also waits for the previous step's stores (measured: ~80
+  // stalled cycles per wave and step); the same goes for the first two pre-activation loads.
+#pragma unroll
+  for (int kk = 0; kk < KQP; kk++) { KEEP_ALIVE2(w01[kk]); KEEP_ALIVE2(w23[kk]); }
+  KEEP_ALIVE(gxA); KEEP_ALIVE(gxB);
   __syncthreads();
   // diagnostics build only: per-phase cycle stamps (scripts/gpu_lstmprof.py).  Each stamp costs ~60 cycles
   // and drains lgkmcnt, so the instrumented step is ~25 % longer than the real one.
@@ -122,8 +130,10 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
 #else
 #define LSTM_STAMP(k) do {} while (0)
 #endif
-  auto step = [&](const int t, float& gxr, const float* hq, float* hw, float& ka0, float& ka1, float& ka2) {
+  auto step = [&](const int t, float& gxr, const float* hq, float* hw, float& ka0, float& ka1, float& ka2,
+                  unsigned& kb0, unsigned& kb1, unsigned& kb2, unsigned& kb3) {
     KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2);  // stores of step t-2 have long completed
+    KEEP_ALIVE(kb0); KEEP_ALIVE(kb1); KEEP_ALIVE(kb2); KEEP_ALIVE(kb3);
     f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
     LSTM_STAMP(0);   // loop overhead since the barrier
 #pragma unroll
@@ -160,23 +170,29 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     c_prev = c;
     LSTM_STAMP(4);   // state update + tanh(c)
     const unsigned f = fr(t);
-    buf_store(gbuf, gl + f * gstride4, act);
-    buf_store(cbuf, cl + f * cstride4, c);
-    buf_store(hbuf, hl + f * hstride4, h);
+    // the store offsets are named and pinned like the data (kb*): otherwise the next step's first FMA
+    // re-uses an address register of these stores and hipcc waits for their completion at the top of
+    // every step (measured: ~80 stalled cycles per wave and step)
+    const unsigned og = gl + f * gstride4, oc = cl + f * cstride4, oh = hl + f * hstride4;
     // h_t is the recurrent part of the NEXT step's source row (dropped after the last step)
-    buf_store(sbuf, t + 1 < T ? sl + fr(t + 1) * sstride4 : BUF_OOB, h);
+    const unsigned os = t + 1 < T ? sl + fr(t + 1) * sstride4 : BUF_OOB;
+    buf_store(gbuf, og, act);
+    buf_store(cbuf, oc, c);
+    buf_store(hbuf, oh, h);
+    buf_store(sbuf, os, h);
     *hw = h;
     ka0 = act; ka1 = c; ka2 = h;
+    kb0 = og; kb1 = oc; kb2 = oh; kb3 = os;
     LSTM_STAMP(5);   // stores + LDS write issued
     __syncthreads();
     LSTM_STAMP(6);   // barrier
   };
   int t = 0;
   for (; t + 1 < T; t += 2) {
-    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2);
-    step(t + 1, gxB, rdB, wrB, kaB0, kaB1, kaB2);
+    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3);
+    step(t + 1, gxB, rdB, wrB, kaB0, kaB1, kaB2, kbB0, kbB1, kbB2, kbB3);
   }
-  if (t < T) step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2);
+  if (t < T) step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3);
 #ifdef CLSTM_LSTM_PROF
   if (a.prof && b == 0 && dir == 0 && lane == 0)
     for (int k = 0; k < 8; k++) a.prof[wave * 8 + k] = pacc[k];
@@ -226,25 +242,33 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
     const int sc = s > 0 ? s : 0;
     return (unsigned)(dir == 0 ? sc : T - 1 - sc);
   };
-  // c_{s-1} reads 0 at s = 0: masked by an out-of-range offset (s - 1 < 0 is wave-uniform)
-  auto cpoff = [&](int s) -> unsigned { return s >= 1 ? cl + fr(s - 1) * cstride4 : BUF_OOB; };
   const float* rdA = lds + js * QS;           // first step reads buffer 0, writes buffer 1
   const float* rdB = lds + DB + js * QS;
   float* wrA = valid ? lds + DB + dslot : lds + 2 * DB;
   float* wrB = valid ? lds + dslot : lds + 2 * DB;
   const bool qb1 = (Q & 2) != 0, qb0 = (Q & 1) != 0;
 
-  // operands are fetched two steps ahead into alternating registers (loop unrolled by two)
-  float actA = buf_load(gbuf, gl + fr(T - 1) * gstride4), actB = buf_load(gbuf, gl + fr(T - 2) * gstride4);
-  float dhA = buf_load(hbuf, cl + fr(T - 1) * cstride4), dhB = buf_load(hbuf, cl + fr(T - 2) * cstride4);
-  float ccA = buf_load(cbuf, cl + fr(T - 1) * cstride4), ccB = buf_load(cbuf, cl + fr(T - 2) * cstride4);  // c_s
-  float cpA = buf_load(cbuf, cpoff(T - 1)), cpB = buf_load(cbuf, cpoff(T - 2));                            // c_{s-1}
+  // Operands (gate activations, dH, c) are fetched two steps ahead into THREE rotating register sets: the
+  // loads for step s-2 are issued at the very top of step s into the set step s+1 finished with.  With two
+  // sets the reload had to wait for the old value's last use inside the step, hipcc loaded into fresh
+  // registers anyway and copied them back at the loop back-edge behind an s_waitcnt vmcnt(1) -- a stall on
+  // prefetches issued a few hundred cycles earlier, every second step.  Now whatever the compiler copies at
+  // the back-edge was requested at least a full step before.  c_{s-1} is the NEXT set's c (no extra load).
+  struct Ops { float act, dh, cc; };
+  Ops X0, X1, X2;
+  X0.act = buf_load(gbuf, gl + fr(T - 1) * gstride4); X1.act = buf_load(gbuf, gl + fr(T - 2) * gstride4);
+  X0.dh = buf_load(hbuf, cl + fr(T - 1) * cstride4);  X1.dh = buf_load(hbuf, cl + fr(T - 2) * cstride4);
+  X0.cc = buf_load(cbuf, cl + fr(T - 1) * cstride4);  X1.cc = buf_load(cbuf, cl + fr(T - 2) * cstride4);
+  X2.act = X2.dh = X2.cc = 0.0f;
   float dc_carry = 0.0f;
-  float kaA = 0.f, kaB = 0.f;  // store-data pins (see KEEP_ALIVE)
+  float ka0 = 0.f, ka1 = 0.f, ka2 = 0.f;  // store-data pins (see KEEP_ALIVE)
   __syncthreads();
-  auto step = [&](const int s, float& actr, float& dhr, float& ccr, float& cpr, const float* dq, float* dw,
-                  float& ka) {
+  // cur: operands of step s; nxt: operands of step s-1 (its c is c_{s-1}); ld: set to refill for step s-2
+  auto step = [&](const int s, Ops& cur, const Ops& nxt, Ops& ld, const float* dq, float* dw, float& ka) {
     KEEP_ALIVE(ka);
+    ld.act = buf_load(gbuf, gl + fr(s - 2) * gstride4);
+    ld.dh = buf_load(hbuf, cl + fr(s - 2) * cstride4);
+    ld.cc = buf_load(cbuf, cl + fr(s - 2) * cstride4);
     // dh_rec[k] = sum_{g,j} R_g[j][k] * delta_g[j](s+1)      [backward_lin1 recurrent half +
     //                                                         backward_stack_delay, :294-304,:398-410]
     f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
@@ -270,23 +294,18 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
     k += quad_xor2(k);
     const float dh_rec = k;
 
+    const float actr = cur.act;
     const float gi = quad_bcast<0>(actr), gf = quad_bcast<1>(actr), go = quad_bcast<2>(actr),
                 ci = quad_bcast<3>(actr);
     // backward_nonlin0 in place (clstm_compute.cc:231-267): y(1-y) for SIG, 1-y^2 for TANH
     const float deriv = g == 3 ? (-actr * actr + 1.0f) : actr * (-actr + 1.0f);
-    const float dh = dhr + dh_rec;             // out[s].d, clstm.cc:626-628 + :646
-    const float c_s = ccr, c_m1 = cpr;
-    // operands of step s-2 are re-issued into the same registers once their old values are dead
-    actr = buf_load(gbuf, gl + fr(s - 2) * gstride4);
-    dhr = buf_load(hbuf, cl + fr(s - 2) * cstride4);
-    ccr = buf_load(cbuf, cl + fr(s - 2) * cstride4);
-    cpr = buf_load(cbuf, cpoff(s - 2));
-    const float th = gate_act(c_s, true);      // backward_nonlingate recomputes tanh(state)
+    const float dh = cur.dh + dh_rec;          // out[s].d, clstm.cc:626-628 + :646
+    const float th = gate_act(cur.cc, true);   // backward_nonlingate recomputes tanh(state)
     const float d_go = th * dh;                //   go.d += t * out.d
     const float dc = dc_carry + (-th * th + 1.0f) * (go * dh);  // state.d += (1-t^2) * (go*out.d)
-    // backward_statemem (clstm_compute.cc:509-515); at s = 0 c_m1 reads 0 (out of range), which
-    // reproduces "gf.d untouched when last < 0"
+    // backward_statemem (clstm_compute.cc:509-515); c_{-1} = 0 reproduces "gf.d untouched when last < 0"
     dc_carry = dc * gf;
+    const float c_m1 = s >= 1 ? nxt.cc : 0.0f;
     const float d_gf = dc * c_m1;
     const float d_gi = dc * ci, d_ci = dc * gi;
     const float dsel = g == 0 ? d_gi : g == 1 ? d_gf : g == 2 ? d_go : d_ci;
@@ -296,12 +315,21 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
     ka = delta;
     __syncthreads();
   };
+  // 3 operand sets x 2 LDS phases: the pattern repeats every 6 steps
   int s = T - 1;
-  for (; s >= 1; s -= 2) {
-    step(s, actA, dhA, ccA, cpA, rdA, wrA, kaA);
-    step(s - 1, actB, dhB, ccB, cpB, rdB, wrB, kaB);
+  for (; s >= 5; s -= 6) {
+    step(s, X0, X1, X2, rdA, wrA, ka0);
+    step(s - 1, X1, X2, X0, rdB, wrB, ka1);
+    step(s - 2, X2, X0, X1, rdA, wrA, ka2);
+    step(s - 3, X0, X1, X2, rdB, wrB, ka0);
+    step(s - 4, X1, X2, X0, rdA, wrA, ka1);
+    step(s - 5, X2, X0, X1, rdB, wrB, ka2);
   }
-  if (s == 0) step(0, actA, dhA, ccA, cpA, rdA, wrA, kaA);
+  if (s >= 0) step(s, X0, X1, X2, rdA, wrA, ka0);
+  if (s >= 1) step(s - 1, X1, X2, X0, rdB, wrB, ka1);
+  if (s >= 2) step(s - 2, X2, X0, X1, rdA, wrA, ka2);
+  if (s >= 3) step(s - 3, X0, X1, X2, rdB, wrB, ka0);
+  if (s >= 4) step(s - 4, X1, X2, X0, rdA, wrA, ka1);
 }
 
 }  // namespace clstm
