@@ -353,8 +353,8 @@ struct Net {
       y.wide = y.nk4 < 0 || force_wide;
       if (y.wide) y.nk4 = 1;
       y.nthreads = y.wide ? 64 : 64 * ((y.no + 15) / 16);
-      y.lds = 1 + y.ni + y.no;
-      y.ldh = ((y.hofs + ndir * y.no + 3) / 4) * 4;
+      y.lds = ((1 + y.ni + y.no + 15) / 16) * 16;   // source rows [1 | x | h_prev], padded to 64-byte rows
+      y.ldh = ((y.hofs + ndir * y.no + 15) / 16) * 16;   // 64-byte aligned rows
       const long long blk = (long long)y.no * (1 + y.ni + y.no);
       y.pd.ni = y.ni; y.pd.no = y.no; y.pd.ndir = ndir; y.pd.nk4 = y.nk4; y.pd.nthreads = y.wide ? 0 : y.nthreads;
       for (int dir = 0; dir < ndir; dir++) {
