@@ -141,24 +141,23 @@ static int pick_nk4(int no) {
     if (v >= need) return v;
   return -1;
 }
-template <int NK4>
+template <int NK4, int KU>
 static void launch_fwd(const LstmSeqArgs& a, int bs, int nthreads, hipStream_t s) {
   const size_t smem = (2 * 4 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
-  CLSTM_LAUNCH((lstm_fwd_kernel<NK4>), dim3(bs, a.ndir), dim3(nthreads), smem, s, a);
+  CLSTM_LAUNCH((lstm_fwd_kernel<NK4, KU>), dim3(bs, a.ndir), dim3(nthreads), smem, s, a);
 }
-template <int NK4>
+template <int NK4, int KU>
 static void launch_bwd(const LstmSeqArgs& a, int bs, int nthreads, hipStream_t s) {
   const size_t smem = (2 * 16 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
-  CLSTM_LAUNCH((lstm_bwd_kernel<NK4>), dim3(bs, a.ndir), dim3(nthreads), smem, s, a);
+  CLSTM_LAUNCH((lstm_bwd_kernel<NK4, KU>), dim3(bs, a.ndir), dim3(nthreads), smem, s, a);
 }
-static void launch_lstm(bool fwd, int nk4, LstmSeqArgs a, int bs, int nthreads, hipStream_t s) {
-  switch (nk4) {
-#define CASE_(N) case N: if (fwd) launch_fwd<N>(a, bs, nthreads, s); else launch_bwd<N>(a, bs, nthreads, s); break;
-    CASE_(1) CASE_(2) CASE_(4) CASE_(7) CASE_(8)
+// k values per lane actually used: the padded 4*nk4 in general, exact for the 97..100-cell case (uw3 BiLSTM(100))
+static int pick_ku(int no, int nk4) { return (nk4 == 7 && (no + 3) / 4 == 25) ? 25 : 4 * nk4; }
+static void launch_lstm(bool fwd, int nk4, int ku, LstmSeqArgs a, int bs, int nthreads, hipStream_t s) {
+#define CASE_(N, K) if (nk4 == N && ku == K) { if (fwd) launch_fwd<N, K>(a, bs, nthreads, s); else launch_bwd<N, K>(a, bs, nthreads, s); check_launch(); return; }
+  CASE_(1, 4) CASE_(2, 8) CASE_(4, 16) CASE_(7, 28) CASE_(7, 25) CASE_(8, 32)
 #undef CASE_
-    default: throw Error("unsupported nhidden for the register-resident recurrence");
-  }
-  check_launch();
+  throw Error("unsupported nhidden for the register-resident recurrence");
 }
 
 // lock-step recurrence (lstm_wide.h): one cooperative launch for the whole sequence when every workgroup
@@ -356,7 +355,7 @@ struct Net {
       y.lds = ((1 + y.ni + y.no + 15) / 16) * 16;   // source rows [1 | x | h_prev], padded to 64-byte rows
       y.ldh = ((y.hofs + ndir * y.no + 15) / 16) * 16;   // 64-byte aligned rows
       const long long blk = (long long)y.no * (1 + y.ni + y.no);
-      y.pd.ni = y.ni; y.pd.no = y.no; y.pd.ndir = ndir; y.pd.nk4 = y.nk4; y.pd.nthreads = y.wide ? 0 : y.nthreads;
+      y.pd.ni = y.ni; y.pd.no = y.no; y.pd.ndir = ndir; y.pd.nk4 = y.nk4; y.pd.nthreads = y.wide ? 0 : y.nthreads; y.pd.ku = pick_ku(y.no, y.nk4);
       for (int dir = 0; dir < ndir; dir++) {
         for (int s = 0; s < 4; s++) y.pd.p_off[dir][s] = off + blockidx[s] * blk;
         off += 4 * blk;
@@ -517,7 +516,7 @@ struct Net {
 #endif
       timing.begin("lstm_fwd", s);
       if (y.wide) launch_lstm_wide(true, wide_args(y, true), tmax, coop_sync, s);
-      else launch_lstm(true, y.nk4, a, bs, y.nthreads, s);
+      else launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
     }
     const int nc = desc.nclasses;
@@ -579,7 +578,7 @@ struct Net {
       a.line_off = line_off.p; a.no = y.no; a.ndir = ndir;
       timing.begin("lstm_bwd", s);
       if (y.wide) launch_lstm_wide(false, wide_args(y, false), tmax, coop_sync, s);
-      else launch_lstm(false, y.nk4, a, bs, y.nthreads, s);
+      else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
       // W.d += delta [1; x_t; h_{t-1}]^T for the four gates of each direction
       // (both directions in one batched launch: half the slabs per direction fill the chip)

@@ -49,7 +49,9 @@ struct LstmSeqArgs {
 
 constexpr int lstm_qstride(int nk4) { return 4 * nk4 + ((nk4 & 1) ? 0 : 4); }
 
-template <int NK4>
+// NK4: float4 groups of k per lane (register / LDS capacity 4*NK4); KU <= 4*NK4: k values a lane really
+// owns = cells per quarter.  (7, 25) is the 100-cell instantiation: 50 instead of 56 packed FMAs per step.
+template <int NK4, int KU>
 __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   constexpr int KQP = 4 * NK4;
   constexpr int QS = KQP + ((NK4 & 1) ? 0 : 4);
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     const int tc = t < T ? t : T - 1;
     return (unsigned)(dir == 0 ? tc : T - 1 - tc);
   };
-  const int hslot = (cell / KQP) * QS + (cell % KQP);
+  const int hslot = (cell / KU) * QS + (cell % KU);
   const float* rdA = lds + q * QS;            // even steps read buffer 0, write buffer 1
   const float* rdB = lds + HB + q * QS;
   float* wrA = lead ? lds + HB + hslot : lds + 2 * HB;
@@ -139,10 +141,10 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
 #pragma unroll
     for (int j = 0; j < NK4; j++) {
       const float4 hv = *reinterpret_cast<const float4*>(hq + 4 * j);
-      a01 = fma2(w01[4 * j], splat2(hv.x), a01); a23 = fma2(w23[4 * j], splat2(hv.x), a23);
-      a01 = fma2(w01[4 * j + 1], splat2(hv.y), a01); a23 = fma2(w23[4 * j + 1], splat2(hv.y), a23);
-      a01 = fma2(w01[4 * j + 2], splat2(hv.z), a01); a23 = fma2(w23[4 * j + 2], splat2(hv.z), a23);
-      a01 = fma2(w01[4 * j + 3], splat2(hv.w), a01); a23 = fma2(w23[4 * j + 3], splat2(hv.w), a23);
+      if (4 * j < KU) { a01 = fma2(w01[4 * j], splat2(hv.x), a01); a23 = fma2(w23[4 * j], splat2(hv.x), a23); }
+      if (4 * j + 1 < KU) { a01 = fma2(w01[4 * j + 1], splat2(hv.y), a01); a23 = fma2(w23[4 * j + 1], splat2(hv.y), a23); }
+      if (4 * j + 2 < KU) { a01 = fma2(w01[4 * j + 2], splat2(hv.z), a01); a23 = fma2(w23[4 * j + 2], splat2(hv.z), a23); }
+      if (4 * j + 3 < KU) { a01 = fma2(w01[4 * j + 3], splat2(hv.w), a01); a23 = fma2(w23[4 * j + 3], splat2(hv.w), a23); }
     }
     LSTM_STAMP(1);   // LDS reads + FMAs
     // reduce-scatter over the quad: lane q ends with gate q's sum over the four k-quarters
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
 #endif
 }
 
-template <int NK4>
+template <int NK4, int KU>
 __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
   constexpr int SLP = 4 * NK4;
   constexpr int QS = SLP + ((NK4 & 1) ? 0 : 4);
@@ -275,10 +277,11 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
 #pragma unroll
     for (int j = 0; j < NK4; j++) {
       const float4 dv = *reinterpret_cast<const float4*>(dq + 4 * j);
-      a01 = fma2(wb01[4 * j], splat2(dv.x), a01); a23 = fma2(wb23[4 * j], splat2(dv.x), a23);
-      a01 = fma2(wb01[4 * j + 1], splat2(dv.y), a01); a23 = fma2(wb23[4 * j + 1], splat2(dv.y), a23);
-      a01 = fma2(wb01[4 * j + 2], splat2(dv.z), a01); a23 = fma2(wb23[4 * j + 2], splat2(dv.z), a23);
-      a01 = fma2(wb01[4 * j + 3], splat2(dv.w), a01); a23 = fma2(wb23[4 * j + 3], splat2(dv.w), a23);
+      // pairs KU .. 4*NK4-1 of a slice are zero padding (SL = ceil(4 no / 16) <= KU)
+      if (4 * j < KU) { a01 = fma2(wb01[4 * j], splat2(dv.x), a01); a23 = fma2(wb23[4 * j], splat2(dv.x), a23); }
+      if (4 * j + 1 < KU) { a01 = fma2(wb01[4 * j + 1], splat2(dv.y), a01); a23 = fma2(wb23[4 * j + 1], splat2(dv.y), a23); }
+      if (4 * j + 2 < KU) { a01 = fma2(wb01[4 * j + 2], splat2(dv.z), a01); a23 = fma2(wb23[4 * j + 2], splat2(dv.z), a23); }
+      if (4 * j + 3 < KU) { a01 = fma2(wb01[4 * j + 3], splat2(dv.w), a01); a23 = fma2(wb23[4 * j + 3], splat2(dv.w), a23); }
     }
     // reduce-scatter over the row of 16 slices: the quad of cell Q ends with dh_rec of that cell.
     // ror:8 pairs quad Q with Q^2, half_mirror pairs Q with Q^1 (slice j with 3-j, which the

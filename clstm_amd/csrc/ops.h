@@ -172,6 +172,7 @@ __global__ void k_update(float* v, float* d, const float* g, size_t len, float l
 struct PackDesc {
   long long p_off[2][4];  // flat offsets of (dir, slot) blocks; slot 0 gi,1 gf,2 go,3 ci
   int ni, no, ndir, nk4, nthreads;
+  int ku;   // k values a forward lane owns = cells per quarter (<= 4*nk4)
 };
 // One launch repacks a layer's parameters after every update:
 //   Wt[k][m] (k < ni, m = dir*4no + 4*cell + slot) and bias[m] for the hoisted input GEMM,
@@ -194,9 +195,9 @@ DEVFN void pack_rf(size_t e, const float* v, float* Rf, const PackDesc& p) {
   const int g = gk / KQP, kk = gk % KQP;
   const int lane = tid & 63, wave = tid >> 6;
   const int cell = wave * 16 + (lane >> 2), q = lane & 3;
-  const int k = q * KQP + kk;
+  const int k = q * p.ku + kk;
   float x = 0.0f;
-  if (cell < p.no && k < p.no) x = v[p.p_off[dir][g] + cell + (size_t)p.no * (1 + p.ni + k)];
+  if (cell < p.no && kk < p.ku && k < p.no) x = v[p.p_off[dir][g] + cell + (size_t)p.no * (1 + p.ni + k)];
   Rf[e] = x;
 }
 DEVFN void pack_rb(size_t e, const float* v, float* Rb, const PackDesc& p) {
