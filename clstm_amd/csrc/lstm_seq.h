@@ -110,7 +110,9 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   float gxA = buf_load(gbuf, gl + fr(0) * gstride4);
   float gxB = buf_load(gbuf, gl + fr(1) * gstride4);
   float kaA0 = 0.f, kaA1 = 0.f, kaA2 = 0.f, kaB0 = 0.f, kaB1 = 0.f, kaB2 = 0.f;  // store-data pins
-  unsigned kbA0 = 0, kbA1 = 0, kbA2 = 0, kbA3 = 0, kbB0 = 0, kbB1 = 0, kbB2 = 0, kbB3 = 0;  // store-offset pins
+  // store-offset pins; nothing to flush before the first step: out-of-range offsets
+  unsigned kbA0 = BUF_OOB, kbA1 = BUF_OOB, kbA2 = BUF_OOB, kbA3 = BUF_OOB;
+  unsigned kbB0 = BUF_OOB, kbB1 = BUF_OOB, kbB2 = BUF_OOB, kbB3 = BUF_OOB;
   buf_store(sbuf, sl + fr(0) * sstride4, 0.0f);  // h_{-1} = 0 (forward_stack_delay, last < 0)
   // Touch every value loaded so far HERE.  hipcc otherwise places the wait for the weight loads at their
   // first use inside the time loop -- a static s_waitcnt vmcnt(3) at the top of every step, sized for the
@@ -132,10 +134,22 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
 #else
 #define LSTM_STAMP(k) do {} while (0)
 #endif
+  // The global stores of a step are DEFERRED to the top of the next one: they are fire-and-forget, but
+  // issuing four of them cost ~200 cycles at the end of the dependent tail of every step; behind the
+  // barrier they issue while the wave would wait for its LDS reads / its SIMD's other wave anyway.
+  // (pa*, pb*: data and offsets of the previous step = the other register set.)
+  auto flush = [&](float pa0, float pa1, float pa2, unsigned pb0, unsigned pb1, unsigned pb2, unsigned pb3) {
+    buf_store(gbuf, pb0, pa0);
+    buf_store(cbuf, pb1, pa1);
+    buf_store(hbuf, pb2, pa2);
+    buf_store(sbuf, pb3, pa2);
+  };
   auto step = [&](const int t, float& gxr, const float* hq, float* hw, float& ka0, float& ka1, float& ka2,
-                  unsigned& kb0, unsigned& kb1, unsigned& kb2, unsigned& kb3) {
+                  unsigned& kb0, unsigned& kb1, unsigned& kb2, unsigned& kb3, float pa0, float pa1, float pa2,
+                  unsigned pb0, unsigned pb1, unsigned pb2, unsigned pb3) {
     KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2);  // stores of step t-2 have long completed
     KEEP_ALIVE(kb0); KEEP_ALIVE(kb1); KEEP_ALIVE(kb2); KEEP_ALIVE(kb3);
+    flush(pa0, pa1, pa2, pb0, pb1, pb2, pb3);
     f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
     LSTM_STAMP(0);   // loop overhead since the barrier
 #pragma unroll
@@ -178,23 +192,24 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     const unsigned og = gl + f * gstride4, oc = cl + f * cstride4, oh = hl + f * hstride4;
     // h_t is the recurrent part of the NEXT step's source row (dropped after the last step)
     const unsigned os = t + 1 < T ? sl + fr(t + 1) * sstride4 : BUF_OOB;
-    buf_store(gbuf, og, act);
-    buf_store(cbuf, oc, c);
-    buf_store(hbuf, oh, h);
-    buf_store(sbuf, os, h);
     *hw = h;
-    ka0 = act; ka1 = c; ka2 = h;
+    ka0 = act; ka1 = c; ka2 = h;                      // stored by the next step's flush
     kb0 = og; kb1 = oc; kb2 = oh; kb3 = os;
-    LSTM_STAMP(5);   // stores + LDS write issued
+    LSTM_STAMP(5);   // LDS write issued
     __syncthreads();
     LSTM_STAMP(6);   // barrier
   };
   int t = 0;
   for (; t + 1 < T; t += 2) {
-    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3);
-    step(t + 1, gxB, rdB, wrB, kaB0, kaB1, kaB2, kbB0, kbB1, kbB2, kbB3);
+    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3, kaB0, kaB1, kaB2, kbB0, kbB1, kbB2, kbB3);
+    step(t + 1, gxB, rdB, wrB, kaB0, kaB1, kaB2, kbB0, kbB1, kbB2, kbB3, kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3);
   }
-  if (t < T) step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3);
+  if (t < T) {
+    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3, kaB0, kaB1, kaB2, kbB0, kbB1, kbB2, kbB3);
+    flush(kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3);
+  } else {
+    flush(kaB0, kaB1, kaB2, kbB0, kbB1, kbB2, kbB3);
+  }
 #ifdef CLSTM_LSTM_PROF
   if (a.prof && b == 0 && dir == 0 && lane == 0)
     for (int k = 0; k < 8; k++) a.prof[wave * 8 + k] = pacc[k];
@@ -266,6 +281,8 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
   float ka0 = 0.f, ka1 = 0.f, ka2 = 0.f;  // store-data pins (see KEEP_ALIVE)
   __syncthreads();
   // cur: operands of step s; nxt: operands of step s-1 (its c is c_{s-1}); ld: set to refill for step s-2
+  // (deferring the delta store to the next step like the forward kernel does was measured slower here:
+  //  126 -> 137 us)
   auto step = [&](const int s, Ops& cur, const Ops& nxt, Ops& ld, const float* dq, float* dw, float& ka) {
     KEEP_ALIVE(ka);
     ld.act = buf_load(gbuf, gl + fr(s - 2) * gstride4);
