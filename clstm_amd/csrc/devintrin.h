@@ -184,6 +184,8 @@ DEVFN bool grid_barrier(int* sync, int target, int* lds_flag) {
 #define KEEP_ALIVE(x) asm volatile("" ::"v"(x))
 // instruction-scheduling fence: nothing is moved across it (keeps load issue order = source order)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// value the optimiser must treat as computed here (no sinking into a conditional, no re-materialisation)
+#define OPAQUE(x) asm volatile("" : "+v"(x))
 #define KEEP_ALIVE2(x) asm volatile("" ::"v"(x))
 
 template <typename T>
@@ -209,6 +211,8 @@ DEVFN float tanh_dev(float x) {
   const float e = fast_exp(2.0f * xc);
   const float big = (e - 1.0f) * fast_rcp(e + 1.0f);
   const float small = xc - xc * xc * xc * (1.0f / 3.0f);
+  // (hipcc turns this select into an exec-masked branch around the exp/rcp chain; forcing it branch-free
+  //  with an opaque value was measured SLOWER in the recurrence: 123 -> 134 us)
   return fabsf(xc) < 0.01f ? small : big;
 }
 

@@ -110,9 +110,6 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   float gxA = buf_load(gbuf, gl + fr(0) * gstride4);
   float gxB = buf_load(gbuf, gl + fr(1) * gstride4);
   float kaA0 = 0.f, kaA1 = 0.f, kaA2 = 0.f, kaB0 = 0.f, kaB1 = 0.f, kaB2 = 0.f;  // store-data pins
-  // store-offset pins; nothing to flush before the first step: out-of-range offsets
-  unsigned kbA0 = BUF_OOB, kbA1 = BUF_OOB, kbA2 = BUF_OOB, kbA3 = BUF_OOB;
-  unsigned kbB0 = BUF_OOB, kbB1 = BUF_OOB, kbB2 = BUF_OOB, kbB3 = BUF_OOB;
   buf_store(sbuf, sl + fr(0) * sstride4, 0.0f);  // h_{-1} = 0 (forward_stack_delay, last < 0)
   // Touch every value loaded so far HERE.  hipcc otherwise places the wait for the weight loads at their
   // first use inside the time loop -- a static s_waitcnt vmcnt(3) at the top of every step, sized for the
@@ -138,18 +135,21 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   // issuing four of them cost ~200 cycles at the end of the dependent tail of every step; behind the
   // barrier they issue while the wave would wait for its LDS reads / its SIMD's other wave anyway.
   // (pa*, pb*: data and offsets of the previous step = the other register set.)
-  auto flush = [&](float pa0, float pa1, float pa2, unsigned pb0, unsigned pb1, unsigned pb2, unsigned pb3) {
-    buf_store(gbuf, pb0, pa0);
-    buf_store(cbuf, pb1, pa1);
-    buf_store(hbuf, pb2, pa2);
-    buf_store(sbuf, pb3, pa2);
+  // (pa*: the previous step's activation, c and h = the other register set; tp: that step, -1 before the first.
+  //  The offset arithmetic happens here too, off the tail.)
+  auto flush = [&](const int tp, float pa0, float pa1, float pa2) {
+    const bool any = tp >= 0;
+    const unsigned f = fr(tp < 0 ? 0 : tp);
+    buf_store(gbuf, any ? gl + f * gstride4 : BUF_OOB, pa0);
+    buf_store(cbuf, any ? cl + f * cstride4 : BUF_OOB, pa1);
+    buf_store(hbuf, any ? hl + f * hstride4 : BUF_OOB, pa2);
+    // h_t is the recurrent part of the NEXT step's source row (dropped after the last step)
+    buf_store(sbuf, any && tp + 1 < T ? sl + fr(tp + 1) * sstride4 : BUF_OOB, pa2);
   };
   auto step = [&](const int t, float& gxr, const float* hq, float* hw, float& ka0, float& ka1, float& ka2,
-                  unsigned& kb0, unsigned& kb1, unsigned& kb2, unsigned& kb3, float pa0, float pa1, float pa2,
-                  unsigned pb0, unsigned pb1, unsigned pb2, unsigned pb3) {
+                  float pa0, float pa1, float pa2) {
     KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2);  // stores of step t-2 have long completed
-    KEEP_ALIVE(kb0); KEEP_ALIVE(kb1); KEEP_ALIVE(kb2); KEEP_ALIVE(kb3);
-    flush(pa0, pa1, pa2, pb0, pb1, pb2, pb3);
+    flush(t - 1, pa0, pa1, pa2);
     f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
     LSTM_STAMP(0);   // loop overhead since the barrier
 #pragma unroll
@@ -185,30 +185,22 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     const float h = gate_act(c, true) * go;  // forward_nonlingate (clstm_compute.cc:530-537)
     c_prev = c;
     LSTM_STAMP(4);   // state update + tanh(c)
-    const unsigned f = fr(t);
-    // the store offsets are named and pinned like the data (kb*): otherwise the next step's first FMA
-    // re-uses an address register of these stores and hipcc waits for their completion at the top of
-    // every step (measured: ~80 stalled cycles per wave and step)
-    const unsigned og = gl + f * gstride4, oc = cl + f * cstride4, oh = hl + f * hstride4;
-    // h_t is the recurrent part of the NEXT step's source row (dropped after the last step)
-    const unsigned os = t + 1 < T ? sl + fr(t + 1) * sstride4 : BUF_OOB;
     *hw = h;
     ka0 = act; ka1 = c; ka2 = h;                      // stored by the next step's flush
-    kb0 = og; kb1 = oc; kb2 = oh; kb3 = os;
     LSTM_STAMP(5);   // LDS write issued
     __syncthreads();
     LSTM_STAMP(6);   // barrier
   };
   int t = 0;
   for (; t + 1 < T; t += 2) {
-    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3, kaB0, kaB1, kaB2, kbB0, kbB1, kbB2, kbB3);
-    step(t + 1, gxB, rdB, wrB, kaB0, kaB1, kaB2, kbB0, kbB1, kbB2, kbB3, kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3);
+    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kaB0, kaB1, kaB2);
+    step(t + 1, gxB, rdB, wrB, kaB0, kaB1, kaB2, kaA0, kaA1, kaA2);
   }
   if (t < T) {
-    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3, kaB0, kaB1, kaB2, kbB0, kbB1, kbB2, kbB3);
-    flush(kaA0, kaA1, kaA2, kbA0, kbA1, kbA2, kbA3);
+    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kaB0, kaB1, kaB2);
+    flush(t, kaA0, kaA1, kaA2);
   } else {
-    flush(kaB0, kaB1, kaB2, kbB0, kbB1, kbB2, kbB3);
+    flush(t - 1, kaB0, kaB1, kaB2);
   }
 #ifdef CLSTM_LSTM_PROF
   if (a.prof && b == 0 && dir == 0 && lane == 0)
@@ -264,6 +256,7 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
   float* wrA = valid ? lds + DB + dslot : lds + 2 * DB;
   float* wrB = valid ? lds + dslot : lds + 2 * DB;
   const bool qb1 = (Q & 2) != 0, qb0 = (Q & 1) != 0;
+  const bool gb1 = (g & 2) != 0, gb0 = (g & 1) != 0;
 
   // Operands (gate activations, dH, c) are fetched two steps ahead into THREE rotating register sets: the
   // loads for step s-2 are issued at the very top of step s into the set step s+1 finished with.  With two
@@ -288,6 +281,24 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
     ld.act = buf_load(gbuf, gl + fr(s - 2) * gstride4);
     ld.dh = buf_load(hbuf, cl + fr(s - 2) * cstride4);
     ld.cc = buf_load(cbuf, cl + fr(s - 2) * cstride4);
+    // Everything that does not depend on this step's mat-vec is computed BEFORE it (its operands were
+    // requested two steps ago): tanh(c), the gate broadcasts, the derivative factor and the second factor
+    // of this lane's gate delta.  The dependent tail behind the reduction is then five VALU operations.
+    const float actr = cur.act;
+    const float gi = quad_bcast<0>(actr), gf = quad_bcast<1>(actr), go = quad_bcast<2>(actr),
+                ci = quad_bcast<3>(actr);
+    // backward_nonlin0 in place (clstm_compute.cc:231-267): y(1-y) for SIG, 1-y^2 for TANH
+    const float deriv = g == 3 ? (-actr * actr + 1.0f) : actr * (-actr + 1.0f);
+    const float th = gate_act(cur.cc, true);   // backward_nonlingate recomputes tanh(state)
+    const float gth = (-th * th + 1.0f) * go;  // state.d += (1-t^2) * (go*out.d)
+    // backward_statemem (clstm_compute.cc:509-515); c_{-1} = 0 reproduces "gf.d untouched when last < 0"
+    float c_m1 = s >= 1 ? nxt.cc : 0.0f;
+    OPAQUE(c_m1);   // otherwise hipcc branches around the wait for this load for the lanes that do not use it
+    // this lane's gate delta is ONE product of two selected factors (selects, no exec-masked branches):
+    //   gi.d = dc*ci   gf.d = dc*c_{s-1}   go.d = tanh(c)*out.d   ci.d = dc*gi
+    const float flo = gb0 ? c_m1 : ci, fhi = gb0 ? gi : th;   // two-level select on the lane's gate bits
+    float fb = deriv * (gb1 ? fhi : flo);
+    OPAQUE(fb);     // really before the mat-vec
     // dh_rec[k] = sum_{g,j} R_g[j][k] * delta_g[j](s+1)      [backward_lin1 recurrent half +
     //                                                         backward_stack_delay, :294-304,:398-410]
     f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
@@ -312,24 +323,10 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
     k += row_half_mirror(sd);
     k += quad_xor1(k);
     k += quad_xor2(k);
-    const float dh_rec = k;
-
-    const float actr = cur.act;
-    const float gi = quad_bcast<0>(actr), gf = quad_bcast<1>(actr), go = quad_bcast<2>(actr),
-                ci = quad_bcast<3>(actr);
-    // backward_nonlin0 in place (clstm_compute.cc:231-267): y(1-y) for SIG, 1-y^2 for TANH
-    const float deriv = g == 3 ? (-actr * actr + 1.0f) : actr * (-actr + 1.0f);
-    const float dh = cur.dh + dh_rec;          // out[s].d, clstm.cc:626-628 + :646
-    const float th = gate_act(cur.cc, true);   // backward_nonlingate recomputes tanh(state)
-    const float d_go = th * dh;                //   go.d += t * out.d
-    const float dc = dc_carry + (-th * th + 1.0f) * (go * dh);  // state.d += (1-t^2) * (go*out.d)
-    // backward_statemem (clstm_compute.cc:509-515); c_{-1} = 0 reproduces "gf.d untouched when last < 0"
+    const float dh = cur.dh + k;               // out[s].d = delta from above + recurrent delta, clstm.cc:626-628 + :646
+    const float dc = dc_carry + gth * dh;
     dc_carry = dc * gf;
-    const float c_m1 = s >= 1 ? nxt.cc : 0.0f;
-    const float d_gf = dc * c_m1;
-    const float d_gi = dc * ci, d_ci = dc * gi;
-    const float dsel = g == 0 ? d_gi : g == 1 ? d_gf : g == 2 ? d_go : d_ci;
-    const float delta = deriv * dsel;
+    const float delta = (g == 2 ? dh : dc) * fb;
     buf_store(dbuf, gl + fr(s) * gstride4, delta);
     *dw = delta;
     ka = delta;

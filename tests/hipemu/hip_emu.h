@@ -170,6 +170,7 @@ inline float fast_exp(float x) { return expf(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 #define KEEP_ALIVE(x) (void)(x)
 #define SCHED_FENCE() ((void)0)
+#define OPAQUE(x) ((void)0)
 struct BufF32 { float* base; size_t bytes; };
 constexpr unsigned BUF_OOB = 0xFFFFFFF0u;
 constexpr unsigned BUF_OOB_BASE = 0x80000000u;
