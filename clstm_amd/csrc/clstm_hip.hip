@@ -536,7 +536,7 @@ struct Net {
   // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
   int pick_split(int R, int Cn, int nbatch = 1) const {
     const long long tiles = (long long)((R + GEMM_BT - 1) / GEMM_BT) * ((Cn + GEMM_BT - 1) / GEMM_BT) * nbatch;
-    static const long long target = getenv("CLSTM_SPLIT_TARGET") ? atoll(getenv("CLSTM_SPLIT_TARGET")) : 768;
+    static const long long target = getenv("CLSTM_SPLIT_TARGET") ? atoll(getenv("CLSTM_SPLIT_TARGET")) : 640;
     long long want = (target + tiles - 1) / tiles;
     const long long maxs = (N + 63) / 64;   // at least 64 frames per slab
     if (want > maxs) want = maxs;
