@@ -31,15 +31,22 @@ def summary(counter):
 
 
 fe, wr = summary("FETCH_SIZE"), summary("WRITE_SIZE")
-names = {"lstm_fwd": "void clstm::lstm_fwd_kernel<7>", "lstm_bwd": "void clstm::lstm_bwd_kernel<7>",
+names = {"lstm_fwd": "void clstm::lstm_fwd_kernel<", "lstm_bwd": "void clstm::lstm_bwd_kernel<",
          "ctc_align": "clstm::ctc_align_kernel", "sgd_update": "clstm::k_update",
          "gemm_dw (all split-K launches, avg)": "void clstm::gemm_f32_kernel<1, 1, clstm::StorePartial>",
          "gemm_gates_x / gemm_softmax (avg)": "void clstm::gemm_f32_kernel<0, 1, clstm::StoreBias>"}
 kern = {}
+def find(table, prefix):
+    for name, v in table.items():
+        if name.startswith(prefix):
+            return v
+    return None
+
+
 for k, full in names.items():
-    if full in fe and full in wr:
-        kern[k] = {"fetch_kib": fe[full], "write_kib": wr[full],
-                   "hbm_bytes": int(round((2.0 * fe[full] + wr[full]) * 1024))}
+    f, w = find(fe, full), find(wr, full)
+    if f is not None and w is not None:
+        kern[k] = {"fetch_kib": f, "write_kib": w, "hbm_bytes": int(round((2.0 * f + w) * 1024))}
 doc = {
     "_comment": "HBM traffic per launch from rocprofv3 PMC passes (profiles/%spmc_*_summary.txt), bench.py default "
                 "workload (minibatch 64, T=200, BiLSTM(100)). FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE "
