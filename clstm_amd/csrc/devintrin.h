@@ -123,12 +123,6 @@ DEVFN float buf_load(BufF32 b, unsigned byte_off) {
 }
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
-DEVFN f32x2 buf_load2(BufF32 b, unsigned byte_off) {
-  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b.r, byte_off, 0, 0));
-}
-DEVFN void buf_store2(BufF32 b, unsigned byte_off, f32x2 v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, v), b.r, byte_off, 0, 0);
-}
 DEVFN f32x4 buf_load4(BufF32 b, unsigned byte_off) {  // 16 bytes, dword alignment suffices
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, byte_off, 0, 0));
 }

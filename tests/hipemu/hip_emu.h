@@ -177,9 +177,7 @@ constexpr unsigned BUF_OOB_BASE = 0x80000000u;
 inline BufF32 make_buf(const float* base, size_t bytes) { return BufF32{const_cast<float*>(base), bytes}; }
 inline float buf_load(BufF32 b, unsigned off) { return ((size_t)off + 4 <= b.bytes) ? b.base[off / 4] : 0.0f; }
 inline f32x4 buf_load4(BufF32 b, unsigned off) { f32x4 r; for (int i = 0; i < 4; i++) r[i] = buf_load(b, off + 4 * i); return r; }
-inline f32x2 buf_load2(BufF32 b, unsigned off) { f32x2 r; r[0] = buf_load(b, off); r[1] = buf_load(b, off + 4); return r; }
 inline void buf_store(BufF32 b, unsigned off, float v) { if ((size_t)off + 4 <= b.bytes) b.base[off / 4] = v; }
-inline void buf_store2(BufF32 b, unsigned off, f32x2 v) { buf_store(b, off, v[0]); buf_store(b, off + 4, v[1]); }
 #define KEEP_ALIVE2(x) (void)(x)
 inline f32x4 buf_load4_dev(BufF32 b, unsigned off) { return buf_load4(b, off); }
 inline void buf_store_dev(BufF32 b, unsigned off, float v) { buf_store(b, off, v); }
