@@ -122,17 +122,32 @@ struct PinnedRing {
 };
 
 // ---- GEMM operand functors ---------------------------------------------------------------------
+// operator(): one element; row4(): four consecutive columns of one row (c % 4 == 0) when vec4() says the
+// destination rows are 16-byte aligned -- the GEMM epilogue then writes whole 256-byte row segments
 struct StoreBias {  // out[r*ld + c] = val + bias[c]
   float* out; long long ld; const float* bias;
   DEVMFN void operator()(int r, int c, float v, int) const { out[(long long)r * ld + c] = v + bias[c]; }
+  DEVMFN bool vec4() const { return (ld & 3) == 0 && (((size_t)out | (size_t)bias) & 15) == 0; }
+  DEVMFN void row4(int r, int c, f32x4 v, int) const {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
+    f32x4 o;
+    o[0] = v[0] + b[0]; o[1] = v[1] + b[1]; o[2] = v[2] + b[2]; o[3] = v[3] + b[3];
+    *reinterpret_cast<f32x4*>(out + (long long)r * ld + c) = o;
+  }
 };
 struct StorePlain {
   float* out; long long ld;
   DEVMFN void operator()(int r, int c, float v, int) const { out[(long long)r * ld + c] = v; }
+  DEVMFN bool vec4() const { return (ld & 3) == 0 && ((size_t)out & 15) == 0; }
+  DEVMFN void row4(int r, int c, f32x4 v, int) const { *reinterpret_cast<f32x4*>(out + (long long)r * ld + c) = v; }
 };
 struct StorePartial {  // split-K slabs [z][R][Cn]
   float* out; int R, Cn;
   DEVMFN void operator()(int r, int c, float v, int z) const { out[((long long)z * R + r) * Cn + c] = v; }
+  DEVMFN bool vec4() const { return (Cn & 3) == 0 && ((size_t)out & 15) == 0; }
+  DEVMFN void row4(int r, int c, f32x4 v, int z) const {
+    *reinterpret_cast<f32x4*>(out + ((long long)z * R + r) * Cn + c) = v;
+  }
 };
 static const int kNK4Table[] = {1, 2, 4, 7, 8};
 static int pick_nk4(int no) {

@@ -31,6 +31,7 @@ constexpr int GEMM_BT = 64;   // tile rows / cols
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_LD = 80;
 constexpr int GEMM_PF = 3;   // k-tiles prefetched in registers
+constexpr int GEMM_LDO = 68;  // LDS row stride of the output tile in the epilogue
 
 struct GemmOperand {
   const float* p;
@@ -42,8 +43,10 @@ struct GemmOperand {
 template <int AMODE, int BMODE, class FE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
                                                        int K, int ksplit, int nsplit) {
-  __shared__ __attribute__((aligned(16))) float As[GEMM_BK * GEMM_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[GEMM_BK * GEMM_LD];
+  // operand tiles during the k loop; the 64 x 64 output tile (row stride 68) during the epilogue
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_BT * GEMM_LDO];
+  float* As = smem;
+  float* Bs = smem + GEMM_BK * GEMM_LD;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -155,6 +158,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperan
       }
       __syncthreads();
     }
+  }
+  if (fe.vec4()) {
+    // Epilogue through LDS: the MFMA layout holds 16-float pieces of a row per lane group; transposed
+    // through the tile every lane writes one 16-byte piece and a wave covers four whole 256-byte row
+    // segments per store instruction (16 partial-line stores per lane otherwise).
+    // (the last k phase ended with a barrier: the operand tiles are dead)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          smem[(wm * 32 + i * 16 + (lane >> 4) * 4 + q) * GEMM_LDO + wn * 32 + j * 16 + (lane & 15)] = acc[i][j][q];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int rl = it * 16 + (tid >> 4), cl = (tid & 15) * 4;
+      const int r = r0 + rl, c = c0 + cl;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&smem[rl * GEMM_LDO + cl]);
+      if (r < R) {
+        if (c + 3 < Cn) fe.row4(r, c, v, z);
+        else
+          for (int e = 0; e < 4; e++)
+            if (c + e < Cn) fe(r, c + e, v[e], z);
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < 2; i++)
