@@ -65,6 +65,7 @@ def run_case(backend, ora32, ni, nh, nc, T, uni=False, scale=30.0, seed=1, lr=1e
     (5, 6, 4, [5, 3]),            # one wave, two ragged lines
     (7, 20, 5, [4]),              # two waves, second partially filled
     (3, 33, 6, [3, 1, 2]),        # NK4=4 instantiation, a 1-frame line
+    (4, 98, 5, [7, 2]),           # exact-k instantiation (25 k per lane) with a partially filled last quarter
 ])
 def test_bidi_small(backend, ora32, ni, nh, nc, T):
     run_case(backend, ora32, ni, nh, nc, T)
