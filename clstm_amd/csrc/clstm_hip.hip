@@ -16,6 +16,7 @@
 #include "devintrin.h"
 #include "gemm_mfma.h"
 #include "gemm_bf16.h"
+#include "softmax_fused.h"
 #include "lstm_seq.h"
 #include "lstm_wide.h"
 #include "ops.h"
@@ -537,15 +538,22 @@ struct Net {
     const int nc = desc.nclasses;
     const float* W1 = v + sm_off;
     // the top layer's output rows are [1 | h]: they ARE the softmax layer's source rows
-    timing.begin("gemm_softmax", s);
-    gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(L.back().hrow(), L.back().ldh, N), gemm_mc(W1 + nc, nc, sm_ni, 0),
-                               StoreBias{Z.p, nc, W1}, (int)N, nc, sm_ni);
-    timing.end(s);
-    check_launch();
-    timing.begin("softmax_norm", s);
-    CLSTM_LAUNCH(k_softmax_norm, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Z.p, nc, (size_t)N);
-    timing.end(s);
-    check_launch();
+    if (nc <= SMX_COLS) {   // logits, limexp and normalisation in one kernel (softmax_fused.h)
+      timing.begin("gemm_softmax", s);
+      softmax_fwd(s, gemm_kc(L.back().hrow(), L.back().ldh, N), W1, (long long)nc * (1 + sm_ni), Z.p, (int)N, nc, sm_ni);
+      timing.end(s);
+      check_launch();
+    } else {
+      timing.begin("gemm_softmax", s);
+      gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(L.back().hrow(), L.back().ldh, N), gemm_mc(W1 + nc, nc, sm_ni, 0),
+                                 StoreBias{Z.p, nc, W1}, (int)N, nc, sm_ni);
+      timing.end(s);
+      check_launch();
+      timing.begin("softmax_norm", s);
+      CLSTM_LAUNCH(k_softmax_norm, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Z.p, nc, (size_t)N);
+      timing.end(s);
+      check_launch();
+    }
   }
 
   // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
