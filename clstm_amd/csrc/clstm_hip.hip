@@ -225,7 +225,7 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       if (zsplit > nzb) zsplit = nzb;
       HIPCHECK(hipMemsetAsync(sync.p, 0, 2 * sizeof(int), s));
       coop_set_smem(lstm_coop_fwd, smem);
-      CLSTM_LAUNCH_COOP(lstm_coop_fwd, dim3((no + 15) / 16, a.ndir, zsplit), dim3(256), smem, s, a);
+      CLSTM_LAUNCH_COOP(lstm_coop_fwd, dim3((no + 15) / 16, a.ndir, zsplit), dim3(WIDE_THREADS), smem, s, a);
       check_launch();
       check_coop(sync, s);
       return;
@@ -233,9 +233,9 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mt - 1) / (16 * mt));
     for (int t = 0; t < tmax; t++) {
       a.step = t;
-      if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step<4>, grid, dim3(256), 0, s, a);
-      else if (mt == 2) CLSTM_LAUNCH(lstm_wide_fwd_step<2>, grid, dim3(256), 0, s, a);
-      else CLSTM_LAUNCH(lstm_wide_fwd_step<1>, grid, dim3(256), 0, s, a);
+      if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step<4>, grid, dim3(WIDE_THREADS), 0, s, a);
+      else if (mt == 2) CLSTM_LAUNCH(lstm_wide_fwd_step<2>, grid, dim3(WIDE_THREADS), 0, s, a);
+      else CLSTM_LAUNCH(lstm_wide_fwd_step<1>, grid, dim3(WIDE_THREADS), 0, s, a);
     }
   } else {
     const int tiles = ((no + 15) / 16) * a.ndir, nzb = (a.bs + 15) / 16;
@@ -245,7 +245,7 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       if (zsplit > nzb) zsplit = nzb;
       HIPCHECK(hipMemsetAsync(sync.p, 0, 2 * sizeof(int), s));
       coop_set_smem(lstm_coop_bwd, smem);
-      CLSTM_LAUNCH_COOP(lstm_coop_bwd, dim3((no + 15) / 16, a.ndir, zsplit), dim3(256), smem, s, a);
+      CLSTM_LAUNCH_COOP(lstm_coop_bwd, dim3((no + 15) / 16, a.ndir, zsplit), dim3(WIDE_THREADS), smem, s, a);
       check_launch();
       check_coop(sync, s);
       return;
@@ -253,7 +253,7 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     const dim3 grid((no + 15) / 16, a.ndir, nzb);
     for (int t = 0; t < tmax; t++) {
       a.step = t;
-      CLSTM_LAUNCH(lstm_wide_bwd_step, grid, dim3(256), 0, s, a);
+      CLSTM_LAUNCH(lstm_wide_bwd_step, grid, dim3(WIDE_THREADS), 0, s, a);
     }
   }
   check_launch();

@@ -50,6 +50,9 @@ struct LstmWideArgs {
 constexpr int WIDE_LDW = 20;  // LDS row stride of a partial tile (16 columns + pad, float4-aligned)
 constexpr int WIDE_PF = 4;    // 16-k groups in flight per wave, per-step kernels (8 measured slower: 200 VGPRs)
 constexpr int WIDE_PF_COOP = 8;  // cooperative kernels: all groups of a 512-cell layer in flight at once
+constexpr int WIDE_NW = 4;    // waves per workgroup = split-K factor (8 was measured on MI355X at 512 cells: 9.9 / 8.5 ms
+                              // against 9.7 / 8.3 ms per pass -- the step is not bound by the MFMA/load rounds of a wave)
+constexpr int WIDE_THREADS = 64 * WIDE_NW;
 constexpr int WIDE_WPAD = 4;  // LDS weight rows are kp + 4 floats: 16 rows x b128 reads cover all banks once
 
 // acc[i] += A_i(16 rows x kslice) . B(kslice x 16 cols) for this wave's quarter of the contraction,
@@ -62,7 +65,7 @@ DEVFN void wide_tile(const BufF32 abuf, const unsigned (&arow)[MT], const BufF32
                      const float* wl, const int kp, float* red) {
   constexpr int PF = COOP ? WIDE_PF_COOP : WIDE_PF;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int kw = kp >> 2;                 // contraction range of one wave (multiple of 16)
+  const int kw = kp / WIDE_NW;            // contraction range of one wave (multiple of 16)
   const int ngroups = kw >> 4;
   const unsigned klane = (unsigned)(wave * kw + 4 * (lane >> 4)) * 4u;
   f32x4 acc[MT][NT];
@@ -183,7 +186,7 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
 #pragma unroll
     for (int q = 0; q < 4; q++) k[q] = 0.0f;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < WIDE_NW; w++) {
       const f32x4 p = *reinterpret_cast<const f32x4*>(&red[((w * MT + (ml >> 4)) * 16 + (ml & 15)) * WIDE_LDW + cl * 4]);
 #pragma unroll
       for (int q = 0; q < 4; q++) k[q] += p[q];
@@ -207,8 +210,8 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
 
 // per-step launch: grid (ceil(no/4), ndir, ceil(bs / 16MT)), 256 threads
 template <int MT>
-__global__ __launch_bounds__(256) void lstm_wide_fwd_step(LstmWideArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[4 * MT * 16 * WIDE_LDW];
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_fwd_step(LstmWideArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[WIDE_NW * MT * 16 * WIDE_LDW];
   wide_fwd_tile<MT, false>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);
 }
 
@@ -239,7 +242,7 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
   // epilogue operands of thread (line, cell), requested ahead of the MFMA loop
   const int ml = tid >> 4, c16 = tid & 15;
   const int line = zb * 16 + ml, cell = ct * 16 + c16;
-  bool live = line < a.bs && cell < no;
+  bool live = ml < 16 && line < a.bs && cell < no;
   int off = 0, T = 0;
   if (live) {
     off = loff[line];
@@ -267,7 +270,7 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
   if (live) {
     float dh_rec = 0.0f;
 #pragma unroll
-    for (int w = 0; w < 4; w++) dh_rec += red[(w * 16 + ml) * WIDE_LDW + c16];
+    for (int w = 0; w < WIDE_NW; w++) dh_rec += red[(w * 16 + ml) * WIDE_LDW + c16];
     const float gi = act[0], gf = act[1], go = act[2], ci = act[3];
     const float dh = dh_in + dh_rec;           // out[s].d, clstm.cc:626-628 + :646
     const float th = gate_act(c_s, true);      // backward_nonlingate recomputes tanh(state)
@@ -288,8 +291,8 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
 }
 
 // per-step launch: grid (ceil(no/16), ndir, ceil(bs/16)), 256 threads
-__global__ __launch_bounds__(256) void lstm_wide_bwd_step(LstmWideArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * WIDE_LDW];
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_bwd_step(LstmWideArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[WIDE_NW * 16 * WIDE_LDW];
   wide_bwd_tile<false>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);
 }
 
@@ -310,7 +313,7 @@ inline __host__ __device__ CoopLds coop_lds_layout(int kp, int nrows, int ncols,
   CoopLds l;
   int o = 0;
   l.weights = o; o += nrows * (kp + WIDE_WPAD);
-  l.red = o;     o += 4 * 16 * (ncols + 4);
+  l.red = o;     o += WIDE_NW * 16 * (ncols + 4);
   l.loff = o;    o += ((bs + 1 + 3) / 4) * 4;
   l.flag = o;    o += 4;
   l.words = o;
@@ -322,7 +325,7 @@ DEVFN void coop_stage(const LstmWideArgs& a, const float* wbase, long long row0,
                       float* wl, int* loff) {
   const int tid = threadIdx.x;
   const int k4 = a.kp >> 2;
-  for (int i = tid; i < nrows * k4; i += 256) {
+  for (int i = tid; i < nrows * k4; i += WIDE_THREADS) {
     const int row = i / k4, c4 = i - row * k4;
     f32x4 v;
 #pragma unroll
@@ -330,7 +333,7 @@ DEVFN void coop_stage(const LstmWideArgs& a, const float* wbase, long long row0,
     if (row0 + row < rows_total) v = *reinterpret_cast<const f32x4*>(wbase + (size_t)(row0 + row) * a.kp + c4 * 4);
     *reinterpret_cast<f32x4*>(wl + row * (a.kp + WIDE_WPAD) + c4 * 4) = v;
   }
-  for (int i = tid; i <= a.bs; i += 256) loff[i] = a.line_off[i];
+  for (int i = tid; i <= a.bs; i += WIDE_THREADS) loff[i] = a.line_off[i];
   __syncthreads();
 }
 
@@ -356,7 +359,7 @@ DEVFN void coop_fwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
   const BufF32 abuf = make_buf(a.H, (size_t)a.N * a.ldh * 4);
   const int ml = tid >> 4, c16 = tid & 15;
   const int line = zb * 16 + ml, cell = ct * 16 + c16;
-  bool live = line < a.bs && cell < no;
+  bool live = ml < 16 && line < a.bs && cell < no;
   int off = 0, T = 0;
   if (live) {
     off = loff[line];
@@ -378,7 +381,7 @@ DEVFN void coop_fwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
 #pragma unroll
     for (int q = 0; q < 4; q++) k[q] = 0.0f;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {   // columns of cell c16: cell group c16>>2, slot (c16&3)*4 + gate
+    for (int w = 0; w < WIDE_NW; w++) {   // columns of cell c16: cell group c16>>2, slot (c16&3)*4 + gate
       const f32x4 p = *reinterpret_cast<const f32x4*>(&red[(w * 16 + ml) * 68 + c16 * 4]);
 #pragma unroll
       for (int q = 0; q < 4; q++) k[q] += p[q];
@@ -399,7 +402,7 @@ DEVFN void coop_fwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
 }
 
 // grid (ceil(no/16), ndir, zsplit), 256 threads; workgroup z walks line blocks z, z + zsplit, ...
-__global__ __launch_bounds__(256) void lstm_coop_fwd(LstmWideArgs a) {
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_coop_fwd(LstmWideArgs a) {
   float* smem = dyn_smem<float>();
   const CoopLds L = coop_lds_layout(a.kp, 64, 64, a.bs);
   float* wl = smem + L.weights;
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256) void lstm_coop_fwd(LstmWideArgs a) {
 }
 
 // grid (ceil(no/16), ndir, zsplit), 256 threads; workgroup z walks line blocks z, z + zsplit, ...
-__global__ __launch_bounds__(256) void lstm_coop_bwd(LstmWideArgs a) {
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_coop_bwd(LstmWideArgs a) {
   float* smem = dyn_smem<float>();
   const CoopLds L = coop_lds_layout(a.kp, 16, 16, a.bs);
   float* wl = smem + L.weights;
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256) void lstm_coop_bwd(LstmWideArgs a) {
 }
 
 // contraction padding of the packed weights
-inline int wide_kp_fwd(int no) { return ((no + 63) / 64) * 64; }
-inline int wide_kp_bwd(int no) { return ((4 * no + 63) / 64) * 64; }
+inline int wide_kp_fwd(int no) { return ((no + 16 * WIDE_NW - 1) / (16 * WIDE_NW)) * 16 * WIDE_NW; }
+inline int wide_kp_bwd(int no) { return ((4 * no + 16 * WIDE_NW - 1) / (16 * WIDE_NW)) * 16 * WIDE_NW; }
 
 }  // namespace clstm
