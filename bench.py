@@ -119,7 +119,11 @@ def main():
     from clstm_amd.parallel import Trainer
 
     lib = abi.load()   # raises if the HIP extension is missing -- there is no fallback path
-    lib.call("clstm_set_stream", torch.cuda.current_stream().cuda_stream)
+    # a real (non-default) stream: the library replays launch-bound loops as hipGraphs, and the legacy
+    # default stream cannot be captured.  Everything below -- kernels, RCCL all-reduce -- runs on it.
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    lib.call("clstm_set_stream", stream.cuda_stream)
     params_h = init_params(NI, NH, NC, seed=0.222)
     nparams = params_h.size
     dev = torch.device("cuda", local_rank)

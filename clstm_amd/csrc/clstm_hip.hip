@@ -205,7 +205,59 @@ static void check_coop(DevBuf<int>& sync, hipStream_t s) {
   HIPCHECK(hipStreamSynchronize(s));
   if (flag != 0) throw Error("cooperative recurrence: grid barrier timed out (workgroups not co-resident?); unset CLSTM_COOP");
 }
-static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, hipStream_t s) {
+// The per-step launches of one sequence pass are a launch-bound inner loop of up to a few hundred
+// dependent kernels: captured once into a hipGraph and replayed while the batch geometry and the buffers
+// stay the same (the per-line lengths live in device memory, so only tmax / bs / pointers key the graph).
+struct StepGraphCache {
+  bool unsupported = false;   // the stream refused capture once: keep launching directly
+#ifndef CLSTM_HIP_EMU
+  struct Entry { LstmWideArgs key; bool fwd; int tmax; hipGraphExec_t exec; };
+  std::vector<Entry> entries;
+  static bool same(const LstmWideArgs& x, const LstmWideArgs& y) {
+    return x.Rw == y.Rw && x.G == y.G && x.C == y.C && x.H == y.H && x.dH == y.dH && x.D == y.D && x.dC == y.dC &&
+           x.line_off == y.line_off && x.S == y.S && x.sdir == y.sdir && x.N == y.N && x.bs == y.bs && x.no == y.no &&
+           x.ndir == y.ndir && x.kp == y.kp && x.lds == y.lds && x.ldh == y.ldh && x.rw_elems == y.rw_elems;
+  }
+  hipGraphExec_t find(bool fwd, const LstmWideArgs& a, int tmax) {
+    for (auto& e : entries)
+      if (e.fwd == fwd && e.tmax == tmax && same(e.key, a)) return e.exec;
+    return nullptr;
+  }
+  void put(bool fwd, const LstmWideArgs& a, int tmax, hipGraphExec_t exec) {
+    if (entries.size() >= 16) { (void)hipGraphExecDestroy(entries.front().exec); entries.erase(entries.begin()); }
+    entries.push_back(Entry{a, fwd, tmax, exec});
+  }
+  ~StepGraphCache() { for (auto& e : entries) (void)hipGraphExecDestroy(e.exec); }
+#endif
+};
+template <class F>
+static void launch_steps(StepGraphCache& cache, bool fwd, const LstmWideArgs& a, int tmax, hipStream_t s, F&& body) {
+#ifndef CLSTM_HIP_EMU
+  static const bool use_graph = !(getenv("CLSTM_WIDE_GRAPH") && atoi(getenv("CLSTM_WIDE_GRAPH")) == 0);
+  if (use_graph && tmax >= 8) {
+    hipGraphExec_t exec = cache.find(fwd, a, tmax);
+    if (!exec && !cache.unsupported) {
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();      // e.g. the legacy default stream cannot be captured: plain launches
+        cache.unsupported = true;
+      } else {
+        body();
+        HIPCHECK(hipStreamEndCapture(s, &graph));
+        HIPCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIPCHECK(hipGraphDestroy(graph));
+        cache.put(fwd, a, tmax, exec);
+      }
+    }
+    if (exec) {
+      HIPCHECK(hipGraphLaunch(exec, s));
+      return;
+    }
+  }
+#endif
+  body();
+}
+static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s) {
   REQUIRE((double)a.N * a.ndir * 4 * a.no * 4 < 2147483000.0,
           "minibatch too large for the lock-step recurrence (frames x 4 x nhidden x ndir x 4 B must stay below 2 GiB)");
   const int no = a.no;
@@ -231,12 +283,15 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       return;
     }
     const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mt - 1) / (16 * mt));
-    for (int t = 0; t < tmax; t++) {
-      a.step = t;
-      if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step<4>, grid, dim3(WIDE_THREADS), 0, s, a);
-      else if (mt == 2) CLSTM_LAUNCH(lstm_wide_fwd_step<2>, grid, dim3(WIDE_THREADS), 0, s, a);
-      else CLSTM_LAUNCH(lstm_wide_fwd_step<1>, grid, dim3(WIDE_THREADS), 0, s, a);
-    }
+    launch_steps(graphs, true, a, tmax, s, [&]() {
+      LstmWideArgs w = a;
+      for (int t = 0; t < tmax; t++) {
+        w.step = t;
+        if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step<4>, grid, dim3(WIDE_THREADS), 0, s, w);
+        else if (mt == 2) CLSTM_LAUNCH(lstm_wide_fwd_step<2>, grid, dim3(WIDE_THREADS), 0, s, w);
+        else CLSTM_LAUNCH(lstm_wide_fwd_step<1>, grid, dim3(WIDE_THREADS), 0, s, w);
+      }
+    });
   } else {
     const int tiles = ((no + 15) / 16) * a.ndir, nzb = (a.bs + 15) / 16;
     const size_t smem = (size_t)coop_lds_layout(a.kp, 16, 16, a.bs).words * sizeof(float);
@@ -251,10 +306,13 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       return;
     }
     const dim3 grid((no + 15) / 16, a.ndir, nzb);
-    for (int t = 0; t < tmax; t++) {
-      a.step = t;
-      CLSTM_LAUNCH(lstm_wide_bwd_step, grid, dim3(WIDE_THREADS), 0, s, a);
-    }
+    launch_steps(graphs, false, a, tmax, s, [&]() {
+      LstmWideArgs w = a;
+      for (int t = 0; t < tmax; t++) {
+        w.step = t;
+        CLSTM_LAUNCH(lstm_wide_bwd_step, grid, dim3(WIDE_THREADS), 0, s, w);
+      }
+    });
   }
   check_launch();
 }
@@ -340,6 +398,7 @@ struct Net {
   DevBuf<float> X, Z, Dz, dX0, partial, partial_sm, aligned, tmp;
   ReduceDesc sm_red{};
   DevBuf<long long> lstm_prof;  // diagnostics build only
+  StepGraphCache step_graphs;   // captured per-step launch sequences of the lock-step recurrence
   DevBuf<int> coop_sync;      // grid-barrier ticket counter + watchdog flag of the cooperative recurrence
   // ctc / decode
   DevBuf<int> states, state_off, dec_idx, dec_cls, dec_loc, dec_cnt;
@@ -531,7 +590,7 @@ struct Net {
       lstm_prof.reserve(64); a.prof = lstm_prof.p;
 #endif
       timing.begin("lstm_fwd", s);
-      if (y.wide) launch_lstm_wide(true, wide_args(y, true), tmax, coop_sync, s);
+      if (y.wide) launch_lstm_wide(true, wide_args(y, true), tmax, coop_sync, step_graphs, s);
       else launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
     }
@@ -600,7 +659,7 @@ struct Net {
       a.Rpk = y.Rb; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = y.dH.p; a.D = y.D.p;
       a.line_off = line_off.p; a.no = y.no; a.ndir = ndir;
       timing.begin("lstm_bwd", s);
-      if (y.wide) launch_lstm_wide(false, wide_args(y, false), tmax, coop_sync, s);
+      if (y.wide) launch_lstm_wide(false, wide_args(y, false), tmax, coop_sync, step_graphs, s);
       else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
       // W.d += delta [1; x_t; h_{t-1}]^T for the four gates of each direction

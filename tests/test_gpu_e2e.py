@@ -129,3 +129,45 @@ def test_stacked_bilstm512_shape_vs_oracle(ora32):
     from common import Backend
     from test_net_parity import run_case
     run_case(Backend("hip"), ora32, 64, [512, 512], 100, [24, 17, 9], scale=3.0, seed=13, lr=1e-4)
+
+
+@pytest.mark.gpu
+def test_lockstep_launch_loop_replayed_as_hipgraph(ora32):
+    """On a real (capturable) stream the per-step launches of the lock-step recurrence are captured into a
+    hipGraph at the first pass and replayed afterwards: first pass, replay and the plain-launch path on the
+    default stream must give identical gradients."""
+    import torch
+    from common import Backend, synth_lines
+    from clstm_amd.net import Network
+    from oracle.oracle import OracleNet
+    be = Backend("hip")
+    rng = np.random.default_rng(31)
+    ni, nh, nc, T = 8, 132, 7, [21, 30, 9]
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 10.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+
+    def run(net, reps):
+        out = []
+        for _ in range(reps):
+            net.set_inputs(lines)
+            net.forward()
+            net.ctc(trs)
+            net.backward()
+            out.append(net.get_grads().copy())
+        return out
+
+    net0 = Network(ni, nh, nc, lib=be.lib)
+    net0.set_params(params)
+    ref = run(net0, 1)[0]
+    st = torch.cuda.Stream()
+    try:
+        be.lib.call("clstm_set_stream", st.cuda_stream)
+        net1 = Network(ni, nh, nc, lib=be.lib)
+        net1.set_params(params)
+        first, replay = run(net1, 2)
+        be.lib.call("clstm_synchronize")
+    finally:
+        be.lib.call("clstm_set_stream", 0)
+    assert np.array_equal(first, ref)
+    assert np.array_equal(replay, ref)
