@@ -23,6 +23,13 @@
 //             row_ror all-reduce leaves dh_rec for the 4 cells in every lane of the row; the
 //             element-wise phase re-uses the forward's (cell, gate) = (lane>>2, lane&3) mapping.
 // One __syncthreads per step (h / delta vector double-buffered in LDS).
+//
+// What a step costs (measured per wave, scripts/gpu_lstmprof.py): FMA phase of the first
+// wave of a SIMD + FMA phase of the second + the dependent tail of the second.  Hence: everything that does
+// not depend on the step's mat-vec runs BEFORE it (backward), everything fire-and-forget runs AFTER the
+// barrier (forward: the global stores of step t issue at the top of step t+1), prefetches are issued at the
+// top of a step into a register set that is dead (three rotating sets, backward), and no s_waitcnt sized for
+// the first iteration may sit inside the loop (values loaded in the prologue are touched before it).
 #pragma once
 #include "devintrin.h"
 
