@@ -12,7 +12,7 @@ dst = os.path.join(ROOT, "profiles")
 pre = "r%s_" % rnd
 for name in ("bench_default.json", "bench_mb1.json", "bench_mb16.json", "bench_mb256.json", "bench_mb1024.json",
              "bench_ragged.json", "bench_b2.json", "host.txt", "pmc_FETCH_SIZE_summary.txt", "pmc_WRITE_SIZE_summary.txt",
-             "pmc_SQ_VALU_MFMA_BUSY_CYCLES_summary.txt", "pmc_GRBM_GUI_ACTIVE_summary.txt"):
+             "pmc_SQ_VALU_MFMA_BUSY_CYCLES_summary.txt", "pmc_GRBM_GUI_ACTIVE_summary.txt", "pmc_SQ_summary.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, pre + name))

@@ -52,6 +52,13 @@ for CNT in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_MFMA" $CNT > "$OUT/pmc_${CNT}_summary.txt" 2>&1; head -8 "$OUT/pmc_${CNT}_summary.txt"
 done
 find "$OUT/pmc_MFMA" -name "*.csv" -size +8M -delete
+echo "=== rocprofv3 PMC pass: SQ wave-state counters (where the waves of each kernel spend their cycles)"
+SQC="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU"
+timeout 600 rocprofv3 --pmc $SQC --kernel-trace --output-format csv -d "$OUT/pmc_SQ" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/rocprof_SQ.log" 2>&1
+tail -2 "$OUT/rocprof_SQ.log"
+for CNT in $SQC; do python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_SQ" $CNT | head -6; done > "$OUT/pmc_SQ_summary.txt" 2>&1
+head -20 "$OUT/pmc_SQ_summary.txt"
+find "$OUT/pmc_SQ" -name "*.csv" -size +8M -delete
 echo "=== bench 2xBiLSTM(512) shape (f32)"
 timeout 600 python "$ROOT/bench.py" --config b2 --steps 5 --warmup 2 --profile-steps 2 > "$OUT/bench_b2.json" 2> "$OUT/bench_b2.err"; cut -c1-300 "$OUT/bench_b2.json"
 echo "=== done"
