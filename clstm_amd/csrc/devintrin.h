@@ -216,10 +216,12 @@ DEVFN float sigmoid_dev(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 // gate nonlinearity without divergence: sigmoid for the three gates, tanh for the cell input;
 // one exp + one rcp either way.
 DEVFN float gate_act(float x, bool is_tanh) {
-  const float xc = fminf(fmaxf(x, -15.0f), 15.0f);
-  const float e = fast_exp(is_tanh ? 2.0f * xc : -x);
+  // One exp and one rcp on the dependent chain, no clamps: with e = exp(-2|x|) in (0, 1] the tanh form
+  // (1 - e) / (1 + e) cannot overflow, and sigmoid's exp(-x) = inf gives rcp(inf) = 0, the correct limit.
+  const float ax = fabsf(x);
+  const float e = fast_exp(is_tanh ? -2.0f * ax : -x);
   const float r = fast_rcp(1.0f + e);
-  const float small = xc - xc * xc * xc * (1.0f / 3.0f);
-  const float th = fabsf(xc) < 0.01f ? small : (e - 1.0f) * r;
+  const float small = ax - ax * ax * ax * (1.0f / 3.0f);      // |x| < 0.01: 1 - e would cancel
+  const float th = copysignf(ax < 0.01f ? small : (1.0f - e) * r, x);
   return is_tanh ? th : r;
 }
