@@ -26,14 +26,22 @@ DEVFN float dpp_mov(float x) {
   const int xi = __builtin_bit_cast(int, x);  // old = src: no zero-init mov, lanes without a source keep x
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, CTRL, 0xF, 0xF, false));
 }
+// Permutations in which EVERY lane has a source lane (quad_perm, row_ror, row_half_mirror): old = 0 with
+// bound_ctrl and full row/bank masks makes `old` dead, so hipcc needs no copy to seed the destination and can
+// fold the move into the consuming VALU instruction (v_add_f32_dpp, v_mul_f32_dpp) -- each saved instruction
+// sits on the dependent tail of a recurrence step.
+template <int CTRL>
+DEVFN float dpp_perm(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
 #ifndef CLSTM_USE_SHFL
-DEVFN float quad_xor1(float x) { return dpp_mov<0xB1>(x); }  // quad_perm [1,0,3,2]
-DEVFN float quad_xor2(float x) { return dpp_mov<0x4E>(x); }  // quad_perm [2,3,0,1]
+DEVFN float quad_xor1(float x) { return dpp_perm<0xB1>(x); }  // quad_perm [1,0,3,2]
+DEVFN float quad_xor2(float x) { return dpp_perm<0x4E>(x); }  // quad_perm [2,3,0,1]
 template <int I>
-DEVFN float quad_bcast(float x) { return dpp_mov<I * 0x55>(x); }  // quad_perm [I,I,I,I]
+DEVFN float quad_bcast(float x) { return dpp_perm<I * 0x55>(x); }  // quad_perm [I,I,I,I]
 template <int N>
-DEVFN float row_ror(float x) { return dpp_mov<0x120 + N>(x); }  // rotate within a row of 16
-DEVFN float row_half_mirror(float x) { return dpp_mov<0x141>(x); }  // lane i <-> i^7 within 8 lanes
+DEVFN float row_ror(float x) { return dpp_perm<0x120 + N>(x); }  // rotate within a row of 16
+DEVFN float row_half_mirror(float x) { return dpp_perm<0x141>(x); }  // lane i <-> i^7 within 8 lanes
 #else
 // Fallback through ds_bpermute (definitionally correct; used to cross-check the DPP codes).
 DEVFN float quad_xor1(float x) { return __shfl_xor(x, 1, 64); }
