@@ -111,6 +111,7 @@ DEVFN f32x4 mfma16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
 DEVFN int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 DEVFN long long dev_clock() { return (long long)__builtin_readcyclecounter(); }
 DEVFN float fast_exp(float x) { return __expf(x); }
+DEVFN float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // ---- buffer (SRD) loads/stores: out-of-range offsets are dropped by the bounds check, so masked
@@ -226,8 +227,12 @@ DEVFN float sigmoid_dev(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 DEVFN float gate_act(float x, bool is_tanh) {
   // One exp and one rcp on the dependent chain, no clamps: with e = exp(-2|x|) in (0, 1] the tanh form
   // (1 - e) / (1 + e) cannot overflow, and sigmoid's exp(-x) = inf gives rcp(inf) = 0, the correct limit.
+  // The exponent argument is (x with the sign bit cleared for tanh) * (-2 log2 e or -log2 e): the mask and
+  // the scale depend only on the lane, so the chain in front of v_exp_f32 is v_and + v_mul.
   const float ax = fabsf(x);
-  const float e = fast_exp(is_tanh ? -2.0f * ax : -x);
+  const unsigned mask = is_tanh ? 0x7FFFFFFFu : 0xFFFFFFFFu;
+  const float scale = is_tanh ? -2.0f * 1.44269504088896341f : -1.44269504088896341f;
+  const float e = fast_exp2(__builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & mask) * scale);
   const float r = fast_rcp(1.0f + e);
   const float small = ax - ax * ax * ax * (1.0f / 3.0f);      // |x| < 0.01: 1 - e would cancel
   const float th = copysignf(ax < 0.01f ? small : (1.0f - e) * r, x);
