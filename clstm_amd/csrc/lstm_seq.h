@@ -109,7 +109,6 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   const float* rdB = lds + HB + q * QS;
   float* wrA = lead ? lds + HB + hslot : lds + 2 * HB;
   float* wrB = lead ? lds + hslot : lds + 2 * HB;
-  const bool qhi = (q & 2) != 0, qlo = (q & 1) != 0;
   float c_prev = 0.0f;
   if (T <= 0) return;
   // input pre-activations are fetched two steps ahead into two alternating registers (the loop is
@@ -169,13 +168,11 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     }
     LSTM_STAMP(1);   // LDS reads + FMAs
     // reduce-scatter over the quad: lane q ends with gate q's sum over the four k-quarters
-    f32x2 keep = qhi ? a23 : a01;
-    const f32x2 send = qhi ? a01 : a23;
-    keep[0] += quad_xor2(send[0]);
-    keep[1] += quad_xor2(send[1]);
-    float k = qlo ? keep[1] : keep[0];
-    const float sd = qlo ? keep[0] : keep[1];
-    k += quad_xor1(sd);
+    // (register slot s of lane q holds gate s^q -- pack_rf -- so what a lane keeps and what it sends sit
+    // in fixed registers: three v_add_f32_dpp, no selects)
+    const float k0 = a01[0] + quad_xor2(a23[0]);
+    const float k1 = a01[1] + quad_xor2(a23[1]);
+    const float k = k0 + quad_xor1(k1);
     // lane q finishes gate q: q=0 gi, 1 gf, 2 go (sigmoid); 3 ci (tanh)   [forward_full1]
     const float pre = k + gxr;
     LSTM_STAMP(2);   // quad reduce + wait for the prefetched pre-activation
@@ -227,7 +224,7 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
   const int no = a.no, nd = a.ndir;
   const int SL = (4 * no + 15) / 16;  // (gate,j) pairs per slice
   const int js = lane & 15;
-  const int g = lane & 3, cell = wave * 16 + (lane >> 2), Q = (lane >> 2) & 3;
+  const int g = lane & 3, cell = wave * 16 + (lane >> 2);   // quad Q = (lane >> 2) & 3 finishes cell 4 kg + Q
   const bool valid = cell < no;
 
   // R_g[j][k] for this lane's 4 output cells as (cell 0,1) and (cell 2,3) pairs
@@ -262,7 +259,6 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
   const float* rdB = lds + DB + js * QS;
   float* wrA = valid ? lds + DB + dslot : lds + 2 * DB;
   float* wrB = valid ? lds + dslot : lds + 2 * DB;
-  const bool qb1 = (Q & 2) != 0, qb0 = (Q & 1) != 0;
   const bool gb1 = (g & 2) != 0, gb0 = (g & 1) != 0;
 
   // Operands (gate activations, dH, c) are fetched two steps ahead into THREE rotating register sets: the
@@ -321,13 +317,10 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
     // reduce-scatter over the row of 16 slices: the quad of cell Q ends with dh_rec of that cell.
     // ror:8 pairs quad Q with Q^2, half_mirror pairs Q with Q^1 (slice j with 3-j, which the
     // quad sum below makes irrelevant).
-    f32x2 keep = qb1 ? a23 : a01;
-    const f32x2 send = qb1 ? a01 : a23;
-    keep[0] += row_ror<8>(send[0]);
-    keep[1] += row_ror<8>(send[1]);
-    float k = qb0 ? keep[1] : keep[0];
-    const float sd = qb0 ? keep[0] : keep[1];
-    k += row_half_mirror(sd);
+    // Register slot i of quad Q holds cell i^Q (pack_rb): keep / send sit in fixed registers, no selects.
+    const float k0 = a01[0] + row_ror<8>(a23[0]);
+    const float k1 = a01[1] + row_ror<8>(a23[1]);
+    float k = k0 + row_half_mirror(k1);
     k += quad_xor1(k);
     k += quad_xor2(k);
     const float dh = cur.dh + k;               // out[s].d = delta from above + recurrent delta, clstm.cc:626-628 + :646

@@ -176,8 +176,8 @@ struct PackDesc {
 };
 // One launch repacks a layer's parameters after every update:
 //   Wt[k][m] (k < ni, m = dir*4no + 4*cell + slot) and bias[m] for the hoisted input GEMM,
-//   Rf[dir][(g*KQP + kk)][tid] = R_g[cell][q*KQP + kk]          forward recurrence registers,
-//   Rb[dir][(i*SLP + pp)][tid] = R_g[j][4*kg + i], (g,j) = pair js*SL+pp   backward recurrence registers.
+//   Rf[dir][(s*KQP + kk)][tid] = R_{s^q}[cell][q*KU + kk]        forward recurrence registers,
+//   Rb[dir][(i*SLP + pp)][tid] = R_g[j][4*kg + (i^Q)], (g,j) = pair js*SL+pp   backward recurrence registers.
 DEVFN void pack_wx(size_t e, const float* v, float* Wt, float* bias, const PackDesc& p) {
   const int M = p.ndir * 4 * p.no;
   const int j = e / M, m = e % M;
@@ -197,7 +197,8 @@ DEVFN void pack_rf(size_t e, const float* v, float* Rf, const PackDesc& p) {
   const int cell = wave * 16 + (lane >> 2), q = lane & 3;
   const int k = q * p.ku + kk;
   float x = 0.0f;
-  if (cell < p.no && kk < p.ku && k < p.no) x = v[p.p_off[dir][g] + cell + (size_t)p.no * (1 + p.ni + k)];
+  // register slot g of lane q holds gate g^q: the quad reduce-scatter then needs no selects (lstm_seq.h)
+  if (cell < p.no && kk < p.ku && k < p.no) x = v[p.p_off[dir][g ^ q] + cell + (size_t)p.no * (1 + p.ni + k)];
   Rf[e] = x;
 }
 DEVFN void pack_rb(size_t e, const float* v, float* Rb, const PackDesc& p) {
@@ -209,8 +210,8 @@ DEVFN void pack_rb(size_t e, const float* v, float* Rb, const PackDesc& p) {
   const int tid = r % p.nthreads, ip = r / p.nthreads;
   const int i = ip / SLP, pp = ip % SLP;
   const int lane = tid & 63, wave = tid >> 6;
-  const int kcell = 4 * (wave * 4 + (lane >> 4)) + i;
   const int js = lane & 15;
+  const int kcell = 4 * (wave * 4 + (lane >> 4)) + (i ^ (js >> 2));   // slot i of quad Q holds cell i^Q
   const int pr = js * SL + pp;
   float x = 0.0f;
   if (pp < SL && pr < 4 * p.no && kcell < p.no) {
