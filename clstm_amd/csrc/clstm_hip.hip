@@ -754,20 +754,27 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
   a.lat = w.lat.p; a.lat_off = (const long long*)w.meta.p; a.nc = nc;
   w.prof.reserve(8); a.prof = w.prof.p; g_last_ctc_prof = w.prof.p;
   if (!w.tables.p) {
-    w.tables.reserve(160);
-    std::vector<double> tb(160);
+    w.tables.reserve(CTC_TABLE_DOUBLES);
+    std::vector<double> tb(CTC_TABLE_DOUBLES);
     for (int i = 0; i < 32; i++) tb[i] = CTC_EXP2_32[i];
     for (int i = 0; i < 64; i++) { tb[32 + i] = CTC_LOG_INVC[i]; tb[96 + i] = CTC_LOG_LOGC[i]; }
-    HIPCHECK(hipMemcpy(w.tables.p, tb.data(), 160 * sizeof(double), hipMemcpyHostToDevice));
+    for (int k = 0; k < 2 * CTC_SP_KMAX + 1; k++) { tb[160 + 2 * k] = CTC_SOFTPLUS[k][0]; tb[161 + 2 * k] = CTC_SOFTPLUS[k][1]; }
+    HIPCHECK(hipMemcpy(w.tables.p, tb.data(), CTC_TABLE_DOUBLES * sizeof(double), hipMemcpyHostToDevice));
   }
   a.tables = w.tables.p;
-  int smax = 1;
-  for (int b = 0; b < bs; b++) smax = std::max(smax, state_off_h[b + 1] - state_off_h[b]);
+  int smax = 1, tmax = 1;
+  for (int b = 0; b < bs; b++) {
+    smax = std::max(smax, state_off_h[b + 1] - state_off_h[b]);
+    tmax = std::max(tmax, line_off_h[b + 1] - line_off_h[b]);
+  }
   a.smax = smax;
   a.ncp = nc | 1;                                   // odd row stride: conflict-free row-per-lane access
-  int tile = (int)((120 * 1024) / ((a.ncp + (smax | 1)) * sizeof(float)));
+  // frames per LDS tile: what the 160 KiB carve leaves after the tables and the per-state vectors
+  const long fixed = (long)ctc_lds_layout(0, a.ncp, smax).words * (long)sizeof(float);
+  int tile = (int)((160 * 1024 - fixed) / (long)((a.ncp + (smax | 1) + 1) * sizeof(float)));
   if (tile > CTC_MAX_TILE) tile = CTC_MAX_TILE;
-  REQUIRE(tile >= 1, "too many classes for the CTC row tile");
+  if (tile > tmax) tile = tmax;
+  REQUIRE(tile >= 1, "too many classes / target states for the CTC row tile");
   a.tile = tile;
   const size_t smem = (size_t)ctc_lds_layout(a.tile, a.ncp, a.smax).words * sizeof(float);
   REQUIRE(smem <= 160 * 1024, "CTC LDS carve exceeds 160 KiB");

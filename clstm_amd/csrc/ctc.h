@@ -40,7 +40,7 @@ struct CtcArgs {
   const int* state_off;  // [bs+1]
   float* lat;            // lattice workspace: per line 3*T*S floats at lat_off[b]
   const long long* lat_off;
-  const double* tables;  // device copy of ctc_tables.h: exp2_32[32] | invc[64] | logc[64]
+  const double* tables;  // device copy of ctc_tables.h: exp2_32[32] | invc[64] | logc[64] | softplus[929][2]
   int nc;
   int ncp;               // LDS row stride of the class tile (odd)
   int tile;              // frames per LDS tile
@@ -69,8 +69,9 @@ inline __host__ __device__ CtcLds ctc_lds_layout(int tile, int ncp, int smax) {
 }
 
 DEVFN float ctc_log_add(float x, float y, const CrTables tb) {  // tensor.h:86-89
-  if (fabsf(x - y) > 10.0f) return fmaxf(x, y);
-  return cr_logf(cr_expf(x - y, tb) + 1.0f, tb) + y;
+  const float d = x - y;
+  const float lg = cr_softplusf(d, tb) + y;   // log(exp(x-y)+1)+y, every float rounding reproduced (cr_math.h)
+  return fabsf(d) > 10.0f ? fmaxf(x, y) : lg; // branch-free: the serial lattice chain has no divergent path
 }
 DEVFN float ctc_limexp(float x, const CrTables tb) {  // tensor.h:78-82
   if (x < -30.0f) return (float)0x1.a56e0c2b7ab97p-44;  // (Float)exp(-30.0)
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   int* stl = reinterpret_cast<int*>(lds + L.states);
   float* vx = lds + L.vx;
   float* red = lds + L.red;
-  const CrTables tb{tabs, tabs + 32, tabs + 96};
+  const CrTables tb{tabs, tabs + 32, tabs + 96, tabs + 160};
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int b = blockIdx.x;
   const int nc = a.nc, ncp = a.ncp, TT = a.tile;
