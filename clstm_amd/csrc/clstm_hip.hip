@@ -758,7 +758,8 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
     std::vector<double> tb(CTC_TABLE_DOUBLES);
     for (int i = 0; i < 32; i++) tb[i] = CTC_EXP2_32[i];
     for (int i = 0; i < 64; i++) { tb[32 + i] = CTC_LOG_INVC[i]; tb[96 + i] = CTC_LOG_LOGC[i]; }
-    for (int k = 0; k < 2 * CTC_SP_KMAX + 1; k++) { tb[160 + 2 * k] = CTC_SOFTPLUS[k][0]; tb[161 + 2 * k] = CTC_SOFTPLUS[k][1]; }
+    for (int k = 0; k < 2 * CTC_SP_KMAX + 1; k++)
+      for (int c = 0; c < 4; c++) tb[160 + 4 * k + c] = CTC_SOFTPLUS[k][c];
     HIPCHECK(hipMemcpy(w.tables.p, tb.data(), CTC_TABLE_DOUBLES * sizeof(double), hipMemcpyHostToDevice));
   }
   a.tables = w.tables.p;

@@ -40,7 +40,7 @@ struct CtcArgs {
   const int* state_off;  // [bs+1]
   float* lat;            // lattice workspace: per line 3*T*S floats at lat_off[b]
   const long long* lat_off;
-  const double* tables;  // device copy of ctc_tables.h: exp2_32[32] | invc[64] | logc[64] | softplus[929][2]
+  const double* tables;  // device copy of ctc_tables.h: exp2_32[32] | invc[64] | logc[64] | softplus[929][4]
   int nc;
   int ncp;               // LDS row stride of the class tile (odd)
   int tile;              // frames per LDS tile
@@ -182,15 +182,16 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
         return (unsigned)(rev ? T - 1 - ic : ic) * rowbytes;
       };
       float v = -5.0f * (float)j;            // skip * j, exact in float
+      float skipi = 0.0f;                    // skip * i, accumulated: exact while 5 T < 2^24
       float lmA = buf_load(lmb, lanepart + frame(0)), lmB = buf_load(lmb, lanepart + frame(1));
       float kaA = 0.0f, kaB = 0.0f;
       auto step = [&](const int i, float& lmr, float& ka) {
         KEEP_ALIVE(ka);
-        float w = wave_shr1(v);
-        if (j == 0) w = -5.0f * (float)i;    // skip * i
         const float lmv = lmr;
         const float same = v + lmv;
-        const float next = w + lmv;
+        // next = w + lmatch with w = v[j-1] (lane 0: skip * i), the lane shift folded into the add
+        const float next = add_wave_shr1(skipi + lmv, v, lmv);
+        skipi -= 5.0f;
         lmr = buf_load(lmb, lanepart + frame(i + 2));  // two frames ahead
         v = ctc_log_add(same, next, tb);
         buf_store(outb, lanepart + frame(i), v);

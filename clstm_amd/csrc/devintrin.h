@@ -59,8 +59,19 @@ DEVFN float wave_shfl(float x, int src) { return __shfl(x, src, 64); }
 DEVFN float wave_shfl_up1(float x) { return __shfl_up(x, 1, 64); }
 #ifndef CLSTM_USE_SHFL
 DEVFN float wave_shr1(float x) { return dpp_mov<0x138>(x); }  // DPP wave_shr:1 (lane 0 keeps its value)
+// lanes >= 1: a[lane-1] + b[lane]; lane 0 (no source lane, bound_ctrl off) keeps `old`.  One VALU operation;
+// hipcc does not fold a DPP move with a live old operand into its consumer, hence the asm (s_nop: the
+// VALU-write -> DPP-read hazard is invisible to the compiler inside asm).
+DEVFN float add_wave_shr1(float old, float a, float b) {
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(a), "v"(b));
+  return old;
+}
 #else
 DEVFN float wave_shr1(float x) { return __shfl_up(x, 1, 64); }
+DEVFN float add_wave_shr1(float old, float a, float b) {
+  const float s = __shfl_up(a, 1, 64) + b;
+  return (threadIdx.x & 63) == 0 ? old : s;
+}
 #endif
 DEVFN int wave_shfl_i(int x, int src) { return __shfl(x, src, 64); }
 DEVFN int wave_shfl_xor_i(int x, int m) { return __shfl_xor(x, m, 64); }

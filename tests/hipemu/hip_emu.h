@@ -106,6 +106,7 @@ inline int wave_shfl_i(int x, int src) {
 inline int wave_shfl_xor_i(int x, int m) { return wave_shfl_i(x, emu_lane() ^ m); }
 inline float wave_shfl_up1(float x) { int l = emu_lane(); return wave_shfl(x, l == 0 ? 0 : l - 1); }
 inline float wave_shr1(float x) { return wave_shfl_up1(x); }
+inline float add_wave_shr1(float old, float a, float b) { const float s = wave_shfl_up1(a) + b; return emu_lane() == 0 ? old : s; }
 inline float quad_xor1(float x) { return wave_shfl(x, emu_lane() ^ 1); }
 inline float quad_xor2(float x) { return wave_shfl(x, emu_lane() ^ 2); }
 template <int I> inline float quad_bcast(float x) { return wave_shfl(x, (emu_lane() & ~3) | I); }
