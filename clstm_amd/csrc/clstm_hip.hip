@@ -752,7 +752,7 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
   a.P = probs; a.Dz = deltas; a.aligned = aligned; a.line_off = (const int*)(w.meta.p + nlo);
   a.states = (const int*)(w.meta.p + nlo + 2 * nio); a.state_off = (const int*)(w.meta.p + nlo + nio);
   a.lat = w.lat.p; a.lat_off = (const long long*)w.meta.p; a.nc = nc;
-  w.prof.reserve(8); a.prof = w.prof.p; g_last_ctc_prof = w.prof.p;
+  w.prof.reserve(16); a.prof = w.prof.p; g_last_ctc_prof = w.prof.p;
   if (!w.tables.p) {
     w.tables.reserve(CTC_TABLE_DOUBLES);
     std::vector<double> tb(CTC_TABLE_DOUBLES);
@@ -1086,7 +1086,7 @@ int clstm_debug_ctc_cycles(long long* out_h) {
   ABI_BEGIN
   REQUIRE(g_last_ctc_prof, "no CTC launch yet");
   HIPCHECK(hipStreamSynchronize(g_stream));
-  HIPCHECK(hipMemcpy(out_h, g_last_ctc_prof, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy(out_h, g_last_ctc_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost));
   ABI_END
 }
 #ifdef CLSTM_LSTM_PROF

@@ -13,6 +13,11 @@
 //   D. per-state normalisation over t, floor 1e-9, double accumulator        (ctc.cc:83-88)
 //   E. aligned[t][c] = sum_s epath[t][s] [class_s == c]; per-frame normalise (ctc.cc:91-109)
 //      and the fused delta  d = aligned - p                                  (clstmhl.h:211-212)
+// Lines whose lattice fits in LDS (T <= tile, T*S <= 12288: the OCR benchmark shape) take ctc_short_line():
+// the same arithmetic, organised for one CU -- match scores once per DISTINCT class (a blank-interleaved
+// target has L+1 equal blank columns), the lattice tile resident in LDS from C to E, branch-free guards
+// (clamped index + select, masked stores to a dump word) so that independent elements interleave instead
+// of paying the LDS / double-precision latency one element at a time.
 // Targets are given as one class per state (the Classes overload, ctc.cc:136-146; mktargets'
 // blank-interleaved list for OCR lines, ctc.cc:148-157).
 // Numerical note: in step E the blank class keeps the reference's double accumulator; a label that
@@ -45,12 +50,12 @@ struct CtcArgs {
   int ncp;               // LDS row stride of the class tile (odd)
   int tile;              // frames per LDS tile
   int smax;              // max states of any line in the batch (sizes the LDS carve)
-  long long* prof;       // optional [8] phase timestamps of block 0 (diagnostics)
+  long long* prof;       // optional [16] phase timestamps of block 0 (diagnostics)
 };
 
 // LDS carve shared by host (size) and kernel (offsets); all offsets in 4-byte words
 struct CtcLds {
-  int tables, part, tot, rowbuf, etile, asum, states, vx, red, words;
+  int tables, part, tot, rowbuf, etile, asum, states, lists, ucol, ucls, vx, red, dump, words;
 };
 inline __host__ __device__ CtcLds ctc_lds_layout(int tile, int ncp, int smax) {
   CtcLds l;
@@ -62,8 +67,12 @@ inline __host__ __device__ CtcLds ctc_lds_layout(int tile, int ncp, int smax) {
   l.etile = o;  o += tile * (smax | 1);
   l.asum = o;   o += tile;
   l.states = o; o += smax;
+  l.lists = o;  o += smax;   // short-line path: [blank states | first label states | repeats]
+  l.ucol = o;   o += smax;   //   column of a state in the table of distinct classes
+  l.ucls = o;   o += smax;   //   class of a column
   l.vx = o;     o += 2 * 2 * (CTC_GROUP + 2);
-  l.red = o;    o += 16;
+  l.red = o;    o += 64;
+  l.dump = o;   o += 2;      // target of masked-off LDS stores (branch-free guards)
   l.words = o;
   return l;
 }
@@ -79,91 +88,12 @@ DEVFN float ctc_limexp(float x, const CrTables tb) {  // tensor.h:78-82
   return cr_expf(x, tb);
 }
 
-__global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
-  float* lds = dyn_smem<float>();
-  const CtcLds L = ctc_lds_layout(a.tile, a.ncp, a.smax);
-  double* tabs = reinterpret_cast<double*>(lds + L.tables);
-  double* part = reinterpret_cast<double*>(lds + L.part);
-  double* tot = reinterpret_cast<double*>(lds + L.tot);
-  float* rowbuf = lds + L.rowbuf;
-  float* etile = lds + L.etile;
-  float* asum = lds + L.asum;
-  int* stl = reinterpret_cast<int*>(lds + L.states);
-  float* vx = lds + L.vx;
-  float* red = lds + L.red;
-  const CrTables tb{tabs, tabs + 32, tabs + 96, tabs + 160};
+// Phase B of both paths: alpha into `al`, the reversed-lattice alpha into `be` ([T][S] each).  The match
+// scores are prefetched from HBM two frames ahead (an LDS source was measured 100 cycles per frame slower:
+// its reads share lgkmcnt with the table reads of log_add and end up waited for right where they are issued).
+DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, const CrTables tb, const int T, const int S) {
+  // (= forwardbackward(), ctc.cc:42-55); serial in t, parallel over the label axis
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int b = blockIdx.x;
-  const int nc = a.nc, ncp = a.ncp, TT = a.tile;
-  const int off = a.line_off[b], T = a.line_off[b + 1] - off;
-  const int soff = a.state_off[b], S = a.state_off[b + 1] - soff;
-  if (T <= 0 || S <= 0) return;
-  const float* P = a.P + (size_t)off * nc;
-  float* Dz = a.Dz + (size_t)off * nc;
-  float* lm = a.lat + a.lat_off[b];
-  float* al = lm + (size_t)T * S;
-  float* be = al + (size_t)T * S;
-  for (int i = tid; i < CTC_TABLE_WORDS / 2; i += CTC_THREADS) tabs[i] = a.tables[i];
-  for (int s = tid; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
-#define CTC_STAMP(k) do { if (a.prof && b == 0 && tid == 0) a.prof[k] = dev_clock(); } while (0)
-  CTC_STAMP(0);
-
-  // ---- A: match scores  lmatch[t][s] = log(max(1e-5,p_t[class_s]) / sum_c max(1e-5,p_t[c])) ------
-  for (int t0 = 0; t0 < T; t0 += TT) {
-    const int nt = (T - t0) < TT ? (T - t0) : TT;
-    __syncthreads();
-    if (ncp == nc) {  // rows are back to back in LDS too: flat coalesced copy, CTC_MLP loads in flight
-      const float* src = P + (size_t)t0 * nc;
-      const int n = nt * nc;
-      for (int i0 = tid; i0 < n; i0 += CTC_MLP * CTC_THREADS) {
-        float x[CTC_MLP];
-#pragma unroll
-        for (int u = 0; u < CTC_MLP; u++) x[u] = (i0 + u * CTC_THREADS < n) ? src[i0 + u * CTC_THREADS] : 0.0f;
-#pragma unroll
-        for (int u = 0; u < CTC_MLP; u++)
-          if (i0 + u * CTC_THREADS < n) rowbuf[i0 + u * CTC_THREADS] = fmaxf(1e-5f, x[u]);
-      }
-    } else {
-      for (int i = tid; i < nt * nc; i += CTC_THREADS) {
-        const int t = i / nc, c = i - t * nc;
-        rowbuf[t * ncp + c] = fmaxf(1e-5f, P[(size_t)t0 * nc + i]);
-      }
-    }
-    __syncthreads();
-    if (tid < nt) {  // sequential float sum in class order, as asum1() (tensor.h:337-342)
-      float acc = 0.0f;
-      const float* r = rowbuf + tid * ncp;
-      for (int c = 0; c < nc; c++) acc += r[c];
-      asum[tid] = acc;
-    }
-    __syncthreads();
-    // (frame, state) pairs flattened over all threads (states need not be a multiple of the wave); the
-    // pair of the next element follows incrementally (no integer division in the loop)
-    {
-      const int dq = CTC_THREADS / S, dr = CTC_THREADS - dq * S;
-      int tq = tid / S, sq = tid - tq * S;
-      for (int i0 = tid; i0 < nt * S; i0 += 4 * CTC_THREADS) {
-        float o[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const bool in = i0 + u * CTC_THREADS < nt * S;
-          o[u] = in ? rowbuf[tq * ncp + stl[sq]] / asum[tq] : 1.0f;
-          tq += dq; sq += dr;
-          if (sq >= S) { sq -= S; tq++; }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + u * CTC_THREADS;
-          const float l = cr_logf(o[u], tb);
-          if (i < nt * S) lm[(size_t)t0 * S + i] = l;
-        }
-      }
-    }
-  }
-  CTC_STAMP(1);
-
-  // ---- B: forward recursion and the same recursion on the (t,s)-reversed lattice
-  //         (= forwardbackward(), ctc.cc:42-55); serial in t, parallel over the label axis --------
   const size_t latbytes = (size_t)T * S * 4;
   const BufF32 lmb = make_buf(lm, latbytes);
   if (S <= 64) {
@@ -262,12 +192,414 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
     }
     if (i < T) step(i, lmA, kaA);
   }
+}
+
+#define CTC_STAMP(k) do { if (a.prof && b == 0 && threadIdx.x == 0) a.prof[k] = dev_clock(); } while (0)
+constexpr int CTC_CCACHE = 24;  // lattice cells per thread kept in registers between the two passes of phase C
+
+// ---- lines whose lattice fits in LDS: phases A..E on one CU, see the header ------------------------------
+// Guards are branch-free throughout: reads use a clamped index and a select, masked-off stores go to `dump`,
+// global accesses go through buffer descriptors (out-of-range = no-op).  Loops are written as a batch of
+// independent reads followed by the arithmetic, so the scheduler can interleave the elements of a batch.
+DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const CrTables tb, const int b,
+                          const int off, const int T, const int S) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int nc = a.nc, ncp = a.ncp;
+  double* part = reinterpret_cast<double*>(lds + L.part);   // 512 doubles, reused phase by phase
+  double* tot = reinterpret_cast<double*>(lds + L.tot);
+  float* rowbuf = lds + L.rowbuf;
+  float* etile = lds + L.etile;
+  int* stl = reinterpret_cast<int*>(lds + L.states);
+  int* lists = reinterpret_cast<int*>(lds + L.lists);
+  int* ucol = reinterpret_cast<int*>(lds + L.ucol);
+  int* ucls = reinterpret_cast<int*>(lds + L.ucls);
+  float* red = lds + L.red;
+  int* wcnt = reinterpret_cast<int*>(red + 16);
+  float* dump = lds + L.dump;
+  float* lm = a.lat + a.lat_off[b];
+  float* al = lm + (size_t)T * S;
+  float* be = al + (size_t)T * S;
+  const int TS = T * S, sp = S | 1;
+  const size_t latbytes = (size_t)TS * 4;
+  const BufF32 pb = make_buf(a.P + (size_t)off * nc, (size_t)T * nc * 4);
+
+  // ---- classify the target states: blank / first state of its class / repeat; distinct classes -> columns
+  int* firstof = reinterpret_cast<int*>(rowbuf);   // first state of a class (rowbuf is free until the P tile)
+  for (int c = tid; c < nc; c += CTC_THREADS) firstof[c] = 0x7fffffff;
+  __syncthreads();
+  const bool live = tid < S;
+  const int sc = stl[live ? tid : 0];
+  if (live) lds_atomic_min(&firstof[sc], tid);
+  __syncthreads();
+  const int fo = firstof[sc];
+  const bool isfirst = live && fo == tid, isblank = live && sc == 0;
+  const bool islab = isfirst && sc != 0, isrep = live && sc != 0 && fo != tid;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned long long mF = wave_ballot(isfirst), mB = wave_ballot(isblank), mL = wave_ballot(islab),
+                           mR = wave_ballot(isrep);
+  if (lane == 0) {
+    wcnt[wave * 4 + 0] = __builtin_popcountll(mF); wcnt[wave * 4 + 1] = __builtin_popcountll(mB);
+    wcnt[wave * 4 + 2] = __builtin_popcountll(mL); wcnt[wave * 4 + 3] = __builtin_popcountll(mR);
+  }
+  __syncthreads();
+  int bF = 0, bB = 0, bL = 0, bR = 0, nu = 0, nb = 0, nf = 0;
+#pragma unroll
+  for (int w = 0; w < CTC_THREADS / 64; w++) {
+    const int cF = wcnt[w * 4], cB = wcnt[w * 4 + 1], cL = wcnt[w * 4 + 2], cR = wcnt[w * 4 + 3];
+    const bool pre = w < wave;
+    bF += pre ? cF : 0; bB += pre ? cB : 0; bL += pre ? cL : 0; bR += pre ? cR : 0;
+    nu += cF; nb += cB; nf += cL;
+  }
+  const int nr = S - nb - nf, nup = nu | 1;
+  if (isfirst) { const int r = bF + __builtin_popcountll(mF & below); firstof[sc] = r; ucls[r] = sc; }
+  if (isblank) lists[bB + __builtin_popcountll(mB & below)] = tid;
+  if (islab) lists[nb + bL + __builtin_popcountll(mL & below)] = tid;
+  if (isrep) lists[nb + nf + bR + __builtin_popcountll(mR & below)] = tid;
+  __syncthreads();
+  if (live) ucol[tid] = firstof[sc];
+  __syncthreads();   // firstof is dead, rowbuf may be filled
+  CTC_STAMP(12);
+
+  // ---- A: match scores, once per distinct class:  lmu[t][u] = log(max(1e-5, p_t[c_u]) / sum_c max(1e-5, p_t[c]))
+  //         x/sum is (float)((double)x * (1/sum)): equal to the reference's float division except for ~1e-8
+  //         of the values (1 ulp of double before the rounding to float)
+  for (int cb = 0; cb < nc; cb += 64) {   // one wave per frame, lanes over classes, eight frames in flight
+    const int c = cb + lane;
+    const bool cok = c < nc;
+    for (int t0 = wave; t0 < T; t0 += 8 * (CTC_THREADS / 64)) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int t = t0 + u * (CTC_THREADS / 64);
+        x[u] = buf_load(pb, (cok && t < T) ? (unsigned)(t * nc + c) * 4u : BUF_OOB);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int t = t0 + u * (CTC_THREADS / 64);
+        float* w = (cok && t < T) ? &rowbuf[t * ncp + c] : dump;
+        *w = fmaxf(1e-5f, x[u]);
+      }
+    }
+  }
+  __syncthreads();
+  CTC_STAMP(13);
+  for (int t = tid; t < T; t += CTC_THREADS) {  // sequential float sum in class order, as asum1() (tensor.h:337-342)
+    const float* r = rowbuf + t * ncp;
+    float acc = 0.0f;
+    for (int c0 = 0; c0 < nc; c0 += 16) {
+      float x[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) x[u] = r[c0 + u < nc ? c0 + u : 0];
+#pragma unroll
+      for (int u = 0; u < 16; u++) acc += (c0 + u < nc) ? x[u] : 0.0f;   // + 0.0f is exact
+    }
+    part[t] = 1.0 / (double)acc;
+  }
+  __syncthreads();
+  CTC_STAMP(14);
+  {
+    const int n = T * nu;
+    const int dq = CTC_THREADS / nu, dr = CTC_THREADS - dq * nu;   // (t, u) of item i, followed incrementally
+    int tq = tid / nu, uq = tid - tq * nu;
+    for (int i0 = tid; i0 < n; i0 += 4 * CTC_THREADS) {
+      float q[4];
+      float* w[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool in = i0 + u * CTC_THREADS < n;
+        const int tc = in ? tq : 0, uc = in ? uq : 0;
+        q[u] = (float)((double)rowbuf[tc * ncp + ucls[uc]] * part[tc]);
+        w[u] = in ? &etile[tc * nup + uc] : dump;
+        tq += dq; uq += dr;
+        if (uq >= nu) { uq -= nu; tq++; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) *w[u] = cr_logf(q[u], tb);
+    }
+  }
+  __syncthreads();
+  CTC_STAMP(15);
+  {  // lmatch rows for the recursion (it prefetches them from HBM two frames ahead: vmcnt, not lgkmcnt)
+    const BufF32 lmw = make_buf(lm, latbytes);
+    for (int s0 = 0; s0 < S; s0 += 64) {   // one wave per frame, lanes over states
+      const int st = s0 + lane;
+      const bool sok = st < S;
+      const float* col = etile + ucol[sok ? st : 0];
+      for (int t0 = wave; t0 < T; t0 += 8 * (CTC_THREADS / 64)) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int t = t0 + u * (CTC_THREADS / 64); x[u] = col[(t < T ? t : T - 1) * nup]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int t = t0 + u * (CTC_THREADS / 64);
+          buf_store(lmw, (sok && t < T) ? (unsigned)(t * S + st) * 4u : BUF_OOB, x[u]);
+        }
+      }
+    }
+  }
+  CTC_STAMP(1);
+
+  // ---- B
+  ctc_lattice(lm, al, be, lds + L.vx, tb, T, S);
+  __syncthreads();
+  CTC_STAMP(2);
+
+  // ---- C: epath = limexp(both - amax2(both)) -> etile[t][s]   (ctc.cc:82)
+  {
+    const BufF32 alb = make_buf(al, latbytes), beb = make_buf(be, latbytes);
+    float bo[CTC_CCACHE];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < CTC_CCACHE; k++) {
+      const int i = tid + k * CTC_THREADS;
+      const float x = buf_load(alb, (unsigned)i * 4u) + buf_load(beb, (unsigned)i * 4u);
+      bo[k] = i < TS ? x : -3.0e38f;
+      mx = fmaxf(mx, bo[k]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    for (int i = tid; i < T * ncp; i += CTC_THREADS) rowbuf[i] = 0.0f;   // class rows of phase E
+    __syncthreads();
+    CTC_STAMP(6);
+    mx = red[0];
+#pragma unroll
+    for (int i = 1; i < CTC_THREADS / 64; i++) mx = fmaxf(mx, red[i]);
+    CTC_STAMP(7);
+    const int dq = CTC_THREADS / S, dr = CTC_THREADS - dq * S;   // (t, s) of cell i, followed incrementally
+    int tq = tid / S, sq = tid - tq * S;
+#pragma unroll
+    for (int k = 0; k < CTC_CCACHE; k++) {
+      // limexp (tensor.h:78-82): the clamp to [-30, 30] followed by the round-once exp gives its three cases
+      const float x = fminf(fmaxf(bo[k] - mx, -30.0f), 30.0f);
+      float* w = (tid + k * CTC_THREADS < TS) ? &etile[tq * sp + sq] : dump;
+      *w = cr_expf(x, tb);
+      tq += dq; sq += dr;
+      if (sq >= S) { sq -= S; tq++; }
+    }
+  }
+  __syncthreads();
+  CTC_STAMP(3);
+
+  // ---- D: per-state totals over time (double accumulator, floor 1e-9) and the normalisation in place;
+  //         x/total is (float)((double)x * (1/total)), see the note at phase D of the tiled path
+  {
+    const int Q = CTC_THREADS / S > 8 ? 8 : CTC_THREADS / S;   // time chunks per state
+    const int q = tid / S, st = tid - q * S;
+    const bool act = q < Q;
+    double acc = 0.0;
+    for (int t0 = act ? q : T; t0 < T; t0 += 8 * Q) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int t = t0 + u * Q; x[u] = etile[(t < T ? t : T - 1) * sp + st]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc += (t0 + u * Q < T) ? (double)x[u] : 0.0;
+    }
+    if (act) part[q * S + st] = acc;
+    __syncthreads();
+    CTC_STAMP(8);
+    if (tid < S) {
+      double sum = 0.0;
+      for (int k = 0; k < Q; k++) sum += part[k * S + tid];
+      tot[tid] = 1.0 / fmax(1e-9, sum);   // reciprocal: the divisions become double multiplies
+    }
+    __syncthreads();
+    CTC_STAMP(9);
+    const double it = tot[st];
+    for (int t0 = act ? q : T; t0 < T; t0 += 8 * Q) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int t = t0 + u * Q; x[u] = etile[(t < T ? t : T - 1) * sp + st]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int t = t0 + u * Q;
+        float* w = (act && t < T) ? &etile[t * sp + st] : dump;
+        *w = (float)((double)x[u] * it);
+      }
+    }
+  }
+  __syncthreads();
+  CTC_STAMP(4);
+
+  // ---- E: project states onto classes (ctc.cc:91-109).  Waves 4-7: lane = one first-occurrence label state,
+  //         looping over frames (plain stores).  Waves 0-3: lane = one frame, the blank states summed in state
+  //         order in double (class 0 collects L+1 states: the reference's double accumulator).
+  if (wave >= 4) {
+    for (int f0 = 0; f0 < nf; f0 += 64) {
+      const bool fok = f0 + lane < nf;
+      const int st = lists[nb + (fok ? f0 + lane : 0)];
+      const int c = stl[st];
+      for (int t0 = wave - 4; t0 < T; t0 += 4 * 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int t = t0 + 4 * u; x[u] = etile[(t < T ? t : T - 1) * sp + st]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int t = t0 + 4 * u;
+          float* w = (fok && t < T) ? &rowbuf[t * ncp + c] : dump;
+          *w = x[u];
+        }
+      }
+    }
+  } else {
+    for (int t = tid; t < T; t += 256) {
+      const float* e = etile + t * sp;
+      double blank = 0.0;
+      for (int i0 = 0; i0 < nb; i0 += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = e[lists[i0 + u < nb ? i0 + u : 0]];
+#pragma unroll
+        for (int u = 0; u < 8; u++) blank += (i0 + u < nb) ? (double)x[u] : 0.0;
+      }
+      part[t] = blank;
+    }
+  }
+  __syncthreads();
+  CTC_STAMP(10);
+  for (int t = tid; t < T; t += CTC_THREADS) {
+    float* row = rowbuf + t * ncp;
+    const float* e = etile + t * sp;
+    for (int i = 0; i < nr; i++) {   // few; a class may repeat more than once: read-modify-write in state order
+      const int st = lists[nb + nf + i];
+      row[stl[st]] += e[st];
+    }
+    row[0] = (float)part[t];
+    double total = 0.0;   // class order, double
+    for (int c0 = 0; c0 < nc; c0 += 16) {
+      float x[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) x[u] = row[c0 + u < nc ? c0 + u : 0];
+#pragma unroll
+      for (int u = 0; u < 16; u++) total += (c0 + u < nc) ? (double)x[u] : 0.0;
+    }
+    part[t] = 1.0 / fmax(total, 1e-9);
+  }
+  __syncthreads();
+  CTC_STAMP(11);
+  {  // per-frame normalisation and the fused delta  d = aligned - p  (clstmhl.h:211-212); one wave per frame
+    const BufF32 dzb = make_buf(a.Dz + (size_t)off * nc, (size_t)T * nc * 4);
+    const BufF32 agb = make_buf(a.aligned ? a.aligned + (size_t)off * nc : a.Dz, a.aligned ? (size_t)T * nc * 4 : 0);
+    for (int cb = 0; cb < nc; cb += 64) {
+      const int c = cb + lane;
+      const bool cok = c < nc;
+      for (int t0 = wave; t0 < T; t0 += 8 * (CTC_THREADS / 64)) {
+        float p[8];
+        unsigned ofs[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int t = t0 + u * (CTC_THREADS / 64);
+          ofs[u] = (cok && t < T) ? (unsigned)(t * nc + c) * 4u : BUF_OOB;
+          p[u] = buf_load(pb, ofs[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int t = t0 + u * (CTC_THREADS / 64);
+          const int tc = t < T ? t : T - 1;
+          const float av = (float)((double)rowbuf[tc * ncp + (cok ? c : 0)] * part[tc]);
+          buf_store(agb, ofs[u], av);
+          buf_store(dzb, ofs[u], av - p[u]);
+        }
+      }
+    }
+  }
+  CTC_STAMP(5);
+}
+
+__global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
+  float* lds = dyn_smem<float>();
+  const CtcLds L = ctc_lds_layout(a.tile, a.ncp, a.smax);
+  double* tabs = reinterpret_cast<double*>(lds + L.tables);
+  double* part = reinterpret_cast<double*>(lds + L.part);
+  double* tot = reinterpret_cast<double*>(lds + L.tot);
+  float* rowbuf = lds + L.rowbuf;
+  float* etile = lds + L.etile;
+  float* asum = lds + L.asum;
+  int* stl = reinterpret_cast<int*>(lds + L.states);
+  float* vx = lds + L.vx;
+  float* red = lds + L.red;
+  const CrTables tb{tabs, tabs + 32, tabs + 96, tabs + 160};
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int b = blockIdx.x;
+  const int nc = a.nc, ncp = a.ncp, TT = a.tile;
+  const int off = a.line_off[b], T = a.line_off[b + 1] - off;
+  const int soff = a.state_off[b], S = a.state_off[b + 1] - soff;
+  if (T <= 0 || S <= 0) return;
+  const float* P = a.P + (size_t)off * nc;
+  float* Dz = a.Dz + (size_t)off * nc;
+  float* lm = a.lat + a.lat_off[b];
+  float* al = lm + (size_t)T * S;
+  float* be = al + (size_t)T * S;
+  for (int i = tid; i < CTC_TABLE_WORDS / 2; i += CTC_THREADS) tabs[i] = a.tables[i];
+  for (int s = tid; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
+  CTC_STAMP(0);
+  if (T <= TT && T * S <= CTC_THREADS * CTC_CCACHE) {   // wave-uniform: the whole workgroup takes one path
+    __syncthreads();
+    ctc_short_line(a, lds, L, tb, b, off, T, S);
+    return;
+  }
+
+  // ---- A: match scores  lmatch[t][s] = log(max(1e-5,p_t[class_s]) / sum_c max(1e-5,p_t[c])) ------
+  for (int t0 = 0; t0 < T; t0 += TT) {
+    const int nt = (T - t0) < TT ? (T - t0) : TT;
+    __syncthreads();
+    if (ncp == nc) {  // rows are back to back in LDS too: flat coalesced copy, CTC_MLP loads in flight
+      const float* src = P + (size_t)t0 * nc;
+      const int n = nt * nc;
+      for (int i0 = tid; i0 < n; i0 += CTC_MLP * CTC_THREADS) {
+        float x[CTC_MLP];
+#pragma unroll
+        for (int u = 0; u < CTC_MLP; u++) x[u] = (i0 + u * CTC_THREADS < n) ? src[i0 + u * CTC_THREADS] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < CTC_MLP; u++)
+          if (i0 + u * CTC_THREADS < n) rowbuf[i0 + u * CTC_THREADS] = fmaxf(1e-5f, x[u]);
+      }
+    } else {
+      for (int i = tid; i < nt * nc; i += CTC_THREADS) {
+        const int t = i / nc, c = i - t * nc;
+        rowbuf[t * ncp + c] = fmaxf(1e-5f, P[(size_t)t0 * nc + i]);
+      }
+    }
+    __syncthreads();
+    if (tid < nt) {  // sequential float sum in class order, as asum1() (tensor.h:337-342)
+      float acc = 0.0f;
+      const float* r = rowbuf + tid * ncp;
+      for (int c = 0; c < nc; c++) acc += r[c];
+      asum[tid] = acc;
+    }
+    __syncthreads();
+    // (frame, state) pairs flattened over all threads (states need not be a multiple of the wave); the
+    // pair of the next element follows incrementally (no integer division in the loop)
+    {
+      const int dq = CTC_THREADS / S, dr = CTC_THREADS - dq * S;
+      int tq = tid / S, sq = tid - tq * S;
+      for (int i0 = tid; i0 < nt * S; i0 += 4 * CTC_THREADS) {
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool in = i0 + u * CTC_THREADS < nt * S;
+          o[u] = in ? rowbuf[tq * ncp + stl[sq]] / asum[tq] : 1.0f;
+          tq += dq; sq += dr;
+          if (sq >= S) { sq -= S; tq++; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * CTC_THREADS;
+          const float l = cr_logf(o[u], tb);
+          if (i < nt * S) lm[(size_t)t0 * S + i] = l;
+        }
+      }
+    }
+  }
+  CTC_STAMP(1);
+
+  // ---- B: forward recursion and the same recursion on the (t,s)-reversed lattice
+  ctc_lattice(lm, al, be, vx, tb, T, S);
   __syncthreads();
   CTC_STAMP(2);
 
   // ---- C: epath = limexp(both - amax2(both)) ---------------------------------------------
   const int TS = T * S;
-  constexpr int CCACHE = 24;  // lattice cells per thread kept in registers between the two passes
+  constexpr int CCACHE = CTC_CCACHE;
   if (TS <= CTC_THREADS * CCACHE) {
     float bo[CCACHE];
     float mx = -3.0e38f;

@@ -73,6 +73,8 @@ DEVFN float add_wave_shr1(float old, float a, float b) {
   return (threadIdx.x & 63) == 0 ? old : s;
 }
 #endif
+DEVFN unsigned long long wave_ballot(bool p) { return __ballot(p); }   // bit l = predicate of lane l
+DEVFN int lds_atomic_min(int* p, int v) { return atomicMin(p, v); }
 DEVFN int wave_shfl_i(int x, int src) { return __shfl(x, src, 64); }
 DEVFN int wave_shfl_xor_i(int x, int m) { return __shfl_xor(x, m, 64); }
 DEVFN float wave_max(float x) {

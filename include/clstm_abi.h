@@ -195,7 +195,8 @@ int clstm_debug_lane_ops(float* out);
  * B [K][Cn] row-major; mode 1 "NT": A [R][K], B given as [Cn][K]; mode 2 "TN": A given as [K][R],
  * B [K][Cn] (split over K into nsplit slabs, reduced deterministically).  C [R][Cn] row-major.
  * Modes 10/11/12: the same three layouts through the bf16-input kernel (gemm_bf16.h). */
-/* shader-clock timestamps of the last CTC launch's block 0 after phases A..E (HOST [8]) */
+/* shader-clock timestamps of the last CTC launch's block 0 (HOST [16]): [0] start, [1..5] after phases A..E,
+ * [6..15] sub-phase stamps of the short-line path (see scripts/gpu_ctcprof.py) */
 int clstm_debug_ctc_cycles(long long* out_h);
 int clstm_debug_gemm(int mode, const float* A, const float* B, float* C, int R, int Cn, int K, int nsplit);
 

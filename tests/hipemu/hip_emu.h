@@ -104,6 +104,19 @@ inline int wave_shfl_i(int x, int src) {
   return r;
 }
 inline int wave_shfl_xor_i(int x, int m) { return wave_shfl_i(x, emu_lane() ^ m); }
+inline unsigned long long wave_ballot(bool p) {
+  *emu_slot(emu_lane()) = p ? 1.0f : 0.0f;
+  emu_wave_sync();
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; l++) if (*emu_slot(l) != 0.0f) m |= 1ull << l;
+  emu_wave_sync();
+  return m;
+}
+inline int lds_atomic_min(int* p, int v) {
+  int old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return old;
+}
 inline float wave_shfl_up1(float x) { int l = emu_lane(); return wave_shfl(x, l == 0 ? 0 : l - 1); }
 inline float wave_shr1(float x) { return wave_shfl_up1(x); }
 inline float add_wave_shr1(float old, float a, float b) { const float s = wave_shfl_up1(a) + b; return emu_lane() == 0 ? old : s; }
