@@ -63,6 +63,7 @@ inline __host__ __device__ CtcLds ctc_lds_layout(int tile, int ncp, int smax) {
   l.tables = o; o += CTC_TABLE_WORDS;  // doubles first: 8-byte aligned
   l.part = o;   o += 2 * 512;
   l.tot = o;    o += 2 * smax;
+  o = (o + 3) & ~3;                    // 16-byte aligned: cleared with ds_write_b128
   l.rowbuf = o; o += tile * ncp;
   l.etile = o;  o += tile * (smax | 1);
   l.asum = o;   o += tile;
@@ -80,7 +81,7 @@ inline __host__ __device__ CtcLds ctc_lds_layout(int tile, int ncp, int smax) {
 DEVFN float ctc_log_add(float x, float y, const CrTables tb) {  // tensor.h:86-89
   const float d = x - y;
   const float lg = cr_softplusf(d, tb) + y;   // log(exp(x-y)+1)+y, every float rounding reproduced (cr_math.h)
-  return fabsf(d) > 10.0f ? fmaxf(x, y) : lg; // branch-free: the serial lattice chain has no divergent path
+  return fabsf(d) > 10.0f ? fmaxf(x, y) : lg; // a select (an asm v_max here turns it into an exec-masked branch)
 }
 DEVFN float ctc_limexp(float x, const CrTables tb) {  // tensor.h:78-82
   if (x < -30.0f) return (float)0x1.a56e0c2b7ab97p-44;  // (Float)exp(-30.0)
@@ -113,7 +114,7 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, const C
       };
       float v = -5.0f * (float)j;            // skip * j, exact in float
       float skipi = 0.0f;                    // skip * i, accumulated: exact while 5 T < 2^24
-      float lmA = buf_load(lmb, lanepart + frame(0)), lmB = buf_load(lmb, lanepart + frame(1));
+      float lmA = buf_load_s(lmb, lanepart, frame(0)), lmB = buf_load_s(lmb, lanepart, frame(1));
       float kaA = 0.0f, kaB = 0.0f;
       auto step = [&](const int i, float& lmr, float& ka) {
         KEEP_ALIVE(ka);
@@ -122,9 +123,9 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, const C
         // next = w + lmatch with w = v[j-1] (lane 0: skip * i), the lane shift folded into the add
         const float next = add_wave_shr1(skipi + lmv, v, lmv);
         skipi -= 5.0f;
-        lmr = buf_load(lmb, lanepart + frame(i + 2));  // two frames ahead
+        lmr = buf_load_s(lmb, lanepart, frame(i + 2));  // two frames ahead
         v = ctc_log_add(same, next, tb);
-        buf_store(outb, lanepart + frame(i), v);
+        buf_store_s(outb, lanepart, frame(i), v);
         ka = v;
       };
       int i = 0;
@@ -195,6 +196,8 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, const C
 }
 
 #define CTC_STAMP(k) do { if (a.prof && b == 0 && threadIdx.x == 0) a.prof[k] = dev_clock(); } while (0)
+constexpr int CTC_TREG = (CTC_TABLE_DOUBLES + CTC_THREADS - 1) / CTC_THREADS;
+constexpr int CTC_PREG = 34;    // posteriors per thread held in registers across the state classification
 constexpr int CTC_CCACHE = 24;  // lattice cells per thread kept in registers between the two passes of phase C
 
 // ---- lines whose lattice fits in LDS: phases A..E on one CU, see the header ------------------------------
@@ -202,7 +205,7 @@ constexpr int CTC_CCACHE = 24;  // lattice cells per thread kept in registers be
 // global accesses go through buffer descriptors (out-of-range = no-op).  Loops are written as a batch of
 // independent reads followed by the arithmetic, so the scheduler can interleave the elements of a batch.
 DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const CrTables tb, const int b,
-                          const int off, const int T, const int S) {
+                          const int off, const int T, const int S, const double (&treg)[CTC_TREG]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int nc = a.nc, ncp = a.ncp;
   double* part = reinterpret_cast<double*>(lds + L.part);   // 512 doubles, reused phase by phase
@@ -223,8 +226,17 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   const size_t latbytes = (size_t)TS * 4;
   const BufF32 pb = make_buf(a.P + (size_t)off * nc, (size_t)T * nc * 4);
 
+  // the posteriors of the line are requested first and land in LDS after the classification
+  const int npost = T * nc;
+  const bool flat = ncp == nc && npost <= CTC_PREG * CTC_THREADS;   // rows back to back in LDS too: flat copy
+  float preg[CTC_PREG];
+  if (flat) {
+#pragma unroll
+    for (int k = 0; k < CTC_PREG; k++) preg[k] = buf_load(pb, (unsigned)(tid + k * CTC_THREADS) * 4u);   // past the end: 0
+  }
+
   // ---- classify the target states: blank / first state of its class / repeat; distinct classes -> columns
-  int* firstof = reinterpret_cast<int*>(rowbuf);   // first state of a class (rowbuf is free until the P tile)
+  int* firstof = reinterpret_cast<int*>(etile);   // first state of a class (etile is free until the match table)
   for (int c = tid; c < nc; c += CTC_THREADS) firstof[c] = 0x7fffffff;
   __syncthreads();
   const bool live = tid < S;
@@ -257,27 +269,41 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   if (isrep) lists[nb + nf + bR + __builtin_popcountll(mR & below)] = tid;
   __syncthreads();
   if (live) ucol[tid] = firstof[sc];
-  __syncthreads();   // firstof is dead, rowbuf may be filled
   CTC_STAMP(12);
+  {
+    double* tabs = reinterpret_cast<double*>(lds + L.tables);
+#pragma unroll
+    for (int k = 0; k < CTC_TREG; k++)
+      if (tid + k * CTC_THREADS < CTC_TABLE_DOUBLES) tabs[tid + k * CTC_THREADS] = treg[k];
+  }
 
   // ---- A: match scores, once per distinct class:  lmu[t][u] = log(max(1e-5, p_t[c_u]) / sum_c max(1e-5, p_t[c]))
   //         x/sum is (float)((double)x * (1/sum)): equal to the reference's float division except for ~1e-8
   //         of the values (1 ulp of double before the rounding to float)
-  for (int cb = 0; cb < nc; cb += 64) {   // one wave per frame, lanes over classes, eight frames in flight
-    const int c = cb + lane;
-    const bool cok = c < nc;
-    for (int t0 = wave; t0 < T; t0 += 8 * (CTC_THREADS / 64)) {
-      float x[8];
+  if (flat) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int t = t0 + u * (CTC_THREADS / 64);
-        x[u] = buf_load(pb, (cok && t < T) ? (unsigned)(t * nc + c) * 4u : BUF_OOB);
-      }
+    for (int k = 0; k < CTC_PREG; k++) {
+      const int i = tid + k * CTC_THREADS;
+      float* w = i < npost ? &rowbuf[i] : dump;
+      *w = fmaxf(1e-5f, preg[k]);
+    }
+  } else {
+    for (int cb = 0; cb < nc; cb += 64) {   // one wave per frame, lanes over classes, eight frames in flight
+      const int c = cb + lane;
+      const bool cok = c < nc;
+      for (int t0 = wave; t0 < T; t0 += 8 * (CTC_THREADS / 64)) {
+        float x[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int t = t0 + u * (CTC_THREADS / 64);
-        float* w = (cok && t < T) ? &rowbuf[t * ncp + c] : dump;
-        *w = fmaxf(1e-5f, x[u]);
+        for (int u = 0; u < 8; u++) {
+          const int t = t0 + u * (CTC_THREADS / 64);
+          x[u] = buf_load(pb, (cok && t < T) ? (unsigned)(t * nc + c) * 4u : BUF_OOB);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int t = t0 + u * (CTC_THREADS / 64);
+          float* w = (cok && t < T) ? &rowbuf[t * ncp + c] : dump;
+          *w = fmaxf(1e-5f, x[u]);
+        }
       }
     }
   }
@@ -339,8 +365,13 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   }
   CTC_STAMP(1);
 
-  // ---- B
+  // ---- B (S <= 64: waves 0 and 1; the other waves clear the class rows of phase E meanwhile)
   ctc_lattice(lm, al, be, lds + L.vx, tb, T, S);
+  if (S > 64 || wave >= 2) {
+    const int first = S > 64 ? tid : tid - 128, step = S > 64 ? CTC_THREADS : CTC_THREADS - 128;
+    float4* r4 = reinterpret_cast<float4*>(rowbuf);   // 16-byte aligned; the tail may spill into the (dead) match table
+    for (int i = first; i < (T * ncp + 3) / 4; i += step) r4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
   __syncthreads();
   CTC_STAMP(2);
 
@@ -358,7 +389,6 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
-    for (int i = tid; i < T * ncp; i += CTC_THREADS) rowbuf[i] = 0.0f;   // class rows of phase E
     __syncthreads();
     CTC_STAMP(6);
     mx = red[0];
@@ -529,14 +559,22 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   float* lm = a.lat + a.lat_off[b];
   float* al = lm + (size_t)T * S;
   float* be = al + (size_t)T * S;
-  for (int i = tid; i < CTC_TABLE_WORDS / 2; i += CTC_THREADS) tabs[i] = a.tables[i];
-  for (int s = tid; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
   CTC_STAMP(0);
+  double treg[CTC_TREG];   // the tables travel through registers: their load latency overlaps what follows
+#pragma unroll
+  for (int k = 0; k < CTC_TREG; k++) {
+    const int i = tid + k * CTC_THREADS;
+    treg[k] = a.tables[i < CTC_TABLE_DOUBLES ? i : CTC_TABLE_DOUBLES - 1];
+  }
+  for (int s = tid; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
   if (T <= TT && T * S <= CTC_THREADS * CTC_CCACHE) {   // wave-uniform: the whole workgroup takes one path
     __syncthreads();
-    ctc_short_line(a, lds, L, tb, b, off, T, S);
+    ctc_short_line(a, lds, L, tb, b, off, T, S, treg);
     return;
   }
+#pragma unroll
+  for (int k = 0; k < CTC_TREG; k++)
+    if (tid + k * CTC_THREADS < CTC_TABLE_DOUBLES) tabs[tid + k * CTC_THREADS] = treg[k];
 
   // ---- A: match scores  lmatch[t][s] = log(max(1e-5,p_t[class_s]) / sum_c max(1e-5,p_t[c])) ------
   for (int t0 = 0; t0 < T; t0 += TT) {

@@ -151,6 +151,19 @@ DEVFN f32x4 buf_load4(BufF32 b, unsigned byte_off) {  // 16 bytes, dword alignme
 DEVFN void buf_store(BufF32 b, unsigned byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.r, byte_off, 0, 0);
 }
+// lane offset (VGPR, bounds-checked) + wave-uniform offset (SGPR, NOT part of the bounds check of a raw
+// buffer): no VALU add per access, and a lane parked at BUF_OOB_BASE stays out of range
+DEVFN float buf_load_s(BufF32 b, unsigned lane_off, unsigned uniform_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, lane_off, uniform_off, 0));
+}
+DEVFN void buf_store_s(BufF32 b, unsigned lane_off, unsigned uniform_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.r, lane_off, uniform_off, 0);
+}
+DEVFN float max_f32(float x, float y) {   // v_max_f32 without the canonicalising self-max of fmaxf (operands are never sNaN)
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
 
 // ---- device-scope (sc1) accesses and the grid barrier of the cooperative kernels (lstm_wide.h) ----
 // Data produced and consumed by DIFFERENT workgroups of one launch: per-XCD L2s are not coherent with

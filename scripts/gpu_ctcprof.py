@@ -23,6 +23,6 @@ for (T, L, nc, bs) in [(200, 25, 83, 64), (200, 25, 83, 1), (400, 80, 83, 16)]:
     print("T=%d S=%d bs=%d phases A,B,C,D,E cycles:" % (T, S, bs), d.tolist(), "total", int(cyc[5]-cyc[0]))
     if cyc[6] > cyc[2]:   # short-line path: sub-phase stamps
         seq = [cyc[0], cyc[12], cyc[13], cyc[14], cyc[15], cyc[1], cyc[2], cyc[6], cyc[7], cyc[3], cyc[8], cyc[9], cyc[4], cyc[10], cyc[11], cyc[5]]
-        names = ["classify", "A tile", "A row sums", "A log", "A rows->HBM", "B", "C load+max+zero", "C max bcast", "C limexp", "D sums", "D totals",
+        names = ["classify", "A tile", "A row sums", "A log", "A rows->HBM", "B", "C load+max", "C max bcast", "C limexp", "D sums", "D totals",
                  "D normalise", "E project/blank", "E frame totals", "E write-out"]
         print("   " + ", ".join("%s %d" % (n, int(b - a)) for n, a, b in zip(names, seq[:-1], seq[1:])))

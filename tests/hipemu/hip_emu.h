@@ -193,6 +193,9 @@ inline BufF32 make_buf(const float* base, size_t bytes) { return BufF32{const_ca
 inline float buf_load(BufF32 b, unsigned off) { return ((size_t)off + 4 <= b.bytes) ? b.base[off / 4] : 0.0f; }
 inline f32x4 buf_load4(BufF32 b, unsigned off) { f32x4 r; for (int i = 0; i < 4; i++) r[i] = buf_load(b, off + 4 * i); return r; }
 inline void buf_store(BufF32 b, unsigned off, float v) { if ((size_t)off + 4 <= b.bytes) b.base[off / 4] = v; }
+inline float buf_load_s(BufF32 b, unsigned lane_off, unsigned uni) { return ((size_t)lane_off + 4 <= b.bytes) ? b.base[(lane_off + uni) / 4] : 0.0f; }
+inline void buf_store_s(BufF32 b, unsigned lane_off, unsigned uni, float v) { if ((size_t)lane_off + 4 <= b.bytes) b.base[(lane_off + uni) / 4] = v; }
+inline float max_f32(float x, float y) { return fmaxf(x, y); }
 #define KEEP_ALIVE2(x) (void)(x)
 inline f32x4 buf_load4_dev(BufF32 b, unsigned off) { return buf_load4(b, off); }
 inline void buf_store_dev(BufF32 b, unsigned off, float v) { buf_store(b, off, v); }
