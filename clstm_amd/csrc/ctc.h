@@ -55,7 +55,7 @@ struct CtcArgs {
 
 // LDS carve shared by host (size) and kernel (offsets); all offsets in 4-byte words
 struct CtcLds {
-  int tables, part, tot, rowbuf, etile, asum, states, lists, ucol, ucls, vx, red, dump, words;
+  int tables, part, tot, rowbuf, etile, asum, states, lists, ucol, ucls, ccol, vx, red, dump, words;
 };
 inline __host__ __device__ CtcLds ctc_lds_layout(int tile, int ncp, int smax) {
   CtcLds l;
@@ -71,6 +71,7 @@ inline __host__ __device__ CtcLds ctc_lds_layout(int tile, int ncp, int smax) {
   l.lists = o;  o += smax;   // short-line path: [blank states | first label states | repeats]
   l.ucol = o;   o += smax;   //   column of a state in the table of distinct classes
   l.ucls = o;   o += smax;   //   class of a column
+  l.ccol = o;   o += ncp;    //   column of a class (-1: no state of that class)
   l.vx = o;     o += 2 * 2 * (CTC_GROUP + 2);
   l.red = o;    o += 64;
   l.dump = o;   o += 2;      // target of masked-off LDS stores (branch-free guards)
@@ -216,6 +217,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   int* lists = reinterpret_cast<int*>(lds + L.lists);
   int* ucol = reinterpret_cast<int*>(lds + L.ucol);
   int* ucls = reinterpret_cast<int*>(lds + L.ucls);
+  int* ccol = reinterpret_cast<int*>(lds + L.ccol);
   float* red = lds + L.red;
   int* wcnt = reinterpret_cast<int*>(red + 16);
   float* dump = lds + L.dump;
@@ -236,7 +238,8 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   }
 
   // ---- classify the target states: blank / first state of its class / repeat; distinct classes -> columns
-  int* firstof = reinterpret_cast<int*>(etile);   // first state of a class (etile is free until the match table)
+  int* firstof = reinterpret_cast<int*>(rowbuf);  // first state of a class; rowbuf holds >= ncp words and is free until
+                                                  // the posteriors land (etile can be smaller than nc for a short line)
   for (int c = tid; c < nc; c += CTC_THREADS) firstof[c] = 0x7fffffff;
   __syncthreads();
   const bool live = tid < S;
@@ -244,31 +247,38 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   if (live) lds_atomic_min(&firstof[sc], tid);
   __syncthreads();
   const int fo = firstof[sc];
-  const bool isfirst = live && fo == tid, isblank = live && sc == 0;
-  const bool islab = isfirst && sc != 0, isrep = live && sc != 0 && fo != tid;
+  const bool isblank = live && sc == 0;
+  const bool islab = live && sc != 0 && fo == tid, isrep = live && sc != 0 && fo != tid;
+  // the distinct classes of the line get the columns 0..nu-1 in CLASS order: a frame's total over the columns
+  // is then the reference's sum over all classes (absent classes contribute exact zeros)
+  const bool pres = tid < nc && firstof[tid < nc ? tid : 0] != 0x7fffffff;
   const unsigned long long below = (1ull << lane) - 1ull;
-  const unsigned long long mF = wave_ballot(isfirst), mB = wave_ballot(isblank), mL = wave_ballot(islab),
+  const unsigned long long mP = wave_ballot(pres), mB = wave_ballot(isblank), mL = wave_ballot(islab),
                            mR = wave_ballot(isrep);
   if (lane == 0) {
-    wcnt[wave * 4 + 0] = __builtin_popcountll(mF); wcnt[wave * 4 + 1] = __builtin_popcountll(mB);
+    wcnt[wave * 4 + 0] = __builtin_popcountll(mP); wcnt[wave * 4 + 1] = __builtin_popcountll(mB);
     wcnt[wave * 4 + 2] = __builtin_popcountll(mL); wcnt[wave * 4 + 3] = __builtin_popcountll(mR);
   }
   __syncthreads();
-  int bF = 0, bB = 0, bL = 0, bR = 0, nu = 0, nb = 0, nf = 0;
+  int bP = 0, bB = 0, bL = 0, bR = 0, nu = 0, nb = 0, nf = 0;
 #pragma unroll
   for (int w = 0; w < CTC_THREADS / 64; w++) {
-    const int cF = wcnt[w * 4], cB = wcnt[w * 4 + 1], cL = wcnt[w * 4 + 2], cR = wcnt[w * 4 + 3];
+    const int cP = wcnt[w * 4], cB = wcnt[w * 4 + 1], cL = wcnt[w * 4 + 2], cR = wcnt[w * 4 + 3];
     const bool pre = w < wave;
-    bF += pre ? cF : 0; bB += pre ? cB : 0; bL += pre ? cL : 0; bR += pre ? cR : 0;
-    nu += cF; nb += cB; nf += cL;
+    bP += pre ? cP : 0; bB += pre ? cB : 0; bL += pre ? cL : 0; bR += pre ? cR : 0;
+    nu += cP; nb += cB; nf += cL;
   }
   const int nr = S - nb - nf, nup = nu | 1;
-  if (isfirst) { const int r = bF + __builtin_popcountll(mF & below); firstof[sc] = r; ucls[r] = sc; }
+  if (tid < nc) {
+    const int r = bP + __builtin_popcountll(mP & below);
+    ccol[tid] = pres ? r : -1;
+    if (pres) ucls[r] = tid;
+  }
   if (isblank) lists[bB + __builtin_popcountll(mB & below)] = tid;
   if (islab) lists[nb + bL + __builtin_popcountll(mL & below)] = tid;
   if (isrep) lists[nb + nf + bR + __builtin_popcountll(mR & below)] = tid;
   __syncthreads();
-  if (live) ucol[tid] = firstof[sc];
+  if (live) ucol[tid] = ccol[sc];
   CTC_STAMP(12);
   {
     double* tabs = reinterpret_cast<double*>(lds + L.tables);
@@ -365,12 +375,32 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   }
   CTC_STAMP(1);
 
-  // ---- B (S <= 64: waves 0 and 1; the other waves clear the class rows of phase E meanwhile)
+  // ---- B (S <= 64: waves 0 and 1).  The other waves meanwhile emit the part of the result that does not
+  //         depend on the lattice: a class without a target state has aligned = 0, delta = -p.
   ctc_lattice(lm, al, be, lds + L.vx, tb, T, S);
-  if (S > 64 || wave >= 2) {
-    const int first = S > 64 ? tid : tid - 128, step = S > 64 ? CTC_THREADS : CTC_THREADS - 128;
-    float4* r4 = reinterpret_cast<float4*>(rowbuf);   // 16-byte aligned; the tail may spill into the (dead) match table
-    for (int i = first; i < (T * ncp + 3) / 4; i += step) r4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  const BufF32 dzb = make_buf(a.Dz + (size_t)off * nc, (size_t)T * nc * 4);
+  const BufF32 agb = make_buf(a.aligned ? a.aligned + (size_t)off * nc : a.Dz, a.aligned ? (size_t)T * nc * 4 : 0);
+  if (S > 64 || (wave & 2)) {   // waves 2, 3, 6, 7: not on the SIMDs of the two lattice waves (w mod 4 = 0, 1)
+    const int w0 = S > 64 ? wave : (wave & 1) + ((wave >> 2) << 1), nw = S > 64 ? CTC_THREADS / 64 : 4;
+    for (int cb = 0; cb < nc; cb += 64) {   // one wave per frame, lanes over classes
+      const int c = cb + lane;
+      const bool absent = c < nc && ccol[c < nc ? c : 0] < 0;
+      for (int t0 = w0; t0 < T; t0 += 8 * nw) {
+        float x[8];
+        unsigned ofs[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int t = t0 + u * nw;
+          ofs[u] = (absent && t < T) ? (unsigned)(t * nc + c) * 4u : BUF_OOB;
+          x[u] = buf_load(pb, ofs[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          buf_store(agb, ofs[u], 0.0f);
+          buf_store(dzb, ofs[u], 0.0f - x[u]);   // (float)0 - p, as aligned - p with aligned = 0
+        }
+      }
+    }
   }
   __syncthreads();
   CTC_STAMP(2);
@@ -450,14 +480,16 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   __syncthreads();
   CTC_STAMP(4);
 
-  // ---- E: project states onto classes (ctc.cc:91-109).  Waves 4-7: lane = one first-occurrence label state,
-  //         looping over frames (plain stores).  Waves 0-3: lane = one frame, the blank states summed in state
-  //         order in double (class 0 collects L+1 states: the reference's double accumulator).
+  // ---- E: project states onto classes (ctc.cc:91-109), compact: one column per class that has a state.
+  //         Waves 4-7: lane = one first-occurrence label state, looping over frames (plain stores).
+  //         Waves 0-3: lane = one frame, the blank states summed in state order in double (class 0 collects
+  //         L+1 states: the reference's double accumulator).
+  float* rowc = rowbuf;   // [T][nup]
   if (wave >= 4) {
     for (int f0 = 0; f0 < nf; f0 += 64) {
       const bool fok = f0 + lane < nf;
       const int st = lists[nb + (fok ? f0 + lane : 0)];
-      const int c = stl[st];
+      const int col = ucol[st];
       for (int t0 = wave - 4; t0 < T; t0 += 4 * 8) {
         float x[8];
 #pragma unroll
@@ -465,7 +497,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           const int t = t0 + 4 * u;
-          float* w = (fok && t < T) ? &rowbuf[t * ncp + c] : dump;
+          float* w = (fok && t < T) ? &rowc[t * nup + col] : dump;
           *w = x[u];
         }
       }
@@ -487,48 +519,46 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   __syncthreads();
   CTC_STAMP(10);
   for (int t = tid; t < T; t += CTC_THREADS) {
-    float* row = rowbuf + t * ncp;
+    float* row = rowc + t * nup;
     const float* e = etile + t * sp;
     for (int i = 0; i < nr; i++) {   // few; a class may repeat more than once: read-modify-write in state order
       const int st = lists[nb + nf + i];
-      row[stl[st]] += e[st];
+      row[ucol[st]] += e[st];
     }
-    row[0] = (float)part[t];
-    double total = 0.0;   // class order, double
-    for (int c0 = 0; c0 < nc; c0 += 16) {
-      float x[16];
+    if (nb > 0) row[ccol[0]] = (float)part[t];
+    double total = 0.0;   // columns are in class order: the reference's double sum, minus its exact zeros
+    for (int u0 = 0; u0 < nu; u0 += 8) {
+      float x[8];
 #pragma unroll
-      for (int u = 0; u < 16; u++) x[u] = row[c0 + u < nc ? c0 + u : 0];
+      for (int u = 0; u < 8; u++) x[u] = row[u0 + u < nu ? u0 + u : 0];
 #pragma unroll
-      for (int u = 0; u < 16; u++) total += (c0 + u < nc) ? (double)x[u] : 0.0;
+      for (int u = 0; u < 8; u++) total += (u0 + u < nu) ? (double)x[u] : 0.0;
     }
     part[t] = 1.0 / fmax(total, 1e-9);
   }
   __syncthreads();
   CTC_STAMP(11);
-  {  // per-frame normalisation and the fused delta  d = aligned - p  (clstmhl.h:211-212); one wave per frame
-    const BufF32 dzb = make_buf(a.Dz + (size_t)off * nc, (size_t)T * nc * 4);
-    const BufF32 agb = make_buf(a.aligned ? a.aligned + (size_t)off * nc : a.Dz, a.aligned ? (size_t)T * nc * 4 : 0);
-    for (int cb = 0; cb < nc; cb += 64) {
-      const int c = cb + lane;
-      const bool cok = c < nc;
-      for (int t0 = wave; t0 < T; t0 += 8 * (CTC_THREADS / 64)) {
-        float p[8];
-        unsigned ofs[8];
+  {  // per-frame normalisation and the fused delta  d = aligned - p  (clstmhl.h:211-212) for the present classes
+    const int n = T * nu;
+    const int dq = CTC_THREADS / nu, dr = CTC_THREADS - dq * nu;   // (t, u) of item i, followed incrementally
+    int tq = tid / nu, uq = tid - tq * nu;
+    for (int i0 = tid; i0 < n; i0 += 4 * CTC_THREADS) {
+      float p[4], av[4];
+      unsigned ofs[4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int t = t0 + u * (CTC_THREADS / 64);
-          ofs[u] = (cok && t < T) ? (unsigned)(t * nc + c) * 4u : BUF_OOB;
-          p[u] = buf_load(pb, ofs[u]);
-        }
+      for (int u = 0; u < 4; u++) {
+        const bool in = i0 + u * CTC_THREADS < n;
+        const int tc = in ? tq : 0, uc = in ? uq : 0;
+        ofs[u] = in ? (unsigned)(tc * nc + ucls[uc]) * 4u : BUF_OOB;
+        p[u] = buf_load(pb, ofs[u]);
+        av[u] = (float)((double)rowc[tc * nup + uc] * part[tc]);
+        tq += dq; uq += dr;
+        if (uq >= nu) { uq -= nu; tq++; }
+      }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int t = t0 + u * (CTC_THREADS / 64);
-          const int tc = t < T ? t : T - 1;
-          const float av = (float)((double)rowbuf[tc * ncp + (cok ? c : 0)] * part[tc]);
-          buf_store(agb, ofs[u], av);
-          buf_store(dzb, ofs[u], av - p[u]);
-        }
+      for (int u = 0; u < 4; u++) {
+        buf_store(agb, ofs[u], av[u]);
+        buf_store(dzb, ofs[u], av[u] - p[u]);
       }
     }
   }
@@ -567,7 +597,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
     treg[k] = a.tables[i < CTC_TABLE_DOUBLES ? i : CTC_TABLE_DOUBLES - 1];
   }
   for (int s = tid; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
-  if (T <= TT && T * S <= CTC_THREADS * CTC_CCACHE) {   // wave-uniform: the whole workgroup takes one path
+  if (T <= TT && T * S <= CTC_THREADS * CTC_CCACHE && nc <= CTC_THREADS) {   // uniform: the whole workgroup takes one path
     __syncthreads();
     ctc_short_line(a, lds, L, tb, b, off, T, S, treg);
     return;

@@ -225,7 +225,7 @@ def test_ctc_reference_known_answers(backend):
     assert np.allclose(d2, a2 - o2, atol=1e-7)
 
 
-@pytest.mark.parametrize("T,L,nc", [(12, 3, 6), (40, 12, 30), (7, 3, 5), (100, 62, 70), (200, 70, 90)])
+@pytest.mark.parametrize("T,L,nc", [(12, 3, 6), (40, 12, 30), (7, 3, 5), (3, 1, 83), (100, 62, 70), (200, 70, 90)])
 def test_ctc_vs_oracle(backend, ora32, T, L, nc):
     # (12..40: lattice resident in LDS;  100 x 125 states and 200 x 141: the tiled path through HBM)
     if backend.kind == "emu" and T > 100:
