@@ -93,7 +93,12 @@ DEVFN float ctc_limexp(float x, const CrTables tb) {  // tensor.h:78-82
 // Phase B of both paths: alpha into `al`, the reversed-lattice alpha into `be` ([T][S] each).  The match
 // scores are prefetched from HBM two frames ahead (an LDS source was measured 100 cycles per frame slower:
 // its reads share lgkmcnt with the table reads of log_add and end up waited for right where they are issued).
-DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, const CrTables tb, const int T, const int S) {
+// LDS_OUT (S <= 64 only): `al` / `be` are LDS arrays -- the stores of a step then leave the vmcnt queue, whose
+// in-order count otherwise makes the wait for a prefetched match row also a wait for the previous stores'
+// write acknowledgements.
+template <bool LDS_OUT>
+DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, float* dump, const CrTables tb, const int T,
+                       const int S) {
   // (= forwardbackward(), ctc.cc:42-55); serial in t, parallel over the label axis
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const size_t latbytes = (size_t)T * S * 4;
@@ -103,8 +108,10 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, const C
     __syncthreads();  // lattice rows of phase A visible
     if (wave < 2) {
       const bool rev = wave == 1;
-      const BufF32 outb = make_buf(rev ? be : al, latbytes);
+      const BufF32 outb = make_buf(rev ? be : al, LDS_OUT ? 0 : latbytes);
       const int j = lane;
+      float* outl = j < S ? (rev ? be : al) + (rev ? S - 1 - j : j) : dump;   // LDS_OUT: this lane's column
+      const int outstride = j < S ? S : 0;
       // lattice cell of (step i, state j): byte offset = lane part + wave-uniform frame part;
       // masked lanes (j >= S) sit at BUF_OOB_BASE, prefetches past the end re-read the last frame
       const unsigned lanepart = j < S ? (unsigned)(rev ? S - 1 - j : j) * 4u : BUF_OOB_BASE;
@@ -126,7 +133,8 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, const C
         skipi -= 5.0f;
         lmr = buf_load_s(lmb, lanepart, frame(i + 2));  // two frames ahead
         v = ctc_log_add(same, next, tb);
-        buf_store_s(outb, lanepart, frame(i), v);
+        if (LDS_OUT) outl[(rev ? T - 1 - i : i) * outstride] = v;
+        else buf_store_s(outb, lanepart, frame(i), v);
         ka = v;
       };
       int i = 0;
@@ -377,7 +385,11 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
 
   // ---- B (S <= 64: waves 0 and 1).  The other waves meanwhile emit the part of the result that does not
   //         depend on the lattice: a class without a target state has aligned = 0, delta = -p.
-  ctc_lattice(lm, al, be, lds + L.vx, tb, T, S);
+  float* all = rowbuf;            // alpha / reversed alpha in LDS (row buffer + lattice tile are both free here)
+  float* bel = rowbuf + TS;
+  const bool lds_lat = S <= 64 && 2 * TS <= L.asum - L.rowbuf;
+  if (lds_lat) ctc_lattice<true>(lm, all, bel, lds + L.vx, dump, tb, T, S);
+  else ctc_lattice<false>(lm, al, be, lds + L.vx, dump, tb, T, S);
   const BufF32 dzb = make_buf(a.Dz + (size_t)off * nc, (size_t)T * nc * 4);
   const BufF32 agb = make_buf(a.aligned ? a.aligned + (size_t)off * nc : a.Dz, a.aligned ? (size_t)T * nc * 4 : 0);
   if (S > 64 || (wave & 2)) {   // waves 2, 3, 6, 7: not on the SIMDs of the two lattice waves (w mod 4 = 0, 1)
@@ -413,7 +425,8 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
 #pragma unroll
     for (int k = 0; k < CTC_CCACHE; k++) {
       const int i = tid + k * CTC_THREADS;
-      const float x = buf_load(alb, (unsigned)i * 4u) + buf_load(beb, (unsigned)i * 4u);
+      const int ic = i < TS ? i : 0;
+      const float x = lds_lat ? all[ic] + bel[ic] : buf_load(alb, (unsigned)i * 4u) + buf_load(beb, (unsigned)i * 4u);
       bo[k] = i < TS ? x : -3.0e38f;
       mx = fmaxf(mx, bo[k]);
     }
@@ -661,7 +674,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   CTC_STAMP(1);
 
   // ---- B: forward recursion and the same recursion on the (t,s)-reversed lattice
-  ctc_lattice(lm, al, be, vx, tb, T, S);
+  ctc_lattice<false>(lm, al, be, vx, nullptr, tb, T, S);
   __syncthreads();
   CTC_STAMP(2);
 
