@@ -214,7 +214,8 @@ constexpr int CTC_CCACHE = 24;  // lattice cells per thread kept in registers be
 // global accesses go through buffer descriptors (out-of-range = no-op).  Loops are written as a batch of
 // independent reads followed by the arithmetic, so the scheduler can interleave the elements of a batch.
 DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const CrTables tb, const int b,
-                          const int off, const int T, const int S, const double (&treg)[CTC_TREG]) {
+                          const int off, const int T, const int S, const double (&treg)[CTC_TREG],
+                          const float (&preg)[CTC_PREG], const bool flat) {
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int nc = a.nc, ncp = a.ncp;
   double* part = reinterpret_cast<double*>(lds + L.part);   // 512 doubles, reused phase by phase
@@ -236,14 +237,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   const size_t latbytes = (size_t)TS * 4;
   const BufF32 pb = make_buf(a.P + (size_t)off * nc, (size_t)T * nc * 4);
 
-  // the posteriors of the line are requested first and land in LDS after the classification
-  const int npost = T * nc;
-  const bool flat = ncp == nc && npost <= CTC_PREG * CTC_THREADS;   // rows back to back in LDS too: flat copy
-  float preg[CTC_PREG];
-  if (flat) {
-#pragma unroll
-    for (int k = 0; k < CTC_PREG; k++) preg[k] = buf_load(pb, (unsigned)(tid + k * CTC_THREADS) * 4u);   // past the end: 0
-  }
+  const int npost = T * nc;   // (flat: the posteriors were requested by the caller and land in LDS after the classification)
 
   // ---- classify the target states: blank / first state of its class / repeat; distinct classes -> columns
   int* firstof = reinterpret_cast<int*>(rowbuf);  // first state of a class; rowbuf holds >= ncp words and is free until
@@ -603,18 +597,32 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   float* al = lm + (size_t)T * S;
   float* be = al + (size_t)T * S;
   CTC_STAMP(0);
-  double treg[CTC_TREG];   // the tables travel through registers: their load latency overlaps what follows
+  // Request order = completion order (vmcnt counts in order): the target states first (needed at once), then the
+  // tables and -- short lines -- the posteriors, whose latency overlaps the state classification.
+  const bool short_line = T <= TT && T * S <= CTC_THREADS * CTC_CCACHE && nc <= CTC_THREADS;   // uniform per workgroup
+  const int st0 = a.states[soff + (tid < S ? tid : 0)];
+  double treg[CTC_TREG];
 #pragma unroll
   for (int k = 0; k < CTC_TREG; k++) {
     const int i = tid + k * CTC_THREADS;
     treg[k] = a.tables[i < CTC_TABLE_DOUBLES ? i : CTC_TABLE_DOUBLES - 1];
   }
-  for (int s = tid; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
-  if (T <= TT && T * S <= CTC_THREADS * CTC_CCACHE && nc <= CTC_THREADS) {   // uniform: the whole workgroup takes one path
+  if (short_line) {
+    const BufF32 pb = make_buf(P, (size_t)T * nc * 4);
+    const bool flat = ncp == nc && T * nc <= CTC_PREG * CTC_THREADS;   // rows back to back in LDS too: flat copy
+    float preg[CTC_PREG];
+    if (flat) {
+#pragma unroll
+      for (int k = 0; k < CTC_PREG; k++) preg[k] = buf_load(pb, (unsigned)(tid + k * CTC_THREADS) * 4u);   // past the end: 0
+    }
+    if (tid < S) stl[tid] = st0;
+    for (int s = tid + CTC_THREADS; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
     __syncthreads();
-    ctc_short_line(a, lds, L, tb, b, off, T, S, treg);
+    ctc_short_line(a, lds, L, tb, b, off, T, S, treg, preg, flat);
     return;
   }
+  if (tid < S) stl[tid] = st0;
+  for (int s = tid + CTC_THREADS; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
 #pragma unroll
   for (int k = 0; k < CTC_TREG; k++)
     if (tid + k * CTC_THREADS < CTC_TABLE_DOUBLES) tabs[tid + k * CTC_THREADS] = treg[k];
