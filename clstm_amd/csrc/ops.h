@@ -276,17 +276,24 @@ DEVFN void reduce_scatter_one(const ReduceDesc& d, size_t e, float* g) {
   const int rc = e - b * RC;
   const int r = rc / d.Cn, c = rc % d.Cn;
   const float* p = d.partial + (size_t)b * d.nsplit * RC + rc;
-  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  float s[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   int z = 0;
-  for (; z + 4 <= d.nsplit; z += 4) {   // four independent loads in flight, fixed summation order
-    s0 += p[(size_t)z * RC];
-    s1 += p[(size_t)(z + 1) * RC];
-    s2 += p[(size_t)(z + 2) * RC];
-    s3 += p[(size_t)(z + 3) * RC];
+  for (; z + 8 <= d.nsplit; z += 8) {   // eight independent loads in flight (the kernel is latency-bound), fixed order
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) x[u] = p[(size_t)(z + u) * RC];
+#pragma unroll
+    for (int u = 0; u < 8; u++) s[u] += x[u];
   }
-  for (; z < d.nsplit; z++) s0 += p[(size_t)z * RC];
+  {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) x[u] = z + u < d.nsplit ? p[(size_t)(z + u) * RC] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; u++) s[u] += x[u];
+  }
   const long long o = (d.moff ? d.moff[(size_t)b * d.Cn + c] : d.base + c) + (long long)d.rs * r;
-  g[o] = (s0 + s1) + (s2 + s3);
+  g[o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 // up to two slab sets per launch (the softmax layer's weight gradient rides with the top LSTM layer's)
 __global__ void k_reduce_scatter(ReduceDesc d0, ReduceDesc d1, float* g) {
