@@ -225,9 +225,10 @@ def test_ctc_reference_known_answers(backend):
     assert np.allclose(d2, a2 - o2, atol=1e-7)
 
 
-@pytest.mark.parametrize("T,L,nc", [(12, 3, 6), (40, 12, 30), (7, 3, 5), (3, 1, 83), (100, 62, 70), (200, 70, 90)])
+@pytest.mark.parametrize("T,L,nc", [(12, 3, 6), (40, 12, 30), (7, 3, 5), (3, 1, 83), (60, 40, 30), (100, 62, 70), (200, 70, 90)])
 def test_ctc_vs_oracle(backend, ora32, T, L, nc):
-    # (12..40: lattice resident in LDS;  100 x 125 states and 200 x 141: the tiled path through HBM)
+    # (12..40: short-line path, lattice resident in LDS; 60 x 81 states: the same with the wide recursion;
+    #  100 x 125 states and 200 x 141: the tiled path through HBM)
     if backend.kind == "emu" and T > 100:
         pytest.skip("large lattice only on the GPU")
     rng = np.random.default_rng(T)
@@ -244,6 +245,31 @@ def test_ctc_vs_oracle(backend, ora32, T, L, nc):
         want = ora32.ctc_align_classes(probs[b], states[b])
         assert_close(al[loff[b]:loff[b + 1]], want, rtol=1e-4, atol=1e-6, what="aligned line %d" % b)
         assert_close(dz[loff[b]:loff[b + 1]], want - probs[b], rtol=1e-4, atol=2e-6, what="delta line %d" % b)
+
+
+@pytest.mark.parametrize("case", ["no_blank", "one_state", "one_frame", "all_same", "many_classes"])
+def test_ctc_target_shapes(backend, ora32, case):
+    """Targets as plain class lists (the Classes overload, ctc.cc:136-146): the short-line path classifies the
+    states into blank / first of its class / repeat -- exercise each combination."""
+    rng = np.random.default_rng(len(case))
+    T, nc = 9, 7
+    if case == "no_blank":
+        st = np.array([3, 1, 4, 1, 5, 2, 6], np.int32)          # no class-0 state at all, one repeat
+    elif case == "one_state":
+        st = np.array([0], np.int32)
+    elif case == "one_frame":
+        T, st = 1, np.array([0, 2, 0], np.int32)
+    elif case == "all_same":
+        st = np.array([2, 2, 2, 2, 2], np.int32)                # four repeats of one label, no blank
+    else:
+        T, nc = 20, 600                                          # > 512 classes: the tiled path
+        st = ora32.mktargets([17, 599, 17, 300])
+    p = rng.random((T, nc)).astype(np.float32) ** 3
+    p /= p.sum(1, keepdims=True)
+    al, dz, _ = ctc_via_abi(backend, [p.astype(np.float32)], [st])
+    want = ora32.ctc_align_classes(p.astype(np.float32), st)
+    assert_close(al, want, rtol=1e-4, atol=1e-6, what="aligned " + case)
+    assert_close(dz, want - p, rtol=1e-4, atol=2e-6, what="delta " + case)
 
 
 def test_ctc_more_states_than_frames(backend, ora32):
