@@ -994,8 +994,17 @@ int clstm_net_set_inputs_d(clstm_net* h, const float* x) {
   Net& n = h->net;
   REQUIRE(n.N > 0, "set_batch first");
   Layer& y = n.L[0];
-  CLSTM_LAUNCH(k_ingest, dim3(nblocks((size_t)n.N * (1 + y.ni))), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni,
-               y.lds, n.ndir, (long long)n.N * y.lds);
+  if (n.packed_dirty && n.L.size() == 1 && !y.wide) {   // the training step: ingest + weight repack in one launch
+    const int M = n.ndir * 4 * y.no, KQP = 4 * y.nk4;
+    const size_t nr = (size_t)n.ndir * 4 * KQP * y.nthreads;
+    const int nbi = nblocks((size_t)n.N * (1 + y.ni)), nbp = nblocks((size_t)(1 + y.ni) * M + 2 * nr);
+    CLSTM_LAUNCH(k_ingest_pack, dim3(nbi + nbp), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni, y.lds, n.ndir,
+                 (long long)n.N * y.lds, nbi, (const float*)n.v, y.Wt, y.bias, y.Rf, y.Rb, y.pd);
+    n.packed_dirty = false;
+  } else {
+    CLSTM_LAUNCH(k_ingest, dim3(nblocks((size_t)n.N * (1 + y.ni))), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni,
+                 y.lds, n.ndir, (long long)n.N * y.lds);
+  }
   check_launch();
   n.src0_ready = true;
   ABI_END

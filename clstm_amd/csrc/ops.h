@@ -333,6 +333,33 @@ __global__ void k_ingest(const float* x, float* X, float* S, size_t N, int ni, i
     for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = v;
   }
 }
+// k_ingest and the first layer's k_pack_layer in ONE launch (a single narrow layer whose parameters changed since
+// the last pack -- every training step): blocks [0, nbi) ingest, the rest repack.  The two jobs are independent
+// and each is far too small to fill the chip, so one launch ramp / tail instead of two.
+__global__ void k_ingest_pack(const float* x, float* X, float* S, size_t N, int ni, int lds, int ndir, long long sdir,
+                              int nbi, const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p) {
+  if ((int)blockIdx.x < nbi) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < N * (size_t)(1 + ni); e += (size_t)nbi * blockDim.x) {
+      const size_t n = e / (1 + ni);
+      const int j = e % (1 + ni);
+      float val = 1.0f;
+      if (j > 0) {
+        val = x[n * ni + (j - 1)];
+        X[n * ni + (j - 1)] = val;
+      }
+      for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = val;
+    }
+  } else {
+    const size_t nwx = (size_t)(1 + p.ni) * p.ndir * 4 * p.no;
+    const size_t nr = (size_t)p.ndir * 4 * 4 * p.nk4 * p.nthreads;
+    const size_t nbp = gridDim.x - nbi;
+    for (size_t e = (size_t)(blockIdx.x - nbi) * blockDim.x + threadIdx.x; e < nwx + 2 * nr; e += nbp * blockDim.x) {
+      if (e < nwx) pack_wx(e, v, Wt, bias, p);
+      else if (e < nwx + nr) pack_rf(e - nwx, v, Rf, p);
+      else pack_rb(e - nwx - nr, v, Rb, p);
+    }
+  }
+}
 // constant-1 column of the output rows [1 | h] (written when the buffer grows; rows never move)
 __global__ void k_fill_col0(float* H, size_t rows, int ld, int col) {
   CLSTM_GRID_STRIDE(e, rows) H[e * ld + col] = 1.0f;
