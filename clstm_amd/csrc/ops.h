@@ -337,7 +337,12 @@ __global__ void k_ingest(const float* x, float* X, float* S, size_t N, int ni, i
 // the last pack -- every training step): blocks [0, nbi) ingest, the rest repack.  The two jobs are independent
 // and each is far too small to fill the chip, so one launch ramp / tail instead of two.
 __global__ void k_ingest_pack(const float* x, float* X, float* S, size_t N, int ni, int lds, int ndir, long long sdir,
-                              int nbi, const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p) {
+                              int nbi, int nbp, const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p,
+                              const int* lo_src, int* lo_dst, int lo_n) {
+  if ((int)blockIdx.x >= nbi + nbp) {   // optional last block: the line offsets, straight from the pinned host slot
+    for (int i = threadIdx.x; i < lo_n; i += blockDim.x) lo_dst[i] = lo_src[i];
+    return;
+  }
   if ((int)blockIdx.x < nbi) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < N * (size_t)(1 + ni); e += (size_t)nbi * blockDim.x) {
       const size_t n = e / (1 + ni);
@@ -352,8 +357,7 @@ __global__ void k_ingest_pack(const float* x, float* X, float* S, size_t N, int 
   } else {
     const size_t nwx = (size_t)(1 + p.ni) * p.ndir * 4 * p.no;
     const size_t nr = (size_t)p.ndir * 4 * 4 * p.nk4 * p.nthreads;
-    const size_t nbp = gridDim.x - nbi;
-    for (size_t e = (size_t)(blockIdx.x - nbi) * blockDim.x + threadIdx.x; e < nwx + 2 * nr; e += nbp * blockDim.x) {
+    for (size_t e = (size_t)(blockIdx.x - nbi) * blockDim.x + threadIdx.x; e < nwx + 2 * nr; e += (size_t)nbp * blockDim.x) {
       if (e < nwx) pack_wx(e, v, Wt, bias, p);
       else if (e < nwx + nr) pack_rf(e - nwx, v, Rf, p);
       else pack_rb(e - nwx - nr, v, Rb, p);
