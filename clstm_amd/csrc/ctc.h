@@ -71,7 +71,7 @@ inline __host__ __device__ CtcLds ctc_lds_layout(int tile, int ncp, int smax) {
   l.lists = o;  o += smax;   // short-line path: [blank states | first label states | repeats]
   l.ucol = o;   o += smax;   //   column of a state in the table of distinct classes
   l.ucls = o;   o += smax;   //   class of a column
-  l.ccol = o;   o += ncp;    //   column of a class (-1: no state of that class)
+  l.ccol = o;   o += ncp <= CTC_THREADS + 1 ? ncp : 0;   //   column of a class (-1: none); short-line path only (<= 512 classes)
   l.vx = o;     o += 2 * 2 * (CTC_GROUP + 2);
   l.red = o;    o += 64;
   l.dump = o;   o += 2;      // target of masked-off LDS stores (branch-free guards)

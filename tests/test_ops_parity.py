@@ -247,7 +247,7 @@ def test_ctc_vs_oracle(backend, ora32, T, L, nc):
         assert_close(dz[loff[b]:loff[b + 1]], want - probs[b], rtol=1e-4, atol=2e-6, what="delta line %d" % b)
 
 
-@pytest.mark.parametrize("case", ["no_blank", "one_state", "one_frame", "all_same", "many_classes"])
+@pytest.mark.parametrize("case", ["no_blank", "one_state", "one_frame", "all_same", "many_classes", "huge_classes"])
 def test_ctc_target_shapes(backend, ora32, case):
     """Targets as plain class lists (the Classes overload, ctc.cc:136-146): the short-line path classifies the
     states into blank / first of its class / repeat -- exercise each combination."""
@@ -261,9 +261,12 @@ def test_ctc_target_shapes(backend, ora32, case):
         T, st = 1, np.array([0, 2, 0], np.int32)
     elif case == "all_same":
         st = np.array([2, 2, 2, 2, 2], np.int32)                # four repeats of one label, no blank
-    else:
+    elif case == "many_classes":
         T, nc = 20, 600                                          # > 512 classes: the tiled path
         st = ora32.mktargets([17, 599, 17, 300])
+    else:
+        T, nc = 4, 25000                                         # one frame of posteriors per LDS tile
+        st = ora32.mktargets([7, 24999])
     p = rng.random((T, nc)).astype(np.float32) ** 3
     p /= p.sum(1, keepdims=True)
     al, dz, _ = ctc_via_abi(backend, [p.astype(np.float32)], [st])
