@@ -447,7 +447,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   __syncthreads();
   CTC_STAMP(3);
 
-  // ---- D: per-state totals over time (double accumulator, floor 1e-9) and the normalisation in place;
+  // ---- D: per-state totals over time (double accumulator, floor 1e-9) -> tot[s] = 1/total;
   //         x/total is (float)((double)x * (1/total)), see the note at phase D of the tiled path
   {
     const int Q = CTC_THREADS / S > 8 ? 8 : CTC_THREADS / S;   // time chunks per state
@@ -471,20 +471,8 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
     }
     __syncthreads();
     CTC_STAMP(9);
-    const double it = tot[st];
-    for (int t0 = act ? q : T; t0 < T; t0 += 8 * Q) {
-      float x[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) { const int t = t0 + u * Q; x[u] = etile[(t < T ? t : T - 1) * sp + st]; }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int t = t0 + u * Q;
-        float* w = (act && t < T) ? &etile[t * sp + st] : dump;
-        *w = (float)((double)x[u] * it);
-      }
-    }
+    // (the normalisation itself is applied where phase E consumes the cells: one LDS pass less)
   }
-  __syncthreads();
   CTC_STAMP(4);
 
   // ---- E: project states onto classes (ctc.cc:91-109), compact: one column per class that has a state.
@@ -497,6 +485,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
       const bool fok = f0 + lane < nf;
       const int st = lists[nb + (fok ? f0 + lane : 0)];
       const int col = ucol[st];
+      const double it = tot[st];   // per-state normalisation (phase D), applied on the fly
       for (int t0 = wave - 4; t0 < T; t0 += 4 * 8) {
         float x[8];
 #pragma unroll
@@ -505,7 +494,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
         for (int u = 0; u < 8; u++) {
           const int t = t0 + 4 * u;
           float* w = (fok && t < T) ? &rowc[t * nup + col] : dump;
-          *w = x[u];
+          *w = (float)((double)x[u] * it);
         }
       }
     }
@@ -515,10 +504,15 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
       double blank = 0.0;
       for (int i0 = 0; i0 < nb; i0 += 8) {
         float x[8];
+        double it[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) x[u] = e[lists[i0 + u < nb ? i0 + u : 0]];
+        for (int u = 0; u < 8; u++) {
+          const int st = lists[i0 + u < nb ? i0 + u : 0];
+          x[u] = e[st];
+          it[u] = tot[st];
+        }
 #pragma unroll
-        for (int u = 0; u < 8; u++) blank += (i0 + u < nb) ? (double)x[u] : 0.0;
+        for (int u = 0; u < 8; u++) blank += (i0 + u < nb) ? (double)(float)((double)x[u] * it[u]) : 0.0;
       }
       part[t] = blank;
     }
@@ -530,7 +524,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
     const float* e = etile + t * sp;
     for (int i = 0; i < nr; i++) {   // few; a class may repeat more than once: read-modify-write in state order
       const int st = lists[nb + nf + i];
-      row[ucol[st]] += e[st];
+      row[ucol[st]] += (float)((double)e[st] * tot[st]);
     }
     if (nb > 0) row[ccol[0]] = (float)part[t];
     double total = 0.0;   // columns are in class order: the reference's double sum, minus its exact zeros
