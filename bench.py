@@ -181,7 +181,7 @@ def main():
             frames += sum(pool[i % len(pool)][0])
         torch.cuda.synchronize()
         for name in ("gemm_gates_x", "lstm_fwd", "gemm_softmax", "softmax_norm", "ctc_align",
-                     "gemm_softmax_dx", "gemm_softmax_dw", "lstm_bwd", "gemm_gates_dw", "gemm_gates_dx",
+                     "gemm_softmax_dw_dx", "gemm_softmax_dx", "gemm_softmax_dw", "lstm_bwd", "gemm_gates_dw", "gemm_gates_dx",
                      "sgd_update"):
             ms, n = net.kernel_time_ms(name)
             if n:

@@ -40,11 +40,11 @@ struct GemmOperand {
   long long bstride;  // floats between batch entries (0: shared by all batch entries)
 };
 
+// one workgroup of the GEMM: `lin` is its linear index in a (gx, gy, gz) grid
 template <int AMODE, int BMODE, class FE>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
-                                                       int K, int ksplit, int nsplit) {
-  // operand tiles during the k loop; the 64 x 64 output tile (row stride 68) during the epilogue
-  __shared__ __attribute__((aligned(16))) float smem[GEMM_BT * GEMM_LDO];
+DEVFN void gemm_f32_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int ksplit, int nsplit,
+                         const unsigned lin, const unsigned gx, const unsigned gy, const unsigned gz) {
+  // smem: operand tiles during the k loop; the 64 x 64 output tile (row stride 68) during the epilogue
   float* As = smem;
   float* Bs = smem + GEMM_BK * GEMM_LD;
   const int tid = threadIdx.x;
@@ -57,9 +57,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperan
   // Bijective for any grid size: XCD x owns q + (x < r) tiles.
   int bx, by, z;
   {
-    const unsigned gx = gridDim.x, gy = gridDim.y;
-    const unsigned total = gx * gy * gridDim.z;
-    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned total = gx * gy * gz;
     const unsigned xcd = lin & 7u, idx = lin >> 3;
     const unsigned q = total >> 3, r = total & 7u;
     const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -198,6 +196,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperan
       }
 }
 
+template <int AMODE, int BMODE, class FE>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
+                                                       int K, int ksplit, int nsplit) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_BT * GEMM_LDO];
+  gemm_f32_body<AMODE, BMODE, FE>(smem, A, B, fe, R, Cn, K, ksplit, nsplit,
+                                  blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y,
+                                  gridDim.z);
+}
+// Two INDEPENDENT small GEMMs in one launch (1-D grid: the first nb1 workgroups run the first problem): each is
+// far from filling the chip and mostly prologue / epilogue latency, so their workgroups interleave on the CUs
+// instead of running back to back (the softmax layer's x.d and W.d products, both reading z.d).
+struct GemmProblem {
+  GemmOperand A, B;
+  int R, Cn, K, ksplit, nsplit;
+  unsigned gx, gy, gz;
+};
+template <int A1, int B1, class FE1, int A2, int B2, class FE2>
+__global__ __launch_bounds__(256) void gemm_f32_pair_kernel(GemmProblem p1, FE1 fe1, GemmProblem p2, FE2 fe2, unsigned nb1) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_BT * GEMM_LDO];
+  if (blockIdx.x < nb1)
+    gemm_f32_body<A1, B1, FE1>(smem, p1.A, p1.B, fe1, p1.R, p1.Cn, p1.K, p1.ksplit, p1.nsplit, blockIdx.x, p1.gx, p1.gy, p1.gz);
+  else
+    gemm_f32_body<A2, B2, FE2>(smem, p2.A, p2.B, fe2, p2.R, p2.Cn, p2.K, p2.ksplit, p2.nsplit, blockIdx.x - nb1, p2.gx, p2.gy,
+                               p2.gz);
+}
+
 // Operand constructors.  `slack` floats after the array may be read (and are multiplied into outputs
 // that are never stored): library-owned buffers are over-allocated, so 3 is always safe for them.
 inline GemmOperand gemm_kc(const float* p, int ld, long long rows, int slack = 3) {
@@ -213,6 +237,20 @@ inline GemmOperand gemm_batched(GemmOperand o, long long bstride, int nbatch) {
   return o;
 }
 
+inline GemmProblem gemm_problem(GemmOperand A, GemmOperand B, int R, int Cn, int K, int nsplit = 1, int nbatch = 1) {
+  if (nsplit < 1) nsplit = 1;
+  int ksplit = (K + nsplit - 1) / nsplit;
+  const int kq = nsplit > 1 ? GEMM_PF * GEMM_BK : GEMM_BK;
+  ksplit = ((ksplit + kq - 1) / kq) * kq;
+  if (ksplit < kq) ksplit = kq;
+  return GemmProblem{A, B, R, Cn, K, ksplit, nsplit, (unsigned)((Cn + GEMM_BT - 1) / GEMM_BT),
+                     (unsigned)((R + GEMM_BT - 1) / GEMM_BT), (unsigned)(nsplit * nbatch)};
+}
+template <int A1, int B1, class FE1, int A2, int B2, class FE2>
+inline void gemm_f32_pair(hipStream_t stream, GemmProblem p1, FE1 fe1, GemmProblem p2, FE2 fe2) {
+  const unsigned nb1 = p1.gx * p1.gy * p1.gz, nb2 = p2.gx * p2.gy * p2.gz;
+  CLSTM_LAUNCH((gemm_f32_pair_kernel<A1, B1, FE1, A2, B2, FE2>), dim3(nb1 + nb2), dim3(256), 0, stream, p1, fe1, p2, fe2, nb1);
+}
 template <int AMODE, int BMODE, class FE>
 inline void gemm_f32(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int nsplit = 1,
                      int nbatch = 1) {
