@@ -160,6 +160,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_enqueued = time.perf_counter() - t0   # host time to enqueue all steps (diagnostic: is the loop host-bound?)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -236,6 +237,7 @@ def main():
                        "minibatch_per_gpu": args.minibatch, "global_minibatch": args.minibatch * world,
                        "parallelism": "dp%d" % world},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+            "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 4),   # host-side cost of issuing a step
         }
         print(json.dumps(out))
     if dist is not None:
