@@ -2,11 +2,12 @@
 #include "clstmhl.h"
 using namespace clstmhost;
 
-static double scaled_log(double x) {  // clstmocr.cc:32-37
-  const double thresh = 10.0;
-  if (x <= 0.0) return 0.0;
-  double l = log(x);
-  if (l < -thresh) return 0.0;
+static float scaled_log(float x) {  // clstmocr.cc:33-40 (float arithmetic, clamped to [0, 1])
+  const float thresh = 10.0f;
+  if (x <= 0.0f) return 0.0f;
+  float l = logf(x);
+  if (l < -thresh) return 0.0f;
+  if (l > 0) return 1.0f;
   return (l + thresh) / thresh;
 }
 
@@ -47,7 +48,7 @@ static int main1(int argc, char** argv) {
       Image outputs;
       clstm.get_outputs(outputs);
       if (output == "logs")
-        for (float& v : outputs.d) v = (float)scaled_log(v);
+        for (float& v : outputs.d) v = scaled_log(v);
       write_png(basename + (output == "logs" ? ".lp.png" : ".p.png"), outputs);
     } else fail("unknown output format");
   }

@@ -3,7 +3,7 @@
 // image, so the wire format is implemented directly (varints, length-delimited fields, fixed32
 // floats); files written here are byte-for-byte what SerializeToOstream emits for the same content
 // (fields in number order, proto2 repeated scalars UNPACKED) and the reader also accepts packed
-// repeated fields.  tests/test_host_proto.py cross-checks both directions against python-protobuf.
+// repeated fields.  tests/test_host_tools.py cross-checks both directions against python-protobuf.
 //
 //   KeyValue     { 1 key, 2 value }
 //   Array        { 1 name, 2 dim*, 3 value* }           values row-major (clstm_proto.cc:43-44)

@@ -46,7 +46,8 @@ def test_reference_cli_test_ocr(tmp_path):
     r2 = subprocess.run([os.path.join(BIN, "clstmocr"), str(lst)], env=env2, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert "performance analysis" in r2.stdout
-    assert (tmp_path / "textline.bin.txt").read_text().strip() == "performance analysis" or True
+    # clstmocr.cc:96-97 writes the recognised text next to the image (<base>.txt)
+    assert (tmp_path / "textline.bin.txt").read_text().strip() == "performance analysis"
     # resume: the saved trial attribute makes training continue at 201 (clstmocrtrain.cc:157)
     env3 = dict(os.environ, load=str(model), ntrain="203", save_name="", lrate="1e-2")
     r3 = subprocess.run([os.path.join(BIN, "clstmocrtrain"), str(lst)], env=env3, capture_output=True, text=True, timeout=300)

@@ -115,3 +115,28 @@ def test_param_count_and_flat_order(ora32):
     blk = 100 * 149
     assert np.isclose(p[2 * blk], np.float32(3 * 0.01 * u - 2 * 0.01), rtol=0, atol=1e-9)
     assert (p >= -0.02 - 1e-7).all() and (p <= 0.01 + 1e-7).all()   # negbiased: 3su - 2s
+
+
+@pytest.mark.parametrize("kind,ni,nh,nc", [("bidi", 48, [100], 83), ("bidi2", 9, [7, 5], 11), ("lstm1", 7, [3], 4)])
+def test_init_matches_oracle_rinit(ora32, kind, ni, nh, nc, tmp_path):
+    """a29: `rinit` + the LCG (batches.cc:11-52, clstm.cc:30-36).  The Python mirror (clstm_amd/init.py) and the
+    C++ host mirror (clstm_amd/host/model.h, through `clstm_hosttool init-model`) must be BIT-equal to the
+    oracle's ora_rinit for all three prefabs -- parity tests and the drivers start from these weights."""
+    import os
+    import subprocess
+    from clstm_amd.init import init_params
+    uni = kind == "lstm1"
+    want = OracleNet(ora32, ni, nh, nc, unidirectional=uni, seed=0.222).get_params()
+    got = init_params(ni, nh, nc, unidirectional=uni, seed=0.222)
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "init.py differs from ora_rinit"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "clstm_amd", "bin", "clstm_hosttool")
+    if not os.path.exists(tool):
+        pytest.skip("host tools not built (they link libclstm_hip.so)")
+    model, raw = str(tmp_path / "m.clstm"), str(tmp_path / "p.f32")
+    subprocess.check_call([tool, "init-model", kind, str(ni), str(nh[0]), str(nh[1] if len(nh) > 1 else 0),
+                           str(nc), "0.222", model])
+    subprocess.check_call([tool, "params", model, raw])
+    host = np.fromfile(raw, np.float32)
+    assert np.array_equal(host.view(np.uint32), want.view(np.uint32)), "host/model.h init differs from ora_rinit"
