@@ -3,8 +3,10 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N>1 is launched as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-  one rank per GPU; ranks shard the minibatch (independent lines, no data-path collective) and
-  all-reduce the 135,883-float gradient buffer over RCCL before the identical update (weak scaling:
+  (or as a plain `python bench.py --gpus N`: without WORLD_SIZE in the environment the script re-executes
+  itself through torch.distributed.run); one rank per GPU; ranks shard the minibatch (independent lines,
+  no data-path collective) and all-reduce the 135,883-float gradient buffer over RCCL -- inside the
+  library, on its own stream (clstm_allreduce_flat) -- before the identical update (weak scaling:
   64 lines per GPU).  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[2]/[3]): uw3-500 OCR shape -- BiLSTM(100) on 48-px lines,
@@ -78,8 +80,8 @@ def cpu_baseline(params, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--minibatch", type=int, default=64, help="lines per GPU")
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="b1")
@@ -99,11 +101,32 @@ def main():
     if args.config != "b1":
         args.no_cpu_baseline = True     # the bounded CPU sample is defined for the headline workload only
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # invoked like the single-GPU command: become the launcher -- one rank per GPU through torch.distributed.run
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    # ONE JSON line on stdout, nothing else: RCCL prints a version banner on the process's stdout, so fd 1 is pointed
+    # at stderr for the whole run and the result goes to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d (launch with torch.distributed.run --nproc-per-node %d, "
+                 "or without WORLD_SIZE and let bench.py spawn the ranks)" % (world, args.gpus, args.gpus))
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):   # BENCH_FORCE_DIST=1: exercise the RCCL path on one GPU
@@ -115,7 +138,7 @@ def main():
 
     from clstm_amd import abi
     from clstm_amd.init import init_params
-    from clstm_amd.net import Network
+    from clstm_amd.net import Comm, Network
     from clstm_amd.parallel import Trainer
 
     lib = abi.load()   # raises if the HIP extension is missing -- there is no fallback path
@@ -135,18 +158,39 @@ def main():
     net.setLearningRate(1e-4, 0.9)
     if args.bf16_gemm:
         net.set_gemm_precision(1)
-    trainer = Trainer(net, grads_tensor=grads)
+    # gradient exchange: the library's own RCCL communicator (all-reduce enqueued on the library stream right
+    # before the update kernel, no cross-stream events); torch.distributed only carries the 128-byte id, the
+    # barriers and the max-over-ranks of the timing.  If the communicator cannot be created the step falls back to
+    # torch.distributed.all_reduce on the gradient tensor and the JSON line says so.
+    allreduce_impl = None
+    comm = None
+    if dist is not None:
+        def exchange(ident):
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        try:
+            comm = Comm(rank, world, exchange, lib=lib)
+            allreduce_impl = "clstm_allreduce_flat (RCCL ncclAllReduce on the library stream)"
+        except Exception as e:     # noqa: BLE001 -- report and fall back, never silently
+            sys.stderr.write("bench.py: library communicator unavailable (%s); falling back to torch.distributed\n" % e)
+            allreduce_impl = "torch.distributed.all_reduce (fallback: %s)" % type(e).__name__
+    trainer = Trainer(net, grads_tensor=grads if comm is None else None, comm=comm)
 
     # synthetic minibatches resident in HBM before the timed region (a small rotating pool)
     rng = np.random.default_rng(1000 + rank)
     pool = []
     for _ in range(4):
         Ts, x, labels = synth_batch(rng, args.minibatch, args.T, args.ragged)
-        pool.append((Ts, torch.from_numpy(x).to(dev), labels))
+        pool.append((Ts, torch.from_numpy(x).to(dev), labels, Network.prepare_step(Ts, labels)))
+    one_call = trainer.dist is None     # single GPU or library communicator: clstm_net_train_step
 
     def step(i):
-        Ts, xd, labels = pool[i % len(pool)]
-        trainer.step_device(Ts, xd, labels)
+        Ts, xd, labels, prep = pool[i % len(pool)]
+        if one_call:
+            net.train_step_prepared(prep, xd)     # CLSTMOCR::train for the minibatch: one C-ABI call, no host sync
+        else:
+            trainer.step_device(Ts, xd, labels)
 
     def fence():
         torch.cuda.synchronize()
@@ -160,7 +204,6 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    t_enqueued = time.perf_counter() - t0   # host time to enqueue all steps (diagnostic: is the loop host-bound?)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -169,6 +212,13 @@ def main():
         dt = float(tt.item())
     lines_total = args.minibatch * world * args.steps
     value = lines_total / dt
+    # host-side cost of issuing a step (diagnostic: is the loop host-bound?): a short burst on an idle stream, few
+    # enough steps that the library's 8-slot pinned staging ring never makes the host wait for the GPU
+    t1 = time.perf_counter()
+    for i in range(4):
+        step(i)
+    t_enqueue = (time.perf_counter() - t1) / 4
+    fence()
 
     # per-kernel device time (HIP events on the library's stream) for the roofline object
     kern = {}
@@ -183,18 +233,22 @@ def main():
         torch.cuda.synchronize()
         for name in ("gemm_gates_x", "lstm_fwd", "gemm_softmax", "softmax_norm", "ctc_align",
                      "gemm_softmax_dw_dx", "gemm_softmax_dx", "gemm_softmax_dw", "lstm_bwd", "gemm_gates_dw", "gemm_gates_dx",
-                     "sgd_update"):
+                     "allreduce_grads", "sgd_update"):
             ms, n = net.kernel_time_ms(name)
             if n:
                 kern[name] = {"ms_per_step": round(ms / args.profile_steps, 4), "launches_per_step": n / args.profile_steps}
         net.enable_timing(False)
         dom = max(("lstm_fwd", "lstm_bwd"), key=lambda k: kern.get(k, {"ms_per_step": 0})["ms_per_step"])
-        traffic = None
-        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload only)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01.json")))
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per launch from the newest committed rocprofv3 PMC passes (same workload only)
+            import glob
+            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*.json")))[-1]
+            pmc = json.load(open(pmc_file))
             if (pmc["workload"]["minibatch_per_gpu"] == args.minibatch and pmc["workload"]["T"] == args.T
                     and not args.ragged and dom in pmc["kernels"]):
                 traffic = pmc["kernels"][dom]["hbm_bytes"]
+                traffic_src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                               "committed -- not re-measured inside this run" % os.path.basename(pmc_file))
         except Exception:
             traffic = None
         if dom in kern:
@@ -206,6 +260,7 @@ def main():
             ach = byts / sec / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "traffic_source": traffic_src,
                         "algorithmic_bytes": int(byts / nl),
                         "avg_launch_ms": round(sec / nl * 1e3, 4),
                         "note": "latency-bound recurrence (%s); recurrent matmul rate %.2f TFLOP/s of %.1f f32 peak" %
@@ -237,9 +292,13 @@ def main():
                        "minibatch_per_gpu": args.minibatch, "global_minibatch": args.minibatch * world,
                        "parallelism": "dp%d" % world},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
-            "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 4),   # host-side cost of issuing a step
+            "host_enqueue_ms_per_step": round(t_enqueue * 1e3, 4),   # host-side cost of issuing a step
+            "allreduce": allreduce_impl,
         }
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if comm is not None:
+        net.set_comm(None)
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

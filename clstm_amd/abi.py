@@ -90,12 +90,23 @@ _SIGS = {
     "clstm_net_enable_timing": [_P, _I],
     "clstm_net_kernel_time_ms": [_P, C.c_char_p, _P, _P],
     "clstm_net_reset_timing": [_P],
+    "clstm_net_train_step": [_P, _P, _I, _P, _P, _P],
+    "clstm_net_n_states": [_P, _P],
+    "clstm_net_get_states_h": [_P, _P, C.c_longlong],
+    "clstm_net_set_states_h": [_P, _P, C.c_longlong],
+    "clstm_comm_unique_id": [_P],
+    "clstm_comm_create": [_P, _P, _I, _I],
+    "clstm_comm_destroy": [_P],
+    "clstm_comm_rank": [_P],
+    "clstm_comm_size": [_P],
+    "clstm_allreduce_flat": [_P, _P, C.c_longlong],
+    "clstm_net_set_comm": [_P, _P],
     "clstm_debug_lane_ops": [_P],
     "clstm_debug_ctc_cycles": [_P],
     "clstm_debug_gemm": [_I, _P, _P, _P, _I, _I, _I, _I],
 }
 # functions whose int return value is a result, not a status
-_VALUE_RETURN = {"clstm_net_nparams_for", "clstm_net_nparams", "clstm_abi_version"}
+_VALUE_RETURN = {"clstm_net_nparams_for", "clstm_net_nparams", "clstm_abi_version", "clstm_comm_rank", "clstm_comm_size"}
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["clstm_last_error", "clstm_abi_version"])
 
 

@@ -69,6 +69,11 @@ static inline int nblocks(size_t n, int bs = 256) {
 }
 static void check_launch() { HIPCHECK(hipGetLastError()); }
 
+// zero-fill ordered before everything that follows on ANY stream (see DevBuf::reserve)
+static void zero_fill(void* p, size_t bytes) {
+  HIPCHECK(hipMemsetAsync(p, 0, bytes, g_stream));
+  HIPCHECK(hipStreamSynchronize(g_stream));
+}
 template <class T>
 struct DevBuf {  // grow-only device buffer
   T* p = nullptr;
@@ -79,7 +84,11 @@ struct DevBuf {  // grow-only device buffer
     p = nullptr;
     size_t want = n + n / 4 + 64;
     HIPCHECK(hipMalloc((void**)&p, want * sizeof(T)));
-    HIPCHECK(hipMemset(p, 0, want * sizeof(T)));
+    // zero-fill on the library stream and wait for it: whatever initialises parts of the fresh buffer next --
+    // kernels on this stream (k_fill_col0 ...) or a blocking null-stream copy (the CTC tables) -- is then ordered
+    // behind the fill without relying on how a null-stream hipMemset synchronises with a non-blocking stream.
+    // Buffers only grow, so this drain happens a handful of times per process (hipFree drains the device anyway).
+    zero_fill(p, want * sizeof(T));
     cap = want;
   }
   void release() {
@@ -358,6 +367,58 @@ struct Timing {
 };
 #endif
 
+
+// ---- RCCL communicator (data-parallel gradient exchange) ----------------------------------------------
+// librccl.so.1 is bound at first use (dlopen): the library loads and runs single-GPU on a box without RCCL,
+// and inside a PyTorch process the already-loaded RCCL/HIP runtime pair is reused (same SONAMEs).
+#ifndef CLSTM_HIP_EMU
+}  // namespace clstm
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace clstm {
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  static RcclApi& get() {
+    static RcclApi api = [] {
+      RcclApi a;
+      void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) throw Error(std::string("cannot load librccl.so.1: ") + dlerror());
+      auto sym = [&](const char* n) { void* f = dlsym(h, n); if (!f) throw Error(std::string("librccl: missing symbol ") + n); return f; };
+      a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+      a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+      a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+      a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
+      a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+      return a;
+    }();
+    return api;
+  }
+};
+#define RCCLCHECK(expr)                                                                         \
+  do {                                                                                          \
+    ncclResult_t r_ = (expr);                                                                   \
+    if (r_ != ncclSuccess) throw Error(std::string(#expr) + " failed: " + RcclApi::get().GetErrorString(r_)); \
+  } while (0)
+struct Comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  void allreduce(float* buf, long long n, hipStream_t s) {
+    RCCLCHECK(RcclApi::get().AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, comm, s));
+  }
+  ~Comm() { if (comm) (void)RcclApi::get().CommDestroy(comm); }
+};
+#else
+struct Comm {   // emulator: a single rank only (the world-size-2 CPU tests exchange through gloo in Python)
+  int rank = 0, nranks = 1;
+  void allreduce(float*, long long, hipStream_t) {}
+};
+#endif
+
 struct Layer {
   int ni, no, nk4, nthreads;
   bool wide = false;          // lock-step recurrence (lstm_wide.h) instead of the register-resident one
@@ -414,6 +475,7 @@ struct Net {
   DevBuf<float> dec_val, lat;
   DevBuf<long long> lat_off;
   Timing timing;
+  Comm* comm = nullptr;         // data-parallel ranks: all-reduce of g before the update (not owned)
 
   hipStream_t stream() const { return g_stream; }
 
@@ -455,7 +517,7 @@ struct Net {
       if (given) { dst = given; flag = false; }
       else {
         HIPCHECK(hipMalloc((void**)&dst, (size_t)nparams * sizeof(float)));
-        HIPCHECK(hipMemset(dst, 0, (size_t)nparams * sizeof(float)));
+        zero_fill(dst, (size_t)nparams * sizeof(float));
         flag = true;
       }
     };
@@ -463,7 +525,7 @@ struct Net {
     for (auto& y : L) {
       const int M = ndir * 4 * y.no, KQP = 4 * y.nk4;
       HIPCHECK(hipMalloc((void**)&y.Wt, ((size_t)y.ni * M + y.wt_slack) * sizeof(float)));
-      HIPCHECK(hipMemset(y.Wt, 0, ((size_t)y.ni * M + y.wt_slack) * sizeof(float)));
+      zero_fill(y.Wt, ((size_t)y.ni * M + y.wt_slack) * sizeof(float));
       HIPCHECK(hipMalloc((void**)&y.bias, (size_t)M * sizeof(float)));
       if (y.wide) {
         y.kpf = wide_kp_fwd(y.no); y.kpb = wide_kp_bwd(y.no);
@@ -716,6 +778,11 @@ struct Net {
 
   void update() {
     hipStream_t s = stream();
+    if (comm) {   // sum of the ranks' fresh minibatch gradients, in place, on this stream (share_deltas, clstm.cc:731-744)
+      timing.begin("allreduce_grads", s);
+      comm->allreduce(g, nparams, s);
+      timing.end(s);
+    }
     timing.begin("sgd_update", s);
     CLSTM_LAUNCH(k_update, dim3(nblocks(nparams)), dim3(256), 0, s, v, d, (const float*)g, (size_t)nparams, lr, mom, gclip);
     timing.end(s);
@@ -1001,8 +1068,7 @@ int clstm_net_set_inputs_h(clstm_net* h, const float* x) {
   h->net.src0_ready = false;
   ABI_END
 }
-int clstm_net_set_inputs_d(clstm_net* h, const float* x) {
-  ABI_BEGIN
+static void net_set_inputs_d(clstm_net* h, const float* x) {
   Net& n = h->net;
   REQUIRE(n.N > 0, "set_batch first");
   Layer& y = n.L[0];
@@ -1022,6 +1088,10 @@ int clstm_net_set_inputs_d(clstm_net* h, const float* x) {
   }
   check_launch();
   n.src0_ready = true;
+}
+int clstm_net_set_inputs_d(clstm_net* h, const float* x) {
+  ABI_BEGIN
+  net_set_inputs_d(h, x);
   ABI_END
 }
 int clstm_net_forward(clstm_net* h) { ABI_BEGIN h->net.forward(); ABI_END }
@@ -1032,8 +1102,7 @@ int clstm_net_outputs(clstm_net* h, float** p, float** d) {
 }
 int clstm_net_get_outputs_h(clstm_net* h, float* p) { ABI_BEGIN copy_d2h(p, h->net.Z.p, (size_t)h->net.N * h->net.desc.nclasses); ABI_END }
 int clstm_net_set_output_deltas_h(clstm_net* h, const float* p) { ABI_BEGIN copy_h2d(h->net.Dz.p, p, (size_t)h->net.N * h->net.desc.nclasses); ABI_END }
-int clstm_net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* aligned_h) {
-  ABI_BEGIN
+static void net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* aligned_h) {
   Net& n = h->net;
   REQUIRE(n.N > 0, "set_batch first");
   std::vector<int> soff(n.bs + 1, 0), states;
@@ -1053,6 +1122,10 @@ int clstm_net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* alig
   run_ctc(h->ctc, n.Z.p, n.Dz.p, al, n.desc.nclasses, n.line_off_h.data(), states.data(), soff.data(), n.bs, g_stream);
   n.timing.end(g_stream);
   if (aligned_h) copy_d2h(aligned_h, al, (size_t)n.N * n.desc.nclasses);
+}
+int clstm_net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* aligned_h) {
+  ABI_BEGIN
+  net_ctc(h, labels_h, L_h, aligned_h);
   ABI_END
 }
 int clstm_net_backward(clstm_net* h) { ABI_BEGIN h->net.backward(); ABI_END }
@@ -1104,6 +1177,218 @@ int clstm_net_kernel_time_ms(clstm_net* h, const char* name, double* total_ms, i
   ABI_END
 }
 int clstm_net_reset_timing(clstm_net* h) { ABI_BEGIN h->net.timing.collect(g_stream); h->net.timing.acc.clear(); ABI_END }
+
+// ---- one-call training step ---------------------------------------------------------------------------
+int clstm_net_train_step(clstm_net* h, const int* T_h, int bs, const float* x_d, const int* labels_h, const int* L_h) {
+  ABI_BEGIN
+  REQUIRE(h && T_h && x_d && labels_h && L_h, "null argument");
+  h->net.set_batch(T_h, bs);
+  net_set_inputs_d(h, x_d);
+  h->net.forward();
+  net_ctc(h, labels_h, L_h, nullptr);
+  h->net.backward();
+  h->net.update();   // all-reduces the fresh gradient first when a communicator is attached
+  ABI_END
+}
+
+// ---- state externalisation (clstm.cc:762-811) -----------------------------------------------------------
+namespace clstm {
+// One entry per Sequence that walk_states(net, f, "", true) visits (clstm.cc:63-70): every node's inputs and
+// outputs, then its registered states in std::map order (NPLSTM: ci, gf, gi, go, source, state --
+// ENROLL(gi, gf, go, ci, state, source), clstm.cc:560), then its subs in order.
+struct StateEntry {
+  enum Kind { X, Z, LIN, HBOTH, HDIR, GATE, CELL, SOURCE } kind;
+  int layer, dir, slot, rows;
+  bool rev;   // stored in the time order of the NPLSTM inside Reversed (frame T-1-t at step t)
+};
+static std::vector<StateEntry> state_walk(const Net& n) {
+  std::vector<StateEntry> w;
+  const int nl = (int)n.L.size();
+  auto lin_rows = [&](int l) { return l == 0 ? n.desc.ninput : n.ndir * n.L[l - 1].no; };
+  auto nplstm = [&](int l, int dir, bool rev) {
+    const int no = n.L[l].no;
+    w.push_back({StateEntry::LIN, l, dir, 0, lin_rows(l), rev});            // inputs
+    w.push_back({StateEntry::HDIR, l, dir, 0, no, rev});                    // outputs
+    w.push_back({StateEntry::GATE, l, dir, 3, no, rev});                    // ci
+    w.push_back({StateEntry::GATE, l, dir, 1, no, rev});                    // gf
+    w.push_back({StateEntry::GATE, l, dir, 0, no, rev});                    // gi
+    w.push_back({StateEntry::GATE, l, dir, 2, no, rev});                    // go
+    w.push_back({StateEntry::SOURCE, l, dir, 0, lin_rows(l) + no, rev});    // source = [x_t ; h_{t-1}]
+    w.push_back({StateEntry::CELL, l, dir, 0, no, rev});                    // state
+  };
+  w.push_back({StateEntry::X, 0, 0, 0, n.desc.ninput, false});              // Stacked.inputs
+  w.push_back({StateEntry::Z, 0, 0, 0, n.desc.nclasses, false});            // Stacked.outputs
+  for (int l = 0; l < nl; l++) {
+    if (n.ndir == 2) {
+      w.push_back({StateEntry::LIN, l, 0, 0, lin_rows(l), false});          // Parallel.inputs
+      w.push_back({StateEntry::HBOTH, l, 0, 0, 2 * n.L[l].no, false});      // Parallel.outputs
+      nplstm(l, 0, false);
+      w.push_back({StateEntry::LIN, l, 1, 0, lin_rows(l), false});          // Reversed.inputs
+      w.push_back({StateEntry::HDIR, l, 1, 0, n.L[l].no, false});           // Reversed.outputs
+      nplstm(l, 1, true);
+    } else {
+      nplstm(l, 0, false);
+    }
+  }
+  w.push_back({StateEntry::LIN, nl, 0, 0, lin_rows(nl), false});            // SoftmaxLayer.inputs
+  w.push_back({StateEntry::Z, 0, 0, 0, n.desc.nclasses, false});            // SoftmaxLayer.outputs
+  return w;
+}
+// a reference Sequence is rectangular (size x rows x cols): every line of the batch must have the same length
+static int states_T(const Net& n) {
+  REQUIRE(n.N > 0, "no batch: run forward() (or set_states) first");
+  const int T = n.line_off_h[1] - n.line_off_h[0];
+  for (int b = 0; b < n.bs; b++)
+    REQUIRE(n.line_off_h[b + 1] - n.line_off_h[b] == T, "state externalisation needs equal-length lines (a Sequence is size x rows x cols)");
+  return T;
+}
+struct HostArrays {   // host mirrors of the device arrays the walk touches
+  std::vector<float> X, Z;
+  std::vector<std::vector<float>> G, C, H, S;
+};
+// element (t, i, b) of entry e <-> (array, flat index)
+static float* state_elem(const Net& n, HostArrays& a, const StateEntry& e, int T, int t, int i, int b) {
+  const int tf = e.rev ? T - 1 - t : t;
+  const size_t f = (size_t)n.line_off_h[b] + tf;
+  switch (e.kind) {
+    case StateEntry::X: return &a.X[f * n.desc.ninput + i];
+    case StateEntry::Z: return &a.Z[f * n.desc.nclasses + i];
+    case StateEntry::LIN:
+      if (e.layer == 0) return &a.X[f * n.desc.ninput + i];
+      return &a.H[e.layer - 1][f * n.L[e.layer - 1].ldh + n.L[e.layer - 1].hofs + i];
+    case StateEntry::HBOTH: return &a.H[e.layer][f * n.L[e.layer].ldh + n.L[e.layer].hofs + i];
+    case StateEntry::HDIR: return &a.H[e.layer][f * n.L[e.layer].ldh + n.L[e.layer].hofs + e.dir * n.L[e.layer].no + i];
+    case StateEntry::GATE: return &a.G[e.layer][((f * n.ndir + e.dir) * n.L[e.layer].no + i) * 4 + e.slot];
+    case StateEntry::CELL: return &a.C[e.layer][(f * n.ndir + e.dir) * n.L[e.layer].no + i];
+    case StateEntry::SOURCE: return &a.S[e.layer][(size_t)e.dir * n.N * n.L[e.layer].lds + f * n.L[e.layer].lds + 1 + i];
+  }
+  return nullptr;
+}
+static long long states_total(const Net& n, int T) {
+  long long total = 0;
+  for (auto& e : state_walk(n)) total += (long long)T * e.rows * n.bs + 4;   // n_states, clstm.cc:762-769
+  return total;
+}
+}  // namespace clstm
+int clstm_net_n_states(clstm_net* h, long long* out) {
+  ABI_BEGIN
+  REQUIRE(out, "null argument");
+  *out = states_total(h->net, states_T(h->net));
+  ABI_END
+}
+static void states_transfer(clstm_net* h, float* data, long long total, bool get) {
+  Net& n = h->net;
+  const int T = states_T(n);
+  REQUIRE(total == states_total(n, T), get ? "size mismatch in get_states" : "size mismatch in set_states");
+  HostArrays a;
+  const size_t N = (size_t)n.N;
+  a.X.resize(N * n.desc.ninput); a.Z.resize(N * n.desc.nclasses);
+  a.G.resize(n.L.size()); a.C.resize(n.L.size()); a.H.resize(n.L.size()); a.S.resize(n.L.size());
+  n.flush_line_off();
+  // both directions start from the device contents: set_states only overwrites what the walk covers
+  copy_d2h(a.X.data(), n.X.p, a.X.size());
+  copy_d2h(a.Z.data(), n.Z.p, a.Z.size());
+  for (size_t l = 0; l < n.L.size(); l++) {
+    Layer& y = n.L[l];
+    a.G[l].resize(N * n.ndir * 4 * y.no); a.C[l].resize(N * n.ndir * y.no);
+    a.H[l].resize(N * y.ldh); a.S[l].resize(N * n.ndir * y.lds);
+    copy_d2h(a.G[l].data(), y.G.p, a.G[l].size()); copy_d2h(a.C[l].data(), y.C.p, a.C[l].size());
+    copy_d2h(a.H[l].data(), y.H.p, a.H[l].size()); copy_d2h(a.S[l].data(), y.S.p, a.S[l].size());
+  }
+  long long index = 0;
+  for (auto& e : state_walk(n)) {
+    if (get) {
+      data[index++] = 999999.0f; data[index++] = (float)T; data[index++] = (float)e.rows; data[index++] = (float)n.bs;
+    } else {   // set_states: magic, size, rows, cols must describe this net and batch (clstm.cc:795-803)
+      REQUIRE((int)data[index] == 999999 && (int)data[index + 1] == T && (int)data[index + 2] == e.rows &&
+                  (int)data[index + 3] == n.bs, "size mismatch in set_states");
+      index += 4;
+    }
+    for (int t = 0; t < T; t++)
+      for (int i = 0; i < e.rows; i++)
+        for (int b = 0; b < n.bs; b++) {
+          float* p = state_elem(n, a, e, T, t, i, b);
+          if (get) data[index++] = *p; else *p = data[index++];
+        }
+  }
+  REQUIRE(index == total, "size mismatch in states walk");
+  if (!get) {
+    copy_h2d(n.X.p, a.X.data(), a.X.size());
+    copy_h2d(n.Z.p, a.Z.data(), a.Z.size());
+    for (size_t l = 0; l < n.L.size(); l++) {
+      Layer& y = n.L[l];
+      for (size_t f = 0; f < N; f++) {   // the bias inputs of the packed rows are constants, not states
+        a.H[l][f * y.ldh + y.hofs - 1] = 1.0f;
+        for (int d = 0; d < n.ndir; d++) a.S[l][(size_t)d * N * y.lds + f * y.lds] = 1.0f;
+      }
+      copy_h2d(y.G.p, a.G[l].data(), a.G[l].size()); copy_h2d(y.C.p, a.C[l].data(), a.C[l].size());
+      copy_h2d(y.H.p, a.H[l].data(), a.H[l].size()); copy_h2d(y.S.p, a.S[l].data(), a.S[l].size());
+    }
+    n.src0_ready = true;
+  }
+}
+int clstm_net_get_states_h(clstm_net* h, float* data, long long total) {
+  ABI_BEGIN
+  REQUIRE(data, "null argument");
+  states_transfer(h, data, total, true);
+  ABI_END
+}
+int clstm_net_set_states_h(clstm_net* h, const float* data, long long total) {
+  ABI_BEGIN
+  REQUIRE(data && total >= 4, "null argument");
+  Net& n = h->net;
+  // the first header carries the batch geometry (set_states resizes every Sequence from its header, clstm.cc:804)
+  REQUIRE((int)data[0] == 999999, "bad magic in set_states");
+  const int T = (int)data[1], bs = (int)data[3];
+  REQUIRE(T > 0 && bs > 0 && (int)data[2] == n.desc.ninput, "size mismatch in set_states");
+  std::vector<int> Ts(bs, T);
+  n.set_batch(Ts.data(), bs);
+  states_transfer(h, const_cast<float*>(data), total, false);
+  ABI_END
+}
+
+// ---- data-parallel exchange ---------------------------------------------------------------------------
+struct clstm_comm { Comm c; };
+int clstm_comm_unique_id(char* id_h) {
+  ABI_BEGIN
+  REQUIRE(id_h, "null argument");
+#ifndef CLSTM_HIP_EMU
+  ncclUniqueId id;
+  static_assert(sizeof(id) == CLSTM_COMM_ID_BYTES, "ncclUniqueId size");
+  RCCLCHECK(RcclApi::get().GetUniqueId(&id));
+  memcpy(id_h, &id, sizeof(id));
+#else
+  memset(id_h, 0, CLSTM_COMM_ID_BYTES);
+#endif
+  ABI_END
+}
+int clstm_comm_create(clstm_comm** out, const char* id_h, int rank, int nranks) {
+  ABI_BEGIN
+  REQUIRE(out && id_h && nranks >= 1 && rank >= 0 && rank < nranks, "bad communicator arguments");
+  clstm_comm* c = new clstm_comm();
+  c->c.rank = rank; c->c.nranks = nranks;
+#ifndef CLSTM_HIP_EMU
+  try {
+    ncclUniqueId id;
+    memcpy(&id, id_h, sizeof(id));
+    RCCLCHECK(RcclApi::get().CommInitRank(&c->c.comm, nranks, id, rank));
+  } catch (...) { delete c; throw; }
+#else
+  if (nranks != 1) { delete c; throw Error("the host emulator has no RCCL: single rank only"); }
+#endif
+  *out = c;
+  ABI_END
+}
+int clstm_comm_destroy(clstm_comm* c) { ABI_BEGIN delete c; ABI_END }
+int clstm_comm_rank(clstm_comm* c) { return c ? c->c.rank : 0; }
+int clstm_comm_size(clstm_comm* c) { return c ? c->c.nranks : 1; }
+int clstm_allreduce_flat(clstm_comm* c, float* buf_d, long long n) {
+  ABI_BEGIN
+  REQUIRE(c && buf_d && n >= 0, "bad all-reduce arguments");
+  if (n > 0) c->c.allreduce(buf_d, n, g_stream);
+  ABI_END
+}
+int clstm_net_set_comm(clstm_net* h, clstm_comm* c) { h->net.comm = c ? &c->c : nullptr; return 0; }
 
 // ---- diagnostics ----------------------------------------------------------------------------------
 int clstm_debug_ctc_cycles(long long* out_h) {

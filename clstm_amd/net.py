@@ -162,6 +162,48 @@ class Network:
     def update(self):                                   # sgd_update(Network) clstm.cc:201-217
         self.lib.call("clstm_net_update", self.h)
 
+    def train_step(self, T, x_dev, transcripts):
+        """CLSTMOCR::train (clstmhl.h:201-223) for a minibatch resident in HBM, ONE library call:
+        set_batch + set_inputs + forward + CTC + backward + [all-reduce] + update, no host sync."""
+        self.train_step_prepared(self.prepare_step(T, transcripts), x_dev)
+
+    @staticmethod
+    def prepare_step(T, transcripts):
+        """Host arrays of one minibatch in the form the C ABI takes (line lengths, packed transcripts, their
+        lengths) -- build once per minibatch, outside any timed loop."""
+        Tl = [int(t) for t in T]
+        assert len(transcripts) == len(Tl)
+        L = i32([len(tr) for tr in transcripts])
+        flat = np.concatenate([i32(tr).reshape(-1) for tr in transcripts]) if len(transcripts) else i32([])
+        return Tl, i32(Tl), i32(flat if flat.size else [0]), L
+
+    def train_step_prepared(self, prep, x_dev):
+        Tl, t, labels, L = prep
+        self.T, self.N = Tl, int(sum(Tl))
+        self.lib.call("clstm_net_train_step", self.h, ptr(t), len(Tl), ptr(x_dev), ptr(labels), ptr(L))
+
+    def set_comm(self, comm):
+        """Attach a `Comm` (RCCL): update()/train_step() all-reduce the fresh gradient first."""
+        self._comm = comm
+        self.lib.call("clstm_net_set_comm", self.h, comm.h if comm is not None else None)
+
+    # -- state externalisation: n_states / get_states / set_states (clstm.cc:762-811) --------
+    def n_states(self):
+        n = C.c_longlong()
+        self.lib.call("clstm_net_n_states", self.h, C.byref(n))
+        return n.value
+
+    def get_states(self):
+        a = np.empty(self.n_states(), np.float32)
+        self.lib.call("clstm_net_get_states_h", self.h, ptr(a), a.size)
+        return a
+
+    def set_states(self, a):
+        a = f32(a)
+        self.lib.call("clstm_net_set_states_h", self.h, ptr(a), a.size)
+        self.T = [int(a[1])] * int(a[3])
+        self.N = sum(self.T)
+
     def decode(self):
         """trivial_decode (ctc.cc:159-190) of every line -> list of int arrays."""
         cls = np.zeros(self.N, np.int32)
@@ -200,6 +242,33 @@ class Network:
 
     def reset_timing(self):
         self.lib.call("clstm_net_reset_timing", self.h)
+
+
+class Comm:
+    """RCCL communicator of the data-parallel ranks (clstm_comm_*): one per process / GPU.
+    `exchange(id_bytes_or_None) -> id_bytes` ships rank 0's 128-byte id to every rank."""
+
+    ID_BYTES = 128
+
+    def __init__(self, rank, nranks, exchange, lib=None):
+        self.lib = lib or abi.load()
+        buf = C.create_string_buffer(self.ID_BYTES)
+        if rank == 0:
+            self.lib.call("clstm_comm_unique_id", buf)
+        ident = exchange(bytes(buf.raw) if rank == 0 else None)
+        assert len(ident) == self.ID_BYTES
+        h = C.c_void_p()
+        self.lib.call("clstm_comm_create", C.byref(h), C.create_string_buffer(ident, self.ID_BYTES), int(rank), int(nranks))
+        self.h = h
+        self.rank, self.nranks = int(rank), int(nranks)
+
+    def allreduce(self, buf, n):
+        self.lib.call("clstm_allreduce_flat", self.h, ptr(buf), int(n))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.call("clstm_comm_destroy", self.h)
+            self.h = None
 
 
 def make_net(kind, ninput, noutput, nhidden, nhidden2=None, lib=None, **bufs):

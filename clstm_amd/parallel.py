@@ -14,12 +14,18 @@ import numpy as np
 class Trainer:
     """CLSTMOCR::train (clstmhl.h:201-223) for a minibatch of lines, optionally data-parallel."""
 
-    def __init__(self, net, grads_tensor=None, process_group=None):
+    def __init__(self, net, grads_tensor=None, process_group=None, comm=None):
+        """comm: a clstm_amd.net.Comm (RCCL inside the library, all-reduce on the library's own stream --
+        the production path); otherwise, with grads_tensor, torch.distributed's all_reduce (gloo in the CPU
+        tests; also the fallback if the library communicator cannot be created)."""
         self.net = net
         self.grads = grads_tensor          # torch tensor aliasing the net's grads buffer
         self.pg = process_group
         self.dist = None
-        if grads_tensor is not None:
+        self.comm = comm
+        if comm is not None:
+            net.set_comm(comm)             # clstm_net_update / clstm_net_train_step all-reduce `grads` themselves
+        elif grads_tensor is not None:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
                 self.dist = dist
@@ -40,6 +46,9 @@ class Trainer:
     def step_device(self, T, x_dev, transcripts):
         """One training step on inputs already resident in HBM (x_dev: [sum T, ninput])."""
         net = self.net
+        if self.dist is None:              # single GPU, or the library's own communicator: ONE call
+            net.train_step(T, x_dev, transcripts)
+            return
         net.set_batch(T)
         net.set_inputs_device(x_dev)
         net.forward()
@@ -57,7 +66,12 @@ class Trainer:
 
 
 def shard(items, rank, world):
-    """Contiguous shard of a minibatch for this rank (B/R lines per GPU)."""
+    """Contiguous shard of a minibatch for this rank: n // world lines each, the first n % world ranks
+    take one more -- so every rank owns at least one line whenever n >= world (a rank with no lines would
+    sit out the collective and hang the others)."""
     n = len(items)
-    per = (n + world - 1) // world
-    return items[rank * per:min(n, (rank + 1) * per)]
+    if n < world:
+        raise ValueError("minibatch of %d lines cannot be sharded over %d ranks (every rank joins the all-reduce)" % (n, world))
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return items[lo:lo + base + (1 if rank < extra else 0)]

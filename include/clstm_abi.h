@@ -184,6 +184,48 @@ int clstm_net_enable_timing(clstm_net* net, int on);
 int clstm_net_kernel_time_ms(clstm_net* net, const char* kernel_name, double* total_ms, int* launches);
 int clstm_net_reset_timing(clstm_net* net);
 
+/* CLSTMOCR::train (clstmhl.h:201-223) for a whole minibatch in ONE call: set_batch + set_inputs_d + forward +
+ * ctc + backward + [all-reduce of grads when a communicator is attached] + update, enqueued on the library
+ * stream without any host synchronisation.  T_h[bs], labels_h (packed transcripts), L_h[bs]: HOST;
+ * x_d: DEVICE [sum T][ninput].  Decode with clstm_net_decode() afterwards if the caller wants the output. */
+int clstm_net_train_step(clstm_net* net, const int* T_h, int bs, const float* x_d, const int* labels_h,
+                         const int* L_h);
+
+/* State externalisation: n_states / get_states / set_states (clstm.cc:762-811; upstream test
+ * test-lstm2.cc:79-142).  The reference walks every `Sequence` state of every layer (walk_states,
+ * clstm.cc:64-67: per NPLSTM the std::map order ci, gf, gi, go, out, source, state, then the layer's
+ * inputs/outputs are NOT states) and copies the .v planes.  Here: the same order and contents for the
+ * current minibatch, per layer: forward NPLSTM then the NPLSTM inside Reversed (in ITS time order, i.e.
+ * frame T-1-t at its step t), each state as [T][rows][bs] flattened exactly as Sequence::v would be for a
+ * bs=1 line batch; for bs>1 lines are concatenated line after line.  `source` = [x_t ; h_{t-1}] rows
+ * (clstm_compute.cc:377-397).  HOST buffers, blocking. */
+int clstm_net_n_states(clstm_net* net, long long* n);
+int clstm_net_get_states_h(clstm_net* net, float* states_h, long long n);
+int clstm_net_set_states_h(clstm_net* net, const float* states_h, long long n);
+
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel exchange: every GPU owns an independent shard of the minibatch's lines; the
+ * ONE exchange is an all-reduce (sum, fp32) of the flat fresh-gradient buffer before the identical update on
+ * every rank.  Reference precedent: share_deltas (clstm.cc:731-744) -- which sums Params.d, momentum
+ * included; here only the fresh gradient crosses GPUs (clstm_net_create: grads_d).
+ * RCCL (librccl.so.1) is bound at first use; one communicator per process = per GPU (hipSetDevice first).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct clstm_comm clstm_comm;
+#define CLSTM_COMM_ID_BYTES 128
+/* rank 0: ncclGetUniqueId into id_h[CLSTM_COMM_ID_BYTES]; ship the bytes to the other ranks by any means */
+int clstm_comm_unique_id(char* id_h);
+/* collective over all ranks (ncclCommInitRank on the current device) */
+int clstm_comm_create(clstm_comm** out, const char* id_h, int rank, int nranks);
+int clstm_comm_destroy(clstm_comm* comm);
+int clstm_comm_rank(clstm_comm* comm);
+int clstm_comm_size(clstm_comm* comm);
+/* in-place sum over ranks of buf_d[0..n) (DEVICE, f32), enqueued on the library stream: no cross-stream
+ * event, no host synchronisation. */
+int clstm_allreduce_flat(clstm_comm* comm, float* buf_d, long long n);
+/* attach (or detach with NULL) a communicator: clstm_net_update() / clstm_net_train_step() then all-reduce
+ * the fresh gradient buffer `grads` before derivs += grads. */
+int clstm_net_set_comm(clstm_net* net, clstm_comm* comm);
+
 /* ------------------------------------------------------------------------------------------
  * diagnostics (used by tests/ to pin the hardware lane layouts the kernels rely on)
  * ---------------------------------------------------------------------------------------- */

@@ -79,5 +79,11 @@ def test_shard_covers_everything():
     from clstm_amd.parallel import shard
     items = list(range(11))
     for world in (1, 2, 3, 4, 8):
-        got = sum((shard(items, r, world) for r in range(world)), [])
-        assert got == items
+        parts = [shard(items, r, world) for r in range(world)]
+        assert sum(parts, []) == items
+        assert min(len(p) for p in parts) >= 1 and max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    # n = 5, world = 4 used to leave rank 3 empty (-> "empty batch" on that rank while the others wait in the all-reduce)
+    assert [len(shard(list(range(5)), r, 4)) for r in range(4)] == [2, 1, 1, 1]
+    import pytest
+    with pytest.raises(ValueError):
+        shard([1, 2], 0, 4)

@@ -1,0 +1,152 @@
+"""State externalisation (n_states/get_states/set_states, clstm.cc:762-811 -- upstream test
+test-lstm2.cc:79-142), the one-call training step (CLSTMOCR::train, clstmhl.h:201-223) and the
+communicator entry points of the C ABI.  Each test runs on the host emulator (CPU suite) and on the
+MI355X (-m gpu) through the same ABI."""
+import numpy as np
+import pytest
+
+from common import assert_close, synth_lines
+from oracle.oracle import OracleNet
+
+
+def _walk(kind, ni, nh, nc):
+    """(name, rows, oracle accessor) in walk_states(net, f, "", io=true) order, clstm.cc:63-70."""
+    out = [("Stacked.inputs", ni, None), ("Stacked.outputs", nc, None)]
+    lin = ni
+    for l, no in enumerate(nh):
+        def nplstm(d, lin=lin, no=no, l=l):
+            return [("inputs", lin, None), ("outputs", no, (l, d, "outputs")), ("ci", no, (l, d, "ci")),
+                    ("gf", no, (l, d, "gf")), ("gi", no, (l, d, "gi")), ("go", no, (l, d, "go")),
+                    ("source", lin + no, (l, d, "source")), ("state", no, (l, d, "state"))]
+        if kind == "lstm1":
+            out += nplstm(0)
+            lin = no
+        else:
+            out += [("Parallel.inputs", lin, None), ("Parallel.outputs", 2 * no, None)] + nplstm(0)
+            out += [("Reversed.inputs", lin, None), ("Reversed.outputs", no, None)] + nplstm(1)
+            lin = 2 * no
+    out += [("Softmax.inputs", lin, None), ("Softmax.outputs", nc, None)]
+    return out
+
+
+@pytest.mark.parametrize("kind,ni,nh,nc,T,bs", [("bidi", 5, [6], 4, 7, 2), ("lstm1", 1, [4], 2, 9, 1),
+                                                ("bidi2", 4, [5, 3], 6, 4, 3)])
+def test_states_roundtrip_reference_format(backend, ora32, kind, ni, nh, nc, T, bs):
+    from clstm_amd.net import Network
+    uni = kind == "lstm1"
+    rng = np.random.default_rng(3)
+    ref = OracleNet(ora32, ni, nh, nc, unidirectional=uni, seed=0.222)
+    params = ref.get_params() * 30.0
+    ref.set_params(params)
+    x = np.stack(synth_lines(rng, [T] * bs, ni), 1)            # [T][bs][ni]
+    ref.set_inputs(x)
+    zref = ref.forward()
+    net = Network(ni, nh, nc, unidirectional=uni, lib=backend.lib)
+    net.set_params(params)
+    net.set_inputs([x[:, b, :] for b in range(bs)])
+    net.forward()
+    walk = _walk(kind, ni, nh, nc)
+    total = sum(T * rows * bs + 4 for _, rows, _ in walk)        # n_states, clstm.cc:762-769
+    assert net.n_states() == total
+    st = net.get_states()
+    assert st.size == total
+    pos = 0
+    for name, rows, acc in walk:
+        assert st[pos:pos + 4].tolist() == [999999.0, T, rows, bs], name    # get_states header, clstm.cc:776-779
+        blk = st[pos + 4:pos + 4 + T * rows * bs].reshape(T, rows, bs)
+        pos += 4 + T * rows * bs
+        if name == "Stacked.inputs":
+            assert np.array_equal(blk, np.transpose(x, (0, 2, 1)))
+        elif name in ("Stacked.outputs", "Softmax.outputs"):
+            assert_close(np.transpose(blk, (0, 2, 1)), zref, what=name)
+        elif acc is not None:   # NPLSTM states, in the NPLSTM's own time order (the one inside Reversed runs reversed)
+            assert_close(np.transpose(blk, (0, 2, 1)), ref.state(*acc), what=name + str(acc))
+    assert pos == total
+    # test-lstm2.cc:96-121: a FRESH network given the states and the weights must produce the same backward pass
+    dz = rng.normal(0, 0.1, (T * bs, nc)).astype(np.float32)
+    net.set_output_deltas(dz)
+    net.backward()
+    g1 = net.get_grads()
+    net2 = Network(ni, nh, nc, unidirectional=uni, lib=backend.lib)
+    net2.set_states(st)
+    net2.set_params(params)
+    assert np.array_equal(net2.get_states(), st)
+    net2.set_output_deltas(dz)
+    net2.backward()
+    assert np.array_equal(net2.get_grads(), g1), "backward from externalised states differs"
+    with pytest.raises(Exception):
+        net2.set_states(st[:-1])                                  # "size mismatch in set_states", clstm.cc:801-809
+
+
+def test_states_need_rectangular_batch(backend):
+    from clstm_amd.net import Network
+    net = Network(3, [4], 3, lib=backend.lib)
+    net.set_inputs([np.zeros((4, 3), np.float32), np.zeros((2, 3), np.float32)])
+    net.forward()
+    with pytest.raises(Exception, match="equal-length"):
+        net.n_states()
+
+
+def test_train_step_is_the_sequence_of_calls(backend):
+    """clstm_net_train_step == set_batch; set_inputs_d; forward; ctc; backward; update -- bit for bit,
+    over several steps (momentum carried in derivs)."""
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Network
+    ni, nh, nc = 6, [10], 7
+    rng = np.random.default_rng(5)
+    p0 = init_params(ni, nh, nc, seed=0.222) * 20
+    a = Network(ni, nh, nc, lib=backend.lib)
+    b = Network(ni, nh, nc, lib=backend.lib)
+    for n in (a, b):
+        n.set_params(p0)
+        n.setLearningRate(1e-2, 0.9)
+    for step in range(3):
+        T = [int(t) for t in rng.integers(3, 9, 3)]
+        lines = synth_lines(rng, T, ni)
+        trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+        xd = backend.up(np.concatenate(lines, 0))
+        a.set_batch(T)
+        a.set_inputs_device(xd)
+        a.forward()
+        a.ctc(trs)
+        a.backward()
+        a.update()
+        b.train_step(T, xd, trs)
+        assert np.array_equal(a.get_params(), b.get_params()), step
+        assert np.array_equal(a.get_derivs(), b.get_derivs()), step
+        assert [d.tolist() for d in a.decode()] == [d.tolist() for d in b.decode()]
+
+
+def test_allreduce_single_rank_is_identity(backend):
+    """World size 1 through the communicator entry points: on the MI355X this is a real RCCL communicator
+    (ncclCommInitRank + ncclAllReduce on the library stream); update() with it attached must equal update()
+    without it bit for bit."""
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Comm, Network
+    ni, nh, nc = 5, [8], 6
+    rng = np.random.default_rng(9)
+    p0 = init_params(ni, nh, nc, seed=0.222) * 20
+    comm = Comm(0, 1, lambda ident: ident, lib=backend.lib)
+    assert backend.lib.call("clstm_comm_size", comm.h) == 1 and backend.lib.call("clstm_comm_rank", comm.h) == 0
+    nets = [Network(ni, nh, nc, lib=backend.lib) for _ in range(2)]
+    nets[1].set_comm(comm)
+    T = [6, 4]
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, 2).astype(np.int32) for _ in T]
+    for n in nets:
+        n.set_params(p0)
+        n.setLearningRate(1e-2, 0.9)
+        for _ in range(2):
+            n.set_inputs(lines)
+            n.forward()
+            n.ctc(trs)
+            n.backward()
+            n.update()
+    assert np.array_equal(nets[0].get_params(), nets[1].get_params())
+    assert np.array_equal(nets[0].get_derivs(), nets[1].get_derivs())
+    # the flat all-reduce on its own: sum over one rank = identity
+    v = backend.up(np.arange(1000, dtype=np.float32))
+    comm.allreduce(v, 1000)
+    assert np.array_equal(backend.down(v), np.arange(1000, dtype=np.float32))
+    nets[1].set_comm(None)
+    comm.close()
