@@ -42,6 +42,7 @@ DEVFN float quad_bcast(float x) { return dpp_perm<I * 0x55>(x); }  // quad_perm 
 template <int N>
 DEVFN float row_ror(float x) { return dpp_perm<0x120 + N>(x); }  // rotate within a row of 16
 DEVFN float row_half_mirror(float x) { return dpp_perm<0x141>(x); }  // lane i <-> i^7 within 8 lanes
+DEVFN float quad_mirror(float x) { return dpp_perm<0x1B>(x); }        // quad_perm [3,2,1,0]: lane i <-> i^3
 #else
 // Fallback through ds_bpermute (definitionally correct; used to cross-check the DPP codes).
 DEVFN float quad_xor1(float x) { return __shfl_xor(x, 1, 64); }
@@ -54,9 +55,15 @@ DEVFN float row_ror(float x) {
   return __shfl(x, (lane & ~15) | ((lane + N) & 15), 64);
 }
 DEVFN float row_half_mirror(float x) { return __shfl(x, (int)(threadIdx.x & 63u) ^ 7, 64); }
+DEVFN float quad_mirror(float x) { return __shfl_xor(x, 3, 64); }
 #endif
 DEVFN float wave_shfl(float x, int src) { return __shfl(x, src, 64); }
 DEVFN float wave_shfl_up1(float x) { return __shfl_up(x, 1, 64); }
+#ifdef CLSTM_USE_SHFL
+template <int I> DEVFN float mul_quad_bcast(float x, float y) { return quad_bcast<I>(x) * y; }
+template <int I> DEVFN float fmac_quad_bcast(float acc, float x, float y) { return fmaf(quad_bcast<I>(x), y, acc); }
+template <int I> DEVFN float mul_quad_bcast_old(float x, float y) { return quad_bcast<I>(x) * y; }
+#endif
 #ifndef CLSTM_USE_SHFL
 DEVFN float wave_shr1(float x) { return dpp_mov<0x138>(x); }  // DPP wave_shr:1 (lane 0 keeps its value)
 // lanes >= 1: a[lane-1] + b[lane]; lane 0 (no source lane, bound_ctrl off) keeps `old`.  One VALU operation;
@@ -91,6 +98,48 @@ DEVFN float wave_sum(float x) {
 // packed f32 FMA (v_pk_fma_f32): two lanes of work per VALU issue slot
 DEVFN f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 DEVFN f32x2 splat2(float x) { return (f32x2){x, x}; }
+// acc += w * (one element of an aligned register pair, broadcast to both halves) as ONE v_pk_fma_f32: op_sel picks
+// the element.  hipcc finds this form for elements x, y, z of a ds_read_b128 result but copies element w into a
+// fresh pair first (a v_mov_b32 per group of four k on the recurrence's issue-bound mat-vec); spelled out here.
+DEVFN f32x2 pair_lo(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+DEVFN f32x2 pair_hi(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+DEVFN f32x2 fma2_lo(f32x2 w, f32x2 hp, f32x2 acc) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "v"(hp));
+  return acc;
+}
+DEVFN f32x2 fma2_hi(f32x2 w, f32x2 hp, f32x2 acc) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(w), "v"(hp));
+  return acc;
+}
+// Quad broadcasts folded into their consumer (one VALU operation instead of v_mov_b32_dpp + the arithmetic; hipcc
+// does not fold these).  s_nop 1: the VALU-write -> DPP-read hazard on x is invisible to the compiler inside asm.
+#define CLSTM_QUAD_OPS(I)                                                                                              \
+  template <> DEVFN float mul_quad_bcast<I>(float x, float y) { /* x[quad lane I] * y */                               \
+    float r;                                                                                                           \
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 quad_perm:[" #I "," #I "," #I "," #I "] row_mask:0xf bank_mask:0xf bound_ctrl:1" \
+        : "=v"(r) : "v"(x), "v"(y));                                                                                  \
+    return r;                                                                                                          \
+  }                                                                                                                    \
+  template <> DEVFN float fmac_quad_bcast<I>(float acc, float x, float y) { /* acc + x[quad lane I] * y, fused */      \
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[" #I "," #I "," #I "," #I "] row_mask:0xf bank_mask:0xf bound_ctrl:1" \
+        : "+v"(acc) : "v"(x), "v"(y));                                                                                \
+    return acc;                                                                                                        \
+  }
+// ..._old: x is known to have been written long before (no hazard, no s_nop on the step's dependent tail)
+#define CLSTM_QUAD_OPS_OLD(I)                                                                                          \
+  template <> DEVFN float mul_quad_bcast_old<I>(float x, float y) {                                                    \
+    float r;                                                                                                           \
+    asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[" #I "," #I "," #I "," #I "] row_mask:0xf bank_mask:0xf bound_ctrl:1"     \
+        : "=v"(r) : "v"(x), "v"(y));                                                                                  \
+    return r;                                                                                                          \
+  }
+#ifndef CLSTM_USE_SHFL
+template <int I> DEVFN float mul_quad_bcast(float x, float y);
+template <int I> DEVFN float mul_quad_bcast_old(float x, float y);
+template <int I> DEVFN float fmac_quad_bcast(float acc, float x, float y);
+CLSTM_QUAD_OPS(0) CLSTM_QUAD_OPS(1) CLSTM_QUAD_OPS(2) CLSTM_QUAD_OPS(3)
+CLSTM_QUAD_OPS_OLD(0) CLSTM_QUAD_OPS_OLD(1) CLSTM_QUAD_OPS_OLD(2) CLSTM_QUAD_OPS_OLD(3)
+#endif
 
 // ---- f32 MFMA: D(16x16) += A(16x4) * B(4x16); exact f32 fma chain (guide: cdna §3) ----
 // lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; holds D[row=(l>>4)*4+r][col=l&15].
@@ -264,3 +313,18 @@ DEVFN float gate_act(float x, bool is_tanh) {
   const float th = copysignf(ax < 0.01f ? small : (1.0f - e) * r, x);
   return is_tanh ? th : r;
 }
+
+// The recurrence kernels' nonlinearity: FIVE dependent VALU operations for either kind, no select, no branch:
+//   r = 1 / (1 + 2^(x * scale)) ;  act = r * A + B
+//   sigmoid: scale = -log2 e, A = 1, B = 0 (exactly gate_act's sigmoid);  tanh x = 2 sigmoid(2x) - 1: scale = -2 log2 e,
+//   A = 2, B = -1.  Limits are exact (2^+big = inf -> r = 0; 2^-big = 0 -> r = 1).  The tanh form cancels for small
+//   |x|: its ABSOLUTE error stays ~2 ulp of 1 (<= 3e-7: v_exp_f32 and v_rcp_f32 are 1-ulp operations), i.e. inside
+//   the parity tests' absolute floor (2e-6) where the relative bar (1e-4) no longer binds.  gate_act's
+//   branchy small-|x| series + select + copysign cost ~12 VALU operations and two exec-mask round trips through
+//   the scalar unit per evaluation, twice per time step on the step's dependent tail (lstm_seq.h).
+constexpr float ACT_SIG_SCALE = -1.44269504088896341f, ACT_TANH_SCALE = -2.0f * 1.44269504088896341f;
+DEVFN float act_affine(float x, float scale, float A, float B) {
+  const float r = fast_rcp(1.0f + fast_exp2(x * scale));
+  return fmaf(r, A, B);
+}
+DEVFN float tanh_fast(float x) { return act_affine(x, ACT_TANH_SCALE, 2.0f, -1.0f); }

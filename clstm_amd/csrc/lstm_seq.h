@@ -31,6 +31,7 @@
 // top of a step into a register set that is dead (three rotating sets, backward), and no s_waitcnt sized for
 // the first iteration may sit inside the loop (values loaded in the prologue are touched before it).
 #pragma once
+#include <type_traits>
 #include "devintrin.h"
 
 namespace clstm {
@@ -105,12 +106,17 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     return (unsigned)(dir == 0 ? tc : T - 1 - tc);
   };
   const int hslot = (cell / KU) * QS + (cell % KU);
+  // lane q finishes gate q: q = 0 gi, 1 gf, 2 go (sigmoid), 3 ci (tanh) -- one affine form for both (act_affine)
+  const float a_scale = q == 3 ? ACT_TANH_SCALE : ACT_SIG_SCALE, a_mul = q == 3 ? 2.0f : 1.0f, a_add = q == 3 ? -1.0f : 0.0f;
   const float* rdA = lds + q * QS;            // even steps read buffer 0, write buffer 1
   const float* rdB = lds + HB + q * QS;
   float* wrA = lead ? lds + HB + hslot : lds + 2 * HB;
   float* wrB = lead ? lds + hslot : lds + 2 * HB;
   float c_prev = 0.0f;
   if (T <= 0) return;
+#ifdef CLSTM_PRIO
+  if (wave >= CLSTM_PRIO) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the later-dispatched waves
+#endif
   // input pre-activations are fetched two steps ahead into two alternating registers (the loop is
   // unrolled by two so that no register rotation forces an early wait on an in-flight load)
   float gxA = buf_load(gbuf, gl + fr(0) * gstride4);
@@ -146,18 +152,40 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   auto flush = [&](const int tp, float pa0, float pa1, float pa2) {
     const bool any = tp >= 0;
     const unsigned f = fr(tp < 0 ? 0 : tp);
-    buf_store(gbuf, any ? gl + f * gstride4 : BUF_OOB, pa0);
-    buf_store(cbuf, any ? cl + f * cstride4 : BUF_OOB, pa1);
-    buf_store(hbuf, any ? hl + f * hstride4 : BUF_OOB, pa2);
+#ifndef CLSTM_EXP_NOSTORE   // (perf experiments only: bit mask of stores to leave out -- results are then wrong)
+#define CLSTM_EXP_NOSTORE 0
+#endif
+    if (!(CLSTM_EXP_NOSTORE & 1)) buf_store(gbuf, any ? gl + f * gstride4 : BUF_OOB, pa0);
+    if (!(CLSTM_EXP_NOSTORE & 2)) buf_store(cbuf, any ? cl + f * cstride4 : BUF_OOB, pa1);
+    if (!(CLSTM_EXP_NOSTORE & 4)) buf_store(hbuf, any ? hl + f * hstride4 : BUF_OOB, pa2);
     // h_t is the recurrent part of the NEXT step's source row (dropped after the last step)
-    buf_store(sbuf, any && tp + 1 < T ? sl + fr(tp + 1) * sstride4 : BUF_OOB, pa2);
+    if (!(CLSTM_EXP_NOSTORE & 8)) buf_store(sbuf, any && tp + 1 < T ? sl + fr(tp + 1) * sstride4 : BUF_OOB, pa2);
   };
+  // WHICH side of the barrier a wave stores on depends on its role (measured: the four stores of all seven waves
+  // issued together right behind the barrier queue at the texture addresser -- 28 wave-instructions at ~10-16
+  // cycles each -- and the waves that define the step then start their LDS reads / FMAs that much later; with no
+  // stores at all the kernel runs 91.6 us instead of 115.4).  The first-dispatched waves (one per SIMD, they win the
+  // VALU arbitration and then sit ~400 cycles at the barrier) store at the END of their step; the later waves, whose
+  // FMAs wait for the older wave of their SIMD anyway, store right behind the barrier.
+#ifndef CLSTM_EARLY_WAVES
+#define CLSTM_EARLY_WAVES 4
+#endif
+  // The two roles are two copies of the whole time loop (one wave-uniform branch in front): inside a copy the
+  // stores sit at a fixed place in straight-line code, so hipcc still counts the VMEM queue exactly (a branch
+  // inside the step made it wait with vmcnt(1), i.e. for the previous step's stores).
+  const bool early = wave_uniform(wave) < CLSTM_EARLY_WAVES;
+  auto run = [&](auto early_tag) {
+  constexpr bool EARLY = decltype(early_tag)::value;
   auto step = [&](const int t, float& gxr, const float* hq, float* hw, float& ka0, float& ka1, float& ka2,
                   float pa0, float pa1, float pa2) {
-    KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2);  // stores of step t-2 have long completed
-    flush(t - 1, pa0, pa1, pa2);
+    if constexpr (!EARLY) {
+      KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2);  // stores of step t-2 have long completed
+      flush(t - 1, pa0, pa1, pa2);
+    }
     f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
     LSTM_STAMP(0);   // loop overhead since the barrier
+    // (hipcc copies element w of every ds_read_b128 into a fresh pair -- 6 v_mov_b32 per step; spelling the
+    //  FMAs as inline asm with op_sel removes them but serialises the LDS reads behind single waits: not kept)
 #pragma unroll
     for (int j = 0; j < NK4; j++) {
       const float4 hv = *reinterpret_cast<const float4*>(hq + 4 * j);
@@ -166,6 +194,10 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
       if (4 * j + 2 < KU) { a01 = fma2(w01[4 * j + 2], splat2(hv.z), a01); a23 = fma2(w23[4 * j + 2], splat2(hv.z), a23); }
       if (4 * j + 3 < KU) { a01 = fma2(w01[4 * j + 3], splat2(hv.w), a01); a23 = fma2(w23[4 * j + 3], splat2(hv.w), a23); }
     }
+    // (early role: the pins end only here, so that the LDS reads above cannot land in the store-data registers --
+    //  hipcc guards an LDS return into such a register with s_waitcnt vmcnt(0), i.e. it would wait for the stores
+    //  just issued)
+    if constexpr (EARLY) { KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2); }
     LSTM_STAMP(1);   // LDS reads + FMAs
     // reduce-scatter over the quad: lane q ends with gate q's sum over the four k-quarters
     // (register slot s of lane q holds gate s^q -- pack_rf -- so what a lane keeps and what it sends sit
@@ -179,18 +211,24 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     // re-issue into the SAME register only now that its old value is dead (no back-edge copy, so
     // the load really stays in flight for two steps)
     gxr = buf_load(gbuf, gl + fr(t + 2) * gstride4);
-    const float act = gate_act(pre, q == 3);
-    const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), go = quad_bcast<2>(act),
-                ci = quad_bcast<3>(act);
-    // forward_statemem (clstm_compute.cc:504-508); c_prev = 0 at t = 0 makes the second term an
-    // exact +0, so no first-step special case (and no loop peeling) is needed
-    LSTM_STAMP(3);   // gate nonlinearity + quad broadcast
-    const float c = ci * gi + gf * c_prev;
-    const float h = gate_act(c, true) * go;  // forward_nonlingate (clstm_compute.cc:530-537)
+    const float act = act_affine(pre, a_scale, a_mul, a_add);
+    // forward_statemem (clstm_compute.cc:504-508): c = ci*gi + gf*c_prev with the quad broadcasts folded into
+    // the arithmetic (v_mul_f32_dpp, v_fmac_f32_dpp); c_prev = 0 at t = 0 makes the second term an exact +0, so
+    // no first-step special case (and no loop peeling) is needed
+    LSTM_STAMP(3);   // gate nonlinearity
+    const float cig = mul_quad_bcast<0>(act, quad_bcast<3>(act));   // gi * ci
+    const float c = fmac_quad_bcast<1>(cig, act, c_prev);           // + gf * c_{t-1}
+    const float h = mul_quad_bcast<2>(act, tanh_fast(c));           // forward_nonlingate (clstm_compute.cc:530-537): go * tanh(c)
     c_prev = c;
     LSTM_STAMP(4);   // state update + tanh(c)
     *hw = h;
-    ka0 = act; ka1 = c; ka2 = h;                      // stored by the next step's flush
+    ka0 = act; ka1 = c; ka2 = h;                      // stored by the next step's flush (later waves)
+    if constexpr (EARLY) {
+      // store FROM the pinned registers: a VMEM store reads its data late, and a copy of the value in a register
+      // that the next step's LDS reads overwrite would put s_waitcnt vmcnt(0) at the top of every step
+      OPAQUE(ka0); OPAQUE(ka1); OPAQUE(ka2);
+      flush(t, ka0, ka1, ka2);
+    }
     LSTM_STAMP(5);   // LDS write issued
     __syncthreads();
     LSTM_STAMP(6);   // barrier
@@ -202,10 +240,12 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
   }
   if (t < T) {
     step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kaB0, kaB1, kaB2);
-    flush(t, kaA0, kaA1, kaA2);
+    if constexpr (!EARLY) flush(t, kaA0, kaA1, kaA2);
   } else {
-    flush(t - 1, kaB0, kaB1, kaB2);
+    if constexpr (!EARLY) flush(t - 1, kaB0, kaB1, kaB2);
   }
+  };
+  if (early) run(std::true_type{}); else run(std::false_type{});
 #ifdef CLSTM_LSTM_PROF
   if (a.prof && b == 0 && dir == 0 && lane == 0)
     for (int k = 0; k < 8; k++) a.prof[wave * 8 + k] = pacc[k];
@@ -242,6 +282,9 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
   const int off = a.line_off[b];
   const int T = a.line_off[b + 1] - off;
   if (T <= 0) return;
+#ifdef CLSTM_PRIO
+  if (wave >= CLSTM_PRIO) __builtin_amdgcn_s_setprio(1);
+#endif
   const int pidx = g * no + cell;  // this lane's delta goes to pair (gate g, j = cell)
   const int dslot = (pidx / SL) * QS + (pidx % SL);
   const unsigned gstride4 = (unsigned)nd * 4 * no * 4, cstride4 = (unsigned)nd * no * 4;
@@ -271,7 +314,7 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
   Ops X0, X1, X2;
   X0.act = buf_load(gbuf, gl + fr(T - 1) * gstride4); X1.act = buf_load(gbuf, gl + fr(T - 2) * gstride4);
   X0.dh = buf_load(hbuf, cl + fr(T - 1) * cstride4);  X1.dh = buf_load(hbuf, cl + fr(T - 2) * cstride4);
-  X0.cc = buf_load(cbuf, cl + fr(T - 1) * cstride4);  X1.cc = buf_load(cbuf, cl + fr(T - 2) * cstride4);
+  X0.cc = buf_load(cbuf, cl + fr(T - 1) * cstride4);  X1.cc = buf_load(cbuf, T >= 2 ? cl + fr(T - 2) * cstride4 : BUF_OOB);
   X2.act = X2.dh = X2.cc = 0.0f;
   float dc_carry = 0.0f;
   float ka0 = 0.f, ka1 = 0.f, ka2 = 0.f;  // store-data pins (see KEEP_ALIVE)
@@ -283,24 +326,24 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
     KEEP_ALIVE(ka);
     ld.act = buf_load(gbuf, gl + fr(s - 2) * gstride4);
     ld.dh = buf_load(hbuf, cl + fr(s - 2) * cstride4);
-    ld.cc = buf_load(cbuf, cl + fr(s - 2) * cstride4);
+    ld.cc = buf_load(cbuf, s >= 2 ? cl + fr(s - 2) * cstride4 : BUF_OOB);   // before the first step: 0 = c_{-1}
     // Everything that does not depend on this step's mat-vec is computed BEFORE it (its operands were
     // requested two steps ago): tanh(c), the gate broadcasts, the derivative factor and the second factor
     // of this lane's gate delta.  The dependent tail behind the reduction is then five VALU operations.
     const float actr = cur.act;
-    const float gi = quad_bcast<0>(actr), gf = quad_bcast<1>(actr), go = quad_bcast<2>(actr),
-                ci = quad_bcast<3>(actr);
-    // backward_nonlin0 in place (clstm_compute.cc:231-267): y(1-y) for SIG, 1-y^2 for TANH
-    const float deriv = g == 3 ? (-actr * actr + 1.0f) : actr * (-actr + 1.0f);
-    const float th = gate_act(cur.cc, true);   // backward_nonlingate recomputes tanh(state)
-    const float gth = (-th * th + 1.0f) * go;  // state.d += (1-t^2) * (go*out.d)
+    // backward_nonlin0 in place (clstm_compute.cc:231-267): y(1-y) = y - y^2 for SIG, 1 - y^2 for TANH
+    const float deriv = fmaf(-actr, actr, g == 3 ? 1.0f : actr);
+    const float th = tanh_fast(cur.cc);        // backward_nonlingate recomputes tanh(state) (same form as the forward)
+    const float gth = mul_quad_bcast<2>(actr, fmaf(-th, th, 1.0f));   // state.d += (1-t^2) * (go*out.d): (1-t^2)*go
     // backward_statemem (clstm_compute.cc:509-515); c_{-1} = 0 reproduces "gf.d untouched when last < 0"
-    float c_m1 = s >= 1 ? nxt.cc : 0.0f;
+    float c_m1 = nxt.cc;   // own step s-1's c; the set loaded for "step -1" read out of range = 0
     OPAQUE(c_m1);   // otherwise hipcc branches around the wait for this load for the lanes that do not use it
     // this lane's gate delta is ONE product of two selected factors (selects, no exec-masked branches):
     //   gi.d = dc*ci   gf.d = dc*c_{s-1}   go.d = tanh(c)*out.d   ci.d = dc*gi
-    const float flo = gb0 ? c_m1 : ci, fhi = gb0 ? gi : th;   // two-level select on the lane's gate bits
-    float fb = deriv * (gb1 ? fhi : flo);
+    // lanes 0 and 3 of a quad need each other's activation (ci / gi): one mirrored quad permutation
+    const float mir = quad_mirror(actr);
+    const float mid = gb0 ? c_m1 : th;                    // lane 1: c_{s-1}, lane 2: tanh(c)
+    float fb = deriv * (gb0 == gb1 ? mir : mid);
     OPAQUE(fb);     // really before the mat-vec
     // dh_rec[k] = sum_{g,j} R_g[j][k] * delta_g[j](s+1)      [backward_lin1 recurrent half +
     //                                                         backward_stack_delay, :294-304,:398-410]
@@ -325,7 +368,7 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
     k += quad_xor2(k);
     const float dh = cur.dh + k;               // out[s].d = delta from above + recurrent delta, clstm.cc:626-628 + :646
     const float dc = dc_carry + gth * dh;
-    dc_carry = dc * gf;
+    dc_carry = mul_quad_bcast_old<1>(actr, dc);   // c_{s-1}.d += c.d * gf (gf broadcast folded into the multiply)
     const float delta = (g == 2 ? dh : dc) * fb;
     buf_store(dbuf, gl + fr(s) * gstride4, delta);
     *dw = delta;

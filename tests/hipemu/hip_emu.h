@@ -74,6 +74,10 @@ struct float4 { float x, y, z, w; };
 typedef float f32x2 __attribute__((vector_size(8)));
 inline f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return a * b + c; }
 inline f32x2 splat2(float x) { return (f32x2){x, x}; }
+inline f32x2 pair_lo(const f32x4& v) { return (f32x2){v.v[0], v.v[1]}; }
+inline f32x2 pair_hi(const f32x4& v) { return (f32x2){v.v[2], v.v[3]}; }
+inline f32x2 fma2_lo(f32x2 w, f32x2 hp, f32x2 acc) { return (f32x2){fmaf(w[0], hp[0], acc[0]), fmaf(w[1], hp[0], acc[1])}; }
+inline f32x2 fma2_hi(f32x2 w, f32x2 hp, f32x2 acc) { return (f32x2){fmaf(w[0], hp[1], acc[0]), fmaf(w[1], hp[1], acc[1])}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
 // ---- block / wave runtime -----------------------------------------------------------
@@ -123,6 +127,10 @@ inline float add_wave_shr1(float old, float a, float b) { const float s = wave_s
 inline float quad_xor1(float x) { return wave_shfl(x, emu_lane() ^ 1); }
 inline float quad_xor2(float x) { return wave_shfl(x, emu_lane() ^ 2); }
 template <int I> inline float quad_bcast(float x) { return wave_shfl(x, (emu_lane() & ~3) | I); }
+template <int I> inline float mul_quad_bcast(float x, float y) { return quad_bcast<I>(x) * y; }
+template <int I> inline float fmac_quad_bcast(float acc, float x, float y) { return fmaf(quad_bcast<I>(x), y, acc); }
+template <int I> inline float mul_quad_bcast_old(float x, float y) { return quad_bcast<I>(x) * y; }
+inline float quad_mirror(float x) { return wave_shfl(x, emu_lane() ^ 3); }
 template <int N> inline float row_ror(float x) {
   // DPP row_ror:N -- lane i of a 16-lane row receives the value of lane (i+N)%16 of that row
   int l = emu_lane();
