@@ -16,6 +16,7 @@
 #include "devintrin.h"
 #include "gemm_mfma.h"
 #include "gemm_bf16.h"
+#include "gemm_dw.h"
 #include "softmax_fused.h"
 #include "lstm_seq.h"
 #include "lstm_wide.h"
@@ -475,6 +476,25 @@ struct Net {
   DevBuf<float> dec_val, lat;
   DevBuf<long long> lat_off;
   Timing timing;
+  // --- weight-gradient GEMM beside the backward recurrence (gemm_dw.h) ---
+  static const int PROG_LINES = 2048;                          // overlap only for minibatches up to this many lines
+  static const int PROG_WORDS = 2 * PROG_LINES * PROG_STRIDE;   // progress words at the tail of a narrow layer's D allocation: [ndir][bs], one per 128 B
+  // CLSTM_OVERLAP / clstm_net_set_overlap: 0 (default) off; 1: on for batches large enough; 2: always (tests force
+  // the path onto tiny nets).  OFF by default -- measured on MI355X at the bench shape (profiles/r02_overlap_*.txt):
+  // the kernels do overlap, but the f32 GEMM needs ~105 us on the 128 CUs the recurrence leaves it (52 us on 256), so
+  // ~45 us of it still trail the 95 us recurrence, and while both run every other kernel of the step slows down by
+  // 10-20 % (chip-wide clock under the higher load): 0.443 ms per step against 0.377 ms with one stream.
+  int overlap = getenv("CLSTM_OVERLAP") ? atoi(getenv("CLSTM_OVERLAP")) : 0;
+  struct Side {   // two streams with complementary CU masks + the events of the fork / join
+    hipStream_t rec = nullptr, side = nullptr;
+    hipEvent_t fork{}, rec_done{}, side_done{};
+    bool tried = false, ok = false;
+  } os;
+  DevBuf<int> dw_ktab, dw_slabs, dw_timeouts;
+  std::vector<int> dw_key;        // line offsets the tables were built for
+  int dw_nslabs = 0, dw_slabs_per_dir = 0, dw_ntiles_max = 0;
+  int prog_base = 1024;           // grows with every backward launch: stale progress words never look complete
+  long long dw_launches = 0;      // overlapped backward passes so far (tests check the path was taken)
   Comm* comm = nullptr;         // data-parallel ranks: all-reduce of g before the update (not owned)
 
   hipStream_t stream() const { return g_stream; }
@@ -610,7 +630,7 @@ struct Net {
           CLSTM_LAUNCH(k_fill_col0, dim3(nblocks(rows)), dim3(256), 0, s, y.H.p, rows, y.ldh, y.hofs - 1);
         }
       }
-      y.D.reserve((size_t)N * ndir * 4 * y.no);
+      y.D.reserve((size_t)N * ndir * 4 * y.no + (y.wide ? 0 : PROG_WORDS + 64));
       y.dH.reserve((size_t)N * ndir * y.no);
       y.S.reserve((size_t)N * ndir * y.lds + 64);
     }
@@ -635,6 +655,7 @@ struct Net {
 
   void forward() {
     REQUIRE(N > 0, "set_batch first");
+    if (getenv("CLSTM_OVERLAP_DRY")) (void)side_streams();   // experiment: the side streams exist but are never used
     flush_line_off();
     repack();
     hipStream_t s = stream();
@@ -700,6 +721,159 @@ struct Net {
     return (int)want;
   }
 
+  // ---- overlap machinery ---------------------------------------------------------------------------------------
+  // Streams with complementary CU masks (measured, profiles/r02_ubench_cumask.txt: mask bit i -> XCD i % 8, then
+  // shader engine (i / 8) % 4 of that XCD, then CU; the two masks below give each stream two whole shader engines =
+  // 16 CUs of every XCD, and kernels on them overlap fully).  Every XCD keeps CUs in both masks: a mask that
+  // emptied an XCD would strand that XCD's share of every grid.
+  bool side_streams() {
+#ifdef CLSTM_HIP_EMU
+    os.tried = os.ok = true;     // emulator: launches are synchronous, producer first (same code path, serial)
+    return true;
+#else
+    if (os.tried) return os.ok;
+    os.tried = true;
+    if (device_cu_count() != 256) return false;
+    uint32_t ma[8] = {0}, mb[8] = {0};
+    for (int i = 0; i < 256; i++) ((((i >> 3) ^ i) & 1) == 0 ? ma : mb)[i / 32] |= 1u << (i % 32);
+    // CLSTM_OVERLAP_MASK=0 (experiment): two plain streams, the kernels share CUs
+    const bool masked = !(getenv("CLSTM_OVERLAP_MASK") && atoi(getenv("CLSTM_OVERLAP_MASK")) == 0);
+    if (masked) {
+      if (hipExtStreamCreateWithCUMask(&os.rec, 8, ma) != hipSuccess || hipExtStreamCreateWithCUMask(&os.side, 8, mb) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+      }
+    } else {
+      HIPCHECK(hipStreamCreateWithFlags(&os.rec, hipStreamNonBlocking));
+      HIPCHECK(hipStreamCreateWithFlags(&os.side, hipStreamNonBlocking));
+    }
+    HIPCHECK(hipEventCreateWithFlags(&os.fork, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&os.rec_done, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&os.side_done, hipEventDisableTiming));
+    os.ok = true;
+    return true;
+#endif
+  }
+  bool overlap_eligible(const Layer& y) {
+    if (!overlap || y.wide || y.no % 16 == 0) return false;          // the reporting lane must own no cell
+    if (bs > PROG_LINES) return false;
+    if (overlap < 2 && (tmax < 64 || N < 2048)) return false;        // too small to be worth the fork / join
+    if ((double)y.D.cap * 4.0 >= 2147483000.0) return false;         // 32-bit byte offsets inside one descriptor
+    return side_streams();
+  }
+  // k-tile tables and slabs of the chunked weight-gradient GEMM for the current batch geometry (rebuilt only when the
+  // line lengths change).  Chunks are ranges of recurrence iterations, longest first: the work left when the
+  // recurrence ends is what the last (short) chunk holds.
+  void build_dw_tables() {
+    if (dw_key == line_off_h && dw_nslabs > 0) return;
+    std::vector<int> cb;   // chunk ends (iterations), multiples of 8 except the last
+    {
+      static const int w[5] = {8, 6, 5, 4, 2};
+      int done = 0;
+      for (int c = 0; c < 5 && done < tmax; c++) {
+        int len = c == 4 ? tmax - done : std::max(16, (tmax * w[c] / 25 + 7) / 8 * 8);
+        if (done + len > tmax || tmax - (done + len) < 8) len = tmax - done;
+        done += len;
+        cb.push_back(done);
+      }
+    }
+    const int tiles_per_slab = std::max(8, (int)((N / 16 + 15) / 16));   // ~16 slabs per direction
+    std::vector<std::vector<int>> tab(ndir);                            // (first frame, count) pairs
+    struct Sl { int tb, nt, need, dir, chunk, part; };
+    std::vector<std::vector<Sl>> sl(ndir);
+    for (int dir = 0; dir < ndir; dir++) {
+      int cs = 0;
+      for (size_t c = 0; c < cb.size(); c++) {
+        const int ce = cb[c];
+        const int t0 = (int)tab[dir].size() / 2;
+        for (int b = 0; b < bs; b++) {
+          const int off = line_off_h[b], T = line_off_h[b + 1] - off;
+          if (T <= cs) continue;
+          const int e = std::min(ce, T);
+          // iterations [cs, e): dir 0 of the backward pass visits frame T-1-it, dir 1 frame it
+          const int f_lo = dir == 0 ? T - e : cs, f_hi = dir == 0 ? T - cs : e;
+          for (int f = f_lo; f < f_hi; f += 16) { tab[dir].push_back(off + f); tab[dir].push_back(std::min(16, f_hi - f)); }
+        }
+        const int nt = (int)tab[dir].size() / 2 - t0;
+        const int parts = std::max(1, (nt + tiles_per_slab - 1) / tiles_per_slab);
+        for (int p = 0; p < parts; p++) {
+          const int a0 = t0 + (int)((long long)nt * p / parts), a1 = t0 + (int)((long long)nt * (p + 1) / parts);
+          sl[dir].push_back(Sl{a0, a1 - a0, ce, dir, (int)c, p});
+        }
+        cs = ce;
+      }
+    }
+    dw_slabs_per_dir = (int)sl[0].size();
+    for (int dir = 1; dir < ndir; dir++) REQUIRE((int)sl[dir].size() == dw_slabs_per_dir, "internal: asymmetric slab lists");
+    dw_ntiles_max = 0;
+    for (int dir = 0; dir < ndir; dir++) dw_ntiles_max = std::max(dw_ntiles_max, (int)tab[dir].size() / 2);
+    // readiness order: chunk, then part, then direction
+    std::vector<DwSlab> slabs;
+    for (int i = 0; i < dw_slabs_per_dir; i++)
+      for (int dir = 0; dir < ndir; dir++) {
+        const Sl& x = sl[dir][i];
+        slabs.push_back(DwSlab{x.tb, x.nt, x.need, dir, dir * dw_slabs_per_dir + i, {0, 0, 0}});
+      }
+    dw_nslabs = (int)slabs.size();
+    const size_t nk = (size_t)ndir * dw_ntiles_max * 2, nsw = slabs.size() * sizeof(DwSlab) / sizeof(int);
+    dw_ktab.reserve(nk + 8);
+    dw_slabs.reserve(nsw + 8);
+    if (!dw_timeouts.p) dw_timeouts.reserve(4);
+    hipStream_t s = stream();
+    int* stage = (int*)ring.acquire((nk + nsw) * sizeof(int));
+    for (int dir = 0; dir < ndir; dir++) {
+      std::fill(stage + (size_t)dir * dw_ntiles_max * 2, stage + (size_t)(dir + 1) * dw_ntiles_max * 2, 0);
+      std::copy(tab[dir].begin(), tab[dir].end(), stage + (size_t)dir * dw_ntiles_max * 2);
+    }
+    memcpy(stage + nk, slabs.data(), nsw * sizeof(int));
+    HIPCHECK(hipMemcpyAsync(dw_ktab.p, stage, nk * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(dw_slabs.p, stage + nk, nsw * sizeof(int), hipMemcpyHostToDevice, s));
+    ring.commit(s);
+    dw_key = line_off_h;
+  }
+  // backward recurrence on the masked stream + the chunked weight-gradient GEMM on the complementary one
+  void backward_layer_overlapped(Layer& y, LstmSeqArgs a, int R, int Cn) {
+    hipStream_t s = stream();
+    build_dw_tables();
+    const int M = ndir * 4 * y.no;
+    const long long prog_off = (long long)y.D.cap - 64 - PROG_WORDS;
+    REQUIRE(prog_off >= (long long)N * M, "internal: progress words overlap the deltas");
+    prog_base += tmax + 64;
+    dw_launches++;
+    if (prog_base > (1 << 30)) prog_base = 1024;   // (words left from ~5 million launches ago could look complete: harmless in practice, D is rewritten)
+    a.prog_off = prog_off;
+    a.prog_base = prog_base;
+    partial.reserve((size_t)ndir * dw_slabs_per_dir * R * Cn);
+    GemmDwArgs g{};
+    g.S = y.S.p; g.sdir = (long long)N * y.lds; g.lds = y.lds; g.s_elems = (long long)N * ndir * y.lds + 3;
+    g.D = y.D.p; g.M = M; g.no4 = 4 * y.no; g.d_elems = (long long)N * M + 3;
+    g.ktab = dw_ktab.p; g.ntiles_max = dw_ntiles_max; g.slabs = (const DwSlab*)dw_slabs.p; g.nslabs = dw_nslabs;
+    g.prog = (const int*)(y.D.p + prog_off); g.line_off = line_off.p; g.bs = bs; g.prog_base = prog_base;
+    g.partial = partial.p; g.R = R; g.Cn = Cn;
+    g.gx = (unsigned)((Cn + GEMM_BT - 1) / GEMM_BT); g.gy = (unsigned)((R + GEMM_BT - 1) / GEMM_BT);
+    g.timeouts = dw_timeouts.p;
+    const unsigned nblk = (unsigned)((dw_nslabs + 7) / 8) * 8u * g.gx * g.gy;
+    hipStream_t srec = os.rec ? os.rec : s, sside = os.side ? os.side : s;
+    if (os.rec) {
+      HIPCHECK(hipEventRecord(os.fork, s));
+      HIPCHECK(hipStreamWaitEvent(srec, os.fork, 0));
+      HIPCHECK(hipStreamWaitEvent(sside, os.fork, 0));
+    }
+    timing.begin("lstm_bwd", srec);
+    launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, srec);
+    timing.end(srec);
+    timing.begin("gemm_gates_dw", sside);
+    CLSTM_LAUNCH(gemm_dw_kernel, dim3(nblk), dim3(256), 0, sside, g);
+    timing.end(sside);
+    check_launch();
+    if (os.rec) {
+      HIPCHECK(hipEventRecord(os.rec_done, srec));
+      HIPCHECK(hipEventRecord(os.side_done, sside));
+      HIPCHECK(hipStreamWaitEvent(s, os.rec_done, 0));
+      HIPCHECK(hipStreamWaitEvent(s, os.side_done, 0));
+    }
+  }
+
   void backward() {
     REQUIRE(N > 0, "set_batch first");
     flush_line_off();
@@ -732,13 +906,22 @@ struct Net {
       LstmSeqArgs a{};
       a.Rpk = y.Rb; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = y.dH.p; a.D = y.D.p;
       a.line_off = line_off.p; a.no = y.no; a.ndir = ndir;
+      // W.d += delta [1; x_t; h_{t-1}]^T for the four gates of each direction
+      // (both directions in one batched launch: half the slabs per direction fill the chip)
+      const int R = 1 + y.ni + y.no, Cn = 4 * y.no;
+      int ns;
+      a.prog_off = -1; a.prog_base = 0;
+      if (!bf16_gemm && overlap_eligible(y)) {
+        // the recurrence and the weight-gradient GEMM run side by side (gemm_dw.h)
+        backward_layer_overlapped(y, a, R, Cn);
+        ns = dw_slabs_per_dir;
+        timing.begin("reduce_scatter", s);
+      } else {
       timing.begin("lstm_bwd", s);
       if (y.wide) launch_lstm_wide(false, wide_args(y, false), tmax, coop_sync, step_graphs, s);
       else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
-      // W.d += delta [1; x_t; h_{t-1}]^T for the four gates of each direction
-      // (both directions in one batched launch: half the slabs per direction fill the chip)
-      const int R = 1 + y.ni + y.no, Cn = 4 * y.no, ns = pick_split(R, Cn, ndir);
+      ns = pick_split(R, Cn, ndir);
       partial.reserve((size_t)ndir * ns * R * Cn);
       timing.begin("gemm_gates_dw", s);
       if (bf16_gemm)
@@ -749,6 +932,7 @@ struct Net {
         gemm_f32<GEMM_MC, GEMM_MC>(s, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
                                    gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
                                    StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns, ndir);
+      }
       {
         const ReduceDesc gates{partial.p, y.moff, 0LL, ns, ndir, R, Cn, y.no};
         ReduceDesc extra{};   // empty unless this is the top layer
@@ -1386,6 +1570,25 @@ int clstm_allreduce_flat(clstm_comm* c, float* buf_d, long long n) {
   ABI_BEGIN
   REQUIRE(c && buf_d && n >= 0, "bad all-reduce arguments");
   if (n > 0) c->c.allreduce(buf_d, n, g_stream);
+  ABI_END
+}
+int clstm_net_set_overlap(clstm_net* h, int mode) {
+  ABI_BEGIN
+  REQUIRE(mode >= 0 && mode <= 2, "overlap mode: 0 off, 1 on where it pays, 2 always (tests)");
+  h->net.overlap = mode;
+  ABI_END
+}
+int clstm_net_overlap_stats(clstm_net* h, long long* launches, int* timeouts) {
+  ABI_BEGIN
+  Net& n = h->net;
+  if (launches) *launches = n.dw_launches;
+  if (timeouts) {
+    *timeouts = 0;
+    if (n.dw_timeouts.p) {
+      HIPCHECK(hipStreamSynchronize(g_stream));
+      HIPCHECK(hipMemcpy(timeouts, n.dw_timeouts.p, sizeof(int), hipMemcpyDeviceToHost));
+    }
+  }
   ABI_END
 }
 int clstm_net_set_comm(clstm_net* h, clstm_comm* c) { h->net.comm = c ? &c->c : nullptr; return 0; }

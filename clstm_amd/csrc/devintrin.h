@@ -227,6 +227,31 @@ DEVFN void buf_store_dev(BufF32 b, unsigned byte_off, float v) {
 DEVFN void buf_store4_dev(BufF32 b, unsigned byte_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b.r, byte_off, 0, 16);
 }
+// Producer / consumer pairs in DIFFERENT launches that run concurrently (lstm_bwd -> gemm_dw.h): system-scope
+// write-through stores and system-scope loads on both sides (guide: "sc0 sc1 stores and loads both sides" needs no
+// fences; per-XCD L2s are not coherent with each other)
+DEVFN void buf_store_wt(BufF32 b, unsigned byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.r, byte_off, 0, 17);
+}
+DEVFN f32x4 buf_load4_wt(BufF32 b, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, byte_off, 0, 17));
+}
+DEVFN int load_i32_wt(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+DEVFN void store_i32_wt(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+DEVFN void atomic_add_i32(int* p, int v) { atomicAdd(p, v); }
+DEVFN void sleep_some() { __builtin_amdgcn_s_sleep(16); }
+// park the wave for roughly 0.35 us per recurrence iteration still missing (s_sleep 13 ~ 832 cycles), at most ~14 us
+DEVFN void sleep_iterations(int n) {
+  n = n > 40 ? 40 : n;
+  for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(13);
+}
+DEVFN int wave_max_i(int x) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const int y = __shfl_xor(x, m, 64); x = y > x ? y : x; }
+  return x;
+}
+DEVFN void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // this wave's loads returned, stores acknowledged
+DEVFN unsigned mad_u24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }   // v_mad_u32_u24 (operands < 2^24)
 constexpr int GRID_WATCHDOG_SPINS = 1 << 21;   // ~seconds of polling before a stuck barrier is reported
 // All workgroups of a cooperative launch meet here.  sync[0]: ticket counter (target = arrivals expected
 // so far), sync[1]: watchdog flag.  Returns false (uniformly within the workgroup) once any workgroup has
@@ -275,6 +300,9 @@ DEVFN T* dyn_smem() {
 #define CLSTM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
 #endif  // CLSTM_HIP_EMU
+
+// progress words (lstm_seq.h -> gemm_dw.h) sit one per 128-byte line: a workgroup rewrites its word every step
+constexpr int PROG_STRIDE = 32;
 
 // ---------------------------------------------------------------------------------------
 // activation functions shared by every kernel (and replicated in numpy by the CPU tests)

@@ -53,14 +53,27 @@ struct LstmSeqArgs {
   int lds, sofs;        //   the forward pass deposits h_{t-1} at column sofs = 1 + ni of the NEXT step's row
   long long sdir;       //   floats between the two directions' S arrays
   long long* prof;      // diagnostics build (-DCLSTM_LSTM_PROF) only: [8 waves][8] summed phase cycles of workgroup 0
+  // backward only -- progress words for a concurrently running consumer of D (gemm_dw.h): word (dir, line) lives
+  // prog_off floats behind D[0] (the tail of D's allocation, so that the per-step delta store reaches it through the
+  // same descriptor) and counts the iterations of that line whose deltas are complete in memory.  -1: none.
+  long long prog_off;
+  int prog_base;        // value that means "0 iterations complete" for this launch (monotonic across launches)
 };
 
+// One workgroup per CU, at most two of its waves per SIMD: tell hipcc, or its scheduler trades the up-front issue of
+// a step's LDS reads for a register count that would admit a third wave nobody launches (seen: 166 -> 148 VGPRs,
+// every ds_read_b128 followed by lgkmcnt(0), backward 92 -> 104 us).
+#ifdef CLSTM_HIP_EMU
+#define CLSTM_TWO_WAVES_PER_SIMD
+#else
+#define CLSTM_TWO_WAVES_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 2)))
+#endif
 constexpr int lstm_qstride(int nk4) { return 4 * nk4 + ((nk4 & 1) ? 0 : 4); }
 
 // NK4: float4 groups of k per lane (register / LDS capacity 4*NK4); KU <= 4*NK4: k values a lane really
 // owns = cells per quarter.  (7, 25) is the 100-cell instantiation: 50 instead of 56 packed FMAs per step.
 template <int NK4, int KU>
-__global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
+__global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_kernel(LstmSeqArgs a) {
   constexpr int KQP = 4 * NK4;
   constexpr int QS = KQP + ((NK4 & 1) ? 0 : 4);
   constexpr int HB = 4 * QS;
@@ -186,13 +199,17 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
     LSTM_STAMP(0);   // loop overhead since the barrier
     // (hipcc copies element w of every ds_read_b128 into a fresh pair -- 6 v_mov_b32 per step; spelling the
     //  FMAs as inline asm with op_sel removes them but serialises the LDS reads behind single waits: not kept)
+    // All LDS reads of the step first, pinned in front of the FMAs (see the backward kernel).
+    float4 hv[NK4];
+#pragma unroll
+    for (int j = 0; j < NK4; j++) hv[j] = *reinterpret_cast<const float4*>(hq + 4 * j);
+    SCHED_FENCE();
 #pragma unroll
     for (int j = 0; j < NK4; j++) {
-      const float4 hv = *reinterpret_cast<const float4*>(hq + 4 * j);
-      if (4 * j < KU) { a01 = fma2(w01[4 * j], splat2(hv.x), a01); a23 = fma2(w23[4 * j], splat2(hv.x), a23); }
-      if (4 * j + 1 < KU) { a01 = fma2(w01[4 * j + 1], splat2(hv.y), a01); a23 = fma2(w23[4 * j + 1], splat2(hv.y), a23); }
-      if (4 * j + 2 < KU) { a01 = fma2(w01[4 * j + 2], splat2(hv.z), a01); a23 = fma2(w23[4 * j + 2], splat2(hv.z), a23); }
-      if (4 * j + 3 < KU) { a01 = fma2(w01[4 * j + 3], splat2(hv.w), a01); a23 = fma2(w23[4 * j + 3], splat2(hv.w), a23); }
+      if (4 * j < KU) { a01 = fma2(w01[4 * j], splat2(hv[j].x), a01); a23 = fma2(w23[4 * j], splat2(hv[j].x), a23); }
+      if (4 * j + 1 < KU) { a01 = fma2(w01[4 * j + 1], splat2(hv[j].y), a01); a23 = fma2(w23[4 * j + 1], splat2(hv[j].y), a23); }
+      if (4 * j + 2 < KU) { a01 = fma2(w01[4 * j + 2], splat2(hv[j].z), a01); a23 = fma2(w23[4 * j + 2], splat2(hv[j].z), a23); }
+      if (4 * j + 3 < KU) { a01 = fma2(w01[4 * j + 3], splat2(hv[j].w), a01); a23 = fma2(w23[4 * j + 3], splat2(hv[j].w), a23); }
     }
     // (early role: the pins end only here, so that the LDS reads above cannot land in the store-data registers --
     //  hipcc guards an LDS return into such a register with s_waitcnt vmcnt(0), i.e. it would wait for the stores
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(64 * NK4) void lstm_fwd_kernel(LstmSeqArgs a) {
 }
 
 template <int NK4, int KU>
-__global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
+__global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_kernel(LstmSeqArgs a) {
   constexpr int SLP = 4 * NK4;
   constexpr int QS = SLP + ((NK4 & 1) ? 0 : 4);
   constexpr int DB = 16 * QS;
@@ -281,7 +298,12 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
 
   const int off = a.line_off[b];
   const int T = a.line_off[b + 1] - off;
-  if (T <= 0) return;
+  if (T <= 0) {   // an empty line is complete at once
+    if (a.prog_off >= 0 && tid == 0) {
+      store_i32_wt(reinterpret_cast<int*>(a.D + a.prog_off) + ((size_t)dir * gridDim.x + b) * PROG_STRIDE, a.prog_base);
+    }
+    return;
+  }
 #ifdef CLSTM_PRIO
   if (wave >= CLSTM_PRIO) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -289,10 +311,23 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
   const int dslot = (pidx / SL) * QS + (pidx % SL);
   const unsigned gstride4 = (unsigned)nd * 4 * no * 4, cstride4 = (unsigned)nd * no * 4;
   const BufF32 gbuf = make_buf(a.G + (size_t)off * (gstride4 / 4), (size_t)T * gstride4);
-  const BufF32 dbuf = make_buf(a.D + (size_t)off * (gstride4 / 4), (size_t)T * gstride4);
+  // Progress reporting (a.prog_off >= 0): the LAST lane of the workgroup owns no cell when 4*no is not a multiple of
+  // the wave size; it rides the per-step delta store -- same instruction, its own address (lane stride 0) and data --
+  // and writes, at iteration `it`, that iterations < it - 3 of this line are complete: every wave has passed the
+  // barrier of iteration it-1, i.e. has consumed operands whose loads were issued behind its delta store of
+  // iteration it-4, and VMEM operations of a wave complete in order (vmcnt).  Stores are written through.
+#ifdef CLSTM_NO_REPORT   // (experiment: the kernel without the progress-reporting lane)
+  const bool report = false;
+#else
+  const bool report = a.prog_off >= 0;
+#endif
+  const bool tagl = report && tid == nthreads - 1;            // requires cell(tid) >= no (checked by the host)
+  const long long prog_rel = a.prog_off + ((long long)dir * gridDim.x + b) * PROG_STRIDE - (long long)off * (gstride4 / 4);
+  const BufF32 dbuf = make_buf(a.D + (size_t)off * (gstride4 / 4), report ? (size_t)(prog_rel + 1) * 4 : (size_t)T * gstride4);
   const BufF32 cbuf = make_buf(a.C + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
   const BufF32 hbuf = make_buf(a.dH + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
   const unsigned gl = valid ? ((unsigned)dir * 4 * no + cell * 4 + g) * 4u : BUF_OOB_BASE;
+  const unsigned ptag = (unsigned)(prog_rel * 4);                    // the reporting lane's store offset (every step the same)
   const unsigned cl = valid ? ((unsigned)dir * no + cell) * 4u : BUF_OOB_BASE;
   auto fr = [&](int s) -> unsigned {  // own step s -> frame, clamped at the first step
     const int sc = s > 0 ? s : 0;
@@ -348,14 +383,20 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
     // dh_rec[k] = sum_{g,j} R_g[j][k] * delta_g[j](s+1)      [backward_lin1 recurrent half +
     //                                                         backward_stack_delay, :294-304,:398-410]
     f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
+    // every LDS read of the step is issued before the first FMA, and pinned there: left to itself hipcc sometimes
+    // (depending on unrelated code elsewhere in the step) re-uses one register quadruple for all of them and waits
+    // for each read in turn -- seven exposed LDS latencies per step (backward 92 -> 104 us)
+    float4 dv[NK4];
+#pragma unroll
+    for (int j = 0; j < NK4; j++) dv[j] = *reinterpret_cast<const float4*>(dq + 4 * j);
+    SCHED_FENCE();
 #pragma unroll
     for (int j = 0; j < NK4; j++) {
-      const float4 dv = *reinterpret_cast<const float4*>(dq + 4 * j);
       // pairs KU .. 4*NK4-1 of a slice are zero padding (SL = ceil(4 no / 16) <= KU)
-      if (4 * j < KU) { a01 = fma2(wb01[4 * j], splat2(dv.x), a01); a23 = fma2(wb23[4 * j], splat2(dv.x), a23); }
-      if (4 * j + 1 < KU) { a01 = fma2(wb01[4 * j + 1], splat2(dv.y), a01); a23 = fma2(wb23[4 * j + 1], splat2(dv.y), a23); }
-      if (4 * j + 2 < KU) { a01 = fma2(wb01[4 * j + 2], splat2(dv.z), a01); a23 = fma2(wb23[4 * j + 2], splat2(dv.z), a23); }
-      if (4 * j + 3 < KU) { a01 = fma2(wb01[4 * j + 3], splat2(dv.w), a01); a23 = fma2(wb23[4 * j + 3], splat2(dv.w), a23); }
+      if (4 * j < KU) { a01 = fma2(wb01[4 * j], splat2(dv[j].x), a01); a23 = fma2(wb23[4 * j], splat2(dv[j].x), a23); }
+      if (4 * j + 1 < KU) { a01 = fma2(wb01[4 * j + 1], splat2(dv[j].y), a01); a23 = fma2(wb23[4 * j + 1], splat2(dv[j].y), a23); }
+      if (4 * j + 2 < KU) { a01 = fma2(wb01[4 * j + 2], splat2(dv[j].z), a01); a23 = fma2(wb23[4 * j + 2], splat2(dv[j].z), a23); }
+      if (4 * j + 3 < KU) { a01 = fma2(wb01[4 * j + 3], splat2(dv[j].w), a01); a23 = fma2(wb23[4 * j + 3], splat2(dv[j].w), a23); }
     }
     // reduce-scatter over the row of 16 slices: the quad of cell Q ends with dh_rec of that cell.
     // ror:8 pairs quad Q with Q^2, half_mirror pairs Q with Q^1 (slice j with 3-j, which the
@@ -370,9 +411,17 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
     const float dc = dc_carry + gth * dh;
     dc_carry = mul_quad_bcast_old<1>(actr, dc);   // c_{s-1}.d += c.d * gf (gf broadcast folded into the multiply)
     const float delta = (g == 2 ? dh : dc) * fb;
-    buf_store(dbuf, gl + fr(s) * gstride4, delta);
+    // (the reporting lane stores the progress word instead: iterations < it - 3 are complete)
+    // (address and data by select: a per-lane stride through v_mad_u32_u24 made hipcc serialise the step's LDS reads)
+    const float sdat = tagl ? __builtin_bit_cast(float, a.prog_base + (T - 1 - s) - 3) : delta;
+    const unsigned soff = tagl ? ptag : gl + fr(s) * gstride4;
+#ifdef CLSTM_D_PLAIN   // (experiment: what the write-through costs; not valid with a concurrent consumer)
+    buf_store(dbuf, soff, sdat);
+#else
+    buf_store_wt(dbuf, soff, sdat);
+#endif
     *dw = delta;
-    ka = delta;
+    ka = sdat;
     __syncthreads();
   };
   // 3 operand sets x 2 LDS phases: the pattern repeats every 6 steps
@@ -390,6 +439,11 @@ __global__ __launch_bounds__(64 * NK4) void lstm_bwd_kernel(LstmSeqArgs a) {
   if (s >= 2) step(s - 2, X2, X0, X1, rdA, wrA, ka2);
   if (s >= 3) step(s - 3, X0, X1, X2, rdB, wrB, ka0);
   if (s >= 4) step(s - 4, X1, X2, X0, rdA, wrA, ka1);
+  if (report) {   // the line is complete: drain this wave's stores, meet, publish "all T iterations"
+    drain_vmem();
+    __syncthreads();
+    if (tagl) buf_store_wt(dbuf, ptag, __builtin_bit_cast(float, a.prog_base + T));
+  }
 }
 
 }  // namespace clstm

@@ -231,6 +231,15 @@ class Network:
         self.lib.call("clstm_net_outputs", self.h, C.byref(p), C.byref(d))
         return p.value, d.value
 
+    def set_overlap(self, mode):
+        """0: weight-gradient GEMM after the backward recurrence; 1: beside it where it pays (default); 2: always."""
+        self.lib.call("clstm_net_set_overlap", self.h, int(mode))
+
+    def overlap_stats(self):
+        n, t = C.c_longlong(), C.c_int()
+        self.lib.call("clstm_net_overlap_stats", self.h, C.byref(n), C.byref(t))
+        return n.value, t.value
+
     # -- timing (bench.py) ---------------------------------------------------------------------
     def enable_timing(self, on=True):
         self.lib.call("clstm_net_enable_timing", self.h, int(on))

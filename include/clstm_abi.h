@@ -180,6 +180,13 @@ int clstm_net_get_state_h(clstm_net* net, int layer, int dir, int which, float* 
 /* name and average device time (ms, hipEvent-timed on the library's stream) of the most
  * recent forward/backward kernels -- used by bench.py for the roofline object.
  * Enable with clstm_net_enable_timing(net, 1). */
+/* The weight-gradient GEMM of a narrow BiLSTM layer runs beside the backward recurrence (two streams with
+ * complementary CU masks; csrc/gemm_dw.h).  mode 0 (default): off (one stream, GEMM after the recurrence); 1:
+ * on for batches large enough; 2: always (tests).  Results are the same sums in a different slab order.
+ * Off by default: measured slower on MI355X at the bench shape.
+ * stats: overlapped backward passes so far; slabs that gave up waiting for the recurrence (must stay 0). */
+int clstm_net_set_overlap(clstm_net* net, int mode);
+int clstm_net_overlap_stats(clstm_net* net, long long* launches, int* timeouts);
 int clstm_net_enable_timing(clstm_net* net, int on);
 int clstm_net_kernel_time_ms(clstm_net* net, const char* kernel_name, double* total_ms, int* launches);
 int clstm_net_reset_timing(clstm_net* net);
