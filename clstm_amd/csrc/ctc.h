@@ -24,6 +24,7 @@
 // occurs k >= 3 times in one transcript is accumulated in float (<= 1 ulp from the reference's
 // double accumulator narrowed to Float).
 #pragma once
+#include <type_traits>
 #include "devintrin.h"
 #define CR_FN DEVFN
 #include "cr_math.h"
@@ -32,7 +33,8 @@ namespace clstm {
 
 constexpr int CTC_THREADS = 512;   // waves 0-3: forward recursion, waves 4-7: reversed-lattice recursion
 constexpr int CTC_GROUP = 256;     // lanes per recursion when S > 64
-constexpr int CTC_RMAX = 2;        // up to 512 target states per line
+constexpr int CTC_RMAX = 8;        // up to 2048 target states per line (transcripts of up to 1023 labels); lines with
+                                   // <= 512 states run the 2-states-per-lane instantiation
 constexpr int CTC_MLP = 8;         // independent global loads a thread keeps in flight in the streaming phases
 constexpr int CTC_MAX_TILE = 256;  // frames per LDS tile (phases A and E)
 
@@ -145,8 +147,11 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, float* 
       if (i < T) step(i, lmA, kaA);
     }
   } else {
-    const int grp = wave >> 2, u = tid & (CTC_GROUP - 1);
     const int R = (S + CTC_GROUP - 1) / CTC_GROUP;
+    // RM: states a lane can hold (2 for S <= 512, else CTC_RMAX): every frame issues RM prefetches and RM guarded updates
+    auto run = [&](auto rm_tag) {
+    constexpr int RM = decltype(rm_tag)::value;
+    const int grp = wave >> 2, u = tid & (CTC_GROUP - 1);
     float* vxg = vx + grp * 2 * (CTC_GROUP + 2);
     vxg[u] = (float)(-5.0 * (u * R + R - 1));
     __syncthreads();
@@ -156,27 +161,27 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, float* 
       if (i >= T || j >= S) return BUF_OOB;
       return (unsigned)(rev ? (size_t)(T - 1 - i) * S + (S - 1 - j) : (size_t)i * S + j) * 4u;
     };
-    float v[CTC_RMAX], lmA[CTC_RMAX], lmB[CTC_RMAX], kaA[CTC_RMAX], kaB[CTC_RMAX];
+    float v[RM], lmA[RM], lmB[RM], kaA[RM], kaB[RM];
 #pragma unroll
-    for (int r = 0; r < CTC_RMAX; r++) {
+    for (int r = 0; r < RM; r++) {
       const int j = u * R + r;
       v[r] = (float)(-5.0 * j);
       lmA[r] = buf_load(lmb, r < R ? loff(0, j) : BUF_OOB);
       lmB[r] = buf_load(lmb, r < R ? loff(1, j) : BUF_OOB);
       kaA[r] = kaB[r] = 0.0f;
     }
-    auto step = [&](const int i, float (&lmr)[CTC_RMAX], float (&ka)[CTC_RMAX]) {
+    auto step = [&](const int i, float (&lmr)[RM], float (&ka)[RM]) {
 #pragma unroll
-      for (int r = 0; r < CTC_RMAX; r++) KEEP_ALIVE(ka[r]);
+      for (int r = 0; r < RM; r++) KEEP_ALIVE(ka[r]);
       const float from_prev = vxg[(i & 1) * (CTC_GROUP + 2) + (u > 0 ? u - 1 : 0)];
-      float lmv[CTC_RMAX];
+      float lmv[RM];
 #pragma unroll
-      for (int r = 0; r < CTC_RMAX; r++) {
+      for (int r = 0; r < RM; r++) {
         lmv[r] = lmr[r];
         lmr[r] = buf_load(lmb, r < R ? loff(i + 2, u * R + r) : BUF_OOB);  // two frames ahead
       }
 #pragma unroll
-      for (int r = CTC_RMAX - 1; r >= 0; r--) {
+      for (int r = RM - 1; r >= 0; r--) {
         if (r < R) {
           const int j = u * R + r;
           float w = (r == 0) ? from_prev : v[r - 1];
@@ -190,7 +195,7 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, float* 
       }
       float last = v[0];
 #pragma unroll
-      for (int r = 1; r < CTC_RMAX; r++)
+      for (int r = 1; r < RM; r++)
         if (r == R - 1) last = v[r];
       vxg[((i + 1) & 1) * (CTC_GROUP + 2) + u] = last;
       __syncthreads();
@@ -201,6 +206,8 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, float* 
       step(i + 1, lmB, kaB);
     }
     if (i < T) step(i, lmA, kaA);
+    };
+    if (R <= 2) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, CTC_RMAX>{});
   }
 }
 
@@ -718,7 +725,14 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   // ---- D: per-state totals over time (double accumulator, floor 1e-9); x/total is evaluated as
   //         (float)((double)x * (1/total)): equal to the reference's (Float)(x/total) except for
   //         ~1e-8 of the values (1 ulp of double before the rounding to float) -----------------------
-  {
+  if (S > CTC_THREADS) {   // long transcripts (more states than threads): one thread per state, states in rounds
+    for (int s = tid; s < S; s += CTC_THREADS) {
+      double acc = 0.0;
+      for (int t = 0; t < T; t++) acc += (double)al[(size_t)t * S + s];
+      tot[s] = 1.0 / fmax(1e-9, acc);
+    }
+    __syncthreads();
+  } else {
     const int Q = CTC_THREADS / S > 8 ? 8 : CTC_THREADS / S;  // time chunks per state (S <= 512)
     if (tid < S * Q) {
       const int s = tid % S, q = tid / S;

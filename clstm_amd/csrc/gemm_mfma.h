@@ -41,12 +41,16 @@ struct GemmOperand {
 };
 
 // one workgroup of the GEMM: `lin` is its linear index in a (gx, gy, gz) grid
-template <int AMODE, int BMODE, class FE>
+// BK: contraction indices staged per barrier pair (16 or 32).  32 halves the barriers and LDS hand-overs per flop --
+// it pays where the k loop is long (the split-K weight-gradient GEMMs: K = frames of a slab) and costs registers
+// (two staging quadruples per operand and tile in flight) and LDS (2 x 32 x 80 floats).
+template <int AMODE, int BMODE, class FE, int BK = GEMM_BK>
 DEVFN void gemm_f32_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int ksplit, int nsplit,
                          const unsigned lin, const unsigned gx, const unsigned gy, const unsigned gz) {
+  constexpr int NP = BK / 16;   // staging passes of 16 contraction indices
   // smem: operand tiles during the k loop; the 64 x 64 output tile (row stride 68) during the epilogue
   float* As = smem;
-  float* Bs = smem + GEMM_BK * GEMM_LD;
+  float* Bs = smem + BK * GEMM_LD;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -86,20 +90,25 @@ DEVFN void gemm_f32_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R
   // Loads are issued unconditionally (tiles past the slab get an out-of-range offset, which the
   // descriptor drops without touching memory): with a fixed number of loads per phase the compiler
   // can count vmcnt exactly instead of draining the queue at every control-flow join.
-  auto load_tile = [&](int k0, f32x4& ra, f32x4& rb) {
-    const bool live = k0 < kend;
-    ra = buf_load4(abuf, live ? (a_base + (unsigned)k0 * a_kstep) * 4u : BUF_OOB);
-    rb = buf_load4(bbuf, live ? (b_base + (unsigned)k0 * b_kstep) * 4u : BUF_OOB);
+  auto load_tile = [&](int k0, f32x4 (&ra)[NP], f32x4 (&rb)[NP]) {
+#pragma unroll
+    for (int h = 0; h < NP; h++) {
+      const bool live = k0 + 16 * h < kend;
+      ra[h] = buf_load4(abuf, live ? (a_base + (unsigned)(k0 + 16 * h) * a_kstep) * 4u : BUF_OOB);
+      rb[h] = buf_load4(bbuf, live ? (b_base + (unsigned)(k0 + 16 * h) * b_kstep) * 4u : BUF_OOB);
+    }
   };
   // frames / contraction indices past the slab hold real data (next slab, next row): zero them.  Done
   // when the tile is staged, not when it is loaded -- touching the registers earlier would put a
   // vmcnt wait right behind the load and serialise the prefetch.
-  auto mask_tile = [&](int k0, f32x4& ra, f32x4& rb) {
+  auto mask_tile = [&](int k0, f32x4 (&ra)[NP], f32x4 (&rb)[NP]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      ra[i] = (k0 + a_k + (AMODE == GEMM_KC ? i : 0) < kend) ? ra[i] : 0.0f;
-      rb[i] = (k0 + b_k + (BMODE == GEMM_KC ? i : 0) < kend) ? rb[i] : 0.0f;
-    }
+    for (int h = 0; h < NP; h++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        ra[h][i] = (k0 + 16 * h + a_k + (AMODE == GEMM_KC ? i : 0) < kend) ? ra[h][i] : 0.0f;
+        rb[h][i] = (k0 + 16 * h + b_k + (BMODE == GEMM_KC ? i : 0) < kend) ? rb[h][i] : 0.0f;
+      }
   };
 
   f32x4 acc[2][2];
@@ -113,36 +122,39 @@ DEVFN void gemm_f32_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R
   // GEMM_PF k-tiles are in flight in registers: a tile's global loads are issued GEMM_PF iterations
   // before it is staged, which covers the ~2000-cycle HBM latency with MFMA work of the same workgroup
   // (the grids here are only 1-3 workgroups per CU, so there is little inter-workgroup overlap to lean on)
-  f32x4 ra[GEMM_PF], rb[GEMM_PF];
+  f32x4 ra[GEMM_PF][NP], rb[GEMM_PF][NP];
 #pragma unroll
   for (int p = 0; p < GEMM_PF; p++) {
-    load_tile(kbeg + p * GEMM_BK, ra[p], rb[p]);
+    load_tile(kbeg + p * BK, ra[p], rb[p]);
     SCHED_FENCE();   // same issue order as inside the loop, so the vmcnt at the loop head stays exact
   }
   const int fk = lane >> 4, fi = lane & 15;
-  for (int kb = kbeg; kb < kend; kb += GEMM_PF * GEMM_BK) {
+  for (int kb = kbeg; kb < kend; kb += GEMM_PF * BK) {
 #pragma unroll
     for (int p = 0; p < GEMM_PF; p++) {
-      const int k0 = kb + p * GEMM_BK;   // phases past the slab multiply zeros (no early exit: the
-                                         // straight-line body keeps the accumulators and vmcnt exact)
+      const int k0 = kb + p * BK;   // phases past the slab multiply zeros (no early exit: the
+                                    // straight-line body keeps the accumulators and vmcnt exact)
       mask_tile(k0, ra[p], rb[p]);
-      if (AMODE == GEMM_KC) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) As[(a_k + i) * GEMM_LD + a_mn] = ra[p][i];
-      } else {
-        *reinterpret_cast<f32x4*>(&As[a_k * GEMM_LD + a_mn]) = ra[p];
-      }
-      if (BMODE == GEMM_KC) {
+      for (int h = 0; h < NP; h++) {
+        if (AMODE == GEMM_KC) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) Bs[(b_k + i) * GEMM_LD + b_mn] = rb[p][i];
-      } else {
-        *reinterpret_cast<f32x4*>(&Bs[b_k * GEMM_LD + b_mn]) = rb[p];
+          for (int i = 0; i < 4; i++) As[(16 * h + a_k + i) * GEMM_LD + a_mn] = ra[p][h][i];
+        } else {
+          *reinterpret_cast<f32x4*>(&As[(16 * h + a_k) * GEMM_LD + a_mn]) = ra[p][h];
+        }
+        if (BMODE == GEMM_KC) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) Bs[(16 * h + b_k + i) * GEMM_LD + b_mn] = rb[p][h][i];
+        } else {
+          *reinterpret_cast<f32x4*>(&Bs[(16 * h + b_k) * GEMM_LD + b_mn]) = rb[p][h];
+        }
       }
       __syncthreads();
-      load_tile(k0 + GEMM_PF * GEMM_BK, ra[p], rb[p]);
+      load_tile(k0 + GEMM_PF * BK, ra[p], rb[p]);
       SCHED_FENCE();
 #pragma unroll
-      for (int kk = 0; kk < GEMM_BK; kk += 4) {
+      for (int kk = 0; kk < BK; kk += 4) {
         float af[2], bf[2];
 #pragma unroll
         for (int i = 0; i < 2; i++) {
@@ -196,11 +208,12 @@ DEVFN void gemm_f32_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R
       }
 }
 
-template <int AMODE, int BMODE, class FE>
+constexpr int gemm_smem_floats(int bk) { return 2 * bk * GEMM_LD > GEMM_BT * GEMM_LDO ? 2 * bk * GEMM_LD : GEMM_BT * GEMM_LDO; }
+template <int AMODE, int BMODE, class FE, int BK = GEMM_BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
                                                        int K, int ksplit, int nsplit) {
-  __shared__ __attribute__((aligned(16))) float smem[GEMM_BT * GEMM_LDO];
-  gemm_f32_body<AMODE, BMODE, FE>(smem, A, B, fe, R, Cn, K, ksplit, nsplit,
+  __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats(BK)];
+  gemm_f32_body<AMODE, BMODE, FE, BK>(smem, A, B, fe, R, Cn, K, ksplit, nsplit,
                                   blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y,
                                   gridDim.z);
 }
@@ -251,17 +264,17 @@ inline void gemm_f32_pair(hipStream_t stream, GemmProblem p1, FE1 fe1, GemmProbl
   const unsigned nb1 = p1.gx * p1.gy * p1.gz, nb2 = p2.gx * p2.gy * p2.gz;
   CLSTM_LAUNCH((gemm_f32_pair_kernel<A1, B1, FE1, A2, B2, FE2>), dim3(nb1 + nb2), dim3(256), 0, stream, p1, fe1, p2, fe2, nb1);
 }
-template <int AMODE, int BMODE, class FE>
+template <int AMODE, int BMODE, class FE, int BK = GEMM_BK>
 inline void gemm_f32(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int nsplit = 1,
                      int nbatch = 1) {
   if (R <= 0 || Cn <= 0) return;
   if (nsplit < 1) nsplit = 1;
   int ksplit = (K + nsplit - 1) / nsplit;
-  const int kq = nsplit > 1 ? GEMM_PF * GEMM_BK : GEMM_BK;   // whole pipeline rounds per slab
+  const int kq = nsplit > 1 ? GEMM_PF * BK : BK;   // whole pipeline rounds per slab
   ksplit = ((ksplit + kq - 1) / kq) * kq;
   if (ksplit < kq) ksplit = kq;
   dim3 grid((Cn + GEMM_BT - 1) / GEMM_BT, (R + GEMM_BT - 1) / GEMM_BT, nsplit * nbatch);
-  CLSTM_LAUNCH((gemm_f32_kernel<AMODE, BMODE, FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+  CLSTM_LAUNCH((gemm_f32_kernel<AMODE, BMODE, FE, BK>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
 }
 
 }  // namespace clstm

@@ -5,6 +5,7 @@
 // runs on the MI355X.
 #pragma once
 #include "model.h"
+#include <thread>
 #include "normalizer.h"
 #include "png_io.h"
 
@@ -121,6 +122,12 @@ struct CLSTMOCR {
     model.codec = codec_;
     attach();
   }
+  void createBidi2(const vector<int>& codec_, int nhidden, int nhidden2) {  // make_net("bidi2", ...), clstm_prefab.cc:86-109
+    LCG lcg;
+    model.create("bidi2", target_height, (int)codec_.size(), nhidden, nhidden2, lcg);
+    model.codec = codec_;
+    attach();
+  }
   void load(const string& fname) {  // clstmhl.h:157-175
     model.load(fname);
     attach();
@@ -160,6 +167,58 @@ struct CLSTMOCR {
     ustring r = fwdbwd(raw, target);
     update();
     return r;
+  }
+  // ---- a minibatch of lines per update (the batched MI355X path: all lines through ONE forward / CTC / backward,
+  // Params.d receives the SUM of the lines' gradients exactly as consecutive CLSTMOCR::fwdbwd calls without an
+  // update in between would leave it, clstmhl.h:201-217) ----------------------------------------------------
+  struct Prepared {          // host-side half of a minibatch: normalised frames + encoded transcripts
+    vector<int> T, L;
+    vector<float> frames;    // packed line after line, frame-major
+    Classes labels;          // packed transcripts
+    vector<ustring> targets;
+  };
+  // GPU-free: may run on a helper thread while the device works on the previous minibatch (uses only its own
+  // normaliser; `codec` is read-only after attach())
+  void prepare(Prepared& p, const vector<Image>& raws, const vector<ustring>& targets) const {
+    p.T.clear(); p.L.clear(); p.frames.clear(); p.labels.clear();
+    p.targets = targets;
+    CenterNormalizer nz;
+    nz.target_height = target_height;
+    Image img;
+    for (size_t b = 0; b < raws.size(); b++) {
+      nz.measure(raws[b]);
+      nz.normalize(img, raws[b]);
+      p.T.push_back(img.w);
+      p.frames.insert(p.frames.end(), img.d.begin(), img.d.end());
+      Classes tr;
+      codec.encode(tr, targets[b]);
+      p.L.push_back((int)tr.size());
+      p.labels.insert(p.labels.end(), tr.begin(), tr.end());
+    }
+  }
+  vector<ustring> train_batch(const Prepared& p) {
+    const int bs = (int)p.T.size();
+    chk(clstm_net_set_batch(net, p.T.data(), bs), "clstm_net_set_batch");
+    chk(clstm_net_set_inputs_h(net, p.frames.data()), "clstm_net_set_inputs_h");
+    chk(clstm_net_forward(net), "clstm_net_forward");
+    int N = 0;
+    for (int t : p.T) N += t;
+    vector<int> cls(N), loc(N), cnt(bs);
+    chk(clstm_net_decode(net, cls.data(), loc.data(), cnt.data()), "clstm_net_decode");
+    aligned.resize((size_t)N * nclasses);
+    Classes dummy(1, 1);
+    chk(clstm_net_ctc(net, p.labels.empty() ? dummy.data() : p.labels.data(), p.L.data(), aligned.data()), "clstm_net_ctc");
+    chk(clstm_net_backward(net), "clstm_net_backward");
+    chk(clstm_net_update(net), "clstm_net_update");
+    vector<ustring> out;
+    int o = 0;
+    for (int b = 0; b < bs; b++) {
+      out.push_back(codec.decode(Classes(cls.begin() + o, cls.begin() + o + cnt[b])));
+      o += p.T[b];
+    }
+    T = p.T.back();   // aligned_utf8() reports the last line of the minibatch
+    if (bs > 1) aligned.erase(aligned.begin(), aligned.begin() + (size_t)(N - T) * nclasses);
+    return out;
   }
   string aligned_utf8() {  // clstmhl.h:224-229
     Classes cs;

@@ -1,5 +1,8 @@
 // clstmocrtrain -- the reference's OCR training driver (clstmocrtrain.cc:97-224) on the MI355X path:
 // same arguments, environment variables, stdout lines and model files; one text line per update.
+// Beyond the reference: batch=N trains on minibatches of N lines per update (the batched device path; a helper
+// thread reads and normalises the next minibatch while the GPU works on the current one), nhidden2=M builds the
+// "bidi2" prefab.  With the defaults (batch=1, nhidden2=0) the run is the reference's, update for update.
 #include "clstmhl.h"
 using namespace clstmhost;
 
@@ -33,7 +36,8 @@ struct Dataset {  // clstmocrtrain.cc:56-76
 static int print_usage(char** argv) {
   std::cerr << "Usage: [VAR=VAL...] " << argv[0] << " TRAININGLIST [TESTLIST]\n"
             << "  Variables: load save_name nhidden lrate momentum target_height ntrain start charsep\n"
-            << "             report_time test_every report_every save_every params   (clstmocrtrain.cc:99-115)\n";
+            << "             report_time test_every report_every save_every params   (clstmocrtrain.cc:99-115)\n"
+            << "             batch (lines per update, default 1)  nhidden2 (> 0: bidi2)   (not in the reference)\n";
   return EXIT_FAILURE;
 }
 
@@ -56,7 +60,9 @@ static int main1(int argc, char** argv) {
     trainingset.getCodec(codec);
     std::cout << "got " << codec.size() << " classes" << std::endl;
     clstm.target_height = int(getrenv("target_height", 48));
-    clstm.createBidi(codec.codec, getienv("nhidden", 100));
+    const int nhidden2 = getienv("nhidden2", 0);
+    if (nhidden2 > 0) clstm.createBidi2(codec.codec, getienv("nhidden", 100), nhidden2);
+    else clstm.createBidi(codec.codec, getienv("nhidden", 100));
     clstm.setLearningRate(getdenv("lrate", 1e-4), getdenv("momentum", 0.9));
   }
   double test_error = 9999.0, best_error = 1e38;
@@ -68,12 +74,47 @@ static int main1(int argc, char** argv) {
   Trigger save_trigger(getienv("save_every", 10000), ntrain, start);
   save_trigger.enable(save_name != "").skip0();
   Trigger report_trigger(getienv("report_every", 100), ntrain, start);
-  for (int trial = start; trial < ntrain; trial++) {
-    int sample = lrand48() % trainingset.size();
-    Image raw;
-    ustring gt;
-    trainingset.readSample(raw, gt, sample);
-    ustring pred = clstm.train(raw, gt);
+  const int batch = std::max(1, getienv("batch", 1));
+  // minibatch pipeline: `next` is read + normalised by a helper thread while the device trains on `cur`
+  auto draw = [&](CLSTMOCR::Prepared& p) {
+    vector<Image> raws;
+    vector<ustring> gts;
+    while ((int)raws.size() < batch) {
+      int sample = lrand48() % trainingset.size();
+      Image raw;
+      ustring gt;
+      trainingset.readSample(raw, gt, sample);
+      if (gt.size() > 1023) {   // the CTC kernel holds at most 2048 target states (2L+1) per line
+        std::cerr << "skipping " << trainingset.fnames[sample] << ": transcript of " << gt.size() << " characters" << std::endl;
+        continue;
+      }
+      raws.push_back(std::move(raw));
+      gts.push_back(std::move(gt));
+    }
+    clstm.prepare(p, raws, gts);
+  };
+  CLSTMOCR::Prepared cur, next;
+  std::thread helper;
+  if (batch > 1) draw(next);
+  for (int trial = start; trial < ntrain; trial += batch) {
+    ustring gt, pred;
+    if (batch == 1) {   // the reference's loop, sample for sample
+      int sample = lrand48() % trainingset.size();
+      Image raw;
+      trainingset.readSample(raw, gt, sample);
+      if (gt.size() > 1023) {
+        std::cerr << "skipping " << trainingset.fnames[sample] << ": transcript of " << gt.size() << " characters" << std::endl;
+        continue;
+      }
+      pred = clstm.train(raw, gt);
+    } else {
+      std::swap(cur, next);
+      if (trial + batch < ntrain) helper = std::thread([&] { draw(next); });
+      vector<ustring> preds = clstm.train_batch(cur);
+      if (helper.joinable()) helper.join();
+      gt = cur.targets.back();
+      pred = preds.back();
+    }
     if (report_trigger(trial)) {
       std::cout << trial << std::endl;
       std::cout << "TRU " << utf32_to_utf8(gt) << std::endl;

@@ -172,3 +172,26 @@ def test_lockstep_launch_loop_replayed_as_hipgraph(ora32):
         be.lib.call("clstm_set_stream", 0)
     assert np.array_equal(first, ref)
     assert np.array_equal(replay, ref)
+
+
+@pytest.mark.gpu
+def test_clstmocrtrain_minibatch_driver(tmp_path):
+    """batch=4 through the C++ driver (prefetch thread + CLSTMOCR::train_batch): four copies of the fixture per
+    update at a quarter of the learning rate is the online run of test-ocr.sh with the same summed gradient, so
+    200 updates must again learn 'performance analysis'."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "clstm_amd", "host"), "-s", "all"])
+    lst = tmp_path / "list.txt"
+    png = tmp_path / "textline.bin.png"
+    png.write_bytes(open(FIXTURE, "rb").read())
+    (tmp_path / "textline.gt.txt").write_text(GT + "\n", encoding="utf-8")
+    lst.write_text(str(png) + "\n")
+    env = dict(os.environ, ntrain="804", batch="4", hidden="50", lrate="2.5e-3", save_every="200", report_every="200",
+               save_name=str(tmp_path / "_mb"), seed="0.222")
+    r = subprocess.run([os.path.join(BIN, "clstmocrtrain"), str(lst)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    model = tmp_path / "_mb-800.clstm"
+    assert model.exists(), r.stdout[-1000:]
+    r2 = subprocess.run([os.path.join(BIN, "clstmocr"), str(lst)], env=dict(os.environ, load=str(model)),
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "performance analysis" in r2.stdout

@@ -275,6 +275,27 @@ def test_ctc_target_shapes(backend, ora32, case):
     assert_close(dz, want - p, rtol=1e-4, atol=2e-6, what="delta " + case)
 
 
+@pytest.mark.parametrize("T,L", [(40, 300), (640, 280)])
+def test_ctc_long_transcripts(backend, ora32, T, L):
+    """More than 512 target states per line (text lines of clstmfiltertrain easily exceed 255 characters; the
+    reference's ctc_align_targets has no limit): 601 states on a short lattice (no complete path, the per-frame
+    normalisation still applies) and 561 states over 640 frames.  The limit is now 2048 states."""
+    if backend.kind == "emu" and T > 100:
+        pytest.skip("large lattice only on the GPU")
+    rng = np.random.default_rng(L)
+    nc = 40
+    p = rng.random((T, nc)).astype(np.float32) ** 2
+    p /= p.sum(1, keepdims=True)
+    st = ora32.mktargets(rng.integers(1, nc, L))
+    assert st.size == 2 * L + 1 and st.size > 512
+    al, dz, _ = ctc_via_abi(backend, [p.astype(np.float32)], [st])
+    want = ora32.ctc_align_classes(p.astype(np.float32), st)
+    assert_close(al, want, rtol=1e-4, atol=1e-6, what="aligned, %d states" % st.size)
+    assert_close(dz, want - p, rtol=1e-4, atol=2e-6, what="delta, %d states" % st.size)
+    with pytest.raises(Exception, match="2048"):
+        ctc_via_abi(backend, [p.astype(np.float32)], [ora32.mktargets(rng.integers(1, nc, 1100))])
+
+
 def test_ctc_more_states_than_frames(backend, ora32):
     # S > T: no complete path exists; the reference still returns per-frame-normalised values
     rng = np.random.default_rng(9)
