@@ -50,6 +50,10 @@ _SIGS = {
     "clstm_backward_stack_delay": [_P, _P, _P, _I, _I, _I],
     "clstm_forward_reverse": [_P, _P, _I, _I, _I],
     "clstm_backward_reverse": [_P, _P, _I, _I, _I],
+    "clstm_forward_btswitch": [_P, _P, _I, _I, _I],
+    "clstm_backward_btswitch": [_P, _P, _I, _I, _I],
+    "clstm_forward_batchstack": [_P, _P, _I, _I, _I, _I, _I],
+    "clstm_backward_batchstack": [_P, _P, _I, _I, _I, _I, _I],
     "clstm_forward_statemem": [_P, _P, _P, _P, _P, _I],
     "clstm_backward_statemem": [_P] * 9 + [_I],
     "clstm_forward_nonlingate": [_P, _P, _P, _I, _I],

@@ -1158,6 +1158,24 @@ int clstm_forward_reverse(float* y, const float* x, int rows, int bs, int N) {
 int clstm_backward_reverse(const float* y, float* x, int rows, int bs, int N) {
   ABI_BEGIN EW(k_backward_reverse, (size_t)rows * bs * N, y, x, (size_t)rows * bs, N) ABI_END
 }
+int clstm_forward_btswitch(float* y, const float* x, int rows, int bs, int N) {
+  ABI_BEGIN EW(k_forward_btswitch, (size_t)rows * bs * N, y, x, rows, bs, N) ABI_END
+}
+int clstm_backward_btswitch(const float* y, float* x, int rows, int bs, int N) {
+  ABI_BEGIN EW(k_backward_btswitch, (size_t)rows * bs * N, y, x, rows, bs, N) ABI_END
+}
+int clstm_forward_batchstack(float* y, const float* x, int d, int bs, int N, int pre, int post) {
+  ABI_BEGIN
+  REQUIRE(pre >= 0 && post >= 0, "batchstack: negative pre/post");
+  EW(k_forward_batchstack, (size_t)(pre + post + 1) * d * bs * 2 * N, y, x, d, bs, N, pre, post)
+  ABI_END
+}
+int clstm_backward_batchstack(const float* y, float* x, int d, int bs, int N, int pre, int post) {
+  ABI_BEGIN
+  REQUIRE(pre >= 0 && post >= 0, "batchstack: negative pre/post");
+  EW(k_backward_batchstack, (size_t)d * bs * N, y, x, d, bs, N, pre, post)
+  ABI_END
+}
 int clstm_forward_statemem(float* st, const float* ci, const float* gi, const float* last, const float* gf, int len) {
   ABI_BEGIN EW(k_forward_statemem, len, st, ci, gi, last, gf, (size_t)len) ABI_END
 }

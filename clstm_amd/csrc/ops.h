@@ -120,6 +120,45 @@ __global__ void k_backward_reverse(const float* y, float* x, size_t plane, int N
     x[(size_t)(N - 1 - t) * 2 * plane + plane + r] += y[t * 2 * plane + plane + r];
   }
 }
+// forward_btswitch / backward_btswitch (clstm_compute.cc:425-447): swap the batch and time axes of a Sequence block
+// (rows, bs, 2, N) -> (rows, N, 2, bs); forward moves the value plane, backward accumulates the derivative plane
+__global__ void k_forward_btswitch(float* y, const float* x, int rows, int bs, int N) {
+  CLSTM_GRID_STRIDE(e, (size_t)rows * bs * N) {
+    const int i = e % rows, b = (e / rows) % bs, t = e / ((size_t)rows * bs);
+    y[i + (size_t)rows * (t + (size_t)N * (0 + 2 * b))] = x[i + (size_t)rows * (b + (size_t)bs * (0 + 2 * t))];
+  }
+}
+__global__ void k_backward_btswitch(const float* y, float* x, int rows, int bs, int N) {
+  CLSTM_GRID_STRIDE(e, (size_t)rows * bs * N) {
+    const int i = e % rows, b = (e / rows) % bs, t = e / ((size_t)rows * bs);
+    x[i + (size_t)rows * (b + (size_t)bs * (1 + 2 * t))] += y[i + (size_t)rows * (t + (size_t)N * (1 + 2 * b))];
+  }
+}
+// forward_batchstack / backward_batchstack (clstm_compute.cc:451-500): y(d*(pre+k) + f, b, ., t) = x(f, b + k, ., t) for
+// k = -pre..post where b + k is a valid batch column, zero elsewhere; forward clears BOTH planes of y and fills the
+// value plane, backward accumulates the derivative plane back into x
+__global__ void k_forward_batchstack(float* y, const float* x, int d, int bs, int N, int pre, int post) {
+  const int copies = pre + post + 1;
+  CLSTM_GRID_STRIDE(e, (size_t)copies * d * bs * 2 * N) {
+    const int r = e % (copies * d);
+    const size_t q = e / (copies * d);
+    const int b = q % bs, p = (q / bs) % 2, t = q / ((size_t)bs * 2);
+    const int k = r / d - pre, f = r % d, sb = b + k;
+    y[e] = (p == 0 && sb >= 0 && sb < bs) ? x[f + (size_t)d * (sb + (size_t)bs * (0 + 2 * t))] : 0.0f;
+  }
+}
+__global__ void k_backward_batchstack(const float* y, float* x, int d, int bs, int N, int pre, int post) {
+  const int copies = pre + post + 1;
+  CLSTM_GRID_STRIDE(e, (size_t)d * bs * N) {   // one thread per x element: no atomics, k summed in the reference's order
+    const int f = e % d, sb = (e / d) % bs, t = e / ((size_t)d * bs);
+    float acc = x[f + (size_t)d * (sb + (size_t)bs * (1 + 2 * t))];
+    for (int k = -pre; k <= post; k++) {
+      const int b = sb - k;
+      if (b >= 0 && b < bs) acc += y[(size_t)d * (pre + k) + f + (size_t)copies * d * (b + (size_t)bs * (1 + 2 * t))];
+    }
+    x[f + (size_t)d * (sb + (size_t)bs * (1 + 2 * t))] = acc;
+  }
+}
 __global__ void k_forward_statemem(float* st, const float* ci, const float* gi, const float* last,
                                    const float* gf, size_t len) {
   CLSTM_GRID_STRIDE(i, len) {

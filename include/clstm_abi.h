@@ -69,6 +69,14 @@ int clstm_backward_stack_delay(const float* z_d, float* x_d, float* ylast_d, int
  * on raw Sequence blocks (batches.h:79-86): dims (rows, bs, 2, N); forward copies v AND d */
 int clstm_forward_reverse(float* y_seq, const float* x_seq, int rows, int bs, int N);
 int clstm_backward_reverse(const float* y_seq, float* x_seq, int rows, int bs, int N);
+/* forward_btswitch / backward_btswitch clstm_compute.cc:425-436 / :437-447 (2-D LSTM plumbing, off the 1-D OCR path):
+ * x_seq dims (rows, bs, 2, N) -> y_seq dims (rows, N, 2, bs); forward moves .v, backward accumulates .d into x */
+int clstm_forward_btswitch(float* y_seq, const float* x_seq, int rows, int bs, int N);
+int clstm_backward_btswitch(const float* y_seq, float* x_seq, int rows, int bs, int N);
+/* forward_batchstack / backward_batchstack clstm_compute.cc:451-475 / :476-500: x_seq dims (d, bs, 2, N),
+ * y_seq dims ((pre+post+1)*d, bs, 2, N); row block pre+k of batch column b holds x's column b+k (zero outside) */
+int clstm_forward_batchstack(float* y_seq, const float* x_seq, int d, int bs, int N, int pre, int post);
+int clstm_backward_batchstack(const float* y_seq, float* x_seq, int d, int bs, int N, int pre, int post);
 /* forward_statemem / backward_statemem clstm_compute.cc:504-508 / :509-515 (last_* NULL if last<0) */
 int clstm_forward_statemem(float* state_v, const float* ci_v, const float* gi_v, const float* last_v,
                            const float* gf_v, int len);
