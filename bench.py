@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="b1")
     ap.add_argument("--bf16-gemm", action="store_true",
                     help="hoisted gate GEMMs with bf16 inputs / f32 accumulation (not the parity path)")
+    ap.add_argument("--bf16", action="store_true",
+                    help="--bf16-gemm plus bf16 MFMA operands inside the lock-step recurrence of wide layers "
+                         "(BASELINE configs[4]: '2 x BiLSTM(512), bf16 MFMA'; not the parity path)")
     ap.add_argument("--ragged", action="store_true", help="T ~ U{150..250} instead of fixed T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
@@ -156,7 +159,9 @@ def main():
     net = Network(NI, NH, NC, lib=lib, params=params, derivs=derivs, grads=grads)
     net.params_changed()
     net.setLearningRate(1e-4, 0.9)
-    if args.bf16_gemm:
+    if args.bf16:
+        net.set_gemm_precision(2)
+    elif args.bf16_gemm:
         net.set_gemm_precision(1)
     # gradient exchange: the library's own RCCL communicator (all-reduce enqueued on the library stream right
     # before the update kernel, no cross-stream events); torch.distributed only carries the 128-byte id, the
@@ -258,7 +263,21 @@ def main():
             sec = kern[dom]["ms_per_step"] * 1e-3                              # same scope
             nl = kern[dom]["launches_per_step"]
             ach = byts / sec / 1e9
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+            if max(nh_list) > 128:
+                # lock-step recurrence of a wide layer: a (lines x no).(no x 4no) product per step and direction --
+                # priced against the matrix peak of the operand type (north star: "MFMA utilisation ... against gfx950 peak")
+                peak = 2500.0 if args.bf16 else F32_MFMA_PEAK_TFS
+                fl = (8.0 if dom == "lstm_fwd" else 8.0) * sum(h * h for h in nh_list) * 2 * frames_per_step
+                tf = fl / sec / 1e12
+                roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                            "frac": round(tf / peak, 5), "traffic": None,
+                            "algorithmic_flops": int(fl / nl), "avg_launch_ms": round(sec / nl * 1e3, 4),
+                            "note": "lock-step recurrence, one launch per time step (latency-bound: %d dependent launches per pass); "
+                                    "whole step: %.1f TFLOP/s of algorithmic flops (SURVEY 8d: 48 T sum no(ni+no) + 6 T nc 2no per line)"
+                                    % (args.T, (48.0 * args.T * sum(o * (i + o) for i, o in zip([NI] + [2 * h for h in nh_list[:-1]], nh_list))
+                                                + 6.0 * args.T * NC * 2 * nh_list[-1]) * args.minibatch / (dt / args.steps) / 1e12)}
+            else:
+              roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "traffic_source": traffic_src,
                         "algorithmic_bytes": int(byts / nl),
@@ -276,18 +295,19 @@ def main():
     if rank == 0:
         out = {
             "metric": "text-line images/sec (fwd+bwd+CTC), 100-unit BiLSTM H=48 T~200" if args.config == "b1" else
-                      "text-line images/sec (fwd+bwd+CTC), 2xBiLSTM(512) H=64 T~400 (f32)",
+                      "text-line images/sec (fwd+bwd+CTC), 2xBiLSTM(512) H=64 T~400 (%s)" % ("bf16 MFMA" if args.bf16 else "f32"),
             "value": round(value, 2), "unit": "lines/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (hoisted gate GEMMs: bf16 in, f32 accumulate)" if args.bf16_gemm else "f32",
+            "dtype": ("bf16 MFMA operands (hoisted gate GEMMs and lock-step recurrence), f32 accumulate / state / softmax / CTC" if args.bf16
+                      else "f32 (hoisted gate GEMMs: bf16 in, f32 accumulate)" if args.bf16_gemm else "f32"),
             "data": "synthetic",
             "config": {"workload": ("uw3-500 OCR shape: BiLSTM(100) H=48 nc=83, T=%s, L=25, minibatch=%d lines/GPU "
                                     "(BASELINE.json configs[2]; x%d GPUs = configs[3] sharding), fwd+CTC+bwd+allreduce+update"
                                     % ("U{150..250}" if args.ragged else args.T, args.minibatch, world))
                                    if args.config == "b1" else
                                    ("stacked 2xBiLSTM(512) H=64 nc=100, T=%s, L=50, minibatch=%d lines/GPU x%d GPUs "
-                                    "(BASELINE.json configs[4] shape, f32), fwd+CTC+bwd+allreduce+update"
+                                    "(BASELINE.json configs[4] shape), fwd+CTC+bwd+allreduce+update"
                                     % (args.T, args.minibatch, world)),
                        "minibatch_per_gpu": args.minibatch, "global_minibatch": args.minibatch * world,
                        "parallelism": "dp%d" % world},

@@ -224,31 +224,35 @@ static void check_coop(DevBuf<int>& sync, hipStream_t s) {
 struct StepGraphCache {
   bool unsupported = false;   // the stream refused capture once: keep launching directly
 #ifndef CLSTM_HIP_EMU
-  struct Entry { LstmWideArgs key; bool fwd; int tmax; hipGraphExec_t exec; };
+  struct Entry { std::vector<char> key; int kind; int tmax; hipGraphExec_t exec; };
   std::vector<Entry> entries;
-  static bool same(const LstmWideArgs& x, const LstmWideArgs& y) {
-    return x.Rw == y.Rw && x.G == y.G && x.C == y.C && x.H == y.H && x.dH == y.dH && x.D == y.D && x.dC == y.dC &&
-           x.line_off == y.line_off && x.S == y.S && x.sdir == y.sdir && x.N == y.N && x.bs == y.bs && x.no == y.no &&
-           x.ndir == y.ndir && x.kp == y.kp && x.lds == y.lds && x.ldh == y.ldh && x.rw_elems == y.rw_elems;
-  }
-  hipGraphExec_t find(bool fwd, const LstmWideArgs& a, int tmax) {
+  // key: the kernel argument struct with the per-step fields zeroed (pointers, geometry), kind: which pass / kernel family
+  hipGraphExec_t find(int kind, const std::vector<char>& key, int tmax) {
     for (auto& e : entries)
-      if (e.fwd == fwd && e.tmax == tmax && same(e.key, a)) return e.exec;
+      if (e.kind == kind && e.tmax == tmax && e.key == key) return e.exec;
     return nullptr;
   }
-  void put(bool fwd, const LstmWideArgs& a, int tmax, hipGraphExec_t exec) {
+  void put(int kind, const std::vector<char>& key, int tmax, hipGraphExec_t exec) {
     if (entries.size() >= 16) { (void)hipGraphExecDestroy(entries.front().exec); entries.erase(entries.begin()); }
-    entries.push_back(Entry{a, fwd, tmax, exec});
+    entries.push_back(Entry{key, kind, tmax, exec});
   }
   ~StepGraphCache() { for (auto& e : entries) (void)hipGraphExecDestroy(e.exec); }
 #endif
 };
-template <class F>
-static void launch_steps(StepGraphCache& cache, bool fwd, const LstmWideArgs& a, int tmax, hipStream_t s, F&& body) {
+template <class A>
+static std::vector<char> graph_key(A a) {
+  a.step = 0;
+  std::vector<char> k(sizeof(A));
+  memcpy(k.data(), &a, sizeof(A));
+  return k;
+}
+template <class A, class F>
+static void launch_steps(StepGraphCache& cache, int kind, const A& a, int tmax, hipStream_t s, F&& body) {
 #ifndef CLSTM_HIP_EMU
   static const bool use_graph = !(getenv("CLSTM_WIDE_GRAPH") && atoi(getenv("CLSTM_WIDE_GRAPH")) == 0);
   if (use_graph && tmax >= 8) {
-    hipGraphExec_t exec = cache.find(fwd, a, tmax);
+    const std::vector<char> key = graph_key(a);
+    hipGraphExec_t exec = cache.find(kind, key, tmax);
     if (!exec && !cache.unsupported) {
       hipGraph_t graph = nullptr;
       if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -259,7 +263,7 @@ static void launch_steps(StepGraphCache& cache, bool fwd, const LstmWideArgs& a,
         HIPCHECK(hipStreamEndCapture(s, &graph));
         HIPCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         HIPCHECK(hipGraphDestroy(graph));
-        cache.put(fwd, a, tmax, exec);
+        cache.put(kind, key, tmax, exec);
       }
     }
     if (exec) {
@@ -270,13 +274,13 @@ static void launch_steps(StepGraphCache& cache, bool fwd, const LstmWideArgs& a,
 #endif
   body();
 }
-static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s) {
+static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s, bool bf16 = false) {
   REQUIRE((double)a.N * a.ndir * 4 * a.no * 4 < 2147483000.0,
           "minibatch too large for the lock-step recurrence (frames x 4 x nhidden x ndir x 4 B must stay below 2 GiB)");
   const int no = a.no;
   // cooperative (single-launch, grid-barrier) variants are opt-in: measured on MI355X at 2xBiLSTM(512),
   // 64 lines: forward 10.4 ms vs 9.7 ms per-step, backward 7.7 ms vs 8.3 ms -- no net gain yet
-  const bool allow_coop = getenv("CLSTM_COOP") && atoi(getenv("CLSTM_COOP")) != 0;
+  const bool allow_coop = !bf16 && getenv("CLSTM_COOP") && atoi(getenv("CLSTM_COOP")) != 0;
   const int ncu = device_cu_count();
   const int mt = a.bs > 32 ? 4 : a.bs > 16 ? 2 : 1;
   a.tmax = tmax;
@@ -296,10 +300,15 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       return;
     }
     const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mt - 1) / (16 * mt));
-    launch_steps(graphs, true, a, tmax, s, [&]() {
+    launch_steps(graphs, bf16 ? 2 : 0, a, tmax, s, [&]() {
       LstmWideArgs w = a;
       for (int t = 0; t < tmax; t++) {
         w.step = t;
+        if (bf16) {
+          if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step_bf16<4>, grid, dim3(WIDE_THREADS), 0, s, w);
+          else if (mt == 2) CLSTM_LAUNCH(lstm_wide_fwd_step_bf16<2>, grid, dim3(WIDE_THREADS), 0, s, w);
+          else CLSTM_LAUNCH(lstm_wide_fwd_step_bf16<1>, grid, dim3(WIDE_THREADS), 0, s, w);
+        } else
         if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step<4>, grid, dim3(WIDE_THREADS), 0, s, w);
         else if (mt == 2) CLSTM_LAUNCH(lstm_wide_fwd_step<2>, grid, dim3(WIDE_THREADS), 0, s, w);
         else CLSTM_LAUNCH(lstm_wide_fwd_step<1>, grid, dim3(WIDE_THREADS), 0, s, w);
@@ -319,11 +328,12 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       return;
     }
     const dim3 grid((no + 15) / 16, a.ndir, nzb);
-    launch_steps(graphs, false, a, tmax, s, [&]() {
+    launch_steps(graphs, bf16 ? 3 : 1, a, tmax, s, [&]() {
       LstmWideArgs w = a;
       for (int t = 0; t < tmax; t++) {
         w.step = t;
-        CLSTM_LAUNCH(lstm_wide_bwd_step, grid, dim3(WIDE_THREADS), 0, s, w);
+        if (bf16) CLSTM_LAUNCH(lstm_wide_bwd_step_bf16, grid, dim3(WIDE_THREADS), 0, s, w);
+        else CLSTM_LAUNCH(lstm_wide_bwd_step, grid, dim3(WIDE_THREADS), 0, s, w);
       }
     });
   }
@@ -431,6 +441,9 @@ struct Layer {
   PackDesc pd;
   float *Wt = nullptr, *bias = nullptr, *Rf = nullptr, *Rb = nullptr, *Rwf = nullptr, *Rwb = nullptr;
   DevBuf<float> dCc;
+  // bf16 recurrence of a wide layer (lstm_wide_bf16.h): packed weights and the bf16 copies of h / the deltas
+  unsigned short *Rbf = nullptr, *Rbb = nullptr;
+  DevBuf<unsigned short> Hb, Db;
   long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
   DevBuf<float> G, C, H, D, dH, S;
   int lds = 0;
@@ -452,6 +465,7 @@ struct Net {
   float lr = 1e-4f, mom = 0.9f, gclip = 100.0f;
   bool packed_dirty = true;
   bool bf16_gemm = getenv("CLSTM_BF16_GEMM") && atoi(getenv("CLSTM_BF16_GEMM")) != 0;  // hoisted gate GEMMs: bf16 in, f32 accumulate
+  bool bf16_rec = getenv("CLSTM_BF16_REC") && atoi(getenv("CLSTM_BF16_REC")) != 0;   // wide layers: bf16 MFMA operands in the recurrence
   bool want_dx0 = false;
   // batch
   int bs = 0, tmax = 0;
@@ -556,6 +570,8 @@ struct Net {
         y.nwb = (long long)ndir * ((y.no + 15) / 16) * 16 * y.kpb;
         HIPCHECK(hipMalloc((void**)&y.Rwf, (size_t)(y.nwf + 4) * sizeof(float)));
         HIPCHECK(hipMalloc((void**)&y.Rwb, (size_t)(y.nwb + 4) * sizeof(float)));
+        HIPCHECK(hipMalloc((void**)&y.Rbf, ((size_t)ndir * ((y.no + 3) / 4) * 16 * wide_kp16_fwd(y.no) + 8) * sizeof(unsigned short)));
+        HIPCHECK(hipMalloc((void**)&y.Rbb, ((size_t)ndir * ((y.no + 15) / 16) * 16 * wide_kp16_bwd(y.no) + 8) * sizeof(unsigned short)));
       } else {
         HIPCHECK(hipMalloc((void**)&y.Rf, (size_t)ndir * 4 * KQP * y.nthreads * sizeof(float)));
         HIPCHECK(hipMalloc((void**)&y.Rb, (size_t)ndir * 4 * KQP * y.nthreads * sizeof(float)));
@@ -573,7 +589,7 @@ struct Net {
   ~Net() {
     for (auto& y : L) {
       (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff);
-      (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); y.dCc.release();
+      (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release();
       y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release();
     }
     if (own_v) (void)hipFree(v);
@@ -591,7 +607,12 @@ struct Net {
     for (auto& y : L) {
       const int M = ndir * 4 * y.no, KQP = 4 * y.nk4;
       const size_t nr = y.wide ? 0 : (size_t)ndir * 4 * KQP * y.nthreads;
-      if (y.wide)
+      if (y.wide && bf16_rec) {
+        const int rf = (y.no + 3) / 4 * 16, kf = wide_kp16_fwd(y.no), rb = (y.no + 15) / 16 * 16, kb = wide_kp16_bwd(y.no);
+        CLSTM_LAUNCH(k_pack_wide_bf16, dim3(nblocks((size_t)ndir * ((size_t)rf * kf + (size_t)rb * kb))), dim3(256), 0, s,
+                     (const float*)v, y.Rbf, y.Rbb, y.pd, rf, kf, rb, kb);
+      }
+      else if (y.wide)
         CLSTM_LAUNCH(k_pack_wide, dim3(nblocks((size_t)(y.nwf + y.nwb))), dim3(256), 0, s, (const float*)v, y.Rwf, y.Rwb,
                      y.pd, y.kpf, y.kpb);
       CLSTM_LAUNCH(k_pack_layer, dim3(nblocks((size_t)(1 + y.ni) * M + 2 * nr)), dim3(256), 0, s, (const float*)v, y.Wt,
@@ -635,6 +656,10 @@ struct Net {
       }
       y.D.reserve((size_t)N * ndir * 4 * y.no + (y.wide ? 0 : PROG_WORDS + 64));
       y.dH.reserve((size_t)N * ndir * y.no);
+      if (y.wide && bf16_rec) {
+        y.Hb.reserve((size_t)N * ndir * wide_kp16_fwd(y.no) + 64);
+        y.Db.reserve((size_t)N * ndir * wide_kp16_bwd(y.no) + 64);
+      }
       y.S.reserve((size_t)N * ndir * y.lds + 64);
     }
     Z.reserve((size_t)N * desc.nclasses);
@@ -653,6 +678,12 @@ struct Net {
     w.dC = y.dCc.p; w.line_off = line_off.p; w.S = y.S.p; w.sdir = (long long)N * y.lds; w.N = N;
     w.lds = y.lds; w.sofs = 1 + y.ni; w.ldh = y.ldh; w.hofs = y.hofs; w.no = y.no; w.ndir = ndir; w.bs = bs;
     w.kp = fwd ? y.kpf : y.kpb;
+    if (bf16_rec) {
+      w.Rw16 = fwd ? y.Rbf : y.Rbb;
+      w.kp16 = fwd ? wide_kp16_fwd(y.no) : wide_kp16_bwd(y.no);
+      w.rw_elems = (long long)ndir * (fwd ? (y.no + 3) / 4 : (y.no + 15) / 16) * 16 * w.kp16;
+      w.Hb = y.Hb.p; w.Db = y.Db.p;
+    }
     return w;
   }
 
@@ -687,7 +718,7 @@ struct Net {
       lstm_prof.reserve(64); a.prof = lstm_prof.p;
 #endif
       timing.begin("lstm_fwd", s);
-      if (y.wide) launch_lstm_wide(true, wide_args(y, true), tmax, coop_sync, step_graphs, s);
+      if (y.wide) launch_lstm_wide(true, wide_args(y, true), tmax, coop_sync, step_graphs, s, bf16_rec);
       else launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
     }
@@ -921,7 +952,7 @@ struct Net {
         timing.begin("reduce_scatter", s);
       } else {
       timing.begin("lstm_bwd", s);
-      if (y.wide) launch_lstm_wide(false, wide_args(y, false), tmax, coop_sync, step_graphs, s);
+      if (y.wide) launch_lstm_wide(false, wide_args(y, false), tmax, coop_sync, step_graphs, s, bf16_rec);
       else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
       ns = pick_split(R, Cn, ndir);
@@ -1368,8 +1399,18 @@ int clstm_net_get_state_h(clstm_net* h, int layer, int dir, int which, float* ou
 }
 int clstm_net_set_gemm_precision(clstm_net* h, int mode) {
   ABI_BEGIN
-  REQUIRE(mode == 0 || mode == 1, "gemm precision: 0 = f32 (exact), 1 = bf16 inputs with f32 accumulation");
-  h->net.bf16_gemm = mode == 1;
+  REQUIRE(mode >= 0 && mode <= 2, "precision: 0 = f32 (exact), 1 = bf16 inputs / f32 accumulation in the hoisted GEMMs, 2 = 1 + bf16 MFMA operands in the lock-step recurrence");
+  Net& n = h->net;
+  const bool rec = mode == 2;
+  if (rec != n.bf16_rec) n.packed_dirty = true;   // the other weight packing is needed
+  n.bf16_gemm = mode >= 1;
+  n.bf16_rec = rec;
+  if (n.N > 0 && rec)   // a batch is already declared: make room for the bf16 operand copies
+    for (auto& y : n.L)
+      if (y.wide) {
+        y.Hb.reserve((size_t)n.N * n.ndir * wide_kp16_fwd(y.no) + 64);
+        y.Db.reserve((size_t)n.N * n.ndir * wide_kp16_bwd(y.no) + 64);
+      }
   ABI_END
 }
 int clstm_net_enable_timing(clstm_net* h, int on) { h->net.timing.on = on != 0; return 0; }

@@ -45,6 +45,11 @@ struct LstmWideArgs {
   int step;             // lock-step index: forward own step s = step, backward own step s = T-1-step
   int tmax;             // cooperative kernels: number of lock-steps (longest line)
   int* sync;            // cooperative kernels: [0] barrier ticket counter (zeroed per launch), [1] watchdog flag
+  // bf16 MFMA operands (per-step kernels lstm_wide_*_step_bf16; BASELINE config "2 x BiLSTM(512), bf16 MFMA"):
+  const unsigned short* Rw16;   // the same weight rows as Rw, bf16, row length kp16
+  unsigned short* Hb;           // [N][nd][kp16]  bf16 copy of h (forward A operand), pad columns stay zero
+  unsigned short* Db;           // [N][nd][kp16]  bf16 copy of the gate deltas at column 4*cell+gate (backward A operand)
+  int kp16;                     // padded contraction length of the bf16 rows, multiple of 32 * WIDE_NW
 };
 
 constexpr int WIDE_LDW = 20;  // LDS row stride of a partial tile (16 columns + pad, float4-aligned)
@@ -130,9 +135,55 @@ DEVFN void wide_tile(const BufF32 abuf, const unsigned (&arow)[MT], const BufF32
         red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * LDR + j * 16 + (lane & 15)] = acc[i][j][q];
 }
 
+// The same tile with bf16 operands on v_mfma_f32_16x16x32_bf16 (f32 accumulation): a lane's fragment of a k32 group is
+// ONE 16-byte load -- 8 consecutive k of its row -- for A (bf16 copies of h / the deltas) and B (bf16 weight rows)
+// alike; a wave owns a quarter of the contraction range, partial tiles meet in `red` exactly as above.  One eighth of
+// the f32 kernel's MFMA instructions and half its operand bytes per step.
+template <int MT, int PF>
+DEVFN void wide_tile_bf16(const BufF32 abuf, const unsigned (&arow)[MT], const BufF32 bbuf, const unsigned brow, const int kp,
+                          float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int kw = kp / WIDE_NW;            // contraction range of one wave (multiple of 32)
+  const int ngroups = kw >> 5;
+  const unsigned klane = (unsigned)(wave * kw + 8 * (lane >> 4)) * 2u;   // bytes
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[i][q] = 0.0f;
+  f32x4 ra[PF][MT], rb[PF];
+  auto load_group = [&](int g, f32x4 (&a)[MT], f32x4& b) {   // unconditional issue: exact vmcnt
+    const bool live = g < ngroups;
+    const unsigned ko = klane + (unsigned)g * 64u;
+#pragma unroll
+    for (int i = 0; i < MT; i++) a[i] = buf_load4(abuf, live ? arow[i] + ko : BUF_OOB);
+    b = buf_load4(bbuf, live ? brow + ko : BUF_OOB);
+  };
+#pragma unroll
+  for (int p = 0; p < PF; p++) {
+    load_group(p, ra[p], rb[p]);
+    SCHED_FENCE();
+  }
+  for (int g0 = 0; g0 < ngroups; g0 += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; p++) {
+      const u16x8 bv = __builtin_bit_cast(u16x8, rb[p]);
+#pragma unroll
+      for (int i = 0; i < MT; i++) acc[i] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[p][i]), bv, acc[i]);
+      load_group(g0 + p + PF, ra[p], rb[p]);
+      SCHED_FENCE();
+    }
+  }
+  constexpr int LDR = 16 + 4;
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * LDR + (lane & 15)] = acc[i][q];
+}
+
 // ---- forward: one time step of 16*MT lines for one (cell group, direction) ------------------------
 // loff: line offsets (global for the per-step launch, an LDS copy in the cooperative kernel)
-template <int MT, bool COOP>
+template <int MT, bool COOP, bool BF16 = false>
 DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, const int dir, const int zb,
                          const int* loff, const float* wl, float* red) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -148,13 +199,17 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
       const int off = loff[m], T = loff[m + 1] - off;
       if (sg >= 1 && sg < T) {
         const int fprev = dir == 0 ? sg - 1 : T - sg;   // frame of own step s-1
-        arow[i] = (unsigned)((long long)(off + fprev) * a.ldh + a.hofs + dir * no) * 4u;
+        arow[i] = BF16 ? (unsigned)((((long long)(off + fprev) * nd + dir) * a.kp16) * 2)
+                       : (unsigned)((long long)(off + fprev) * a.ldh + a.hofs + dir * no) * 4u;
       }
     }
   }
-  const BufF32 abuf = make_buf(a.H, (size_t)a.N * a.ldh * 4);
-  const BufF32 bbuf = make_buf(a.Rw, (size_t)a.rw_elems * 4);
-  const unsigned brow = (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp) * 4u;
+  const BufF32 abuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)a.N * nd * a.kp16 * 2)
+                            : make_buf(a.H, (size_t)a.N * a.ldh * 4);
+  const BufF32 bbuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Rw16), (size_t)a.rw_elems * 2)
+                            : make_buf(a.Rw, (size_t)a.rw_elems * 4);
+  const unsigned brow = BF16 ? (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp16) * 2u
+                             : (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp) * 4u;
 
   // epilogue role of this thread: (line, cell); its operands are requested before the MFMA loop so
   // that their HBM latency hides under it (masked threads read nothing: out-of-range offsets)
@@ -177,7 +232,8 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
   const float c_prev = buf_load(cbuf, live && sg >= 1
       ? (unsigned)((((long long)(off + (dir == 0 ? sg - 1 : T - sg)) * nd + dir) * no + cell) * 4) : BUF_OOB);
 
-  wide_tile<MT, 1, COOP>(abuf, arow, bbuf, brow, wl, a.kp, red);
+  if (BF16) wide_tile_bf16<MT, 4>(abuf, arow, bbuf, brow, a.kp16, red);
+  else wide_tile<MT, 1, COOP>(abuf, arow, bbuf, brow, wl, a.kp, red);
   __syncthreads();
 
   // fused forward_full1 x4 + forward_statemem + forward_nonlingate for (line, cell)
@@ -202,6 +258,7 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
     // h_t is next step's A operand of every workgroup of this direction
     if (COOP) buf_store_dev(abuf, (unsigned)(n * a.ldh + a.hofs + dir * no + cell) * 4u, h);
     else a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
+    if (BF16) a.Hb[(n * nd + dir) * a.kp16 + cell] = (unsigned short)(bf16_pack2(h, 0.0f) & 0xFFFFu);   // next step's A operand
     float* srow = a.S + (size_t)dir * a.sdir;
     if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;                      // h_{-1} = 0
     if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
@@ -215,8 +272,14 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_fwd_step(LstmWideArgs 
   wide_fwd_tile<MT, false>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);
 }
 
+template <int MT>
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_fwd_step_bf16(LstmWideArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[WIDE_NW * MT * 16 * WIDE_LDW];
+  wide_fwd_tile<MT, false, true>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);
+}
+
 // ---- backward: one time step of 16 lines for one (16-cell tile, direction) ------------------------
-template <bool COOP>
+template <bool COOP, bool BF16 = false>
 DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, const int dir, const int zb,
                          const int* loff, const float* wl, float* red) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -231,13 +294,17 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
       const int off = loff[m], T = loff[m + 1] - off;
       if (sg >= 1 && sg < T) {
         const int fnext = dir == 0 ? T - sg : sg - 1;   // frame of own step s+1, s = T-1-sg
-        arow[0] = (unsigned)(((long long)(off + fnext) * nd + dir) * 4 * no) * 4u;
+        arow[0] = BF16 ? (unsigned)((((long long)(off + fnext) * nd + dir) * a.kp16) * 2)
+                       : (unsigned)(((long long)(off + fnext) * nd + dir) * 4 * no) * 4u;
       }
     }
   }
-  const BufF32 abuf = make_buf(a.D, (size_t)a.N * nd * 4 * no * 4);
-  const BufF32 bbuf = make_buf(a.Rw, (size_t)a.rw_elems * 4);
-  const unsigned brow = (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp) * 4u;
+  const BufF32 abuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Db), (size_t)a.N * nd * a.kp16 * 2)
+                            : make_buf(a.D, (size_t)a.N * nd * 4 * no * 4);
+  const BufF32 bbuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Rw16), (size_t)a.rw_elems * 2)
+                            : make_buf(a.Rw, (size_t)a.rw_elems * 4);
+  const unsigned brow = BF16 ? (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp16) * 2u
+                             : (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp) * 4u;
 
   // epilogue operands of thread (line, cell), requested ahead of the MFMA loop
   const int ml = tid >> 4, c16 = tid & 15;
@@ -264,7 +331,8 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
   const unsigned dcoff = (unsigned)((((long long)line * nd + dir) * no + cell) * 4);
   const float dc_carry = buf_load(dcbuf, live && sg >= 1 ? dcoff : BUF_OOB);   // own write of the previous step
 
-  wide_tile<1, 1, COOP>(abuf, arow, bbuf, brow, wl, a.kp, red);
+  if (BF16) wide_tile_bf16<1, 8>(abuf, arow, bbuf, brow, a.kp16, red);
+  else wide_tile<1, 1, COOP>(abuf, arow, bbuf, brow, wl, a.kp, red);
   __syncthreads();
 
   if (live) {
@@ -287,7 +355,16 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
     // the deltas are next step's A operand of every workgroup of this direction
     if (COOP) buf_store4_dev(abuf, coff * 4u, dl);
     else *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
+    if (BF16) {   // next step's A operand
+      unsigned* db = reinterpret_cast<unsigned*>(a.Db + (n * nd + dir) * a.kp16 + 4 * cell);
+      db[0] = bf16_pack2(dl[0], dl[1]);
+      db[1] = bf16_pack2(dl[2], dl[3]);
+    }
   }
+}
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_bwd_step_bf16(LstmWideArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[WIDE_NW * 16 * WIDE_LDW];
+  wide_bwd_tile<false, true>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);
 }
 
 // per-step launch: grid (ceil(no/16), ndir, ceil(bs/16)), 256 threads
@@ -447,5 +524,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_coop_bwd(LstmWideArgs a) {
 // contraction padding of the packed weights
 inline int wide_kp_fwd(int no) { return ((no + 16 * WIDE_NW - 1) / (16 * WIDE_NW)) * 16 * WIDE_NW; }
 inline int wide_kp_bwd(int no) { return ((4 * no + 16 * WIDE_NW - 1) / (16 * WIDE_NW)) * 16 * WIDE_NW; }
+// bf16 rows: every wave's quarter of the contraction is whole k32 groups
+inline int wide_kp16_fwd(int no) { return ((no + 32 * WIDE_NW - 1) / (32 * WIDE_NW)) * 32 * WIDE_NW; }
+inline int wide_kp16_bwd(int no) { return ((4 * no + 32 * WIDE_NW - 1) / (32 * WIDE_NW)) * 32 * WIDE_NW; }
 
 }  // namespace clstm

@@ -291,6 +291,33 @@ __global__ void k_pack_wide(const float* v, float* Rwf, float* Rwb, PackDesc p, 
     }
   }
 }
+// recurrent weights of a wide layer as bf16 for the *_step_bf16 kernels of lstm_wide.h, zero padded:
+//   Rbf[dir][rows_f][kp]   row = cell*4+slot : R_slot[cell][k]            (forward: B rows, k contiguous)
+//   Rbb[dir][rows_b][kpb]  row = cell k      : R_slot[j][k] at col 4*j+slot (backward: contraction over (j, slot))
+__global__ void k_pack_wide_bf16(const float* v, unsigned short* Rbf, unsigned short* Rbb, PackDesc p, int rows_f, int kp,
+                                 int rows_b, int kpb) {
+  const size_t nf = (size_t)p.ndir * rows_f * kp, nb = (size_t)p.ndir * rows_b * kpb;
+  CLSTM_GRID_STRIDE(e, nf + nb) {
+    float x = 0.0f;
+    if (e < nf) {
+      const int k = e % kp;
+      const size_t q = e / kp;
+      const int row = q % rows_f, dir = q / rows_f;
+      const int cell = row >> 2, slot = row & 3;
+      if (cell < p.no && k < p.no) x = v[p.p_off[dir][slot] + cell + (size_t)p.no * (1 + p.ni + k)];
+      Rbf[e] = (unsigned short)(bf16_pack2(x, 0.0f) & 0xFFFFu);
+    } else {
+      const size_t e2 = e - nf;
+      const int col = e2 % kpb;
+      const size_t q = e2 / kpb;
+      const int k = q % rows_b, dir = q / rows_b;
+      const int j = col >> 2, slot = col & 3;
+      if (j < p.no && k < p.no) x = v[p.p_off[dir][slot] + j + (size_t)p.no * (1 + p.ni + k)];
+      Rbb[e2] = (unsigned short)(bf16_pack2(x, 0.0f) & 0xFFFFu);
+    }
+  }
+}
+
 // S[dir][n][0] = 1, S[dir][n][1..ni] = x_n for every direction: the non-recurrent part of the source
 // rows [1 | x_t | h_{t-1}] (forward_stack_delay + the bias column of Params, tensor.h:263-264)
 __global__ void k_build_source(float* S, const float* x, size_t N, int ni, int ldx, int lds, int ndir, long long sdir) {

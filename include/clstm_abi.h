@@ -136,8 +136,11 @@ int clstm_net_create(clstm_net** out, const clstm_net_desc* desc, float* params_
 int clstm_net_destroy(clstm_net* net);
 /* Precision of the hoisted gate GEMMs (W_x.x for all frames, the weight-gradient and input-delta GEMMs):
  *   0 (default) exact f32 MFMA -- the parity path (1e-4 on activations);
- *   1           bf16 inputs, f32 accumulation (v_mfma_f32_16x16x32_bf16) -- what BASELINE config
- *               "2 x BiLSTM(512), bf16 MFMA" names; the recurrence, softmax and CTC stay f32. */
+ *   1           bf16 inputs, f32 accumulation (v_mfma_f32_16x16x32_bf16) in those GEMMs; the recurrence, softmax
+ *               and CTC stay f32;
+ *   2           1 + bf16 MFMA operands (recurrent weights, h, gate deltas) inside the lock-step recurrence of
+ *               layers wider than 128 cells (csrc/lstm_wide.h: *_step_bf16) -- what BASELINE config "2 x BiLSTM(512), bf16
+ *               MFMA" names; accumulation, cell state, softmax and CTC stay f32.  Not parity modes. */
 int clstm_net_set_gemm_precision(clstm_net* net, int mode);
 int clstm_net_nparams(clstm_net* net);
 int clstm_net_buffers(clstm_net* net, float** params_d, float** derivs_d, float** grads_d);

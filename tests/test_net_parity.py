@@ -231,3 +231,42 @@ def test_bf16_gate_gemms_track_the_f32_path(backend, ora32):
     g, w = net.get_grads(), want["derivs"]
     assert np.abs(g - w).max() < 5e-2 * np.abs(w).max()
     assert not np.array_equal(g, w)          # the switch really changed the arithmetic
+
+
+@pytest.mark.parametrize("nh,T", [([20, 16], [9, 5, 7]), ([37], [12, 1, 8])])
+def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatch, nh, T):
+    """clstm_net_set_gemm_precision(2): bf16 MFMA operands (recurrent weights, h, gate deltas) inside the lock-step
+    recurrence (lstm_wide.h, *_step_bf16) on top of the bf16 hoisted GEMMs -- BASELINE config "2 x BiLSTM(512), bf16 MFMA".
+    Not a parity mode.  Stated tolerance against the f32 oracle: gate activations / cell states / outputs within 3e-2
+    absolute, CTC decodes equal on this well-separated case, gradient within 8 % of its largest entry; and the
+    f32 gate activations stored for the backward pass must be exactly what the kernel computed (same arrays)."""
+    from clstm_amd.net import Network
+    monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")      # the lock-step path on sizes the emulator can run
+    rng = np.random.default_rng(23)
+    ni, nc = 12, 6
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+    skeys = [(l, d, w) for l in range(len(nh)) for d in (0, 1) for w in ("gi", "gf", "go", "ci", "state", "outputs")]
+    want = oracle_minibatch(ora32, OracleNet, params, ni, nh, nc, lines, trs, states=skeys, lr=1e-3, mom=0.9)
+    net = Network(ni, nh, nc, lib=backend.lib)
+    net.set_params(params)
+    net.set_gemm_precision(2)
+    net.set_inputs(lines)
+    net.forward()
+    got = net.split(net.outputs())
+    for b in range(len(T)):
+        assert np.abs(got[b] - want["outputs"][b]).max() < 3e-2
+    for k in skeys:
+        s = net.split(net.state(*k))
+        for b in range(len(T)):
+            assert np.abs(s[b] - want["states"][k][b]).max() < 3e-2, (k, b)
+    assert [d.tolist() for d in net.decode()] == [d.tolist() for d in want["decode"]]
+    net.ctc(trs)
+    net.backward()
+    g, w = net.get_grads(), want["derivs"]
+    assert np.abs(g - w).max() < 8e-2 * np.abs(w).max()
+    assert not np.array_equal(g, w)          # the switch really changed the arithmetic
+    net.update()                              # repack (bf16 weights) + a second step must run
+    net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
+    assert np.isfinite(net.get_grads()).all()
