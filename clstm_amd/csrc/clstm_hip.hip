@@ -103,15 +103,20 @@ struct DevBuf {  // grow-only device buffer
 // copied here and DMA'd asynchronously, so declaring a batch never drains the stream and the host
 // can run ahead of the GPU.  A slot is reused only after the copy recorded on it has completed.
 struct PinnedRing {
-  static const int SLOTS = 8;
+  // An event record between two kernels costs ~5 us of stream time on MI355X (a barrier packet the next dispatch waits
+  // for; profiles/r02_timeline_one_stream.txt of the first version shows the gaps), so slots are recycled in GROUPS:
+  // one event per GROUP commits, recorded behind the group's last copy and waited for when the ring comes round to
+  // the group's first slot again.
+  static const int SLOTS = 32, GROUP = 8;
   void* h[SLOTS] = {};
   size_t cap[SLOTS] = {};
-  hipEvent_t ev[SLOTS] = {};
-  bool busy[SLOTS] = {};
-  int cur = 0;
+  hipEvent_t ev[SLOTS / GROUP] = {};
+  bool busy[SLOTS / GROUP] = {};
+  int cur = SLOTS - 1;
   void* acquire(size_t bytes) {
     cur = (cur + 1) % SLOTS;
-    if (busy[cur]) { HIPCHECK(hipEventSynchronize(ev[cur])); busy[cur] = false; }
+    const int g = cur / GROUP;
+    if (cur % GROUP == 0 && busy[g]) { HIPCHECK(hipEventSynchronize(ev[g])); busy[g] = false; }
     if (cap[cur] < bytes) {
       if (h[cur]) (void)hipHostFree(h[cur]);
       cap[cur] = bytes * 2 + 256;
@@ -119,16 +124,18 @@ struct PinnedRing {
     }
     return h[cur];
   }
-  void commit(hipStream_t s) {
-    if (!ev[cur]) HIPCHECK(hipEventCreateWithFlags(&ev[cur], hipEventDisableTiming));
-    HIPCHECK(hipEventRecord(ev[cur], s));
-    busy[cur] = true;
+  void commit(hipStream_t s) {   // the copy / kernel reading the current slot has been enqueued on s
+    if (cur % GROUP != GROUP - 1) return;
+    const int g = cur / GROUP;
+    if (!ev[g]) HIPCHECK(hipEventCreateWithFlags(&ev[g], hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(ev[g], s));
+    busy[g] = true;
   }
   ~PinnedRing() {
-    for (int i = 0; i < SLOTS; i++) {
+    for (int i = 0; i < SLOTS / GROUP; i++)
       if (ev[i]) (void)hipEventDestroy(ev[i]);
+    for (int i = 0; i < SLOTS; i++)
       if (h[i]) (void)hipHostFree(h[i]);
-    }
   }
 };
 
@@ -1012,15 +1019,22 @@ struct Net {
 static thread_local long long* g_last_ctc_prof = nullptr;
 // CTC on an arbitrary packed batch (used by the net and by the stand-alone ABI entry)
 struct CtcWorkspace {
+  CtcArgs pending{};            // kernel arguments of a prepared-but-not-launched alignment (train step)
+  size_t pending_smem = 0;
+  int pending_bs = 0;
   PinnedRing ring;
   DevBuf<long long> prof;
   DevBuf<double> tables;
   DevBuf<char> meta;
   DevBuf<float> lat;
 };
+// The per-minibatch metadata block [lat_off (bs+1 x i64) | line_off | state_off | states] is staged in a pinned slot;
+// `defer` (non-null): do not enqueue its copy -- the caller folds it into a kernel it launches anyway before the CTC
+// kernel (the input-ingest launch of a training step) and receives source, destination and size here.
+struct CtcMetaCopy { const int* src = nullptr; int* dst = nullptr; int nwords = 0; };
 static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* aligned, int nc,
                     const int* line_off_h, const int* states_h, const int* state_off_h, int bs,
-                    hipStream_t s) {
+                    hipStream_t s, CtcMetaCopy* defer = nullptr, bool launch = true) {
   REQUIRE(bs > 0, "empty batch");
   std::vector<long long> lo(bs + 1, 0);
   for (int b = 0; b < bs; b++) {
@@ -1042,8 +1056,12 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
     memcpy(stage + nlo, line_off_h, nio);
     memcpy(stage + nlo + nio, state_off_h, nio);
     if (ns > 0) memcpy(stage + nlo + 2 * nio, states_h, (size_t)ns * sizeof(int));
-    HIPCHECK(hipMemcpyAsync(w.meta.p, stage, nlo + 2 * nio + nst, hipMemcpyHostToDevice, s));
-    w.ring.commit(s);
+    if (defer) {
+      defer->src = (const int*)stage; defer->dst = (int*)w.meta.p; defer->nwords = (int)((nlo + 2 * nio + nst) / sizeof(int));
+    } else {
+      HIPCHECK(hipMemcpyAsync(w.meta.p, stage, nlo + 2 * nio + nst, hipMemcpyHostToDevice, s));
+      w.ring.commit(s);
+    }
   }
   CtcArgs a{};
   a.P = probs; a.Dz = deltas; a.aligned = aligned; a.line_off = (const int*)(w.meta.p + nlo);
@@ -1083,8 +1101,8 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
     smem_set = smem;
   }
 #endif
-  CLSTM_LAUNCH(ctc_align_kernel, dim3(bs), dim3(CTC_THREADS), smem, s, a);
-  check_launch();
+  w.pending = a; w.pending_smem = smem; w.pending_bs = bs;
+  if (launch) { CLSTM_LAUNCH(ctc_align_kernel, dim3(bs), dim3(CTC_THREADS), smem, s, a); check_launch(); }
 }
 struct DecodeWorkspace {
   DevBuf<int> line_off, idx, cls, loc, cnt;
@@ -1304,25 +1322,33 @@ int clstm_net_set_inputs_h(clstm_net* h, const float* x) {
   h->net.src0_ready = false;
   ABI_END
 }
-static void net_set_inputs_d(clstm_net* h, const float* x) {
+static void net_set_inputs_d(clstm_net* h, const float* x, const CtcMetaCopy* aux = nullptr) {
   Net& n = h->net;
   REQUIRE(n.N > 0, "set_batch first");
   Layer& y = n.L[0];
+  bool aux_done = false;
   if (n.packed_dirty && n.L.size() == 1 && !y.wide) {   // the training step: ingest + weight repack in one launch
     const int M = n.ndir * 4 * y.no, KQP = 4 * y.nk4;
     const size_t nr = (size_t)n.ndir * 4 * KQP * y.nthreads;
     const int nbi = nblocks((size_t)n.N * (1 + y.ni)), nbp = nblocks((size_t)(1 + y.ni) * M + 2 * nr);
-    const bool lo = n.lo_pending;
-    CLSTM_LAUNCH(k_ingest_pack, dim3(nbi + nbp + (lo ? 1 : 0)), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni, y.lds,
+    const bool lo = n.lo_pending, ax = aux && aux->nwords > 0;
+    // optional trailing blocks read small host arrays straight from their pinned slots: the line offsets and -- in a
+    // training step -- the CTC metadata (no DMA launches, no event records on the stream's critical path)
+    CLSTM_LAUNCH(k_ingest_pack, dim3(nbi + nbp + (lo ? 1 : 0) + (ax ? (aux->nwords + 255) / 256 : 0)), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni, y.lds,
                  n.ndir, (long long)n.N * y.lds, nbi, nbp, (const float*)n.v, y.Wt, y.bias, y.Rf, y.Rb, y.pd,
-                 lo ? n.lo_stage : nullptr, n.line_off.p, n.bs + 1);
+                 lo ? n.lo_stage : nullptr, n.line_off.p, n.bs + 1, ax ? aux->src : nullptr, ax ? aux->dst : nullptr, ax ? aux->nwords : 0);
     if (lo) { n.ring.commit(g_stream); n.lo_pending = false; }
+    if (ax) { h->ctc.ring.commit(g_stream); aux_done = true; }
     n.packed_dirty = false;
   } else {
     CLSTM_LAUNCH(k_ingest, dim3(nblocks((size_t)n.N * (1 + y.ni))), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni,
                  y.lds, n.ndir, (long long)n.N * y.lds);
   }
   check_launch();
+  if (aux && aux->nwords > 0 && !aux_done) {   // not the fused launch: a plain asynchronous copy
+    HIPCHECK(hipMemcpyAsync(aux->dst, aux->src, (size_t)aux->nwords * sizeof(int), hipMemcpyHostToDevice, g_stream));
+    h->ctc.ring.commit(g_stream);
+  }
   n.src0_ready = true;
 }
 int clstm_net_set_inputs_d(clstm_net* h, const float* x) {
@@ -1338,7 +1364,8 @@ int clstm_net_outputs(clstm_net* h, float** p, float** d) {
 }
 int clstm_net_get_outputs_h(clstm_net* h, float* p) { ABI_BEGIN copy_d2h(p, h->net.Z.p, (size_t)h->net.N * h->net.desc.nclasses); ABI_END }
 int clstm_net_set_output_deltas_h(clstm_net* h, const float* p) { ABI_BEGIN copy_h2d(h->net.Dz.p, p, (size_t)h->net.N * h->net.desc.nclasses); ABI_END }
-static void net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* aligned_h) {
+static void net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* aligned_h, CtcMetaCopy* defer = nullptr,
+                    bool launch = true) {
   Net& n = h->net;
   REQUIRE(n.N > 0, "set_batch first");
   std::vector<int> soff(n.bs + 1, 0), states;
@@ -1354,10 +1381,18 @@ static void net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* al
   }
   float* al = nullptr;
   if (aligned_h) { n.aligned.reserve((size_t)n.N * n.desc.nclasses); al = n.aligned.p; }
+  if (launch) n.timing.begin("ctc_align", g_stream);
+  run_ctc(h->ctc, n.Z.p, n.Dz.p, al, n.desc.nclasses, n.line_off_h.data(), states.data(), soff.data(), n.bs, g_stream, defer, launch);
+  if (launch) n.timing.end(g_stream);
+  if (aligned_h && launch) copy_d2h(aligned_h, al, (size_t)n.N * n.desc.nclasses);
+}
+// the alignment prepared by net_ctc(..., launch = false)
+static void net_ctc_launch(clstm_net* h) {
+  Net& n = h->net;
   n.timing.begin("ctc_align", g_stream);
-  run_ctc(h->ctc, n.Z.p, n.Dz.p, al, n.desc.nclasses, n.line_off_h.data(), states.data(), soff.data(), n.bs, g_stream);
+  CLSTM_LAUNCH(ctc_align_kernel, dim3(h->ctc.pending_bs), dim3(CTC_THREADS), h->ctc.pending_smem, g_stream, h->ctc.pending);
+  check_launch();
   n.timing.end(g_stream);
-  if (aligned_h) copy_d2h(aligned_h, al, (size_t)n.N * n.desc.nclasses);
 }
 int clstm_net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* aligned_h) {
   ABI_BEGIN
@@ -1429,9 +1464,11 @@ int clstm_net_train_step(clstm_net* h, const int* T_h, int bs, const float* x_d,
   ABI_BEGIN
   REQUIRE(h && T_h && x_d && labels_h && L_h, "null argument");
   h->net.set_batch(T_h, bs);
-  net_set_inputs_d(h, x_d);
+  CtcMetaCopy meta;
+  net_ctc(h, labels_h, L_h, nullptr, &meta, false);   // host half of the alignment first: its metadata rides the ingest launch
+  net_set_inputs_d(h, x_d, &meta);
   h->net.forward();
-  net_ctc(h, labels_h, L_h, nullptr);
+  net_ctc_launch(h);
   h->net.backward();
   h->net.update();   // all-reduces the fresh gradient first when a communicator is attached
   ABI_END

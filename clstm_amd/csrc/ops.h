@@ -404,9 +404,19 @@ __global__ void k_ingest(const float* x, float* X, float* S, size_t N, int ni, i
 // and each is far too small to fill the chip, so one launch ramp / tail instead of two.
 __global__ void k_ingest_pack(const float* x, float* X, float* S, size_t N, int ni, int lds, int ndir, long long sdir,
                               int nbi, int nbp, const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p,
-                              const int* lo_src, int* lo_dst, int lo_n) {
-  if ((int)blockIdx.x >= nbi + nbp) {   // optional last block: the line offsets, straight from the pinned host slot
-    for (int i = threadIdx.x; i < lo_n; i += blockDim.x) lo_dst[i] = lo_src[i];
+                              const int* lo_src, int* lo_dst, int lo_n, const int* aux_src, int* aux_dst, int aux_n) {
+  if ((int)blockIdx.x >= nbi + nbp) {   // optional trailing blocks: small host arrays, straight from their pinned slots
+    // (one element per thread: a read of host memory takes microseconds, so they must all be in flight at once)
+    int blk = (int)blockIdx.x - (nbi + nbp);
+    if (lo_src) {                       //   the line offsets: first trailing block
+      if (blk == 0) {
+        for (int i = threadIdx.x; i < lo_n; i += blockDim.x) lo_dst[i] = lo_src[i];
+        return;
+      }
+      blk--;
+    }
+    const int i = blk * (int)blockDim.x + (int)threadIdx.x;   //   the CTC metadata of this training step
+    if (i < aux_n) aux_dst[i] = aux_src[i];
     return;
   }
   if ((int)blockIdx.x < nbi) {
