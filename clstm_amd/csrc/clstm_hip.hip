@@ -17,6 +17,7 @@
 #include "gemm_mfma.h"
 #include "gemm_bf16.h"
 #include "gemm_dw.h"
+#include "lstm_bwd_dw.h"
 #include "softmax_fused.h"
 #include "lstm_seq.h"
 #include "lstm_wide.h"
@@ -194,6 +195,18 @@ static void launch_lstm(bool fwd, int nk4, int ku, LstmSeqArgs a, int bs, int nt
   CASE_(1, 4) CASE_(2, 8) CASE_(4, 16) CASE_(7, 28) CASE_(7, 25) CASE_(8, 32)
 #undef CASE_
   throw Error("unsupported nhidden for the register-resident recurrence");
+}
+
+template <int NK4, int KU>
+static void launch_bwd_dw(const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s, int workers) {
+  const size_t smem = (2 * 16 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
+  CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec, workers);
+}
+static bool launch_lstm_bwd_dw(int nk4, int ku, const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s, int workers) {
+#define CASE_(N, K) if (nk4 == N && ku == K) { launch_bwd_dw<N, K>(a, g, nrec, ngemm, nthreads, s, workers); check_launch(); return true; }
+  CASE_(7, 25) CASE_(7, 28) CASE_(4, 16) CASE_(8, 32)    // (thread count must cover the GEMM role's 256)
+#undef CASE_
+  return false;
 }
 
 // lock-step recurrence (lstm_wide.h): one cooperative launch for the whole sequence when every workgroup
@@ -503,18 +516,19 @@ struct Net {
   // --- weight-gradient GEMM beside the backward recurrence (gemm_dw.h) ---
   static const int PROG_LINES = 2048;                          // overlap only for minibatches up to this many lines
   static const int PROG_WORDS = 2 * PROG_LINES * PROG_STRIDE;   // progress words at the tail of a narrow layer's D allocation: [ndir][bs], one per 128 B
-  // CLSTM_OVERLAP / clstm_net_set_overlap: 0 (default) off; 1: on for batches large enough; 2: always (tests force
-  // the path onto tiny nets).  OFF by default -- measured on MI355X at the bench shape (profiles/r02_overlap_*.txt):
-  // the kernels do overlap, but the f32 GEMM needs ~105 us on the 128 CUs the recurrence leaves it (52 us on 256), so
-  // ~45 us of it still trail the 95 us recurrence, and while both run every other kernel of the step slows down by
-  // 10-20 % (chip-wide clock under the higher load): 0.443 ms per step against 0.377 ms with one stream.
-  int overlap = getenv("CLSTM_OVERLAP") ? atoi(getenv("CLSTM_OVERLAP")) : 0;
+  // CLSTM_OVERLAP / clstm_net_set_overlap: 0 off (GEMM after the recurrence); 1 (default): recurrence and GEMM as two
+  // roles of ONE launch (lstm_bwd_dw.h) for batches large enough -- 0.369 -> 0.356 ms per step at the bench shape;
+  // 2: the same always (tests force it onto tiny nets);
+  // 3: two launches on streams with complementary CU masks -- measured slower than mode 0 on MI355X at the bench shape
+  // (0.443 vs 0.377 ms per step, profiles/r02_timeline_overlap.txt: fork and join through events cost ~37 us and the
+  // f32 GEMM needs ~105 us on the 128 CUs the masks leave it), kept for the record.
+  int overlap = getenv("CLSTM_OVERLAP") ? atoi(getenv("CLSTM_OVERLAP")) : 1;
   struct Side {   // two streams with complementary CU masks + the events of the fork / join
     hipStream_t rec = nullptr, side = nullptr;
     hipEvent_t fork{}, rec_done{}, side_done{};
     bool tried = false, ok = false;
   } os;
-  DevBuf<int> dw_ktab, dw_slabs, dw_timeouts;
+  DevBuf<int> dw_ktab, dw_slabs, dw_timeouts, dw_queue;   // dw_queue: [8] queue heads | [8 * 256] CU marks
   std::vector<int> dw_key;        // line offsets the tables were built for
   int dw_nslabs = 0, dw_slabs_per_dir = 0, dw_ntiles_max = 0;
   int prog_base = 1024;           // grows with every backward launch: stale progress words never look complete
@@ -798,9 +812,10 @@ struct Net {
   bool overlap_eligible(const Layer& y) {
     if (!overlap || y.wide || y.no % 16 == 0) return false;          // the reporting lane must own no cell
     if (bs > PROG_LINES) return false;
-    if (overlap < 2 && (tmax < 64 || N < 2048)) return false;        // too small to be worth the fork / join
+    if ((overlap == 1) && (tmax < 64 || N < 2048)) return false;     // too small to profit
     if ((double)y.D.cap * 4.0 >= 2147483000.0) return false;         // 32-bit byte offsets inside one descriptor
-    return side_streams();
+    if (overlap == 3) return side_streams();                         // two streams with complementary CU masks
+    return overlap == 2 || y.nthreads >= 256;                        // one launch, two workgroup roles (lstm_bwd_dw.h)
   }
   // k-tile tables and slabs of the chunked weight-gradient GEMM for the current batch geometry (rebuilt only when the
   // line lengths change).  Chunks are ranges of recurrence iterations, longest first: the work left when the
@@ -808,7 +823,13 @@ struct Net {
   void build_dw_tables() {
     if (dw_key == line_off_h && dw_nslabs > 0) return;
     std::vector<int> cb;   // chunk ends (iterations), multiples of 8 except the last
-    {
+    // equal chunks of 16 iterations measured best at the bench shape (8: 0.407 ms per step, 16: 0.356, 32: 0.359,
+    // 48: 0.360, decreasing 64..16: 0.3615); CLSTM_DW_CHUNK=0 selects the decreasing plan
+    static const int uniform = getenv("CLSTM_DW_CHUNK") ? atoi(getenv("CLSTM_DW_CHUNK")) : 16;
+    if (uniform >= 8) {
+      for (int done = uniform; done < tmax; done += uniform) cb.push_back(done);
+      cb.push_back(tmax);
+    } else {
       static const int w[5] = {8, 6, 5, 4, 2};
       int done = 0;
       for (int c = 0; c < 5 && done < tmax; c++) {
@@ -893,9 +914,28 @@ struct Net {
     g.partial = partial.p; g.R = R; g.Cn = Cn;
     g.gx = (unsigned)((Cn + GEMM_BT - 1) / GEMM_BT); g.gy = (unsigned)((R + GEMM_BT - 1) / GEMM_BT);
     g.timeouts = dw_timeouts.p;
+    if (!dw_queue.p) dw_queue.reserve(8 + 8 * 256 + 8);
+    g.qhead = dw_queue.p; g.cu_busy = dw_queue.p + 8; g.ndir = ndir;
     const unsigned nblk = (unsigned)((dw_nslabs + 7) / 8) * 8u * g.gx * g.gy;
-    hipStream_t srec = os.rec ? os.rec : s, sside = os.side ? os.side : s;
-    if (os.rec) {
+#ifndef CLSTM_HIP_EMU
+    if (overlap != 3 && y.nthreads >= 256) {   // ONE launch: the recurrence's workgroups first, the GEMM's behind them
+      timing.begin("lstm_bwd", s);
+      // workers: three per CU fit beside nothing else (168 registers per lane), one beside a recurrence workgroup
+      // GEMM role: 0 (default) one (slab, tile) item per workgroup in dispatch order; >= 1: that many persistent workers
+      // pulling items from per-XCD queues (1 = 512) -- measured slower (0.362 vs 0.356 ms per step): a 448-thread
+      // workgroup slot per worker leaves room for only two workers on an idle CU
+      static const int workers = getenv("CLSTM_DW_WORKERS") ? atoi(getenv("CLSTM_DW_WORKERS")) : 0;
+      const unsigned nworkers = workers ? (unsigned)std::min<long long>((long long)nblk, workers > 1 ? workers : 512) : nblk;
+      REQUIRE(launch_lstm_bwd_dw(y.nk4, y.pd.ku, a, g, bs * ndir, nworkers, y.nthreads, s, workers), "internal: no fused instantiation");
+      timing.end(s);
+      return;
+    }
+#endif
+    // two launches: on streams with complementary CU masks (mode 3), or one after the other (host emulator; layers too
+    // narrow for the GEMM role's 256 threads when the tests force the path)
+    const bool fork = overlap == 3 && os.rec;
+    hipStream_t srec = fork ? os.rec : s, sside = fork ? os.side : s;
+    if (fork) {
       HIPCHECK(hipEventRecord(os.fork, s));
       HIPCHECK(hipStreamWaitEvent(srec, os.fork, 0));
       HIPCHECK(hipStreamWaitEvent(sside, os.fork, 0));
@@ -907,7 +947,7 @@ struct Net {
     CLSTM_LAUNCH(gemm_dw_kernel, dim3(nblk), dim3(256), 0, sside, g);
     timing.end(sside);
     check_launch();
-    if (os.rec) {
+    if (fork) {
       HIPCHECK(hipEventRecord(os.rec_done, srec));
       HIPCHECK(hipEventRecord(os.side_done, sside));
       HIPCHECK(hipStreamWaitEvent(s, os.rec_done, 0));
@@ -946,7 +986,7 @@ struct Net {
       const int M = ndir * 4 * y.no;
       LstmSeqArgs a{};
       a.Rpk = y.Rb; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = y.dH.p; a.D = y.D.p;
-      a.line_off = line_off.p; a.no = y.no; a.ndir = ndir;
+      a.line_off = line_off.p; a.no = y.no; a.ndir = ndir; a.bs = bs;
       // W.d += delta [1; x_t; h_{t-1}]^T for the four gates of each direction
       // (both directions in one batched launch: half the slabs per direction fill the chip)
       const int R = 1 + y.ni + y.no, Cn = 4 * y.no;
@@ -979,7 +1019,7 @@ struct Net {
         ReduceDesc extra{};   // empty unless this is the top layer
         if (l == (int)L.size() - 1) extra = sm_red;
         const size_t work = (size_t)ndir * R * Cn + (size_t)extra.R * extra.Cn * extra.nbatch;
-        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, s, gates, extra, g);
+        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, s, gates, extra, g, dw_queue.p, dw_queue.p ? 8 : 0);
       }
       timing.end(s);
       check_launch();
@@ -1673,7 +1713,7 @@ int clstm_allreduce_flat(clstm_comm* c, float* buf_d, long long n) {
 }
 int clstm_net_set_overlap(clstm_net* h, int mode) {
   ABI_BEGIN
-  REQUIRE(mode >= 0 && mode <= 2, "overlap mode: 0 off, 1 on where it pays, 2 always (tests)");
+  REQUIRE(mode >= 0 && mode <= 3, "overlap mode: 0 off, 1 one launch with two roles where it pays, 2 the same always (tests), 3 two masked streams");
   h->net.overlap = mode;
   ABI_END
 }
@@ -1726,7 +1766,7 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     part->reserve((size_t)nsplit * R * Cn);
     gemm_f32<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
-                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm);
+                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0);
   } else if (mode == 10) gemm_bf16<GEMM_KC, GEMM_MC>(g_stream, gemm_kc(A, K, R, 0), gemm_mc(B, Cn, K, 0), StorePlain{Cm, Cn}, R, Cn, K);
   else if (mode == 11) gemm_bf16<GEMM_KC, GEMM_KC>(g_stream, gemm_kc(A, K, R, 0), gemm_kc(B, K, Cn, 0), StorePlain{Cm, Cn}, R, Cn, K);
   else if (mode == 12) {
@@ -1735,7 +1775,7 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     part->reserve((size_t)nsplit * R * Cn);
     gemm_bf16<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
-                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm);
+                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0);
   } else throw Error("bad mode");
   check_launch();
   ABI_END

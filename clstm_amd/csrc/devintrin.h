@@ -239,6 +239,14 @@ DEVFN f32x4 buf_load4_wt(BufF32 b, unsigned byte_off) {
 DEVFN int load_i32_wt(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 DEVFN void store_i32_wt(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 DEVFN void atomic_add_i32(int* p, int v) { atomicAdd(p, v); }
+DEVFN int atomic_fetch_add_i32(int* p, int v) { return atomicAdd(p, v); }
+// where this wave runs: XCC (XCD) id 0..7 and a slot number of its CU within the XCD (shader engine, array, CU)
+DEVFN int hw_xcc_id() { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return (int)(x & 0xF); }
+DEVFN int hw_cu_slot() {
+  unsigned hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  return (hw_xcc_id() & 7) * 256 + (int)((hw >> 8) & 0xFF);
+}
 DEVFN void sleep_some() { __builtin_amdgcn_s_sleep(16); }
 // park the wave for roughly 0.35 us per recurrence iteration still missing (s_sleep 13 ~ 832 cycles), at most ~14 us
 DEVFN void sleep_iterations(int n) {

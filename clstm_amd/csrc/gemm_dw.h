@@ -35,45 +35,32 @@ struct GemmDwArgs {
   int nslabs;
   const int* prog;          // [ndir][bs] progress words (iterations complete, biased by prog_base)
   const int* line_off;
-  int bs, prog_base;
+  int bs, prog_base, ndir;
   float* partial;           // [ndir * slabs_per_dir][R][Cn]
   int R, Cn;
   unsigned gx, gy;          // output tiles along Cn, R
   int* timeouts;            // incremented when a slab gave up waiting (diagnostics; results are then wrong)
+  // persistent workers (lstm_bwd_dw.h): per-XCD work queues and the CUs the recurrence occupies
+  int* qhead;               // [8] next item of XCD x (zeroed between launches by k_reduce_scatter)
+  int* cu_busy;             // [8 * 256] = prog_base of this launch where a recurrence workgroup runs (hw_cu_slot())
 };
 
 constexpr int DW_WATCHDOG_POLLS = 1 << 16;
 
-__global__ __launch_bounds__(256) void gemm_dw_kernel(GemmDwArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[GEMM_BT * GEMM_LDO];
-  float* As = smem;
-  float* Bs = smem + GEMM_BK * GEMM_LD;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  // workgroup b runs on XCD b % 8: XCD x takes slabs x, x+8, ... (all output tiles of a slab pull its frames through
-  // ONE L2), and because slabs are listed in readiness order every XCD gets early and late ones alike
-  const unsigned tiles = a.gx * a.gy;
-  const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-  const unsigned si = (idx / tiles) * 8u + xcd;
-  if (si >= (unsigned)a.nslabs) return;
-  const DwSlab sl = a.slabs[si];
-  const unsigned tile = idx % tiles;
-  const int r0 = (int)(tile / a.gx) * GEMM_BT, c0 = (int)(tile % a.gx) * GEMM_BT;
-  const int dir = sl.dir;
-
-  // ---- wait until every line has completed the chunk's iterations ----------------------------------------------
-  // Only wave 0 looks (one progress word per lane), and rarely: a poll is a system-scope load of up to 64 cache
-  // lines, and hundreds of workgroups polling every microsecond starve the recurrence's write-through stores
-  // (measured: 92 -> 630 us).  After each look the wave sleeps for most of the time the slowest line still needs
-  // (~0.45 us per iteration), so a workgroup polls a handful of times in all.
+// ---- wait until every line has completed `need_it` iterations of direction `dir` (called by all 256 threads) -------
+// Only wave 0 looks (one progress word per lane), and rarely: a poll is a system-scope load of up to 64 cache
+// lines, and hundreds of workgroups polling every microsecond starve the recurrence's write-through stores
+// (measured: 92 -> 630 us).  After each look the wave sleeps for most of the time the slowest line still needs
+// (~0.45 us per iteration), so a workgroup polls a handful of times in all.
+DEVFN void gemm_dw_wait(const GemmDwArgs& a, const int dir, const int need_it) {
+  const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
   if (wave == 0) {
     int polls = 0;
     for (;;) {
       int deficit = 0;
       for (int b = lane; b < a.bs; b += 64) {
         const int T = a.line_off[b + 1] - a.line_off[b];
-        const int need = a.prog_base + (sl.need_it < T ? sl.need_it : T);
+        const int need = a.prog_base + (need_it < T ? need_it : T);
         const int d = need - load_i32_wt(a.prog + ((size_t)dir * a.bs + b) * PROG_STRIDE);
         deficit = d > deficit ? d : deficit;
       }
@@ -87,6 +74,19 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(GemmDwArgs a) {
     }
   }
   __syncthreads();
+}
+
+// one work item: output tile `tile` of slab `si` (256 threads; `smem` = GEMM_BT * GEMM_LDO floats)
+DEVFN void gemm_dw_item(const GemmDwArgs& a, float* smem, const unsigned si, const unsigned tile) {
+  float* As = smem;
+  float* Bs = smem + GEMM_BK * GEMM_LD;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const DwSlab sl = a.slabs[si];
+  const int r0 = (int)(tile / a.gx) * GEMM_BT, c0 = (int)(tile % a.gx) * GEMM_BT;
+  const int dir = sl.dir;
+  gemm_dw_wait(a, dir, sl.need_it);
 
   const int a_mn = (tid & 15) * 4, a_k = tid >> 4;   // MC staging: 4 consecutive columns of frame row (tid >> 4)
   const BufF32 abuf = make_buf(a.S + (size_t)dir * a.sdir, (size_t)(a.s_elems - (long long)dir * a.sdir) * 4);
@@ -176,6 +176,48 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(GemmDwArgs a) {
         for (int e = 0; e < 4; e++)
           if (c + e < a.Cn) out[(size_t)r * a.Cn + c + e] = v[e];
     }
+  }
+}
+// grid mode: workgroup `block` computes one item.  Workgroup b runs on XCD b % 8: XCD x takes slabs x, x+8, ... (all
+// output tiles of a slab pull its frames through ONE L2), and because slabs are listed in readiness order every XCD
+// gets early and late ones alike
+DEVFN void gemm_dw_body(const GemmDwArgs& a, float* smem, const unsigned block) {
+  const unsigned tiles = a.gx * a.gy;
+  const unsigned xcd = block & 7u, idx = block >> 3;
+  const unsigned si = (idx / tiles) * 8u + xcd;
+  if (si >= (unsigned)a.nslabs) return;
+  gemm_dw_item(a, smem, si, idx % tiles);
+}
+__global__ __launch_bounds__(256) void gemm_dw_kernel(GemmDwArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[GEMM_BT * GEMM_LDO];
+  gemm_dw_body(a, smem, blockIdx.x);
+}
+
+// persistent worker (a role of lstm_bwd_dw_kernel): pulls items of its XCD's queue until it is empty.  A worker that
+// finds itself on a CU where a recurrence workgroup runs would only get the issue slots that workgroup leaves and
+// hold its slab back; it waits until every line is complete and joins for the remainder.
+DEVFN void gemm_dw_worker(const GemmDwArgs& a, float* smem, int* lds_item) {
+  const int tid = threadIdx.x;
+  const unsigned tiles = a.gx * a.gy;
+  const int xcd = hw_xcc_id() & 7;
+  const int nslabs_x = (a.nslabs - xcd + 7) / 8;
+  const int nitems = nslabs_x * (int)tiles;
+  sleep_iterations(8);    // ~3 us: the recurrence workgroups (dispatched first) have marked their CUs by now
+  if (tid == 0) *lds_item = load_i32_wt(a.cu_busy + hw_cu_slot()) == a.prog_base ? 1 : 0;
+  __syncthreads();
+  const bool shared_cu = *lds_item != 0;
+  __syncthreads();
+  if (shared_cu) {
+    for (int d = 0; d < a.ndir; d++) gemm_dw_wait(a, d, 0x3fffffff);
+  }
+  for (;;) {
+    if (tid == 0) *lds_item = atomic_fetch_add_i32(a.qhead + xcd, 1);
+    __syncthreads();
+    const int item = *lds_item;
+    __syncthreads();
+    if (item >= nitems) break;
+    gemm_dw_item(a, smem, (unsigned)(item / (int)tiles) * 8u + (unsigned)xcd, (unsigned)item % tiles);
+    __syncthreads();
   }
 }
 

@@ -58,6 +58,7 @@ struct LstmSeqArgs {
   // same descriptor) and counts the iterations of that line whose deltas are complete in memory.  -1: none.
   long long prog_off;
   int prog_base;        // value that means "0 iterations complete" for this launch (monotonic across launches)
+  int bs;               // lines in the batch (index stride of the progress words)
 };
 
 // One workgroup per CU, at most two of its waves per SIMD: tell hipcc, or its scheduler trades the up-front issue of
@@ -269,15 +270,15 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
 #endif
 }
 
+// (workgroup body: line b, direction dir -- also one of the two roles of lstm_bwd_dw_kernel below)
 template <int NK4, int KU>
-__global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_kernel(LstmSeqArgs a) {
+DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
   constexpr int SLP = 4 * NK4;
   constexpr int QS = SLP + ((NK4 & 1) ? 0 : 4);
   constexpr int DB = 16 * QS;
   float* lds = dyn_smem<float>();  // dbuf[2][DB] + dump word
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x;
-  const int b = blockIdx.x, dir = blockIdx.y;
   const int no = a.no, nd = a.ndir;
   const int SL = (4 * no + 15) / 16;  // (gate,j) pairs per slice
   const int js = lane & 15;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_ke
   const int T = a.line_off[b + 1] - off;
   if (T <= 0) {   // an empty line is complete at once
     if (a.prog_off >= 0 && tid == 0) {
-      store_i32_wt(reinterpret_cast<int*>(a.D + a.prog_off) + ((size_t)dir * gridDim.x + b) * PROG_STRIDE, a.prog_base);
+      store_i32_wt(reinterpret_cast<int*>(a.D + a.prog_off) + ((size_t)dir * a.bs + b) * PROG_STRIDE, a.prog_base);
     }
     return;
   }
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_ke
   const bool report = a.prog_off >= 0;
 #endif
   const bool tagl = report && tid == nthreads - 1;            // requires cell(tid) >= no (checked by the host)
-  const long long prog_rel = a.prog_off + ((long long)dir * gridDim.x + b) * PROG_STRIDE - (long long)off * (gstride4 / 4);
+  const long long prog_rel = a.prog_off + ((long long)dir * a.bs + b) * PROG_STRIDE - (long long)off * (gstride4 / 4);
   const BufF32 dbuf = make_buf(a.D + (size_t)off * (gstride4 / 4), report ? (size_t)(prog_rel + 1) * 4 : (size_t)T * gstride4);
   const BufF32 cbuf = make_buf(a.C + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
   const BufF32 hbuf = make_buf(a.dH + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
@@ -444,6 +445,10 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_ke
     __syncthreads();
     if (tagl) buf_store_wt(dbuf, ptag, __builtin_bit_cast(float, a.prog_base + T));
   }
+}
+template <int NK4, int KU>
+__global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_kernel(LstmSeqArgs a) {
+  lstm_bwd_body<NK4, KU>(a, blockIdx.x, blockIdx.y);
 }
 
 }  // namespace clstm

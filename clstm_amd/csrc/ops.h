@@ -362,7 +362,9 @@ DEVFN void reduce_scatter_one(const ReduceDesc& d, size_t e, float* g) {
   g[o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 // up to two slab sets per launch (the softmax layer's weight gradient rides with the top LSTM layer's)
-__global__ void k_reduce_scatter(ReduceDesc d0, ReduceDesc d1, float* g) {
+__global__ void k_reduce_scatter(ReduceDesc d0, ReduceDesc d1, float* g, int* zero, int zero_n) {
+  // (house-keeping that rides this launch: the work-queue heads of the fused backward launch return to zero)
+  if (zero && blockIdx.x == 0 && (int)threadIdx.x < zero_n) zero[threadIdx.x] = 0;
   const size_t n0 = (size_t)d0.R * d0.Cn * d0.nbatch, n1 = (size_t)d1.R * d1.Cn * d1.nbatch;
   CLSTM_GRID_STRIDE(e, n0 + n1) {
     if (e < n0) reduce_scatter_one(d0, e, g);

@@ -191,11 +191,12 @@ int clstm_net_get_state_h(clstm_net* net, int layer, int dir, int which, float* 
 /* name and average device time (ms, hipEvent-timed on the library's stream) of the most
  * recent forward/backward kernels -- used by bench.py for the roofline object.
  * Enable with clstm_net_enable_timing(net, 1). */
-/* The weight-gradient GEMM of a narrow BiLSTM layer runs beside the backward recurrence (two streams with
- * complementary CU masks; csrc/gemm_dw.h).  mode 0 (default): off (one stream, GEMM after the recurrence); 1:
- * on for batches large enough; 2: always (tests).  Results are the same sums in a different slab order.
- * Off by default: measured slower on MI355X at the bench shape.
- * stats: overlapped backward passes so far; slabs that gave up waiting for the recurrence (must stay 0). */
+/* The weight-gradient GEMM of a narrow BiLSTM layer runs beside the backward recurrence (csrc/gemm_dw.h):
+ * mode 0: off (GEMM after the recurrence); 1 (default): both as two workgroup roles of ONE launch
+ * (csrc/lstm_bwd_dw.h) for batches large enough to profit; 2: the same always (tests); 3: two launches on streams
+ * with complementary CU masks (measured slower than mode 0, kept for the record).  Results are the same sums in a
+ * different slab order.  stats: overlapped backward passes so far; slabs that gave up waiting for the recurrence
+ * (must stay 0). */
 int clstm_net_set_overlap(clstm_net* net, int mode);
 int clstm_net_overlap_stats(clstm_net* net, long long* launches, int* timeouts);
 int clstm_net_enable_timing(clstm_net* net, int on);

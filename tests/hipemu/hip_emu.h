@@ -211,6 +211,9 @@ inline f32x4 buf_load4_wt(BufF32 b, unsigned off) { return buf_load4(b, off); }
 inline int load_i32_wt(const int* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 inline void store_i32_wt(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 inline void atomic_add_i32(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline int atomic_fetch_add_i32(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline int hw_xcc_id() { return 0; }
+inline int hw_cu_slot() { return 0; }
 inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const unsigned*) { *s = nullptr; return 0; }
 inline void sleep_some() { sched_yield(); }
 inline void sleep_iterations(int) { sched_yield(); }
