@@ -244,6 +244,9 @@ def main():
                 kern[name] = {"ms_per_step": round(ms / args.profile_steps, 4), "launches_per_step": n / args.profile_steps}
         net.enable_timing(False)
         dom = max(("lstm_fwd", "lstm_bwd"), key=lambda k: kern.get(k, {"ms_per_step": 0})["ms_per_step"])
+        if "gemm_gates_dw" not in kern:
+            dom = "lstm_fwd"     # the backward recurrence shares its launch with the weight-gradient GEMM (lstm_bwd_dw.h):
+                                 # the pure fused gate kernel of the step is the forward recurrence
         traffic, traffic_src = None, None
         try:   # HBM bytes per launch from the newest committed rocprofv3 PMC passes (same workload only)
             import glob

@@ -1,7 +1,7 @@
 #!/bin/bash
-# One gpurun call: GPU parity tests, smoke, bench lines, rocprof kernel stats.
-# Usage (from the build container):  gpurun --timeout 1500 -- 'bash scripts/gpu_round.sh r01'
-TAG=${1:-r01}
+# One gpurun call: GPU parity tests, smoke, bench lines, rocprof kernel stats, PMC passes, diagnostics.
+# Usage (from the build container):  gpurun --timeout 2400 -- 'bash scripts/gpu_round.sh r02'
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$ROOT"
 OUT="$ROOT/gpurun_out/$TAG"
@@ -10,55 +10,67 @@ export TMPDIR=/tmp
 { rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -8; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket"; } > "$OUT/host.txt" 2>&1
 python -c "from oracle.oracle import build; build()" > "$OUT/oracle_build.log" 2>&1
 
-echo "=== pytest -m gpu" 
+echo "=== pytest -m gpu"
 timeout 1200 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
-RC=$?
-tail -15 "$OUT/pytest_gpu.log"
-if [ $RC -ne 0 ]; then
-  echo "=== DPP variant failed; full run + shfl variant for diagnosis"
-  timeout 900 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu_all.log" 2>&1; tail -40 "$OUT/pytest_gpu_all.log"
-  CLSTM_HIP_VARIANT=shfl timeout 900 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu_shfl.log" 2>&1; tail -30 "$OUT/pytest_gpu_shfl.log"
-fi
-
+tail -3 "$OUT/pytest_gpu.log"
 echo "=== smoke"
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -3 "$OUT/smoke.log"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -1 "$OUT/smoke.log"
 
+B() { timeout 600 python bench.py "$@"; }
 echo "=== bench (default = minibatch 64, T=200)"
-timeout 900 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; cat "$OUT/bench_default.json"; tail -3 "$OUT/bench_default.err"
+B > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; cut -c1-400 "$OUT/bench_default.json"; tail -2 "$OUT/bench_default.err" | grep -v amdgpu
 for MB in 1 16 256 1024; do
-  echo "=== bench minibatch $MB"
-  timeout 300 python bench.py --minibatch $MB --no-cpu-baseline --steps 20 > "$OUT/bench_mb$MB.json" 2> "$OUT/bench_mb$MB.err"; cat "$OUT/bench_mb$MB.json"; tail -2 "$OUT/bench_mb$MB.err"
+  B --minibatch $MB --no-cpu-baseline --steps 50 --warmup 10 > "$OUT/bench_mb$MB.json" 2> "$OUT/bench_mb$MB.err"; cut -c1-220 "$OUT/bench_mb$MB.json"
 done
-echo "=== bench ragged"
-timeout 300 python bench.py --ragged --no-cpu-baseline --steps 20 > "$OUT/bench_ragged.json" 2> "$OUT/bench_ragged.err"; cat "$OUT/bench_ragged.json"
+B --ragged --no-cpu-baseline > "$OUT/bench_ragged.json" 2>/dev/null; cut -c1-220 "$OUT/bench_ragged.json"
+CLSTM_OVERLAP=0 B --no-cpu-baseline > "$OUT/bench_overlap0.json" 2>/dev/null; cut -c1-220 "$OUT/bench_overlap0.json"
+BENCH_FORCE_DIST=1 B --no-cpu-baseline > "$OUT/bench_forcedist.json" 2>/dev/null; cut -c1-220 "$OUT/bench_forcedist.json"
+echo "=== bench 2xBiLSTM(512) shape: f32 / bf16 hoisted GEMMs / bf16 MFMA everywhere"
+B --config b2 --steps 10 --warmup 3 --profile-steps 2 > "$OUT/bench_b2.json" 2>/dev/null; cut -c1-200 "$OUT/bench_b2.json"
+B --config b2 --steps 10 --warmup 3 --profile-steps 2 --bf16-gemm > "$OUT/bench_b2_bf16gemm.json" 2>/dev/null; cut -c1-200 "$OUT/bench_b2_bf16gemm.json"
+B --config b2 --steps 10 --warmup 3 --profile-steps 2 --bf16 > "$OUT/bench_b2_bf16.json" 2>/dev/null; cut -c1-200 "$OUT/bench_b2_bf16.json"
 
-echo "=== rocprofv3 kernel stats"
+echo "=== rocprofv3 kernel stats + one-step timeline"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > "$OUT/rocprof.log" 2>&1
-tail -3 "$OUT/rocprof.log"
-find "$OUT/prof" -name "*kernel_stats*" | head -2 | while read f; do echo "--- $f"; head -25 "$f"; done
+tail -1 "$OUT/rocprof.log" | cut -c1-200
+find "$OUT/prof" -name "*kernel_stats*" | head -1 | while read f; do head -16 "$f"; done
+F=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)
+python - "$F" "$OUT/timeline.txt" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "k_ingest_pack" in r["Kernel_Name"]]
+a, b = idx[-2], idx[-1]
+t0 = int(rows[a]["Start_Timestamp"])
+out = open(sys.argv[2], "w")
+out.write("one training step under rocprofv3 --kernel-trace (us from the start of k_ingest_pack): start  end  duration  kernel\n")
+for r in rows[a:b]:
+    s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+    out.write("%9.2f %9.2f %8.2f  %s\n" % (s / 1e3, e / 1e3, (e - s) / 1e3, r["Kernel_Name"].split("(")[0][:80]))
+out.write("step length %.2f us\n" % ((int(rows[b]["Start_Timestamp"]) - t0) / 1e3))
+out.close()
+print(open(sys.argv[2]).read())
+PY
 find "$OUT/prof" -name "*kernel_trace*" -size +20M -delete
-echo "=== rocprofv3 PMC passes (HBM traffic): FETCH_SIZE, WRITE_SIZE in separate runs"
+echo "=== rocprofv3 PMC passes (separate runs): FETCH_SIZE, WRITE_SIZE, MFMA busy, SQ wave states"
 for CNT in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_$CNT" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/rocprof_$CNT.log" 2>&1
-  tail -2 "$OUT/rocprof_$CNT.log"
-  python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_$CNT" $CNT > "$OUT/pmc_${CNT}_summary.txt" 2>&1; cat "$OUT/pmc_${CNT}_summary.txt"
+  python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_$CNT" $CNT > "$OUT/pmc_${CNT}_summary.txt" 2>&1; head -14 "$OUT/pmc_${CNT}_summary.txt"
   find "$OUT/pmc_$CNT" -name "*.csv" -size +8M -delete
 done
-echo "=== rocprofv3 PMC pass: MFMA busy cycles (north star: MFMA utilisation of the batched gate GEMMs)"
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_MFMA" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/rocprof_MFMA.log" 2>&1
-tail -2 "$OUT/rocprof_MFMA.log"
 for CNT in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_MFMA" $CNT > "$OUT/pmc_${CNT}_summary.txt" 2>&1; head -8 "$OUT/pmc_${CNT}_summary.txt"
 done
 find "$OUT/pmc_MFMA" -name "*.csv" -size +8M -delete
-echo "=== rocprofv3 PMC pass: SQ wave-state counters (where the waves of each kernel spend their cycles)"
 SQC="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU"
 timeout 600 rocprofv3 --pmc $SQC --kernel-trace --output-format csv -d "$OUT/pmc_SQ" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/rocprof_SQ.log" 2>&1
-tail -2 "$OUT/rocprof_SQ.log"
 for CNT in $SQC; do python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_SQ" $CNT | head -6; done > "$OUT/pmc_SQ_summary.txt" 2>&1
-head -20 "$OUT/pmc_SQ_summary.txt"
+head -12 "$OUT/pmc_SQ_summary.txt"
 find "$OUT/pmc_SQ" -name "*.csv" -size +8M -delete
-echo "=== bench 2xBiLSTM(512) shape (f32)"
-timeout 600 python "$ROOT/bench.py" --config b2 --steps 5 --warmup 2 --profile-steps 2 > "$OUT/bench_b2.json" 2> "$OUT/bench_b2.err"; cut -c1-300 "$OUT/bench_b2.json"
+echo "=== diagnostics: per-phase cycles of the forward recurrence and of the CTC kernel"
+cd "$ROOT"
+CLSTM_HIP_VARIANT=prof timeout 300 python scripts/gpu_lstmprof.py > "$OUT/lstm_fwd_phase_cycles.txt" 2>&1; tail -9 "$OUT/lstm_fwd_phase_cycles.txt"
+timeout 300 python scripts/gpu_ctcprof.py > "$OUT/ctc_phase_cycles.txt" 2>&1; tail -6 "$OUT/ctc_phase_cycles.txt"
 echo "=== done"
