@@ -180,6 +180,15 @@ static int pick_nk4(int no) {
 }
 template <int NK4, int KU>
 static void launch_fwd(const LstmSeqArgs& a, int bs, int nthreads, hipStream_t s) {
+  // CLSTM_FWD2=1: the second form of the kernel (the first-dispatched waves store everybody's results from LDS).
+  // Parity-tested, measured on MI355X: 100.5 us vs 96.6 us for the first form -- the stores of the waves that define
+  // the step were already hidden behind their wait for the older wave's FMAs -- so it is not the default.
+  static const bool fwd2 = getenv("CLSTM_FWD2") && atoi(getenv("CLSTM_FWD2")) != 0;
+  if (fwd2) {
+    const size_t smem2 = (2 * (4 * (size_t)lstm_qstride(NK4) + 16 * NK4 + 64 * NK4) + 4) * sizeof(float);
+    CLSTM_LAUNCH((lstm_fwd2_kernel<NK4, KU>), dim3(bs, a.ndir), dim3(nthreads), smem2, s, a);
+    return;
+  }
   const size_t smem = (2 * 4 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
   CLSTM_LAUNCH((lstm_fwd_kernel<NK4, KU>), dim3(bs, a.ndir), dim3(nthreads), smem, s, a);
 }
