@@ -1,7 +1,9 @@
-// hip_emu.h -- TEST-ONLY host-thread emulator of the handful of HIP/gfx950 primitives that
+// hip_emu.h -- TEST-ONLY host emulator of the handful of HIP/gfx950 primitives that
 // clstm_amd/csrc uses (see devintrin.h).  It lets the CPU test-suite (-m "not gpu") execute
-// the real kernel sources -- one OS thread per GPU thread, blocks run one after another --
-// to validate indexing, LDS hand-offs and barrier placement where no GPU is available.
+// the real kernel sources -- one FIBER per GPU thread (a workgroup is a set of fibers switched
+// cooperatively on one OS thread, so a barrier costs a few context switches instead of a futex
+// storm), workgroups spread over the host cores -- to validate indexing, LDS hand-offs and
+// barrier placement where no GPU is available.
 // MFMA / DPP lane layouts follow /opt/skills/guides/cdna_hip_programming.md §3 and the LLVM
 // DppCtrl table; they are assumptions of the emulator, re-checked on hardware by
 // tests/test_gpu_intrinsics.py.  Never built into, or loaded by, the product library.
@@ -59,7 +61,7 @@ inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local   /* one workgroup at a time per OS thread */
 #define __restrict__
 #define hipFuncSetAttribute(...) 0
 #define DEVFN static inline
@@ -81,17 +83,32 @@ inline f32x2 fma2_hi(f32x2 w, f32x2 hp, f32x2 acc) { return (f32x2){fmaf(w[0], h
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
 // ---- block / wave runtime -----------------------------------------------------------
+struct EmuBar { unsigned n = 0, count = 0, gen = 0; };
+struct EmuFiber { void* sp; uint3_emu tid; unsigned wave; bool done; };
 struct EmuBlock {
-  pthread_barrier_t block_bar;
-  std::vector<pthread_barrier_t> wave_bar;
+  EmuBar block_bar;
+  std::vector<EmuBar> wave_bar;
   std::vector<float> xf;   // [wave][64][16] exchange slots
   char* smem;
+  std::vector<EmuFiber> fib;
+  unsigned cur = 0, live = 0;
+  void* main_sp = nullptr;
+  void (*body)(void*) = nullptr;
+  void* body_arg = nullptr;
 };
 extern thread_local EmuBlock* emu_blk;
-inline void __syncthreads() { pthread_barrier_wait(&emu_blk->block_bar); }
+void emu_yield();                                   // run the next live fiber of this workgroup
+void emu_run_block(EmuBlock& blk, dim3 block, void (*body)(void*), void* arg);
+void emu_parallel_for(unsigned n, void (*fn)(unsigned, void*), void* arg);
+inline void emu_bar_wait(EmuBar& b) {
+  const unsigned g = b.gen;
+  if (++b.count >= b.n) { b.count = 0; b.gen++; return; }
+  while (b.gen == g) emu_yield();
+}
+inline void __syncthreads() { emu_bar_wait(emu_blk->block_bar); }
 inline int emu_lane() { return threadIdx.x & 63; }
 inline int emu_wave() { return threadIdx.x >> 6; }
-inline void emu_wave_sync() { pthread_barrier_wait(&emu_blk->wave_bar[emu_wave()]); }
+inline void emu_wave_sync() { emu_bar_wait(emu_blk->wave_bar[emu_wave()]); }
 inline float* emu_slot(int lane, int k = 0) { return &emu_blk->xf[((size_t)emu_wave() * 64 + lane) * 16 + k]; }
 
 inline float wave_shfl(float x, int src) {
@@ -215,8 +232,8 @@ inline int atomic_fetch_add_i32(int* p, int v) { return __atomic_fetch_add(p, v,
 inline int hw_xcc_id() { return 0; }
 inline int hw_cu_slot() { return 0; }
 inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const unsigned*) { *s = nullptr; return 0; }
-inline void sleep_some() { sched_yield(); }
-inline void sleep_iterations(int) { sched_yield(); }
+inline void sleep_some() { emu_yield(); sched_yield(); }
+inline void sleep_iterations(int) { emu_yield(); sched_yield(); }
 inline int wave_max_i(int x) { for (int m = 32; m >= 1; m >>= 1) { const int y = wave_shfl_i(x, emu_lane() ^ m); x = y > x ? y : x; } return x; }
 inline void drain_vmem() {}
 inline unsigned mad_u24(unsigned a, unsigned b, unsigned c) { return a * b + c; }
@@ -244,41 +261,34 @@ inline bool grid_barrier(int* sync, int target, int* lds_flag) {
   return *lds_flag == 0;
 }
 
-// cooperative launch: ALL blocks live at once (needed by grid_barrier); only for small test grids
+inline void emu_init_block(EmuBlock& blk, unsigned nthreads, std::vector<char>& sm, size_t smem) {
+  if (nthreads % 64 != 0) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }
+  blk.xf.assign((size_t)nthreads * 16, 0.f);
+  sm.assign(smem + 16, 0);
+  blk.smem = sm.data();
+}
+
+// cooperative launch: ALL blocks live at once (needed by grid_barrier) -- one OS thread per workgroup; only
+// for small test grids
 template <typename K, typename A>
 void emu_launch_coop(K kernel, dim3 grid, dim3 block, size_t smem, A arg) {
   const unsigned nthreads = block.x * block.y * block.z;
   const unsigned nblocks = grid.x * grid.y * grid.z;
-  if (nthreads % 64 != 0) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }
-  if ((size_t)nblocks * nthreads > 20000) { fprintf(stderr, "emu: cooperative grid too large for the emulator\n"); abort(); }
-  std::vector<EmuBlock> blks(nblocks);
-  std::vector<std::vector<char>> sms(nblocks);
+  if (nblocks > 512) { fprintf(stderr, "emu: cooperative grid too large for the emulator\n"); abort(); }
+  struct Ctx { K kernel; A* arg; } ctx{kernel, &arg};
   std::vector<std::thread> th;
-  th.reserve((size_t)nblocks * nthreads);
-  for (unsigned b = 0; b < nblocks; b++) {
-    EmuBlock& blk = blks[b];
-    pthread_barrier_init(&blk.block_bar, nullptr, nthreads);
-    blk.wave_bar.resize(nthreads / 64);
-    for (auto& w : blk.wave_bar) pthread_barrier_init(&w, nullptr, 64);
-    blk.xf.assign((size_t)nthreads * 16, 0.f);
-    sms[b].assign(smem + 16, 0);
-    blk.smem = sms[b].data();
-  }
+  th.reserve(nblocks);
   for (unsigned b = 0; b < nblocks; b++)
-    for (unsigned t = 0; t < nthreads; t++)
-      th.emplace_back([&, b, t]() {
-        emu_blk = &blks[b];
-        threadIdx = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
-        blockIdx = {b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y)};
-        blockDim = block;
-        gridDim = grid;
-        kernel(arg);
-      });
+    th.emplace_back([&, b]() {
+      EmuBlock blk;
+      std::vector<char> sm;
+      emu_init_block(blk, nthreads, sm, smem);
+      blockIdx = {b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y)};
+      blockDim = block;
+      gridDim = grid;
+      emu_run_block(blk, block, [](void* p) { Ctx* c = (Ctx*)p; c->kernel(*c->arg); }, &ctx);
+    });
   for (auto& t : th) t.join();
-  for (auto& blk : blks) {
-    pthread_barrier_destroy(&blk.block_bar);
-    for (auto& w : blk.wave_bar) pthread_barrier_destroy(&w);
-  }
 }
 #define CLSTM_LAUNCH_COOP(kernel, grid, block, smem, stream, argstruct) \
   emu_launch_coop(kernel, dim3(grid), dim3(block), smem, argstruct)
@@ -286,32 +296,19 @@ void emu_launch_coop(K kernel, dim3 grid, dim3 block, size_t smem, A arg) {
 template <typename K, typename... Args>
 void emu_launch(K kernel, dim3 grid, dim3 block, size_t smem, Args... args) {
   const unsigned nthreads = block.x * block.y * block.z;
-  if (nthreads % 64 != 0) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }
-  for (unsigned bz = 0; bz < grid.z; bz++)
-    for (unsigned by = 0; by < grid.y; by++)
-      for (unsigned bx = 0; bx < grid.x; bx++) {
-        EmuBlock blk;
-        pthread_barrier_init(&blk.block_bar, nullptr, nthreads);
-        blk.wave_bar.resize(nthreads / 64);
-        for (auto& w : blk.wave_bar) pthread_barrier_init(&w, nullptr, 64);
-        blk.xf.assign((size_t)nthreads * 16, 0.f);
-        std::vector<char> sm(smem + 16, 0);
-        blk.smem = sm.data();
-        std::vector<std::thread> th;
-        th.reserve(nthreads);
-        for (unsigned t = 0; t < nthreads; t++)
-          th.emplace_back([&, t]() {
-            emu_blk = &blk;
-            threadIdx = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
-            blockIdx = {bx, by, bz};
-            blockDim = block;
-            gridDim = grid;
-            kernel(args...);
-          });
-        for (auto& t : th) t.join();
-        pthread_barrier_destroy(&blk.block_bar);
-        for (auto& w : blk.wave_bar) pthread_barrier_destroy(&w);
-      }
+  auto call = [&]() { kernel(args...); };
+  typedef decltype(call) Call;
+  struct Ctx { Call* fn; dim3 grid, block; unsigned nthreads; size_t smem; } ctx{&call, grid, block, nthreads, smem};
+  emu_parallel_for(grid.x * grid.y * grid.z, [](unsigned b, void* p) {
+    Ctx* c = (Ctx*)p;
+    EmuBlock blk;
+    std::vector<char> sm;
+    emu_init_block(blk, c->nthreads, sm, c->smem);
+    blockIdx = {b % c->grid.x, (b / c->grid.x) % c->grid.y, b / (c->grid.x * c->grid.y)};
+    blockDim = c->block;
+    gridDim = c->grid;
+    emu_run_block(blk, c->block, [](void* q) { (*((Ctx*)q)->fn)(); }, c);
+  }, &ctx);
 }
 #define CLSTM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   emu_launch(kernel, dim3(grid), dim3(block), smem, __VA_ARGS__)
