@@ -329,15 +329,13 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       return;
     }
     const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mt - 1) / (16 * mt));
+    const dim3 grid16(((no + 15) / 16) * a.ndir * ((a.bs + 15) / 16));
     launch_steps(graphs, bf16 ? 2 : 0, a, tmax, s, [&]() {
       LstmWideArgs w = a;
       for (int t = 0; t < tmax; t++) {
         w.step = t;
-        if (bf16) {
-          if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step_bf16<4>, grid, dim3(WIDE_THREADS), 0, s, w);
-          else if (mt == 2) CLSTM_LAUNCH(lstm_wide_fwd_step_bf16<2>, grid, dim3(WIDE_THREADS), 0, s, w);
-          else CLSTM_LAUNCH(lstm_wide_fwd_step_bf16<1>, grid, dim3(WIDE_THREADS), 0, s, w);
-        } else
+        if (bf16) CLSTM_LAUNCH(lstm_wide_fwd_step16_bf16, grid16, dim3(WIDE_THREADS), 0, s, w);
+        else
         if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step<4>, grid, dim3(WIDE_THREADS), 0, s, w);
         else if (mt == 2) CLSTM_LAUNCH(lstm_wide_fwd_step<2>, grid, dim3(WIDE_THREADS), 0, s, w);
         else CLSTM_LAUNCH(lstm_wide_fwd_step<1>, grid, dim3(WIDE_THREADS), 0, s, w);
@@ -357,11 +355,12 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       return;
     }
     const dim3 grid((no + 15) / 16, a.ndir, nzb);
+    const dim3 grid16(((no + 15) / 16) * a.ndir * nzb);
     launch_steps(graphs, bf16 ? 3 : 1, a, tmax, s, [&]() {
       LstmWideArgs w = a;
       for (int t = 0; t < tmax; t++) {
         w.step = t;
-        if (bf16) CLSTM_LAUNCH(lstm_wide_bwd_step_bf16, grid, dim3(WIDE_THREADS), 0, s, w);
+        if (bf16) CLSTM_LAUNCH(lstm_wide_bwd_step16_bf16, grid16, dim3(WIDE_THREADS), 0, s, w);
         else CLSTM_LAUNCH(lstm_wide_bwd_step, grid, dim3(WIDE_THREADS), 0, s, w);
       }
     });
@@ -687,8 +686,9 @@ struct Net {
       y.D.reserve((size_t)N * ndir * 4 * y.no + (y.wide ? 0 : PROG_WORDS + 64));
       y.dH.reserve((size_t)N * ndir * y.no);
       if (y.wide && bf16_rec) {
-        y.Hb.reserve((size_t)N * ndir * wide_kp16_fwd(y.no) + 64);
-        y.Db.reserve((size_t)N * ndir * wide_kp16_bwd(y.no) + 64);
+        // lock-step rings [step parity][dir][line][k] (lstm_wide.h); never smaller than the per-frame layout of the first version
+        y.Hb.reserve((size_t)std::max<long long>(N, 2LL * bs) * ndir * wide_kp16_fwd(y.no) + 64);
+        y.Db.reserve((size_t)std::max<long long>(N, 2LL * bs) * ndir * wide_kp16_bwd(y.no) + 64);
       }
       y.S.reserve((size_t)N * ndir * y.lds + 64);
     }
@@ -1492,8 +1492,8 @@ int clstm_net_set_gemm_precision(clstm_net* h, int mode) {
   if (n.N > 0 && rec)   // a batch is already declared: make room for the bf16 operand copies
     for (auto& y : n.L)
       if (y.wide) {
-        y.Hb.reserve((size_t)n.N * n.ndir * wide_kp16_fwd(y.no) + 64);
-        y.Db.reserve((size_t)n.N * n.ndir * wide_kp16_bwd(y.no) + 64);
+        y.Hb.reserve((size_t)std::max<long long>(n.N, 2LL * n.bs) * n.ndir * wide_kp16_fwd(y.no) + 64);
+        y.Db.reserve((size_t)std::max<long long>(n.N, 2LL * n.bs) * n.ndir * wide_kp16_bwd(y.no) + 64);
       }
   ABI_END
 }

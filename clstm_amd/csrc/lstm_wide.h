@@ -139,9 +139,12 @@ DEVFN void wide_tile(const BufF32 abuf, const unsigned (&arow)[MT], const BufF32
 // ONE 16-byte load -- 8 consecutive k of its row -- for A (bf16 copies of h / the deltas) and B (bf16 weight rows)
 // alike; a wave owns a quarter of the contraction range, partial tiles meet in `red` exactly as above.  One eighth of
 // the f32 kernel's MFMA instructions and half its operand bytes per step.
-template <int MT, int PF>
+// `after_prologue` runs once the first PF groups are requested: the place for loads whose latency is longer than the
+// tile's own (epilogue operands from HBM) -- VMEM returns in order, so anything issued BEFORE the tile's loads would be
+// waited for by the first MFMA.
+template <int MT, int PF, class AP>
 DEVFN void wide_tile_bf16(const BufF32 abuf, const unsigned (&arow)[MT], const BufF32 bbuf, const unsigned brow, const int kp,
-                          float* red) {
+                          float* red, AP after_prologue) {
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int kw = kp / WIDE_NW;            // contraction range of one wave (multiple of 32)
   const int ngroups = kw >> 5;
@@ -164,6 +167,8 @@ DEVFN void wide_tile_bf16(const BufF32 abuf, const unsigned (&arow)[MT], const B
     load_group(p, ra[p], rb[p]);
     SCHED_FENCE();
   }
+  after_prologue();
+  SCHED_FENCE();
   for (int g0 = 0; g0 < ngroups; g0 += PF) {
 #pragma unroll
     for (int p = 0; p < PF; p++) {
@@ -181,8 +186,154 @@ DEVFN void wide_tile_bf16(const BufF32 abuf, const unsigned (&arow)[MT], const B
     for (int q = 0; q < 4; q++) red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * LDR + (lane & 15)] = acc[i][q];
 }
 
+// 16 lines x 64 columns (four 16-row weight tiles, `btile` bytes apart) on the same instruction: one A fragment serves
+// four MFMAs, so a workgroup pulls a quarter of the FRESH bytes (h_{t-1}: written one launch ago by other XCDs, an L2
+// miss) per product column; the weight rows it reads instead are L2-resident for the whole sequence.
+template <int PF, class AP>
+DEVFN void wide_tile_bf16_n4(const BufF32 abuf, const unsigned arow, const BufF32 bbuf, const unsigned brow,
+                             const unsigned btile, const int kp, float* red, AP after_prologue) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int kw = kp / WIDE_NW;
+  const int ngroups = kw >> 5;
+  const unsigned klane = (unsigned)(wave * kw + 8 * (lane >> 4)) * 2u;   // bytes
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
+  f32x4 ra[PF], rb[PF][4];
+  auto load_group = [&](int g, f32x4& a, f32x4 (&b)[4]) {   // unconditional issue: exact vmcnt
+    const bool live = g < ngroups;
+    const unsigned ko = klane + (unsigned)g * 64u;
+    a = buf_load4(abuf, live ? arow + ko : BUF_OOB);
+#pragma unroll
+    for (int j = 0; j < 4; j++) b[j] = buf_load4(bbuf, live ? brow + (unsigned)j * btile + ko : BUF_OOB);
+  };
+#pragma unroll
+  for (int p = 0; p < PF; p++) {
+    load_group(p, ra[p], rb[p]);
+    SCHED_FENCE();
+  }
+  after_prologue();
+  SCHED_FENCE();
+  for (int g0 = 0; g0 < ngroups; g0 += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; p++) {
+      const u16x8 av = __builtin_bit_cast(u16x8, ra[p]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[j] = mfma16x16x32_bf16(av, __builtin_bit_cast(u16x8, rb[p][j]), acc[j]);
+      load_group(g0 + p + PF, ra[p], rb[p]);
+      SCHED_FENCE();
+    }
+  }
+  constexpr int LDR = 64 + 4;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * LDR + j * 16 + (lane & 15)] = acc[j][q];
+}
+
+// XCD-aware order of a launch's work items (same bijection as gemm_mfma.h): the dispatcher places workgroup `lin` on
+// XCD lin % 8; XCD x gets the CONTIGUOUS run of items [x*q ...), so with the cell tile as the fastest item index all
+// tiles of one (line block, direction) -- which read the same fresh h rows and write neighbouring cells of the same
+// cache lines -- sit behind one L2.
+DEVFN unsigned xcd_contiguous_item(const unsigned lin, const unsigned total) {
+  const unsigned xcd = lin & 7u, idx = lin >> 3;
+  const unsigned q = total >> 3, r = total & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ---- forward, bf16 operands: one time step of 16 lines x (16 cells x 4 gates) ----------------------------------------
+// What bounds a per-step launch at 512 cells is not the MFMA work (16 instructions per wave) but the bytes that are
+// new since the previous launch and the shape of the stores (measured by leaving parts out, 64 lines x 400 frames:
+// 9.45 us per step, of which stores 3.2, h loads 2.2, other epilogue loads 0.9, epilogue math 0.8, empty launch 2.6):
+//  * the bf16 copy of h lives in a LOCK-STEP ring Hb[step parity][dir][line][kp16] -- its address does not depend on
+//    the line offsets, so the loads are the first instructions of the kernel, not behind a dependent load;
+//  * 16 cells per workgroup and the XCD-contiguous item order: every store instruction of a wave writes 16 x 64 B
+//    (C, H, S) or 16 x 256 B (G) runs, and the cache lines of a frame's state are completed inside ONE L2 (with 4 cells
+//    per workgroup and round-robin placement eight XCDs each wrote 16 B of every 128-B line).
+DEVFN void wide_fwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int ct, const int dir, const int zb, float* red) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int no = a.no, nd = a.ndir;
+  const int ncg = (no + 3) >> 2;
+  const int m = zb * 16 + (lane & 15);
+  const unsigned arow = (sg >= 1 && m < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + m) * a.kp16) * 2u : BUF_OOB_BASE;
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * a.bs * a.kp16 * 2);
+  const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(a.Rw16), (size_t)a.rw_elems * 2);
+  const unsigned brow = (unsigned)(((long long)(dir * ncg + ct * 4) * 16 + (lane & 15)) * a.kp16) * 2u;   // rows past the
+  const unsigned btile = (unsigned)(16 * a.kp16) * 2u;                   // last cell group: dropped by the descriptor
+
+  const int ml = tid >> 4, c16 = tid & 15;
+  const int line = zb * 16 + ml, cell = ct * 16 + c16;
+  // the line's offsets are REQUESTED first and USED behind the tile's loads (no branch, no early wait)
+  const BufF32 lbuf = make_buf(reinterpret_cast<const float*>(a.line_off), (size_t)(a.bs + 1) * 4);
+  const float lo0 = buf_load(lbuf, line < a.bs ? (unsigned)line * 4u : BUF_OOB);
+  const float lo1 = buf_load(lbuf, line < a.bs ? (unsigned)line * 4u + 4u : BUF_OOB);
+  SCHED_FENCE();
+  bool live;
+  int off, T;
+  long long n;
+  const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
+  const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
+  f32x4 gx;
+  float c_prev;
+  wide_tile_bf16_n4<4>(abuf, arow, bbuf, brow, btile, a.kp16, red, [&]() {
+    off = __builtin_bit_cast(int, lo0);
+    T = __builtin_bit_cast(int, lo1) - off;
+    live = line < a.bs && cell < no && sg < T;
+    n = off + (dir == 0 ? sg : T - 1 - sg);
+    gx = buf_load4(gbuf, live ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB);
+    c_prev = buf_load(cbuf, live && sg >= 1
+        ? (unsigned)((((long long)(off + (dir == 0 ? sg - 1 : T - sg)) * nd + dir) * no + cell) * 4) : BUF_OOB);
+  });
+  __syncthreads();
+
+  float h = 0.0f;
+  if (live) {
+    f32x4 k;
+#pragma unroll
+    for (int q = 0; q < 4; q++) k[q] = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WIDE_NW; w++) {   // columns of cell c16: cell group c16>>2, slot (c16&3)*4 + gate
+      const f32x4 p = *reinterpret_cast<const f32x4*>(&red[(w * 16 + ml) * 68 + c16 * 4]);
+#pragma unroll
+      for (int q = 0; q < 4; q++) k[q] += p[q];
+    }
+    const float gi = gate_act(k[0] + gx[0], false), gf = gate_act(k[1] + gx[1], false),
+                go = gate_act(k[2] + gx[2], false), ci = gate_act(k[3] + gx[3], true);
+    const float c = ci * gi + gf * c_prev;      // c_prev reads 0 at the first step
+    h = gate_act(c, true) * go;
+    f32x4 act;
+    act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
+    *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
+    a.C[(n * nd + dir) * no + cell] = c;
+    a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
+    float* srow = a.S + (size_t)dir * a.sdir;
+    if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;                      // h_{-1} = 0
+    if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+  }
+  // next step's A operand: two cells per 4-byte store (the odd lane's h comes over by DPP; every lane takes part)
+  const float hn = quad_xor1(h);
+  if (live && !(c16 & 1))
+    *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) =
+        bf16_pack2(h, cell + 1 < no ? hn : 0.0f);
+}
+
+// grid: ceil(no/16) * ndir * ceil(bs/16) workgroups (1-D), 256 threads
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_fwd_step16_bf16(LstmWideArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[WIDE_NW * 16 * 68];
+  const int ntile = (a.no + 15) >> 4;
+  const unsigned v = xcd_contiguous_item(blockIdx.x, gridDim.x);
+  const int ct = (int)(v % (unsigned)ntile), dir = (int)((v / (unsigned)ntile) % (unsigned)a.ndir),
+            zb = (int)(v / (unsigned)(ntile * a.ndir));
+  wide_fwd_tile16_bf16(a, a.step, ct, dir, zb, red);
+}
+
 // ---- forward: one time step of 16*MT lines for one (cell group, direction) ------------------------
 // loff: line offsets (global for the per-step launch, an LDS copy in the cooperative kernel)
+#ifndef CLSTM_WEXP   // perf experiments only: bit mask of work to leave out of the forward step (results are then wrong)
+#define CLSTM_WEXP 0
+#endif
 template <int MT, bool COOP, bool BF16 = false>
 DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, const int dir, const int zb,
                          const int* loff, const float* wl, float* red) {
@@ -203,13 +354,15 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
                        : (unsigned)((long long)(off + fprev) * a.ldh + a.hofs + dir * no) * 4u;
       }
     }
+    if (CLSTM_WEXP & 1) arow[i] = BUF_OOB_BASE;
   }
   const BufF32 abuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)a.N * nd * a.kp16 * 2)
                             : make_buf(a.H, (size_t)a.N * a.ldh * 4);
   const BufF32 bbuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Rw16), (size_t)a.rw_elems * 2)
                             : make_buf(a.Rw, (size_t)a.rw_elems * 4);
-  const unsigned brow = BF16 ? (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp16) * 2u
-                             : (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp) * 4u;
+  const unsigned brow = (CLSTM_WEXP & 2) ? BUF_OOB_BASE
+                        : BF16 ? (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp16) * 2u
+                               : (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp) * 4u;
 
   // epilogue role of this thread: (line, cell); its operands are requested before the MFMA loop so
   // that their HBM latency hides under it (masked threads read nothing: out-of-range offsets)
@@ -225,19 +378,19 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
   const long long n = off + (dir == 0 ? sg : T - 1 - sg);
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
   const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
-  const unsigned goff = live ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB;
+  const unsigned goff = live && !(CLSTM_WEXP & 32) ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB;
   const f32x4 gx = buf_load4(gbuf, goff);
   // c_{s-1} was written by this very thread one step ago (same (line, cell) role), so a plain load is
   // coherent in the cooperative kernel as well
-  const float c_prev = buf_load(cbuf, live && sg >= 1
+  const float c_prev = buf_load(cbuf, live && sg >= 1 && !(CLSTM_WEXP & 32)
       ? (unsigned)((((long long)(off + (dir == 0 ? sg - 1 : T - sg)) * nd + dir) * no + cell) * 4) : BUF_OOB);
 
-  if (BF16) wide_tile_bf16<MT, 4>(abuf, arow, bbuf, brow, a.kp16, red);
+  if (BF16) wide_tile_bf16<MT, 4>(abuf, arow, bbuf, brow, a.kp16, red, []() {});
   else wide_tile<MT, 1, COOP>(abuf, arow, bbuf, brow, wl, a.kp, red);
   __syncthreads();
 
   // fused forward_full1 x4 + forward_statemem + forward_nonlingate for (line, cell)
-  if (live) {
+  if (live && !(CLSTM_WEXP & 16)) {
     f32x4 k;
 #pragma unroll
     for (int q = 0; q < 4; q++) k[q] = 0.0f;
@@ -253,6 +406,7 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
     const float h = gate_act(c, true) * go;
     f32x4 act;
     act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
+    if ((CLSTM_WEXP & 8) && h != 12345.678f) return;
     *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
     a.C[(n * nd + dir) * no + cell] = c;
     // h_t is next step's A operand of every workgroup of this direction
@@ -279,6 +433,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_fwd_step_bf16(LstmWide
 }
 
 // ---- backward: one time step of 16 lines for one (16-cell tile, direction) ------------------------
+#ifndef CLSTM_WEXPB   // perf experiments only: bit mask of work to leave out of the backward step (results are then wrong)
+#define CLSTM_WEXPB 0
+#endif
 template <bool COOP, bool BF16 = false>
 DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, const int dir, const int zb,
                          const int* loff, const float* wl, float* red) {
@@ -298,13 +455,15 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
                        : (unsigned)(((long long)(off + fnext) * nd + dir) * 4 * no) * 4u;
       }
     }
+    if (CLSTM_WEXPB & 1) arow[0] = BUF_OOB_BASE;
   }
   const BufF32 abuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Db), (size_t)a.N * nd * a.kp16 * 2)
                             : make_buf(a.D, (size_t)a.N * nd * 4 * no * 4);
   const BufF32 bbuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Rw16), (size_t)a.rw_elems * 2)
                             : make_buf(a.Rw, (size_t)a.rw_elems * 4);
-  const unsigned brow = BF16 ? (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp16) * 2u
-                             : (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp) * 4u;
+  const unsigned brow = (CLSTM_WEXPB & 2) ? BUF_OOB_BASE
+                        : BF16 ? (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp16) * 2u
+                               : (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp) * 4u;
 
   // epilogue operands of thread (line, cell), requested ahead of the MFMA loop
   const int ml = tid >> 4, c16 = tid & 15;
@@ -316,6 +475,8 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
     T = loff[line + 1] - off;
     live = sg < T;
   }
+  const bool lv = live;
+  if (CLSTM_WEXPB & 32) live = false;
   const int s = T - 1 - sg;
   const long long n = off + (dir == 0 ? s : sg);
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
@@ -331,8 +492,88 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
   const unsigned dcoff = (unsigned)((((long long)line * nd + dir) * no + cell) * 4);
   const float dc_carry = buf_load(dcbuf, live && sg >= 1 ? dcoff : BUF_OOB);   // own write of the previous step
 
-  if (BF16) wide_tile_bf16<1, 8>(abuf, arow, bbuf, brow, a.kp16, red);
+  if (BF16) wide_tile_bf16<1, 8>(abuf, arow, bbuf, brow, a.kp16, red, []() {});
   else wide_tile<1, 1, COOP>(abuf, arow, bbuf, brow, wl, a.kp, red);
+  __syncthreads();
+  live = lv;
+
+  if (live && !(CLSTM_WEXPB & 16)) {
+    float dh_rec = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WIDE_NW; w++) dh_rec += red[(w * 16 + ml) * WIDE_LDW + c16];
+    const float gi = act[0], gf = act[1], go = act[2], ci = act[3];
+    const float dh = dh_in + dh_rec;           // out[s].d, clstm.cc:626-628 + :646
+    const float th = gate_act(c_s, true);      // backward_nonlingate recomputes tanh(state)
+    const float d_go = th * dh;
+    const float dc = dc_carry + (-th * th + 1.0f) * (go * dh);
+    a.dC[dcoff / 4] = dc * gf;                 // backward_statemem (clstm_compute.cc:509-515)
+    const float d_gf = dc * c_m1;
+    const float d_gi = dc * ci, d_ci = dc * gi;
+    f32x4 dl;                                  // backward_nonlin0: y(1-y) for SIG, 1-y^2 for TANH
+    dl[0] = (gi * (-gi + 1.0f)) * d_gi;
+    dl[1] = (gf * (-gf + 1.0f)) * d_gf;
+    dl[2] = (go * (-go + 1.0f)) * d_go;
+    dl[3] = (-ci * ci + 1.0f) * d_ci;
+    if ((CLSTM_WEXPB & 8) && dl[3] != 12345.678f) return;
+    // the deltas are next step's A operand of every workgroup of this direction
+    if (COOP) buf_store4_dev(abuf, coff * 4u, dl);
+    else *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
+    if (BF16) {   // next step's A operand
+      unsigned* db = reinterpret_cast<unsigned*>(a.Db + (n * nd + dir) * a.kp16 + 4 * cell);
+      db[0] = bf16_pack2(dl[0], dl[1]);
+      db[1] = bf16_pack2(dl[2], dl[3]);
+    }
+  }
+}
+// ---- backward, bf16 operands: the same three measures as wide_fwd_tile16_bf16 (measured by leaving parts out: 7.75 us
+// per step = delta loads 1.4 + weight loads 1.3 + epilogue operand loads 1.3 + epilogue 1.0 + empty launch 2.8) --
+// the bf16 deltas in a lock-step ring Db[step parity][dir][line][kp16], XCD-contiguous item order (one XCD: the 16 lines'
+// 64 KB of fresh deltas once, one direction's 2 MB of weight rows resident in its L2), and the epilogue's operands --
+// forward-pass arrays that come from HBM -- requested BEHIND the first round of tile loads.
+DEVFN void wide_bwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int ct, const int dir, const int zb, float* red) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int no = a.no, nd = a.ndir;
+  const int nct = (no + 15) >> 4;
+  unsigned arow[1];
+  {
+    const int m = zb * 16 + (lane & 15);
+    arow[0] = (sg >= 1 && m < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + m) * a.kp16) * 2u : BUF_OOB_BASE;
+  }
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Db), (size_t)2 * nd * a.bs * a.kp16 * 2);
+  const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(a.Rw16), (size_t)a.rw_elems * 2);
+  const unsigned brow = (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp16) * 2u;
+
+  const int ml = tid >> 4, c16 = tid & 15;
+  const int line = zb * 16 + ml, cell = ct * 16 + c16;
+  const BufF32 lbuf = make_buf(reinterpret_cast<const float*>(a.line_off), (size_t)(a.bs + 1) * 4);
+  const float lo0 = buf_load(lbuf, line < a.bs ? (unsigned)line * 4u : BUF_OOB);   // requested first, used behind the
+  const float lo1 = buf_load(lbuf, line < a.bs ? (unsigned)line * 4u + 4u : BUF_OOB);   // tile's loads
+  SCHED_FENCE();
+  bool live;
+  int off, T, s;
+  long long n;
+  const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
+  const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
+  const BufF32 hbuf = make_buf(a.dH, (size_t)a.N * nd * no * 4);
+  const BufF32 dcbuf = make_buf(a.dC, (size_t)a.bs * nd * no * 4);
+  unsigned coff;
+  const unsigned dcoff = (unsigned)((((long long)line * nd + dir) * no + cell) * 4);
+  f32x4 act;
+  float dh_in, c_s, c_m1, dc_carry;
+  wide_tile_bf16<1, 8>(abuf, arow, bbuf, brow, a.kp16, red, [&]() {
+    off = __builtin_bit_cast(int, lo0);
+    T = __builtin_bit_cast(int, lo1) - off;
+    live = line < a.bs && cell < no && sg < T;
+    s = T - 1 - sg;
+    n = off + (dir == 0 ? s : sg);
+    coff = (unsigned)(((n * nd + dir) * no + cell) * 4);
+    act = buf_load4(gbuf, live ? coff * 4u : BUF_OOB);
+    dh_in = buf_load(hbuf, live ? (unsigned)((n * (nd * no) + dir * no + cell) * 4) : BUF_OOB);
+    c_s = buf_load(cbuf, live ? coff : BUF_OOB);
+    c_m1 = buf_load(cbuf, live && s >= 1       // c_{s-1}; 0 at s = 0 ("gf.d untouched when last < 0")
+        ? (unsigned)((((long long)(off + (dir == 0 ? s - 1 : sg + 1)) * nd + dir) * no + cell) * 4) : BUF_OOB);
+    dc_carry = buf_load(dcbuf, live && sg >= 1 ? dcoff : BUF_OOB);   // own write of the previous step
+  });
   __syncthreads();
 
   if (live) {
@@ -352,16 +593,22 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
     dl[1] = (gf * (-gf + 1.0f)) * d_gf;
     dl[2] = (go * (-go + 1.0f)) * d_go;
     dl[3] = (-ci * ci + 1.0f) * d_ci;
-    // the deltas are next step's A operand of every workgroup of this direction
-    if (COOP) buf_store4_dev(abuf, coff * 4u, dl);
-    else *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
-    if (BF16) {   // next step's A operand
-      unsigned* db = reinterpret_cast<unsigned*>(a.Db + (n * nd + dir) * a.kp16 + 4 * cell);
-      db[0] = bf16_pack2(dl[0], dl[1]);
-      db[1] = bf16_pack2(dl[2], dl[3]);
-    }
+    *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
+    unsigned* db = reinterpret_cast<unsigned*>(a.Db + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + 4 * cell);
+    db[0] = bf16_pack2(dl[0], dl[1]);          // next step's A operand
+    db[1] = bf16_pack2(dl[2], dl[3]);
   }
 }
+// grid: ceil(no/16) * ndir * ceil(bs/16) workgroups (1-D), 256 threads
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_bwd_step16_bf16(LstmWideArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[WIDE_NW * 16 * WIDE_LDW];
+  const int ntile = (a.no + 15) >> 4;
+  const unsigned v = xcd_contiguous_item(blockIdx.x, gridDim.x);
+  const int ct = (int)(v % (unsigned)ntile), dir = (int)((v / (unsigned)ntile) % (unsigned)a.ndir),
+            zb = (int)(v / (unsigned)(ntile * a.ndir));
+  wide_bwd_tile16_bf16(a, a.step, ct, dir, zb, red);
+}
+
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_bwd_step_bf16(LstmWideArgs a) {
   __shared__ __attribute__((aligned(16))) float red[WIDE_NW * 16 * WIDE_LDW];
   wide_bwd_tile<false, true>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);

@@ -31,8 +31,6 @@ def test_lane_ops(backend):
 @pytest.mark.parametrize("R,Cn,K,ns", [(64, 64, 16, 1), (70, 45, 37, 1), (149, 400, 333, 5), (5, 3, 2, 1),
                                        (130, 83, 200, 3)])
 def test_gemm_modes(backend, mode, R, Cn, K, ns):
-    if backend.kind == "emu" and R * Cn > 20000:
-        pytest.skip("big tile counts only on the GPU")
     rng = np.random.default_rng(R * 1000 + Cn)
     A = rng.normal(size=(R, K)).astype(np.float32)
     B = rng.normal(size=(K, Cn)).astype(np.float32)
@@ -52,8 +50,6 @@ def test_gemm_modes(backend, mode, R, Cn, K, ns):
 def test_gemm_bf16_modes(backend, mode, R, Cn, K, ns):
     """bf16-input / f32-accumulate GEMM (gemm_bf16.h): exact against a float64 product of the SAME inputs
     rounded to bf16 (asymmetric random operands, so a transposed fragment would show)."""
-    if backend.kind == "emu" and R * Cn > 20000:
-        pytest.skip("big tile counts only on the GPU")
     rng = np.random.default_rng(R * 1000 + Cn + 7)
     A = rng.normal(size=(R, K)).astype(np.float32)
     B = rng.normal(size=(K, Cn)).astype(np.float32)

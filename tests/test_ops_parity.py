@@ -229,8 +229,6 @@ def test_ctc_reference_known_answers(backend):
 def test_ctc_vs_oracle(backend, ora32, T, L, nc):
     # (12..40: short-line path, lattice resident in LDS; 60 x 81 states: the same with the wide recursion;
     #  100 x 125 states and 200 x 141: the tiled path through HBM)
-    if backend.kind == "emu" and T > 100:
-        pytest.skip("large lattice only on the GPU")
     rng = np.random.default_rng(T)
     probs, states = [], []
     for b in range(3):
@@ -280,8 +278,6 @@ def test_ctc_long_transcripts(backend, ora32, T, L):
     """More than 512 target states per line (text lines of clstmfiltertrain easily exceed 255 characters; the
     reference's ctc_align_targets has no limit): 601 states on a short lattice (no complete path, the per-frame
     normalisation still applies) and 561 states over 640 frames.  The limit is now 2048 states."""
-    if backend.kind == "emu" and T > 100:
-        pytest.skip("large lattice only on the GPU")
     rng = np.random.default_rng(L)
     nc = 40
     p = rng.random((T, nc)).astype(np.float32) ** 2
