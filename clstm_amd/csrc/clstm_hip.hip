@@ -774,9 +774,10 @@ struct Net {
   }
 
   // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
-  int pick_split(int R, int Cn, int nbatch = 1) const {
-    const long long tiles = (long long)((R + GEMM_BT - 1) / GEMM_BT) * ((Cn + GEMM_BT - 1) / GEMM_BT) * nbatch;
-    static const long long target = getenv("CLSTM_SPLIT_TARGET") ? atoll(getenv("CLSTM_SPLIT_TARGET")) : 640;
+  int pick_split(int R, int Cn, int nbatch = 1, int tile = GEMM_BT) const {
+    const long long tiles = (long long)((R + tile - 1) / tile) * ((Cn + tile - 1) / tile) * nbatch;
+    static const long long target0 = getenv("CLSTM_SPLIT_TARGET") ? atoll(getenv("CLSTM_SPLIT_TARGET")) : 640;
+    const long long target = tile == GEMM_BT ? target0 : 480;   // 128 x 128 tiles: two workgroups per CU
     long long want = (target + tiles - 1) / tiles;
     const long long maxs = (N + 63) / 64;   // at least 64 frames per slab
     if (want > maxs) want = maxs;
@@ -1011,7 +1012,7 @@ struct Net {
       if (y.wide) launch_lstm_wide(false, wide_args(y, false), tmax, coop_sync, step_graphs, s, bf16_rec);
       else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
-      ns = pick_split(R, Cn, ndir);
+      ns = bf16_gemm && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
       partial.reserve((size_t)ndir * ns * R * Cn);
       timing.begin("gemm_gates_dw", s);
       if (bf16_gemm)

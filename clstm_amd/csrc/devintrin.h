@@ -16,6 +16,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define DEVFN __device__ __forceinline__
 #define DEVMFN __device__ __forceinline__  // member functions

@@ -135,6 +135,192 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmOperand A, GemmOpera
       }
 }
 
+// ---- 128 x 128 tile ------------------------------------------------------------------------------------------------
+// The 64 x 64 kernel above moves 2 x 64 x 32 f32 through a CU's vector cache per 4 MFMAs of a wave: at the configs[4]
+// shapes it ran at 5-7 % of the bf16 MFMA rate (weight-gradient product of 2 x BiLSTM(512): 430 GFLOP in 3.0 ms).  Here a
+// workgroup owns 128 x 128 (its four waves 64 x 64 each = 4 x 4 MFMA tiles, 16 MFMAs per 8 fragment reads), which halves
+// the operand bytes per flop; the operand tiles are double-buffered in LDS (ONE barrier per 32-k block: block t+1 is
+// converted and written into the other buffer while the MFMAs of block t run) behind a ring of three register-staged
+// blocks (2 KB of loads per thread in flight, two workgroups per CU).  Operands stay f32 in memory and are rounded to
+// bf16 while staged, as above, so with 0.0625 B per MAC the kernel is bound by the vector-cache fill rate (64 B/clk per
+// CU = half the bf16 MFMA rate) -- the next step would be bf16 copies of the activations written by their producers.
+//   KC staging: thread t -> row t>>1, 16 consecutive k at (t&1)*16: four float4 -> two ds_write_b128
+//   MC staging: lane l of wave w -> mn = 32 w + 4 (l&7) .. +3, k = 4 (l>>3) .. +3: four float4 (one per k), transposed
+//               in registers -> four ds_write_b64 (row mn+i, 4 consecutive k)
+#ifndef CLSTM_GEXP   // perf experiments only: bit mask of work to leave out of the 128 x 128 kernel (results are then wrong)
+#define CLSTM_GEXP 0
+#endif
+constexpr int GB2_BT = 128;
+constexpr int GB2_PF = 3;
+// LDS image of an operand block: [mn][32 k] bf16, 64-byte rows WITHOUT padding; the four 16-byte k-chunks of row r sit
+// at chunk position c ^ gb2_sw(r).  Found by enumerating layouts against the instruction lane groups of the LDS
+// (MI355X_MICROARCH.md, LDS): fragment reads (ds_read_b128, 4 x 16 lanes) and the KC staging writes (ds_write_b128,
+// 8 x 8 lanes) are conflict-free, the transposing MC staging writes (ds_write_b64, 4 x 16 lanes) 2-way.  The padded
+// [mn][40] image of the 64 x 64 kernel costs 2x / 2x / 4x on the same three -- and the LDS array, not the MFMA pipe, is
+// what this kernel saturates first (measured by leaving parts out: staging alone was 35 % of the weight-gradient GEMM).
+constexpr int GB2_LDH = 32;
+constexpr int GB2_TILE = GB2_BT * GB2_LDH;   // halfs per operand buffer
+DEVFN int gb2_sw(int row) { return ((row >> 1) ^ (row >> 2)) & 3; }
+
+template <int AMODE, int BMODE, class FE>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
+                                                               int K, int ksplit, int nsplit) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[2 * GB2_TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * GB2_TILE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int bx, by, z;   // XCD-aware tile order, see gemm_mfma.h
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = lin & 7u, idx = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = (int)(v % gx);
+    by = (int)((v / gx) % gy);
+    z = (int)(v / (gx * gy));
+  }
+  const int r0 = by * GB2_BT, c0 = bx * GB2_BT;
+  const int batch = z / nsplit;
+  const int kbeg = (z - batch * nsplit) * ksplit;
+  const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
+
+  const int a_mn = AMODE == GEMM_KC ? (tid >> 1) : wave * 32 + (lane & 7) * 4;
+  const int a_k = AMODE == GEMM_KC ? (tid & 1) * 16 : (lane >> 3) * 4;
+  const int b_mn = BMODE == GEMM_KC ? (tid >> 1) : wave * 32 + (lane & 7) * 4;
+  const int b_k = BMODE == GEMM_KC ? (tid & 1) * 16 : (lane >> 3) * 4;
+  const BufF32 abuf = make_buf(A.p + batch * A.bstride, (size_t)(A.elems - batch * A.bstride) * 4);
+  const BufF32 bbuf = make_buf(B.p + batch * B.bstride, (size_t)(B.elems - batch * B.bstride) * 4);
+  const unsigned a_base = AMODE == GEMM_KC ? (unsigned)(r0 + a_mn) * A.ld + a_k : (unsigned)a_k * A.ld + r0 + a_mn;
+  const unsigned b_base = BMODE == GEMM_KC ? (unsigned)(c0 + b_mn) * B.ld + b_k : (unsigned)b_k * B.ld + c0 + b_mn;
+  const unsigned a_kstep = AMODE == GEMM_KC ? 1u : (unsigned)A.ld, b_kstep = BMODE == GEMM_KC ? 1u : (unsigned)B.ld;
+  const unsigned a_next = AMODE == GEMM_KC ? 4u : (unsigned)A.ld, b_next = BMODE == GEMM_KC ? 4u : (unsigned)B.ld;
+
+  // Block addresses: per-lane byte offsets of the four float4 (fixed) + the block's offset (one add per load, the sum
+  // stays inside the descriptor's bounds check).  Blocks past the slab re-read its last block (their products are
+  // zeroed when staged): no select per load.
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    aoff[j] = (a_base + (unsigned)j * a_next) * 4u;
+    boff[j] = (b_base + (unsigned)j * b_next) * 4u;
+  }
+  const int klast = kbeg + ((kend - kbeg - 1) / GB_BK) * GB_BK;   // first k of the slab's last block (kend > kbeg)
+  f32x4 ra[GB2_PF][4], rb[GB2_PF][4];
+  auto load_tile = [&](int k0, f32x4 (&a)[4], f32x4 (&b)[4]) {
+    const unsigned kc = (unsigned)wave_uniform(k0 < klast ? k0 : klast);
+    const unsigned ao = (CLSTM_GEXP & 1) ? BUF_OOB_BASE : kc * a_kstep * 4u, bo = (CLSTM_GEXP & 1) ? BUF_OOB_BASE : kc * b_kstep * 4u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) a[j] = buf_load4(abuf, aoff[j] + ao);
+#pragma unroll
+    for (int j = 0; j < 4; j++) b[j] = buf_load4(bbuf, boff[j] + bo);
+  };
+  // round to bf16 and store k-contiguous.  Whole blocks take the plain path; the slab's last block (and the
+  // zero blocks behind it) mask contraction indices >= kend per element (one wave-uniform branch per block).
+  auto stage = [&](const int MODE, unsigned short* S, const int mn, const int kk, const int k0, const f32x4 (&r)[4]) {
+    const bool whole = wave_uniform(k0 + GB_BK <= kend ? 1 : 0) != 0;
+    if (MODE == GEMM_KC) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        float x[8];
+        if (whole) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) x[i] = r[2 * h + (i >> 2)][i & 3];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i++) x[i] = (k0 + kk + 8 * h + i < kend) ? r[2 * h + (i >> 2)][i & 3] : 0.0f;
+        }
+        *reinterpret_cast<u16x8*>(&S[mn * GB2_LDH + ((((kk >> 3) + h) ^ gb2_sw(mn)) << 3)]) = bf16_pack8(x);
+      }
+    } else {
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = r[j];
+      if (!whole) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[j][i] = (k0 + kk + j < kend) ? v[j][i] : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        u32x2 w2;
+        w2[0] = bf16_pack2(v[0][i], v[1][i]);
+        w2[1] = bf16_pack2(v[2][i], v[3][i]);
+        *reinterpret_cast<u32x2*>(&S[(mn + i) * GB2_LDH + (((kk >> 3) ^ gb2_sw(mn + i)) << 3) + (kk & 4)]) = w2;
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+
+#pragma unroll
+  for (int p = 0; p < GB2_PF; p++) {
+    load_tile(kbeg + p * GB_BK, ra[p], rb[p]);
+    SCHED_FENCE();
+  }
+  // block 0 -> buffer 0
+  stage(AMODE, As, a_mn, a_k, kbeg, ra[0]);
+  stage(BMODE, Bs, b_mn, b_k, kbeg, rb[0]);
+  load_tile(kbeg + GB2_PF * GB_BK, ra[0], rb[0]);
+  SCHED_FENCE();
+  __syncthreads();
+  const int fk = lane >> 4, fi = lane & 15;
+  const int fsw = (fk ^ gb2_sw(fi)) << 3;   // this lane's chunk position (rows 16 apart share the swizzle)
+  int cur = 0;   // LDS buffer (in halfs) that holds the block the MFMAs are about to consume
+  for (int kb = kbeg; kb < kend; kb += GB2_PF * GB_BK) {
+#pragma unroll
+    for (int p = 0; p < GB2_PF; p++) {
+      const int k0 = kb + p * GB_BK;   // block in LDS buffer `cur` (phases past the slab multiply zeros)
+      constexpr int pn_of[3] = {1, 2, 0};
+      const int pn = pn_of[p];         // register set of block k0 + 32: convert it into the other buffer ...
+      if (!(CLSTM_GEXP & 4)) {
+      stage(AMODE, As + (cur ^ GB2_TILE), a_mn, a_k, k0 + GB_BK, ra[pn]);
+      stage(BMODE, Bs + (cur ^ GB2_TILE), b_mn, b_k, k0 + GB_BK, rb[pn]);
+      }
+      load_tile(k0 + GB_BK + GB2_PF * GB_BK, ra[pn], rb[pn]);   // ... and re-use the set for the block three ahead
+      SCHED_FENCE();
+      u16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        af[i] = *reinterpret_cast<const u16x8*>(&As[cur + (wm * 64 + i * 16 + fi) * GB2_LDH + fsw]);
+        bf[i] = *reinterpret_cast<const u16x8*>(&Bs[cur + (wn * 64 + i * 16 + fi) * GB2_LDH + fsw]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (!(CLSTM_GEXP & 2) || (i == 0 && j == 0)) acc[i][j] = mfma16x16x32_bf16(af[i], bf[j], acc[i][j]);
+      if (!(CLSTM_GEXP & 8)) __syncthreads();
+      cur ^= GB2_TILE;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = r0 + wm * 64 + i * 16 + (lane >> 4) * 4 + q;
+        const int c = c0 + wn * 64 + j * 16 + (lane & 15);
+        if (r < R && c < Cn) fe(r, c, acc[i][j][q], z);
+      }
+}
+
+// shapes that fill 128 x 128 tiles reasonably (CLSTM_GEMM_BIG=0: always the 64 x 64 kernel)
+inline bool gemm_bf16_big(int R, int Cn) {
+  static const bool on = !(getenv("CLSTM_GEMM_BIG") && atoi(getenv("CLSTM_GEMM_BIG")) == 0);
+  return on && R >= 96 && Cn >= 96;
+}
+
 // Operand slack: the second float4 of a KC row may run 7 floats past the row end (library buffers carry
 // >= 64 floats of slack; exact-size user arrays get a descriptor that ends at the last element).
 template <int AMODE, int BMODE, class FE>
@@ -146,6 +332,12 @@ inline void gemm_bf16(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe, i
   const int kq = nsplit > 1 ? GB_PF * GB_BK : GB_BK;
   ksplit = ((ksplit + kq - 1) / kq) * kq;
   if (ksplit < kq) ksplit = kq;
+  if (gemm_bf16_big(R, Cn)) {
+    // (KC rows are read 16 floats at a time here: up to 15 floats past the row end, same slack rule)
+    dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);
+    CLSTM_LAUNCH((gemm_bf16_128_kernel<AMODE, BMODE, FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+    return;
+  }
   dim3 grid((Cn + GEMM_BT - 1) / GEMM_BT, (R + GEMM_BT - 1) / GEMM_BT, nsplit * nbatch);
   CLSTM_LAUNCH((gemm_bf16_kernel<AMODE, BMODE, FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
 }

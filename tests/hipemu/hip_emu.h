@@ -74,6 +74,7 @@ struct f32x4 {
 };
 struct float4 { float x, y, z, w; };
 typedef float f32x2 __attribute__((vector_size(8)));
+typedef unsigned u32x2 __attribute__((vector_size(8)));
 inline f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return a * b + c; }
 inline f32x2 splat2(float x) { return (f32x2){x, x}; }
 inline f32x2 pair_lo(const f32x4& v) { return (f32x2){v.v[0], v.v[1]}; }

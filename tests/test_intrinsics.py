@@ -46,7 +46,10 @@ def test_gemm_modes(backend, mode, R, Cn, K, ns):
 
 @pytest.mark.parametrize("mode", [10, 11, 12])
 @pytest.mark.parametrize("R,Cn,K,ns", [(64, 64, 32, 1), (70, 45, 37, 1), (149, 400, 333, 5), (5, 3, 2, 1),
-                                       (130, 83, 200, 3)])
+                                       (130, 83, 200, 3),
+                                       # the 128 x 128-tile kernel (R, Cn >= 96): whole tiles, ragged edges, k tails, slabs
+                                       (128, 128, 32, 1), (256, 256, 64, 1), (97, 200, 31, 1), (300, 130, 1000, 2),
+                                       (577, 260, 129, 3)])
 def test_gemm_bf16_modes(backend, mode, R, Cn, K, ns):
     """bf16-input / f32-accumulate GEMM (gemm_bf16.h): exact against a float64 product of the SAME inputs
     rounded to bf16 (asymmetric random operands, so a transposed fragment would show)."""
