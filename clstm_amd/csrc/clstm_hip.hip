@@ -536,6 +536,7 @@ struct Net {
     hipEvent_t fork{}, rec_done{}, side_done{};
     bool tried = false, ok = false;
   } os;
+  DevBuf<long long> dw_trace;
   DevBuf<int> dw_ktab, dw_slabs, dw_timeouts, dw_queue;   // dw_queue: [8] queue heads | [8 * 256] CU marks
   std::vector<int> dw_key;        // line offsets the tables were built for
   int dw_nslabs = 0, dw_slabs_per_dir = 0, dw_ntiles_max = 0;
@@ -773,6 +774,9 @@ struct Net {
     }
   }
 
+  // overlapped weight-gradient GEMM: 1 = bf16 MFMA on hi + lo split operands (three products, f32-grade: gemm_dw.h),
+  // 0 = f32 MFMA (CLSTM_DW_X3=0)
+  int dw_x3 = getenv("CLSTM_DW_X3") ? atoi(getenv("CLSTM_DW_X3")) : 1;
   // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
   int pick_split(int R, int Cn, int nbatch = 1, int tile = GEMM_BT) const {
     const long long tiles = (long long)((R + tile - 1) / tile) * ((Cn + tile - 1) / tile) * nbatch;
@@ -849,7 +853,7 @@ struct Net {
         cb.push_back(done);
       }
     }
-    const int tiles_per_slab = std::max(8, (int)((N / 16 + 15) / 16));   // ~16 slabs per direction
+    const int tiles_per_slab = std::min(DW_STAB_MAX, std::max(8, (int)((N / 16 + 15) / 16)));   // ~16 slabs per direction (a slab's table must fit the items' LDS copy)
     std::vector<std::vector<int>> tab(ndir);                            // (first frame, count) pairs
     struct Sl { int tb, nt, need, dir, chunk, part; };
     std::vector<std::vector<Sl>> sl(ndir);
@@ -867,7 +871,12 @@ struct Net {
           for (int f = f_lo; f < f_hi; f += 16) { tab[dir].push_back(off + f); tab[dir].push_back(std::min(16, f_hi - f)); }
         }
         const int nt = (int)tab[dir].size() / 2 - t0;
-        const int parts = std::max(1, (nt + tiles_per_slab - 1) / tiles_per_slab);
+        int parts = std::max(1, (nt + tiles_per_slab - 1) / tiles_per_slab);
+        // The items of the LAST chunks cannot start before the recurrence ends, so their latency -- a serial walk over a
+        // slab's frames, ~1 us per 32 -- is the launch's tail (profiles/r02_dw_timeline.txt): cut those chunks into
+        // more, shorter slabs (>= 2 table entries each).
+        static const int tail_parts = getenv("CLSTM_DW_TAIL_PARTS") ? atoi(getenv("CLSTM_DW_TAIL_PARTS")) : 4;   // (1: 118 us, 4: 112, 8: 115 -- more items than free CUs at the end)
+        if (c + 2 >= cb.size()) parts = std::max(parts, std::min(tail_parts, std::max(1, nt / 2)));   // (the last two: both are released within ~8 us of the end)
         for (int p = 0; p < parts; p++) {
           const int a0 = t0 + (int)((long long)nt * p / parts), a1 = t0 + (int)((long long)nt * (p + 1) / parts);
           sl[dir].push_back(Sl{a0, a1 - a0, ce, dir, (int)c, p});
@@ -924,9 +933,15 @@ struct Net {
     g.partial = partial.p; g.R = R; g.Cn = Cn;
     g.gx = (unsigned)((Cn + GEMM_BT - 1) / GEMM_BT); g.gy = (unsigned)((R + GEMM_BT - 1) / GEMM_BT);
     g.timeouts = dw_timeouts.p;
-    if (!dw_queue.p) dw_queue.reserve(8 + 8 * 256 + 8);
+    if (!dw_queue.p) dw_queue.reserve(8 + 8 * 256 + 8 + 4 * PROG_STRIDE);
     g.qhead = dw_queue.p; g.cu_busy = dw_queue.p + 8; g.ndir = ndir;
-    const unsigned nblk = (unsigned)((dw_nslabs + 7) / 8) * 8u * g.gx * g.gy;
+    g.minprog = dw_queue.p + 8 + 8 * 256 + 8 + PROG_STRIDE - ((8 + 8 * 256 + 8) % PROG_STRIDE);   // own 128-byte lines
+    g.tcap = tmax + 32;
+    g.x3 = dw_x3;
+    static const char* trace_path = getenv("CLSTM_DW_TRACE");   // diagnostics: wall-clock stamps of every workgroup of the fused launch
+    const size_t trace_rows = (size_t)bs * ndir + (size_t)((dw_nslabs + 7) / 8) * 8 * g.gx * g.gy + 8;
+    if (trace_path) { dw_trace.reserve(trace_rows * 4); g.trace = dw_trace.p; g.trace_base = bs * ndir; }
+    const unsigned nblk = 1u + (unsigned)((dw_nslabs + 7) / 8) * 8u * g.gx * g.gy;   // the monitor + one per item
 #ifndef CLSTM_HIP_EMU
     if (overlap != 3 && y.nthreads >= 256) {   // ONE launch: the recurrence's workgroups first, the GEMM's behind them
       timing.begin("lstm_bwd", s);
@@ -938,6 +953,16 @@ struct Net {
       const unsigned nworkers = workers ? (unsigned)std::min<long long>((long long)nblk, workers > 1 ? workers : 512) : nblk;
       REQUIRE(launch_lstm_bwd_dw(y.nk4, y.pd.ku, a, g, bs * ndir, nworkers, y.nthreads, s, workers), "internal: no fused instantiation");
       timing.end(s);
+      if (trace_path) {
+        HIPCHECK(hipStreamSynchronize(s));
+        std::vector<long long> h(trace_rows * 4);
+        HIPCHECK(hipMemcpy(h.data(), dw_trace.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(trace_path, "w")) {
+          fprintf(f, "# rows 0..%d: recurrence workgroups (start, -, end); then one row per (slab, tile) item: start ready done need_it; 100 MHz ticks\n", bs * ndir - 1);
+          for (size_t i = 0; i < trace_rows; i++) fprintf(f, "%lld %lld %lld %lld\n", h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+          fclose(f);
+        }
+      }
       return;
     }
 #endif

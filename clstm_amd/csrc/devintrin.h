@@ -173,6 +173,8 @@ DEVFN f32x4 mfma16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
 // descriptors derived from it live in SGPRs instead of waterfall loops (guide T20)
 DEVFN int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 DEVFN long long dev_clock() { return (long long)__builtin_readcyclecounter(); }
+// chip-wide constant-rate clock (100 MHz): comparable across CUs, for launch-internal timelines (diagnostics)
+DEVFN long long wall_clock() { return (long long)__builtin_amdgcn_s_memrealtime(); }
 DEVFN float fast_exp(float x) { return __expf(x); }
 DEVFN float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

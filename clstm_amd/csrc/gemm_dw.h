@@ -14,7 +14,8 @@
 // Frames of a chunk are not contiguous in the packed line batch: a host-built table lists the k-tiles
 // (first frame, count <= 16) in slab order.  Tile / staging / MFMA structure as gemm_mfma.h (MC x MC operands).
 #pragma once
-#include "gemm_mfma.h"
+#include <type_traits>
+#include "gemm_bf16.h"
 
 namespace clstm {
 
@@ -43,34 +44,86 @@ struct GemmDwArgs {
   // persistent workers (lstm_bwd_dw.h): per-XCD work queues and the CUs the recurrence occupies
   int* qhead;               // [8] next item of XCD x (zeroed between launches by k_reduce_scatter)
   int* cu_busy;             // [8 * 256] = prog_base of this launch where a recurrence workgroup runs (hw_cu_slot())
+  int* minprog;             // [ndir] (PROG_STRIDE apart): prog_base + iterations EVERY line of that direction has completed,
+                            //   published by the monitor workgroup (gemm_dw_monitor); what the items poll
+  int tcap;                 // value published once every line is complete (longest line + 32)
+  long long* trace;         // diagnostics (CLSTM_DW_TRACE): [workgroup][4] wall-clock stamps -- start, ready, done
+  int trace_base;           // first trace row of the GEMM role's workgroups
+  int x3;                   // 1: products on the bf16 MFMA with both operands split hi + lo (gemm_dw_item_x3), 0: f32 MFMA
 };
+
+// blocks of the x3 item in flight in registers (6 and 8 were measured: the fused launch then needs > 168 registers,
+// only one GEMM workgroup fits a CU, 142 / 148 us against 116)
+#ifndef CLSTM_DW_PF
+#define CLSTM_DW_PF 3
+#endif
+constexpr int DW_PF = CLSTM_DW_PF;
+constexpr int DW_SMEM_FLOATS = 8192 + 2048;   // + the slab's k-tile table (DW_STAB_MAX entries of 2 ints)
+constexpr int DW_STAB_MAX = 1024;   // 32 KB: two buffers of four 64 x 32 bf16 images (x3 path); the epilogue tile fits too
+static_assert(8192 >= GEMM_BT * GEMM_LDO, "epilogue tile");
 
 constexpr int DW_WATCHDOG_POLLS = 1 << 16;
 
-// ---- wait until every line has completed `need_it` iterations of direction `dir` (called by all 256 threads) -------
-// Only wave 0 looks (one progress word per lane), and rarely: a poll is a system-scope load of up to 64 cache
-// lines, and hundreds of workgroups polling every microsecond starve the recurrence's write-through stores
-// (measured: 92 -> 630 us).  After each look the wave sleeps for most of the time the slowest line still needs
-// (~0.45 us per iteration), so a workgroup polls a handful of times in all.
+// ---- progress: one monitor, many waiters ---------------------------------------------------------------------------
+// A workgroup that waited by looking at the lines' progress words itself paid a system-scope load of up to 64 cache
+// lines per look, so hundreds of waiters could only look rarely (every look starves the recurrence's write-through
+// stores: 92 -> 630 us when they polled freely) and the last chunk's items noticed the end of the recurrence ~13 us
+// late (measured with the contraction left out: 109 us against 96).  Now ONE wave of ONE extra workgroup (the first
+// behind the recurrence's in dispatch order) looks at the lines every ~0.5 us and publishes, per direction, the number
+// of iterations every line has completed; the items poll that single word.
+DEVFN void gemm_dw_monitor(const GemmDwArgs& a) {
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x & 63;
+  int polls = 0;
+  for (;;) {
+    int all = 0x3fffffff;
+    int pv[2][4];                      // all loads of a look are requested before the first is used (up to 256 lines per direction)
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int b = lane + 64 * j;
+        pv[dir][j] = dir < a.ndir && b < a.bs ? load_i32_wt(a.prog + ((size_t)dir * a.bs + b) * PROG_STRIDE) : 0;
+      }
+    for (int dir = 0; dir < a.ndir; dir++) {
+      int m = 0x3fffffff;
+      for (int b = lane, j = 0; b < a.bs; b += 64, j++) {
+        const int T = a.line_off[b + 1] - a.line_off[b];
+        const int p = (j < 4 ? pv[dir][j] : load_i32_wt(a.prog + ((size_t)dir * a.bs + b) * PROG_STRIDE)) - a.prog_base;   // < 0: words of an older launch
+        const int v = p >= T ? 0x3fffffff : (p < 0 ? 0 : p);   // a finished line constrains nothing
+        m = v < m ? v : m;
+      }
+      m = -wave_max_i(-m);
+      if (lane == 0) store_i32_wt(a.minprog + dir * PROG_STRIDE, a.prog_base + (m > a.tcap ? a.tcap : m));
+      all = m < all ? m : all;
+    }
+    if (all >= 0x3fffffff) break;            // every line of every direction is complete (and tcap is published)
+    if (++polls > (DW_WATCHDOG_POLLS << 4)) {   // never hang the device: release the waiters, flag it, produce garbage
+      if (lane == 0) {
+        atomic_add_i32(a.timeouts, 1);
+        for (int dir = 0; dir < a.ndir; dir++) store_i32_wt(a.minprog + dir * PROG_STRIDE, a.prog_base + a.tcap);
+      }
+      break;
+    }
+  }
+}
+
+// wait until every line has completed `need_it` iterations of direction `dir` (called by all 256 threads): wave 0
+// polls the monitor's word, sleeping for about the time the missing iterations take (at most ~8 of them)
 DEVFN void gemm_dw_wait(const GemmDwArgs& a, const int dir, const int need_it) {
-  const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
+  const int wave = wave_uniform(threadIdx.x >> 6);
   if (wave == 0) {
+    const int need = need_it < a.tcap ? need_it : a.tcap;
     int polls = 0;
     for (;;) {
-      int deficit = 0;
-      for (int b = lane; b < a.bs; b += 64) {
-        const int T = a.line_off[b + 1] - a.line_off[b];
-        const int need = a.prog_base + (need_it < T ? need_it : T);
-        const int d = need - load_i32_wt(a.prog + ((size_t)dir * a.bs + b) * PROG_STRIDE);
-        deficit = d > deficit ? d : deficit;
-      }
-      deficit = wave_max_i(deficit);
-      if (deficit <= 0) break;
-      if (++polls > DW_WATCHDOG_POLLS) {   // never hang the device: give up, flag it, produce garbage
-        if (lane == 0) atomic_add_i32(a.timeouts, 1);
+      const int have = wave_uniform(load_i32_wt(a.minprog + dir * PROG_STRIDE) - a.prog_base);
+      if (have >= need) break;
+      if (++polls > (DW_WATCHDOG_POLLS << 4)) {   // the monitor never showed up
+        if ((threadIdx.x & 63) == 0) atomic_add_i32(a.timeouts, 1);
         break;
       }
-      sleep_iterations(deficit);
+      const int deficit = need - (have < 0 ? 0 : have);
+      sleep_iterations(deficit > 6 ? 6 : deficit);
     }
   }
   __syncthreads();
@@ -178,18 +231,182 @@ DEVFN void gemm_dw_item(const GemmDwArgs& a, float* smem, const unsigned si, con
     }
   }
 }
+// ---- the same work item on the bf16 MFMA, f32-grade: each f32 operand element x is split into hi = bf16(x) and
+// lo = bf16(x - hi) (the difference is exact in f32), and a product is  hi.hi + hi.lo + lo.hi  -- three
+// v_mfma_f32_16x16x32_bf16 with f32 accumulation.  What is dropped is lo.lo and the rounding of lo: < 2^-16 |x||y| per
+// product, against 2^-24 for an f32 multiply -- the gradient stays within ~1e-5 of its largest entry (measured against
+// the float64 oracle: tests/test_gpu_e2e.py::test_full_shape_gradient_error_vs_float64), well inside the 1e-4 the
+// parity tests grant, while a 32-frame block costs a wave 12 MFMAs of 16 cycles instead of 32 of 32: the product that
+// needed the whole chip for ~45 us (and held the fused backward launch 39 us past the recurrence's end) now keeps
+// pace with the recurrence on the half of the chip the recurrence leaves idle.
+// Staging: waves 0-1 convert the S block, waves 2-3 the D block; lane (m8, kg) loads frames 4 kg .. 4 kg + 3 of the
+// 32-frame block (two 16-frame table entries), 4 columns each, transposes in registers and writes 4 k of one row per
+// ds_write_b64 into swizzled [mn][32 k] images (gemm_bf16.h: conflict-free fragment reads); images are double-buffered,
+// one barrier per block.
+DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, const unsigned tile) {
+  constexpr int IMG = 64 * 32;                 // halfs per image
+  unsigned short* img = reinterpret_cast<unsigned short*>(smem);   // [buffer][A hi | A lo | B hi | B lo][64][32]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const DwSlab sl = a.slabs[si];
+  const int r0 = (int)(tile / a.gx) * GEMM_BT, c0 = (int)(tile % a.gx) * GEMM_BT;
+  const int dir = sl.dir;
+  const long long t_start = a.trace ? wall_clock() : 0;
+  // The slab's k-tile table goes to LDS while the item waits.  Read from global memory inside the loop, an entry was a
+  // DEPENDENT load in front of every block's operand loads, and VMEM returns in order: waiting for it meant waiting for
+  // every operand load still in flight -- one full memory latency per block (measured: 15 us per 16-block item).
+  const int* tab = a.ktab + (size_t)dir * a.ntiles_max * 2;
+  int* stab = reinterpret_cast<int*>(smem + 8192);
+  for (int i = tid; i < 2 * sl.ntiles && i < 2 * DW_STAB_MAX; i += 256) stab[i] = tab[2 * sl.tile_begin + i];   // (the host keeps slabs <= DW_STAB_MAX entries)
+  if (!(a.x3 & 2)) gemm_dw_wait(a, dir, sl.need_it);
+  else __syncthreads();
+  const long long t_ready = a.trace ? wall_clock() : 0;   // (bits 2, 4 of x3: perf experiments -- no wait / no contraction)
+
+  const bool isB = wave >= 2;                                      // wave-uniform staging role
+  const int s_mn = (wave & 1) * 32 + (lane & 7) * 4, s_kg = lane >> 3;   // 4 columns x frames 4 kg .. 4 kg + 3
+  const BufF32 abuf = make_buf(a.S + (size_t)dir * a.sdir, (size_t)(a.s_elems - (long long)dir * a.sdir) * 4);
+  const BufF32 bbuf = make_buf(a.D, (size_t)a.d_elems * 4);
+  const unsigned col = isB ? (unsigned)(dir * a.no4 + c0 + s_mn) : (unsigned)(r0 + s_mn);
+  const unsigned ldrow = isB ? (unsigned)a.M : (unsigned)a.lds;
+  const int tend = (a.x3 & 4) ? sl.tile_begin : sl.tile_begin + sl.ntiles;
+  const int e_half = s_kg >> 2, kk0 = (s_kg & 3) * 4;              // table entry of the pair, first frame row within it
+
+  // block b = table entries (tile_begin + 2b, + 2b + 1); unconditional loads, rows past an entry's count read zeros.
+  // ROLE is a compile-time constant inside each copy of the loop below: a wave-uniform `isB ? load_wt : load` compiles to
+  // branches around the VMEM instructions, and hipcc then waits with vmcnt(0) at every join -- the ring of blocks in
+  // flight collapsed to one (measured: ~0.9 us per block, 15 us per 16-block item).
+  auto load_block = [&](auto role, int t, f32x4 (&r)[4]) {
+    constexpr bool ROLE_B = decltype(role)::value;
+    const int te = t + e_half;
+    const bool live = te < tend;
+    const int tt = live ? te : sl.tile_begin;
+    const int f0 = stab[2 * (tt - sl.tile_begin)];
+    const int cn = stab[2 * (tt - sl.tile_begin) + 1];
+    const int cnt = live ? cn : 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned off = kk0 + j < cnt ? ((unsigned)(f0 + kk0 + j) * ldrow + col) * 4u : BUF_OOB;
+      if constexpr (ROLE_B) r[j] = buf_load4_wt(bbuf, off);
+      else r[j] = buf_load4(abuf, off);
+    }
+  };
+  unsigned short* const my_img = img + (isB ? 2 * IMG : 0);
+  int wofs[4];                                                     // halfs: row, swizzled chunk, half chunk
+#pragma unroll
+  for (int i = 0; i < 4; i++) wofs[i] = (s_mn + i) * 32 + ((((s_kg >> 1) ^ gb2_sw(s_mn + i)) << 3) | ((s_kg & 1) << 2));
+  auto stage = [&](int buf, const f32x4 (&r)[4]) {
+    unsigned short* d = my_img + buf * 4 * IMG;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      u32x2 h, l;
+      h[0] = bf16_pack2(r[0][i], r[1][i]);
+      h[1] = bf16_pack2(r[2][i], r[3][i]);
+      const float e0 = r[0][i] - __builtin_bit_cast(float, h[0] << 16), e1 = r[1][i] - __builtin_bit_cast(float, h[0] & 0xffff0000u);
+      const float e2 = r[2][i] - __builtin_bit_cast(float, h[1] << 16), e3 = r[3][i] - __builtin_bit_cast(float, h[1] & 0xffff0000u);
+      l[0] = bf16_pack2(e0, e1);
+      l[1] = bf16_pack2(e2, e3);
+      *reinterpret_cast<u32x2*>(d + wofs[i]) = h;
+      *reinterpret_cast<u32x2*>(d + IMG + wofs[i]) = l;
+    }
+  };
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+
+  const int fk = lane >> 4, fi = lane & 15;
+  const int fofs = fi * 32 + ((fk ^ gb2_sw(fi)) << 3);
+  auto run = [&](auto role) {
+  f32x4 rr[DW_PF][4];
+#pragma unroll
+  for (int p = 0; p < DW_PF; p++) {
+    load_block(role, sl.tile_begin + 2 * p, rr[p]);
+    SCHED_FENCE();
+  }
+  stage(0, rr[0]);
+  load_block(role, sl.tile_begin + 2 * DW_PF, rr[0]);
+  SCHED_FENCE();
+  __syncthreads();
+  int cur = 0;
+  for (int tb = sl.tile_begin; tb < tend; tb += 2 * DW_PF) {
+#pragma unroll
+    for (int p = 0; p < DW_PF; p++) {
+      const int pn = p + 1 == DW_PF ? 0 : p + 1;
+      stage(cur ^ 1, rr[pn]);                                   // block tb/2 + p + 1 into the other buffer
+      load_block(role, tb + 2 * (p + 1 + DW_PF), rr[pn]);
+      SCHED_FENCE();
+      const unsigned short* b0 = img + cur * 4 * IMG;
+      u16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        ah[i] = *reinterpret_cast<const u16x8*>(b0 + (wm * 32 + i * 16) * 32 + fofs);
+        al[i] = *reinterpret_cast<const u16x8*>(b0 + IMG + (wm * 32 + i * 16) * 32 + fofs);
+        bh[i] = *reinterpret_cast<const u16x8*>(b0 + 2 * IMG + (wn * 32 + i * 16) * 32 + fofs);
+        bl[i] = *reinterpret_cast<const u16x8*>(b0 + 3 * IMG + (wn * 32 + i * 16) * 32 + fofs);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = mfma16x16x32_bf16(al[i], bh[j], acc[i][j]);
+          acc[i][j] = mfma16x16x32_bf16(ah[i], bl[j], acc[i][j]);
+          acc[i][j] = mfma16x16x32_bf16(ah[i], bh[j], acc[i][j]);
+        }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  };
+  if (isB) run(std::true_type{}); else run(std::false_type{});
+  // epilogue through LDS: whole 256-byte row segments per store instruction (as gemm_mfma.h)
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        smem[(wm * 32 + i * 16 + (lane >> 4) * 4 + q) * GEMM_LDO + wn * 32 + j * 16 + (lane & 15)] = acc[i][j][q];
+  __syncthreads();
+  float* out = a.partial + (size_t)sl.out_z * a.R * a.Cn;
+  const bool v4 = (a.Cn & 3) == 0 && ((size_t)a.partial & 15) == 0;
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int rl = it * 16 + (tid >> 4), cl = (tid & 15) * 4;
+    const int r = r0 + rl, c = c0 + cl;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(&smem[rl * GEMM_LDO + cl]);
+    if (r < a.R) {
+      if (v4 && c + 3 < a.Cn) *reinterpret_cast<f32x4*>(out + (size_t)r * a.Cn + c) = v;
+      else
+        for (int e = 0; e < 4; e++)
+          if (c + e < a.Cn) out[(size_t)r * a.Cn + c + e] = v[e];
+    }
+  }
+  if (a.trace && tid == 0) {
+    long long* tr = a.trace + ((size_t)a.trace_base + si * (a.gx * a.gy) + tile) * 4;
+    tr[0] = t_start; tr[1] = t_ready; tr[2] = wall_clock(); tr[3] = sl.need_it;
+  }
+}
+
 // grid mode: workgroup `block` computes one item.  Workgroup b runs on XCD b % 8: XCD x takes slabs x, x+8, ... (all
 // output tiles of a slab pull its frames through ONE L2), and because slabs are listed in readiness order every XCD
 // gets early and late ones alike
-DEVFN void gemm_dw_body(const GemmDwArgs& a, float* smem, const unsigned block) {
+DEVFN void gemm_dw_body(const GemmDwArgs& a, float* smem, unsigned block) {
+  if (block == 0) { gemm_dw_monitor(a); return; }   // the first workgroup behind the recurrence's watches the lines
+  block -= 1;
   const unsigned tiles = a.gx * a.gy;
   const unsigned xcd = block & 7u, idx = block >> 3;
   const unsigned si = (idx / tiles) * 8u + xcd;
   if (si >= (unsigned)a.nslabs) return;
-  gemm_dw_item(a, smem, si, idx % tiles);
+  if (a.x3) gemm_dw_item_x3(a, smem, si, idx % tiles);
+  else gemm_dw_item(a, smem, si, idx % tiles);
 }
 __global__ __launch_bounds__(256) void gemm_dw_kernel(GemmDwArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[GEMM_BT * GEMM_LDO];
+  __shared__ __attribute__((aligned(16))) float smem[DW_SMEM_FLOATS];
   gemm_dw_body(a, smem, blockIdx.x);
 }
 
@@ -216,7 +433,8 @@ DEVFN void gemm_dw_worker(const GemmDwArgs& a, float* smem, int* lds_item) {
     const int item = *lds_item;
     __syncthreads();
     if (item >= nitems) break;
-    gemm_dw_item(a, smem, (unsigned)(item / (int)tiles) * 8u + (unsigned)xcd, (unsigned)item % tiles);
+    if (a.x3) gemm_dw_item_x3(a, smem, (unsigned)(item / (int)tiles) * 8u + (unsigned)xcd, (unsigned)item % tiles);
+    else gemm_dw_item(a, smem, (unsigned)(item / (int)tiles) * 8u + (unsigned)xcd, (unsigned)item % tiles);
     __syncthreads();
   }
 }

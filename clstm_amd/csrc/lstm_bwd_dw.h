@@ -17,16 +17,19 @@ namespace clstm {
 
 template <int NK4, int KU>
 __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_dw_kernel(LstmSeqArgs a, GemmDwArgs g, int nrec, int workers) {
-  __shared__ __attribute__((aligned(16))) float gsm[GEMM_BT * GEMM_LDO];
+  __shared__ __attribute__((aligned(16))) float gsm[DW_SMEM_FLOATS];
   __shared__ int item;
   if ((int)blockIdx.x < nrec) {
     if (threadIdx.x == 0) store_i32_wt(g.cu_busy + hw_cu_slot(), g.prog_base);   // this CU belongs to the recurrence
 #ifndef CLSTM_HIP_EMU
     __builtin_amdgcn_s_setprio(3);
 #endif
+    const long long t0 = g.trace ? wall_clock() : 0;
     lstm_bwd_body<NK4, KU>(a, (int)blockIdx.x % a.bs, (int)blockIdx.x / a.bs);
+    if (g.trace && threadIdx.x == 0) { g.trace[blockIdx.x * 4] = t0; g.trace[blockIdx.x * 4 + 2] = wall_clock(); }
   } else {
     if (threadIdx.x >= 256) return;   // the GEMM role is four waves; the others retire (a barrier counts live waves only)
+    if (workers && blockIdx.x == (unsigned)nrec) { gemm_dw_monitor(g); return; }
     if (workers) gemm_dw_worker(g, gsm, &item);
     else gemm_dw_body(g, gsm, blockIdx.x - (unsigned)nrec);   // one item per workgroup, in dispatch order
   }

@@ -206,6 +206,7 @@ inline f32x4 mfma16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
 }
 inline int wave_uniform(int x) { return x; }
 inline long long dev_clock() { return 0; }
+inline long long wall_clock() { return 0; }
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
