@@ -876,7 +876,8 @@ struct Net {
         // slab's frames, ~1 us per 32 -- is the launch's tail (profiles/r02_dw_timeline.txt): cut those chunks into
         // more, shorter slabs (>= 2 table entries each).
         static const int tail_parts = getenv("CLSTM_DW_TAIL_PARTS") ? atoi(getenv("CLSTM_DW_TAIL_PARTS")) : 4;   // (1: 118 us, 4: 112, 8: 115 -- more items than free CUs at the end)
-        if (c + 2 >= cb.size()) parts = std::max(parts, std::min(tail_parts, std::max(1, nt / 2)));   // (the last two: both are released within ~8 us of the end)
+        static const int tail_chunks = getenv("CLSTM_DW_TAIL_CHUNKS") ? atoi(getenv("CLSTM_DW_TAIL_CHUNKS")) : 3;
+        if (c + tail_chunks >= cb.size()) parts = std::max(parts, std::min(tail_parts, std::max(1, nt / 2)));   // (those whose items still run when the recurrence ends)
         for (int p = 0; p < parts; p++) {
           const int a0 = t0 + (int)((long long)nt * p / parts), a1 = t0 + (int)((long long)nt * (p + 1) / parts);
           sl[dir].push_back(Sl{a0, a1 - a0, ce, dir, (int)c, p});

@@ -123,7 +123,7 @@ DEVFN void gemm_dw_wait(const GemmDwArgs& a, const int dir, const int need_it) {
         break;
       }
       const int deficit = need - (have < 0 ? 0 : have);
-      sleep_iterations(deficit > 6 ? 6 : deficit);
+      sleep_iterations(deficit > 12 ? 6 : 1);   // close to ready: look every ~0.35 us (a look is one word)
     }
   }
   __syncthreads();

@@ -30,7 +30,10 @@ enum { GEMM_KC = 0, GEMM_MC = 1 };
 constexpr int GEMM_BT = 64;   // tile rows / cols
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_LD = 80;
-constexpr int GEMM_PF = 3;   // k-tiles prefetched in registers
+#ifndef CLSTM_GEMM_PF
+#define CLSTM_GEMM_PF 3
+#endif
+constexpr int GEMM_PF = CLSTM_GEMM_PF;   // k-tiles prefetched in registers
 constexpr int GEMM_LDO = 68;  // LDS row stride of the output tile in the epilogue
 
 struct GemmOperand {

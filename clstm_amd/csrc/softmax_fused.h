@@ -13,6 +13,10 @@
 
 namespace clstm {
 
+#ifndef CLSTM_SMX_PF
+#define CLSTM_SMX_PF 3
+#endif
+constexpr int SMX_PF = CLSTM_SMX_PF;   // k-tiles in flight in registers
 constexpr int SMX_COLS = 96;   // classes per workgroup (6 MFMA column tiles)
 constexpr int SMX_LDB = 112;   // LDS row stride of the weight tile (112 mod 32 = 16, see gemm_mfma.h)
 
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const f
   const int b_k1 = (tid + 256) / 24, b_c1 = ((tid + 256) % 24) * 4;
   const bool b_second = tid + 256 < GEMM_BK * 24;
 
-  f32x4 ra[GEMM_PF], rb0[GEMM_PF], rb1[GEMM_PF];
+  f32x4 ra[SMX_PF], rb0[SMX_PF], rb1[SMX_PF];
   auto load_tile = [&](int k0, f32x4& a, f32x4& b0, f32x4& b1) {
     const bool live = k0 < K;
     a = buf_load4(abuf, live ? (a_base + (unsigned)k0) * 4u : BUF_OOB);
@@ -55,14 +59,14 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const f
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
 #pragma unroll
-  for (int p = 0; p < GEMM_PF; p++) {
+  for (int p = 0; p < SMX_PF; p++) {
     load_tile(p * GEMM_BK, ra[p], rb0[p], rb1[p]);
     SCHED_FENCE();
   }
   const int fk = lane >> 4, fi = lane & 15;
-  for (int kb = 0; kb < K; kb += GEMM_PF * GEMM_BK) {
+  for (int kb = 0; kb < K; kb += SMX_PF * GEMM_BK) {
 #pragma unroll
-    for (int p = 0; p < GEMM_PF; p++) {
+    for (int p = 0; p < SMX_PF; p++) {
       const int k0 = kb + p * GEMM_BK;   // phases past K multiply zeros
 #pragma unroll
       for (int i = 0; i < 4; i++) As[(a_k + i) * GEMM_LD + a_mn] = (k0 + a_k + i < K) ? ra[p][i] : 0.0f;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const f
         if (b_second) *reinterpret_cast<f32x4*>(&Bs[b_k1 * SMX_LDB + b_c1]) = v1;
       }
       __syncthreads();
-      load_tile(k0 + GEMM_PF * GEMM_BK, ra[p], rb0[p], rb1[p]);
+      load_tile(k0 + SMX_PF * GEMM_BK, ra[p], rb0[p], rb1[p]);
       SCHED_FENCE();
 #pragma unroll
       for (int kk = 0; kk < GEMM_BK; kk += 4) {
