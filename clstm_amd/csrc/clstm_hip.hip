@@ -500,14 +500,15 @@ struct Net {
   bool src0_ready = false;    // layer 0's source rows [1 | x] already written by set_inputs_d
   long long N = 0;
   std::vector<int> line_off_h;
-  DevBuf<int> line_off;
+  DevBuf<int> line_off;            // [bs + 1] first frame of each line | [bs] dispatch order (set_batch)
+  std::vector<int> order_h;
   PinnedRing ring;
   const int* lo_stage = nullptr;   // pinned copy of the line offsets not yet on the device
   bool lo_pending = false;
   void flush_line_off() {
     if (!lo_pending) return;
     hipStream_t s = stream();
-    HIPCHECK(hipMemcpyAsync(line_off.p, lo_stage, (bs + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(line_off.p, lo_stage, (2 * bs + 1) * sizeof(int), hipMemcpyHostToDevice, s));
     ring.commit(s);
     lo_pending = false;
   }
@@ -665,10 +666,17 @@ struct Net {
     tmax = 0;
     for (int b = 0; b < nb; b++) tmax = std::max(tmax, T_h[b]);
     src0_ready = false;
-    line_off.reserve(nb + 1);
+    // behind the offsets: the order in which the per-line workgroups take the lines -- longest first, so that when
+    // there are more lines than CUs the long ones are not the last to start (stable: equal lengths keep their order)
+    order_h.resize(nb);
+    for (int b = 0; b < nb; b++) order_h[b] = b;
+    static const bool longest_first = !(getenv("CLSTM_LINE_ORDER") && atoi(getenv("CLSTM_LINE_ORDER")) == 0);
+    if (longest_first) std::stable_sort(order_h.begin(), order_h.end(), [&](int x, int y) { return T_h[x] > T_h[y]; });
+    line_off.reserve(2 * nb + 1);
     hipStream_t s = stream();
-    int* stage = (int*)ring.acquire((nb + 1) * sizeof(int));
+    int* stage = (int*)ring.acquire((2 * nb + 1) * sizeof(int));
     memcpy(stage, line_off_h.data(), (nb + 1) * sizeof(int));
+    memcpy(stage + nb + 1, order_h.data(), nb * sizeof(int));
     // The device copy is made by the next input-ingest launch (which reads the pinned slot directly: one DMA
     // launch of ~4 us less per step) or, if something else needs it first, by flush_line_off().
     lo_stage = stage; lo_pending = true;
@@ -743,7 +751,7 @@ struct Net {
       timing.end(s);
       LstmSeqArgs a{};
       a.Rpk = y.Rf; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = nullptr; a.D = nullptr;
-      a.line_off = line_off.p; a.no = y.no; a.ndir = ndir; a.ldh = y.ldh; a.hofs = y.hofs;
+      a.line_off = line_off.p; a.order = line_off.p + bs + 1; a.no = y.no; a.ndir = ndir; a.ldh = y.ldh; a.hofs = y.hofs;
       a.S = y.S.p; a.lds = y.lds; a.sofs = 1 + y.ni; a.sdir = (long long)N * y.lds;
 #ifdef CLSTM_LSTM_PROF
       lstm_prof.reserve(64); a.prof = lstm_prof.p;
@@ -1022,7 +1030,7 @@ struct Net {
       const int M = ndir * 4 * y.no;
       LstmSeqArgs a{};
       a.Rpk = y.Rb; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = y.dH.p; a.D = y.D.p;
-      a.line_off = line_off.p; a.no = y.no; a.ndir = ndir; a.bs = bs;
+      a.line_off = line_off.p; a.order = line_off.p + bs + 1; a.no = y.no; a.ndir = ndir; a.bs = bs;
       // W.d += delta [1; x_t; h_{t-1}]^T for the four gates of each direction
       // (both directions in one batched launch: half the slabs per direction fill the chip)
       const int R = 1 + y.ni + y.no, Cn = 4 * y.no;
@@ -1122,20 +1130,25 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
   const int ns = state_off_h[bs];
   for (int i = 0; i < ns; i++) REQUIRE(states_h[i] >= 0 && states_h[i] < nc, "target class out of range");
   w.lat.reserve((size_t)(lo[bs] > 0 ? lo[bs] : 1));
-  // one pinned slot, one device block, one copy: [lat_off (bs+1 x i64) | line_off | state_off | states]
+  // one pinned slot, one device block, one copy: [lat_off (bs+1 x i64) | line_off | state_off | states | order]
   const size_t nlo = (size_t)(bs + 1) * sizeof(long long), nio = (size_t)(bs + 1) * sizeof(int);
-  const size_t nst = (size_t)(ns > 0 ? ns : 1) * sizeof(int);
-  w.meta.reserve(nlo + 2 * nio + nst);
+  const size_t nst = (size_t)(ns > 0 ? ns : 1) * sizeof(int), nord = (size_t)bs * sizeof(int);
+  w.meta.reserve(nlo + 2 * nio + nst + nord);
   {
-    char* stage = (char*)w.ring.acquire(nlo + 2 * nio + nst);
+    char* stage = (char*)w.ring.acquire(nlo + 2 * nio + nst + nord);
     memcpy(stage, lo.data(), nlo);
     memcpy(stage + nlo, line_off_h, nio);
     memcpy(stage + nlo + nio, state_off_h, nio);
     if (ns > 0) memcpy(stage + nlo + 2 * nio, states_h, (size_t)ns * sizeof(int));
+    // workgroups take the lines largest lattice first (one workgroup per line; more lines than CUs run in rounds)
+    std::vector<int> order(bs);
+    for (int b = 0; b < bs; b++) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return lo[x + 1] - lo[x] > lo[y + 1] - lo[y]; });
+    memcpy(stage + nlo + 2 * nio + nst, order.data(), nord);
     if (defer) {
-      defer->src = (const int*)stage; defer->dst = (int*)w.meta.p; defer->nwords = (int)((nlo + 2 * nio + nst) / sizeof(int));
+      defer->src = (const int*)stage; defer->dst = (int*)w.meta.p; defer->nwords = (int)((nlo + 2 * nio + nst + nord) / sizeof(int));
     } else {
-      HIPCHECK(hipMemcpyAsync(w.meta.p, stage, nlo + 2 * nio + nst, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipMemcpyAsync(w.meta.p, stage, nlo + 2 * nio + nst + nord, hipMemcpyHostToDevice, s));
       w.ring.commit(s);
     }
   }
@@ -1143,6 +1156,7 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
   a.P = probs; a.Dz = deltas; a.aligned = aligned; a.line_off = (const int*)(w.meta.p + nlo);
   a.states = (const int*)(w.meta.p + nlo + 2 * nio); a.state_off = (const int*)(w.meta.p + nlo + nio);
   a.lat = w.lat.p; a.lat_off = (const long long*)w.meta.p; a.nc = nc;
+  a.order = (const int*)(w.meta.p + nlo + 2 * nio + nst);
   w.prof.reserve(16); a.prof = w.prof.p; g_last_ctc_prof = w.prof.p;
   if (!w.tables.p) {
     w.tables.reserve(CTC_TABLE_DOUBLES);
@@ -1412,7 +1426,7 @@ static void net_set_inputs_d(clstm_net* h, const float* x, const CtcMetaCopy* au
     // training step -- the CTC metadata (no DMA launches, no event records on the stream's critical path)
     CLSTM_LAUNCH(k_ingest_pack, dim3(nbi + nbp + (lo ? 1 : 0) + (ax ? (aux->nwords + 255) / 256 : 0)), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni, y.lds,
                  n.ndir, (long long)n.N * y.lds, nbi, nbp, (const float*)n.v, y.Wt, y.bias, y.Rf, y.Rb, y.pd,
-                 lo ? n.lo_stage : nullptr, n.line_off.p, n.bs + 1, ax ? aux->src : nullptr, ax ? aux->dst : nullptr, ax ? aux->nwords : 0);
+                 lo ? n.lo_stage : nullptr, n.line_off.p, 2 * n.bs + 1, ax ? aux->src : nullptr, ax ? aux->dst : nullptr, ax ? aux->nwords : 0);
     if (lo) { n.ring.commit(g_stream); n.lo_pending = false; }
     if (ax) { h->ctc.ring.commit(g_stream); aux_done = true; }
     n.packed_dirty = false;

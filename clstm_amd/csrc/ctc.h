@@ -43,6 +43,7 @@ struct CtcArgs {
   float* Dz;             // [N][nc] out: aligned - P
   float* aligned;        // [N][nc] out (optional, may be null): alignment posteriors
   const int* line_off;   // [bs+1]
+  const int* order;      // [bs] line of the b-th workgroup (largest lattice first), or null
   const int* states;     // packed state classes
   const int* state_off;  // [bs+1]
   float* lat;            // lattice workspace: per line 3*T*S floats at lat_off[b]
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   float* red = lds + L.red;
   const CrTables tb{tabs, tabs + 32, tabs + 96, tabs + 160};
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int b = blockIdx.x;
+  const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   const int nc = a.nc, ncp = a.ncp, TT = a.tile;
   const int off = a.line_off[b], T = a.line_off[b + 1] - off;
   const int soff = a.state_off[b], S = a.state_off[b + 1] - soff;

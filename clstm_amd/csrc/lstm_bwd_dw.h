@@ -25,7 +25,8 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_dw
     __builtin_amdgcn_s_setprio(3);
 #endif
     const long long t0 = g.trace ? wall_clock() : 0;
-    lstm_bwd_body<NK4, KU>(a, (int)blockIdx.x % a.bs, (int)blockIdx.x / a.bs);
+    const int bl = (int)blockIdx.x % a.bs;
+    lstm_bwd_body<NK4, KU>(a, a.order ? a.order[bl] : bl, (int)blockIdx.x / a.bs);
     if (g.trace && threadIdx.x == 0) { g.trace[blockIdx.x * 4] = t0; g.trace[blockIdx.x * 4 + 2] = wall_clock(); }
   } else {
     if (threadIdx.x >= 256) return;   // the GEMM role is four waves; the others retire (a barrier counts live waves only)

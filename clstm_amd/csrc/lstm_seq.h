@@ -47,6 +47,7 @@ struct LstmSeqArgs {
   const float* dH;      // [N][2*no]     bwd: delta on H            (backward only)
   float* D;             // [N][2][4*no]  bwd: gate pre-activation deltas (backward only)
   const int* line_off;  // [bs+1] first token of each line
+  const int* order;     // [bs] line that the b-th workgroup of a direction walks (longest first), or null
   int no;
   int ndir;             // 2 (bidirectional) or 1 (forward only, "lstm1")
   float* S;             // [ndir][N][lds] source rows [1 | x_t | h_{t-1}] for the weight-gradient GEMM;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
   float* lds = dyn_smem<float>();  // hbuf[2][HB] + dump word
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x;
-  const int b = blockIdx.x, dir = blockIdx.y;
+  const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, dir = blockIdx.y;
   const int no = a.no;
   const int q = lane & 3, cell = wave * 16 + (lane >> 2);
   const bool valid = cell < no;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd2_k
   const int nthreads = blockDim.x;             // 64 * ceil(no / 16): may be fewer waves than NK4 provides for
   const int nwaves = nthreads >> 6;
   const int EW = nwaves < EWMAX ? nwaves : EWMAX, EWT = 64 * EW;
-  const int b = blockIdx.x, dir = blockIdx.y;
+  const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, dir = blockIdx.y;
   const int no = a.no, nd = a.ndir;
   const int q = lane & 3, cell = wave * 16 + (lane >> 2);
   const bool valid = cell < no;
@@ -617,7 +618,7 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
 }
 template <int NK4, int KU>
 __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_kernel(LstmSeqArgs a) {
-  lstm_bwd_body<NK4, KU>(a, blockIdx.x, blockIdx.y);
+  lstm_bwd_body<NK4, KU>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, blockIdx.y);
 }
 
 }  // namespace clstm

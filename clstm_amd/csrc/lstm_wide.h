@@ -186,6 +186,9 @@ DEVFN void wide_tile_bf16(const BufF32 abuf, const unsigned (&arow)[MT], const B
     for (int q = 0; q < 4; q++) red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * LDR + (lane & 15)] = acc[i][q];
 }
 
+#ifndef CLSTM_WEXP   // perf experiments only: bit mask of work to leave out of the forward step (results are then wrong)
+#define CLSTM_WEXP 0
+#endif
 // 16 lines x 64 columns (four 16-row weight tiles, `btile` bytes apart) on the same instruction: one A fragment serves
 // four MFMAs, so a workgroup pulls a quarter of the FRESH bytes (h_{t-1}: written one launch ago by other XCDs, an L2
 // miss) per product column; the weight rows it reads instead are L2-resident for the whole sequence.
@@ -257,10 +260,10 @@ DEVFN void wide_fwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int c
   const int no = a.no, nd = a.ndir;
   const int ncg = (no + 3) >> 2;
   const int m = zb * 16 + (lane & 15);
-  const unsigned arow = (sg >= 1 && m < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + m) * a.kp16) * 2u : BUF_OOB_BASE;
+  const unsigned arow = (sg >= 1 && m < a.bs && !(CLSTM_WEXP & 1)) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + m) * a.kp16) * 2u : BUF_OOB_BASE;
   const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * a.bs * a.kp16 * 2);
   const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(a.Rw16), (size_t)a.rw_elems * 2);
-  const unsigned brow = (unsigned)(((long long)(dir * ncg + ct * 4) * 16 + (lane & 15)) * a.kp16) * 2u;   // rows past the
+  const unsigned brow = (CLSTM_WEXP & 2) ? BUF_OOB_BASE : (unsigned)(((long long)(dir * ncg + ct * 4) * 16 + (lane & 15)) * a.kp16) * 2u;   // rows past the
   const unsigned btile = (unsigned)(16 * a.kp16) * 2u;                   // last cell group: dropped by the descriptor
 
   const int ml = tid >> 4, c16 = tid & 15;
@@ -280,7 +283,7 @@ DEVFN void wide_fwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int c
   wide_tile_bf16_n4<4>(abuf, arow, bbuf, brow, btile, a.kp16, red, [&]() {
     off = __builtin_bit_cast(int, lo0);
     T = __builtin_bit_cast(int, lo1) - off;
-    live = line < a.bs && cell < no && sg < T;
+    live = line < a.bs && cell < no && sg < T && !(CLSTM_WEXP & 32);
     n = off + (dir == 0 ? sg : T - 1 - sg);
     gx = buf_load4(gbuf, live ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB);
     c_prev = buf_load(cbuf, live && sg >= 1
@@ -289,7 +292,8 @@ DEVFN void wide_fwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int c
   __syncthreads();
 
   float h = 0.0f;
-  if (live) {
+  if (CLSTM_WEXP & 32) live = line < a.bs && cell < no && sg < T;
+  if (live && !(CLSTM_WEXP & 16)) {
     f32x4 k;
 #pragma unroll
     for (int q = 0; q < 4; q++) k[q] = 0.0f;
@@ -305,6 +309,7 @@ DEVFN void wide_fwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int c
     h = gate_act(c, true) * go;
     f32x4 act;
     act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
+    if ((CLSTM_WEXP & 8) && h != 12345.678f) return;
     *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
     a.C[(n * nd + dir) * no + cell] = c;
     a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
@@ -331,9 +336,6 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_fwd_step16_bf16(LstmWi
 
 // ---- forward: one time step of 16*MT lines for one (cell group, direction) ------------------------
 // loff: line offsets (global for the per-step launch, an LDS copy in the cooperative kernel)
-#ifndef CLSTM_WEXP   // perf experiments only: bit mask of work to leave out of the forward step (results are then wrong)
-#define CLSTM_WEXP 0
-#endif
 template <int MT, bool COOP, bool BF16 = false>
 DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, const int dir, const int zb,
                          const int* loff, const float* wl, float* red) {
