@@ -17,6 +17,9 @@ namespace clstm {
 #define CLSTM_SMX_PF 3
 #endif
 constexpr int SMX_PF = CLSTM_SMX_PF;   // k-tiles in flight in registers
+#ifndef CLSTM_SEXP   // perf experiments only (results wrong)
+#define CLSTM_SEXP 0
+#endif
 constexpr int SMX_COLS = 96;   // classes per workgroup (6 MFMA column tiles)
 constexpr int SMX_LDB = 112;   // LDS row stride of the weight tile (112 mod 32 = 16, see gemm_mfma.h)
 
@@ -48,16 +51,19 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const f
 
   f32x4 ra[SMX_PF], rb0[SMX_PF], rb1[SMX_PF];
   auto load_tile = [&](int k0, f32x4& a, f32x4& b0, f32x4& b1) {
-    const bool live = k0 < K;
+    const bool live = k0 < K && !(CLSTM_SEXP & 1);
     a = buf_load4(abuf, live ? (a_base + (unsigned)k0) * 4u : BUF_OOB);
     b0 = buf_load4(bbuf, live ? ((unsigned)nc * (1 + k0 + b_k0) + b_c0) * 4u : BUF_OOB);
     b1 = buf_load4(bbuf, live && b_second ? ((unsigned)nc * (1 + k0 + b_k1) + b_c1) * 4u : BUF_OOB);
   };
   f32x4 acc[6];
+  float bias[6];
 #pragma unroll
-  for (int j = 0; j < 6; j++)
+  for (int j = 0; j < 6; j++) {
+    bias[j] = buf_load(bbuf, j * 16 + (lane & 15) < nc ? (unsigned)(j * 16 + (lane & 15)) * 4u : BUF_OOB);   // W1[:, 0]
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
+  }
 #pragma unroll
   for (int p = 0; p < SMX_PF; p++) {
     load_tile(p * GEMM_BK, ra[p], rb0[p], rb1[p]);
@@ -78,20 +84,28 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const f
         *reinterpret_cast<f32x4*>(&Bs[b_k0 * SMX_LDB + b_c0]) = v0;
         if (b_second) *reinterpret_cast<f32x4*>(&Bs[b_k1 * SMX_LDB + b_c1]) = v1;
       }
-      __syncthreads();
+      if (!(CLSTM_SEXP & 8)) __syncthreads();
       load_tile(k0 + SMX_PF * GEMM_BK, ra[p], rb0[p], rb1[p]);
       SCHED_FENCE();
 #pragma unroll
       for (int kk = 0; kk < GEMM_BK; kk += 4) {
         const float af = As[(kk + fk) * GEMM_LD + wave * 16 + fi];
 #pragma unroll
-        for (int j = 0; j < 6; j++) acc[j] = mfma16x16x4(af, Bs[(kk + fk) * SMX_LDB + j * 16 + fi], acc[j]);
+        for (int j = 0; j < 6; j++) if (!(CLSTM_SEXP & 2) || j == 0) acc[j] = mfma16x16x4(af, Bs[(kk + fk) * SMX_LDB + j * 16 + fi], acc[j]);
       }
       __syncthreads();
     }
   }
+  if ((CLSTM_SEXP & 4) && acc[0][0] != 12345.6f) return;
   // epilogue: lane holds rows (lane>>4)*4 + q and columns j*16 + (lane&15); a row's 96 columns sit in the
-  // 16 lanes of one row group
+  // 16 lanes of one row group.  (The six biases of a lane were requested before the k loop: read inside this loop
+  // they were 24 dependent L1 round trips -- the epilogue took 6.8 of the kernel's 21 us.)
+  // Branch-free: clamp + selects for limexp's two cut-offs, out-of-range buffer offsets for the masked stores (with
+  // `if`s hipcc built an exec-masked block per element: 96 s_and_saveexec in this epilogue).
+  const BufF32 zbuf = make_buf(Z, (size_t)N * nc * 4);
+  bool cok[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) cok[j] = j * 16 + (lane & 15) < nc;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int r = r0 + wave * 16 + (lane >> 4) * 4 + q;
@@ -99,22 +113,21 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const f
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      const int c = j * 16 + (lane & 15);
-      const float x = acc[j][q] + (c < nc ? W1[c] : 0.0f);
-      e[j] = c < nc ? smx_limexp(x) : 0.0f;
+      const float x = acc[j][q] + bias[j];
+      float v = expf(fminf(fmaxf(x, -30.0f), 30.0f));
+      v = x < -30.0f ? (float)0x1.a56e0c2b7ab97p-44 : v;   // (Float)exp(-30.0), tensor.h:78-82
+      v = x > 30.0f ? (float)0x1.37047090c0b53p+43 : v;    // (Float)exp(30.0)
+      e[j] = cok[j] ? v : 0.0f;
       s += e[j];
     }
     s += row_ror<8>(s);
     s += row_ror<4>(s);
     s += row_ror<2>(s);
     s += row_ror<1>(s);
-    if (r < N) {
+    const unsigned rowoff = (unsigned)r * (unsigned)nc;
 #pragma unroll
-      for (int j = 0; j < 6; j++) {
-        const int c = j * 16 + (lane & 15);
-        if (c < nc) Z[(size_t)r * nc + c] = e[j] / s;
-      }
-    }
+    for (int j = 0; j < 6; j++)
+      buf_store(zbuf, r < N && cok[j] ? (rowoff + (unsigned)(j * 16 + (lane & 15))) * 4u : BUF_OOB, e[j] / s);
   }
 }
 
