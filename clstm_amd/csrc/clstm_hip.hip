@@ -739,6 +739,9 @@ struct Net {
       if (bf16_gemm)
         gemm_bf16<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N, layer_input_slack(l)),
                                     gemm_mc(y.Wt, M, y.ni, y.wt_slack), StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
+      else if (gemm_x3_fwd)
+        gemm_x3<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N, layer_input_slack(l)),
+                                  gemm_mc(y.Wt, M, y.ni, y.wt_slack), StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
       else
         gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N), gemm_mc(y.Wt, M, y.ni, 0),
                                    StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
@@ -785,6 +788,12 @@ struct Net {
   // overlapped weight-gradient GEMM: 1 = bf16 MFMA on hi + lo split operands (three products, f32-grade: gemm_dw.h),
   // 0 = f32 MFMA (CLSTM_DW_X3=0)
   int dw_x3 = getenv("CLSTM_DW_X3") ? atoi(getenv("CLSTM_DW_X3")) : 1;
+  // the short hoisted products of the f32 path (W_x, softmax W.d / x.d) the same way (gemm_x3, gemm_bf16.h); CLSTM_GEMM_X3=0: f32 MFMA
+  bool gemm_x3_on = !(getenv("CLSTM_GEMM_X3") && atoi(getenv("CLSTM_GEMM_X3")) == 0);
+  // NOT the forward product W_x.x (CLSTM_GEMM_X3=2 for experiments): its ~2^-17 relative error per product shows up in
+  // gate pre-activations that cancel to ~0 (a tanh gate at -0.0021 came out 5.6e-6 off where the parity bar allows
+  // 2.2e-6), and with K = 49 the split costs more staging than it saves MFMA time (28.5 vs 20.9 us)
+  bool gemm_x3_fwd = getenv("CLSTM_GEMM_X3") && atoi(getenv("CLSTM_GEMM_X3")) == 2;
   // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
   int pick_split(int R, int Cn, int nbatch = 1, int tile = GEMM_BT) const {
     const long long tiles = (long long)((R + tile - 1) / tile) * ((Cn + tile - 1) / tile) * nbatch;
@@ -1016,6 +1025,12 @@ struct Net {
       // W.d (split-K slabs) and x.d in ONE launch: two small independent products, each mostly prologue and
       // epilogue latency on its own (13.9 + 12.4 us back to back)
       timing.begin("gemm_softmax_dw_dx", s);
+      if (gemm_x3_on)
+        gemm_x3_pair<GEMM_MC, GEMM_MC, StorePartial, GEMM_KC, GEMM_KC, StorePlain>(
+            s, gemm_problem(gemm_mc(top.srow(), top.ldh, N), gemm_mc(Dz.p, nc, N), R, Cn, (int)N, ns),
+            StorePartial{partial_sm.p, R, Cn},
+            gemm_problem(gemm_kc(Dz.p, nc, N), gemm_kc(W1 + nc, nc, sm_ni, 0), (int)N, sm_ni, nc), StorePlain{top.dH.p, sm_ni});
+      else
       gemm_f32_pair<GEMM_MC, GEMM_MC, StorePartial, GEMM_KC, GEMM_KC, StorePlain>(
           s, gemm_problem(gemm_mc(top.srow(), top.ldh, N), gemm_mc(Dz.p, nc, N), R, Cn, (int)N, ns),
           StorePartial{partial_sm.p, R, Cn},
@@ -1824,6 +1839,15 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     if (nsplit < 1) nsplit = 1;
     part->reserve((size_t)nsplit * R * Cn);
     gemm_bf16<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
+    CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
+                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0);
+  } else if (mode == 20) gemm_x3<GEMM_KC, GEMM_MC>(g_stream, gemm_kc(A, K, R, 0), gemm_mc(B, Cn, K, 0), StorePlain{Cm, Cn}, R, Cn, K);
+  else if (mode == 21) gemm_x3<GEMM_KC, GEMM_KC>(g_stream, gemm_kc(A, K, R, 0), gemm_kc(B, K, Cn, 0), StorePlain{Cm, Cn}, R, Cn, K);
+  else if (mode == 22) {
+    if (!part) part = new DevBuf<float>();
+    if (nsplit < 1) nsplit = 1;
+    part->reserve((size_t)nsplit * R * Cn);
+    gemm_x3<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
                  (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0);
   } else throw Error("bad mode");

@@ -315,6 +315,214 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
       }
 }
 
+// ---- f32-grade products on the bf16 MFMA: 64 x 64 tile, operands split hi + lo ------------------------------------------
+// Same interface as gemm_f32_body (gemm_mfma.h) and -- to ~1e-6 of a product, see gemm_dw.h -- the same result:
+// every f32 operand element is staged as hi = bf16(x) and lo = bf16(x - hi), a product is hi.hi + hi.lo + lo.hi on
+// v_mfma_f32_16x16x32_bf16 with f32 accumulation.  Leaving parts out of the f32 kernel showed the MFMA pipe as the
+// largest single item of the short products of a training step (softmax W.d / x.d pair 9 of 24 us, W_x 5 of 21, fused
+// softmax 6 of 21): a 32-k block costs a wave 12 MFMAs of 16 cycles here instead of 32 of 32.
+// Four swizzled [mn][32 k] images (A hi, A lo, B hi, B lo; gb2_sw) per buffer, two buffers, one barrier per block;
+// every thread stages 8 elements of each operand (KC: 8 consecutive k of a row -> one ds_write_b128 per image;
+// MC: 4 columns x (k, k+1) -> four ds_write_b32 per image); ring of three register-staged blocks.
+constexpr int GX3_IMG = 64 * 32;                 // halfs per image
+constexpr int GX3_SMEM_FLOATS = 2 * 4 * GX3_IMG / 2;   // 32 KB
+static_assert(GX3_SMEM_FLOATS >= GEMM_BT * GEMM_LDO, "epilogue tile");
+
+template <int AMODE, int BMODE, class FE>
+DEVFN void gemm_x3_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int ksplit, int nsplit,
+                        const unsigned lin, const unsigned gx, const unsigned gy, const unsigned gz) {
+  unsigned short* img = reinterpret_cast<unsigned short*>(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int bx, by, z;   // XCD-aware tile order, see gemm_mfma.h
+  {
+    const unsigned total = gx * gy * gz;
+    const unsigned xcd = lin & 7u, idx = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = (int)(v % gx);
+    by = (int)((v / gx) % gy);
+    z = (int)(v / (gx * gy));
+  }
+  const int r0 = by * GEMM_BT, c0 = bx * GEMM_BT;
+  const int batch = z / nsplit;
+  const int kbeg = (z - batch * nsplit) * ksplit;
+  const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
+
+  // staging unit of this thread (two float4 per operand and block):
+  //   KC: row tid>>2, k = (tid&3)*8 .. +7      MC: mn = (tid&15)*4 .. +3, k = (tid>>4)*2, +1
+  const int a_mn = AMODE == GEMM_KC ? (tid >> 2) : (tid & 15) * 4, a_k = AMODE == GEMM_KC ? (tid & 3) * 8 : (tid >> 4) * 2;
+  const int b_mn = BMODE == GEMM_KC ? (tid >> 2) : (tid & 15) * 4, b_k = BMODE == GEMM_KC ? (tid & 3) * 8 : (tid >> 4) * 2;
+  const BufF32 abuf = make_buf(A.p + batch * A.bstride, (size_t)(A.elems - batch * A.bstride) * 4);
+  const BufF32 bbuf = make_buf(B.p + batch * B.bstride, (size_t)(B.elems - batch * B.bstride) * 4);
+  const unsigned a_base = AMODE == GEMM_KC ? (unsigned)(r0 + a_mn) * A.ld + a_k : (unsigned)a_k * A.ld + r0 + a_mn;
+  const unsigned b_base = BMODE == GEMM_KC ? (unsigned)(c0 + b_mn) * B.ld + b_k : (unsigned)b_k * B.ld + c0 + b_mn;
+  const unsigned a_kstep = AMODE == GEMM_KC ? 1u : (unsigned)A.ld, b_kstep = BMODE == GEMM_KC ? 1u : (unsigned)B.ld;
+  const unsigned a_second = AMODE == GEMM_KC ? 4u : (unsigned)A.ld, b_second = BMODE == GEMM_KC ? 4u : (unsigned)B.ld;
+  const unsigned aoff0 = a_base * 4u, aoff1 = (a_base + a_second) * 4u, boff0 = b_base * 4u, boff1 = (b_base + b_second) * 4u;
+  const int klast = kbeg + ((kend - kbeg - 1) / GB_BK) * GB_BK;   // blocks past the slab re-read its last block (zeroed when staged)
+
+  f32x4 ra[GB_PF][2], rb[GB_PF][2];
+  auto load_tile = [&](int k0, f32x4 (&a)[2], f32x4 (&b)[2]) {
+    const unsigned kc = (unsigned)wave_uniform(k0 < klast ? k0 : klast);
+    const unsigned ao = kc * a_kstep * 4u, bo = kc * b_kstep * 4u;
+    a[0] = buf_load4(abuf, aoff0 + ao);
+    a[1] = buf_load4(abuf, aoff1 + ao);
+    b[0] = buf_load4(bbuf, boff0 + bo);
+    b[1] = buf_load4(bbuf, boff1 + bo);
+  };
+  // split + store; contraction indices >= kend are zeroed (only the slab's last block and the zero blocks behind it)
+  auto stage = [&](const int MODE, unsigned short* hi, const int mn, const int kk, const int k0, const f32x4 (&r)[2]) {
+    const bool whole = wave_uniform(k0 + GB_BK <= kend ? 1 : 0) != 0;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = r[i >> 2][i & 3];
+    if (!whole) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int k = MODE == GEMM_KC ? kk + i : kk + (i >> 2);
+        x[i] = k0 + k < kend ? x[i] : 0.0f;
+      }
+    }
+    unsigned short* lo = hi + GX3_IMG;
+    if (MODE == GEMM_KC) {
+      const u16x8 h = bf16_pack8(x);
+      float e[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) e[i] = x[i] - __builtin_bit_cast(float, (unsigned)h[i] << 16);
+      const int o = mn * 32 + (((kk >> 3) ^ gb2_sw(mn)) << 3);
+      *reinterpret_cast<u16x8*>(hi + o) = h;
+      *reinterpret_cast<u16x8*>(lo + o) = bf16_pack8(e);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {   // column mn + i: the pair (k, k+1)
+        const unsigned h = bf16_pack2(x[i], x[4 + i]);
+        const float e0 = x[i] - __builtin_bit_cast(float, h << 16), e1 = x[4 + i] - __builtin_bit_cast(float, h & 0xffff0000u);
+        const int o = (mn + i) * 32 + ((((kk >> 3) ^ gb2_sw(mn + i)) << 3) | (kk & 7));
+        *reinterpret_cast<unsigned*>(hi + o) = h;
+        *reinterpret_cast<unsigned*>(lo + o) = bf16_pack2(e0, e1);
+      }
+    }
+  };
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+
+#pragma unroll
+  for (int p = 0; p < GB_PF; p++) {
+    load_tile(kbeg + p * GB_BK, ra[p], rb[p]);
+    SCHED_FENCE();
+  }
+  stage(AMODE, img, a_mn, a_k, kbeg, ra[0]);
+  stage(BMODE, img + 2 * GX3_IMG, b_mn, b_k, kbeg, rb[0]);
+  load_tile(kbeg + GB_PF * GB_BK, ra[0], rb[0]);
+  SCHED_FENCE();
+  __syncthreads();
+  const int fk = lane >> 4, fi = lane & 15;
+  const int fofs = fi * 32 + ((fk ^ gb2_sw(fi)) << 3);
+  int cur = 0;
+  for (int kb = kbeg; kb < kend; kb += GB_PF * GB_BK) {
+#pragma unroll
+    for (int p = 0; p < GB_PF; p++) {
+      static_assert(GB_PF == 3, "register ring of three blocks");
+      const int k0 = kb + p * GB_BK;
+      const int pn = p == 2 ? 0 : p + 1;
+      unsigned short* nb = img + (cur ^ 1) * 4 * GX3_IMG;
+      stage(AMODE, nb, a_mn, a_k, k0 + GB_BK, ra[pn]);
+      stage(BMODE, nb + 2 * GX3_IMG, b_mn, b_k, k0 + GB_BK, rb[pn]);
+      load_tile(k0 + GB_BK + GB_PF * GB_BK, ra[pn], rb[pn]);
+      SCHED_FENCE();
+      const unsigned short* b0 = img + cur * 4 * GX3_IMG;
+      u16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        ah[i] = *reinterpret_cast<const u16x8*>(b0 + (wm * 32 + i * 16) * 32 + fofs);
+        al[i] = *reinterpret_cast<const u16x8*>(b0 + GX3_IMG + (wm * 32 + i * 16) * 32 + fofs);
+        bh[i] = *reinterpret_cast<const u16x8*>(b0 + 2 * GX3_IMG + (wn * 32 + i * 16) * 32 + fofs);
+        bl[i] = *reinterpret_cast<const u16x8*>(b0 + 3 * GX3_IMG + (wn * 32 + i * 16) * 32 + fofs);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = mfma16x16x32_bf16(al[i], bh[j], acc[i][j]);
+          acc[i][j] = mfma16x16x32_bf16(ah[i], bl[j], acc[i][j]);
+          acc[i][j] = mfma16x16x32_bf16(ah[i], bh[j], acc[i][j]);
+        }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  if (fe.vec4()) {   // epilogue through LDS, as gemm_f32_body
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          smem[(wm * 32 + i * 16 + (lane >> 4) * 4 + q) * GEMM_LDO + wn * 32 + j * 16 + (lane & 15)] = acc[i][j][q];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int rl = it * 16 + (tid >> 4), cl = (tid & 15) * 4;
+      const int r = r0 + rl, c = c0 + cl;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&smem[rl * GEMM_LDO + cl]);
+      if (r < R) {
+        if (c + 3 < Cn) fe.row4(r, c, v, z);
+        else
+          for (int e = 0; e < 4; e++)
+            if (c + e < Cn) fe(r, c + e, v[e], z);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = r0 + wm * 32 + i * 16 + (lane >> 4) * 4 + q;
+        const int c = c0 + wn * 32 + j * 16 + (lane & 15);
+        if (r < R && c < Cn) fe(r, c, acc[i][j][q], z);
+      }
+}
+
+template <int AMODE, int BMODE, class FE>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int ksplit,
+                                                      int nsplit) {
+  __shared__ __attribute__((aligned(16))) float smem[GX3_SMEM_FLOATS];
+  gemm_x3_body<AMODE, BMODE, FE>(smem, A, B, fe, R, Cn, K, ksplit, nsplit,
+                                 blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z);
+}
+template <int A1, int B1, class FE1, int A2, int B2, class FE2>
+__global__ __launch_bounds__(256) void gemm_x3_pair_kernel(GemmProblem p1, FE1 fe1, GemmProblem p2, FE2 fe2, unsigned nb1) {
+  __shared__ __attribute__((aligned(16))) float smem[GX3_SMEM_FLOATS];
+  if (blockIdx.x < nb1)
+    gemm_x3_body<A1, B1, FE1>(smem, p1.A, p1.B, fe1, p1.R, p1.Cn, p1.K, p1.ksplit, p1.nsplit, blockIdx.x, p1.gx, p1.gy, p1.gz);
+  else
+    gemm_x3_body<A2, B2, FE2>(smem, p2.A, p2.B, fe2, p2.R, p2.Cn, p2.K, p2.ksplit, p2.nsplit, blockIdx.x - nb1, p2.gx, p2.gy, p2.gz);
+}
+// launchers with the signatures of gemm_f32 / gemm_f32_pair (KC operands are read 8 floats at a time: same slack rule
+// as gemm_bf16)
+template <int AMODE, int BMODE, class FE>
+inline void gemm_x3(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1) {
+  if (R <= 0 || Cn <= 0) return;
+  const GemmProblem p = gemm_problem(A, B, R, Cn, K, nsplit, nbatch);
+  CLSTM_LAUNCH((gemm_x3_kernel<AMODE, BMODE, FE>), dim3(p.gx, p.gy, p.gz), dim3(256), 0, stream, A, B, fe, R, Cn, K, p.ksplit, p.nsplit);
+}
+template <int A1, int B1, class FE1, int A2, int B2, class FE2>
+inline void gemm_x3_pair(hipStream_t stream, GemmProblem p1, FE1 fe1, GemmProblem p2, FE2 fe2) {
+  const unsigned nb1 = p1.gx * p1.gy * p1.gz, nb2 = p2.gx * p2.gy * p2.gz;
+  CLSTM_LAUNCH((gemm_x3_pair_kernel<A1, B1, FE1, A2, B2, FE2>), dim3(nb1 + nb2), dim3(256), 0, stream, p1, fe1, p2, fe2, nb1);
+}
+
 // shapes that fill 128 x 128 tiles reasonably (CLSTM_GEMM_BIG=0: always the 64 x 64 kernel)
 inline bool gemm_bf16_big(int R, int Cn) {
   static const bool on = !(getenv("CLSTM_GEMM_BIG") && atoi(getenv("CLSTM_GEMM_BIG")) == 0);

@@ -44,6 +44,26 @@ def test_gemm_modes(backend, mode, R, Cn, K, ns):
     assert (np.abs(got - want) <= 2e-6 * scale + 1e-6).all()
 
 
+@pytest.mark.parametrize("mode", [20, 21, 22])
+@pytest.mark.parametrize("R,Cn,K,ns", [(64, 64, 32, 1), (70, 45, 37, 1), (149, 400, 333, 5), (5, 3, 2, 1), (130, 83, 200, 3),
+                                       (200, 83, 49, 1), (97, 200, 1000, 2)])
+def test_gemm_x3_modes(backend, mode, R, Cn, K, ns):
+    """f32-grade GEMM on the bf16 MFMA (operands split hi + lo, three products; gemm_bf16.h gemm_x3_body): against the
+    float64 product of the f32 inputs, within 1e-5 of sum |a||b| (the f32 MFMA kernel is held to 2e-6)."""
+    rng = np.random.default_rng(R * 1000 + Cn + 3)
+    A = rng.normal(size=(R, K)).astype(np.float32)
+    B = rng.normal(size=(K, Cn)).astype(np.float32)
+    want = A.astype(np.float64) @ B.astype(np.float64)
+    Ad = backend.up(A if mode < 22 else A.T)
+    Bd = backend.up(B if mode != 21 else B.T)
+    Cd = backend.zeros((R, Cn))
+    backend.lib.call("clstm_debug_gemm", mode, ptr(Ad), ptr(Bd), ptr(Cd), R, Cn, K, ns if mode >= 22 else 1)
+    got = backend.down(Cd)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    err = np.abs(got - want) / (scale + 1e-30)
+    assert (np.abs(got - want) <= 1e-5 * scale + 1e-6).all(), float(err.max())
+
+
 @pytest.mark.parametrize("mode", [10, 11, 12])
 @pytest.mark.parametrize("R,Cn,K,ns", [(64, 64, 32, 1), (70, 45, 37, 1), (149, 400, 333, 5), (5, 3, 2, 1),
                                        (130, 83, 200, 3),
