@@ -742,6 +742,12 @@ struct Net {
       else if (gemm_x3_fwd)
         gemm_x3<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N, layer_input_slack(l)),
                                   gemm_mc(y.Wt, M, y.ni, y.wt_slack), StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
+      else if (y.ni <= 64 && gemm_single_pass)
+        // (experiment, CLSTM_GEMM_SINGLE=1) the whole contraction (1 + 48 input rows of an OCR line image) in ONE 64-k
+        // block: one staging pass and one barrier pair per workgroup instead of six phases of 16 -- slower, nothing
+        // overlaps the one round of loads
+        gemm_f32<GEMM_KC, GEMM_MC, StoreBias, 64, 1>(s, gemm_kc(layer_input(l), layer_input_ld(l), N), gemm_mc(y.Wt, M, y.ni, 0),
+                                                    StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
       else
         gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N), gemm_mc(y.Wt, M, y.ni, 0),
                                    StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
@@ -790,6 +796,7 @@ struct Net {
   int dw_x3 = getenv("CLSTM_DW_X3") ? atoi(getenv("CLSTM_DW_X3")) : 1;
   // the short hoisted products of the f32 path (W_x, softmax W.d / x.d) the same way (gemm_x3, gemm_bf16.h); CLSTM_GEMM_X3=0: f32 MFMA
   bool gemm_x3_on = !(getenv("CLSTM_GEMM_X3") && atoi(getenv("CLSTM_GEMM_X3")) == 0);
+  bool gemm_single_pass = getenv("CLSTM_GEMM_SINGLE") && atoi(getenv("CLSTM_GEMM_SINGLE")) != 0;   // measured slower: 26.4 vs 22.2 us
   // NOT the forward product W_x.x (CLSTM_GEMM_X3=2 for experiments): its ~2^-17 relative error per product shows up in
   // gate pre-activations that cancel to ~0 (a tanh gate at -0.0021 came out 5.6e-6 off where the parity bar allows
   // 2.2e-6), and with K = 49 the split costs more staging than it saves MFMA time (28.5 vs 20.9 us)

@@ -50,7 +50,7 @@ struct GemmOperand {
 // BK: contraction indices staged per barrier pair (16 or 32).  32 halves the barriers and LDS hand-overs per flop --
 // it pays where the k loop is long (the split-K weight-gradient GEMMs: K = frames of a slab) and costs registers
 // (two staging quadruples per operand and tile in flight) and LDS (2 x 32 x 80 floats).
-template <int AMODE, int BMODE, class FE, int BK = GEMM_BK>
+template <int AMODE, int BMODE, class FE, int BK = GEMM_BK, int PF = GEMM_PF>
 DEVFN void gemm_f32_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int ksplit, int nsplit,
                          const unsigned lin, const unsigned gx, const unsigned gy, const unsigned gz) {
   constexpr int NP = BK / 16;   // staging passes of 16 contraction indices
@@ -128,16 +128,16 @@ DEVFN void gemm_f32_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R
   // GEMM_PF k-tiles are in flight in registers: a tile's global loads are issued GEMM_PF iterations
   // before it is staged, which covers the ~2000-cycle HBM latency with MFMA work of the same workgroup
   // (the grids here are only 1-3 workgroups per CU, so there is little inter-workgroup overlap to lean on)
-  f32x4 ra[GEMM_PF][NP], rb[GEMM_PF][NP];
+  f32x4 ra[PF][NP], rb[PF][NP];
 #pragma unroll
-  for (int p = 0; p < GEMM_PF; p++) {
+  for (int p = 0; p < PF; p++) {
     load_tile(kbeg + p * BK, ra[p], rb[p]);
     SCHED_FENCE();   // same issue order as inside the loop, so the vmcnt at the loop head stays exact
   }
   const int fk = lane >> 4, fi = lane & 15;
-  for (int kb = kbeg; kb < kend; kb += GEMM_PF * BK) {
+  for (int kb = kbeg; kb < kend; kb += PF * BK) {
 #pragma unroll
-    for (int p = 0; p < GEMM_PF; p++) {
+    for (int p = 0; p < PF; p++) {
       const int k0 = kb + p * BK;   // phases past the slab multiply zeros (no early exit: the
                                     // straight-line body keeps the accumulators and vmcnt exact)
       mask_tile(k0, ra[p], rb[p]);
@@ -157,10 +157,11 @@ DEVFN void gemm_f32_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R
         }
       }
       __syncthreads();
-      load_tile(k0 + GEMM_PF * BK, ra[p], rb[p]);
+      if (PF > 1 || K > BK) load_tile(k0 + PF * BK, ra[p], rb[p]);
       SCHED_FENCE();
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 4) {
+        if (PF == 1 && kk > 0 && wave_uniform(k0 + kk >= kend ? 1 : 0)) break;   // single-pass form: stop at the last k-step
         float af[2], bf[2];
 #pragma unroll
         for (int i = 0; i < 2; i++) {
@@ -216,11 +217,11 @@ DEVFN void gemm_f32_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R
 }
 
 constexpr int gemm_smem_floats(int bk) { return 2 * bk * GEMM_LD > GEMM_BT * GEMM_LDO ? 2 * bk * GEMM_LD : GEMM_BT * GEMM_LDO; }
-template <int AMODE, int BMODE, class FE, int BK = GEMM_BK>
+template <int AMODE, int BMODE, class FE, int BK = GEMM_BK, int PF = GEMM_PF>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
                                                        int K, int ksplit, int nsplit) {
   __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats(BK)];
-  gemm_f32_body<AMODE, BMODE, FE, BK>(smem, A, B, fe, R, Cn, K, ksplit, nsplit,
+  gemm_f32_body<AMODE, BMODE, FE, BK, PF>(smem, A, B, fe, R, Cn, K, ksplit, nsplit,
                                   blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y,
                                   gridDim.z);
 }
@@ -271,17 +272,17 @@ inline void gemm_f32_pair(hipStream_t stream, GemmProblem p1, FE1 fe1, GemmProbl
   const unsigned nb1 = p1.gx * p1.gy * p1.gz, nb2 = p2.gx * p2.gy * p2.gz;
   CLSTM_LAUNCH((gemm_f32_pair_kernel<A1, B1, FE1, A2, B2, FE2>), dim3(nb1 + nb2), dim3(256), 0, stream, p1, fe1, p2, fe2, nb1);
 }
-template <int AMODE, int BMODE, class FE, int BK = GEMM_BK>
+template <int AMODE, int BMODE, class FE, int BK = GEMM_BK, int PF = GEMM_PF>
 inline void gemm_f32(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int nsplit = 1,
                      int nbatch = 1) {
   if (R <= 0 || Cn <= 0) return;
   if (nsplit < 1) nsplit = 1;
   int ksplit = (K + nsplit - 1) / nsplit;
-  const int kq = nsplit > 1 ? GEMM_PF * BK : BK;   // whole pipeline rounds per slab
+  const int kq = nsplit > 1 ? PF * BK : BK;   // whole pipeline rounds per slab
   ksplit = ((ksplit + kq - 1) / kq) * kq;
   if (ksplit < kq) ksplit = kq;
   dim3 grid((Cn + GEMM_BT - 1) / GEMM_BT, (R + GEMM_BT - 1) / GEMM_BT, nsplit * nbatch);
-  CLSTM_LAUNCH((gemm_f32_kernel<AMODE, BMODE, FE, BK>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+  CLSTM_LAUNCH((gemm_f32_kernel<AMODE, BMODE, FE, BK, PF>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
 }
 
 }  // namespace clstm
