@@ -540,6 +540,11 @@ struct Net {
   DevBuf<long long> dw_trace;
   DevBuf<int> dw_ktab, dw_slabs, dw_timeouts, dw_queue;   // dw_queue: [8] queue heads | [8 * 256] CU marks
   std::vector<int> dw_key;        // line offsets the tables were built for
+  // the softmax layer's W.d as independent items of the top layer's fused backward launch (gemm_dw.h, GemmDwArgs::x*)
+  DevBuf<int> dwx_tab;            // [entries][2] contiguous 16-frame entries | slabs
+  long long dwx_N = -1;
+  int dwx_nslabs = 0, dwx_entries = 0;
+  bool dwx_active = false;        // this backward pass: the top layer's launch carries them
   int dw_nslabs = 0, dw_slabs_per_dir = 0, dw_ntiles_max = 0;
   int prog_base = 1024;           // grows with every backward launch: stale progress words never look complete
   long long dw_launches = 0;      // overlapped backward passes so far (tests check the path was taken)
@@ -963,10 +968,20 @@ struct Net {
     g.minprog = dw_queue.p + 8 + 8 * 256 + 8 + PROG_STRIDE - ((8 + 8 * 256 + 8) % PROG_STRIDE);   // own 128-byte lines
     g.tcap = tmax + 32;
     g.x3 = dw_x3;
+    unsigned nextra = 0;
+    if (dwx_active && &y == &L.back()) {
+      const int xR = 1 + sm_ni, xCn = desc.nclasses;
+      g.xS = y.srow(); g.xlds = y.ldh; g.xs_elems = (long long)N * y.ldh + 3;
+      g.xD = Dz.p; g.xM = xCn; g.xd_elems = (long long)N * xCn + 3;
+      g.xtab = dwx_tab.p; g.xslabs = (const DwSlab*)(dwx_tab.p + 2 * dwx_entries); g.xnslabs = dwx_nslabs;
+      g.xpartial = partial_sm.p; g.xR = xR; g.xCn = xCn;
+      g.xgx = (unsigned)((xCn + GEMM_BT - 1) / GEMM_BT); g.xgy = (unsigned)((xR + GEMM_BT - 1) / GEMM_BT);
+      nextra = (unsigned)dwx_nslabs * g.xgx * g.xgy;
+    }
     static const char* trace_path = getenv("CLSTM_DW_TRACE");   // diagnostics: wall-clock stamps of every workgroup of the fused launch
     const size_t trace_rows = (size_t)bs * ndir + (size_t)((dw_nslabs + 7) / 8) * 8 * g.gx * g.gy + 8;
     if (trace_path) { dw_trace.reserve(trace_rows * 4); g.trace = dw_trace.p; g.trace_base = bs * ndir; }
-    const unsigned nblk = 1u + (unsigned)((dw_nslabs + 7) / 8) * 8u * g.gx * g.gy;   // the monitor + one per item
+    const unsigned nblk = 1u + nextra + (unsigned)((dw_nslabs + 7) / 8) * 8u * g.gx * g.gy;   // the monitor + the independent items + one per item
 #ifndef CLSTM_HIP_EMU
     if (overlap != 3 && y.nthreads >= 256) {   // ONE launch: the recurrence's workgroups first, the GEMM's behind them
       timing.begin("lstm_bwd", s);
@@ -1027,12 +1042,37 @@ struct Net {
     Layer& top = L.back();
     {  // (a side stream for this GEMM was measured on MI355X: no gain -- the recurrence workgroups it would
        // overlap with slow down by as much -- so everything stays on one stream)
-      const int R = 1 + sm_ni, Cn = nc, ns = pick_split(R, Cn);
+      const int R = 1 + sm_ni, Cn = nc;
+      int ns = pick_split(R, Cn);
+      // W.d depends on nothing the backward recurrence produces: when the top layer's backward runs as the fused launch
+      // (lstm_bwd_dw.h) its slabs are items of THAT launch -- they execute on the idle half of the chip during the ~14 us
+      // before the recurrence's first chunk is released -- and only x.d stays in front of the recurrence.
+      static const bool dwx_on = !(getenv("CLSTM_DW_EXTRA") && atoi(getenv("CLSTM_DW_EXTRA")) == 0);
+      static const bool dwx_workers = getenv("CLSTM_DW_WORKERS") && atoi(getenv("CLSTM_DW_WORKERS")) != 0;
+      dwx_active = dwx_on && !dwx_workers && !bf16_gemm && (dw_x3 & 1) && overlap_eligible(top);
+      if (dwx_active) {
+        if (dwx_N != N) {   // contiguous frames: entries of 16, slabs of 32 entries (512 frames: one short item each)
+          dwx_entries = (int)((N + 15) / 16);
+          dwx_nslabs = (dwx_entries + 31) / 32;
+          const size_t nsw = (size_t)dwx_nslabs * sizeof(DwSlab) / sizeof(int);
+          dwx_tab.reserve((size_t)2 * dwx_entries + nsw + 8);
+          int* stage = (int*)ring.acquire(((size_t)2 * dwx_entries + nsw) * sizeof(int));
+          for (int e = 0; e < dwx_entries; e++) { stage[2 * e] = 16 * e; stage[2 * e + 1] = (int)std::min<long long>(16, N - 16LL * e); }
+          DwSlab* sl = (DwSlab*)(stage + 2 * dwx_entries);
+          for (int i = 0; i < dwx_nslabs; i++) sl[i] = DwSlab{32 * i, std::min(32, dwx_entries - 32 * i), 0, 0, i, {0, 0, 0}};
+          HIPCHECK(hipMemcpyAsync(dwx_tab.p, stage, ((size_t)2 * dwx_entries + nsw) * sizeof(int), hipMemcpyHostToDevice, s));
+          ring.commit(s);
+          dwx_N = N;
+        }
+        ns = dwx_nslabs;
+      }
       partial_sm.reserve((size_t)ns * R * Cn);
       // W.d (split-K slabs) and x.d in ONE launch: two small independent products, each mostly prologue and
       // epilogue latency on its own (13.9 + 12.4 us back to back)
       timing.begin("gemm_softmax_dw_dx", s);
-      if (gemm_x3_on)
+      if (dwx_active)
+        gemm_x3<GEMM_KC, GEMM_KC>(s, gemm_kc(Dz.p, nc, N), gemm_kc(W1 + nc, nc, sm_ni, 0), StorePlain{top.dH.p, sm_ni}, (int)N, sm_ni, nc);
+      else if (gemm_x3_on)
         gemm_x3_pair<GEMM_MC, GEMM_MC, StorePartial, GEMM_KC, GEMM_KC, StorePlain>(
             s, gemm_problem(gemm_mc(top.srow(), top.ldh, N), gemm_mc(Dz.p, nc, N), R, Cn, (int)N, ns),
             StorePartial{partial_sm.p, R, Cn},

@@ -49,6 +49,13 @@ struct GemmDwArgs {
   int tcap;                 // value published once every line is complete (longest line + 32)
   long long* trace;         // diagnostics (CLSTM_DW_TRACE): [workgroup][4] wall-clock stamps -- start, ready, done
   int trace_base;           // first trace row of the GEMM role's workgroups
+  // a second product of the same form that depends on NOTHING in this launch -- the softmax layer's W.d = sum_t z.d_t [1;h_t]^T
+  // (SoftmaxLayer::backward, clstm.cc:411-417): its items come first in dispatch order and run on the idle half of the
+  // chip while the first chunk of the recurrence is still being produced (x3 items only)
+  const float* xS; int xlds; long long xs_elems;   // A': [frame][xlds], row r of the product = column r
+  const float* xD; int xM; long long xd_elems;     // B': [frame][xM]
+  const int* xtab; const DwSlab* xslabs; int xnslabs;   // its k-tile table (contiguous frames) and slabs (need_it = 0)
+  float* xpartial; int xR, xCn; unsigned xgx, xgy;
   int x3;                   // 1: products on the bf16 MFMA with both operands split hi + lo (gemm_dw_item_x3), 0: f32 MFMA
 };
 
@@ -243,32 +250,35 @@ DEVFN void gemm_dw_item(const GemmDwArgs& a, float* smem, const unsigned si, con
 // 32-frame block (two 16-frame table entries), 4 columns each, transposes in registers and writes 4 k of one row per
 // ds_write_b64 into swizzled [mn][32 k] images (gemm_bf16.h: conflict-free fragment reads); images are double-buffered,
 // one barrier per block.
-DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, const unsigned tile) {
+DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, const unsigned tile, const bool extra = false) {
   constexpr int IMG = 64 * 32;                 // halfs per image
   unsigned short* img = reinterpret_cast<unsigned short*>(smem);   // [buffer][A hi | A lo | B hi | B lo][64][32]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const DwSlab sl = a.slabs[si];
-  const int r0 = (int)(tile / a.gx) * GEMM_BT, c0 = (int)(tile % a.gx) * GEMM_BT;
+  const DwSlab sl = extra ? a.xslabs[si] : a.slabs[si];
+  const unsigned pgx = extra ? a.xgx : a.gx;
+  const int pR = extra ? a.xR : a.R, pCn = extra ? a.xCn : a.Cn;
+  const int r0 = (int)(tile / pgx) * GEMM_BT, c0 = (int)(tile % pgx) * GEMM_BT;
   const int dir = sl.dir;
   const long long t_start = a.trace ? wall_clock() : 0;
   // The slab's k-tile table goes to LDS while the item waits.  Read from global memory inside the loop, an entry was a
   // DEPENDENT load in front of every block's operand loads, and VMEM returns in order: waiting for it meant waiting for
   // every operand load still in flight -- one full memory latency per block (measured: 15 us per 16-block item).
-  const int* tab = a.ktab + (size_t)dir * a.ntiles_max * 2;
+  const int* tab = extra ? a.xtab : a.ktab + (size_t)dir * a.ntiles_max * 2;
   int* stab = reinterpret_cast<int*>(smem + 8192);
   for (int i = tid; i < 2 * sl.ntiles && i < 2 * DW_STAB_MAX; i += 256) stab[i] = tab[2 * sl.tile_begin + i];   // (the host keeps slabs <= DW_STAB_MAX entries)
-  if (!(a.x3 & 2)) gemm_dw_wait(a, dir, sl.need_it);
+  if (!(a.x3 & 2) && sl.need_it > 0) gemm_dw_wait(a, dir, sl.need_it);
   else __syncthreads();
   const long long t_ready = a.trace ? wall_clock() : 0;   // (bits 2, 4 of x3: perf experiments -- no wait / no contraction)
 
   const bool isB = wave >= 2;                                      // wave-uniform staging role
   const int s_mn = (wave & 1) * 32 + (lane & 7) * 4, s_kg = lane >> 3;   // 4 columns x frames 4 kg .. 4 kg + 3
-  const BufF32 abuf = make_buf(a.S + (size_t)dir * a.sdir, (size_t)(a.s_elems - (long long)dir * a.sdir) * 4);
-  const BufF32 bbuf = make_buf(a.D, (size_t)a.d_elems * 4);
-  const unsigned col = isB ? (unsigned)(dir * a.no4 + c0 + s_mn) : (unsigned)(r0 + s_mn);
-  const unsigned ldrow = isB ? (unsigned)a.M : (unsigned)a.lds;
+  const BufF32 abuf = extra ? make_buf(a.xS, (size_t)a.xs_elems * 4)
+                            : make_buf(a.S + (size_t)dir * a.sdir, (size_t)(a.s_elems - (long long)dir * a.sdir) * 4);
+  const BufF32 bbuf = extra ? make_buf(a.xD, (size_t)a.xd_elems * 4) : make_buf(a.D, (size_t)a.d_elems * 4);
+  const unsigned col = isB ? (unsigned)((extra ? 0 : dir * a.no4) + c0 + s_mn) : (unsigned)(r0 + s_mn);
+  const unsigned ldrow = isB ? (unsigned)(extra ? a.xM : a.M) : (unsigned)(extra ? a.xlds : a.lds);
   const int tend = (a.x3 & 4) ? sl.tile_begin : sl.tile_begin + sl.ntiles;
   const int e_half = s_kg >> 2, kk0 = (s_kg & 3) * 4;              // table entry of the pair, first frame row within it
 
@@ -372,21 +382,21 @@ DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, 
       for (int q = 0; q < 4; q++)
         smem[(wm * 32 + i * 16 + (lane >> 4) * 4 + q) * GEMM_LDO + wn * 32 + j * 16 + (lane & 15)] = acc[i][j][q];
   __syncthreads();
-  float* out = a.partial + (size_t)sl.out_z * a.R * a.Cn;
-  const bool v4 = (a.Cn & 3) == 0 && ((size_t)a.partial & 15) == 0;
+  float* out = (extra ? a.xpartial : a.partial) + (size_t)sl.out_z * pR * pCn;
+  const bool v4 = (pCn & 3) == 0 && ((size_t)out & 15) == 0;
 #pragma unroll
   for (int it = 0; it < 4; it++) {
     const int rl = it * 16 + (tid >> 4), cl = (tid & 15) * 4;
     const int r = r0 + rl, c = c0 + cl;
     const f32x4 v = *reinterpret_cast<const f32x4*>(&smem[rl * GEMM_LDO + cl]);
-    if (r < a.R) {
-      if (v4 && c + 3 < a.Cn) *reinterpret_cast<f32x4*>(out + (size_t)r * a.Cn + c) = v;
+    if (r < pR) {
+      if (v4 && c + 3 < pCn) *reinterpret_cast<f32x4*>(out + (size_t)r * pCn + c) = v;
       else
         for (int e = 0; e < 4; e++)
-          if (c + e < a.Cn) out[(size_t)r * a.Cn + c + e] = v[e];
+          if (c + e < pCn) out[(size_t)r * pCn + c + e] = v[e];
     }
   }
-  if (a.trace && tid == 0) {
+  if (a.trace && tid == 0 && !extra) {
     long long* tr = a.trace + ((size_t)a.trace_base + si * (a.gx * a.gy) + tile) * 4;
     tr[0] = t_start; tr[1] = t_ready; tr[2] = wall_clock(); tr[3] = sl.need_it;
   }
@@ -398,6 +408,9 @@ DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, 
 DEVFN void gemm_dw_body(const GemmDwArgs& a, float* smem, unsigned block) {
   if (block == 0) { gemm_dw_monitor(a); return; }   // the first workgroup behind the recurrence's watches the lines
   block -= 1;
+  const unsigned nextra = a.x3 ? (unsigned)a.xnslabs * a.xgx * a.xgy : 0u;   // independent items first (see GemmDwArgs)
+  if (block < nextra) { gemm_dw_item_x3(a, smem, block / (a.xgx * a.xgy), block % (a.xgx * a.xgy), true); return; }
+  block -= nextra;
   const unsigned tiles = a.gx * a.gy;
   const unsigned xcd = block & 7u, idx = block >> 3;
   const unsigned si = (idx / tiles) * 8u + xcd;
