@@ -1049,17 +1049,20 @@ struct Net {
       // before the recurrence's first chunk is released -- and only x.d stays in front of the recurrence.
       static const bool dwx_on = !(getenv("CLSTM_DW_EXTRA") && atoi(getenv("CLSTM_DW_EXTRA")) == 0);
       static const bool dwx_workers = getenv("CLSTM_DW_WORKERS") && atoi(getenv("CLSTM_DW_WORKERS")) != 0;
-      dwx_active = dwx_on && !dwx_workers && !bf16_gemm && (dw_x3 & 1) && overlap_eligible(top);
+      // (only while the recurrence leaves CUs idle: with 256 lines the same items cost the fused launch +42 us for 19 saved)
+      dwx_active = dwx_on && !dwx_workers && !bf16_gemm && (dw_x3 & 1) && overlap_eligible(top) &&
+                   (long long)bs * ndir * 4 <= 3LL * device_cu_count();
       if (dwx_active) {
         if (dwx_N != N) {   // contiguous frames: entries of 16, slabs of 32 entries (512 frames: one short item each)
           dwx_entries = (int)((N + 15) / 16);
-          dwx_nslabs = (dwx_entries + 31) / 32;
+          const int eps = std::min(DW_STAB_MAX, std::max(32, (dwx_entries + 63) / 64));   // entries per slab: at most ~64 slabs to reduce
+          dwx_nslabs = (dwx_entries + eps - 1) / eps;
           const size_t nsw = (size_t)dwx_nslabs * sizeof(DwSlab) / sizeof(int);
           dwx_tab.reserve((size_t)2 * dwx_entries + nsw + 8);
           int* stage = (int*)ring.acquire(((size_t)2 * dwx_entries + nsw) * sizeof(int));
           for (int e = 0; e < dwx_entries; e++) { stage[2 * e] = 16 * e; stage[2 * e + 1] = (int)std::min<long long>(16, N - 16LL * e); }
           DwSlab* sl = (DwSlab*)(stage + 2 * dwx_entries);
-          for (int i = 0; i < dwx_nslabs; i++) sl[i] = DwSlab{32 * i, std::min(32, dwx_entries - 32 * i), 0, 0, i, {0, 0, 0}};
+          for (int i = 0; i < dwx_nslabs; i++) sl[i] = DwSlab{eps * i, std::min(eps, dwx_entries - eps * i), 0, 0, i, {0, 0, 0}};
           HIPCHECK(hipMemcpyAsync(dwx_tab.p, stage, ((size_t)2 * dwx_entries + nsw) * sizeof(int), hipMemcpyHostToDevice, s));
           ring.commit(s);
           dwx_N = N;
