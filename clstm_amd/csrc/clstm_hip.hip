@@ -1486,7 +1486,9 @@ static void net_set_inputs_d(clstm_net* h, const float* x, const CtcMetaCopy* au
     const int M = n.ndir * 4 * y.no, KQP = 4 * y.nk4;
     const size_t nr = (size_t)n.ndir * 4 * KQP * y.nthreads;
     const int nbi = nblocks((size_t)n.N * (1 + y.ni)), nbp = nblocks((size_t)(1 + y.ni) * M + 2 * nr);
-    const bool lo = n.lo_pending, ax = aux && aux->nwords > 0;
+    static const bool host_reads = !(getenv("CLSTM_INGEST_HOST") && atoi(getenv("CLSTM_INGEST_HOST")) == 0);   // experiment: DMA copies instead
+    if (!host_reads) n.flush_line_off();
+    const bool lo = n.lo_pending, ax = host_reads && aux && aux->nwords > 0;
     // optional trailing blocks read small host arrays straight from their pinned slots: the line offsets and -- in a
     // training step -- the CTC metadata (no DMA launches, no event records on the stream's critical path)
     CLSTM_LAUNCH(k_ingest_pack, dim3(nbi + nbp + (lo ? 1 : 0) + (ax ? (aux->nwords + 255) / 256 : 0)), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni, y.lds,
