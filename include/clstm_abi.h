@@ -195,7 +195,10 @@ int clstm_net_get_state_h(clstm_net* net, int layer, int dir, int which, float* 
  * mode 0: off (GEMM after the recurrence); 1 (default): both as two workgroup roles of ONE launch
  * (csrc/lstm_bwd_dw.h) for batches large enough to profit; 2: the same always (tests); 3: two launches on streams
  * with complementary CU masks (measured slower than mode 0, kept for the record).  Results are the same sums in a
- * different slab order.  stats: overlapped backward passes so far; slabs that gave up waiting for the recurrence
+ * different slab order; in modes 1-3 the products run on the bf16 MFMA with both f32 operands split hi + lo (three
+ * products per term, f32 accumulation: error per product < 2^-16, i.e. the sum is as close to the exact one as an
+ * f32 fmaf chain; environment CLSTM_DW_X3=0 selects the f32 MFMA), and the top layer's launch also computes the softmax
+ * layer's W.d.  stats: overlapped backward passes so far; slabs that gave up waiting for the recurrence
  * (must stay 0). */
 int clstm_net_set_overlap(clstm_net* net, int mode);
 int clstm_net_overlap_stats(clstm_net* net, long long* launches, int* timeouts);
