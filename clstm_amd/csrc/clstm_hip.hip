@@ -537,6 +537,7 @@ struct Net {
     hipEvent_t fork{}, rec_done{}, side_done{};
     bool tried = false, ok = false;
   } os;
+  unsigned dw_done_total = 0;     // recurrence workgroups launched so far through the fused launch (GemmDwArgs::done)
   DevBuf<long long> dw_trace;
   DevBuf<int> dw_ktab, dw_slabs, dw_timeouts, dw_queue;   // dw_queue: [8] queue heads | [8 * 256] CU marks
   std::vector<int> dw_key;        // line offsets the tables were built for
@@ -967,6 +968,7 @@ struct Net {
     g.qhead = dw_queue.p; g.cu_busy = dw_queue.p + 8; g.ndir = ndir;
     g.minprog = dw_queue.p + 8 + 8 * 256 + 8 + PROG_STRIDE - ((8 + 8 * 256 + 8) % PROG_STRIDE);   // own 128-byte lines
     g.tcap = tmax + 32;
+    g.done = nullptr; g.done_target = 0;
     g.x3 = dw_x3;
     unsigned nextra = 0;
     if (dwx_active && &y == &L.back()) {
@@ -991,6 +993,9 @@ struct Net {
       // workgroup slot per worker leaves room for only two workers on an idle CU
       static const int workers = getenv("CLSTM_DW_WORKERS") ? atoi(getenv("CLSTM_DW_WORKERS")) : 0;
       const unsigned nworkers = workers ? (unsigned)std::min<long long>((long long)nblk, workers > 1 ? workers : 512) : nblk;
+      g.done = g.minprog + 2 * PROG_STRIDE;   // own 128-byte line behind the monitor's words; zero-filled once, then only added to
+      dw_done_total += (unsigned)(bs * ndir);
+      g.done_target = (int)dw_done_total;
       REQUIRE(launch_lstm_bwd_dw(y.nk4, y.pd.ku, a, g, bs * ndir, nworkers, y.nthreads, s, workers), "internal: no fused instantiation");
       timing.end(s);
       if (trace_path) {

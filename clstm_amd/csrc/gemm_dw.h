@@ -47,6 +47,8 @@ struct GemmDwArgs {
   int* minprog;             // [ndir] (PROG_STRIDE apart): prog_base + iterations EVERY line of that direction has completed,
                             //   published by the monitor workgroup (gemm_dw_monitor); what the items poll
   int tcap;                 // value published once every line is complete (longest line + 32)
+  int* done;                // += 1 by every recurrence workgroup when its line is complete and its stores have landed
+  int done_target;          //   value of *done when ALL of this launch's lines are complete (the counter is never reset)
   long long* trace;         // diagnostics (CLSTM_DW_TRACE): [workgroup][4] wall-clock stamps -- start, ready, done
   int trace_base;           // first trace row of the GEMM role's workgroups
   // a second product of the same form that depends on NOTHING in this launch -- the softmax layer's W.d = sum_t z.d_t [1;h_t]^T
@@ -121,9 +123,14 @@ DEVFN void gemm_dw_wait(const GemmDwArgs& a, const int dir, const int need_it) {
   const int wave = wave_uniform(threadIdx.x >> 6);
   if (wave == 0) {
     const int need = need_it < a.tcap ? need_it : a.tcap;
+    // the last chunk (every iteration of every line) is released by the recurrence workgroups themselves: one counter,
+    // no monitor hop (its look + publish + our poll cost ~2.5 us exactly where the launch's tail is)
+    const bool all = a.done && need_it >= a.tcap - 32;
     int polls = 0;
     for (;;) {
-      const int have = wave_uniform(load_i32_wt(a.minprog + dir * PROG_STRIDE) - a.prog_base);
+      int have;
+      if (all) have = (int)((unsigned)wave_uniform(load_i32_wt(a.done)) - (unsigned)a.done_target) >= 0 ? need : need - 1;
+      else have = wave_uniform(load_i32_wt(a.minprog + dir * PROG_STRIDE) - a.prog_base);
       if (have >= need) break;
       if (++polls > (DW_WATCHDOG_POLLS << 4)) {   // the monitor never showed up
         if ((threadIdx.x & 63) == 0) atomic_add_i32(a.timeouts, 1);

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_dw
     const long long t0 = g.trace ? wall_clock() : 0;
     const int bl = (int)blockIdx.x % a.bs;
     lstm_bwd_body<NK4, KU>(a, a.order ? a.order[bl] : bl, (int)blockIdx.x / a.bs);
+    if (g.done && threadIdx.x == 0) atomic_add_i32(g.done, 1);   // (the body ended with drain + barrier: this line's deltas are in memory)
     if (g.trace && threadIdx.x == 0) { g.trace[blockIdx.x * 4] = t0; g.trace[blockIdx.x * 4 + 2] = wall_clock(); }
   } else {
     if (threadIdx.x >= 256) return;   // the GEMM role is four waves; the others retire (a barrier counts live waves only)
