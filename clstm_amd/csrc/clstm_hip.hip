@@ -303,6 +303,54 @@ static void launch_steps(StepGraphCache& cache, int kind, const A& a, int tmax, 
 #endif
   body();
 }
+// Outcome of the persistent (one launch per pass) recurrence kernels.  The first launches of a process are checked
+// synchronously -- a failed placement check (error word 1: nothing written) falls back to the per-step launches for
+// good.  Later launches copy their error word into a pinned ring and are checked when the slot comes round again or at
+// the next host read-back: the host keeps enqueueing ahead of the GPU (four stream synchronisations per minibatch cost
+// ~0.1 ms of idle GPU at the configs[4] shape).
+struct XcdOutcome {
+  static const int SLOTS = 16;
+  int* pinned = nullptr;
+  hipEvent_t ev[SLOTS] = {};
+  bool pending[SLOTS] = {};
+  int next = 0, verified = 0;
+  void check_slot(int i) {
+    if (!pending[i]) return;
+    HIPCHECK(hipEventSynchronize(ev[i]));
+    pending[i] = false;
+    if (pinned[i] != 0)
+      throw Error(pinned[i] == 1 ? "persistent recurrence: workgroups were not spread evenly over the XCDs in a later launch; results since then are invalid -- set CLSTM_XCD_REC=0"
+                                 : "persistent recurrence: a group barrier timed out in the middle of the sequence; set CLSTM_XCD_REC=0");
+  }
+  void check_all() { for (int i = 0; i < SLOTS; i++) check_slot(i); }
+  // returns false if the launch failed its placement check and nothing was written (synchronous phase only)
+  bool after_launch(const int* err_d, hipStream_t s) {
+#ifdef CLSTM_HIP_EMU
+    if (*err_d == 2) throw Error("persistent recurrence: group barrier timed out");
+    return *err_d == 0;
+#else
+    if (verified < 4) {
+      int flag = 0;
+      HIPCHECK(hipMemcpyAsync(&flag, err_d, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      if (flag == 0) { verified++; return true; }
+      if (flag != 1) throw Error("persistent recurrence: a group barrier timed out in the middle of the sequence; set CLSTM_XCD_REC=0");
+      return false;
+    }
+    if (!pinned) HIPCHECK(hipHostMalloc((void**)&pinned, SLOTS * sizeof(int)));
+    const int i = next;
+    next = (next + 1) % SLOTS;
+    check_slot(i);
+    if (!ev[i]) HIPCHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    HIPCHECK(hipMemcpyAsync(pinned + i, err_d, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipEventRecord(ev[i], s));
+    pending[i] = true;
+    return true;
+#endif
+  }
+};
+static XcdOutcome g_xcd_outcome;
+
 static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s, bool bf16 = false) {
   REQUIRE((double)a.N * a.ndir * 4 * a.no * 4 < 2147483000.0,
           "minibatch too large for the lock-step recurrence (frames x 4 x nhidden x ndir x 4 B must stay below 2 GiB)");
@@ -327,6 +375,21 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       check_launch();
       check_coop(sync, s);
       return;
+    }
+    // bf16 operands: ONE launch, a workgroup group per XCD with its weight rows resident in LDS (lstm_xcd_fwd_bf16)
+    static const bool xcd_on = !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
+    static bool xcd_failed = false;   // the placement check failed once on this device: per-step launches from then on
+    const int ntile = (no + 15) / 16;
+    if (bf16 && xcd_on && !xcd_failed && tmax > 1 && a.ndir * nzb <= 8 && ntile <= 32 && a.kp16 <= 512 && 8 * ntile <= std::max(ncu, 16)) {
+      sync.reserve(XcdSyncLayout::WORDS);
+      a.sync = sync.p;
+      HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+      const size_t smem = (size_t)xcd_fwd_lds_bytes();
+      coop_set_smem(lstm_xcd_fwd_bf16, smem);
+      CLSTM_LAUNCH_COOP(lstm_xcd_fwd_bf16, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+      check_launch();
+      if (g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s)) return;
+      xcd_failed = true;   // workgroups were not spread evenly over the XCDs; nothing was written: run the per-step path
     }
     const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mt - 1) / (16 * mt));
     const dim3 grid16(((no + 15) / 16) * a.ndir * ((a.bs + 15) / 16));
@@ -353,6 +416,20 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       check_launch();
       check_coop(sync, s);
       return;
+    }
+    static const bool xcd_on = !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
+    static bool xcd_failed = false;
+    const int ntile = (no + 15) / 16;
+    if (bf16 && xcd_on && !xcd_failed && tmax > 1 && a.ndir * nzb <= 8 && ntile <= 32 && a.kp16 <= 2048 && 8 * ntile <= std::max(ncu, 16)) {
+      sync.reserve(XcdSyncLayout::WORDS);
+      a.sync = sync.p;
+      HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+      const size_t smem = (size_t)xcd_bwd_lds_bytes();
+      coop_set_smem(lstm_xcd_bwd_bf16, smem);
+      CLSTM_LAUNCH_COOP(lstm_xcd_bwd_bf16, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+      check_launch();
+      if (g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s)) return;
+      xcd_failed = true;
     }
     const dim3 grid((no + 15) / 16, a.ndir, nzb);
     const dim3 grid16(((no + 15) / 16) * a.ndir * nzb);
@@ -1304,7 +1381,7 @@ extern "C" {
 const char* clstm_last_error(void) { return g_err.c_str(); }
 int clstm_abi_version(void) { return 1; }
 int clstm_set_stream(void* s) { g_stream = (hipStream_t)s; return 0; }
-int clstm_synchronize(void) { ABI_BEGIN HIPCHECK(hipStreamSynchronize(g_stream)); ABI_END }
+int clstm_synchronize(void) { ABI_BEGIN HIPCHECK(hipStreamSynchronize(g_stream)); g_xcd_outcome.check_all(); ABI_END }
 
 // ---- per-op entry points -------------------------------------------------------------------------
 int clstm_forward_nonlin0(float* y, int len, int nl) { ABI_BEGIN EW(k_forward_nonlin0, len, y, (size_t)len, nl) ABI_END }
@@ -1463,6 +1540,7 @@ static void copy_h2d(float* dst, const float* src, size_t n) {
 static void copy_d2h(float* dst, const float* src, size_t n) {
   HIPCHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, g_stream));
   HIPCHECK(hipStreamSynchronize(g_stream));
+  g_xcd_outcome.check_all();   // whatever is read back was produced by launches whose outcome is known now
 }
 int clstm_net_set_params_h(clstm_net* h, const float* p) { ABI_BEGIN copy_h2d(h->net.v, p, h->net.nparams); h->net.packed_dirty = true; ABI_END }
 int clstm_net_get_params_h(clstm_net* h, float* p) { ABI_BEGIN copy_d2h(p, h->net.v, h->net.nparams); ABI_END }

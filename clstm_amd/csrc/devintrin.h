@@ -251,6 +251,7 @@ DEVFN int hw_cu_slot() {
   return (hw_xcc_id() & 7) * 256 + (int)((hw >> 8) & 0xFF);
 }
 DEVFN void sleep_some() { __builtin_amdgcn_s_sleep(16); }
+DEVFN void poll_pause() { __builtin_amdgcn_s_sleep(1); }   // ~64 cycles between two looks at a word another workgroup will change
 // park the wave for roughly 0.35 us per recurrence iteration still missing (s_sleep 13 ~ 832 cycles), at most ~14 us
 DEVFN void sleep_iterations(int n) {
   n = n > 40 ? 40 : n;

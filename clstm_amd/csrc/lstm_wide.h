@@ -770,6 +770,289 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_coop_bwd(LstmWideArgs a) {
   }
 }
 
+// ---- persistent forward recurrence, bf16 operands, one workgroup GROUP per XCD -------------------------------------------
+// The per-step launches of lstm_wide_fwd_step16_bf16 cannot go below ~5 us per step: 3.2 us for an empty dependent launch
+// plus an L2-bound round of operand loads, of which the 64 KB of weight rows per workgroup and step (1.3 us) never change.
+// Here ONE launch walks all time steps.  The unit of synchronisation is the XCD, not the chip: the 32 cell tiles of one
+// (line block, direction) form a group, a group lives on ONE XCD (a workgroup reads its XCD from the hardware id register
+// and claims the next tile of that XCD's group), so
+//   * a group's h ring rows are written and read through ONE L2: plain stores (they stay in that L2) + s_waitcnt vmcnt(0),
+//     L1-bypassing (sc1) loads -- no write-through to memory, no cross-XCD hop;
+//   * a step is separated from the next by a GROUP barrier (32 arrivals on the group's own counter), not a grid barrier;
+//   * the 64 weight rows of a tile (64 KB bf16) are staged into LDS once and stay there;
+//   * the epilogue operands of step s (gate pre-activations from HBM, c_{s-1}) are requested BEFORE the wait for step
+//     s-1's h, so their latency is off the dependent chain.
+// Grid = 8 x ceil(no/16) workgroups of 256 threads with > 80 KB of LDS each (one per CU, all co-resident: at most 256);
+// groups = ndir x ceil(bs/16) <= 8.  Placement is CHECKED, not assumed: after claiming, every workgroup waits until all
+// have claimed and verifies that every group got its ceil(no/16) tiles; otherwise it raises sync[1] and leaves BEFORE
+// anything is written (the host then runs the per-step path).  Every poll loop carries a watchdog.
+struct XcdSyncLayout { enum { ARRIVED = 0, ERROR = 1, SLOT0 = 8, GROUP0 = 32, GROUP_STRIDE = 32, WORDS = 32 + 8 * 32 }; };
+constexpr int XCD_LDW = 512 + 8;        // halfs per resident weight row (conflict-free ds_read_b128 fragments), kp16 <= 512
+inline __host__ __device__ int xcd_fwd_lds_bytes() { return 64 * XCD_LDW * 2 + WIDE_NW * 16 * 68 * 4 + 64; }
+
+// thread 0 polls, everybody learns the outcome; `code` is what a time-out writes into the error word (1: before anything
+// was written -- the host may fall back to the per-step path; 2: in the middle of the sequence -- fatal)
+DEVFN bool xcd_poll(int* word, int target, int* err, int* lds_flag, int code) {
+  if (threadIdx.x == 0) {
+    int spins = 0, bad = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      poll_pause();
+      if ((++spins & 63) == 0) {
+        bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!bad && spins > GRID_WATCHDOG_SPINS) { bad = code; __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (bad) break;
+      }
+    }
+    *lds_flag = bad;
+  }
+  __syncthreads();
+  const bool ok = *lds_flag == 0;
+  __syncthreads();
+  return ok;
+}
+
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a) {
+  unsigned short* wl = dyn_smem<unsigned short>();                         // [64][XCD_LDW]
+  float* red = reinterpret_cast<float*>(wl + 64 * XCD_LDW);                // [4][16][68]
+  int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * 68);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int no = a.no, nd = a.ndir;
+  const int ntile = (no + 15) >> 4, nzb = (a.bs + 15) >> 4, ngroups = nd * nzb, ncg = (no + 3) >> 2;
+  int* const sync = a.sync;
+  // ---- claim a tile of this XCD's group, then check the placement of the whole grid ----
+  const int xcd = hw_xcc_id() & 7;
+  if (tid == 0) {
+    flag[1] = __hip_atomic_fetch_add(sync + XcdSyncLayout::SLOT0 + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(sync + XcdSyncLayout::ARRIVED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int ct = flag[1];
+  if (!xcd_poll(sync + XcdSyncLayout::ARRIVED, (int)gridDim.x, sync + XcdSyncLayout::ERROR, flag, 1)) return;
+  if (tid == 0) {
+    int bad = 0;
+    for (int g = 0; g < ngroups; g++)
+      bad |= __hip_atomic_load(sync + XcdSyncLayout::SLOT0 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile;
+    if (bad) __hip_atomic_store(sync + XcdSyncLayout::ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag[0] = bad;
+  }
+  __syncthreads();
+  if (flag[0] != 0) return;                       // uneven placement: nothing has been written yet
+  if (xcd >= ngroups || ct >= ntile) return;      // spare workgroup
+  const int dir = xcd % nd, zb = xcd / nd;
+  int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
+
+  // ---- the tile's 64 weight rows: cell groups 4ct .. 4ct+3 of this direction, 16 rows (cell_local*4 + gate) each ----
+  {
+    const int c8 = a.kp16 >> 3;   // 16-byte chunks per row
+    for (int i = tid; i < 64 * c8; i += WIDE_THREADS) {
+      const int row = i / c8, c = i - row * c8;
+      const long long grow = (long long)(dir * ncg + ct * 4) * 16 + row;
+      u16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = 0;
+      if ((ct * 4) * 16 + row < ncg * 16) v = *reinterpret_cast<const u16x8*>(a.Rw16 + grow * a.kp16 + c * 8);
+      *reinterpret_cast<u16x8*>(wl + row * XCD_LDW + c * 8) = v;
+    }
+  }
+  // epilogue role: (line, cell); the line's extent is fixed for the whole launch
+  const int ml = tid >> 4, c16 = tid & 15;
+  const int line = zb * 16 + ml, cell = ct * 16 + c16;
+  int off = 0, T = 0;
+  if (line < a.bs) { off = a.line_off[line]; T = a.line_off[line + 1] - off; }
+  const bool mine = line < a.bs && cell < no;
+  const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
+  const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * a.bs * a.kp16 * 2);
+  // A fragment of this lane: line zb*16 + (lane&15), 8 k at wave*kw + 32 g + 8 (lane>>4)
+  const int kw = a.kp16 / WIDE_NW, ngrp = kw >> 5;   // <= 4 groups of 32 per wave
+  const int am = zb * 16 + (lane & 15);
+  const unsigned akl = (unsigned)(wave * kw + 8 * (lane >> 4)) * 2u;
+  const unsigned short* wfrag = wl + (lane & 15) * XCD_LDW + wave * kw + 8 * (lane >> 4);
+  __syncthreads();
+
+  for (int sg = 0; sg < a.tmax; sg++) {
+    const bool live = mine && sg < T;
+    const long long n = off + (dir == 0 ? sg : T - 1 - sg);
+    // operands that do not depend on the other workgroups: requested before the wait
+    const f32x4 gx = buf_load4(gbuf, live ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB);
+    float c_prev = buf_load(cbuf, live && sg >= 1
+        ? (unsigned)((((long long)(off + (dir == 0 ? sg - 1 : T - sg)) * nd + dir) * no + cell) * 4) : BUF_OOB);
+    if (sg >= 1 && !xcd_poll(gcount, ntile * sg, sync + XcdSyncLayout::ERROR, flag, 2)) return;   // h_{s-1} of the whole group is in the L2
+    // ---- 16 lines x 64 columns, split-K over the four waves ----
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
+    const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 2u + akl : BUF_OOB_BASE;
+    f32x4 ra[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) ra[g] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (g < ngrp) {
+        const u16x8 av = __builtin_bit_cast(u16x8, ra[g]);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[j] = mfma16x16x32_bf16(av, *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDW + g * 32), acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * 68 + j * 16 + (lane & 15)] = acc[j][q];
+    __syncthreads();
+    float h = 0.0f;
+    if (live) {
+      f32x4 k;
+#pragma unroll
+      for (int q = 0; q < 4; q++) k[q] = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WIDE_NW; w++) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(&red[(w * 16 + ml) * 68 + c16 * 4]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) k[q] += p[q];
+      }
+      const float gi = gate_act(k[0] + gx[0], false), gf = gate_act(k[1] + gx[1], false),
+                  go = gate_act(k[2] + gx[2], false), ci = gate_act(k[3] + gx[3], true);
+      const float c = ci * gi + gf * c_prev;
+      h = gate_act(c, true) * go;
+      f32x4 act;
+      act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
+      *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
+      a.C[(n * nd + dir) * no + cell] = c;
+      a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
+      float* srow = a.S + (size_t)dir * a.sdir;
+      if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
+      if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+    }
+    const float hn = quad_xor1(h);
+    if (live && !(c16 & 1))
+      *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) =
+          bf16_pack2(h, cell + 1 < no ? hn : 0.0f);
+    // publish: every store of this workgroup acknowledged by the L2, then one arrival on the group's counter
+    drain_vmem();
+    __syncthreads();
+    if (tid == 0 && sg + 1 < a.tmax) __hip_atomic_fetch_add(gcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---- persistent backward recurrence, same scheme: 16 lines x 16 cells per workgroup, its 16 weight rows (R^T, 2048 k)
+// resident in LDS, the group's bf16 delta ring exchanged through the XCD's L2, the carried state delta in a register ----
+constexpr int XCD_LDWB = 2048 + 8;      // halfs per resident weight row of the backward tile, kp16 <= 2048
+inline __host__ __device__ int xcd_bwd_lds_bytes() {
+  const int need = 16 * XCD_LDWB * 2 + WIDE_NW * 16 * WIDE_LDW * 4 + 64;
+  return need > 84 * 1024 ? need : 84 * 1024;   // > 80 KB: one workgroup per CU, whatever the tile needs
+}
+
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a) {
+  unsigned short* wl = dyn_smem<unsigned short>();                         // [16][XCD_LDWB]
+  float* red = reinterpret_cast<float*>(wl + 16 * XCD_LDWB);               // [4][16][WIDE_LDW]
+  int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * WIDE_LDW);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int no = a.no, nd = a.ndir;
+  const int ntile = (no + 15) >> 4, nzb = (a.bs + 15) >> 4, ngroups = nd * nzb;
+  int* const sync = a.sync;
+  const int xcd = hw_xcc_id() & 7;
+  if (tid == 0) {
+    flag[1] = __hip_atomic_fetch_add(sync + XcdSyncLayout::SLOT0 + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(sync + XcdSyncLayout::ARRIVED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int ct = flag[1];
+  if (!xcd_poll(sync + XcdSyncLayout::ARRIVED, (int)gridDim.x, sync + XcdSyncLayout::ERROR, flag, 1)) return;
+  if (tid == 0) {
+    int bad = 0;
+    for (int g = 0; g < ngroups; g++)
+      bad |= __hip_atomic_load(sync + XcdSyncLayout::SLOT0 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile;
+    if (bad) __hip_atomic_store(sync + XcdSyncLayout::ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag[0] = bad;
+  }
+  __syncthreads();
+  if (flag[0] != 0) return;
+  if (xcd >= ngroups || ct >= ntile) return;
+  const int dir = xcd % nd, zb = xcd / nd;
+  int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
+  {
+    const int c8 = a.kp16 >> 3;
+    for (int i = tid; i < 16 * c8; i += WIDE_THREADS) {
+      const int row = i / c8, c = i - row * c8;
+      *reinterpret_cast<u16x8*>(wl + row * XCD_LDWB + c * 8) =
+          *reinterpret_cast<const u16x8*>(a.Rw16 + ((long long)(dir * ntile + ct) * 16 + row) * a.kp16 + c * 8);
+    }
+  }
+  const int ml = tid >> 4, c16 = tid & 15;
+  const int line = zb * 16 + ml, cell = ct * 16 + c16;
+  int off = 0, T = 0;
+  if (line < a.bs) { off = a.line_off[line]; T = a.line_off[line + 1] - off; }
+  const bool mine = line < a.bs && cell < no;
+  const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
+  const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
+  const BufF32 hbuf = make_buf(a.dH, (size_t)a.N * nd * no * 4);
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Db), (size_t)2 * nd * a.bs * a.kp16 * 2);
+  const int kw = a.kp16 / WIDE_NW, ngrp = kw >> 5;   // <= 16 groups of 32 per wave
+  const int am = zb * 16 + (lane & 15);
+  const unsigned akl = (unsigned)(wave * kw + 8 * (lane >> 4)) * 2u;
+  const unsigned short* wfrag = wl + (lane & 15) * XCD_LDWB + wave * kw + 8 * (lane >> 4);
+  float dc_carry = 0.0f;   // dc_{s+1} * gf_{s+1} of this (line, cell): carried in a register, not through memory
+  __syncthreads();
+
+  for (int sg = 0; sg < a.tmax; sg++) {
+    const bool live = mine && sg < T;
+    const int s = T - 1 - sg;
+    const long long n = off + (dir == 0 ? s : sg);
+    const unsigned coff = (unsigned)(((n * nd + dir) * no + cell) * 4);
+    const f32x4 act = buf_load4(gbuf, live ? coff * 4u : BUF_OOB);
+    const float dh_in = buf_load(hbuf, live ? (unsigned)((n * (nd * no) + dir * no + cell) * 4) : BUF_OOB);
+    const float c_s = buf_load(cbuf, live ? coff : BUF_OOB);
+    const float c_m1 = buf_load(cbuf, live && s >= 1
+        ? (unsigned)((((long long)(off + (dir == 0 ? s - 1 : sg + 1)) * nd + dir) * no + cell) * 4) : BUF_OOB);
+    if (sg >= 1 && !xcd_poll(gcount, ntile * sg, sync + XcdSyncLayout::ERROR, flag, 2)) return;
+    f32x4 acc;
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = 0.0f;
+    const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 2u + akl : BUF_OOB_BASE;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {   // two rounds of eight 32-k groups
+      f32x4 ra[8];
+#pragma unroll
+      for (int g = 0; g < 8; g++) ra[g] = buf_load4_dev(abuf, half * 8 + g < ngrp ? arow + (unsigned)(half * 8 + g) * 64u : BUF_OOB);
+#pragma unroll
+      for (int g = 0; g < 8; g++)
+        if (half * 8 + g < ngrp)
+          acc = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[g]), *reinterpret_cast<const u16x8*>(wfrag + (half * 8 + g) * 32), acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * WIDE_LDW + (lane & 15)] = acc[q];
+    __syncthreads();
+    if (live) {
+      float dh_rec = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WIDE_NW; w++) dh_rec += red[(w * 16 + ml) * WIDE_LDW + c16];
+      const float gi = act[0], gf = act[1], go = act[2], ci = act[3];
+      const float dh = dh_in + dh_rec;
+      const float th = gate_act(c_s, true);
+      const float d_go = th * dh;
+      const float dc = (sg >= 1 ? dc_carry : 0.0f) + (-th * th + 1.0f) * (go * dh);
+      dc_carry = dc * gf;
+      const float d_gf = dc * c_m1;
+      const float d_gi = dc * ci, d_ci = dc * gi;
+      f32x4 dl;
+      dl[0] = (gi * (-gi + 1.0f)) * d_gi;
+      dl[1] = (gf * (-gf + 1.0f)) * d_gf;
+      dl[2] = (go * (-go + 1.0f)) * d_go;
+      dl[3] = (-ci * ci + 1.0f) * d_ci;
+      *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
+      unsigned* db = reinterpret_cast<unsigned*>(a.Db + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + 4 * cell);
+      db[0] = bf16_pack2(dl[0], dl[1]);
+      db[1] = bf16_pack2(dl[2], dl[3]);
+    }
+    drain_vmem();
+    __syncthreads();
+    if (tid == 0 && sg + 1 < a.tmax) __hip_atomic_fetch_add(gcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // contraction padding of the packed weights
 inline int wide_kp_fwd(int no) { return ((no + 16 * WIDE_NW - 1) / (16 * WIDE_NW)) * 16 * WIDE_NW; }
 inline int wide_kp_bwd(int no) { return ((4 * no + 16 * WIDE_NW - 1) / (16 * WIDE_NW)) * 16 * WIDE_NW; }

@@ -231,10 +231,16 @@ inline int load_i32_wt(const int* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CS
 inline void store_i32_wt(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 inline void atomic_add_i32(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline int atomic_fetch_add_i32(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
-inline int hw_xcc_id() { return 0; }
+inline int hw_xcc_id() { return (int)(blockIdx.x & 7u); }   // the dispatcher's round-robin placement
 inline int hw_cu_slot() { return 0; }
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, __ATOMIC_SEQ_CST)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, __ATOMIC_SEQ_CST)
+constexpr int GRID_WATCHDOG_SPINS = 1 << 24;
 inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const unsigned*) { *s = nullptr; return 0; }
 inline void sleep_some() { emu_yield(); sched_yield(); }
+inline void poll_pause() { emu_yield(); sched_yield(); }
 inline void sleep_iterations(int) { emu_yield(); sched_yield(); }
 inline int wave_max_i(int x) { for (int m = 32; m >= 1; m >>= 1) { const int y = wave_shfl_i(x, emu_lane() ^ m); x = y > x ? y : x; } return x; }
 inline void drain_vmem() {}
