@@ -551,6 +551,7 @@ struct Layer {
   DevBuf<unsigned short> Hb, Db;
   long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
   DevBuf<float> G, C, H, D, dH, S;
+  DevBuf<float> pdw;          // split-K slabs of this layer's weight-gradient product when it runs on the side stream
   int lds = 0;
   int wt_slack = 32;          // floats past Wt a vectorised staging load may touch
   int ldh = 0, hofs = 4;      // H rows: [pad pad pad 1 | h_dir0 | h_dir1], h at column hofs (16-byte aligned)
@@ -1194,31 +1195,41 @@ struct Net {
       else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
       ns = bf16_gemm && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
-      partial.reserve((size_t)ndir * ns * R * Cn);
-      timing.begin("gemm_gates_dw", s);
-      if (bf16_gemm)
-        gemm_bf16<GEMM_MC, GEMM_MC>(s, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
-                                    gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
-                                    StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns, ndir);
-      else
-        gemm_f32<GEMM_MC, GEMM_MC, StorePartial, GEMM_BK_DW>(s, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
-                                                             gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
-                                                             StorePartial{partial.p, R, Cn}, R, Cn, (int)N, ns, ndir);
       }
-      {
-        const ReduceDesc gates{partial.p, y.moff, 0LL, ns, ndir, R, Cn, y.no};
+      // (Experiment, off by default.)  Stacked lock-step layers in bf16: the weight-gradient product of layer l (~1 ms at 2 x BiLSTM(512)) depends only on
+      // that layer's recurrence, while the persistent recurrence of layer l-1 that follows keeps every CU busy with four
+      // latency-bound waves.  So x.d goes first (layer l-1 waits for it), then W.d and its slab reduction run on a
+      // LOW-priority side stream beside the next recurrence (whose workgroups, on the other stream, are dispatched first)
+      // and the main stream joins before the update.
+      const bool defer = l > 0 && y.wide && bf16_rec && bf16_gemm && dw_side_stream();
+      DevBuf<float>& pbuf = defer ? y.pdw : partial;
+      auto do_dw = [&](hipStream_t q) {
+        if (bf16_gemm || !overlap_eligible(y)) {
+          pbuf.reserve((size_t)ndir * ns * R * Cn);
+          timing.begin("gemm_gates_dw", q);
+          if (bf16_gemm)
+            gemm_bf16<GEMM_MC, GEMM_MC>(q, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
+                                        gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
+                                        StorePartial{pbuf.p, R, Cn}, R, Cn, (int)N, ns, ndir);
+          else
+            gemm_f32<GEMM_MC, GEMM_MC, StorePartial, GEMM_BK_DW>(q, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
+                                                                 gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
+                                                                 StorePartial{pbuf.p, R, Cn}, R, Cn, (int)N, ns, ndir);
+        }
+        const ReduceDesc gates{pbuf.p, y.moff, 0LL, ns, ndir, R, Cn, y.no};
         ReduceDesc extra{};   // empty unless this is the top layer
         if (l == (int)L.size() - 1) extra = sm_red;
         const size_t work = (size_t)ndir * R * Cn + (size_t)extra.R * extra.Cn * extra.nbatch;
-        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, s, gates, extra, g, dw_queue.p, dw_queue.p ? 8 : 0);
-      }
-      timing.end(s);
-      check_launch();
-      // input deltas: x.d = sum_dir W_x^T delta (Parallel::backward sums both subs, clstm.cc:538-541)
-      float* dx = nullptr;
-      if (l > 0) dx = L[l - 1].dH.p;
-      else if (want_dx0) { dX0.reserve((size_t)N * y.ni); dx = dX0.p; }
-      if (dx) {
+        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, g, dw_queue.p, dw_queue.p ? 8 : 0);
+        timing.end(q);
+        check_launch();
+      };
+      auto do_dx = [&]() {
+        // input deltas: x.d = sum_dir W_x^T delta (Parallel::backward sums both subs, clstm.cc:538-541)
+        float* dx = nullptr;
+        if (l > 0) dx = L[l - 1].dH.p;
+        else if (want_dx0) { dX0.reserve((size_t)N * y.ni); dx = dX0.p; }
+        if (!dx) return;
         timing.begin("gemm_gates_dx", s);
         if (bf16_gemm)
           gemm_bf16<GEMM_KC, GEMM_KC>(s, gemm_kc(y.D.p, M, N, 32), gemm_kc(y.Wt, M, y.ni, y.wt_slack), StorePlain{dx, y.ni},
@@ -1228,8 +1239,47 @@ struct Net {
                                      y.ni, M);
         timing.end(s);
         check_launch();
+      };
+      if (defer) {
+        do_dx();
+        HIPCHECK(hipEventRecord(dw_fork, s));
+        HIPCHECK(hipStreamWaitEvent(dw_side, dw_fork, 0));
+        do_dw(dw_side);
+        dw_side_pending = true;
+      } else {
+        do_dw(s);
+        do_dx();
       }
     }
+    if (dw_side_pending) {   // the gradient is complete only when the side stream's slab reductions are
+      HIPCHECK(hipEventRecord(dw_join, dw_side));
+      HIPCHECK(hipStreamWaitEvent(s, dw_join, 0));
+      dw_side_pending = false;
+    }
+  }
+
+  // low-priority stream for weight-gradient products that run beside the next layer's recurrence
+  hipStream_t dw_side = nullptr;
+  hipEvent_t dw_fork{}, dw_join{};
+  bool dw_side_tried = false, dw_side_pending = false;
+  bool dw_side_stream() {
+#ifdef CLSTM_HIP_EMU
+    return false;
+#else
+    // opt-in (CLSTM_DW_SIDE=1): measured at 2 x BiLSTM(512) the product running beside it slows the latency-bound
+    // recurrence by more than it hides (9.75 vs 9.52 ms per minibatch)
+    static const bool on = getenv("CLSTM_DW_SIDE") && atoi(getenv("CLSTM_DW_SIDE")) != 0;
+    if (!on) return false;
+    if (!dw_side_tried) {
+      dw_side_tried = true;
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = numerically greatest = lowest priority
+      if (hipStreamCreateWithPriority(&dw_side, hipStreamNonBlocking, lo) != hipSuccess) { dw_side = nullptr; return false; }
+      if (hipEventCreateWithFlags(&dw_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&dw_join, hipEventDisableTiming) != hipSuccess) { dw_side = nullptr; return false; }
+    }
+    return dw_side != nullptr;
+#endif
   }
 
   void update() {
