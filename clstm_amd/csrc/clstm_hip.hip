@@ -424,9 +424,16 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       sync.reserve(XcdSyncLayout::WORDS);
       a.sync = sync.p;
       HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
-      const size_t smem = (size_t)xcd_bwd_lds_bytes();
-      coop_set_smem(lstm_xcd_bwd_bf16, smem);
-      CLSTM_LAUNCH_COOP(lstm_xcd_bwd_bf16, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+      static const int nt_env = getenv("CLSTM_XCD_BWD_NT") ? atoi(getenv("CLSTM_XCD_BWD_NT")) : 1;
+      if (nt_env >= 2 && ntile >= 2) {   // two 16-cell tiles per workgroup: half the delta traffic through each XCD's L2 (measured: no difference)
+        const size_t smem = (size_t)xcd_bwd_lds_bytes<2>();
+        coop_set_smem(lstm_xcd_bwd_bf16<2>, smem);
+        CLSTM_LAUNCH_COOP(lstm_xcd_bwd_bf16<2>, dim3(8 * ((ntile + 1) / 2)), dim3(WIDE_THREADS), smem, s, a);
+      } else {
+        const size_t smem = (size_t)xcd_bwd_lds_bytes<1>();
+        coop_set_smem(lstm_xcd_bwd_bf16<1>, smem);
+        CLSTM_LAUNCH_COOP(lstm_xcd_bwd_bf16<1>, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+      }
       check_launch();
       if (g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s)) return;
       xcd_failed = true;

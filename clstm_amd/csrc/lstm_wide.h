@@ -870,13 +870,19 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   const unsigned short* wfrag = wl + (lane & 15) * XCD_LDW + wave * kw + 8 * (lane >> 4);
   __syncthreads();
 
+  // The gate pre-activations of step s come from HBM (~2 us) and VMEM returns in order: requested at the top of step s
+  // they would hold back the h rows requested behind them.  They are requested one step AHEAD, behind that step's h
+  // loads; c_{s-1} is this thread's own result of the previous step and stays in a register.
+  auto gx_load = [&](int sg) -> f32x4 {
+    const bool lv = mine && sg < T;
+    const long long nn = off + (dir == 0 ? sg : T - 1 - sg);
+    return buf_load4(gbuf, lv ? (unsigned)(((nn * nd + dir) * no + cell) * 16) : BUF_OOB);
+  };
+  f32x4 gx = gx_load(0);
+  float c_prev = 0.0f;
   for (int sg = 0; sg < a.tmax; sg++) {
     const bool live = mine && sg < T;
     const long long n = off + (dir == 0 ? sg : T - 1 - sg);
-    // operands that do not depend on the other workgroups: requested before the wait
-    const f32x4 gx = buf_load4(gbuf, live ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB);
-    float c_prev = buf_load(cbuf, live && sg >= 1
-        ? (unsigned)((((long long)(off + (dir == 0 ? sg - 1 : T - sg)) * nd + dir) * no + cell) * 4) : BUF_OOB);
     if (sg >= 1 && !xcd_poll(gcount, ntile * sg, sync + XcdSyncLayout::ERROR, flag, 2)) return;   // h_{s-1} of the whole group is in the L2
     // ---- 16 lines x 64 columns, split-K over the four waves ----
     f32x4 acc[4];
@@ -888,6 +894,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
     f32x4 ra[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) ra[g] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+    SCHED_FENCE();
+    const f32x4 gx_next = gx_load(sg + 1);
+    SCHED_FENCE();
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       if (g < ngrp) {
@@ -935,6 +944,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
     // publish: every store of this workgroup acknowledged by the L2, then one arrival on the group's counter.  (Storing
     // the bf16 h first and the other arrays behind the arrival was measured SLOWER, 3.5 vs 3.2 us per step: VMEM
     // completes in order, so the next step's operand loads then wait behind those stores.)
+    c_prev = c_new;
+    gx = gx_next;
     drain_vmem();
     __syncthreads();
     if (tid == 0 && sg + 1 < a.tmax) __hip_atomic_fetch_add(gcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -944,18 +955,25 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
 // ---- persistent backward recurrence, same scheme: 16 lines x 16 cells per workgroup, its 16 weight rows (R^T, 2048 k)
 // resident in LDS, the group's bf16 delta ring exchanged through the XCD's L2, the carried state delta in a register ----
 constexpr int XCD_LDWB = 2048 + 8;      // halfs per resident weight row of the backward tile, kp16 <= 2048
+// NT: 16-cell tiles per workgroup.  Every workgroup of a group reads the group's WHOLE delta ring row block (16 lines x
+// 2048 k x 2 B = 64 KB) each step, so the step is bound by that L2's bandwidth (32 workgroups: 2 MB per step; the
+// forward kernel moves 0.5 MB and runs 2.9 us per step against 4.3): with two tiles per workgroup a group has 16
+// workgroups, half the traffic, and twice the MFMA work per wave (still < 0.3 us).
+template <int NT>
 inline __host__ __device__ int xcd_bwd_lds_bytes() {
-  const int need = 16 * XCD_LDWB * 2 + WIDE_NW * 16 * WIDE_LDW * 4 + 64;
+  const int need = NT * 16 * XCD_LDWB * 2 + WIDE_NW * 16 * (NT * 16 + 4) * 4 + 64;
   return need > 84 * 1024 ? need : 84 * 1024;   // > 80 KB: one workgroup per CU, whatever the tile needs
 }
 
+template <int NT>
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a) {
-  unsigned short* wl = dyn_smem<unsigned short>();                         // [16][XCD_LDWB]
-  float* red = reinterpret_cast<float*>(wl + 16 * XCD_LDWB);               // [4][16][WIDE_LDW]
-  int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * WIDE_LDW);
+  constexpr int LDR = NT * 16 + 4;
+  unsigned short* wl = dyn_smem<unsigned short>();                         // [NT*16][XCD_LDWB]
+  float* red = reinterpret_cast<float*>(wl + NT * 16 * XCD_LDWB);          // [4][16][LDR]
+  int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * LDR);
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int no = a.no, nd = a.ndir;
-  const int ntile = (no + 15) >> 4, nzb = (a.bs + 15) >> 4, ngroups = nd * nzb;
+  const int ntile = (no + 15) >> 4, ntile2 = (ntile + NT - 1) / NT, nzb = (a.bs + 15) >> 4, ngroups = nd * nzb;
   int* const sync = a.sync;
   const int xcd = hw_xcc_id() & 7;
   if (tid == 0) {
@@ -963,33 +981,40 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
     __hip_atomic_fetch_add(sync + XcdSyncLayout::ARRIVED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  const int ct = flag[1];
+  const int slot = flag[1];
   if (!xcd_poll(sync + XcdSyncLayout::ARRIVED, (int)gridDim.x, sync + XcdSyncLayout::ERROR, flag, 1)) return;
   if (tid == 0) {
     int bad = 0;
     for (int g = 0; g < ngroups; g++)
-      bad |= __hip_atomic_load(sync + XcdSyncLayout::SLOT0 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile;
+      bad |= __hip_atomic_load(sync + XcdSyncLayout::SLOT0 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile2;
     if (bad) __hip_atomic_store(sync + XcdSyncLayout::ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     flag[0] = bad;
   }
   __syncthreads();
   if (flag[0] != 0) return;
-  if (xcd >= ngroups || ct >= ntile) return;
+  if (xcd >= ngroups || slot >= ntile2) return;
   const int dir = xcd % nd, zb = xcd / nd;
   int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
   {
     const int c8 = a.kp16 >> 3;
-    for (int i = tid; i < 16 * c8; i += WIDE_THREADS) {
+    for (int i = tid; i < NT * 16 * c8; i += WIDE_THREADS) {
       const int row = i / c8, c = i - row * c8;
-      *reinterpret_cast<u16x8*>(wl + row * XCD_LDWB + c * 8) =
-          *reinterpret_cast<const u16x8*>(a.Rw16 + ((long long)(dir * ntile + ct) * 16 + row) * a.kp16 + c * 8);
+      const int ct = slot * NT + (row >> 4);
+      u16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = 0;
+      if (ct < ntile) v = *reinterpret_cast<const u16x8*>(a.Rw16 + ((long long)(dir * ntile + ct) * 16 + (row & 15)) * a.kp16 + c * 8);
+      *reinterpret_cast<u16x8*>(wl + row * XCD_LDWB + c * 8) = v;
     }
   }
   const int ml = tid >> 4, c16 = tid & 15;
-  const int line = zb * 16 + ml, cell = ct * 16 + c16;
+  const int line = zb * 16 + ml;
   int off = 0, T = 0;
   if (line < a.bs) { off = a.line_off[line]; T = a.line_off[line + 1] - off; }
-  const bool mine = line < a.bs && cell < no;
+  int cellj[NT];
+  bool minej[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++) { cellj[j] = (slot * NT + j) * 16 + c16; minej[j] = line < a.bs && cellj[j] < no; }
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
   const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
   const BufF32 hbuf = make_buf(a.dH, (size_t)a.N * nd * no * 4);
@@ -998,62 +1023,103 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
   const int am = zb * 16 + (lane & 15);
   const unsigned akl = (unsigned)(wave * kw + 8 * (lane >> 4)) * 2u;
   const unsigned short* wfrag = wl + (lane & 15) * XCD_LDWB + wave * kw + 8 * (lane >> 4);
-  float dc_carry = 0.0f;   // dc_{s+1} * gf_{s+1} of this (line, cell): carried in a register, not through memory
+  float dc_carry[NT];      // dc_{s+1} * gf_{s+1} of this thread's (line, cell)s: carried in registers, not through memory
+#pragma unroll
+  for (int j = 0; j < NT; j++) dc_carry[j] = 0.0f;
   __syncthreads();
 
+  // Epilogue operands (forward-pass arrays, from HBM) are requested one step AHEAD and behind that step's delta loads, so
+  // that they never sit in front of them in the in-order VMEM queue; c_s of a step is the c_{s-1} the previous step loaded.
+  struct Ops { f32x4 act; float dh_in, c_m1; };
+  auto ops_load = [&](int sg, int j) -> Ops {
+    const bool lv = minej[j] && sg < T;
+    const int ss = T - 1 - sg;
+    const long long nn = off + (dir == 0 ? ss : sg);
+    Ops o;
+    o.act = buf_load4(gbuf, lv ? (unsigned)(((nn * nd + dir) * no + cellj[j]) * 16) : BUF_OOB);
+    o.dh_in = buf_load(hbuf, lv ? (unsigned)((nn * (nd * no) + dir * no + cellj[j]) * 4) : BUF_OOB);
+    o.c_m1 = buf_load(cbuf, lv && ss >= 1
+        ? (unsigned)((((long long)(off + (dir == 0 ? ss - 1 : sg + 1)) * nd + dir) * no + cellj[j]) * 4) : BUF_OOB);
+    return o;
+  };
+  Ops cur[NT];
+  float c_s[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    cur[j] = ops_load(0, j);
+    const bool lv = minej[j] && 0 < T;
+    c_s[j] = buf_load(cbuf, lv ? (unsigned)((((long long)(off + (dir == 0 ? T - 1 : 0)) * nd + dir) * no + cellj[j]) * 4) : BUF_OOB);
+  }
   for (int sg = 0; sg < a.tmax; sg++) {
-    const bool live = mine && sg < T;
     const int s = T - 1 - sg;
     const long long n = off + (dir == 0 ? s : sg);
-    const unsigned coff = (unsigned)(((n * nd + dir) * no + cell) * 4);
-    const f32x4 act = buf_load4(gbuf, live ? coff * 4u : BUF_OOB);
-    const float dh_in = buf_load(hbuf, live ? (unsigned)((n * (nd * no) + dir * no + cell) * 4) : BUF_OOB);
-    const float c_s = buf_load(cbuf, live ? coff : BUF_OOB);
-    const float c_m1 = buf_load(cbuf, live && s >= 1
-        ? (unsigned)((((long long)(off + (dir == 0 ? s - 1 : sg + 1)) * nd + dir) * no + cell) * 4) : BUF_OOB);
-    if (sg >= 1 && !xcd_poll(gcount, ntile * sg, sync + XcdSyncLayout::ERROR, flag, 2)) return;
-    f32x4 acc;
+    bool live[NT];
 #pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] = 0.0f;
+    for (int j = 0; j < NT; j++) live[j] = minej[j] && sg < T;
+    if (sg >= 1 && !xcd_poll(gcount, ntile2 * sg, sync + XcdSyncLayout::ERROR, flag, 2)) return;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
     const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 2u + akl : BUF_OOB_BASE;
+    Ops nxt[NT];
+    {   // all sixteen 32-k groups of the wave's quarter requested at once: ONE L2 round trip per step (two rounds of
+        // eight cost a second one: 4.3 vs 3.x us per step)
+      f32x4 ra[16];
 #pragma unroll
-    for (int half = 0; half < 2; half++) {   // two rounds of eight 32-k groups
-      f32x4 ra[8];
+      for (int g = 0; g < 16; g++) ra[g] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+      SCHED_FENCE();
 #pragma unroll
-      for (int g = 0; g < 8; g++) ra[g] = buf_load4_dev(abuf, half * 8 + g < ngrp ? arow + (unsigned)(half * 8 + g) * 64u : BUF_OOB);
+      for (int j = 0; j < NT; j++) nxt[j] = ops_load(sg + 1, j);
+      SCHED_FENCE();
 #pragma unroll
-      for (int g = 0; g < 8; g++)
-        if (half * 8 + g < ngrp)
-          acc = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[g]), *reinterpret_cast<const u16x8*>(wfrag + (half * 8 + g) * 32), acc);
+      for (int g = 0; g < 16; g++)
+        if (g < ngrp) {
+          const u16x8 av = __builtin_bit_cast(u16x8, ra[g]);
+#pragma unroll
+          for (int j = 0; j < NT; j++)
+            acc[j] = mfma16x16x32_bf16(av, *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDWB + g * 32), acc[j]);
+        }
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * WIDE_LDW + (lane & 15)] = acc[q];
-    __syncthreads();
-    f32x4 dl;
-    if (live) {
-      float dh_rec = 0.0f;
+    for (int j = 0; j < NT; j++)
 #pragma unroll
-      for (int w = 0; w < WIDE_NW; w++) dh_rec += red[(w * 16 + ml) * WIDE_LDW + c16];
-      const float gi = act[0], gf = act[1], go = act[2], ci = act[3];
-      const float dh = dh_in + dh_rec;
-      const float th = gate_act(c_s, true);
-      const float d_go = th * dh;
-      const float dc = (sg >= 1 ? dc_carry : 0.0f) + (-th * th + 1.0f) * (go * dh);
-      dc_carry = dc * gf;
-      const float d_gf = dc * c_m1;
-      const float d_gi = dc * ci, d_ci = dc * gi;
-      dl[0] = (gi * (-gi + 1.0f)) * d_gi;
-      dl[1] = (gf * (-gf + 1.0f)) * d_gf;
-      dl[2] = (go * (-go + 1.0f)) * d_go;
-      dl[3] = (-ci * ci + 1.0f) * d_ci;
-      unsigned* db = reinterpret_cast<unsigned*>(a.Db + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + 4 * cell);
-      db[0] = bf16_pack2(dl[0], dl[1]);   // what the group waits for goes first (see the forward kernel)
-      db[1] = bf16_pack2(dl[2], dl[3]);
+      for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * LDR + j * 16 + (lane & 15)] = acc[j][q];
+    __syncthreads();
+    f32x4 dl[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      if (live[j]) {
+        float dh_rec = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WIDE_NW; w++) dh_rec += red[(w * 16 + ml) * LDR + j * 16 + c16];
+        const float gi = cur[j].act[0], gf = cur[j].act[1], go = cur[j].act[2], ci = cur[j].act[3];
+        const float dh = cur[j].dh_in + dh_rec;
+        const float th = gate_act(c_s[j], true);
+        const float d_go = th * dh;
+        const float dc = (sg >= 1 ? dc_carry[j] : 0.0f) + (-th * th + 1.0f) * (go * dh);
+        dc_carry[j] = dc * gf;
+        const float d_gf = dc * cur[j].c_m1;
+        const float d_gi = dc * ci, d_ci = dc * gi;
+        dl[j][0] = (gi * (-gi + 1.0f)) * d_gi;
+        dl[j][1] = (gf * (-gf + 1.0f)) * d_gf;
+        dl[j][2] = (go * (-go + 1.0f)) * d_go;
+        dl[j][3] = (-ci * ci + 1.0f) * d_ci;
+        unsigned* db = reinterpret_cast<unsigned*>(a.Db + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + 4 * cellj[j]);
+        db[0] = bf16_pack2(dl[j][0], dl[j][1]);   // what the group waits for goes first
+        db[1] = bf16_pack2(dl[j][2], dl[j][3]);
+      }
     }
     drain_vmem();
     __syncthreads();
     if (tid == 0 && sg + 1 < a.tmax) __hip_atomic_fetch_add(gcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (live) *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      if (live[j]) *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cellj[j]) * 4) = dl[j];
+      c_s[j] = cur[j].c_m1;
+      cur[j] = nxt[j];
+    }
   }
 }
 
