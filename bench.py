@@ -275,9 +275,11 @@ def main():
                 roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                             "frac": round(tf / peak, 5), "traffic": None,
                             "algorithmic_flops": int(fl / nl), "avg_launch_ms": round(sec / nl * 1e3, 4),
-                            "note": "lock-step recurrence, one launch per time step (latency-bound: %d dependent launches per pass); "
+                            "note": ("lock-step recurrence, ONE persistent launch per pass: a workgroup group per XCD, %d group-barrier-separated steps (latency-bound); "
+                                     if args.bf16 and os.environ.get("CLSTM_XCD_REC", "1") != "0" else
+                                     "lock-step recurrence, one launch per time step (latency-bound: %d dependent launches per pass); ") % args.T +
                                     "whole step: %.1f TFLOP/s of algorithmic flops (SURVEY 8d: 48 T sum no(ni+no) + 6 T nc 2no per line)"
-                                    % (args.T, (48.0 * args.T * sum(o * (i + o) for i, o in zip([NI] + [2 * h for h in nh_list[:-1]], nh_list))
+                                    % ((48.0 * args.T * sum(o * (i + o) for i, o in zip([NI] + [2 * h for h in nh_list[:-1]], nh_list))
                                                 + 6.0 * args.T * NC * 2 * nh_list[-1]) * args.minibatch / (dt / args.steps) / 1e12)}
             else:
               roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
