@@ -376,10 +376,22 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       check_coop(sync, s);
       return;
     }
-    // bf16 operands: ONE launch, a workgroup group per XCD with its weight rows resident in LDS (lstm_xcd_fwd_bf16)
-    static const bool xcd_on = !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
+    // ONE launch, a workgroup group per XCD with its weight rows resident in LDS (lstm_xcd_fwd_bf16 / lstm_xcd_fwd_f32)
+    const bool xcd_on = !allow_coop && !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
     static bool xcd_failed = false;   // the placement check failed once on this device: per-step launches from then on
     const int ntile = (no + 15) / 16;
+    if (!bf16 && xcd_on && !xcd_failed && tmax > 1 && a.ndir * nzb <= 8 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16) &&
+        (size_t)xcd_fwd_f32_lds_bytes(a.kp) <= 160 * 1024) {
+      sync.reserve(XcdSyncLayout::WORDS);
+      a.sync = sync.p;
+      HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+      const size_t smem = (size_t)xcd_fwd_f32_lds_bytes(a.kp);
+      coop_set_smem(lstm_xcd_fwd_f32, smem);
+      CLSTM_LAUNCH_COOP(lstm_xcd_fwd_f32, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+      check_launch();
+      if (g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s)) return;
+      xcd_failed = true;
+    }
     if (bf16 && xcd_on && !xcd_failed && tmax > 1 && a.ndir * nzb <= 8 && ntile <= 32 && a.kp16 <= 512 && 8 * ntile <= std::max(ncu, 16)) {
       sync.reserve(XcdSyncLayout::WORDS);
       a.sync = sync.p;
@@ -417,9 +429,21 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       check_coop(sync, s);
       return;
     }
-    static const bool xcd_on = !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
+    const bool xcd_on = !allow_coop && !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
     static bool xcd_failed = false;
     const int ntile = (no + 15) / 16;
+    if (!bf16 && xcd_on && !xcd_failed && tmax > 1 && a.ndir * nzb <= 8 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16) &&
+        (size_t)xcd_bwd_f32_lds_bytes(a.kp) <= 160 * 1024) {
+      sync.reserve(XcdSyncLayout::WORDS);
+      a.sync = sync.p;
+      HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+      const size_t smem = (size_t)xcd_bwd_f32_lds_bytes(a.kp);
+      coop_set_smem(lstm_xcd_bwd_f32, smem);
+      CLSTM_LAUNCH_COOP(lstm_xcd_bwd_f32, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+      check_launch();
+      if (g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s)) return;
+      xcd_failed = true;
+    }
     if (bf16 && xcd_on && !xcd_failed && tmax > 1 && a.ndir * nzb <= 8 && ntile <= 32 && a.kp16 <= 2048 && 8 * ntile <= std::max(ncu, 16)) {
       sync.reserve(XcdSyncLayout::WORDS);
       a.sync = sync.p;

@@ -1123,6 +1123,271 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
   }
 }
 
+// ---- the same persistent per-XCD scheme with f32 operands (the parity-grade path of wide layers) -----------------------
+// v_mfma_f32_16x16x4_f32, weight rows f32 in LDS (64 x (kp + 4) forward = 132 KB at 512 cells, 16 x (kp + 4) backward),
+// h_{t-1} / delta_{t+1} rows read straight from the per-frame arrays H / D (plain stores by the group's workgroups,
+// L1-bypassing loads -- one L2), fragments as in wide_tile: lane (i, kq) loads four consecutive k of row i, MFMA e of a
+// 16-k group uses element e of both operands' float4.  Arithmetic identical to the per-step kernels (same tile, same
+// split-K order), so the results are bit-identical to them.
+inline __host__ __device__ int xcd_fwd_f32_lds_bytes(int kp) { return (64 * (kp + WIDE_WPAD) + WIDE_NW * 16 * 68 + 16) * 4; }
+inline __host__ __device__ int xcd_bwd_f32_lds_bytes(int kp) {
+  const int need = (16 * (kp + WIDE_WPAD) + WIDE_NW * 16 * WIDE_LDW + 16) * 4;
+  return need > 84 * 1024 ? need : 84 * 1024;
+}
+
+// role assignment + placement check shared by the f32 kernels; returns false if this workgroup has nothing to do (or the
+// launch is being abandoned)
+DEVFN bool xcd_claim(int* sync, int* flag, const int ntile, const int ngroups, int& xcd, int& slot) {
+  const int tid = threadIdx.x;
+  xcd = hw_xcc_id() & 7;
+  if (tid == 0) {
+    flag[1] = __hip_atomic_fetch_add(sync + XcdSyncLayout::SLOT0 + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(sync + XcdSyncLayout::ARRIVED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  slot = flag[1];
+  if (!xcd_poll(sync + XcdSyncLayout::ARRIVED, (int)gridDim.x, sync + XcdSyncLayout::ERROR, flag, 1)) return false;
+  if (tid == 0) {
+    int bad = 0;
+    for (int g = 0; g < ngroups; g++)
+      bad |= __hip_atomic_load(sync + XcdSyncLayout::SLOT0 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile;
+    if (bad) __hip_atomic_store(sync + XcdSyncLayout::ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag[0] = bad;
+  }
+  __syncthreads();
+  const bool ok = flag[0] == 0;
+  __syncthreads();
+  return ok && xcd < ngroups && slot < ntile;
+}
+
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a) {
+  float* wl = dyn_smem<float>();                                   // [64][kp + 4]
+  const int ldw = a.kp + WIDE_WPAD;
+  float* red = wl + 64 * ldw;                                      // [4][16][68]
+  int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * 68);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int no = a.no, nd = a.ndir;
+  const int ntile = (no + 15) >> 4, nzb = (a.bs + 15) >> 4, ncg = (no + 3) >> 2;
+  int xcd, ct;
+  if (!xcd_claim(a.sync, flag, ntile, nd * nzb, xcd, ct)) return;
+  const int dir = xcd % nd, zb = xcd / nd;
+  int* const gcount = a.sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
+  {
+    const int k4 = a.kp >> 2;
+    const float* wbase = a.Rw + (size_t)dir * ncg * 16 * a.kp;
+    for (int i = tid; i < 64 * k4; i += WIDE_THREADS) {
+      const int row = i / k4, c4 = i - row * k4;
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = 0.0f;
+      if ((long long)ct * 64 + row < (long long)ncg * 16) v = *reinterpret_cast<const f32x4*>(wbase + ((size_t)ct * 64 + row) * a.kp + c4 * 4);
+      *reinterpret_cast<f32x4*>(wl + row * ldw + c4 * 4) = v;
+    }
+  }
+  const int ml = tid >> 4, c16 = tid & 15;
+  const int line = zb * 16 + ml, cell = ct * 16 + c16;
+  int off = 0, T = 0;
+  if (line < a.bs) { off = a.line_off[line]; T = a.line_off[line + 1] - off; }
+  const bool mine = line < a.bs && cell < no;
+  // A-fragment role of this lane: line zb*16 + (lane&15)
+  const int am = zb * 16 + (lane & 15);
+  int aoff = 0, aT = 0;
+  if (am < a.bs) { aoff = a.line_off[am]; aT = a.line_off[am + 1] - aoff; }
+  const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
+  const BufF32 hbuf = make_buf(a.H, (size_t)a.N * a.ldh * 4);
+  const int kw = a.kp / WIDE_NW, ngrp = kw >> 4;     // 16-k groups per wave (<= 8 at 512 cells)
+  const unsigned klane = (unsigned)(wave * kw + 4 * (lane >> 4)) * 4u;
+  const float* wrow = wl + (lane & 15) * ldw + wave * kw + 4 * (lane >> 4);
+  auto gx_load = [&](int sg) -> f32x4 {
+    const bool lv = mine && sg < T;
+    const long long nn = off + (dir == 0 ? sg : T - 1 - sg);
+    return buf_load4(gbuf, lv ? (unsigned)(((nn * nd + dir) * no + cell) * 16) : BUF_OOB);
+  };
+  f32x4 gx = gx_load(0);
+  float c_prev = 0.0f;
+  __syncthreads();
+
+  for (int sg = 0; sg < a.tmax; sg++) {
+    const bool live = mine && sg < T;
+    const long long n = off + (dir == 0 ? sg : T - 1 - sg);
+    if (sg >= 1 && !xcd_poll(gcount, ntile * sg, a.sync + XcdSyncLayout::ERROR, flag, 2)) return;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
+    const unsigned arow = (sg >= 1 && am < a.bs && sg < aT)
+        ? (unsigned)((long long)(aoff + (dir == 0 ? sg - 1 : aT - sg)) * a.ldh + a.hofs + dir * no) * 4u + klane : BUF_OOB_BASE;
+    f32x4 ra[8];
+#pragma unroll
+    for (int g = 0; g < 8; g++) ra[g] = buf_load4_dev(hbuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+    SCHED_FENCE();
+    const f32x4 gx_next = gx_load(sg + 1);
+    SCHED_FENCE();
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      if (g < ngrp) {
+        f32x4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) bv[j] = *reinterpret_cast<const f32x4*>(wrow + j * 16 * ldw + g * 16);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[j] = mfma16x16x4(ra[g][e], bv[j][e], acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * 68 + j * 16 + (lane & 15)] = acc[j][q];
+    __syncthreads();
+    float c_new = 0.0f;
+    if (live) {
+      f32x4 k;
+#pragma unroll
+      for (int q = 0; q < 4; q++) k[q] = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WIDE_NW; w++) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(&red[(w * 16 + ml) * 68 + c16 * 4]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) k[q] += p[q];
+      }
+      const float gi = gate_act(k[0] + gx[0], false), gf = gate_act(k[1] + gx[1], false),
+                  go = gate_act(k[2] + gx[2], false), ci = gate_act(k[3] + gx[3], true);
+      c_new = ci * gi + gf * c_prev;
+      const float h = gate_act(c_new, true) * go;
+      f32x4 act;
+      act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
+      a.H[n * a.ldh + a.hofs + dir * no + cell] = h;     // next step's A operand of the whole group
+      *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
+      a.C[(n * nd + dir) * no + cell] = c_new;
+      float* srow = a.S + (size_t)dir * a.sdir;
+      if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
+      if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+    }
+    c_prev = c_new;
+    gx = gx_next;
+    drain_vmem();
+    __syncthreads();
+    if (tid == 0 && sg + 1 < a.tmax) __hip_atomic_fetch_add(gcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a) {
+  float* wl = dyn_smem<float>();                                   // [16][kp + 4]
+  const int ldw = a.kp + WIDE_WPAD;
+  float* red = wl + 16 * ldw;                                      // [4][16][WIDE_LDW]
+  int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * WIDE_LDW);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int no = a.no, nd = a.ndir;
+  const int ntile = (no + 15) >> 4, nzb = (a.bs + 15) >> 4;
+  int xcd, ct;
+  if (!xcd_claim(a.sync, flag, ntile, nd * nzb, xcd, ct)) return;
+  const int dir = xcd % nd, zb = xcd / nd;
+  int* const gcount = a.sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
+  {
+    const int k4 = a.kp >> 2;
+    const float* wbase = a.Rw + ((size_t)dir * ntile + ct) * 16 * a.kp;
+    for (int i = tid; i < 16 * k4; i += WIDE_THREADS) {
+      const int row = i / k4, c4 = i - row * k4;
+      *reinterpret_cast<f32x4*>(wl + row * ldw + c4 * 4) = *reinterpret_cast<const f32x4*>(wbase + (size_t)row * a.kp + c4 * 4);
+    }
+  }
+  const int ml = tid >> 4, c16 = tid & 15;
+  const int line = zb * 16 + ml, cell = ct * 16 + c16;
+  int off = 0, T = 0;
+  if (line < a.bs) { off = a.line_off[line]; T = a.line_off[line + 1] - off; }
+  const bool mine = line < a.bs && cell < no;
+  const int am = zb * 16 + (lane & 15);
+  int aoff = 0, aT = 0;
+  if (am < a.bs) { aoff = a.line_off[am]; aT = a.line_off[am + 1] - aoff; }
+  const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
+  const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
+  const BufF32 hbuf = make_buf(a.dH, (size_t)a.N * nd * no * 4);
+  const BufF32 dbuf = make_buf(a.D, (size_t)a.N * nd * 4 * no * 4);
+  const int kw = a.kp / WIDE_NW, ngrp = kw >> 4;     // 16-k groups per wave (32 at 512 cells), walked in rounds of 8
+  const unsigned klane = (unsigned)(wave * kw + 4 * (lane >> 4)) * 4u;
+  const float* wrow = wl + (lane & 15) * ldw + wave * kw + 4 * (lane >> 4);
+  struct Ops { f32x4 act; float dh_in, c_m1; };
+  auto ops_load = [&](int sg) -> Ops {
+    const bool lv = mine && sg < T;
+    const int ss = T - 1 - sg;
+    const long long nn = off + (dir == 0 ? ss : sg);
+    Ops o;
+    o.act = buf_load4(gbuf, lv ? (unsigned)(((nn * nd + dir) * no + cell) * 16) : BUF_OOB);
+    o.dh_in = buf_load(hbuf, lv ? (unsigned)((nn * (nd * no) + dir * no + cell) * 4) : BUF_OOB);
+    o.c_m1 = buf_load(cbuf, lv && ss >= 1
+        ? (unsigned)((((long long)(off + (dir == 0 ? ss - 1 : sg + 1)) * nd + dir) * no + cell) * 4) : BUF_OOB);
+    return o;
+  };
+  Ops cur = ops_load(0);
+  float c_s = buf_load(cbuf, mine && 0 < T ? (unsigned)((((long long)(off + (dir == 0 ? T - 1 : 0)) * nd + dir) * no + cell) * 4) : BUF_OOB);
+  float dc_carry = 0.0f;
+  __syncthreads();
+
+  for (int sg = 0; sg < a.tmax; sg++) {
+    const bool live = mine && sg < T;
+    const int s = T - 1 - sg;
+    const long long n = off + (dir == 0 ? s : sg);
+    if (sg >= 1 && !xcd_poll(gcount, ntile * sg, a.sync + XcdSyncLayout::ERROR, flag, 2)) return;
+    f32x4 acc;
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = 0.0f;
+    const unsigned arow = (sg >= 1 && am < a.bs && sg < aT)
+        ? (unsigned)(((long long)(aoff + (dir == 0 ? aT - sg : sg - 1)) * nd + dir) * 4 * no) * 4u + klane : BUF_OOB_BASE;
+    // rounds of 8 groups, the next round's loads requested before this round's MFMAs
+    f32x4 ra[2][8];
+#pragma unroll
+    for (int g = 0; g < 8; g++) ra[0][g] = buf_load4_dev(dbuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+    SCHED_FENCE();
+    Ops nxt = ops_load(sg + 1);
+    SCHED_FENCE();
+    for (int r0 = 0; r0 < ngrp; r0 += 16) {
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int gb = r0 + half * 8;
+#pragma unroll
+        for (int g = 0; g < 8; g++) ra[half ^ 1][g] = buf_load4_dev(dbuf, gb + 8 + g < ngrp ? arow + (unsigned)(gb + 8 + g) * 64u : BUF_OOB);
+        SCHED_FENCE();
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+          const int gg = gb + g < ngrp ? gb + g : ngrp - 1;   // groups past the end multiply zero A rows
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(wrow + gg * 16);
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc = mfma16x16x4(ra[half][g][e], bv[e], acc);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * WIDE_LDW + (lane & 15)] = acc[q];
+    __syncthreads();
+    f32x4 dl;
+    if (live) {
+      float dh_rec = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WIDE_NW; w++) dh_rec += red[(w * 16 + ml) * WIDE_LDW + c16];
+      const float gi = cur.act[0], gf = cur.act[1], go = cur.act[2], ci = cur.act[3];
+      const float dh = cur.dh_in + dh_rec;
+      const float th = gate_act(c_s, true);
+      const float d_go = th * dh;
+      const float dc = (sg >= 1 ? dc_carry : 0.0f) + (-th * th + 1.0f) * (go * dh);
+      dc_carry = dc * gf;
+      const float d_gf = dc * cur.c_m1;
+      const float d_gi = dc * ci, d_ci = dc * gi;
+      dl[0] = (gi * (-gi + 1.0f)) * d_gi;
+      dl[1] = (gf * (-gf + 1.0f)) * d_gf;
+      dl[2] = (go * (-go + 1.0f)) * d_go;
+      dl[3] = (-ci * ci + 1.0f) * d_ci;
+      *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;   // next step's A operand of the whole group
+    }
+    c_s = cur.c_m1;
+    cur = nxt;
+    drain_vmem();
+    __syncthreads();
+    if (tid == 0 && sg + 1 < a.tmax) __hip_atomic_fetch_add(gcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // contraction padding of the packed weights
 inline int wide_kp_fwd(int no) { return ((no + 16 * WIDE_NW - 1) / (16 * WIDE_NW)) * 16 * WIDE_NW; }
 inline int wide_kp_bwd(int no) { return ((4 * no + 16 * WIDE_NW - 1) / (16 * WIDE_NW)) * 16 * WIDE_NW; }

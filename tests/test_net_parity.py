@@ -83,12 +83,14 @@ def test_bidi_uw3_shape_short(backend, ora32):
     (4, [7, 5], 4, [4, 6]),               # forced: two stacked layers
     (6, 21, 5, [3] * 18 + [5]),           # forced: 19 lines -> two 16-line blocks (MT = 2 forward tile)
 ])
-@pytest.mark.parametrize("coop", [True, False], ids=["cooperative", "per_step_launch"])
+@pytest.mark.parametrize("coop", ["coop", "steps", "xcd"], ids=["cooperative", "per_step_launch", "persistent_per_xcd"])
 def test_lockstep_recurrence_forced(backend, ora32, monkeypatch, ni, nh, nc, T, coop):
-    # the lock-step MFMA recurrence of lstm_wide.h on sizes the register-resident kernels also handle:
-    # once as ONE cooperative launch with grid barriers, once as one launch per time step
+    # the lock-step MFMA recurrence of lstm_wide.h on sizes the register-resident kernels also handle: as ONE
+    # cooperative launch with grid barriers, as one launch per time step, and as ONE persistent launch with a workgroup
+    # group per XCD (lstm_xcd_fwd_f32 / lstm_xcd_bwd_f32: the default for wide layers)
     monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
-    monkeypatch.setenv("CLSTM_COOP", "1" if coop else "0")
+    monkeypatch.setenv("CLSTM_COOP", "1" if coop == "coop" else "0")
+    monkeypatch.setenv("CLSTM_XCD_REC", "1" if coop == "xcd" else "0")
     run_case(backend, ora32, ni, nh, nc, T)
 
 
