@@ -811,6 +811,42 @@ DEVFN bool xcd_poll(int* word, int target, int* err, int* lds_flag, int code) {
   return ok;
 }
 
+// The per-step group barrier as STAMPS instead of a counter (CLSTM_XCD_STAMPS, default): an atomic arrival leaves the L2
+// (its line is dropped: the pollers' next look goes to memory, ~1 us); a plain store of "my tile has finished step s" into
+// the group's own 128-byte line stays in the XCD's L2, and the poller's lanes read all tiles' stamps with one L1-bypassing
+// load each.
+#ifndef CLSTM_XCD_STAMPS
+#define CLSTM_XCD_STAMPS 1
+#endif
+DEVFN void xcd_arrive(int* gwords, const int tile, const int step_done) {   // called by thread 0 behind drain + barrier
+  if (CLSTM_XCD_STAMPS) __hip_atomic_store(gwords + tile, step_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_fetch_add(gwords, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every tile of the group has finished `steps_done` steps
+DEVFN bool xcd_wait_group(int* gwords, const int ntile, const int steps_done, int* err, int* lds_flag) {
+  if (!CLSTM_XCD_STAMPS) return xcd_poll(gwords, ntile * steps_done, err, lds_flag, 2);
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    int spins = 0, bad = 0;
+    for (;;) {
+      const int v = lane < ntile ? __hip_atomic_load(gwords + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : steps_done;
+      if (wave_ballot(v < steps_done) == 0ull) break;
+      poll_pause();
+      if ((++spins & 63) == 0) {
+        bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!bad && spins > GRID_WATCHDOG_SPINS) { bad = 2; if (lane == 0) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        bad = wave_uniform(bad);
+        if (bad) break;
+      }
+    }
+    if (lane == 0) *lds_flag = bad;
+  }
+  __syncthreads();
+  const bool ok = *lds_flag == 0;
+  __syncthreads();
+  return ok;
+}
+
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a) {
   unsigned short* wl = dyn_smem<unsigned short>();                         // [64][XCD_LDW]
   float* red = reinterpret_cast<float*>(wl + 64 * XCD_LDW);                // [4][16][68]
@@ -883,7 +919,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   for (int sg = 0; sg < a.tmax; sg++) {
     const bool live = mine && sg < T;
     const long long n = off + (dir == 0 ? sg : T - 1 - sg);
-    if (sg >= 1 && !xcd_poll(gcount, ntile * sg, sync + XcdSyncLayout::ERROR, flag, 2)) return;   // h_{s-1} of the whole group is in the L2
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;   // h_{s-1} of the whole group is in the L2
     // ---- 16 lines x 64 columns, split-K over the four waves ----
     f32x4 acc[4];
 #pragma unroll
@@ -948,7 +984,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
     gx = gx_next;
     drain_vmem();
     __syncthreads();
-    if (tid == 0 && sg + 1 < a.tmax) __hip_atomic_fetch_add(gcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
   }
 }
 
@@ -1056,7 +1092,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
     bool live[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++) live[j] = minej[j] && sg < T;
-    if (sg >= 1 && !xcd_poll(gcount, ntile2 * sg, sync + XcdSyncLayout::ERROR, flag, 2)) return;
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile2, sg, sync + XcdSyncLayout::ERROR, flag)) return;
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++)
@@ -1113,7 +1149,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
     }
     drain_vmem();
     __syncthreads();
-    if (tid == 0 && sg + 1 < a.tmax) __hip_atomic_fetch_add(gcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, slot, sg + 1);
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       if (live[j]) *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cellj[j]) * 4) = dl[j];
@@ -1210,7 +1246,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a)
   for (int sg = 0; sg < a.tmax; sg++) {
     const bool live = mine && sg < T;
     const long long n = off + (dir == 0 ? sg : T - 1 - sg);
-    if (sg >= 1 && !xcd_poll(gcount, ntile * sg, a.sync + XcdSyncLayout::ERROR, flag, 2)) return;
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, a.sync + XcdSyncLayout::ERROR, flag)) return;
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -1269,7 +1305,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a)
     gx = gx_next;
     drain_vmem();
     __syncthreads();
-    if (tid == 0 && sg + 1 < a.tmax) __hip_atomic_fetch_add(gcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
   }
 }
 
@@ -1329,7 +1365,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a)
     const bool live = mine && sg < T;
     const int s = T - 1 - sg;
     const long long n = off + (dir == 0 ? s : sg);
-    if (sg >= 1 && !xcd_poll(gcount, ntile * sg, a.sync + XcdSyncLayout::ERROR, flag, 2)) return;
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, a.sync + XcdSyncLayout::ERROR, flag)) return;
     f32x4 acc;
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] = 0.0f;
@@ -1384,7 +1420,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a)
     cur = nxt;
     drain_vmem();
     __syncthreads();
-    if (tid == 0 && sg + 1 < a.tmax) __hip_atomic_fetch_add(gcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
   }
 }
 

@@ -234,6 +234,7 @@ inline int atomic_fetch_add_i32(int* p, int v) { return __atomic_fetch_add(p, v,
 inline int hw_xcc_id() { return (int)(blockIdx.x & 7u); }   // the dispatcher's round-robin placement
 inline int hw_cu_slot() { return 0; }
 #define __HIP_MEMORY_SCOPE_AGENT 0
+#define __HIP_MEMORY_SCOPE_WORKGROUP 1
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n(p, __ATOMIC_SEQ_CST)
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, __ATOMIC_SEQ_CST)
