@@ -139,8 +139,11 @@ int clstm_net_destroy(clstm_net* net);
  *   1           bf16 inputs, f32 accumulation (v_mfma_f32_16x16x32_bf16) in those GEMMs; the recurrence, softmax
  *               and CTC stay f32;
  *   2           1 + bf16 MFMA operands (recurrent weights, h, gate deltas) inside the lock-step recurrence of
- *               layers wider than 128 cells (csrc/lstm_wide.h: *_step_bf16) -- what BASELINE config "2 x BiLSTM(512), bf16
- *               MFMA" names; accumulation, cell state, softmax and CTC stay f32.  Not parity modes. */
+ *               layers wider than 128 cells (csrc/lstm_wide.h: lstm_xcd_*_bf16) -- what BASELINE config "2 x BiLSTM(512),
+ *               bf16 MFMA" names; accumulation, cell state, softmax and CTC stay f32.  Not parity modes.
+ * Layers wider than 128 cells run their recurrence as ONE persistent launch per pass in every mode (a workgroup group
+ * per XCD, csrc/lstm_wide.h; environment CLSTM_XCD_REC=0: one launch per time step); in modes 0 and 1 with f32 operands
+ * and results bit-identical to the per-step kernels. */
 int clstm_net_set_gemm_precision(clstm_net* net, int mode);
 int clstm_net_nparams(clstm_net* net);
 int clstm_net_buffers(clstm_net* net, float** params_d, float** derivs_d, float** grads_d);
