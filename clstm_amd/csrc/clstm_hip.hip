@@ -380,27 +380,41 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     const bool xcd_on = !allow_coop && !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
     static bool xcd_failed = false;   // the placement check failed once on this device: per-step launches from then on
     const int ntile = (no + 15) / 16;
-    if (!bf16 && xcd_on && !xcd_failed && tmax > 1 && a.ndir * nzb <= 8 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16) &&
+    // (minibatches of more than 8 / ndir line blocks: one launch per chunk of line blocks)
+    const int zb_per = std::max(1, 8 / a.ndir);
+    if (!bf16 && xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16) &&
         (size_t)xcd_fwd_f32_lds_bytes(a.kp) <= 160 * 1024) {
-      sync.reserve(XcdSyncLayout::WORDS);
-      a.sync = sync.p;
-      HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
-      const size_t smem = (size_t)xcd_fwd_f32_lds_bytes(a.kp);
-      coop_set_smem(lstm_xcd_fwd_f32, smem);
-      CLSTM_LAUNCH_COOP(lstm_xcd_fwd_f32, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
-      check_launch();
-      if (g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s)) return;
+      bool ok = true;
+      for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
+        a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
+        sync.reserve(XcdSyncLayout::WORDS);
+        a.sync = sync.p;
+        HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+        const size_t smem = (size_t)xcd_fwd_f32_lds_bytes(a.kp);
+        coop_set_smem(lstm_xcd_fwd_f32, smem);
+        CLSTM_LAUNCH_COOP(lstm_xcd_fwd_f32, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+        check_launch();
+        ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
+        REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
+      }
+      if (ok) return;
       xcd_failed = true;
     }
-    if (bf16 && xcd_on && !xcd_failed && tmax > 1 && a.ndir * nzb <= 8 && ntile <= 32 && a.kp16 <= 512 && 8 * ntile <= std::max(ncu, 16)) {
-      sync.reserve(XcdSyncLayout::WORDS);
-      a.sync = sync.p;
-      HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
-      const size_t smem = (size_t)xcd_fwd_lds_bytes();
-      coop_set_smem(lstm_xcd_fwd_bf16, smem);
-      CLSTM_LAUNCH_COOP(lstm_xcd_fwd_bf16, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
-      check_launch();
-      if (g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s)) return;
+    if (bf16 && xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && a.kp16 <= 512 && 8 * ntile <= std::max(ncu, 16)) {
+      bool ok = true;
+      for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
+        a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
+        sync.reserve(XcdSyncLayout::WORDS);
+        a.sync = sync.p;
+        HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+        const size_t smem = (size_t)xcd_fwd_lds_bytes();
+        coop_set_smem(lstm_xcd_fwd_bf16, smem);
+        CLSTM_LAUNCH_COOP(lstm_xcd_fwd_bf16, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+        check_launch();
+        ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
+        REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
+      }
+      if (ok) return;
       xcd_failed = true;   // workgroups were not spread evenly over the XCDs; nothing was written: run the per-step path
     }
     const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mt - 1) / (16 * mt));
@@ -432,34 +446,47 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     const bool xcd_on = !allow_coop && !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
     static bool xcd_failed = false;
     const int ntile = (no + 15) / 16;
-    if (!bf16 && xcd_on && !xcd_failed && tmax > 1 && a.ndir * nzb <= 8 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16) &&
+    const int zb_per = std::max(1, 8 / a.ndir);
+    if (!bf16 && xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16) &&
         (size_t)xcd_bwd_f32_lds_bytes(a.kp) <= 160 * 1024) {
-      sync.reserve(XcdSyncLayout::WORDS);
-      a.sync = sync.p;
-      HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
-      const size_t smem = (size_t)xcd_bwd_f32_lds_bytes(a.kp);
-      coop_set_smem(lstm_xcd_bwd_f32, smem);
-      CLSTM_LAUNCH_COOP(lstm_xcd_bwd_f32, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
-      check_launch();
-      if (g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s)) return;
+      bool ok = true;
+      for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
+        a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
+        sync.reserve(XcdSyncLayout::WORDS);
+        a.sync = sync.p;
+        HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+        const size_t smem = (size_t)xcd_bwd_f32_lds_bytes(a.kp);
+        coop_set_smem(lstm_xcd_bwd_f32, smem);
+        CLSTM_LAUNCH_COOP(lstm_xcd_bwd_f32, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+        check_launch();
+        ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
+        REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
+      }
+      if (ok) return;
       xcd_failed = true;
     }
-    if (bf16 && xcd_on && !xcd_failed && tmax > 1 && a.ndir * nzb <= 8 && ntile <= 32 && a.kp16 <= 2048 && 8 * ntile <= std::max(ncu, 16)) {
-      sync.reserve(XcdSyncLayout::WORDS);
-      a.sync = sync.p;
-      HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+    if (bf16 && xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && a.kp16 <= 2048 && 8 * ntile <= std::max(ncu, 16)) {
       static const int nt_env = getenv("CLSTM_XCD_BWD_NT") ? atoi(getenv("CLSTM_XCD_BWD_NT")) : 1;
-      if (nt_env >= 2 && ntile >= 2) {   // two 16-cell tiles per workgroup: half the delta traffic through each XCD's L2 (measured: no difference)
-        const size_t smem = (size_t)xcd_bwd_lds_bytes<2>();
-        coop_set_smem(lstm_xcd_bwd_bf16<2>, smem);
-        CLSTM_LAUNCH_COOP(lstm_xcd_bwd_bf16<2>, dim3(8 * ((ntile + 1) / 2)), dim3(WIDE_THREADS), smem, s, a);
-      } else {
-        const size_t smem = (size_t)xcd_bwd_lds_bytes<1>();
-        coop_set_smem(lstm_xcd_bwd_bf16<1>, smem);
-        CLSTM_LAUNCH_COOP(lstm_xcd_bwd_bf16<1>, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+      bool ok = true;
+      for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
+        a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
+        sync.reserve(XcdSyncLayout::WORDS);
+        a.sync = sync.p;
+        HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+        if (nt_env >= 2 && ntile >= 2) {   // two 16-cell tiles per workgroup: half the delta traffic through each XCD's L2 (measured: no difference)
+          const size_t smem = (size_t)xcd_bwd_lds_bytes<2>();
+          coop_set_smem(lstm_xcd_bwd_bf16<2>, smem);
+          CLSTM_LAUNCH_COOP(lstm_xcd_bwd_bf16<2>, dim3(8 * ((ntile + 1) / 2)), dim3(WIDE_THREADS), smem, s, a);
+        } else {
+          const size_t smem = (size_t)xcd_bwd_lds_bytes<1>();
+          coop_set_smem(lstm_xcd_bwd_bf16<1>, smem);
+          CLSTM_LAUNCH_COOP(lstm_xcd_bwd_bf16<1>, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+        }
+        check_launch();
+        ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
+        REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
       }
-      check_launch();
-      if (g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s)) return;
+      if (ok) return;
       xcd_failed = true;
     }
     const dim3 grid((no + 15) / 16, a.ndir, nzb);

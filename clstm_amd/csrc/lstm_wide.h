@@ -44,6 +44,7 @@ struct LstmWideArgs {
   int kp;               // padded contraction length, multiple of 64
   int step;             // lock-step index: forward own step s = step, backward own step s = T-1-step
   int tmax;             // cooperative kernels: number of lock-steps (longest line)
+  int zb0, zbn;         // persistent per-XCD kernels: this launch walks the 16-line blocks [zb0, zb0 + zbn), zbn * ndir <= 8
   int* sync;            // cooperative kernels: [0] barrier ticket counter (zeroed per launch), [1] watchdog flag
   // bf16 MFMA operands (per-step kernels lstm_wide_*_step_bf16; BASELINE config "2 x BiLSTM(512), bf16 MFMA"):
   const unsigned short* Rw16;   // the same weight rows as Rw, bf16, row length kp16
@@ -853,7 +854,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * 68);
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int no = a.no, nd = a.ndir;
-  const int ntile = (no + 15) >> 4, nzb = (a.bs + 15) >> 4, ngroups = nd * nzb, ncg = (no + 3) >> 2;
+  const int ntile = (no + 15) >> 4, nzb = a.zbn, ngroups = nd * nzb, ncg = (no + 3) >> 2;
   int* const sync = a.sync;
   // ---- claim a tile of this XCD's group, then check the placement of the whole grid ----
   const int xcd = hw_xcc_id() & 7;
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   __syncthreads();
   if (flag[0] != 0) return;                       // uneven placement: nothing has been written yet
   if (xcd >= ngroups || ct >= ntile) return;      // spare workgroup
-  const int dir = xcd % nd, zb = xcd / nd;
+  const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
   int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
 
   // ---- the tile's 64 weight rows: cell groups 4ct .. 4ct+3 of this direction, 16 rows (cell_local*4 + gate) each ----
@@ -1009,7 +1010,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
   int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * LDR);
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int no = a.no, nd = a.ndir;
-  const int ntile = (no + 15) >> 4, ntile2 = (ntile + NT - 1) / NT, nzb = (a.bs + 15) >> 4, ngroups = nd * nzb;
+  const int ntile = (no + 15) >> 4, ntile2 = (ntile + NT - 1) / NT, nzb = a.zbn, ngroups = nd * nzb;
   int* const sync = a.sync;
   const int xcd = hw_xcc_id() & 7;
   if (tid == 0) {
@@ -1029,7 +1030,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
   __syncthreads();
   if (flag[0] != 0) return;
   if (xcd >= ngroups || slot >= ntile2) return;
-  const int dir = xcd % nd, zb = xcd / nd;
+  const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
   int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
   {
     const int c8 = a.kp16 >> 3;
@@ -1203,10 +1204,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a)
   int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * 68);
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int no = a.no, nd = a.ndir;
-  const int ntile = (no + 15) >> 4, nzb = (a.bs + 15) >> 4, ncg = (no + 3) >> 2;
+  const int ntile = (no + 15) >> 4, nzb = a.zbn, ncg = (no + 3) >> 2;
   int xcd, ct;
   if (!xcd_claim(a.sync, flag, ntile, nd * nzb, xcd, ct)) return;
-  const int dir = xcd % nd, zb = xcd / nd;
+  const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
   int* const gcount = a.sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
   {
     const int k4 = a.kp >> 2;
@@ -1316,10 +1317,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a)
   int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * WIDE_LDW);
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int no = a.no, nd = a.ndir;
-  const int ntile = (no + 15) >> 4, nzb = (a.bs + 15) >> 4;
+  const int ntile = (no + 15) >> 4, nzb = a.zbn;
   int xcd, ct;
   if (!xcd_claim(a.sync, flag, ntile, nd * nzb, xcd, ct)) return;
-  const int dir = xcd % nd, zb = xcd / nd;
+  const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
   int* const gcount = a.sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
   {
     const int k4 = a.kp >> 2;

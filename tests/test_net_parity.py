@@ -94,6 +94,16 @@ def test_lockstep_recurrence_forced(backend, ora32, monkeypatch, ni, nh, nc, T, 
     run_case(backend, ora32, ni, nh, nc, T)
 
 
+def test_lockstep_persistent_chunks(backend, ora32, monkeypatch):
+    # 70 ragged lines = five 16-line blocks: with two directions the persistent per-XCD launch walks them as two chunks
+    # (four blocks + one); smaller weights and learning rate than the other cases -- with 70 lines of gradient sums the
+    # update check's absolute floor (1e-7) is below lr x the gradient's own 1e-4 tolerance
+    monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
+    monkeypatch.setenv("CLSTM_COOP", "0")
+    monkeypatch.setenv("CLSTM_XCD_REC", "1")
+    run_case(backend, ora32, 4, 20, 4, [1 + (7 * i) % 5 for i in range(70)], scale=8.0, lr=1e-3)
+
+
 def test_lockstep_recurrence_nhidden_over_128(backend, ora32):
     # nhidden > 128 takes the lock-step path by itself (BASELINE config 2 x BiLSTM(512) shape family)
     T = [2, 1] if backend.kind == "emu" else [37, 50, 11]
