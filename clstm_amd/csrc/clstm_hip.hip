@@ -350,8 +350,10 @@ struct XcdOutcome {
   }
 };
 static XcdOutcome g_xcd_outcome;
+static bool g_wide_persistent = false;   // the last launch_lstm_wide call ran the persistent per-XCD kernels
 
 static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s, bool bf16 = false) {
+  g_wide_persistent = false;
   REQUIRE((double)a.N * a.ndir * 4 * a.no * 4 < 2147483000.0,
           "minibatch too large for the lock-step recurrence (frames x 4 x nhidden x ndir x 4 B must stay below 2 GiB)");
   const int no = a.no;
@@ -397,7 +399,7 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
         ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
         REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
       }
-      if (ok) return;
+      if (ok) { g_wide_persistent = true; return; }
       xcd_failed = true;
     }
     if (bf16 && xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && a.kp16 <= 512 && 8 * ntile <= std::max(ncu, 16)) {
@@ -414,7 +416,7 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
         ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
         REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
       }
-      if (ok) return;
+      if (ok) { g_wide_persistent = true; return; }
       xcd_failed = true;   // workgroups were not spread evenly over the XCDs; nothing was written: run the per-step path
     }
     const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mt - 1) / (16 * mt));
@@ -462,7 +464,7 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
         ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
         REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
       }
-      if (ok) return;
+      if (ok) { g_wide_persistent = true; return; }
       xcd_failed = true;
     }
     if (bf16 && xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && a.kp16 <= 2048 && 8 * ntile <= std::max(ncu, 16)) {
@@ -486,7 +488,7 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
         ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
         REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
       }
-      if (ok) return;
+      if (ok) { g_wide_persistent = true; return; }
       xcd_failed = true;
     }
     const dim3 grid((no + 15) / 16, a.ndir, nzb);
@@ -609,6 +611,8 @@ struct Layer {
   DevBuf<unsigned short> Hb, Db;
   long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
   DevBuf<float> G, C, H, D, dH, S;
+  DevBuf<unsigned short> Dbf;  // per-frame bf16 gate deltas written by the persistent backward kernel (A operand of the x.d GEMM)
+  DevBuf<unsigned short> Wtb;  // bf16 copy of Wt ([ni][M], k = gate column contiguous): B operand of the bf16-source x.d product
   DevBuf<float> pdw;          // split-K slabs of this layer's weight-gradient product when it runs on the side stream
   int lds = 0;
   int wt_slack = 32;          // floats past Wt a vectorised staging load may touch
@@ -790,6 +794,10 @@ struct Net {
                      y.pd, y.kpf, y.kpb);
       CLSTM_LAUNCH(k_pack_layer, dim3(nblocks((size_t)(1 + y.ni) * M + 2 * nr)), dim3(256), 0, s, (const float*)v, y.Wt,
                    y.bias, y.Rf, y.Rb, y.pd);
+      if (y.wide && bf16_rec) {   // bf16 copy of W_x^T for the bf16-source x.d product
+        y.Wtb.reserve((size_t)y.ni * M + 64);
+        CLSTM_LAUNCH(k_to_bf16, dim3(nblocks((size_t)y.ni * M)), dim3(256), 0, s, (const float*)y.Wt, y.Wtb.p, (size_t)y.ni * M);
+      }
     }
     check_launch();
     packed_dirty = false;
@@ -864,6 +872,7 @@ struct Net {
       w.kp16 = fwd ? wide_kp16_fwd(y.no) : wide_kp16_bwd(y.no);
       w.rw_elems = (long long)ndir * (fwd ? (y.no + 3) / 4 : (y.no + 15) / 16) * 16 * w.kp16;
       w.Hb = y.Hb.p; w.Db = y.Db.p;
+      if (!fwd && wide_kp16_bwd(y.no) == 4 * y.no) { y.Dbf.reserve((size_t)N * ndir * w.kp16 + 64); w.Dbf = y.Dbf.p; }
     }
     return w;
   }
@@ -1241,6 +1250,7 @@ struct Net {
       // (both directions in one batched launch: half the slabs per direction fill the chip)
       const int R = 1 + y.ni + y.no, Cn = 4 * y.no;
       int ns;
+      bool bwd_persistent = false;
       a.prog_off = -1; a.prog_base = 0;
       if (!bf16_gemm && overlap_eligible(y)) {
         // the recurrence and the weight-gradient GEMM run side by side (gemm_dw.h)
@@ -1252,6 +1262,7 @@ struct Net {
       if (y.wide) launch_lstm_wide(false, wide_args(y, false), tmax, coop_sync, step_graphs, s, bf16_rec);
       else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
+      bwd_persistent = y.wide && g_wide_persistent;
       ns = bf16_gemm && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
       }
       // (Experiment, off by default.)  Stacked lock-step layers in bf16: the weight-gradient product of layer l (~1 ms at 2 x BiLSTM(512)) depends only on
@@ -1289,7 +1300,12 @@ struct Net {
         else if (want_dx0) { dX0.reserve((size_t)N * y.ni); dx = dX0.p; }
         if (!dx) return;
         timing.begin("gemm_gates_dx", s);
-        if (bf16_gemm)
+        static const bool b16src = !(getenv("CLSTM_GEMM_B16SRC") && atoi(getenv("CLSTM_GEMM_B16SRC")) == 0);
+        if (b16src && bf16_gemm && bf16_rec && bwd_persistent && wide_kp16_bwd(y.no) == 4 * y.no && y.Wtb.p && y.Dbf.p)
+          // the persistent recurrence left the deltas as a k-contiguous bf16 array: both operands go to LDS as they are
+          gemm_b16kk(s, GemmOperand16{y.Dbf.p, M, (long long)N * M}, GemmOperand16{y.Wtb.p, M, (long long)y.ni * M},
+                     StorePlain{dx, y.ni}, (int)N, y.ni, M);
+        else if (bf16_gemm)
           gemm_bf16<GEMM_KC, GEMM_KC>(s, gemm_kc(y.D.p, M, N, 32), gemm_kc(y.Wt, M, y.ni, y.wt_slack), StorePlain{dx, y.ni},
                                       (int)N, y.ni, M);
         else
@@ -2084,6 +2100,9 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     gemm_bf16<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
                  (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0);
+  } else if (mode == 30) {   // A: [R][K] bf16, B: [Cn][K] bf16 (the caller passes halfs in float-typed pointers)
+    gemm_b16kk(g_stream, GemmOperand16{(const unsigned short*)A, K, (long long)R * K}, GemmOperand16{(const unsigned short*)B, K, (long long)Cn * K},
+               StorePlain{Cm, Cn}, R, Cn, K);
   } else if (mode == 20) gemm_x3<GEMM_KC, GEMM_MC>(g_stream, gemm_kc(A, K, R, 0), gemm_mc(B, Cn, K, 0), StorePlain{Cm, Cn}, R, Cn, K);
   else if (mode == 21) gemm_x3<GEMM_KC, GEMM_KC>(g_stream, gemm_kc(A, K, R, 0), gemm_kc(B, K, Cn, 0), StorePlain{Cm, Cn}, R, Cn, K);
   else if (mode == 22) {

@@ -315,6 +315,120 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
       }
 }
 
+// ---- 128 x 128 tile, BOTH operands already bf16 and k-contiguous in memory ------------------------------------------
+//   out(r, c) = sum_k A16[r * lda + k] * B16[c * ldb + k]
+// What the f32-source kernel spends most of its time on -- 15 GB of f32 operands through the L2s per configs[4] step, the
+// conversion, the transposing LDS writes -- does not exist here: a thread moves 2 x 16 bytes (16 k) per operand and
+// block straight from memory into the swizzled LDS image (ds_write_b128, conflict-free).  Used where a producer can leave
+// a bf16 k-contiguous copy of its output at no extra cost (the persistent recurrence's delta ring IS that array) and
+// for the weight operand (packed once per update).  No split-K, no batch: the products it serves have K <= 4096.
+struct GemmOperand16 { const unsigned short* p; int ld; long long elems; };   // ld, elems in halfs (ld even)
+template <class FE>
+__global__ __launch_bounds__(256, 2) void gemm_b16kk_128_kernel(GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[2 * GB2_TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * GB2_TILE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int bx, by;
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy;
+    const unsigned lin = blockIdx.x + gx * blockIdx.y;
+    const unsigned xcd = lin & 7u, idx = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = (int)(v % gx);
+    by = (int)(v / gx);
+  }
+  const int r0 = by * GB2_BT, c0 = bx * GB2_BT;
+  const int s_mn = tid >> 1, s_k = (tid & 1) * 16;   // row of the tile, first of its 16 k
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(A.p), (size_t)A.elems * 2);
+  const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(B.p), (size_t)B.elems * 2);
+  const unsigned aoff = ((unsigned)(r0 + s_mn) * (unsigned)A.ld + (unsigned)s_k) * 2u;
+  const unsigned boff = ((unsigned)(c0 + s_mn) * (unsigned)B.ld + (unsigned)s_k) * 2u;
+  const int klast = ((K - 1) / GB_BK) * GB_BK;
+  f32x4 ra[GB2_PF][2], rb[GB2_PF][2];
+  auto load_tile = [&](int k0, f32x4 (&a)[2], f32x4 (&b)[2]) {
+    const unsigned kc = (unsigned)wave_uniform(k0 < klast ? k0 : klast) * 2u;
+    a[0] = buf_load4(abuf, aoff + kc);
+    a[1] = buf_load4(abuf, aoff + kc + 16u);
+    b[0] = buf_load4(bbuf, boff + kc);
+    b[1] = buf_load4(bbuf, boff + kc + 16u);
+  };
+  auto stage = [&](unsigned short* S, const int k0, const f32x4 (&r)[2]) {
+    const bool whole = wave_uniform(k0 + GB_BK <= K ? 1 : 0) != 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      u16x8 v = __builtin_bit_cast(u16x8, r[h]);
+      if (!whole) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = (k0 + s_k + 8 * h + i < K) ? v[i] : (unsigned short)0;
+      }
+      *reinterpret_cast<u16x8*>(&S[s_mn * GB2_LDH + ((((s_k >> 3) + h) ^ gb2_sw(s_mn)) << 3)]) = v;
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+#pragma unroll
+  for (int p = 0; p < GB2_PF; p++) {
+    load_tile(p * GB_BK, ra[p], rb[p]);
+    SCHED_FENCE();
+  }
+  stage(As, 0, ra[0]);
+  stage(Bs, 0, rb[0]);
+  load_tile(GB2_PF * GB_BK, ra[0], rb[0]);
+  SCHED_FENCE();
+  __syncthreads();
+  const int fk = lane >> 4, fi = lane & 15;
+  const int fsw = (fk ^ gb2_sw(fi)) << 3;
+  int cur = 0;
+  for (int kb = 0; kb < K; kb += GB2_PF * GB_BK) {
+#pragma unroll
+    for (int p = 0; p < GB2_PF; p++) {
+      const int k0 = kb + p * GB_BK;
+      const int pn = p == GB2_PF - 1 ? 0 : p + 1;
+      stage(As + (cur ^ GB2_TILE), k0 + GB_BK, ra[pn]);
+      stage(Bs + (cur ^ GB2_TILE), k0 + GB_BK, rb[pn]);
+      load_tile(k0 + GB_BK + GB2_PF * GB_BK, ra[pn], rb[pn]);
+      SCHED_FENCE();
+      u16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        af[i] = *reinterpret_cast<const u16x8*>(&As[cur + (wm * 64 + i * 16 + fi) * GB2_LDH + fsw]);
+        bf[i] = *reinterpret_cast<const u16x8*>(&Bs[cur + (wn * 64 + i * 16 + fi) * GB2_LDH + fsw]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(af[i], bf[j], acc[i][j]);
+      __syncthreads();
+      cur ^= GB2_TILE;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = r0 + wm * 64 + i * 16 + (lane >> 4) * 4 + q;
+        const int c = c0 + wn * 64 + j * 16 + (lane & 15);
+        if (r < R && c < Cn) fe(r, c, acc[i][j][q], 0);
+      }
+}
+template <class FE>
+inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K) {
+  if (R <= 0 || Cn <= 0 || K <= 0) return;
+  dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, 1);
+  CLSTM_LAUNCH((gemm_b16kk_128_kernel<FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K);
+}
+
 // ---- f32-grade products on the bf16 MFMA: 64 x 64 tile, operands split hi + lo ------------------------------------------
 // Same interface as gemm_f32_body (gemm_mfma.h) and -- to ~1e-6 of a product, see gemm_dw.h -- the same result:
 // every f32 operand element is staged as hi = bf16(x) and lo = bf16(x - hi), a product is hi.hi + hi.lo + lo.hi on

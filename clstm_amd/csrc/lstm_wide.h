@@ -50,6 +50,7 @@ struct LstmWideArgs {
   const unsigned short* Rw16;   // the same weight rows as Rw, bf16, row length kp16
   unsigned short* Hb;           // [N][nd][kp16]  bf16 copy of h (forward A operand), pad columns stay zero
   unsigned short* Db;           // [N][nd][kp16]  bf16 copy of the gate deltas at column 4*cell+gate (backward A operand)
+  unsigned short* Dbf;          // persistent backward kernel: per-frame [N][nd][kp16] bf16 deltas (operand of the x.d GEMM), or null
   int kp16;                     // padded contraction length of the bf16 rows, multiple of 32 * WIDE_NW
 };
 
@@ -1153,7 +1154,14 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
     if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, slot, sg + 1);
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-      if (live[j]) *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cellj[j]) * 4) = dl[j];
+      if (live[j]) {
+        *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cellj[j]) * 4) = dl[j];
+        if (a.Dbf) {   // k-contiguous bf16 copy per frame: the ready-made A operand of the x.d product (gemm_b16kk)
+          unsigned* df = reinterpret_cast<unsigned*>(a.Dbf + (size_t)(n * nd + dir) * a.kp16 + 4 * cellj[j]);
+          df[0] = bf16_pack2(dl[j][0], dl[j][1]);
+          df[1] = bf16_pack2(dl[j][2], dl[j][3]);
+        }
+      }
       c_s[j] = cur[j].c_m1;
       cur[j] = nxt[j];
     }

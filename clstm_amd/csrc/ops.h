@@ -401,6 +401,11 @@ __global__ void k_ingest(const float* x, float* X, float* S, size_t N, int ni, i
     for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = v;
   }
 }
+// bf16 copy of an f32 array (weight operands of the bf16-source GEMM, gemm_bf16.h)
+__global__ void k_to_bf16(const float* src, unsigned short* dst, size_t n) {
+  CLSTM_GRID_STRIDE(e, n) dst[e] = (unsigned short)(bf16_pack2(src[e], 0.0f) & 0xFFFFu);
+}
+
 // k_ingest and the first layer's k_pack_layer in ONE launch (a single narrow layer whose parameters changed since
 // the last pack -- every training step): blocks [0, nbi) ingest, the rest repack.  The two jobs are independent
 // and each is far too small to fill the chip, so one launch ramp / tail instead of two.

@@ -100,3 +100,29 @@ def test_device_activations(backend):
         y = backend.up(x)
         backend.lib.call("clstm_forward_nonlin0", ptr(y), x.size, nl)
         assert_close(backend.down(y), f(x.astype(np.float64)), rtol=1e-5, atol=1e-30, what="nl %d" % nl)
+
+
+def _bf16_bits(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return u.astype(np.uint16)
+
+
+@pytest.mark.parametrize("R,Cn,K", [(128, 128, 32), (256, 256, 64), (97, 200, 30), (300, 130, 1000), (129, 513, 96)])
+def test_gemm_bf16_sources(backend, R, Cn, K):
+    """128 x 128-tile GEMM whose operands are ALREADY bf16 and k-contiguous in memory (gemm_b16kk_128_kernel): exact
+    against the float64 product of the same bf16 values (f32 accumulation: 2e-6 of sum |a||b|)."""
+    rng = np.random.default_rng(R + Cn + K)
+    A = rng.normal(size=(R, K)).astype(np.float32)
+    B = rng.normal(size=(Cn, K)).astype(np.float32)
+    Ab, Bb = _bf16_bits(A), _bf16_bits(B)
+    Af = (Ab.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    Bf = (Bb.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    want = Af @ Bf.T
+    Ad = backend.up(Ab, dtype=np.uint16)
+    Bd = backend.up(Bb, dtype=np.uint16)
+    Cd = backend.zeros((R, Cn))
+    backend.lib.call("clstm_debug_gemm", 30, ptr(Ad), ptr(Bd), ptr(Cd), R, Cn, K, 1)
+    got = backend.down(Cd)
+    scale = np.abs(Af) @ np.abs(Bf).T
+    assert (np.abs(got - want) <= 2e-6 * scale + 1e-6).all()
