@@ -611,6 +611,9 @@ struct Layer {
   DevBuf<unsigned short> Hb, Db;
   long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
   DevBuf<float> G, C, H, D, dH, S;
+  DevBuf<unsigned short> Hbf;  // per-frame bf16 h of both directions written by the persistent forward kernel (A operand of the next layer's W_x product)
+  DevBuf<unsigned short> WtbT; // bf16 W_x, k-contiguous ([M][ni]): B operand of that product
+  bool fwd_persistent = false; // this forward pass ran the persistent kernel (Hbf is valid)
   DevBuf<unsigned short> Dbf;  // per-frame bf16 gate deltas written by the persistent backward kernel (A operand of the x.d GEMM)
   DevBuf<unsigned short> Wtb;  // bf16 copy of Wt ([ni][M], k = gate column contiguous): B operand of the bf16-source x.d product
   DevBuf<float> pdw;          // split-K slabs of this layer's weight-gradient product when it runs on the side stream
@@ -797,6 +800,8 @@ struct Net {
       if (y.wide && bf16_rec) {   // bf16 copy of W_x^T for the bf16-source x.d product
         y.Wtb.reserve((size_t)y.ni * M + 64);
         CLSTM_LAUNCH(k_to_bf16, dim3(nblocks((size_t)y.ni * M)), dim3(256), 0, s, (const float*)y.Wt, y.Wtb.p, (size_t)y.ni * M);
+        y.WtbT.reserve((size_t)y.ni * M + 64);
+        CLSTM_LAUNCH(k_transpose_to_bf16, dim3(nblocks((size_t)y.ni * M)), dim3(256), 0, s, (const float*)y.Wt, y.WtbT.p, y.ni, M);
       }
     }
     check_launch();
@@ -873,6 +878,7 @@ struct Net {
       w.rw_elems = (long long)ndir * (fwd ? (y.no + 3) / 4 : (y.no + 15) / 16) * 16 * w.kp16;
       w.Hb = y.Hb.p; w.Db = y.Db.p;
       if (!fwd && wide_kp16_bwd(y.no) == 4 * y.no) { y.Dbf.reserve((size_t)N * ndir * w.kp16 + 64); w.Dbf = y.Dbf.p; }
+      if (fwd && (y.no & 1) == 0 && &y != &L.back()) { y.Hbf.reserve((size_t)N * ndir * y.no + 64); w.Hbf = y.Hbf.p; w.hbf_ld = ndir * y.no; }
     }
     return w;
   }
@@ -887,7 +893,12 @@ struct Net {
       Layer& y = L[l];
       const int M = ndir * 4 * y.no;
       timing.begin("gemm_gates_x", s);
-      if (bf16_gemm)
+      static const bool b16src = !(getenv("CLSTM_GEMM_B16SRC") && atoi(getenv("CLSTM_GEMM_B16SRC")) == 0);
+      if (b16src && bf16_gemm && bf16_rec && l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.WtbT.p && y.ni == ndir * L[l - 1].no && (y.ni & 1) == 0)
+        // the layer below left its outputs as a k-contiguous bf16 array: both operands go to LDS as they are
+        gemm_b16kk(s, GemmOperand16{L[l - 1].Hbf.p, y.ni, (long long)N * y.ni}, GemmOperand16{y.WtbT.p, y.ni, (long long)M * y.ni},
+                   StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
+      else if (bf16_gemm)
         gemm_bf16<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N, layer_input_slack(l)),
                                     gemm_mc(y.Wt, M, y.ni, y.wt_slack), StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
       else if (gemm_x3_fwd)
@@ -917,7 +928,7 @@ struct Net {
       lstm_prof.reserve(64); a.prof = lstm_prof.p;
 #endif
       timing.begin("lstm_fwd", s);
-      if (y.wide) launch_lstm_wide(true, wide_args(y, true), tmax, coop_sync, step_graphs, s, bf16_rec);
+      if (y.wide) { launch_lstm_wide(true, wide_args(y, true), tmax, coop_sync, step_graphs, s, bf16_rec); y.fwd_persistent = g_wide_persistent && bf16_rec; }
       else launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
     }

@@ -50,6 +50,8 @@ struct LstmWideArgs {
   const unsigned short* Rw16;   // the same weight rows as Rw, bf16, row length kp16
   unsigned short* Hb;           // [N][nd][kp16]  bf16 copy of h (forward A operand), pad columns stay zero
   unsigned short* Db;           // [N][nd][kp16]  bf16 copy of the gate deltas at column 4*cell+gate (backward A operand)
+  unsigned short* Hbf;          // persistent forward kernel: per-frame [N][hbf_ld] bf16 copy of h (dir d at column d*no): the next
+  int hbf_ld;                   //   layer's W_x product reads it as its k-contiguous A operand; or null
   unsigned short* Dbf;          // persistent backward kernel: per-frame [N][nd][kp16] bf16 deltas (operand of the x.d GEMM), or null
   int kp16;                     // padded contraction length of the bf16 rows, multiple of 32 * WIDE_NW
 };
@@ -976,9 +978,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
       if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
     }
     const float hn = quad_xor1(h);
-    if (live && !(c16 & 1))
-      *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) =
-          bf16_pack2(h, cell + 1 < no ? hn : 0.0f);
+    if (live && !(c16 & 1)) {
+      const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);
+      *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) = hp;
+      if (a.Hbf) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
+    }
     // publish: every store of this workgroup acknowledged by the L2, then one arrival on the group's counter.  (Storing
     // the bf16 h first and the other arrays behind the arrival was measured SLOWER, 3.5 vs 3.2 us per step: VMEM
     // completes in order, so the next step's operand loads then wait behind those stores.)

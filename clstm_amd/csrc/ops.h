@@ -406,6 +406,14 @@ __global__ void k_to_bf16(const float* src, unsigned short* dst, size_t n) {
   CLSTM_GRID_STRIDE(e, n) dst[e] = (unsigned short)(bf16_pack2(src[e], 0.0f) & 0xFFFFu);
 }
 
+// dst[c][k] = bf16(src[k][c]): the k-contiguous bf16 form of W_x ([ni][M] -> [M][ni]) for the bf16-source W_x.x product
+__global__ void k_transpose_to_bf16(const float* src, unsigned short* dst, int rows, int cols) {
+  CLSTM_GRID_STRIDE(e, (size_t)rows * cols) {
+    const int c = (int)(e / rows), k = (int)(e % rows);
+    dst[e] = (unsigned short)(bf16_pack2(src[(size_t)k * cols + c], 0.0f) & 0xFFFFu);
+  }
+}
+
 // k_ingest and the first layer's k_pack_layer in ONE launch (a single narrow layer whose parameters changed since
 // the last pack -- every training step): blocks [0, nbi) ingest, the rest repack.  The two jobs are independent
 // and each is far too small to fill the chip, so one launch ramp / tail instead of two.
