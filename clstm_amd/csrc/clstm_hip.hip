@@ -154,6 +154,7 @@ struct StoreBias {  // out[r*ld + c] = val + bias[c]
     *reinterpret_cast<f32x4*>(out + (long long)r * ld + c) = o;
   }
 };
+static long long g_path_count[8];   // clstm_debug_path_count (diagnostics)
 struct StorePlain {
   float* out; long long ld;
   DEVMFN void operator()(int r, int c, float v, int) const { out[(long long)r * ld + c] = v; }
@@ -167,6 +168,10 @@ struct StorePartial {  // split-K slabs [z][R][Cn]
   DEVMFN void row4(int r, int c, f32x4 v, int z) const {
     *reinterpret_cast<f32x4*>(out + ((long long)z * R + r) * Cn + c) = v;
   }
+};
+struct StorePartialRot {  // split-K slabs whose operand rows were ordered [x | h | 1]: row r lands in row (r + 1) mod R of [1 | x | h]
+  float* out; int R, Cn;
+  DEVMFN void operator()(int r, int c, float v, int z) const { out[((long long)z * R + (r + 1 == R ? 0 : r + 1)) * Cn + c] = v; }
 };
 #ifndef GEMM_BK_DW
 #define GEMM_BK_DW 16   // frames staged per barrier pair in the weight-gradient GEMM (32 measured slower: 61.1 vs 58.3 us)
@@ -614,6 +619,8 @@ struct Layer {
   DevBuf<unsigned short> Hbf;  // per-frame bf16 h of both directions written by the persistent forward kernel (A operand of the next layer's W_x product)
   DevBuf<unsigned short> WtbT; // bf16 W_x, k-contiguous ([M][ni]): B operand of that product
   bool fwd_persistent = false; // this forward pass ran the persistent kernel (Hbf is valid)
+  DevBuf<unsigned short> Sbf;  // bf16 source rows [x | h_{t-1} | 1] per direction (x: k_source_x_bf16, h: the persistent forward kernel)
+  bool sbf_ready = false;      // ... complete for this forward pass
   DevBuf<unsigned short> Dbf;  // per-frame bf16 gate deltas written by the persistent backward kernel (A operand of the x.d GEMM)
   DevBuf<unsigned short> Wtb;  // bf16 copy of Wt ([ni][M], k = gate column contiguous): B operand of the bf16-source x.d product
   DevBuf<float> pdw;          // split-K slabs of this layer's weight-gradient product when it runs on the side stream
@@ -770,7 +777,7 @@ struct Net {
     for (auto& y : L) {
       (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff);
       (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release();
-      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release();
+      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false;
     }
     if (own_v) (void)hipFree(v);
     if (own_d) (void)hipFree(d);
@@ -878,6 +885,12 @@ struct Net {
       w.rw_elems = (long long)ndir * (fwd ? (y.no + 3) / 4 : (y.no + 15) / 16) * 16 * w.kp16;
       w.Hb = y.Hb.p; w.Db = y.Db.p;
       if (!fwd && wide_kp16_bwd(y.no) == 4 * y.no) { y.Dbf.reserve((size_t)N * ndir * w.kp16 + 64); w.Dbf = y.Dbf.p; }
+      static const bool b16mc_on = !(getenv("CLSTM_GEMM_B16MC") && atoi(getenv("CLSTM_GEMM_B16MC")) == 0);
+      if (fwd && b16mc_on && bf16_gemm && (y.ni & 7) == 0 && (y.no & 7) == 0 && wide_kp16_bwd(y.no) == 4 * y.no) {
+        const int ldsb = y.ni + y.no + 8;
+        y.Sbf.reserve((size_t)N * ndir * ldsb + 64);
+        w.Sbf = y.Sbf.p; w.sbf_ld = ldsb; w.sbf_ofs = y.ni; w.sbf_dir = (long long)N * ldsb;
+      }
       if (fwd && (y.no & 1) == 0 && &y != &L.back()) { y.Hbf.reserve((size_t)N * ndir * y.no + 64); w.Hbf = y.Hbf.p; w.hbf_ld = ndir * y.no; }
     }
     return w;
@@ -895,10 +908,12 @@ struct Net {
       timing.begin("gemm_gates_x", s);
       static const bool b16src = !(getenv("CLSTM_GEMM_B16SRC") && atoi(getenv("CLSTM_GEMM_B16SRC")) == 0);
       if (b16src && bf16_gemm && bf16_rec && l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.WtbT.p && y.ni == ndir * L[l - 1].no && (y.ni & 1) == 0)
+      {
         // the layer below left its outputs as a k-contiguous bf16 array: both operands go to LDS as they are
+        g_path_count[2]++;
         gemm_b16kk(s, GemmOperand16{L[l - 1].Hbf.p, y.ni, (long long)N * y.ni}, GemmOperand16{y.WtbT.p, y.ni, (long long)M * y.ni},
                    StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
-      else if (bf16_gemm)
+      } else if (bf16_gemm)
         gemm_bf16<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N, layer_input_slack(l)),
                                     gemm_mc(y.Wt, M, y.ni, y.wt_slack), StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
       else if (gemm_x3_fwd)
@@ -928,7 +943,18 @@ struct Net {
       lstm_prof.reserve(64); a.prof = lstm_prof.p;
 #endif
       timing.begin("lstm_fwd", s);
-      if (y.wide) { launch_lstm_wide(true, wide_args(y, true), tmax, coop_sync, step_graphs, s, bf16_rec); y.fwd_persistent = g_wide_persistent && bf16_rec; }
+      if (y.wide) {
+        const LstmWideArgs w = wide_args(y, true);
+        launch_lstm_wide(true, w, tmax, coop_sync, step_graphs, s, bf16_rec);
+        y.fwd_persistent = g_wide_persistent && bf16_rec;
+        if (g_wide_persistent) g_path_count[0]++;
+        y.sbf_ready = y.fwd_persistent && w.Sbf;
+        if (y.sbf_ready) {   // the non-recurrent columns of the bf16 source rows (the recurrence stored the h columns)
+          const bool from16 = l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.ni == ndir * L[l - 1].no;
+          CLSTM_LAUNCH(k_source_x_bf16, dim3(nblocks((size_t)N * ((y.ni >> 3) + 1))), dim3(256), 0, s, y.Sbf.p, from16 ? nullptr : layer_input(l),
+                       from16 ? L[l - 1].Hbf.p : nullptr, from16 ? y.ni : layer_input_ld(l), (size_t)N, y.ni, y.ni + y.no, w.sbf_ld, ndir, w.sbf_dir);
+        }
+      }
       else launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
     }
@@ -1274,6 +1300,7 @@ struct Net {
       else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
       bwd_persistent = y.wide && g_wide_persistent;
+      if (bwd_persistent) g_path_count[1]++;
       ns = bf16_gemm && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
       }
       // (Experiment, off by default.)  Stacked lock-step layers in bf16: the weight-gradient product of layer l (~1 ms at 2 x BiLSTM(512)) depends only on
@@ -1287,7 +1314,14 @@ struct Net {
         if (bf16_gemm || !overlap_eligible(y)) {
           pbuf.reserve((size_t)ndir * ns * R * Cn);
           timing.begin("gemm_gates_dw", q);
-          if (bf16_gemm)
+          if (bf16_gemm && bf16_rec && bwd_persistent && y.sbf_ready && y.Dbf.p && gemm_bf16_big(R, Cn)) {
+            // both operands bf16 as their producers left them (deltas: the persistent backward recurrence; sources: the
+            // forward pass), transposed by the LDS on the way into the MFMA
+            const int ldsb = y.ni + y.no + 8;
+            g_path_count[4]++;
+            gemm_b16mc(q, GemmOperand16B{y.Sbf.p, ldsb, (long long)N * ndir * ldsb, (long long)N * ldsb},
+                       GemmOperand16B{y.Dbf.p, M, (long long)N * M, 4LL * y.no}, StorePartialRot{pbuf.p, R, Cn}, R, Cn, (int)N, ns, ndir);
+          } else if (bf16_gemm)
             gemm_bf16<GEMM_MC, GEMM_MC>(q, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
                                         gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
                                         StorePartial{pbuf.p, R, Cn}, R, Cn, (int)N, ns, ndir);
@@ -1313,10 +1347,12 @@ struct Net {
         timing.begin("gemm_gates_dx", s);
         static const bool b16src = !(getenv("CLSTM_GEMM_B16SRC") && atoi(getenv("CLSTM_GEMM_B16SRC")) == 0);
         if (b16src && bf16_gemm && bf16_rec && bwd_persistent && wide_kp16_bwd(y.no) == 4 * y.no && y.Wtb.p && y.Dbf.p)
+        {
           // the persistent recurrence left the deltas as a k-contiguous bf16 array: both operands go to LDS as they are
+          g_path_count[3]++;
           gemm_b16kk(s, GemmOperand16{y.Dbf.p, M, (long long)N * M}, GemmOperand16{y.Wtb.p, M, (long long)y.ni * M},
                      StorePlain{dx, y.ni}, (int)N, y.ni, M);
-        else if (bf16_gemm)
+        } else if (bf16_gemm)
           gemm_bf16<GEMM_KC, GEMM_KC>(s, gemm_kc(y.D.p, M, N, 32), gemm_kc(y.Wt, M, y.ni, y.wt_slack), StorePlain{dx, y.ni},
                                       (int)N, y.ni, M);
         else
@@ -1981,6 +2017,7 @@ static void states_transfer(clstm_net* h, float* data, long long total, bool get
       }
       copy_h2d(y.G.p, a.G[l].data(), a.G[l].size()); copy_h2d(y.C.p, a.C[l].data(), a.C[l].size());
       copy_h2d(y.H.p, a.H[l].data(), a.H[l].size()); copy_h2d(y.S.p, a.S[l].data(), a.S[l].size());
+      y.sbf_ready = false;   // the bf16 copies made by the forward pass no longer match these states
     }
     n.src0_ready = true;
   }
@@ -2083,6 +2120,12 @@ int clstm_debug_lstm_cycles(clstm_net* h, long long* out_h) {   // diagnostics b
   ABI_END
 }
 #endif
+int clstm_debug_path_count(int which, long long* out_h) {
+  ABI_BEGIN
+  REQUIRE(which >= 0 && which < 8 && out_h, "bad path index");
+  *out_h = g_path_count[which];
+  ABI_END
+}
 int clstm_debug_lane_ops(float* out) {
   ABI_BEGIN
   CLSTM_LAUNCH(k_debug_lane_ops, dim3(1), dim3(64), 0, g_stream, out);
@@ -2114,6 +2157,14 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
   } else if (mode == 30) {   // A: [R][K] bf16, B: [Cn][K] bf16 (the caller passes halfs in float-typed pointers)
     gemm_b16kk(g_stream, GemmOperand16{(const unsigned short*)A, K, (long long)R * K}, GemmOperand16{(const unsigned short*)B, K, (long long)Cn * K},
                StorePlain{Cm, Cn}, R, Cn, K);
+  } else if (mode == 32) {   // A: [K][R] bf16, B: [K][Cn] bf16 (R, Cn multiples of 8), split-K slabs reduced afterwards
+    if (!part) part = new DevBuf<float>();
+    if (nsplit < 1) nsplit = 1;
+    part->reserve((size_t)nsplit * R * Cn);
+    gemm_b16mc(g_stream, GemmOperand16B{(const unsigned short*)A, R, (long long)K * R, 0}, GemmOperand16B{(const unsigned short*)B, Cn, (long long)K * Cn, 0},
+               StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
+    CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
+                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0);
   } else if (mode == 20) gemm_x3<GEMM_KC, GEMM_MC>(g_stream, gemm_kc(A, K, R, 0), gemm_mc(B, Cn, K, 0), StorePlain{Cm, Cn}, R, Cn, K);
   else if (mode == 21) gemm_x3<GEMM_KC, GEMM_KC>(g_stream, gemm_kc(A, K, R, 0), gemm_kc(B, K, Cn, 0), StorePlain{Cm, Cn}, R, Cn, K);
   else if (mode == 22) {

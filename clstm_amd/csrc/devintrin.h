@@ -169,6 +169,21 @@ DEVFN f32x4 mfma16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// ds_read_b64_tr_b16 (gfx950): the 16 lanes of a lane group each pass the address of 4 consecutive bf16 (8-byte aligned);
+// with lane i pointing at chunk i of a [4][16] row-major block, lane i receives COLUMN i (elements i, 16 + i, 32 + i,
+// 48 + i), i.e. result(i, j) = chunk (4 j + i / 4), element i % 4 -- measured on the part by scripts/probe/tr16.hip.
+// This is the MFMA fragment of an operand that lies contraction-major in memory (gemm_bf16.h, gemm_b16mc).
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+DEVFN u32x2 lds_read_tr16(const unsigned short* p) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)p));
+}
+DEVFN u16x8 join_u16x8(u32x2 a, u32x2 b) {
+  u32x4 v;
+  v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+  return __builtin_bit_cast(u16x8, v);
+}
+
 // value known to be wave-uniform (e.g. threadIdx.x >> 6): tell the compiler so that buffer
 // descriptors derived from it live in SGPRs instead of waterfall loops (guide T20)
 DEVFN int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

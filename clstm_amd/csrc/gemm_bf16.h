@@ -429,6 +429,133 @@ inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE 
   CLSTM_LAUNCH((gemm_b16kk_128_kernel<FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K);
 }
 
+// ---- 128 x 128 tile, both operands bf16 and CONTRACTION-major in memory (the weight-gradient product) -----------------
+//   out(r, c) = sum_n A16[n * lda + r] * B16[n * ldb + c]          (n = frame-line index, 25600 of them at configs[4])
+// The f32-source kernel above has to transpose such operands while it stages them (four ds_write_b64 per four float4,
+// 2-way conflicts) after pulling twice the bytes through the vector cache.  Here the rows go from memory into LDS as
+// they are -- thread t moves 16 bytes = 8 consecutive r of contraction row t >> 4 (and of row 16 + (t >> 4)), one
+// ds_write_b128 each -- and the transposition is done by the LDS itself: ds_read_b64_tr_b16 hands lane i of a 16-lane
+// group column i of a [4 n][16 r] block, which is exactly an MFMA fragment (4 of a lane's 8 contraction slots; a second
+// read 16 rows further fills the other 4; A and B use the same slot -> n assignment, which is all the MFMA asks for).
+// LDS image of an operand block: 8 strips of 16 columns, each [32 n][16] bf16 = 1 KB contiguous (a wave's fragment read
+// covers 512 contiguous bytes: conflict-free by construction) + 32 bytes so that the 8 lanes of a ds_write_b128 group
+// (4 strips x 2 halves of one row) fall into 8 distinct 16-byte bank slots.
+struct GemmOperand16B { const unsigned short* p; int ld; long long elems; long long bstride; };   // halfs; ld % 8 == 0, bstride even
+constexpr int GT_STRIP = 32 * 16 + 16;   // halfs
+constexpr int GT_TILE = 8 * GT_STRIP;
+template <class FE>
+__global__ __launch_bounds__(256, 2) void gemm_b16mc_128_kernel(GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K,
+                                                                int ksplit, int nsplit) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[2 * GT_TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * GT_TILE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int bx, by, z;   // XCD-aware tile order, see gemm_mfma.h
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = lin & 7u, idx = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = (int)(v % gx);
+    by = (int)((v / gx) % gy);
+    z = (int)(v / (gx * gy));
+  }
+  const int r0 = by * GB2_BT, c0 = bx * GB2_BT;
+  const int batch = z / nsplit;
+  const int kbeg = (z - batch * nsplit) * ksplit;
+  const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
+  const int s_c = tid & 15, s_k = tid >> 4;   // 16-byte chunk of the row, contraction row (and row + 16) of the block
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(A.p + batch * A.bstride), (size_t)(A.elems - batch * A.bstride) * 2);
+  const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(B.p + batch * B.bstride), (size_t)(B.elems - batch * B.bstride) * 2);
+  // columns past R / Cn read whatever follows in the row (or the next row): they only reach outputs that are not stored
+  const unsigned aoff = ((unsigned)s_k * (unsigned)A.ld + (unsigned)(r0 + s_c * 8)) * 2u, a16 = 32u * (unsigned)A.ld;
+  const unsigned boff = ((unsigned)s_k * (unsigned)B.ld + (unsigned)(c0 + s_c * 8)) * 2u, b16 = 32u * (unsigned)B.ld;
+  const unsigned a_kstep = 2u * (unsigned)A.ld, b_kstep = 2u * (unsigned)B.ld;
+  f32x4 ra[GB2_PF][2], rb[GB2_PF][2];
+  // contraction rows past the slab load zeros: their offset is pushed out of the descriptor's range (one select per
+  // load instead of one per staged element; nothing to mask when the block is staged)
+  auto load_tile = [&](int k0, f32x4 (&a)[2], f32x4 (&b)[2]) {
+    const unsigned kc = (unsigned)wave_uniform(k0);
+    const bool l0 = k0 + s_k < kend, l1 = k0 + s_k + 16 < kend;
+    a[0] = buf_load4(abuf, l0 ? aoff + kc * a_kstep : BUF_OOB);
+    a[1] = buf_load4(abuf, l1 ? aoff + kc * a_kstep + a16 : BUF_OOB);
+    b[0] = buf_load4(bbuf, l0 ? boff + kc * b_kstep : BUF_OOB);
+    b[1] = buf_load4(bbuf, l1 ? boff + kc * b_kstep + b16 : BUF_OOB);
+  };
+  const int s_at = (s_c >> 1) * GT_STRIP + s_k * 16 + (s_c & 1) * 8;
+  auto stage = [&](unsigned short* S, const int, const f32x4 (&r)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) *reinterpret_cast<f32x4*>(&S[s_at + h * 256]) = r[h];
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+#pragma unroll
+  for (int p = 0; p < GB2_PF; p++) {
+    load_tile(kbeg + p * GB_BK, ra[p], rb[p]);
+    SCHED_FENCE();
+  }
+  stage(As, kbeg, ra[0]);
+  stage(Bs, kbeg, rb[0]);
+  load_tile(kbeg + GB2_PF * GB_BK, ra[0], rb[0]);
+  SCHED_FENCE();
+  __syncthreads();
+  const int f_at = lane * 4;   // lane l of a group points at chunk l of the group's [4 n][16] block: rows 4 (l >> 4) .. + 3
+  int cur = 0;
+  for (int kb = kbeg; kb < kend; kb += GB2_PF * GB_BK) {
+#pragma unroll
+    for (int p = 0; p < GB2_PF; p++) {
+      const int k0 = kb + p * GB_BK;
+      const int pn = p == GB2_PF - 1 ? 0 : p + 1;
+      stage(As + (cur ^ GT_TILE), k0 + GB_BK, ra[pn]);
+      stage(Bs + (cur ^ GT_TILE), k0 + GB_BK, rb[pn]);
+      load_tile(k0 + GB_BK + GB2_PF * GB_BK, ra[pn], rb[pn]);
+      SCHED_FENCE();
+      u16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned short* ap = &As[cur + (wm * 4 + i) * GT_STRIP + f_at];
+        const unsigned short* bp = &Bs[cur + (wn * 4 + i) * GT_STRIP + f_at];
+        af[i] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256));
+        bf[i] = join_u16x8(lds_read_tr16(bp), lds_read_tr16(bp + 256));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(af[i], bf[j], acc[i][j]);
+      __syncthreads();
+      cur ^= GT_TILE;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = r0 + wm * 64 + i * 16 + (lane >> 4) * 4 + q;
+        const int c = c0 + wn * 64 + j * 16 + (lane & 15);
+        if (r < R && c < Cn) fe(r, c, acc[i][j][q], z);
+      }
+}
+template <class FE>
+inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1) {
+  if (R <= 0 || Cn <= 0 || K <= 0) return;
+  if (nsplit < 1) nsplit = 1;
+  int ksplit = (K + nsplit - 1) / nsplit;
+  const int kq = nsplit > 1 ? GB2_PF * GB_BK : GB_BK;
+  ksplit = ((ksplit + kq - 1) / kq) * kq;
+  dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);
+  CLSTM_LAUNCH((gemm_b16mc_128_kernel<FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+}
+
 // ---- f32-grade products on the bf16 MFMA: 64 x 64 tile, operands split hi + lo ------------------------------------------
 // Same interface as gemm_f32_body (gemm_mfma.h) and -- to ~1e-6 of a product, see gemm_dw.h -- the same result:
 // every f32 operand element is staged as hi = bf16(x) and lo = bf16(x - hi), a product is hi.hi + hi.lo + lo.hi on

@@ -52,6 +52,8 @@ struct LstmWideArgs {
   unsigned short* Db;           // [N][nd][kp16]  bf16 copy of the gate deltas at column 4*cell+gate (backward A operand)
   unsigned short* Hbf;          // persistent forward kernel: per-frame [N][hbf_ld] bf16 copy of h (dir d at column d*no): the next
   int hbf_ld;                   //   layer's W_x product reads it as its k-contiguous A operand; or null
+  unsigned short* Sbf;          // persistent forward kernel: bf16 source rows [x | h_{t-1} | 1] of THIS layer, [dir][N][sbf_ld] (h-part written here), or null
+  int sbf_ld, sbf_ofs; long long sbf_dir;
   unsigned short* Dbf;          // persistent backward kernel: per-frame [N][nd][kp16] bf16 deltas (operand of the x.d GEMM), or null
   int kp16;                     // padded contraction length of the bf16 rows, multiple of 32 * WIDE_NW
 };
@@ -982,6 +984,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
       const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);
       *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) = hp;
       if (a.Hbf) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
+      if (a.Sbf) {   // h_{t-1} column block of the next frame's bf16 source row (weight-gradient operand, gemm_b16mc)
+        unsigned short* sb = a.Sbf + (size_t)dir * a.sbf_dir + a.sbf_ofs + cell;
+        if (sg == 0) *reinterpret_cast<unsigned*>(sb + (size_t)n * a.sbf_ld) = 0u;
+        if (sg + 1 < T) *reinterpret_cast<unsigned*>(sb + (size_t)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.sbf_ld) = hp;
+      }
     }
     // publish: every store of this workgroup acknowledged by the L2, then one arrival on the group's counter.  (Storing
     // the bf16 h first and the other arrays behind the arrival was measured SLOWER, 3.5 vs 3.2 us per step: VMEM

@@ -406,6 +406,35 @@ __global__ void k_to_bf16(const float* src, unsigned short* dst, size_t n) {
   CLSTM_GRID_STRIDE(e, n) dst[e] = (unsigned short)(bf16_pack2(src[e], 0.0f) & 0xFFFFu);
 }
 
+// x-part and bias column of the bf16 source rows [x_t | h_{t-1} | 1 | 0 ..] (pitch ldsb, one array per direction; ni and
+// one_col = ni + no multiples of 8): the contraction-major operand of the weight-gradient GEMM (gemm_b16mc).  x comes from
+// the layer below's bf16 outputs (xb, 16-byte copies) or from f32 input frames (xf); the h-part is stored by the
+// persistent forward recurrence itself (lstm_wide.h).
+__global__ void k_source_x_bf16(unsigned short* Sbf, const float* xf, const unsigned short* xb, int ldx, size_t N, int ni, int one_col,
+                                int ldsb, int ndir, long long sbdir) {
+  const int cpr = (ni >> 3) + 1;
+  CLSTM_GRID_STRIDE(e, N * (size_t)cpr) {
+    const size_t n = e / cpr;
+    const int j = (int)(e - n * cpr);
+    u16x8 v;
+    int col = j * 8;
+    if (j < (ni >> 3)) {
+      if (xb) v = *reinterpret_cast<const u16x8*>(&xb[n * ldx + col]);
+      else {
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = xf[n * ldx + col + i];
+        v = bf16_pack8(x);
+      }
+    } else {
+      col = one_col;
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = (unsigned short)(i == 0 ? 0x3F80 : 0);
+    }
+    for (int d = 0; d < ndir; d++) *reinterpret_cast<u16x8*>(&Sbf[(size_t)d * sbdir + n * ldsb + col]) = v;
+  }
+}
+
 // dst[c][k] = bf16(src[k][c]): the k-contiguous bf16 form of W_x ([ni][M] -> [M][ni]) for the bf16-source W_x.x product
 __global__ void k_transpose_to_bf16(const float* src, unsigned short* dst, int rows, int cols) {
   CLSTM_GRID_STRIDE(e, (size_t)rows * cols) {

@@ -266,6 +266,11 @@ int clstm_debug_lane_ops(float* out);
  * [6..15] sub-phase stamps of the short-line path (see scripts/gpu_ctcprof.py) */
 int clstm_debug_ctc_cycles(long long* out_h);
 int clstm_debug_gemm(int mode, const float* A, const float* B, float* C, int R, int Cn, int K, int nsplit);
+/* how often this process has taken an optional fast path (HOST out): which = 0 persistent per-XCD forward recurrence,
+ * 1 persistent backward recurrence, 2 W_x.x from the lower layer's bf16 outputs, 3 x.d from the bf16 delta array,
+ * 4 weight-gradient product from contraction-major bf16 operands (LDS transpose reads).  Tests use it to make sure the
+ * path they mean to cover is the one that ran. */
+int clstm_debug_path_count(int which, long long* out_h);
 
 #ifdef __cplusplus
 }

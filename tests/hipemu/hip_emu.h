@@ -204,6 +204,25 @@ inline f32x4 mfma16x16x32_bf16(u16x8 a, u16x8 b, f32x4 c) {
   emu_wave_sync();
   return d;
 }
+// ds_read_b64_tr_b16: see devintrin.h (lane i of a 16-lane group gets element i % 4 of the chunks of lanes i / 4 + 4 j)
+inline u32x2 lds_read_tr16(const unsigned short* p) {
+  const int l = emu_lane();
+  memcpy(emu_slot(l, 0), p, 8);
+  emu_wave_sync();
+  unsigned short r[4];
+  const int g = l & ~15, i = l & 15;
+  for (int j = 0; j < 4; j++) r[j] = reinterpret_cast<const unsigned short*>(emu_slot(g + 4 * j + (i >> 2), 0))[i & 3];
+  emu_wave_sync();
+  u32x2 out;
+  memcpy(&out, r, 8);
+  return out;
+}
+inline u16x8 join_u16x8(u32x2 a, u32x2 b) {
+  u16x8 r;
+  memcpy(&r.v[0], &a, 8);
+  memcpy(&r.v[4], &b, 8);
+  return r;
+}
 inline int wave_uniform(int x) { return x; }
 inline long long dev_clock() { return 0; }
 inline long long wall_clock() { return 0; }

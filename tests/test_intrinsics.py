@@ -126,3 +126,25 @@ def test_gemm_bf16_sources(backend, R, Cn, K):
     got = backend.down(Cd)
     scale = np.abs(Af) @ np.abs(Bf).T
     assert (np.abs(got - want) <= 2e-6 * scale + 1e-6).all()
+
+
+@pytest.mark.parametrize("R,Cn,K,ns", [(128, 128, 32, 1), (256, 256, 64, 1), (104, 200, 30, 1), (304, 136, 1000, 3), (136, 520, 700, 2)])
+def test_gemm_bf16_contraction_major(backend, R, Cn, K, ns):
+    """128 x 128-tile GEMM whose bf16 operands lie contraction-major in memory ([K][R], [K][Cn]: the weight-gradient
+    product's frame-major deltas and sources), transposed by ds_read_b64_tr_b16 on the way into the MFMA
+    (gemm_b16mc_128_kernel), with split-K slabs: exact against the float64 product of the same bf16 values.  The random
+    operands make the check transpose-detecting."""
+    rng = np.random.default_rng(R + Cn + K)
+    A = rng.normal(size=(K, R)).astype(np.float32)
+    B = rng.normal(size=(K, Cn)).astype(np.float32)
+    Ab, Bb = _bf16_bits(A), _bf16_bits(B)
+    Af = (Ab.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    Bf = (Bb.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    want = Af.T @ Bf
+    Ad = backend.up(Ab, dtype=np.uint16)
+    Bd = backend.up(Bb, dtype=np.uint16)
+    Cd = backend.zeros((R, Cn))
+    backend.lib.call("clstm_debug_gemm", 32, ptr(Ad), ptr(Bd), ptr(Cd), R, Cn, K, ns)
+    got = backend.down(Cd)
+    scale = np.abs(Af).T @ np.abs(Bf)
+    assert (np.abs(got - want) <= 2e-6 * scale + 1e-6).all()

@@ -1,3 +1,4 @@
+import os
 """Parity of the fused network path (clstm_net_* ABI) against the oracle.
 
 Every test runs twice: backend 'emu' executes the real kernel sources on CPU threads
@@ -247,7 +248,8 @@ def test_bf16_gate_gemms_track_the_f32_path(backend, ora32):
 
 @pytest.mark.parametrize("nh,T", [([20, 16], [9, 5, 7]), ([37], [12, 1, 8]),
                                   # 20 ragged lines = two line blocks x two directions = four XCD groups of the persistent kernels
-                                  ([48, 32], [14, 9, 3, 11, 7, 14, 1, 8, 13, 5, 12, 6, 10, 2, 9, 14, 4, 11, 7, 13])])
+                                  ([48, 32], [14, 9, 3, 11, 7, 14, 1, 8, 13, 5, 12, 6, 10, 2, 9, 14, 4, 11, 7, 13]),
+                                  ([32, 32], [9, 5, 7, 3])])
 def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatch, nh, T):
     """clstm_net_set_gemm_precision(2): bf16 MFMA operands (recurrent weights, h, gate deltas) inside the lock-step
     recurrence (lstm_wide.h, *_step_bf16) on top of the bf16 hoisted GEMMs -- BASELINE config "2 x BiLSTM(512), bf16 MFMA".
@@ -258,6 +260,7 @@ def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatc
     monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")      # the lock-step path on sizes the emulator can run
     rng = np.random.default_rng(23)
     ni, nc = 12, 6
+    before = [_path_count(backend, k) for k in range(5)]
     params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
     lines = synth_lines(rng, T, ni)
     trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
@@ -284,3 +287,16 @@ def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatc
     net.update()                              # repack (bf16 weights) + a second step must run
     net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
     assert np.isfinite(net.get_grads()).all()
+    took = [_path_count(backend, k) - before[k] for k in range(5)]
+    if nh == [32, 32]:
+        # sized so that every optional bf16 fast path is eligible even on the emulator's 16 CUs: persistent per-XCD
+        # recurrences (two cell tiles per direction), W_x.x from the lower layer's bf16 outputs, x.d from the bf16 delta
+        # array, and the weight gradient from contraction-major bf16 operands through the LDS transpose reads
+        assert all(t > 0 for t in took), took
+
+
+def _path_count(backend, which):
+    import ctypes
+    out = ctypes.c_longlong(0)
+    backend.lib.call("clstm_debug_path_count", which, ctypes.byref(out))
+    return out.value
