@@ -172,6 +172,10 @@ struct StorePartial {  // split-K slabs [z][R][Cn]
 struct StorePartialRot {  // split-K slabs whose operand rows were ordered [x | h | 1]: row r lands in row (r + 1) mod R of [1 | x | h]
   float* out; int R, Cn;
   DEVMFN void operator()(int r, int c, float v, int z) const { out[((long long)z * R + (r + 1 == R ? 0 : r + 1)) * Cn + c] = v; }
+  DEVMFN bool vec4() const { return (Cn & 3) == 0 && ((size_t)out & 15) == 0; }
+  DEVMFN void row4(int r, int c, f32x4 v, int z) const {
+    *reinterpret_cast<f32x4*>(out + ((long long)z * R + (r + 1 == R ? 0 : r + 1)) * Cn + c) = v;
+  }
 };
 #ifndef GEMM_BK_DW
 #define GEMM_BK_DW 16   // frames staged per barrier pair in the weight-gradient GEMM (32 measured slower: 61.1 vs 58.3 us)

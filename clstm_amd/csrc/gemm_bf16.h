@@ -162,6 +162,30 @@ constexpr int GB2_LDH = 32;
 constexpr int GB2_TILE = GB2_BT * GB2_LDH;   // halfs per operand buffer
 DEVFN int gb2_sw(int row) { return ((row >> 1) ^ (row >> 2)) & 3; }
 
+// Epilogue of the 128 x 128 kernels.  Their MFMAs are issued with the operands exchanged (B fragment first), so an
+// accumulator holds the TRANSPOSED 16 x 16 tile: lane l has four consecutive columns (4 (l >> 4) .. + 3) of output row
+// l & 15 -- one 16-byte store (row4) instead of four 4-byte stores of a column piece; a wave's store instruction covers
+// sixteen 64-byte row segments.
+template <class FE>
+DEVFN void gb2_store(const FE& fe, const f32x4 (&acc)[4][4], const int rw, const int cw, const int lane, const int R, const int Cn, const int z) {
+  const bool v4 = fe.vec4();
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int r = rw + i * 16 + (lane & 15);
+      const int c = cw + j * 16 + (lane >> 4) * 4;
+      if (r < R) {
+        if (v4 && c + 3 < Cn) fe.row4(r, c, acc[i][j], z);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (c + e < Cn) fe(r, c + e, acc[i][j][e], z);
+        }
+      }
+    }
+}
+
 template <int AMODE, int BMODE, class FE>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
                                                                int K, int ksplit, int nsplit) {
@@ -298,21 +322,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (!(CLSTM_GEXP & 2) || (i == 0 && j == 0)) acc[i][j] = mfma16x16x32_bf16(af[i], bf[j], acc[i][j]);
+          if (!(CLSTM_GEXP & 2) || (i == 0 && j == 0)) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
       if (!(CLSTM_GEXP & 8)) __syncthreads();
       cur ^= GB2_TILE;
     }
   }
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int r = r0 + wm * 64 + i * 16 + (lane >> 4) * 4 + q;
-        const int c = c0 + wn * 64 + j * 16 + (lane & 15);
-        if (r < R && c < Cn) fe(r, c, acc[i][j][q], z);
-      }
+  gb2_store(fe, acc, r0 + wm * 64, c0 + wn * 64, lane, R, Cn, z);
 }
 
 // ---- 128 x 128 tile, BOTH operands already bf16 and k-contiguous in memory ------------------------------------------
@@ -406,21 +421,12 @@ __global__ __launch_bounds__(256, 2) void gemm_b16kk_128_kernel(GemmOperand16 A,
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
       __syncthreads();
       cur ^= GB2_TILE;
     }
   }
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int r = r0 + wm * 64 + i * 16 + (lane >> 4) * 4 + q;
-        const int c = c0 + wn * 64 + j * 16 + (lane & 15);
-        if (r < R && c < Cn) fe(r, c, acc[i][j][q], 0);
-      }
+  gb2_store(fe, acc, r0 + wm * 64, c0 + wn * 64, lane, R, Cn, 0);
 }
 template <class FE>
 inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K) {
@@ -529,21 +535,12 @@ __global__ __launch_bounds__(256, 2) void gemm_b16mc_128_kernel(GemmOperand16B A
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
       __syncthreads();
       cur ^= GT_TILE;
     }
   }
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int r = r0 + wm * 64 + i * 16 + (lane >> 4) * 4 + q;
-        const int c = c0 + wn * 64 + j * 16 + (lane & 15);
-        if (r < R && c < Cn) fe(r, c, acc[i][j][q], z);
-      }
+  gb2_store(fe, acc, r0 + wm * 64, c0 + wn * 64, lane, R, Cn, z);
 }
 template <class FE>
 inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1) {
