@@ -625,6 +625,7 @@ struct Layer {
   bool fwd_persistent = false; // this forward pass ran the persistent kernel (Hbf is valid)
   DevBuf<unsigned short> Sbf;  // bf16 source rows [x | h_{t-1} | 1] per direction (x: k_source_x_bf16, h: the persistent forward kernel)
   bool sbf_ready = false;      // ... complete for this forward pass
+  bool sx_valid = true;        // the [1 | x] columns of S (f32) are current (built lazily when the bf16 rows serve the weight gradient)
   DevBuf<unsigned short> Dbf;  // per-frame bf16 gate deltas written by the persistent backward kernel (A operand of the x.d GEMM)
   DevBuf<unsigned short> Wtb;  // bf16 copy of Wt ([ni][M], k = gate column contiguous): B operand of the bf16-source x.d product
   DevBuf<float> pdw;          // split-K slabs of this layer's weight-gradient product when it runs on the side stream
@@ -900,6 +901,17 @@ struct Net {
     return w;
   }
 
+  void ensure_source_x(int l) {
+    Layer& y = L[l];
+    if (y.sx_valid) return;
+    hipStream_t s = stream();
+    timing.begin("build_source", s);
+    CLSTM_LAUNCH(k_build_source, dim3(nblocks((size_t)N * (1 + y.ni))), dim3(256), 0, s, y.S.p, layer_input(l),
+                 (size_t)N, y.ni, layer_input_ld(l), y.lds, ndir, (long long)N * y.lds);
+    timing.end(s);
+    y.sx_valid = true;
+  }
+
   void forward() {
     REQUIRE(N > 0, "set_batch first");
     if (getenv("CLSTM_OVERLAP_DRY")) (void)side_streams();   // experiment: the side streams exist but are never used
@@ -934,11 +946,11 @@ struct Net {
                                    StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
       timing.end(s);
       check_launch();
-      timing.begin("build_source", s);
-      if (l > 0 || !src0_ready)
-      CLSTM_LAUNCH(k_build_source, dim3(nblocks((size_t)N * (1 + y.ni))), dim3(256), 0, s, y.S.p, layer_input(l),
-                   (size_t)N, y.ni, layer_input_ld(l), y.lds, ndir, (long long)N * y.lds);
-      timing.end(s);
+      // the [1 | x] columns of the f32 source rows: written now -- unless this is an upper layer whose weight-gradient
+      // product will read the bf16 rows instead (decided after the recurrence below; ensure_source_x() then builds them
+      // only if something still asks for them: a fallback path or the state API)
+      y.sx_valid = l == 0 && src0_ready;
+      if (l == 0 || !y.wide) ensure_source_x(l);   // (the register-resident recurrence of narrow layers reads whole source rows)
       LstmSeqArgs a{};
       a.Rpk = y.Rf; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = nullptr; a.D = nullptr;
       a.line_off = line_off.p; a.order = line_off.p + bs + 1; a.no = y.no; a.ndir = ndir; a.ldh = y.ldh; a.hofs = y.hofs;
@@ -961,6 +973,7 @@ struct Net {
       }
       else launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
+      if (!y.sbf_ready) ensure_source_x(l);
     }
     const int nc = desc.nclasses;
     const float* W1 = v + sm_off;
@@ -1312,13 +1325,15 @@ struct Net {
       // latency-bound waves.  So x.d goes first (layer l-1 waits for it), then W.d and its slab reduction run on a
       // LOW-priority side stream beside the next recurrence (whose workgroups, on the other stream, are dispatched first)
       // and the main stream joins before the update.
+      const bool dw_from_bf16 = bf16_gemm && bf16_rec && bwd_persistent && y.sbf_ready && y.Dbf.p && gemm_bf16_big(R, Cn);
+      if (!dw_from_bf16) ensure_source_x(l);   // the f32-source products below read S
       const bool defer = l > 0 && y.wide && bf16_rec && bf16_gemm && dw_side_stream();
       DevBuf<float>& pbuf = defer ? y.pdw : partial;
       auto do_dw = [&](hipStream_t q) {
         if (bf16_gemm || !overlap_eligible(y)) {
           pbuf.reserve((size_t)ndir * ns * R * Cn);
           timing.begin("gemm_gates_dw", q);
-          if (bf16_gemm && bf16_rec && bwd_persistent && y.sbf_ready && y.Dbf.p && gemm_bf16_big(R, Cn)) {
+          if (dw_from_bf16) {
             // both operands bf16 as their producers left them (deltas: the persistent backward recurrence; sources: the
             // forward pass), transposed by the LDS on the way into the MFMA
             const int ldsb = y.ni + y.no + 8;
@@ -1990,6 +2005,7 @@ static void states_transfer(clstm_net* h, float* data, long long total, bool get
     Layer& y = n.L[l];
     a.G[l].resize(N * n.ndir * 4 * y.no); a.C[l].resize(N * n.ndir * y.no);
     a.H[l].resize(N * y.ldh); a.S[l].resize(N * n.ndir * y.lds);
+    n.ensure_source_x((int)l);
     copy_d2h(a.G[l].data(), y.G.p, a.G[l].size()); copy_d2h(a.C[l].data(), y.C.p, a.C[l].size());
     copy_d2h(a.H[l].data(), y.H.p, a.H[l].size()); copy_d2h(a.S[l].data(), y.S.p, a.S[l].size());
   }
@@ -2022,6 +2038,7 @@ static void states_transfer(clstm_net* h, float* data, long long total, bool get
       copy_h2d(y.G.p, a.G[l].data(), a.G[l].size()); copy_h2d(y.C.p, a.C[l].data(), a.C[l].size());
       copy_h2d(y.H.p, a.H[l].data(), a.H[l].size()); copy_h2d(y.S.p, a.S[l].data(), a.S[l].size());
       y.sbf_ready = false;   // the bf16 copies made by the forward pass no longer match these states
+      y.sx_valid = true;
     }
     n.src0_ready = true;
   }

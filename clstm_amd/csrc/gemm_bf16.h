@@ -446,9 +446,19 @@ inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE 
 // LDS image of an operand block: 8 strips of 16 columns, each [32 n][16] bf16 = 1 KB contiguous (a wave's fragment read
 // covers 512 contiguous bytes: conflict-free by construction) + 32 bytes so that the 8 lanes of a ds_write_b128 group
 // (4 strips x 2 halves of one row) fall into 8 distinct 16-byte bank slots.
+#ifndef CLSTM_TEXP   // perf experiments only: bit mask of work to leave out of gemm_b16mc_128_kernel (results are then wrong)
+#define CLSTM_TEXP 0
+#endif
 struct GemmOperand16B { const unsigned short* p; int ld; long long elems; long long bstride; };   // halfs; ld % 8 == 0, bstride even
 constexpr int GT_STRIP = 32 * 16 + 16;   // halfs
 constexpr int GT_TILE = 8 * GT_STRIP;
+#ifndef CLSTM_GT_PF
+#define CLSTM_GT_PF 3
+#endif
+constexpr int GT_PF = CLSTM_GT_PF;   // 32-row blocks in flight in registers
+#ifndef CLSTM_GT_SWP
+#define CLSTM_GT_SWP 0
+#endif
 template <class FE>
 __global__ __launch_bounds__(256, 2) void gemm_b16mc_128_kernel(GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K,
                                                                 int ksplit, int nsplit) {
@@ -480,12 +490,12 @@ __global__ __launch_bounds__(256, 2) void gemm_b16mc_128_kernel(GemmOperand16B A
   const unsigned aoff = ((unsigned)s_k * (unsigned)A.ld + (unsigned)(r0 + s_c * 8)) * 2u, a16 = 32u * (unsigned)A.ld;
   const unsigned boff = ((unsigned)s_k * (unsigned)B.ld + (unsigned)(c0 + s_c * 8)) * 2u, b16 = 32u * (unsigned)B.ld;
   const unsigned a_kstep = 2u * (unsigned)A.ld, b_kstep = 2u * (unsigned)B.ld;
-  f32x4 ra[GB2_PF][2], rb[GB2_PF][2];
+  f32x4 ra[GT_PF][2], rb[GT_PF][2];
   // contraction rows past the slab load zeros: their offset is pushed out of the descriptor's range (one select per
   // load instead of one per staged element; nothing to mask when the block is staged)
   auto load_tile = [&](int k0, f32x4 (&a)[2], f32x4 (&b)[2]) {
     const unsigned kc = (unsigned)wave_uniform(k0);
-    const bool l0 = k0 + s_k < kend, l1 = k0 + s_k + 16 < kend;
+    const bool l0 = !(CLSTM_TEXP & 1) && k0 + s_k < kend, l1 = !(CLSTM_TEXP & 1) && k0 + s_k + 16 < kend;
     a[0] = buf_load4(abuf, l0 ? aoff + kc * a_kstep : BUF_OOB);
     a[1] = buf_load4(abuf, l1 ? aoff + kc * a_kstep + a16 : BUF_OOB);
     b[0] = buf_load4(bbuf, l0 ? boff + kc * b_kstep : BUF_OOB);
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void gemm_b16mc_128_kernel(GemmOperand16B A
   const int s_at = (s_c >> 1) * GT_STRIP + s_k * 16 + (s_c & 1) * 8;
   auto stage = [&](unsigned short* S, const int, const f32x4 (&r)[2]) {
 #pragma unroll
-    for (int h = 0; h < 2; h++) *reinterpret_cast<f32x4*>(&S[s_at + h * 256]) = r[h];
+    for (int h = 0; h < 2; h++) if (!(CLSTM_TEXP & 4) || r[h][0] == 1234.5f) *reinterpret_cast<f32x4*>(&S[s_at + h * 256]) = r[h];
   };
   f32x4 acc[4][4];
 #pragma unroll
@@ -503,43 +513,95 @@ __global__ __launch_bounds__(256, 2) void gemm_b16mc_128_kernel(GemmOperand16B A
     for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+  const int f_at = lane * 4;   // lane l of a group points at chunk l of the group's [4 n][16] block: rows 4 (l >> 4) .. + 3
+  auto read_frags = [&](const int buf, u16x8 (&af)[4], u16x8 (&bf)[4]) {
 #pragma unroll
-  for (int p = 0; p < GB2_PF; p++) {
+    for (int i = 0; i < 4; i++) {
+      const unsigned short* ap = &As[buf + (wm * 4 + i) * GT_STRIP + f_at];
+      const unsigned short* bp = &Bs[buf + (wn * 4 + i) * GT_STRIP + f_at];
+      if (CLSTM_TEXP & 8) {   // (experiment) one fragment read per operand instead of four
+        if (i == 0) { af[0] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256)); bf[0] = join_u16x8(lds_read_tr16(bp), lds_read_tr16(bp + 256)); }
+        else { af[i] = af[0]; bf[i] = bf[0]; }
+        continue;
+      }
+      af[i] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256));
+      bf[i] = join_u16x8(lds_read_tr16(bp), lds_read_tr16(bp + 256));
+    }
+  };
+  auto mfma_block = [&](const u16x8 (&af)[4], const u16x8 (&bf)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (!(CLSTM_TEXP & 2) || (i == 0 && j == 0)) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
+  };
+#if CLSTM_GT_SWP
+  // Software pipeline, one barrier per 32-row block b:  LDS holds blocks b and b + 1, the register ring blocks b + 2 ..
+  // b + 1 + GT_PF, and the fragments of block b were READ during block b - 1.  After the barrier (everyone has its
+  // fragments of b, everyone's copy of b + 1 is in LDS) a wave issues the fragment reads of b + 1, then the 16 MFMAs of b
+  // -- which run while those reads return -- then overwrites b's LDS buffer with b + 2 and reloads the ring slot.
+  static_assert((GT_PF & 1) == 0 || !CLSTM_GT_SWP, "fragment parity and ring slot must both be static: even ring depth");
+#pragma unroll
+  for (int p = 0; p < GT_PF; p++) {
     load_tile(kbeg + p * GB_BK, ra[p], rb[p]);
     SCHED_FENCE();
   }
   stage(As, kbeg, ra[0]);
   stage(Bs, kbeg, rb[0]);
-  load_tile(kbeg + GB2_PF * GB_BK, ra[0], rb[0]);
+  load_tile(kbeg + GT_PF * GB_BK, ra[0], rb[0]);
+  SCHED_FENCE();
+  stage(As + GT_TILE, kbeg + GB_BK, ra[1]);
+  stage(Bs + GT_TILE, kbeg + GB_BK, rb[1]);
+  load_tile(kbeg + (GT_PF + 1) * GB_BK, ra[1], rb[1]);
   SCHED_FENCE();
   __syncthreads();
-  const int f_at = lane * 4;   // lane l of a group points at chunk l of the group's [4 n][16] block: rows 4 (l >> 4) .. + 3
-  int cur = 0;
-  for (int kb = kbeg; kb < kend; kb += GB2_PF * GB_BK) {
+  u16x8 fa[2][4], fb[2][4];
+  read_frags(0, fa[0], fb[0]);
+  for (int kb = kbeg; kb < kend; kb += GT_PF * GB_BK) {
 #pragma unroll
-    for (int p = 0; p < GB2_PF; p++) {
+    for (int u = 0; u < GT_PF; u++) {
+      const int k0 = kb + u * GB_BK;
+      if (!(CLSTM_TEXP & 16)) __syncthreads();
+      read_frags(((u + 1) & 1) * GT_TILE, fa[(u + 1) & 1], fb[(u + 1) & 1]);
+      SCHED_FENCE();
+      mfma_block(fa[u & 1], fb[u & 1]);
+      SCHED_FENCE();
+      constexpr int dummy = 0; (void)dummy;
+      const int slot = (u + 2) % GT_PF;
+      stage(As + (u & 1) * GT_TILE, k0 + 2 * GB_BK, ra[slot]);
+      stage(Bs + (u & 1) * GT_TILE, k0 + 2 * GB_BK, rb[slot]);
+      load_tile(k0 + (2 + GT_PF) * GB_BK, ra[slot], rb[slot]);
+      SCHED_FENCE();
+    }
+  }
+#else
+#pragma unroll
+  for (int p = 0; p < GT_PF; p++) {
+    load_tile(kbeg + p * GB_BK, ra[p], rb[p]);
+    SCHED_FENCE();
+  }
+  stage(As, kbeg, ra[0]);
+  stage(Bs, kbeg, rb[0]);
+  load_tile(kbeg + GT_PF * GB_BK, ra[0], rb[0]);
+  SCHED_FENCE();
+  __syncthreads();
+  int cur = 0;
+  for (int kb = kbeg; kb < kend; kb += GT_PF * GB_BK) {
+#pragma unroll
+    for (int p = 0; p < GT_PF; p++) {
       const int k0 = kb + p * GB_BK;
-      const int pn = p == GB2_PF - 1 ? 0 : p + 1;
+      const int pn = p == GT_PF - 1 ? 0 : p + 1;
       stage(As + (cur ^ GT_TILE), k0 + GB_BK, ra[pn]);
       stage(Bs + (cur ^ GT_TILE), k0 + GB_BK, rb[pn]);
-      load_tile(k0 + GB_BK + GB2_PF * GB_BK, ra[pn], rb[pn]);
+      load_tile(k0 + GB_BK + GT_PF * GB_BK, ra[pn], rb[pn]);
       SCHED_FENCE();
       u16x8 af[4], bf[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const unsigned short* ap = &As[cur + (wm * 4 + i) * GT_STRIP + f_at];
-        const unsigned short* bp = &Bs[cur + (wn * 4 + i) * GT_STRIP + f_at];
-        af[i] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256));
-        bf[i] = join_u16x8(lds_read_tr16(bp), lds_read_tr16(bp + 256));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
-      __syncthreads();
+      read_frags(cur, af, bf);
+      mfma_block(af, bf);
+      if (!(CLSTM_TEXP & 16)) __syncthreads();
       cur ^= GT_TILE;
     }
   }
+#endif
   gb2_store(fe, acc, r0 + wm * 64, c0 + wn * 64, lane, R, Cn, z);
 }
 template <class FE>
@@ -547,7 +609,7 @@ inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, F
   if (R <= 0 || Cn <= 0 || K <= 0) return;
   if (nsplit < 1) nsplit = 1;
   int ksplit = (K + nsplit - 1) / nsplit;
-  const int kq = nsplit > 1 ? GB2_PF * GB_BK : GB_BK;
+  const int kq = nsplit > 1 ? GT_PF * GB_BK : GB_BK;
   ksplit = ((ksplit + kq - 1) / kq) * kq;
   dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);
   CLSTM_LAUNCH((gemm_b16mc_128_kernel<FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
