@@ -1012,6 +1012,7 @@ struct Net {
     static const long long target0 = getenv("CLSTM_SPLIT_TARGET") ? atoll(getenv("CLSTM_SPLIT_TARGET")) : 640;
     const long long target = tile == GEMM_BT ? target0 : 480;   // 128 x 128 tiles: two workgroups per CU
     long long want = (target + tiles - 1) / tiles;
+    if (tile == 256) want = device_cu_count() / tiles;          // 256 x 256 tiles: one workgroup per CU, never a second round
     const long long maxs = (N + 63) / 64;   // at least 64 frames per slab
     if (want > maxs) want = maxs;
     if (want > 64) want = 64;
@@ -1318,7 +1319,6 @@ struct Net {
       timing.end(s);
       bwd_persistent = y.wide && g_wide_persistent;
       if (bwd_persistent) g_path_count[1]++;
-      ns = bf16_gemm && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
       }
       // (Experiment, off by default.)  Stacked lock-step layers in bf16: the weight-gradient product of layer l (~1 ms at 2 x BiLSTM(512)) depends only on
       // that layer's recurrence, while the persistent recurrence of layer l-1 that follows keeps every CU busy with four
@@ -1326,6 +1326,9 @@ struct Net {
       // LOW-priority side stream beside the next recurrence (whose workgroups, on the other stream, are dispatched first)
       // and the main stream joins before the update.
       const bool dw_from_bf16 = bf16_gemm && bf16_rec && bwd_persistent && y.sbf_ready && y.Dbf.p && gemm_bf16_big(R, Cn);
+      if (bf16_gemm || !overlap_eligible(y))
+        ns = dw_from_bf16 && gemm_tile256(R, Cn) ? pick_split(R, Cn, ndir, 256)
+             : bf16_gemm && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
       if (!dw_from_bf16) ensure_source_x(l);   // the f32-source products below read S
       const bool defer = l > 0 && y.wide && bf16_rec && bf16_gemm && dw_side_stream();
       DevBuf<float>& pbuf = defer ? y.pdw : partial;

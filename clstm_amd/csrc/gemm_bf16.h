@@ -166,11 +166,11 @@ DEVFN int gb2_sw(int row) { return ((row >> 1) ^ (row >> 2)) & 3; }
 // accumulator holds the TRANSPOSED 16 x 16 tile: lane l has four consecutive columns (4 (l >> 4) .. + 3) of output row
 // l & 15 -- one 16-byte store (row4) instead of four 4-byte stores of a column piece; a wave's store instruction covers
 // sixteen 64-byte row segments.
-template <class FE>
-DEVFN void gb2_store(const FE& fe, const f32x4 (&acc)[4][4], const int rw, const int cw, const int lane, const int R, const int Cn, const int z) {
+template <class FE, int WI = 4>
+DEVFN void gb2_store(const FE& fe, const f32x4 (&acc)[WI][4], const int rw, const int cw, const int lane, const int R, const int Cn, const int z) {
   const bool v4 = fe.vec4();
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < WI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int r = rw + i * 16 + (lane & 15);
@@ -338,13 +338,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
 // a bf16 k-contiguous copy of its output at no extra cost (the persistent recurrence's delta ring IS that array) and
 // for the weight operand (packed once per update).  No split-K, no batch: the products it serves have K <= 4096.
 struct GemmOperand16 { const unsigned short* p; int ld; long long elems; };   // ld, elems in halfs (ld even)
-template <class FE>
-__global__ __launch_bounds__(256, 2) void gemm_b16kk_128_kernel(GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K) {
-  __shared__ __attribute__((aligned(16))) unsigned short As[2 * GB2_TILE];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * GB2_TILE];
+// (WI as in gemm_b16mc_kernel below: 4 -> 128 x 128 tile / four waves, 8 -> 256 x 256 / eight waves of 128 x 64)
+template <class FE, int WI>
+__global__ __launch_bounds__(64 * WI, 2) void gemm_b16kk_kernel(GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K) {
+  constexpr int NWN = WI / 2, BT = 32 * WI, TILE = BT * GB2_LDH;
+  __shared__ __attribute__((aligned(16))) unsigned short As[2 * TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * TILE];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   int bx, by;
   {
     const unsigned gx = gridDim.x, gy = gridDim.y;
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void gemm_b16kk_128_kernel(GemmOperand16 A,
     bx = (int)(v % gx);
     by = (int)(v / gx);
   }
-  const int r0 = by * GB2_BT, c0 = bx * GB2_BT;
+  const int r0 = by * BT, c0 = bx * BT;
   const int s_mn = tid >> 1, s_k = (tid & 1) * 16;   // row of the tile, first of its 16 k
   const BufF32 abuf = make_buf(reinterpret_cast<const float*>(A.p), (size_t)A.elems * 2);
   const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(B.p), (size_t)B.elems * 2);
@@ -383,9 +385,9 @@ __global__ __launch_bounds__(256, 2) void gemm_b16kk_128_kernel(GemmOperand16 A,
       *reinterpret_cast<u16x8*>(&S[s_mn * GB2_LDH + ((((s_k >> 3) + h) ^ gb2_sw(s_mn)) << 3)]) = v;
     }
   };
-  f32x4 acc[4][4];
+  f32x4 acc[WI][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < WI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -408,31 +410,36 @@ __global__ __launch_bounds__(256, 2) void gemm_b16kk_128_kernel(GemmOperand16 A,
     for (int p = 0; p < GB2_PF; p++) {
       const int k0 = kb + p * GB_BK;
       const int pn = p == GB2_PF - 1 ? 0 : p + 1;
-      stage(As + (cur ^ GB2_TILE), k0 + GB_BK, ra[pn]);
-      stage(Bs + (cur ^ GB2_TILE), k0 + GB_BK, rb[pn]);
+      stage(As + (cur ^ TILE), k0 + GB_BK, ra[pn]);
+      stage(Bs + (cur ^ TILE), k0 + GB_BK, rb[pn]);
       load_tile(k0 + GB_BK + GB2_PF * GB_BK, ra[pn], rb[pn]);
       SCHED_FENCE();
-      u16x8 af[4], bf[4];
+      u16x8 af[WI], bf[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        af[i] = *reinterpret_cast<const u16x8*>(&As[cur + (wm * 64 + i * 16 + fi) * GB2_LDH + fsw]);
-        bf[i] = *reinterpret_cast<const u16x8*>(&Bs[cur + (wn * 64 + i * 16 + fi) * GB2_LDH + fsw]);
-      }
+      for (int i = 0; i < WI; i++) af[i] = *reinterpret_cast<const u16x8*>(&As[cur + (wm * (16 * WI) + i * 16 + fi) * GB2_LDH + fsw]);
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) bf[j] = *reinterpret_cast<const u16x8*>(&Bs[cur + (wn * 64 + j * 16 + fi) * GB2_LDH + fsw]);
+#pragma unroll
+      for (int i = 0; i < WI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
       __syncthreads();
-      cur ^= GB2_TILE;
+      cur ^= TILE;
     }
   }
-  gb2_store(fe, acc, r0 + wm * 64, c0 + wn * 64, lane, R, Cn, 0);
+  gb2_store<FE, WI>(fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, 0);
 }
+inline bool gemm_tile256(int R, int Cn);
 template <class FE>
 inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K) {
   if (R <= 0 || Cn <= 0 || K <= 0) return;
+  if (gemm_tile256(R, Cn)) {
+    dim3 grid((Cn + 255) / 256, (R + 255) / 256, 1);
+    CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K);
+    return;
+  }
   dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, 1);
-  CLSTM_LAUNCH((gemm_b16kk_128_kernel<FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K);
+  CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 4>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K);
 }
 
 // ---- 128 x 128 tile, both operands bf16 and CONTRACTION-major in memory (the weight-gradient product) -----------------
@@ -446,7 +453,7 @@ inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE 
 // LDS image of an operand block: 8 strips of 16 columns, each [32 n][16] bf16 = 1 KB contiguous (a wave's fragment read
 // covers 512 contiguous bytes: conflict-free by construction) + 32 bytes so that the 8 lanes of a ds_write_b128 group
 // (4 strips x 2 halves of one row) fall into 8 distinct 16-byte bank slots.
-#ifndef CLSTM_TEXP   // perf experiments only: bit mask of work to leave out of gemm_b16mc_128_kernel (results are then wrong)
+#ifndef CLSTM_TEXP   // perf experiments only: bit mask of work to leave out of gemm_b16mc_kernel (results are then wrong)
 #define CLSTM_TEXP 0
 #endif
 struct GemmOperand16B { const unsigned short* p; int ld; long long elems; long long bstride; };   // halfs; ld % 8 == 0, bstride even
@@ -459,14 +466,17 @@ constexpr int GT_PF = CLSTM_GT_PF;   // 32-row blocks in flight in registers
 #ifndef CLSTM_GT_SWP
 #define CLSTM_GT_SWP 0
 #endif
-template <class FE>
-__global__ __launch_bounds__(256, 2) void gemm_b16mc_128_kernel(GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K,
-                                                                int ksplit, int nsplit) {
-  __shared__ __attribute__((aligned(16))) unsigned short As[2 * GT_TILE];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * GT_TILE];
+// WI = 16-row strips of a wave's tile: 4 -> 128 x 128 per workgroup (four waves 2 x 2, 64 x 64 each), 8 -> 256 x 256 (eight
+// waves 2 x 4, 128 x 64 each: half the LDS and vector-cache bytes per MFMA; one workgroup per CU).
+template <class FE, int WI>
+__global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K,
+                                                                   int ksplit, int nsplit) {
+  constexpr int NWN = WI / 2, BT = 32 * WI, NSTRIP = 2 * WI, TILE = NSTRIP * GT_STRIP, CHUNKS = BT / 8;
+  __shared__ __attribute__((aligned(16))) unsigned short As[2 * TILE];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * TILE];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   int bx, by, z;   // XCD-aware tile order, see gemm_mfma.h
   {
     const unsigned gx = gridDim.x, gy = gridDim.y;
@@ -479,11 +489,11 @@ __global__ __launch_bounds__(256, 2) void gemm_b16mc_128_kernel(GemmOperand16B A
     by = (int)((v / gx) % gy);
     z = (int)(v / (gx * gy));
   }
-  const int r0 = by * GB2_BT, c0 = bx * GB2_BT;
+  const int r0 = by * BT, c0 = bx * BT;
   const int batch = z / nsplit;
   const int kbeg = (z - batch * nsplit) * ksplit;
   const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
-  const int s_c = tid & 15, s_k = tid >> 4;   // 16-byte chunk of the row, contraction row (and row + 16) of the block
+  const int s_c = tid % CHUNKS, s_k = tid / CHUNKS;   // 16-byte chunk of the row, contraction row (0 .. 15, and row + 16) of the block
   const BufF32 abuf = make_buf(reinterpret_cast<const float*>(A.p + batch * A.bstride), (size_t)(A.elems - batch * A.bstride) * 2);
   const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(B.p + batch * B.bstride), (size_t)(B.elems - batch * B.bstride) * 2);
   // columns past R / Cn read whatever follows in the row (or the next row): they only reach outputs that are not stored
@@ -506,31 +516,31 @@ __global__ __launch_bounds__(256, 2) void gemm_b16mc_128_kernel(GemmOperand16B A
 #pragma unroll
     for (int h = 0; h < 2; h++) if (!(CLSTM_TEXP & 4) || r[h][0] == 1234.5f) *reinterpret_cast<f32x4*>(&S[s_at + h * 256]) = r[h];
   };
-  f32x4 acc[4][4];
+  f32x4 acc[WI][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < WI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
   const int f_at = lane * 4;   // lane l of a group points at chunk l of the group's [4 n][16] block: rows 4 (l >> 4) .. + 3
-  auto read_frags = [&](const int buf, u16x8 (&af)[4], u16x8 (&bf)[4]) {
+  auto read_frags = [&](const int buf, u16x8 (&af)[WI], u16x8 (&bf)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const unsigned short* ap = &As[buf + (wm * 4 + i) * GT_STRIP + f_at];
-      const unsigned short* bp = &Bs[buf + (wn * 4 + i) * GT_STRIP + f_at];
-      if (CLSTM_TEXP & 8) {   // (experiment) one fragment read per operand instead of four
-        if (i == 0) { af[0] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256)); bf[0] = join_u16x8(lds_read_tr16(bp), lds_read_tr16(bp + 256)); }
-        else { af[i] = af[0]; bf[i] = bf[0]; }
-        continue;
-      }
+    for (int i = 0; i < WI; i++) {
+      const unsigned short* ap = &As[buf + (wm * WI + i) * GT_STRIP + f_at];
+      if ((CLSTM_TEXP & 8) && i > 0) { af[i] = af[0]; continue; }   // (experiment) one fragment read per operand
       af[i] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256));
-      bf[i] = join_u16x8(lds_read_tr16(bp), lds_read_tr16(bp + 256));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned short* bp = &Bs[buf + (wn * 4 + j) * GT_STRIP + f_at];
+      if ((CLSTM_TEXP & 8) && j > 0) { bf[j] = bf[0]; continue; }
+      bf[j] = join_u16x8(lds_read_tr16(bp), lds_read_tr16(bp + 256));
     }
   };
-  auto mfma_block = [&](const u16x8 (&af)[4], const u16x8 (&bf)[4]) {
+  auto mfma_block = [&](const u16x8 (&af)[WI], const u16x8 (&bf)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < WI; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) if (!(CLSTM_TEXP & 2) || (i == 0 && j == 0)) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
   };
@@ -549,26 +559,26 @@ __global__ __launch_bounds__(256, 2) void gemm_b16mc_128_kernel(GemmOperand16B A
   stage(Bs, kbeg, rb[0]);
   load_tile(kbeg + GT_PF * GB_BK, ra[0], rb[0]);
   SCHED_FENCE();
-  stage(As + GT_TILE, kbeg + GB_BK, ra[1]);
-  stage(Bs + GT_TILE, kbeg + GB_BK, rb[1]);
+  stage(As + TILE, kbeg + GB_BK, ra[1]);
+  stage(Bs + TILE, kbeg + GB_BK, rb[1]);
   load_tile(kbeg + (GT_PF + 1) * GB_BK, ra[1], rb[1]);
   SCHED_FENCE();
   __syncthreads();
-  u16x8 fa[2][4], fb[2][4];
+  u16x8 fa[2][WI], fb[2][4];
   read_frags(0, fa[0], fb[0]);
   for (int kb = kbeg; kb < kend; kb += GT_PF * GB_BK) {
 #pragma unroll
     for (int u = 0; u < GT_PF; u++) {
       const int k0 = kb + u * GB_BK;
       if (!(CLSTM_TEXP & 16)) __syncthreads();
-      read_frags(((u + 1) & 1) * GT_TILE, fa[(u + 1) & 1], fb[(u + 1) & 1]);
+      read_frags(((u + 1) & 1) * TILE, fa[(u + 1) & 1], fb[(u + 1) & 1]);
       SCHED_FENCE();
       mfma_block(fa[u & 1], fb[u & 1]);
       SCHED_FENCE();
       constexpr int dummy = 0; (void)dummy;
       const int slot = (u + 2) % GT_PF;
-      stage(As + (u & 1) * GT_TILE, k0 + 2 * GB_BK, ra[slot]);
-      stage(Bs + (u & 1) * GT_TILE, k0 + 2 * GB_BK, rb[slot]);
+      stage(As + (u & 1) * TILE, k0 + 2 * GB_BK, ra[slot]);
+      stage(Bs + (u & 1) * TILE, k0 + 2 * GB_BK, rb[slot]);
       load_tile(k0 + (2 + GT_PF) * GB_BK, ra[slot], rb[slot]);
       SCHED_FENCE();
     }
@@ -590,19 +600,27 @@ __global__ __launch_bounds__(256, 2) void gemm_b16mc_128_kernel(GemmOperand16B A
     for (int p = 0; p < GT_PF; p++) {
       const int k0 = kb + p * GB_BK;
       const int pn = p == GT_PF - 1 ? 0 : p + 1;
-      stage(As + (cur ^ GT_TILE), k0 + GB_BK, ra[pn]);
-      stage(Bs + (cur ^ GT_TILE), k0 + GB_BK, rb[pn]);
+      stage(As + (cur ^ TILE), k0 + GB_BK, ra[pn]);
+      stage(Bs + (cur ^ TILE), k0 + GB_BK, rb[pn]);
       load_tile(k0 + GB_BK + GT_PF * GB_BK, ra[pn], rb[pn]);
       SCHED_FENCE();
-      u16x8 af[4], bf[4];
+      u16x8 af[WI], bf[4];
       read_frags(cur, af, bf);
       mfma_block(af, bf);
       if (!(CLSTM_TEXP & 16)) __syncthreads();
-      cur ^= GT_TILE;
+      cur ^= TILE;
     }
   }
 #endif
-  gb2_store(fe, acc, r0 + wm * 64, c0 + wn * 64, lane, R, Cn, z);
+  gb2_store<FE, WI>(fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, z);
+}
+// 256 x 256 tiles where the problem is large enough and their padding costs at most 10 % more work than 128 x 128 tiles do
+// (1537 rows: 7 x 256 vs 13 x 128, + 8 %; 561 rows: 3 x 256 vs 5 x 128, + 20 % -- stays with 128)
+inline bool gemm_tile256(int R, int Cn) {
+  static const bool on = !(getenv("CLSTM_GEMM_T256") && atoi(getenv("CLSTM_GEMM_T256")) == 0);
+  if (!on || R < 192 || Cn < 192) return false;
+  const long long w256 = (long long)((R + 255) / 256) * ((Cn + 255) / 256) * 4, w128 = (long long)((R + 127) / 128) * ((Cn + 127) / 128);
+  return 10 * w256 <= 11 * w128;
 }
 template <class FE>
 inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1) {
@@ -611,8 +629,13 @@ inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, F
   int ksplit = (K + nsplit - 1) / nsplit;
   const int kq = nsplit > 1 ? GT_PF * GB_BK : GB_BK;
   ksplit = ((ksplit + kq - 1) / kq) * kq;
+  if (gemm_tile256(R, Cn)) {
+    dim3 grid((Cn + 255) / 256, (R + 255) / 256, nsplit * nbatch);
+    CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+    return;
+  }
   dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);
-  CLSTM_LAUNCH((gemm_b16mc_128_kernel<FE>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+  CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 4>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
 }
 
 // ---- f32-grade products on the bf16 MFMA: 64 x 64 tile, operands split hi + lo ------------------------------------------

@@ -24,8 +24,10 @@ dt = (time.perf_counter() - t0) / n
 print("R %d Cn %d K %d ns %d: %.1f us  %.0f TFLOP/s" % (R, Cn, K, ns, dt * 1e6, 2.0 * R * Cn * K / dt / 1e12))
 '''
 shapes = [(1544, 2048, 25600, 2), (568, 2048, 25600, 3)]
+if os.environ.get("GEMM_SHAPES"):   # "R,Cn,K,ns;R,Cn,K,ns"
+    shapes = [tuple(int(x) for x in t.split(",")) for t in os.environ["GEMM_SHAPES"].split(";")]
 for v in [""] + sys.argv[1:]:
     env = dict(os.environ, CLSTM_HIP_VARIANT=v)
-    for sh in shapes[:1 if v else 2]:
+    for sh in (shapes if os.environ.get("GEMM_SHAPES") else shapes[:1 if v else 2]):
         out = subprocess.run([sys.executable, "-c", CHILD] + [str(x) for x in sh], env=env, capture_output=True, text=True, timeout=300)
         print("[%s]" % (v or "base"), (out.stdout.strip().splitlines() or [out.stderr[-300:]])[-1], flush=True)

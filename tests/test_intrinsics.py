@@ -108,7 +108,8 @@ def _bf16_bits(x):
     return u.astype(np.uint16)
 
 
-@pytest.mark.parametrize("R,Cn,K", [(128, 128, 32), (256, 256, 64), (97, 200, 30), (300, 130, 1000), (129, 513, 96)])
+@pytest.mark.parametrize("R,Cn,K", [(128, 128, 32), (256, 256, 64), (97, 200, 30), (300, 130, 1000), (129, 513, 96),
+                                    (500, 512, 96), (250, 760, 70)])   # (256, 256) and the last two: 256 x 256 tiles
 def test_gemm_bf16_sources(backend, R, Cn, K):
     """128 x 128-tile GEMM whose operands are ALREADY bf16 and k-contiguous in memory (gemm_b16kk_128_kernel): exact
     against the float64 product of the same bf16 values (f32 accumulation: 2e-6 of sum |a||b|)."""
@@ -128,7 +129,8 @@ def test_gemm_bf16_sources(backend, R, Cn, K):
     assert (np.abs(got - want) <= 2e-6 * scale + 1e-6).all()
 
 
-@pytest.mark.parametrize("R,Cn,K,ns", [(128, 128, 32, 1), (256, 256, 64, 1), (104, 200, 30, 1), (304, 136, 1000, 3), (136, 520, 700, 2)])
+@pytest.mark.parametrize("R,Cn,K,ns", [(128, 128, 32, 1), (256, 256, 64, 1), (104, 200, 30, 1), (304, 136, 1000, 3), (136, 520, 700, 2),
+                                       (504, 512, 700, 2), (248, 760, 130, 1)])   # (256, 256) and the last two: 256 x 256 tiles
 def test_gemm_bf16_contraction_major(backend, R, Cn, K, ns):
     """128 x 128-tile GEMM whose bf16 operands lie contraction-major in memory ([K][R], [K][Cn]: the weight-gradient
     product's frame-major deltas and sources), transposed by ds_read_b64_tr_b16 on the way into the MFMA
