@@ -625,6 +625,7 @@ struct Layer {
   bool fwd_persistent = false; // this forward pass ran the persistent kernel (Hbf is valid)
   DevBuf<unsigned short> Sbf;  // bf16 source rows [x | h_{t-1} | 1] per direction (x: k_source_x_bf16, h: the persistent forward kernel)
   bool sbf_ready = false;      // ... complete for this forward pass
+  bool d_f32_valid = true;     // D (f32 gate deltas) is current (a persistent bf16 backward pass may leave only Dbf)
   bool sx_valid = true;        // the [1 | x] columns of S (f32) are current (built lazily when the bf16 rows serve the weight gradient)
   DevBuf<unsigned short> Dbf;  // per-frame bf16 gate deltas written by the persistent backward kernel (A operand of the x.d GEMM)
   DevBuf<unsigned short> Wtb;  // bf16 copy of Wt ([ni][M], k = gate column contiguous): B operand of the bf16-source x.d product
@@ -889,7 +890,13 @@ struct Net {
       w.kp16 = fwd ? wide_kp16_fwd(y.no) : wide_kp16_bwd(y.no);
       w.rw_elems = (long long)ndir * (fwd ? (y.no + 3) / 4 : (y.no + 15) / 16) * 16 * w.kp16;
       w.Hb = y.Hb.p; w.Db = y.Db.p;
-      if (!fwd && wide_kp16_bwd(y.no) == 4 * y.no) { y.Dbf.reserve((size_t)N * ndir * w.kp16 + 64); w.Dbf = y.Dbf.p; }
+      if (!fwd && wide_kp16_bwd(y.no) == 4 * y.no) {
+        y.Dbf.reserve((size_t)N * ndir * w.kp16 + 64); w.Dbf = y.Dbf.p;
+        // with bf16 GEMMs behind it, nobody reads the f32 deltas of a persistent pass (16 bytes per lane and step, 0.17 ms
+        // per configs[4] minibatch); ensure_delta_f32() expands Dbf for a fallback product
+        static const bool skip = !(getenv("CLSTM_XCD_SKIP_D") && atoi(getenv("CLSTM_XCD_SKIP_D")) == 0);
+        w.skip_d = skip && bf16_gemm;
+      }
       static const bool b16mc_on = !(getenv("CLSTM_GEMM_B16MC") && atoi(getenv("CLSTM_GEMM_B16MC")) == 0);
       if (fwd && b16mc_on && bf16_gemm && (y.ni & 7) == 0 && (y.no & 7) == 0 && wide_kp16_bwd(y.no) == 4 * y.no) {
         const int ldsb = y.ni + y.no + 8;
@@ -901,6 +908,12 @@ struct Net {
     return w;
   }
 
+  void ensure_delta_f32(int l) {
+    Layer& y = L[l];
+    if (y.d_f32_valid) return;
+    CLSTM_LAUNCH(k_bf16_to_f32, dim3(nblocks((size_t)N * ndir * 4 * y.no)), dim3(256), 0, stream(), y.Dbf.p, y.D.p, (size_t)N * ndir * 4 * y.no);
+    y.d_f32_valid = true;
+  }
   void ensure_source_x(int l) {
     Layer& y = L[l];
     if (y.sx_valid) return;
@@ -1314,10 +1327,15 @@ struct Net {
         timing.begin("reduce_scatter", s);
       } else {
       timing.begin("lstm_bwd", s);
-      if (y.wide) launch_lstm_wide(false, wide_args(y, false), tmax, coop_sync, step_graphs, s, bf16_rec);
-      else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
+      int skipped_d = 0;
+      if (y.wide) {
+        const LstmWideArgs w = wide_args(y, false);
+        launch_lstm_wide(false, w, tmax, coop_sync, step_graphs, s, bf16_rec);
+        skipped_d = w.skip_d;
+      } else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
       bwd_persistent = y.wide && g_wide_persistent;
+      y.d_f32_valid = !(bwd_persistent && bf16_rec && skipped_d);
       if (bwd_persistent) g_path_count[1]++;
       }
       // (Experiment, off by default.)  Stacked lock-step layers in bf16: the weight-gradient product of layer l (~1 ms at 2 x BiLSTM(512)) depends only on
@@ -1329,7 +1347,7 @@ struct Net {
       if (bf16_gemm || !overlap_eligible(y))
         ns = dw_from_bf16 && gemm_tile256(R, Cn) ? pick_split(R, Cn, ndir, 256)
              : bf16_gemm && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
-      if (!dw_from_bf16) ensure_source_x(l);   // the f32-source products below read S
+      if (!dw_from_bf16) { ensure_source_x(l); ensure_delta_f32(l); }   // the f32-source products below read S and D
       const bool defer = l > 0 && y.wide && bf16_rec && bf16_gemm && dw_side_stream();
       DevBuf<float>& pbuf = defer ? y.pdw : partial;
       auto do_dw = [&](hipStream_t q) {
@@ -1374,7 +1392,7 @@ struct Net {
           g_path_count[3]++;
           gemm_b16kk(s, GemmOperand16{y.Dbf.p, M, (long long)N * M}, GemmOperand16{y.Wtb.p, M, (long long)y.ni * M},
                      StorePlain{dx, y.ni}, (int)N, y.ni, M);
-        } else if (bf16_gemm)
+        } else if (ensure_delta_f32(l), bf16_gemm)
           gemm_bf16<GEMM_KC, GEMM_KC>(s, gemm_kc(y.D.p, M, N, 32), gemm_kc(y.Wt, M, y.ni, y.wt_slack), StorePlain{dx, y.ni},
                                       (int)N, y.ni, M);
         else

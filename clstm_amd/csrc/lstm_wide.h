@@ -52,6 +52,7 @@ struct LstmWideArgs {
   unsigned short* Db;           // [N][nd][kp16]  bf16 copy of the gate deltas at column 4*cell+gate (backward A operand)
   unsigned short* Hbf;          // persistent forward kernel: per-frame [N][hbf_ld] bf16 copy of h (dir d at column d*no): the next
   int hbf_ld;                   //   layer's W_x product reads it as its k-contiguous A operand; or null
+  int skip_d;                   // persistent backward kernel: the f32 deltas D are not stored (every consumer reads Dbf; the host expands Dbf if one does not)
   unsigned short* Sbf;          // persistent forward kernel: bf16 source rows [x | h_{t-1} | 1] of THIS layer, [dir][N][sbf_ld] (h-part written here), or null
   int sbf_ld, sbf_ofs; long long sbf_dir;
   unsigned short* Dbf;          // persistent backward kernel: per-frame [N][nd][kp16] bf16 deltas (operand of the x.d GEMM), or null
@@ -975,9 +976,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
       *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
       a.C[(n * nd + dir) * no + cell] = c_new;
       a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
+      if (!(CLSTM_WEXP & 64)) {
       float* srow = a.S + (size_t)dir * a.sdir;
       if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
       if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+      }
     }
     const float hn = quad_xor1(h);
     if (live && !(c16 & 1)) {
@@ -1166,7 +1169,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       if (live[j]) {
-        *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cellj[j]) * 4) = dl[j];
+        if (!a.skip_d) *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cellj[j]) * 4) = dl[j];
         if (a.Dbf) {   // k-contiguous bf16 copy per frame: the ready-made A operand of the x.d product (gemm_b16kk)
           unsigned* df = reinterpret_cast<unsigned*>(a.Dbf + (size_t)(n * nd + dir) * a.kp16 + 4 * cellj[j]);
           df[0] = bf16_pack2(dl[j][0], dl[j][1]);

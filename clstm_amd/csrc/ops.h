@@ -401,6 +401,11 @@ __global__ void k_ingest(const float* x, float* X, float* S, size_t N, int ni, i
     for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = v;
   }
 }
+// f32 expansion of a bf16 array (exact): the gate deltas for a fallback product when the persistent backward recurrence
+// stored only their bf16 form
+__global__ void k_bf16_to_f32(const unsigned short* src, float* dst, size_t n) {
+  CLSTM_GRID_STRIDE(e, n) dst[e] = __builtin_bit_cast(float, (unsigned)src[e] << 16);
+}
 // bf16 copy of an f32 array (weight operands of the bf16-source GEMM, gemm_bf16.h)
 __global__ void k_to_bf16(const float* src, unsigned short* dst, size_t n) {
   CLSTM_GRID_STRIDE(e, n) dst[e] = (unsigned short)(bf16_pack2(src[e], 0.0f) & 0xFFFFu);

@@ -249,7 +249,10 @@ def test_bf16_gate_gemms_track_the_f32_path(backend, ora32):
 @pytest.mark.parametrize("nh,T", [([20, 16], [9, 5, 7]), ([37], [12, 1, 8]),
                                   # 20 ragged lines = two line blocks x two directions = four XCD groups of the persistent kernels
                                   ([48, 32], [14, 9, 3, 11, 7, 14, 1, 8, 13, 5, 12, 6, 10, 2, 9, 14, 4, 11, 7, 13]),
-                                  ([32, 32], [9, 5, 7, 3])])
+                                  ([32, 32], [9, 5, 7, 3]),
+                                  # persistent backward pass that stores only bf16 deltas + a weight-gradient product that falls back to
+                                  # the f32-source kernel (12 inputs: no bf16 source rows): the deltas are expanded on demand
+                                  ([32], [9, 5, 7, 3])])
 def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatch, nh, T):
     """clstm_net_set_gemm_precision(2): bf16 MFMA operands (recurrent weights, h, gate deltas) inside the lock-step
     recurrence (lstm_wide.h, *_step_bf16) on top of the bf16 hoisted GEMMs -- BASELINE config "2 x BiLSTM(512), bf16 MFMA".
