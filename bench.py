@@ -276,7 +276,7 @@ def main():
                             "frac": round(tf / peak, 5), "traffic": None,
                             "algorithmic_flops": int(fl / nl), "avg_launch_ms": round(sec / nl * 1e3, 4),
                             "note": ("lock-step recurrence, ONE persistent launch per pass: a workgroup group per XCD, %d group-barrier-separated steps (latency-bound); "
-                                     if args.bf16 and os.environ.get("CLSTM_XCD_REC", "1") != "0" else
+                                     if os.environ.get("CLSTM_XCD_REC", "1") != "0" and os.environ.get("CLSTM_COOP", "0") == "0" else
                                      "lock-step recurrence, one launch per time step (latency-bound: %d dependent launches per pass); ") % args.T +
                                     "whole step: %.1f TFLOP/s of algorithmic flops (SURVEY 8d: 48 T sum no(ni+no) + 6 T nc 2no per line)"
                                     % ((48.0 * args.T * sum(o * (i + o) for i, o in zip([NI] + [2 * h for h in nh_list[:-1]], nh_list))
