@@ -669,6 +669,7 @@ struct Net {
     lo_pending = false;
   }
   DevBuf<float> X, Z, Dz, dX0, partial, partial_sm, aligned, tmp;
+  DevBuf<unsigned short> xbf;   // bf16 copy of the input frames (first wide layer's W_x product in precision mode 2)
   ReduceDesc sm_red{};
   DevBuf<long long> lstm_prof;  // diagnostics build only
   StepGraphCache step_graphs;   // captured per-step launch sequences of the lock-step recurrence
@@ -941,6 +942,14 @@ struct Net {
         // the layer below left its outputs as a k-contiguous bf16 array: both operands go to LDS as they are
         g_path_count[2]++;
         gemm_b16kk(s, GemmOperand16{L[l - 1].Hbf.p, y.ni, (long long)N * y.ni}, GemmOperand16{y.WtbT.p, y.ni, (long long)M * y.ni},
+                   StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
+      } else if (b16src && bf16_gemm && bf16_rec && l == 0 && y.wide && y.WtbT.p && (y.ni & 7) == 0 && gemm_tile256((int)N, M)) {
+        // first layer: a bf16 copy of the input frames (N x ni, a few MB) buys the bf16-source kernel with its 256 x 256
+        // tiles and 16-byte stores for the product whose 4 M floats of pre-activations per frame-line are its whole cost
+        xbf.reserve((size_t)N * y.ni + 64);
+        CLSTM_LAUNCH(k_to_bf16, dim3(nblocks((size_t)N * y.ni)), dim3(256), 0, s, layer_input(0), xbf.p, (size_t)N * y.ni);
+        g_path_count[2]++;
+        gemm_b16kk(s, GemmOperand16{xbf.p, y.ni, (long long)N * y.ni}, GemmOperand16{y.WtbT.p, y.ni, (long long)M * y.ni},
                    StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
       } else if (bf16_gemm)
         gemm_bf16<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N, layer_input_slack(l)),
