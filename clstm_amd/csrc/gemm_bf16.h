@@ -457,21 +457,18 @@ inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE 
 #define CLSTM_TEXP 0
 #endif
 struct GemmOperand16B { const unsigned short* p; int ld; long long elems; long long bstride; };   // halfs; ld % 8 == 0, bstride even
-constexpr int GT_STRIP = 32 * 16 + 16;   // halfs
-constexpr int GT_TILE = 8 * GT_STRIP;
 #ifndef CLSTM_GT_PF
 #define CLSTM_GT_PF 3
 #endif
-constexpr int GT_PF = CLSTM_GT_PF;   // 32-row blocks in flight in registers
-#ifndef CLSTM_GT_SWP
-#define CLSTM_GT_SWP 0
-#endif
+constexpr int GT_PF = CLSTM_GT_PF;   // blocks in flight in registers (NB = 1; two with NB = 2: the same 128 rows ahead)
 // WI = 16-row strips of a wave's tile: 4 -> 128 x 128 per workgroup (four waves 2 x 2, 64 x 64 each), 8 -> 256 x 256 (eight
 // waves 2 x 4, 128 x 64 each: half the LDS and vector-cache bytes per MFMA; one workgroup per CU).
-template <class FE, int WI>
+// NB = 32-row sub-blocks per barrier (contraction rows per LDS buffer = 32 NB).
+template <class FE, int WI, int NB>
 __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K,
-                                                                   int ksplit, int nsplit) {
-  constexpr int NWN = WI / 2, BT = 32 * WI, NSTRIP = 2 * WI, TILE = NSTRIP * GT_STRIP, CHUNKS = BT / 8;
+                                                               int ksplit, int nsplit) {
+  constexpr int NWN = WI / 2, BT = 32 * WI, NSTRIP = 2 * WI, STRIP = NB * 512 + 16, TILE = NSTRIP * STRIP, CHUNKS = BT / 8;
+  constexpr int BKB = 32 * NB, NL = 2 * NB, PF = NB == 1 ? GT_PF : 2;
   __shared__ __attribute__((aligned(16))) unsigned short As[2 * TILE];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * TILE];
   const int tid = threadIdx.x;
@@ -493,28 +490,33 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
   const int batch = z / nsplit;
   const int kbeg = (z - batch * nsplit) * ksplit;
   const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
-  const int s_c = tid % CHUNKS, s_k = tid / CHUNKS;   // 16-byte chunk of the row, contraction row (0 .. 15, and row + 16) of the block
+  const int s_c = tid % CHUNKS, s_k = tid / CHUNKS;   // 16-byte chunk of the row; contraction rows s_k + 16 h of the block
   const BufF32 abuf = make_buf(reinterpret_cast<const float*>(A.p + batch * A.bstride), (size_t)(A.elems - batch * A.bstride) * 2);
   const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(B.p + batch * B.bstride), (size_t)(B.elems - batch * B.bstride) * 2);
   // columns past R / Cn read whatever follows in the row (or the next row): they only reach outputs that are not stored
   const unsigned aoff = ((unsigned)s_k * (unsigned)A.ld + (unsigned)(r0 + s_c * 8)) * 2u, a16 = 32u * (unsigned)A.ld;
   const unsigned boff = ((unsigned)s_k * (unsigned)B.ld + (unsigned)(c0 + s_c * 8)) * 2u, b16 = 32u * (unsigned)B.ld;
   const unsigned a_kstep = 2u * (unsigned)A.ld, b_kstep = 2u * (unsigned)B.ld;
-  f32x4 ra[GT_PF][2], rb[GT_PF][2];
+  f32x4 ra[PF][NL], rb[PF][NL];
   // contraction rows past the slab load zeros: their offset is pushed out of the descriptor's range (one select per
   // load instead of one per staged element; nothing to mask when the block is staged)
-  auto load_tile = [&](int k0, f32x4 (&a)[2], f32x4 (&b)[2]) {
+  auto load_tile = [&](int k0, f32x4 (&a)[NL], f32x4 (&b)[NL]) {
     const unsigned kc = (unsigned)wave_uniform(k0);
-    const bool l0 = !(CLSTM_TEXP & 1) && k0 + s_k < kend, l1 = !(CLSTM_TEXP & 1) && k0 + s_k + 16 < kend;
-    a[0] = buf_load4(abuf, l0 ? aoff + kc * a_kstep : BUF_OOB);
-    a[1] = buf_load4(abuf, l1 ? aoff + kc * a_kstep + a16 : BUF_OOB);
-    b[0] = buf_load4(bbuf, l0 ? boff + kc * b_kstep : BUF_OOB);
-    b[1] = buf_load4(bbuf, l1 ? boff + kc * b_kstep + b16 : BUF_OOB);
-  };
-  const int s_at = (s_c >> 1) * GT_STRIP + s_k * 16 + (s_c & 1) * 8;
-  auto stage = [&](unsigned short* S, const int, const f32x4 (&r)[2]) {
 #pragma unroll
-    for (int h = 0; h < 2; h++) if (!(CLSTM_TEXP & 4) || r[h][0] == 1234.5f) *reinterpret_cast<f32x4*>(&S[s_at + h * 256]) = r[h];
+    for (int h = 0; h < NL; h++) {
+      const bool lv = !(CLSTM_TEXP & 1) && k0 + s_k + 16 * h < kend;
+      a[h] = buf_load4(abuf, lv ? aoff + kc * a_kstep + (unsigned)h * a16 : BUF_OOB);
+    }
+#pragma unroll
+    for (int h = 0; h < NL; h++) {
+      const bool lv = !(CLSTM_TEXP & 1) && k0 + s_k + 16 * h < kend;
+      b[h] = buf_load4(bbuf, lv ? boff + kc * b_kstep + (unsigned)h * b16 : BUF_OOB);
+    }
+  };
+  const int s_at = (s_c >> 1) * STRIP + s_k * 16 + (s_c & 1) * 8;
+  auto stage = [&](unsigned short* S, const f32x4 (&r)[NL]) {
+#pragma unroll
+    for (int h = 0; h < NL; h++) if (!(CLSTM_TEXP & 4) || r[h][0] == 1234.5f) *reinterpret_cast<f32x4*>(&S[s_at + h * 256]) = r[h];
   };
   f32x4 acc[WI][4];
 #pragma unroll
@@ -524,94 +526,56 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
 #pragma unroll
       for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
   const int f_at = lane * 4;   // lane l of a group points at chunk l of the group's [4 n][16] block: rows 4 (l >> 4) .. + 3
-  auto read_frags = [&](const int buf, u16x8 (&af)[WI], u16x8 (&bf)[4]) {
-#pragma unroll
-    for (int i = 0; i < WI; i++) {
-      const unsigned short* ap = &As[buf + (wm * WI + i) * GT_STRIP + f_at];
-      if ((CLSTM_TEXP & 8) && i > 0) { af[i] = af[0]; continue; }   // (experiment) one fragment read per operand
-      af[i] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256));
-    }
+  auto mfma_sub = [&](const int buf) {   // one 32-row sub-block: fragments by transpose reads, WI x 4 MFMAs
+    u16x8 bf[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const unsigned short* bp = &Bs[buf + (wn * 4 + j) * GT_STRIP + f_at];
-      if ((CLSTM_TEXP & 8) && j > 0) { bf[j] = bf[0]; continue; }
+      const unsigned short* bp = &Bs[buf + (wn * 4 + j) * STRIP + f_at];
+      if ((CLSTM_TEXP & 8) && j > 0) { bf[j] = bf[0]; continue; }   // (experiment) one fragment read per operand
       bf[j] = join_u16x8(lds_read_tr16(bp), lds_read_tr16(bp + 256));
     }
-  };
-  auto mfma_block = [&](const u16x8 (&af)[WI], const u16x8 (&bf)[4]) {
 #pragma unroll
-    for (int i = 0; i < WI; i++)
+    for (int i0 = 0; i0 < WI; i0 += 4) {   // four A strips at a time: 32 fragment registers live, not 16 + 4 WI
+      u16x8 af[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) if (!(CLSTM_TEXP & 2) || (i == 0 && j == 0)) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
-  };
-#if CLSTM_GT_SWP
-  // Software pipeline, one barrier per 32-row block b:  LDS holds blocks b and b + 1, the register ring blocks b + 2 ..
-  // b + 1 + GT_PF, and the fragments of block b were READ during block b - 1.  After the barrier (everyone has its
-  // fragments of b, everyone's copy of b + 1 is in LDS) a wave issues the fragment reads of b + 1, then the 16 MFMAs of b
-  // -- which run while those reads return -- then overwrites b's LDS buffer with b + 2 and reloads the ring slot.
-  static_assert((GT_PF & 1) == 0 || !CLSTM_GT_SWP, "fragment parity and ring slot must both be static: even ring depth");
+      for (int i = 0; i < 4; i++) {
+        const unsigned short* ap = &As[buf + (wm * WI + i0 + i) * STRIP + f_at];
+        if ((CLSTM_TEXP & 8) && i > 0) { af[i] = af[0]; continue; }
+        af[i] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256));
+      }
 #pragma unroll
-  for (int p = 0; p < GT_PF; p++) {
-    load_tile(kbeg + p * GB_BK, ra[p], rb[p]);
-    SCHED_FENCE();
-  }
-  stage(As, kbeg, ra[0]);
-  stage(Bs, kbeg, rb[0]);
-  load_tile(kbeg + GT_PF * GB_BK, ra[0], rb[0]);
-  SCHED_FENCE();
-  stage(As + TILE, kbeg + GB_BK, ra[1]);
-  stage(Bs + TILE, kbeg + GB_BK, rb[1]);
-  load_tile(kbeg + (GT_PF + 1) * GB_BK, ra[1], rb[1]);
-  SCHED_FENCE();
-  __syncthreads();
-  u16x8 fa[2][WI], fb[2][4];
-  read_frags(0, fa[0], fb[0]);
-  for (int kb = kbeg; kb < kend; kb += GT_PF * GB_BK) {
+      for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int u = 0; u < GT_PF; u++) {
-      const int k0 = kb + u * GB_BK;
-      if (!(CLSTM_TEXP & 16)) __syncthreads();
-      read_frags(((u + 1) & 1) * TILE, fa[(u + 1) & 1], fb[(u + 1) & 1]);
-      SCHED_FENCE();
-      mfma_block(fa[u & 1], fb[u & 1]);
-      SCHED_FENCE();
-      constexpr int dummy = 0; (void)dummy;
-      const int slot = (u + 2) % GT_PF;
-      stage(As + (u & 1) * TILE, k0 + 2 * GB_BK, ra[slot]);
-      stage(Bs + (u & 1) * TILE, k0 + 2 * GB_BK, rb[slot]);
-      load_tile(k0 + (2 + GT_PF) * GB_BK, ra[slot], rb[slot]);
-      SCHED_FENCE();
+        for (int j = 0; j < 4; j++) if (!(CLSTM_TEXP & 2) || (i0 + i == 0 && j == 0)) acc[i0 + i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i0 + i][j]);   // transposed: see gb2_store
+      if (NB > 1) SCHED_FENCE();
     }
-  }
-#else
+  };
 #pragma unroll
-  for (int p = 0; p < GT_PF; p++) {
-    load_tile(kbeg + p * GB_BK, ra[p], rb[p]);
+  for (int p = 0; p < PF; p++) {
+    load_tile(kbeg + p * BKB, ra[p], rb[p]);
     SCHED_FENCE();
   }
-  stage(As, kbeg, ra[0]);
-  stage(Bs, kbeg, rb[0]);
-  load_tile(kbeg + GT_PF * GB_BK, ra[0], rb[0]);
+  stage(As, ra[0]);
+  stage(Bs, rb[0]);
+  load_tile(kbeg + PF * BKB, ra[0], rb[0]);
   SCHED_FENCE();
   __syncthreads();
   int cur = 0;
-  for (int kb = kbeg; kb < kend; kb += GT_PF * GB_BK) {
+  for (int kb = kbeg; kb < kend; kb += PF * BKB) {
 #pragma unroll
-    for (int p = 0; p < GT_PF; p++) {
-      const int k0 = kb + p * GB_BK;
-      const int pn = p == GT_PF - 1 ? 0 : p + 1;
-      stage(As + (cur ^ TILE), k0 + GB_BK, ra[pn]);
-      stage(Bs + (cur ^ TILE), k0 + GB_BK, rb[pn]);
-      load_tile(k0 + GB_BK + GT_PF * GB_BK, ra[pn], rb[pn]);
+    for (int p = 0; p < PF; p++) {
+      const int k0 = kb + p * BKB;
+      const int pn = p == PF - 1 ? 0 : p + 1;
+      stage(As + (cur ^ TILE), ra[pn]);
+      stage(Bs + (cur ^ TILE), rb[pn]);
+      load_tile(k0 + BKB + PF * BKB, ra[pn], rb[pn]);
       SCHED_FENCE();
-      u16x8 af[WI], bf[4];
-      read_frags(cur, af, bf);
-      mfma_block(af, bf);
+#pragma unroll
+      for (int sb = 0; sb < NB; sb++) mfma_sub(cur + sb * 512);
       if (!(CLSTM_TEXP & 16)) __syncthreads();
       cur ^= TILE;
     }
   }
-#endif
   gb2_store<FE, WI>(fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, z);
 }
 // 256 x 256 tiles where the problem is large enough and their padding costs at most 10 % more work than 128 x 128 tiles do
@@ -626,16 +590,21 @@ template <class FE>
 inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1) {
   if (R <= 0 || Cn <= 0 || K <= 0) return;
   if (nsplit < 1) nsplit = 1;
+  // (experiment, CLSTM_GEMM_BK64=1: 64 contraction rows per barrier on the 256 x 256 tile -- 231 VGPRs, 130 KB LDS, measured
+  // equal to the 32-row loop: 227 vs 226 us at 1544 x 2048 x 25600)
+  static const bool bk64 = getenv("CLSTM_GEMM_BK64") && atoi(getenv("CLSTM_GEMM_BK64")) != 0;
+  const bool big = gemm_tile256(R, Cn);
   int ksplit = (K + nsplit - 1) / nsplit;
-  const int kq = nsplit > 1 ? GT_PF * GB_BK : GB_BK;
+  const int kq = nsplit > 1 ? (big && bk64 ? 2 * 64 : GT_PF * GB_BK) : (big && bk64 ? 64 : GB_BK);   // whole ring rounds per slab
   ksplit = ((ksplit + kq - 1) / kq) * kq;
-  if (gemm_tile256(R, Cn)) {
+  if (big) {
     dim3 grid((Cn + 255) / 256, (R + 255) / 256, nsplit * nbatch);
-    CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+    if (bk64) CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 2>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+    else CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 1>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
     return;
   }
   dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);
-  CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 4>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+  CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 4, 1>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
 }
 
 // ---- f32-grade products on the bf16 MFMA: 64 x 64 tile, operands split hi + lo ------------------------------------------

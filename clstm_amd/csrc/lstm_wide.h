@@ -972,7 +972,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
       h = gate_act(c_new, true) * go;
       act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
     }
-    if (live) {
+    if (live && !(CLSTM_WEXP & 256)) {
       *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
       a.C[(n * nd + dir) * no + cell] = c_new;
       a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
@@ -986,8 +986,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
     if (live && !(c16 & 1)) {
       const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);
       *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) = hp;
-      if (a.Hbf) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
-      if (a.Sbf) {   // h_{t-1} column block of the next frame's bf16 source row (weight-gradient operand, gemm_b16mc)
+      if (a.Hbf && !(CLSTM_WEXP & 256)) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
+      if (a.Sbf && !(CLSTM_WEXP & 256)) {   // h_{t-1} column block of the next frame's bf16 source row (weight-gradient operand, gemm_b16mc)
         unsigned short* sb = a.Sbf + (size_t)dir * a.sbf_dir + a.sbf_ofs + cell;
         if (sg == 0) *reinterpret_cast<unsigned*>(sb + (size_t)n * a.sbf_ld) = 0u;
         if (sg + 1 < T) *reinterpret_cast<unsigned*>(sb + (size_t)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.sbf_ld) = hp;
