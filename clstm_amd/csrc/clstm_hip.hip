@@ -239,7 +239,8 @@ static int device_cu_count() {
   }();
   return n;
 #else
-  return 16;   // emulator: keeps cooperative test grids small
+  static const int n = getenv("CLSTM_EMU_CUS") ? atoi(getenv("CLSTM_EMU_CUS")) : 16;   // emulator: keeps cooperative test grids small
+  return n;
 #endif
 }
 template <class K>
@@ -339,11 +340,17 @@ struct XcdOutcome {
     return *err_d == 0;
 #else
     if (verified < 4) {
-      int flag = 0;
-      HIPCHECK(hipMemcpyAsync(&flag, err_d, sizeof(int), hipMemcpyDeviceToHost, s));
+      int w[32] = {0};   // sync words 0..31: [1] = error word, [2..7] = diagnostics of a timed-out wait (lstm_wide.h)
+      HIPCHECK(hipMemcpyAsync(w, err_d - 1, sizeof(w), hipMemcpyDeviceToHost, s));
       HIPCHECK(hipStreamSynchronize(s));
+      const int flag = w[1];
       if (flag == 0) { verified++; return true; }
-      if (flag != 1) throw Error("persistent recurrence: a group barrier timed out in the middle of the sequence; set CLSTM_XCD_REC=0");
+      if (flag != 1) {
+        char msg[640];
+        snprintf(msg, sizeof msg, "persistent recurrence: a group barrier timed out in the middle of the sequence; set CLSTM_XCD_REC=0 "
+                 "[step %d, saw tag 0x%x, waited for 0x%x, wave/lane 0x%x, xcd/tile 0x%x]", w[2], w[3], w[4], w[5], w[6]);
+        throw Error(msg);
+      }
       return false;
     }
     if (!pinned) HIPCHECK(hipHostMalloc((void**)&pinned, SLOTS * sizeof(int)));
@@ -419,8 +426,19 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
         a.sync = sync.p;
         HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
         const size_t smem = (size_t)xcd_fwd_lds_bytes();
-        coop_set_smem(lstm_xcd_fwd_bf16, smem);
-        CLSTM_LAUNCH_COOP(lstm_xcd_fwd_bf16, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+        // (experiment, CLSTM_XCD_LL=1) tagged h ring, "flag in data" (lstm_wide.h): correct, but 3.1 us per step against
+        // 2.0 us with the stamp barrier on the part -- off by default
+        static const bool ll_on = getenv("CLSTM_XCD_LL") && atoi(getenv("CLSTM_XCD_LL")) != 0;
+        static unsigned epoch = 0;
+        if (ll_on && tmax < 4096 && (a.kp16 & 1) == 0) {
+          a.epoch = (++epoch) & 0xFFFFFu;
+          if (a.epoch == 0) a.epoch = (++epoch) & 0xFFFFFu;   // 0 is what a fresh (zero-filled) ring holds
+          coop_set_smem(lstm_xcd_fwd_bf16<true>, smem);
+          CLSTM_LAUNCH_COOP(lstm_xcd_fwd_bf16<true>, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+        } else {
+          coop_set_smem(lstm_xcd_fwd_bf16<false>, smem);
+          CLSTM_LAUNCH_COOP(lstm_xcd_fwd_bf16<false>, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+        }
         check_launch();
         ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
         REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
@@ -865,7 +883,7 @@ struct Net {
       y.dH.reserve((size_t)N * ndir * y.no);
       if (y.wide && bf16_rec) {
         // lock-step rings [step parity][dir][line][k] (lstm_wide.h); never smaller than the per-frame layout of the first version
-        y.Hb.reserve((size_t)std::max<long long>(N, 2LL * bs) * ndir * wide_kp16_fwd(y.no) + 64);
+        y.Hb.reserve((size_t)std::max<long long>(N, 4LL * bs) * ndir * wide_kp16_fwd(y.no) + 64);   // (4 bs: the tagged ring of the persistent forward kernel)
         y.Db.reserve((size_t)std::max<long long>(N, 2LL * bs) * ndir * wide_kp16_bwd(y.no) + 64);
       }
       y.S.reserve((size_t)N * ndir * y.lds + 64);
@@ -1903,7 +1921,7 @@ int clstm_net_set_gemm_precision(clstm_net* h, int mode) {
   if (n.N > 0 && rec)   // a batch is already declared: make room for the bf16 operand copies
     for (auto& y : n.L)
       if (y.wide) {
-        y.Hb.reserve((size_t)std::max<long long>(n.N, 2LL * n.bs) * n.ndir * wide_kp16_fwd(y.no) + 64);
+        y.Hb.reserve((size_t)std::max<long long>(n.N, 4LL * n.bs) * n.ndir * wide_kp16_fwd(y.no) + 64);
         y.Db.reserve((size_t)std::max<long long>(n.N, 2LL * n.bs) * n.ndir * wide_kp16_bwd(y.no) + 64);
       }
   ABI_END

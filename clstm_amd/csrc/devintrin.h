@@ -239,6 +239,18 @@ DEVFN float max_f32(float x, float y) {   // v_max_f32 without the canonicalisin
 DEVFN f32x4 buf_load4_dev(BufF32 b, unsigned byte_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, byte_off, 0, 16));
 }
+// polling loops over such loads: the compiler may hoist a loop-invariant load out of the loop (no write to that memory is
+// visible to it); a memory clobber at the top of the loop keeps it inside without changing the cache policy
+#define COMPILER_MEMORY_BARRIER() asm volatile("" ::: "memory")
+// the same as four INTEGER dwords (tagged ring units: data words and tag words side by side; keeping the tags out of the
+// floating-point type keeps the compiler from treating the four lanes of the vector alike)
+struct U32x4 { unsigned v[4]; };
+DEVFN U32x4 buf_load4u_dev(BufF32 b, unsigned byte_off) {
+  const i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(b.r, byte_off, 0, 16);
+  U32x4 o;
+  o.v[0] = (unsigned)r[0]; o.v[1] = (unsigned)r[1]; o.v[2] = (unsigned)r[2]; o.v[3] = (unsigned)r[3];
+  return o;
+}
 DEVFN void buf_store_dev(BufF32 b, unsigned byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.r, byte_off, 0, 16);
 }

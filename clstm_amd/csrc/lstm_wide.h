@@ -52,6 +52,7 @@ struct LstmWideArgs {
   unsigned short* Db;           // [N][nd][kp16]  bf16 copy of the gate deltas at column 4*cell+gate (backward A operand)
   unsigned short* Hbf;          // persistent forward kernel: per-frame [N][hbf_ld] bf16 copy of h (dir d at column d*no): the next
   int hbf_ld;                   //   layer's W_x product reads it as its k-contiguous A operand; or null
+  unsigned epoch;               // persistent forward kernel with the tagged ring: launch number (tags = epoch << 12 | step)
   int skip_d;                   // persistent backward kernel: the f32 deltas D are not stored (every consumer reads Dbf; the host expands Dbf if one does not)
   unsigned short* Sbf;          // persistent forward kernel: bf16 source rows [x | h_{t-1} | 1] of THIS layer, [dir][N][sbf_ld] (h-part written here), or null
   int sbf_ld, sbf_ofs; long long sbf_dir;
@@ -854,6 +855,19 @@ DEVFN bool xcd_wait_group(int* gwords, const int ntile, const int steps_done, in
   return ok;
 }
 
+// LL = 1 (EXPERIMENT, CLSTM_XCD_LL=1; measured slower than the stamp barrier, see profiles/README.md) -- "flag in data",
+// the low-latency protocol of collective libraries: every 8-byte unit of the h ring carries
+// two bf16 cells AND a 32-bit tag (launch epoch << 12 | step); a consumer needs no barrier -- it loads the ring rows it is
+// going to multiply and checks the tags of what arrived, re-loading until every unit carries the tag of the step it waits
+// for.  An aligned 8-byte store is one L2 write, so a unit is never seen half-written.  Compared with the stamp barrier
+// (store, wait for the L2's acknowledgement, workgroup barrier, stamp store, poll, THEN load) the dependent chain between
+// two steps is one store and one load.  The ring doubles (8 bytes per cell pair); a slot is rewritten two steps later,
+// which a producer can only reach after it has consumed everybody's data of the step in between (so every consumer of
+// the old contents is done), and the epoch keeps a previous launch's units from matching.
+#ifndef CLSTM_LL_POLICY   // (diagnostics) cache policy of the tagged ring: 1 system-scope loads, 2 + system-scope stores
+#define CLSTM_LL_POLICY 0
+#endif
+template <bool LL>
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a) {
   unsigned short* wl = dyn_smem<unsigned short>();                         // [64][XCD_LDW]
   float* red = reinterpret_cast<float*>(wl + 64 * XCD_LDW);                // [4][16][68]
@@ -905,12 +919,13 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   const bool mine = line < a.bs && cell < no;
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
   const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
-  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * a.bs * a.kp16 * 2);
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * a.bs * a.kp16 * (LL ? 4 : 2));
   // A fragment of this lane: line zb*16 + (lane&15), 8 k at wave*kw + 32 g + 8 (lane>>4)
   const int kw = a.kp16 / WIDE_NW, ngrp = kw >> 5;   // <= 4 groups of 32 per wave
   const int am = zb * 16 + (lane & 15);
-  const unsigned akl = (unsigned)(wave * kw + 8 * (lane >> 4)) * 2u;
+  const unsigned akl = (unsigned)(wave * kw + 8 * (lane >> 4)) * (LL ? 4u : 2u);   // (tagged ring: 4 bytes per cell)
   const unsigned short* wfrag = wl + (lane & 15) * XCD_LDW + wave * kw + 8 * (lane >> 4);
+  const int kprod = ntile * 16;   // cells that have a producer (the rest of kp16 is padding nobody writes)
   __syncthreads();
 
   // The gate pre-activations of step s come from HBM (~2 us) and VMEM returns in order: requested at the top of step s
@@ -923,22 +938,122 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   };
   f32x4 gx = gx_load(0);
   float c_prev = 0.0f;
+  // the per-frame outputs of one step (nobody inside the pass reads them)
+  auto store_frame = [&](const f32x4 act, const float c_new, const float h, const unsigned hp, const long long n, const int sg, const bool live) {
+    if (live && !(CLSTM_WEXP & 256)) {
+      *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
+    }
+    if (live && !(CLSTM_WEXP & 256) && !((CLSTM_WEXP & 512) && (c16 & 3))) {
+      a.C[(n * nd + dir) * no + cell] = c_new;
+      a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
+      if (!(CLSTM_WEXP & 64)) {
+      float* srow = a.S + (size_t)dir * a.sdir;
+      if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
+      if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+      }
+    }
+    if (live && !(c16 & 1)) {
+      if constexpr (!LL) *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) = hp;
+      if (a.Hbf && !(CLSTM_WEXP & 256)) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
+      if (a.Sbf && !(CLSTM_WEXP & 256)) {   // h_{t-1} column block of the next frame's bf16 source row (weight-gradient operand, gemm_b16mc)
+        unsigned short* sb = a.Sbf + (size_t)dir * a.sbf_dir + a.sbf_ofs + cell;
+        if (sg == 0) *reinterpret_cast<unsigned*>(sb + (size_t)n * a.sbf_ld) = 0u;
+        if (sg + 1 < T) *reinterpret_cast<unsigned*>(sb + (size_t)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.sbf_ld) = hp;
+      }
+    }
+  };
+  f32x4 fr_act = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float fr_c = 0.0f, fr_h = 0.0f;
+  unsigned fr_hp = 0u;
+  long long fr_n = 0;
+  int fr_sg = 0;
+  bool fr_live = false;
   for (int sg = 0; sg < a.tmax; sg++) {
     const bool live = mine && sg < T;
     const long long n = off + (dir == 0 ? sg : T - 1 - sg);
-    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;   // h_{s-1} of the whole group is in the L2
-    // ---- 16 lines x 64 columns, split-K over the four waves ----
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
+    f32x4 gx_next;
+    if constexpr (LL) {
+      // ---- tagged ring: load, check, re-load until every unit this lane multiplies carries this step's tag ----
+      const unsigned want = (a.epoch << 12) | (unsigned)sg;
+      const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 4u + akl : BUF_OOB_BASE;
+      const int kl = wave * kw + 8 * (lane >> 4);
+      U32x4 ra[4][2];
+      int spins = 0;
+      bool first = true;
+      for (;;) {
+        COMPILER_MEMORY_BARRIER();   // the loads below must be re-issued every round (nothing in the loop writes that memory as far as the compiler can see)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) ra[g][hh] = buf_load4u_dev(abuf, g < ngrp ? arow + (unsigned)g * 128u + (unsigned)hh * 16u : BUF_OOB);
+        SCHED_FENCE();
+        if (first) { gx_next = gx_load(sg + 1); store_frame(fr_act, fr_c, fr_h, fr_hp, fr_n, fr_sg, fr_live); first = false; }
+        SCHED_FENCE();
+        unsigned miss = 0u;
+        if (sg >= 1 && am < a.bs) {
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+              for (int e = 0; e < 2; e++)
+                if (g < ngrp && kl + 32 * g + 4 * hh + 2 * e < kprod) miss |= ra[g][hh].v[2 * e + 1] ^ want;
+        }
+        if (wave_ballot(miss != 0u) == 0ull) break;
+        // Not all there yet.  Re-loading the whole operand (8 KB per wave and round, every wave of every workgroup) floods
+        // the L2 -- measured 3.0 us per step against 2.0 with the stamp barrier -- so wait on SAMPLES instead: one unit of
+        // every producer store instruction this wave depends on (its 8 tiles x the 4 producer waves = 32 lanes, 16 bytes
+        // each), and re-load the operand when they all carry the tag.
+        {
+          const int tl = ((wave * kw) >> 4) + (lane >> 2), sl = zb * 16 + 4 * (lane & 3);
+          const bool sv = lane < 32 && (lane >> 2) < (kw >> 4) && sl < a.bs && tl * 16 < kprod;
+          const unsigned soff = sv ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + sl) * a.kp16) * 4u + (unsigned)tl * 64u : BUF_OOB;
+          bool abandon = false;
+          for (;;) {
+            COMPILER_MEMORY_BARRIER();
+            const U32x4 sm = buf_load4u_dev(abuf, soff);
+            if (wave_ballot(sv && sm.v[1] != want) == 0ull) break;
+            poll_pause();
+            if ((++spins & 63) == 0) {
+              int bad = __hip_atomic_load(sync + XcdSyncLayout::ERROR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (!bad && spins > GRID_WATCHDOG_SPINS) {
+                bad = 2;
+                if (lane == 0) {   // diagnostics for the host's error message (sync words 2..6)
+                  sync[2] = sg; sync[3] = (int)sm.v[1]; sync[4] = (int)want; sync[5] = (wave << 16) | lane; sync[6] = (xcd << 8) | ct;
+                  __hip_atomic_store(sync + XcdSyncLayout::ERROR, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+              }
+              if (wave_uniform(bad)) { abandon = true; break; }
+            }
+          }
+          if (abandon) break;   // abandoned launch: run to the end on whatever is there, the host reports the error
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        if (g < ngrp) {
+          U32x4 d;
+          d.v[0] = ra[g][0].v[0]; d.v[1] = ra[g][0].v[2]; d.v[2] = ra[g][1].v[0]; d.v[3] = ra[g][1].v[2];
+          const u16x8 av = __builtin_bit_cast(u16x8, d);
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            acc[j] = mfma16x16x32_bf16(av, *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDW + g * 32), acc[j]);
+        }
+      }
+    } else {
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;   // h_{s-1} of the whole group is in the L2
+    // ---- 16 lines x 64 columns, split-K over the four waves ----
     const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 2u + akl : BUF_OOB_BASE;
     f32x4 ra[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) ra[g] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
     SCHED_FENCE();
-    const f32x4 gx_next = gx_load(sg + 1);
+    gx_next = gx_load(sg + 1);
     SCHED_FENCE();
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -948,6 +1063,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
         for (int j = 0; j < 4; j++)
           acc[j] = mfma16x16x32_bf16(av, *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDW + g * 32), acc[j]);
       }
+    }
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -972,36 +1088,35 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
       h = gate_act(c_new, true) * go;
       act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
     }
-    if (live && !(CLSTM_WEXP & 256)) {
-      *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
-      a.C[(n * nd + dir) * no + cell] = c_new;
-      a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
-      if (!(CLSTM_WEXP & 64)) {
-      float* srow = a.S + (size_t)dir * a.sdir;
-      if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
-      if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
-      }
-    }
     const float hn = quad_xor1(h);
-    if (live && !(c16 & 1)) {
-      const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);
-      *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) = hp;
-      if (a.Hbf && !(CLSTM_WEXP & 256)) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
-      if (a.Sbf && !(CLSTM_WEXP & 256)) {   // h_{t-1} column block of the next frame's bf16 source row (weight-gradient operand, gemm_b16mc)
-        unsigned short* sb = a.Sbf + (size_t)dir * a.sbf_dir + a.sbf_ofs + cell;
-        if (sg == 0) *reinterpret_cast<unsigned*>(sb + (size_t)n * a.sbf_ld) = 0u;
-        if (sg + 1 < T) *reinterpret_cast<unsigned*>(sb + (size_t)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.sbf_ld) = hp;
+    const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);   // (h = 0 for a line that has ended)
+    if constexpr (LL) {   // every line of the block publishes every step (a finished line: zeros), or its consumers would wait
+      if (line < a.bs && !(c16 & 1)) {
+        // (workgroup-scope store, sc0, like the stamps of the barrier variant)
+        const unsigned long long unit = (unsigned long long)hp | ((unsigned long long)((a.epoch << 12) | (unsigned)(sg + 1)) << 32);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.Hb) + ((((size_t)((sg & 1) * nd + dir) * a.bs + line) * (a.kp16 >> 1)) + (cell >> 1)),
+                           unit, __ATOMIC_RELAXED, CLSTM_LL_POLICY >= 2 ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+      // the per-frame outputs wait in registers until the next step's operand loads have been issued (store_frame in the
+      // wait loop above): the VMEM counter is in order, so a load issued behind them would also wait for THEIR acknowledgements
+      fr_act = act; fr_c = c_new; fr_h = h; fr_hp = hp; fr_n = n; fr_sg = sg; fr_live = live;
+    } else {
+      store_frame(act, c_new, h, hp, n, sg, live);
     }
     // publish: every store of this workgroup acknowledged by the L2, then one arrival on the group's counter.  (Storing
     // the bf16 h first and the other arrays behind the arrival was measured SLOWER, 3.5 vs 3.2 us per step: VMEM
     // completes in order, so the next step's operand loads then wait behind those stores.)
     c_prev = c_new;
     gx = gx_next;
+    if constexpr (LL) {
+      __syncthreads();   // (the reduction buffer is rewritten by the next step)
+    } else {
     drain_vmem();
     __syncthreads();
     if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
+    }
   }
+  if constexpr (LL) store_frame(fr_act, fr_c, fr_h, fr_hp, fr_n, fr_sg, fr_live);   // the last step's outputs
 }
 
 // ---- persistent backward recurrence, same scheme: 16 lines x 16 cells per workgroup, its 16 weight rows (R^T, 2048 k)

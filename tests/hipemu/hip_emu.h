@@ -244,6 +244,9 @@ inline void buf_store_s(BufF32 b, unsigned lane_off, unsigned uni, float v) { if
 inline float max_f32(float x, float y) { return fmaxf(x, y); }
 #define KEEP_ALIVE2(x) (void)(x)
 inline f32x4 buf_load4_dev(BufF32 b, unsigned off) { return buf_load4(b, off); }
+struct U32x4 { unsigned v[4]; };
+inline U32x4 buf_load4u_dev(BufF32 b, unsigned off) { const f32x4 r = buf_load4(b, off); U32x4 o; memcpy(o.v, r.v, 16); return o; }
+#define COMPILER_MEMORY_BARRIER() asm volatile("" ::: "memory")
 inline void buf_store_wt(BufF32 b, unsigned off, float v) { buf_store(b, off, v); }
 inline f32x4 buf_load4_wt(BufF32 b, unsigned off) { return buf_load4(b, off); }
 inline int load_i32_wt(const int* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }

@@ -303,3 +303,38 @@ def _path_count(backend, which):
     out = ctypes.c_longlong(0)
     backend.lib.call("clstm_debug_path_count", which, ctypes.byref(out))
     return out.value
+
+
+def test_tagged_ring_variant_matches_in_a_subprocess(backend):
+    """The opt-in "flag in data" variant of the persistent forward kernel (CLSTM_XCD_LL=1: 8-byte ring units that carry a
+    step tag, consumers re-load until the tags match, no group barrier) must give the same forward outputs as the default
+    stamp-barrier kernel.  The switch is read once per process, hence the subprocess; ragged lines make finished lines
+    publish zeros."""
+    import subprocess, sys, json
+    if backend.kind != "emu":
+        pytest.skip("emulator-only check of an experiment path (the GPU run of it is in profiles/README.md)")
+    code = r"""
+import os, sys, json, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+os.environ["CLSTM_FORCE_WIDE"] = "1"
+import common
+from clstm_amd.net import Network
+lib = common.emu_lib()
+rng = np.random.default_rng(11)
+ni, nh, nc = 8, [32, 32], 5
+T = [9, 5, 7, 3, 1, 8]
+net = Network(ni, nh, nc, lib=lib)
+net.set_params(rng.normal(0, 0.3, net.nparams).astype(np.float32))
+net.set_gemm_precision(2)
+net.set_inputs(common.synth_lines(rng, T, ni))
+net.forward()
+print(json.dumps(net.outputs().astype(np.float64).round(7).tolist()))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for ll in ("0", "1"):
+        env = dict(os.environ, CLSTM_XCD_LL=ll)
+        r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"))], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-800:]
+        outs.append(np.array(json.loads(r.stdout.strip().splitlines()[-1])))
+    assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
