@@ -1899,6 +1899,7 @@ int clstm_net_get_state_h(clstm_net* h, int layer, int dir, int which, float* ou
   REQUIRE(layer >= 0 && layer < (int)n.L.size() && dir >= 0 && dir < n.ndir && which >= 0 && which <= 9, "bad state selector");
   Layer& y = n.L[layer];
   n.tmp.reserve((size_t)n.N * y.no);
+  if (which >= 6) n.ensure_delta_f32(layer);   // (a persistent bf16 backward pass leaves the deltas as bf16 only)
   const float* src = which < 4 ? y.G.p : which == 4 ? y.C.p : y.D.p;
   const int slot = which < 4 ? which : which >= 6 ? which - 6 : -1;
   if (which == 5)

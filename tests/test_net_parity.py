@@ -290,7 +290,13 @@ def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatc
     net.update()                              # repack (bf16 weights) + a second step must run
     net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
     assert np.isfinite(net.get_grads()).all()
+    # the gate deltas are still readable through the state API after a persistent bf16 backward pass (which stores them as
+    # bf16 only and expands them on demand): finite, not all zero, and bf16-representable exactly when that path ran
+    dl = net.state(len(nh) - 1, 0, "d_gi")
+    assert np.isfinite(dl).all() and np.abs(dl).max() > 0
     took = [_path_count(backend, k) - before[k] for k in range(5)]
+    if took[1] > 0 and took[3] + took[4] > 0 and 4 * nh[-1] % 128 == 0:
+        assert np.array_equal((dl.view(np.uint32) & 0xFFFF), np.zeros(dl.shape, np.uint32))
     if nh == [32, 32]:
         # sized so that every optional bf16 fast path is eligible even on the emulator's 16 CUs: persistent per-XCD
         # recurrences (two cell tiles per direction), W_x.x from the lower layer's bf16 outputs, x.d from the bf16 delta
