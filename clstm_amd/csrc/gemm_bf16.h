@@ -578,13 +578,14 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
   }
   gb2_store<FE, WI>(fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, z);
 }
-// 256 x 256 tiles where the problem is large enough and their padding costs at most 10 % more work than 128 x 128 tiles do
-// (1537 rows: 7 x 256 vs 13 x 128, + 8 %; 561 rows: 3 x 256 vs 5 x 128, + 20 % -- stays with 128)
+// 256 x 256 tiles where the problem is large enough and their padding costs at most 25 % more work than 128 x 128 tiles do:
+// the big tile runs ~1.4x faster per flop (1537 rows: 7 x 256 vs 13 x 128, + 8 %; 561 rows: 3 x 256 vs 5 x 128, + 20 %:
+// 98 vs 116 us for one direction of the first layer's weight gradient)
 inline bool gemm_tile256(int R, int Cn) {
   static const bool on = !(getenv("CLSTM_GEMM_T256") && atoi(getenv("CLSTM_GEMM_T256")) == 0);
   if (!on || R < 192 || Cn < 192) return false;
   const long long w256 = (long long)((R + 255) / 256) * ((Cn + 255) / 256) * 4, w128 = (long long)((R + 127) / 128) * ((Cn + 127) / 128);
-  return 10 * w256 <= 11 * w128;
+  return 4 * w256 <= 5 * w128;
 }
 template <class FE>
 inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1) {
