@@ -344,3 +344,42 @@ print(json.dumps(net.outputs().astype(np.float64).round(7).tolist()))
         assert r.returncode == 0, r.stderr[-800:]
         outs.append(np.array(json.loads(r.stdout.strip().splitlines()[-1])))
     assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
+
+
+def test_lazy_f32_source_columns_match_the_eager_build(backend):
+    """Upper layers whose weight gradient reads the bf16 source rows skip the f32 [1 | x] source columns in the forward pass
+    and build them on demand (ensure_source_x).  Forward at precision 2, backward at precision 1 (f32 recurrence, f32-source
+    weight-gradient GEMM: needs those columns): the gradient must be bit-identical to a process in which the columns were
+    built eagerly (CLSTM_GEMM_B16MC=0).  The switch is read once per process, hence the subprocesses."""
+    import subprocess, sys, json
+    if backend.kind != "emu":
+        pytest.skip("host-logic check, run on the emulator")
+    code = r"""
+import os, sys, json, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+os.environ["CLSTM_FORCE_WIDE"] = "1"
+import common
+from clstm_amd.net import Network
+lib = common.emu_lib()
+rng = np.random.default_rng(12)
+ni, nh, nc = 16, [32, 32], 5
+T = [9, 5, 7, 3]
+net = Network(ni, nh, nc, lib=lib)
+net.set_params(rng.normal(0, 0.3, net.nparams).astype(np.float32))
+net.set_gemm_precision(2)
+net.set_inputs(common.synth_lines(rng, T, ni))
+net.forward()
+net.set_gemm_precision(1)
+net.ctc([rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T])
+net.backward()
+g = net.get_grads()
+print(json.dumps([float(np.abs(g.astype(np.float64)).sum()), g.view(np.uint32).astype(np.uint64).sum().item()]))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mc in ("1", "0"):
+        env = dict(os.environ, CLSTM_GEMM_B16MC=mc)
+        r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"))], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-800:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0][0] > 0 and outs[0] == outs[1], outs
