@@ -189,15 +189,6 @@ static int pick_nk4(int no) {
 }
 template <int NK4, int KU>
 static void launch_fwd(const LstmSeqArgs& a, int bs, int nthreads, hipStream_t s) {
-  // CLSTM_FWD2=1: the second form of the kernel (the first-dispatched waves store everybody's results from LDS).
-  // Parity-tested, measured on MI355X: 100.5 us vs 96.6 us for the first form -- the stores of the waves that define
-  // the step were already hidden behind their wait for the older wave's FMAs -- so it is not the default.
-  static const bool fwd2 = getenv("CLSTM_FWD2") && atoi(getenv("CLSTM_FWD2")) != 0;
-  if (fwd2) {
-    const size_t smem2 = (2 * (4 * (size_t)lstm_qstride(NK4) + 16 * NK4 + 64 * NK4) + 4) * sizeof(float);
-    CLSTM_LAUNCH((lstm_fwd2_kernel<NK4, KU>), dim3(bs, a.ndir), dim3(nthreads), smem2, s, a);
-    return;
-  }
   const size_t smem = (2 * 4 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
   CLSTM_LAUNCH((lstm_fwd_kernel<NK4, KU>), dim3(bs, a.ndir), dim3(nthreads), smem, s, a);
 }
@@ -216,18 +207,18 @@ static void launch_lstm(bool fwd, int nk4, int ku, LstmSeqArgs a, int bs, int nt
 }
 
 template <int NK4, int KU>
-static void launch_bwd_dw(const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s, int workers) {
+static void launch_bwd_dw(const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s) {
   const size_t smem = (2 * 16 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
-  CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec, workers);
+  CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec);
 }
-static bool launch_lstm_bwd_dw(int nk4, int ku, const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s, int workers) {
-#define CASE_(N, K) if (nk4 == N && ku == K) { launch_bwd_dw<N, K>(a, g, nrec, ngemm, nthreads, s, workers); check_launch(); return true; }
+static bool launch_lstm_bwd_dw(int nk4, int ku, const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s) {
+#define CASE_(N, K) if (nk4 == N && ku == K) { launch_bwd_dw<N, K>(a, g, nrec, ngemm, nthreads, s); check_launch(); return true; }
   CASE_(7, 25) CASE_(7, 28) CASE_(4, 16) CASE_(8, 32)    // (thread count must cover the GEMM role's 256)
 #undef CASE_
   return false;
 }
 
-// lock-step recurrence (lstm_wide.h): one cooperative launch for the whole sequence when every workgroup
+// lock-step recurrence (lstm_wide.h): one persistent launch for the whole sequence when every workgroup
 // can be resident at once (grid <= CU count, weights fit LDS), else one launch per time step
 static int device_cu_count() {
 #ifndef CLSTM_HIP_EMU
@@ -248,14 +239,6 @@ static void coop_set_smem(K kernel, size_t smem) {
 #ifndef CLSTM_HIP_EMU
   HIPCHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 #endif
-}
-// the grid barrier's watchdog flag: a cooperative launch whose workgroups were not all resident reports
-// here instead of hanging (costs one 4-byte read-back per sequence pass of a wide layer)
-static void check_coop(DevBuf<int>& sync, hipStream_t s) {
-  int flag = 0;
-  HIPCHECK(hipMemcpyAsync(&flag, sync.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
-  if (flag != 0) throw Error("cooperative recurrence: grid barrier timed out (workgroups not co-resident?); unset CLSTM_COOP");
 }
 // The per-step launches of one sequence pass are a launch-bound inner loop of up to a few hundred
 // dependent kernels: captured once into a hipGraph and replayed while the batch geometry and the buffers
@@ -372,154 +355,54 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
   g_wide_persistent = false;
   REQUIRE((double)a.N * a.ndir * 4 * a.no * 4 < 2147483000.0,
           "minibatch too large for the lock-step recurrence (frames x 4 x nhidden x ndir x 4 B must stay below 2 GiB)");
-  const int no = a.no;
-  // cooperative (single-launch, grid-barrier) variants are opt-in: measured on MI355X at 2xBiLSTM(512),
-  // 64 lines: forward 10.4 ms vs 9.7 ms per-step, backward 7.7 ms vs 8.3 ms -- no net gain yet
-  const bool allow_coop = !bf16 && getenv("CLSTM_COOP") && atoi(getenv("CLSTM_COOP")) != 0;
-  const int ncu = device_cu_count();
-  const int mt = a.bs > 32 ? 4 : a.bs > 16 ? 2 : 1;
+  const int no = a.no, ncu = device_cu_count();
+  const int ntile = (no + 15) / 16, nzb = (a.bs + 15) / 16;
   a.tmax = tmax;
-  sync.reserve(4);
+  sync.reserve(XcdSyncLayout::WORDS);
   a.sync = sync.p;
-  if (fwd) {
-    const int tiles = ((no + 15) / 16) * a.ndir, nzb = (a.bs + 15) / 16;
-    const size_t smem = (size_t)coop_lds_layout(a.kp, 64, 64, a.bs).words * sizeof(float);
-    if (allow_coop && tmax > 1 && tiles <= ncu && smem <= 160 * 1024) {
-      int zsplit = ncu / tiles;
-      if (zsplit > nzb) zsplit = nzb;
-      HIPCHECK(hipMemsetAsync(sync.p, 0, 2 * sizeof(int), s));
-      coop_set_smem(lstm_coop_fwd, smem);
-      CLSTM_LAUNCH_COOP(lstm_coop_fwd, dim3((no + 15) / 16, a.ndir, zsplit), dim3(WIDE_THREADS), smem, s, a);
+  // ONE launch per pass, a workgroup group per XCD with its weight rows resident in LDS (lstm_xcd_*: the default).
+  // CLSTM_XCD_REC=0 selects the per-step launches below; they are also the fallback when the placement check of the
+  // first launch fails (workgroups not spread evenly over the XCDs: nothing has been written at that point).
+  const bool xcd_on = !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
+  static bool xcd_failed = false;
+  // (minibatches of more than 8 / ndir line blocks: one launch per chunk of line blocks)
+  const int zb_per = std::max(1, 8 / a.ndir);
+  auto persistent = [&](auto kernel, size_t smem) {
+    bool ok = true;
+    for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
+      a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
+      HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+      coop_set_smem(kernel, smem);
+      CLSTM_LAUNCH_COOP(kernel, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
       check_launch();
-      check_coop(sync, s);
-      return;
+      ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
+      REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
     }
-    // ONE launch, a workgroup group per XCD with its weight rows resident in LDS (lstm_xcd_fwd_bf16 / lstm_xcd_fwd_f32)
-    const bool xcd_on = !allow_coop && !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
-    static bool xcd_failed = false;   // the placement check failed once on this device: per-step launches from then on
-    const int ntile = (no + 15) / 16;
-    // (minibatches of more than 8 / ndir line blocks: one launch per chunk of line blocks)
-    const int zb_per = std::max(1, 8 / a.ndir);
-    if (!bf16 && xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16) &&
-        (size_t)xcd_fwd_f32_lds_bytes(a.kp) <= 160 * 1024) {
-      bool ok = true;
-      for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
-        a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
-        sync.reserve(XcdSyncLayout::WORDS);
-        a.sync = sync.p;
-        HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
-        const size_t smem = (size_t)xcd_fwd_f32_lds_bytes(a.kp);
-        coop_set_smem(lstm_xcd_fwd_f32, smem);
-        CLSTM_LAUNCH_COOP(lstm_xcd_fwd_f32, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
-        check_launch();
-        ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
-        REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
-      }
-      if (ok) { g_wide_persistent = true; return; }
-      xcd_failed = true;
-    }
-    if (bf16 && xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && a.kp16 <= 512 && 8 * ntile <= std::max(ncu, 16)) {
-      bool ok = true;
-      for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
-        a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
-        sync.reserve(XcdSyncLayout::WORDS);
-        a.sync = sync.p;
-        HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
-        const size_t smem = (size_t)xcd_fwd_lds_bytes();
-        // (experiment, CLSTM_XCD_LL=1) tagged h ring, "flag in data" (lstm_wide.h): correct, but 3.1 us per step against
-        // 2.0 us with the stamp barrier on the part -- off by default
-        static const bool ll_on = getenv("CLSTM_XCD_LL") && atoi(getenv("CLSTM_XCD_LL")) != 0;
-        static unsigned epoch = 0;
-        if (ll_on && tmax < 4096 && (a.kp16 & 1) == 0) {
-          a.epoch = (++epoch) & 0xFFFFFu;
-          if (a.epoch == 0) a.epoch = (++epoch) & 0xFFFFFu;   // 0 is what a fresh (zero-filled) ring holds
-          coop_set_smem(lstm_xcd_fwd_bf16<true>, smem);
-          CLSTM_LAUNCH_COOP(lstm_xcd_fwd_bf16<true>, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
-        } else {
-          coop_set_smem(lstm_xcd_fwd_bf16<false>, smem);
-          CLSTM_LAUNCH_COOP(lstm_xcd_fwd_bf16<false>, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
-        }
-        check_launch();
-        ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
-        REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
-      }
-      if (ok) { g_wide_persistent = true; return; }
-      xcd_failed = true;   // workgroups were not spread evenly over the XCDs; nothing was written: run the per-step path
-    }
+    if (ok) g_wide_persistent = true; else xcd_failed = true;
+    return ok;
+  };
+  const bool fits = xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16);
+  if (fwd) {
+    if (fits && !bf16 && (size_t)xcd_fwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_fwd_f32, (size_t)xcd_fwd_f32_lds_bytes(a.kp))) return;
+    if (fits && bf16 && a.kp16 <= 512 && persistent(lstm_xcd_fwd_bf16, (size_t)xcd_fwd_lds_bytes())) return;
+    const int mt = a.bs > 32 ? 4 : a.bs > 16 ? 2 : 1;
     const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mt - 1) / (16 * mt));
-    const dim3 grid16(((no + 15) / 16) * a.ndir * ((a.bs + 15) / 16));
+    const dim3 grid16(ntile * a.ndir * nzb);
     launch_steps(graphs, bf16 ? 2 : 0, a, tmax, s, [&]() {
       LstmWideArgs w = a;
       for (int t = 0; t < tmax; t++) {
         w.step = t;
         if (bf16) CLSTM_LAUNCH(lstm_wide_fwd_step16_bf16, grid16, dim3(WIDE_THREADS), 0, s, w);
-        else
-        if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step<4>, grid, dim3(WIDE_THREADS), 0, s, w);
+        else if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step<4>, grid, dim3(WIDE_THREADS), 0, s, w);
         else if (mt == 2) CLSTM_LAUNCH(lstm_wide_fwd_step<2>, grid, dim3(WIDE_THREADS), 0, s, w);
         else CLSTM_LAUNCH(lstm_wide_fwd_step<1>, grid, dim3(WIDE_THREADS), 0, s, w);
       }
     });
   } else {
-    const int tiles = ((no + 15) / 16) * a.ndir, nzb = (a.bs + 15) / 16;
-    const size_t smem = (size_t)coop_lds_layout(a.kp, 16, 16, a.bs).words * sizeof(float);
-    if (allow_coop && tmax > 1 && tiles <= ncu && smem <= 160 * 1024) {
-      int zsplit = ncu / tiles;
-      if (zsplit > nzb) zsplit = nzb;
-      HIPCHECK(hipMemsetAsync(sync.p, 0, 2 * sizeof(int), s));
-      coop_set_smem(lstm_coop_bwd, smem);
-      CLSTM_LAUNCH_COOP(lstm_coop_bwd, dim3((no + 15) / 16, a.ndir, zsplit), dim3(WIDE_THREADS), smem, s, a);
-      check_launch();
-      check_coop(sync, s);
-      return;
-    }
-    const bool xcd_on = !allow_coop && !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
-    static bool xcd_failed = false;
-    const int ntile = (no + 15) / 16;
-    const int zb_per = std::max(1, 8 / a.ndir);
-    if (!bf16 && xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16) &&
-        (size_t)xcd_bwd_f32_lds_bytes(a.kp) <= 160 * 1024) {
-      bool ok = true;
-      for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
-        a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
-        sync.reserve(XcdSyncLayout::WORDS);
-        a.sync = sync.p;
-        HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
-        const size_t smem = (size_t)xcd_bwd_f32_lds_bytes(a.kp);
-        coop_set_smem(lstm_xcd_bwd_f32, smem);
-        CLSTM_LAUNCH_COOP(lstm_xcd_bwd_f32, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
-        check_launch();
-        ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
-        REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
-      }
-      if (ok) { g_wide_persistent = true; return; }
-      xcd_failed = true;
-    }
-    if (bf16 && xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && a.kp16 <= 2048 && 8 * ntile <= std::max(ncu, 16)) {
-      static const int nt_env = getenv("CLSTM_XCD_BWD_NT") ? atoi(getenv("CLSTM_XCD_BWD_NT")) : 1;
-      bool ok = true;
-      for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
-        a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
-        sync.reserve(XcdSyncLayout::WORDS);
-        a.sync = sync.p;
-        HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
-        if (nt_env >= 2 && ntile >= 2) {   // two 16-cell tiles per workgroup: half the delta traffic through each XCD's L2 (measured: no difference)
-          const size_t smem = (size_t)xcd_bwd_lds_bytes<2>();
-          coop_set_smem(lstm_xcd_bwd_bf16<2>, smem);
-          CLSTM_LAUNCH_COOP(lstm_xcd_bwd_bf16<2>, dim3(8 * ((ntile + 1) / 2)), dim3(WIDE_THREADS), smem, s, a);
-        } else {
-          const size_t smem = (size_t)xcd_bwd_lds_bytes<1>();
-          coop_set_smem(lstm_xcd_bwd_bf16<1>, smem);
-          CLSTM_LAUNCH_COOP(lstm_xcd_bwd_bf16<1>, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
-        }
-        check_launch();
-        ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
-        REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
-      }
-      if (ok) { g_wide_persistent = true; return; }
-      xcd_failed = true;
-    }
-    const dim3 grid((no + 15) / 16, a.ndir, nzb);
-    const dim3 grid16(((no + 15) / 16) * a.ndir * nzb);
+    if (fits && !bf16 && (size_t)xcd_bwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_bwd_f32, (size_t)xcd_bwd_f32_lds_bytes(a.kp))) return;
+    if (fits && bf16 && a.kp16 <= 2048 && persistent(lstm_xcd_bwd_bf16, (size_t)xcd_bwd_lds_bytes())) return;
+    const dim3 grid(ntile, a.ndir, nzb);
+    const dim3 grid16(ntile * a.ndir * nzb);
     launch_steps(graphs, bf16 ? 3 : 1, a, tmax, s, [&]() {
       LstmWideArgs w = a;
       for (int t = 0; t < tmax; t++) {
@@ -647,7 +530,6 @@ struct Layer {
   bool sx_valid = true;        // the [1 | x] columns of S (f32) are current (built lazily when the bf16 rows serve the weight gradient)
   DevBuf<unsigned short> Dbf;  // per-frame bf16 gate deltas written by the persistent backward kernel (A operand of the x.d GEMM)
   DevBuf<unsigned short> Wtb;  // bf16 copy of Wt ([ni][M], k = gate column contiguous): B operand of the bf16-source x.d product
-  DevBuf<float> pdw;          // split-K slabs of this layer's weight-gradient product when it runs on the side stream
   int lds = 0;
   int wt_slack = 32;          // floats past Wt a vectorised staging load may touch
   int ldh = 0, hofs = 4;      // H rows: [pad pad pad 1 | h_dir0 | h_dir1], h at column hofs (16-byte aligned)
@@ -666,8 +548,8 @@ struct Net {
   bool own_v = false, own_d = false, own_g = false;
   float lr = 1e-4f, mom = 0.9f, gclip = 100.0f;
   bool packed_dirty = true;
-  bool bf16_gemm = getenv("CLSTM_BF16_GEMM") && atoi(getenv("CLSTM_BF16_GEMM")) != 0;  // hoisted gate GEMMs: bf16 in, f32 accumulate
-  bool bf16_rec = getenv("CLSTM_BF16_REC") && atoi(getenv("CLSTM_BF16_REC")) != 0;   // wide layers: bf16 MFMA operands in the recurrence
+  bool bf16_gemm = false;   // hoisted gate GEMMs: bf16 in, f32 accumulate   (clstm_net_set_gemm_precision)
+  bool bf16_rec = false;    // wide layers: bf16 MFMA operands in the recurrence
   bool want_dx0 = false;
   // batch
   int bs = 0, tmax = 0;
@@ -702,19 +584,12 @@ struct Net {
   static const int PROG_WORDS = 2 * PROG_LINES * PROG_STRIDE;   // progress words at the tail of a narrow layer's D allocation: [ndir][bs], one per 128 B
   // CLSTM_OVERLAP / clstm_net_set_overlap: 0 off (GEMM after the recurrence); 1 (default): recurrence and GEMM as two
   // roles of ONE launch (lstm_bwd_dw.h) for batches large enough -- 0.369 -> 0.356 ms per step at the bench shape;
-  // 2: the same always (tests force it onto tiny nets);
-  // 3: two launches on streams with complementary CU masks -- measured slower than mode 0 on MI355X at the bench shape
-  // (0.443 vs 0.377 ms per step, profiles/r02_timeline_overlap.txt: fork and join through events cost ~37 us and the
-  // f32 GEMM needs ~105 us on the 128 CUs the masks leave it), kept for the record.
+  // 2: the same always (tests force it onto tiny nets).  (Two streams with complementary CU masks were measured
+  // slower than mode 0 -- 0.443 vs 0.377 ms per step, profiles/r02_timeline_overlap.txt -- and are gone.)
   int overlap = getenv("CLSTM_OVERLAP") ? atoi(getenv("CLSTM_OVERLAP")) : 1;
-  struct Side {   // two streams with complementary CU masks + the events of the fork / join
-    hipStream_t rec = nullptr, side = nullptr;
-    hipEvent_t fork{}, rec_done{}, side_done{};
-    bool tried = false, ok = false;
-  } os;
   unsigned dw_done_total = 0;     // recurrence workgroups launched so far through the fused launch (GemmDwArgs::done)
   DevBuf<long long> dw_trace;
-  DevBuf<int> dw_ktab, dw_slabs, dw_timeouts, dw_queue;   // dw_queue: [8] queue heads | [8 * 256] CU marks
+  DevBuf<int> dw_ktab, dw_slabs, dw_timeouts, dw_queue;   // dw_queue: the monitor's published minima and the `done` counter, each on its own 128-byte line
   std::vector<int> dw_key;        // line offsets the tables were built for
   // the softmax layer's W.d as independent items of the top layer's fused backward launch (gemm_dw.h, GemmDwArgs::x*)
   DevBuf<int> dwx_tab;            // [entries][2] contiguous 16-frame entries | slabs
@@ -857,8 +732,7 @@ struct Net {
     // there are more lines than CUs the long ones are not the last to start (stable: equal lengths keep their order)
     order_h.resize(nb);
     for (int b = 0; b < nb; b++) order_h[b] = b;
-    static const bool longest_first = !(getenv("CLSTM_LINE_ORDER") && atoi(getenv("CLSTM_LINE_ORDER")) == 0);
-    if (longest_first) std::stable_sort(order_h.begin(), order_h.end(), [&](int x, int y) { return T_h[x] > T_h[y]; });
+    std::stable_sort(order_h.begin(), order_h.end(), [&](int x, int y) { return T_h[x] > T_h[y]; });
     line_off.reserve(2 * nb + 1);
     hipStream_t s = stream();
     int* stage = (int*)ring.acquire((2 * nb + 1) * sizeof(int));
@@ -913,8 +787,7 @@ struct Net {
         y.Dbf.reserve((size_t)N * ndir * w.kp16 + 64); w.Dbf = y.Dbf.p;
         // with bf16 GEMMs behind it, nobody reads the f32 deltas of a persistent pass (16 bytes per lane and step, 0.17 ms
         // per configs[4] minibatch); ensure_delta_f32() expands Dbf for a fallback product
-        static const bool skip = !(getenv("CLSTM_XCD_SKIP_D") && atoi(getenv("CLSTM_XCD_SKIP_D")) == 0);
-        w.skip_d = skip && bf16_gemm;
+        w.skip_d = bf16_gemm;
       }
       static const bool b16mc_on = !(getenv("CLSTM_GEMM_B16MC") && atoi(getenv("CLSTM_GEMM_B16MC")) == 0);
       if (fwd && b16mc_on && bf16_gemm && (y.ni & 7) == 0 && (y.no & 7) == 0 && wide_kp16_bwd(y.no) == 4 * y.no) {
@@ -946,7 +819,6 @@ struct Net {
 
   void forward() {
     REQUIRE(N > 0, "set_batch first");
-    if (getenv("CLSTM_OVERLAP_DRY")) (void)side_streams();   // experiment: the side streams exist but are never used
     flush_line_off();
     repack();
     hipStream_t s = stream();
@@ -954,14 +826,13 @@ struct Net {
       Layer& y = L[l];
       const int M = ndir * 4 * y.no;
       timing.begin("gemm_gates_x", s);
-      static const bool b16src = !(getenv("CLSTM_GEMM_B16SRC") && atoi(getenv("CLSTM_GEMM_B16SRC")) == 0);
-      if (b16src && bf16_gemm && bf16_rec && l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.WtbT.p && y.ni == ndir * L[l - 1].no && (y.ni & 1) == 0)
+      if (bf16_gemm && bf16_rec && l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.WtbT.p && y.ni == ndir * L[l - 1].no && (y.ni & 1) == 0)
       {
         // the layer below left its outputs as a k-contiguous bf16 array: both operands go to LDS as they are
         g_path_count[2]++;
         gemm_b16kk(s, GemmOperand16{L[l - 1].Hbf.p, y.ni, (long long)N * y.ni}, GemmOperand16{y.WtbT.p, y.ni, (long long)M * y.ni},
                    StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
-      } else if (b16src && bf16_gemm && bf16_rec && l == 0 && y.wide && y.WtbT.p && (y.ni & 7) == 0 && gemm_tile256((int)N, M)) {
+      } else if (bf16_gemm && bf16_rec && l == 0 && y.wide && y.WtbT.p && (y.ni & 7) == 0 && gemm_tile256((int)N, M)) {
         // first layer: a bf16 copy of the input frames (N x ni, a few MB) buys the bf16-source kernel with its 256 x 256
         // tiles and 16-byte stores for the product whose 4 M floats of pre-activations per frame-line are its whole cost
         xbf.reserve((size_t)N * y.ni + 64);
@@ -972,15 +843,6 @@ struct Net {
       } else if (bf16_gemm)
         gemm_bf16<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N, layer_input_slack(l)),
                                     gemm_mc(y.Wt, M, y.ni, y.wt_slack), StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
-      else if (gemm_x3_fwd)
-        gemm_x3<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N, layer_input_slack(l)),
-                                  gemm_mc(y.Wt, M, y.ni, y.wt_slack), StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
-      else if (y.ni <= 64 && gemm_single_pass)
-        // (experiment, CLSTM_GEMM_SINGLE=1) the whole contraction (1 + 48 input rows of an OCR line image) in ONE 64-k
-        // block: one staging pass and one barrier pair per workgroup instead of six phases of 16 -- slower, nothing
-        // overlaps the one round of loads
-        gemm_f32<GEMM_KC, GEMM_MC, StoreBias, 64, 1>(s, gemm_kc(layer_input(l), layer_input_ld(l), N), gemm_mc(y.Wt, M, y.ni, 0),
-                                                    StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
       else
         gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(layer_input(l), layer_input_ld(l), N), gemm_mc(y.Wt, M, y.ni, 0),
                                    StoreBias{y.G.p, M, y.bias}, (int)N, M, y.ni);
@@ -1039,18 +901,15 @@ struct Net {
   // overlapped weight-gradient GEMM: 1 = bf16 MFMA on hi + lo split operands (three products, f32-grade: gemm_dw.h),
   // 0 = f32 MFMA (CLSTM_DW_X3=0)
   int dw_x3 = getenv("CLSTM_DW_X3") ? atoi(getenv("CLSTM_DW_X3")) : 1;
-  // the short hoisted products of the f32 path (W_x, softmax W.d / x.d) the same way (gemm_x3, gemm_bf16.h); CLSTM_GEMM_X3=0: f32 MFMA
+  // the softmax layer's backward products W.d / x.d the same way (gemm_x3, gemm_bf16.h); CLSTM_GEMM_X3=0: f32 MFMA.
+  // NOT the forward product W_x.x: its ~2^-17 relative error per product shows up in gate pre-activations that cancel to
+  // ~0 (a tanh gate at -0.0021 came out 5.6e-6 off where the parity bar allows 2.2e-6), and with K = 49 the split costs
+  // more staging than it saves MFMA time (28.5 vs 20.9 us).
   bool gemm_x3_on = !(getenv("CLSTM_GEMM_X3") && atoi(getenv("CLSTM_GEMM_X3")) == 0);
-  bool gemm_single_pass = getenv("CLSTM_GEMM_SINGLE") && atoi(getenv("CLSTM_GEMM_SINGLE")) != 0;   // measured slower: 26.4 vs 22.2 us
-  // NOT the forward product W_x.x (CLSTM_GEMM_X3=2 for experiments): its ~2^-17 relative error per product shows up in
-  // gate pre-activations that cancel to ~0 (a tanh gate at -0.0021 came out 5.6e-6 off where the parity bar allows
-  // 2.2e-6), and with K = 49 the split costs more staging than it saves MFMA time (28.5 vs 20.9 us)
-  bool gemm_x3_fwd = getenv("CLSTM_GEMM_X3") && atoi(getenv("CLSTM_GEMM_X3")) == 2;
   // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
   int pick_split(int R, int Cn, int nbatch = 1, int tile = GEMM_BT) const {
     const long long tiles = (long long)((R + tile - 1) / tile) * ((Cn + tile - 1) / tile) * nbatch;
-    static const long long target0 = getenv("CLSTM_SPLIT_TARGET") ? atoll(getenv("CLSTM_SPLIT_TARGET")) : 640;
-    const long long target = tile == GEMM_BT ? target0 : 480;   // 128 x 128 tiles: two workgroups per CU
+    const long long target = tile == GEMM_BT ? 640 : 480;   // 64 x 64 tiles: 640 measured best (272: slower); 128 x 128 tiles: two workgroups per CU
     long long want = (target + tiles - 1) / tiles;
     if (tile == 256) want = device_cu_count() / tiles;          // 256 x 256 tiles: one workgroup per CU, never a second round
     const long long maxs = (N + 63) / 64;   // at least 64 frames per slab
@@ -1061,44 +920,11 @@ struct Net {
   }
 
   // ---- overlap machinery ---------------------------------------------------------------------------------------
-  // Streams with complementary CU masks (measured, profiles/r02_ubench_cumask.txt: mask bit i -> XCD i % 8, then
-  // shader engine (i / 8) % 4 of that XCD, then CU; the two masks below give each stream two whole shader engines =
-  // 16 CUs of every XCD, and kernels on them overlap fully).  Every XCD keeps CUs in both masks: a mask that
-  // emptied an XCD would strand that XCD's share of every grid.
-  bool side_streams() {
-#ifdef CLSTM_HIP_EMU
-    os.tried = os.ok = true;     // emulator: launches are synchronous, producer first (same code path, serial)
-    return true;
-#else
-    if (os.tried) return os.ok;
-    os.tried = true;
-    if (device_cu_count() != 256) return false;
-    uint32_t ma[8] = {0}, mb[8] = {0};
-    for (int i = 0; i < 256; i++) ((((i >> 3) ^ i) & 1) == 0 ? ma : mb)[i / 32] |= 1u << (i % 32);
-    // CLSTM_OVERLAP_MASK=0 (experiment): two plain streams, the kernels share CUs
-    const bool masked = !(getenv("CLSTM_OVERLAP_MASK") && atoi(getenv("CLSTM_OVERLAP_MASK")) == 0);
-    if (masked) {
-      if (hipExtStreamCreateWithCUMask(&os.rec, 8, ma) != hipSuccess || hipExtStreamCreateWithCUMask(&os.side, 8, mb) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-      }
-    } else {
-      HIPCHECK(hipStreamCreateWithFlags(&os.rec, hipStreamNonBlocking));
-      HIPCHECK(hipStreamCreateWithFlags(&os.side, hipStreamNonBlocking));
-    }
-    HIPCHECK(hipEventCreateWithFlags(&os.fork, hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&os.rec_done, hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&os.side_done, hipEventDisableTiming));
-    os.ok = true;
-    return true;
-#endif
-  }
   bool overlap_eligible(const Layer& y) {
     if (!overlap || y.wide || y.no % 16 == 0) return false;          // the reporting lane must own no cell
     if (bs > PROG_LINES) return false;
     if ((overlap == 1) && (tmax < 64 || N < 2048)) return false;     // too small to profit
     if ((double)y.D.cap * 4.0 >= 2147483000.0) return false;         // 32-bit byte offsets inside one descriptor
-    if (overlap == 3) return side_streams();                         // two streams with complementary CU masks
     return overlap == 2 || y.nthreads >= 256;                        // one launch, two workgroup roles (lstm_bwd_dw.h)
   }
   // k-tile tables and slabs of the chunked weight-gradient GEMM for the current batch geometry (rebuilt only when the
@@ -1108,21 +934,9 @@ struct Net {
     if (dw_key == line_off_h && dw_nslabs > 0) return;
     std::vector<int> cb;   // chunk ends (iterations), multiples of 8 except the last
     // equal chunks of 16 iterations measured best at the bench shape (8: 0.407 ms per step, 16: 0.356, 32: 0.359,
-    // 48: 0.360, decreasing 64..16: 0.3615); CLSTM_DW_CHUNK=0 selects the decreasing plan
-    static const int uniform = getenv("CLSTM_DW_CHUNK") ? atoi(getenv("CLSTM_DW_CHUNK")) : 16;
-    if (uniform >= 8) {
-      for (int done = uniform; done < tmax; done += uniform) cb.push_back(done);
-      cb.push_back(tmax);
-    } else {
-      static const int w[5] = {8, 6, 5, 4, 2};
-      int done = 0;
-      for (int c = 0; c < 5 && done < tmax; c++) {
-        int len = c == 4 ? tmax - done : std::max(16, (tmax * w[c] / 25 + 7) / 8 * 8);
-        if (done + len > tmax || tmax - (done + len) < 8) len = tmax - done;
-        done += len;
-        cb.push_back(done);
-      }
-    }
+    // 48: 0.360, a decreasing plan 64..16: 0.3615)
+    for (int done = 16; done < tmax; done += 16) cb.push_back(done);
+    cb.push_back(tmax);
     const int tiles_per_slab = std::min(DW_STAB_MAX, std::max(8, (int)((N / 16 + 15) / 16)));   // ~16 slabs per direction (a slab's table must fit the items' LDS copy)
     std::vector<std::vector<int>> tab(ndir);                            // (first frame, count) pairs
     struct Sl { int tb, nt, need, dir, chunk, part; };
@@ -1145,8 +959,7 @@ struct Net {
         // The items of the LAST chunks cannot start before the recurrence ends, so their latency -- a serial walk over a
         // slab's frames, ~1 us per 32 -- is the launch's tail (profiles/r02_dw_timeline.txt): cut those chunks into
         // more, shorter slabs (>= 2 table entries each).
-        static const int tail_parts = getenv("CLSTM_DW_TAIL_PARTS") ? atoi(getenv("CLSTM_DW_TAIL_PARTS")) : 4;   // (1: 118 us, 4: 112, 8: 115 -- more items than free CUs at the end)
-        static const int tail_chunks = getenv("CLSTM_DW_TAIL_CHUNKS") ? atoi(getenv("CLSTM_DW_TAIL_CHUNKS")) : 3;
+        const int tail_parts = 4, tail_chunks = 3;   // (parts 1: 118 us, 4: 112, 8: 115 -- more items than free CUs at the end)
         if (c + tail_chunks >= cb.size()) parts = std::max(parts, std::min(tail_parts, std::max(1, nt / 2)));   // (those whose items still run when the recurrence ends)
         for (int p = 0; p < parts; p++) {
           const int a0 = t0 + (int)((long long)nt * p / parts), a1 = t0 + (int)((long long)nt * (p + 1) / parts);
@@ -1183,7 +996,7 @@ struct Net {
     ring.commit(s);
     dw_key = line_off_h;
   }
-  // backward recurrence on the masked stream + the chunked weight-gradient GEMM on the complementary one
+  // backward recurrence + the chunked weight-gradient GEMM as two workgroup roles of one launch
   void backward_layer_overlapped(Layer& y, LstmSeqArgs a, int R, int Cn) {
     hipStream_t s = stream();
     build_dw_tables();
@@ -1204,9 +1017,9 @@ struct Net {
     g.partial = partial.p; g.R = R; g.Cn = Cn;
     g.gx = (unsigned)((Cn + GEMM_BT - 1) / GEMM_BT); g.gy = (unsigned)((R + GEMM_BT - 1) / GEMM_BT);
     g.timeouts = dw_timeouts.p;
-    if (!dw_queue.p) dw_queue.reserve(8 + 8 * 256 + 8 + 4 * PROG_STRIDE);
-    g.qhead = dw_queue.p; g.cu_busy = dw_queue.p + 8; g.ndir = ndir;
-    g.minprog = dw_queue.p + 8 + 8 * 256 + 8 + PROG_STRIDE - ((8 + 8 * 256 + 8) % PROG_STRIDE);   // own 128-byte lines
+    if (!dw_queue.p) dw_queue.reserve(5 * PROG_STRIDE);
+    g.ndir = ndir;
+    g.minprog = dw_queue.p + PROG_STRIDE;   // own 128-byte lines
     g.tcap = tmax + 32;
     g.done = nullptr; g.done_target = 0;
     g.x3 = dw_x3;
@@ -1225,18 +1038,12 @@ struct Net {
     if (trace_path) { dw_trace.reserve(trace_rows * 4); g.trace = dw_trace.p; g.trace_base = bs * ndir; }
     const unsigned nblk = 1u + nextra + (unsigned)((dw_nslabs + 7) / 8) * 8u * g.gx * g.gy;   // the monitor + the independent items + one per item
 #ifndef CLSTM_HIP_EMU
-    if (overlap != 3 && y.nthreads >= 256) {   // ONE launch: the recurrence's workgroups first, the GEMM's behind them
+    if (y.nthreads >= 256) {   // ONE launch: the recurrence's workgroups first, the GEMM's (one (slab, tile) item each) behind them
       timing.begin("lstm_bwd", s);
-      // workers: three per CU fit beside nothing else (168 registers per lane), one beside a recurrence workgroup
-      // GEMM role: 0 (default) one (slab, tile) item per workgroup in dispatch order; >= 1: that many persistent workers
-      // pulling items from per-XCD queues (1 = 512) -- measured slower (0.362 vs 0.356 ms per step): a 448-thread
-      // workgroup slot per worker leaves room for only two workers on an idle CU
-      static const int workers = getenv("CLSTM_DW_WORKERS") ? atoi(getenv("CLSTM_DW_WORKERS")) : 0;
-      const unsigned nworkers = workers ? (unsigned)std::min<long long>((long long)nblk, workers > 1 ? workers : 512) : nblk;
       g.done = g.minprog + 2 * PROG_STRIDE;   // own 128-byte line behind the monitor's words; zero-filled once, then only added to
       dw_done_total += (unsigned)(bs * ndir);
       g.done_target = (int)dw_done_total;
-      REQUIRE(launch_lstm_bwd_dw(y.nk4, y.pd.ku, a, g, bs * ndir, nworkers, y.nthreads, s, workers), "internal: no fused instantiation");
+      REQUIRE(launch_lstm_bwd_dw(y.nk4, y.pd.ku, a, g, bs * ndir, nblk, y.nthreads, s), "internal: no fused instantiation");
       timing.end(s);
       if (trace_path) {
         HIPCHECK(hipStreamSynchronize(s));
@@ -1251,28 +1058,15 @@ struct Net {
       return;
     }
 #endif
-    // two launches: on streams with complementary CU masks (mode 3), or one after the other (host emulator; layers too
-    // narrow for the GEMM role's 256 threads when the tests force the path)
-    const bool fork = overlap == 3 && os.rec;
-    hipStream_t srec = fork ? os.rec : s, sside = fork ? os.side : s;
-    if (fork) {
-      HIPCHECK(hipEventRecord(os.fork, s));
-      HIPCHECK(hipStreamWaitEvent(srec, os.fork, 0));
-      HIPCHECK(hipStreamWaitEvent(sside, os.fork, 0));
-    }
-    timing.begin("lstm_bwd", srec);
-    launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, srec);
-    timing.end(srec);
-    timing.begin("gemm_gates_dw", sside);
-    CLSTM_LAUNCH(gemm_dw_kernel, dim3(nblk), dim3(256), 0, sside, g);
-    timing.end(sside);
+    // two launches one after the other (host emulator; layers too narrow for the GEMM role's 256 threads when the
+    // tests force the path): the items find every progress word complete
+    timing.begin("lstm_bwd", s);
+    launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
+    timing.end(s);
+    timing.begin("gemm_gates_dw", s);
+    CLSTM_LAUNCH(gemm_dw_kernel, dim3(nblk), dim3(256), 0, s, g);
+    timing.end(s);
     check_launch();
-    if (fork) {
-      HIPCHECK(hipEventRecord(os.rec_done, srec));
-      HIPCHECK(hipEventRecord(os.side_done, sside));
-      HIPCHECK(hipStreamWaitEvent(s, os.rec_done, 0));
-      HIPCHECK(hipStreamWaitEvent(s, os.side_done, 0));
-    }
   }
 
   void backward() {
@@ -1292,10 +1086,8 @@ struct Net {
       // W.d depends on nothing the backward recurrence produces: when the top layer's backward runs as the fused launch
       // (lstm_bwd_dw.h) its slabs are items of THAT launch -- they execute on the idle half of the chip during the ~14 us
       // before the recurrence's first chunk is released -- and only x.d stays in front of the recurrence.
-      static const bool dwx_on = !(getenv("CLSTM_DW_EXTRA") && atoi(getenv("CLSTM_DW_EXTRA")) == 0);
-      static const bool dwx_workers = getenv("CLSTM_DW_WORKERS") && atoi(getenv("CLSTM_DW_WORKERS")) != 0;
       // (only while the recurrence leaves CUs idle: with 256 lines the same items cost the fused launch +42 us for 19 saved)
-      dwx_active = dwx_on && !dwx_workers && !bf16_gemm && (dw_x3 & 1) && overlap_eligible(top) &&
+      dwx_active = !bf16_gemm && (dw_x3 & 1) && overlap_eligible(top) &&
                    (long long)bs * ndir * 4 <= 3LL * device_cu_count();
       if (dwx_active) {
         if (dwx_N != N) {   // contiguous frames: entries of 16, slabs of 32 entries (512 frames: one short item each)
@@ -1365,18 +1157,12 @@ struct Net {
       y.d_f32_valid = !(bwd_persistent && bf16_rec && skipped_d);
       if (bwd_persistent) g_path_count[1]++;
       }
-      // (Experiment, off by default.)  Stacked lock-step layers in bf16: the weight-gradient product of layer l (~1 ms at 2 x BiLSTM(512)) depends only on
-      // that layer's recurrence, while the persistent recurrence of layer l-1 that follows keeps every CU busy with four
-      // latency-bound waves.  So x.d goes first (layer l-1 waits for it), then W.d and its slab reduction run on a
-      // LOW-priority side stream beside the next recurrence (whose workgroups, on the other stream, are dispatched first)
-      // and the main stream joins before the update.
       const bool dw_from_bf16 = bf16_gemm && bf16_rec && bwd_persistent && y.sbf_ready && y.Dbf.p && gemm_bf16_big(R, Cn);
       if (bf16_gemm || !overlap_eligible(y))
         ns = dw_from_bf16 && gemm_tile256(R, Cn) ? pick_split(R, Cn, ndir, 256)
              : bf16_gemm && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
       if (!dw_from_bf16) { ensure_source_x(l); ensure_delta_f32(l); }   // the f32-source products below read S and D
-      const bool defer = l > 0 && y.wide && bf16_rec && bf16_gemm && dw_side_stream();
-      DevBuf<float>& pbuf = defer ? y.pdw : partial;
+      DevBuf<float>& pbuf = partial;
       auto do_dw = [&](hipStream_t q) {
         if (bf16_gemm || !overlap_eligible(y)) {
           pbuf.reserve((size_t)ndir * ns * R * Cn);
@@ -1401,7 +1187,7 @@ struct Net {
         ReduceDesc extra{};   // empty unless this is the top layer
         if (l == (int)L.size() - 1) extra = sm_red;
         const size_t work = (size_t)ndir * R * Cn + (size_t)extra.R * extra.Cn * extra.nbatch;
-        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, g, dw_queue.p, dw_queue.p ? 8 : 0);
+        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, g, (int*)nullptr, 0);
         timing.end(q);
         check_launch();
       };
@@ -1412,8 +1198,7 @@ struct Net {
         else if (want_dx0) { dX0.reserve((size_t)N * y.ni); dx = dX0.p; }
         if (!dx) return;
         timing.begin("gemm_gates_dx", s);
-        static const bool b16src = !(getenv("CLSTM_GEMM_B16SRC") && atoi(getenv("CLSTM_GEMM_B16SRC")) == 0);
-        if (b16src && bf16_gemm && bf16_rec && bwd_persistent && wide_kp16_bwd(y.no) == 4 * y.no && y.Wtb.p && y.Dbf.p)
+        if (bf16_gemm && bf16_rec && bwd_persistent && wide_kp16_bwd(y.no) == 4 * y.no && y.Wtb.p && y.Dbf.p)
         {
           // the persistent recurrence left the deltas as a k-contiguous bf16 array: both operands go to LDS as they are
           g_path_count[3]++;
@@ -1428,46 +1213,9 @@ struct Net {
         timing.end(s);
         check_launch();
       };
-      if (defer) {
-        do_dx();
-        HIPCHECK(hipEventRecord(dw_fork, s));
-        HIPCHECK(hipStreamWaitEvent(dw_side, dw_fork, 0));
-        do_dw(dw_side);
-        dw_side_pending = true;
-      } else {
-        do_dw(s);
-        do_dx();
-      }
+      do_dw(s);
+      do_dx();
     }
-    if (dw_side_pending) {   // the gradient is complete only when the side stream's slab reductions are
-      HIPCHECK(hipEventRecord(dw_join, dw_side));
-      HIPCHECK(hipStreamWaitEvent(s, dw_join, 0));
-      dw_side_pending = false;
-    }
-  }
-
-  // low-priority stream for weight-gradient products that run beside the next layer's recurrence
-  hipStream_t dw_side = nullptr;
-  hipEvent_t dw_fork{}, dw_join{};
-  bool dw_side_tried = false, dw_side_pending = false;
-  bool dw_side_stream() {
-#ifdef CLSTM_HIP_EMU
-    return false;
-#else
-    // opt-in (CLSTM_DW_SIDE=1): measured at 2 x BiLSTM(512) the product running beside it slows the latency-bound
-    // recurrence by more than it hides (9.75 vs 9.52 ms per minibatch)
-    static const bool on = getenv("CLSTM_DW_SIDE") && atoi(getenv("CLSTM_DW_SIDE")) != 0;
-    if (!on) return false;
-    if (!dw_side_tried) {
-      dw_side_tried = true;
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = numerically greatest = lowest priority
-      if (hipStreamCreateWithPriority(&dw_side, hipStreamNonBlocking, lo) != hipSuccess) { dw_side = nullptr; return false; }
-      if (hipEventCreateWithFlags(&dw_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&dw_join, hipEventDisableTiming) != hipSuccess) { dw_side = nullptr; return false; }
-    }
-    return dw_side != nullptr;
-#endif
   }
 
   void update() {
@@ -1807,9 +1555,7 @@ static void net_set_inputs_d(clstm_net* h, const float* x, const CtcMetaCopy* au
     const int M = n.ndir * 4 * y.no, KQP = 4 * y.nk4;
     const size_t nr = (size_t)n.ndir * 4 * KQP * y.nthreads;
     const int nbi = nblocks((size_t)n.N * (1 + y.ni)), nbp = nblocks((size_t)(1 + y.ni) * M + 2 * nr);
-    static const bool host_reads = !(getenv("CLSTM_INGEST_HOST") && atoi(getenv("CLSTM_INGEST_HOST")) == 0);   // experiment: DMA copies instead
-    if (!host_reads) n.flush_line_off();
-    const bool lo = n.lo_pending, ax = host_reads && aux && aux->nwords > 0;
+    const bool lo = n.lo_pending, ax = aux && aux->nwords > 0;
     // optional trailing blocks read small host arrays straight from their pinned slots: the line offsets and -- in a
     // training step -- the CTC metadata (no DMA launches, no event records on the stream's critical path)
     CLSTM_LAUNCH(k_ingest_pack, dim3(nbi + nbp + (lo ? 1 : 0) + (ax ? (aux->nwords + 255) / 256 : 0)), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni, y.lds,
@@ -2155,7 +1901,7 @@ int clstm_allreduce_flat(clstm_comm* c, float* buf_d, long long n) {
 }
 int clstm_net_set_overlap(clstm_net* h, int mode) {
   ABI_BEGIN
-  REQUIRE(mode >= 0 && mode <= 3, "overlap mode: 0 off, 1 one launch with two roles where it pays, 2 the same always (tests), 3 two masked streams");
+  REQUIRE(mode >= 0 && mode <= 2, "overlap mode: 0 off, 1 one launch with two roles where it pays, 2 the same always (tests)");
   h->net.overlap = mode;
   ABI_END
 }

@@ -601,7 +601,8 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   CTC_STAMP(0);
   // Request order = completion order (vmcnt counts in order): the target states first (needed at once), then the
   // tables and -- short lines -- the posteriors, whose latency overlaps the state classification.
-  const bool short_line = T <= TT && T * S <= CTC_THREADS * CTC_CCACHE && nc <= CTC_THREADS;   // uniform per workgroup
+  // (the short-line path classifies ONE target state per thread: transcripts of more than 255 labels take the tiled path)
+  const bool short_line = T <= TT && S <= CTC_THREADS && T * S <= CTC_THREADS * CTC_CCACHE && nc <= CTC_THREADS;   // uniform per workgroup
   const int st0 = a.states[soff + (tid < S ? tid : 0)];
   double treg[CTC_TREG];
 #pragma unroll

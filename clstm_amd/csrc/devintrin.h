@@ -242,21 +242,6 @@ DEVFN f32x4 buf_load4_dev(BufF32 b, unsigned byte_off) {
 // polling loops over such loads: the compiler may hoist a loop-invariant load out of the loop (no write to that memory is
 // visible to it); a memory clobber at the top of the loop keeps it inside without changing the cache policy
 #define COMPILER_MEMORY_BARRIER() asm volatile("" ::: "memory")
-// the same as four INTEGER dwords (tagged ring units: data words and tag words side by side; keeping the tags out of the
-// floating-point type keeps the compiler from treating the four lanes of the vector alike)
-struct U32x4 { unsigned v[4]; };
-DEVFN U32x4 buf_load4u_dev(BufF32 b, unsigned byte_off) {
-  const i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(b.r, byte_off, 0, 16);
-  U32x4 o;
-  o.v[0] = (unsigned)r[0]; o.v[1] = (unsigned)r[1]; o.v[2] = (unsigned)r[2]; o.v[3] = (unsigned)r[3];
-  return o;
-}
-DEVFN void buf_store_dev(BufF32 b, unsigned byte_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.r, byte_off, 0, 16);
-}
-DEVFN void buf_store4_dev(BufF32 b, unsigned byte_off, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b.r, byte_off, 0, 16);
-}
 // Producer / consumer pairs in DIFFERENT launches that run concurrently (lstm_bwd -> gemm_dw.h): system-scope
 // write-through stores and system-scope loads on both sides (guide: "sc0 sc1 stores and loads both sides" needs no
 // fences; per-XCD L2s are not coherent with each other)
@@ -270,13 +255,8 @@ DEVFN int load_i32_wt(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAX
 DEVFN void store_i32_wt(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 DEVFN void atomic_add_i32(int* p, int v) { atomicAdd(p, v); }
 DEVFN int atomic_fetch_add_i32(int* p, int v) { return atomicAdd(p, v); }
-// where this wave runs: XCC (XCD) id 0..7 and a slot number of its CU within the XCD (shader engine, array, CU)
+// where this wave runs: XCC (XCD) id 0..7
 DEVFN int hw_xcc_id() { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return (int)(x & 0xF); }
-DEVFN int hw_cu_slot() {
-  unsigned hw;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-  return (hw_xcc_id() & 7) * 256 + (int)((hw >> 8) & 0xFF);
-}
 DEVFN void sleep_some() { __builtin_amdgcn_s_sleep(16); }
 DEVFN void poll_pause() { __builtin_amdgcn_s_sleep(1); }   // ~64 cycles between two looks at a word another workgroup will change
 // park the wave for roughly 0.35 us per recurrence iteration still missing (s_sleep 13 ~ 832 cycles), at most ~14 us
@@ -292,28 +272,6 @@ DEVFN int wave_max_i(int x) {
 DEVFN void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // this wave's loads returned, stores acknowledged
 DEVFN unsigned mad_u24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }   // v_mad_u32_u24 (operands < 2^24)
 constexpr int GRID_WATCHDOG_SPINS = 1 << 21;   // ~seconds of polling before a stuck barrier is reported
-// All workgroups of a cooperative launch meet here.  sync[0]: ticket counter (target = arrivals expected
-// so far), sync[1]: watchdog flag.  Returns false (uniformly within the workgroup) once any workgroup has
-// given up waiting; the caller leaves the kernel.
-DEVFN bool grid_barrier(int* sync, int target, int* lds_flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's sc1 stores have been written through
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0, bad = 0;
-    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // relaxed polling
-      if ((++spins & 255) == 0) {   // the watchdog flag is looked at rarely: the poll stays one load per turn
-        bad = __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (spins > GRID_WATCHDOG_SPINS) bad = 1;
-        if (bad) break;
-      }
-    }
-    if (bad) __hip_atomic_store(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *lds_flag = bad;
-  }
-  __syncthreads();
-  return *lds_flag == 0;
-}
 #define CLSTM_LAUNCH_COOP(kernel, grid, block, smem, stream, argstruct)                                  \
   do {                                                                                                   \
     void* coop_args_[] = {(void*)&(argstruct)};                                                          \

@@ -147,9 +147,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmOperand A, GemmOpera
 //   KC staging: thread t -> row t>>1, 16 consecutive k at (t&1)*16: four float4 -> two ds_write_b128
 //   MC staging: lane l of wave w -> mn = 32 w + 4 (l&7) .. +3, k = 4 (l>>3) .. +3: four float4 (one per k), transposed
 //               in registers -> four ds_write_b64 (row mn+i, 4 consecutive k)
-#ifndef CLSTM_GEXP   // perf experiments only: bit mask of work to leave out of the 128 x 128 kernel (results are then wrong)
-#define CLSTM_GEXP 0
-#endif
 constexpr int GB2_BT = 128;
 constexpr int GB2_PF = 3;
 // LDS image of an operand block: [mn][32 k] bf16, 64-byte rows WITHOUT padding; the four 16-byte k-chunks of row r sit
@@ -235,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
   f32x4 ra[GB2_PF][4], rb[GB2_PF][4];
   auto load_tile = [&](int k0, f32x4 (&a)[4], f32x4 (&b)[4]) {
     const unsigned kc = (unsigned)wave_uniform(k0 < klast ? k0 : klast);
-    const unsigned ao = (CLSTM_GEXP & 1) ? BUF_OOB_BASE : kc * a_kstep * 4u, bo = (CLSTM_GEXP & 1) ? BUF_OOB_BASE : kc * b_kstep * 4u;
+    const unsigned ao = kc * a_kstep * 4u, bo = kc * b_kstep * 4u;
 #pragma unroll
     for (int j = 0; j < 4; j++) a[j] = buf_load4(abuf, aoff[j] + ao);
 #pragma unroll
@@ -306,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
       const int k0 = kb + p * GB_BK;   // block in LDS buffer `cur` (phases past the slab multiply zeros)
       constexpr int pn_of[3] = {1, 2, 0};
       const int pn = pn_of[p];         // register set of block k0 + 32: convert it into the other buffer ...
-      if (!(CLSTM_GEXP & 4)) {
+      {
       stage(AMODE, As + (cur ^ GB2_TILE), a_mn, a_k, k0 + GB_BK, ra[pn]);
       stage(BMODE, Bs + (cur ^ GB2_TILE), b_mn, b_k, k0 + GB_BK, rb[pn]);
       }
@@ -322,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (!(CLSTM_GEXP & 2) || (i == 0 && j == 0)) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
-      if (!(CLSTM_GEXP & 8)) __syncthreads();
+          acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
+      __syncthreads();
       cur ^= GB2_TILE;
     }
   }
@@ -453,14 +450,8 @@ inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE 
 // LDS image of an operand block: 8 strips of 16 columns, each [32 n][16] bf16 = 1 KB contiguous (a wave's fragment read
 // covers 512 contiguous bytes: conflict-free by construction) + 32 bytes so that the 8 lanes of a ds_write_b128 group
 // (4 strips x 2 halves of one row) fall into 8 distinct 16-byte bank slots.
-#ifndef CLSTM_TEXP   // perf experiments only: bit mask of work to leave out of gemm_b16mc_kernel (results are then wrong)
-#define CLSTM_TEXP 0
-#endif
 struct GemmOperand16B { const unsigned short* p; int ld; long long elems; long long bstride; };   // halfs; ld % 8 == 0, bstride even
-#ifndef CLSTM_GT_PF
-#define CLSTM_GT_PF 3
-#endif
-constexpr int GT_PF = CLSTM_GT_PF;   // blocks in flight in registers (NB = 1; two with NB = 2: the same 128 rows ahead)
+constexpr int GT_PF = 3;   // blocks in flight in registers (NB = 1; two with NB = 2: the same 128 rows ahead)
 // WI = 16-row strips of a wave's tile: 4 -> 128 x 128 per workgroup (four waves 2 x 2, 64 x 64 each), 8 -> 256 x 256 (eight
 // waves 2 x 4, 128 x 64 each: half the LDS and vector-cache bytes per MFMA; one workgroup per CU).
 // NB = 32-row sub-blocks per barrier (contraction rows per LDS buffer = 32 NB).
@@ -504,19 +495,19 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
     const unsigned kc = (unsigned)wave_uniform(k0);
 #pragma unroll
     for (int h = 0; h < NL; h++) {
-      const bool lv = !(CLSTM_TEXP & 1) && k0 + s_k + 16 * h < kend;
+      const bool lv = k0 + s_k + 16 * h < kend;
       a[h] = buf_load4(abuf, lv ? aoff + kc * a_kstep + (unsigned)h * a16 : BUF_OOB);
     }
 #pragma unroll
     for (int h = 0; h < NL; h++) {
-      const bool lv = !(CLSTM_TEXP & 1) && k0 + s_k + 16 * h < kend;
+      const bool lv = k0 + s_k + 16 * h < kend;
       b[h] = buf_load4(bbuf, lv ? boff + kc * b_kstep + (unsigned)h * b16 : BUF_OOB);
     }
   };
   const int s_at = (s_c >> 1) * STRIP + s_k * 16 + (s_c & 1) * 8;
   auto stage = [&](unsigned short* S, const f32x4 (&r)[NL]) {
 #pragma unroll
-    for (int h = 0; h < NL; h++) if (!(CLSTM_TEXP & 4) || r[h][0] == 1234.5f) *reinterpret_cast<f32x4*>(&S[s_at + h * 256]) = r[h];
+    for (int h = 0; h < NL; h++) *reinterpret_cast<f32x4*>(&S[s_at + h * 256]) = r[h];
   };
   f32x4 acc[WI][4];
 #pragma unroll
@@ -531,7 +522,6 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const unsigned short* bp = &Bs[buf + (wn * 4 + j) * STRIP + f_at];
-      if ((CLSTM_TEXP & 8) && j > 0) { bf[j] = bf[0]; continue; }   // (experiment) one fragment read per operand
       bf[j] = join_u16x8(lds_read_tr16(bp), lds_read_tr16(bp + 256));
     }
 #pragma unroll
@@ -540,13 +530,12 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const unsigned short* ap = &As[buf + (wm * WI + i0 + i) * STRIP + f_at];
-        if ((CLSTM_TEXP & 8) && i > 0) { af[i] = af[0]; continue; }
         af[i] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256));
       }
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (!(CLSTM_TEXP & 2) || (i0 + i == 0 && j == 0)) acc[i0 + i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i0 + i][j]);   // transposed: see gb2_store
+        for (int j = 0; j < 4; j++) acc[i0 + i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i0 + i][j]);   // transposed: see gb2_store
       if (NB > 1) SCHED_FENCE();
     }
   };
@@ -572,7 +561,7 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
       SCHED_FENCE();
 #pragma unroll
       for (int sb = 0; sb < NB; sb++) mfma_sub(cur + sb * 512);
-      if (!(CLSTM_TEXP & 16)) __syncthreads();
+      __syncthreads();
       cur ^= TILE;
     }
   }
@@ -582,8 +571,7 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
 // the big tile runs ~1.4x faster per flop (1537 rows: 7 x 256 vs 13 x 128, + 8 %; 561 rows: 3 x 256 vs 5 x 128, + 20 %:
 // 98 vs 116 us for one direction of the first layer's weight gradient)
 inline bool gemm_tile256(int R, int Cn) {
-  static const bool on = !(getenv("CLSTM_GEMM_T256") && atoi(getenv("CLSTM_GEMM_T256")) == 0);
-  if (!on || R < 192 || Cn < 192) return false;
+  if (R < 192 || Cn < 192) return false;
   const long long w256 = (long long)((R + 255) / 256) * ((Cn + 255) / 256) * 4, w128 = (long long)((R + 127) / 128) * ((Cn + 127) / 128);
   return 4 * w256 <= 5 * w128;
 }
@@ -591,17 +579,15 @@ template <class FE>
 inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1) {
   if (R <= 0 || Cn <= 0 || K <= 0) return;
   if (nsplit < 1) nsplit = 1;
-  // (experiment, CLSTM_GEMM_BK64=1: 64 contraction rows per barrier on the 256 x 256 tile -- 231 VGPRs, 130 KB LDS, measured
-  // equal to the 32-row loop: 227 vs 226 us at 1544 x 2048 x 25600)
-  static const bool bk64 = getenv("CLSTM_GEMM_BK64") && atoi(getenv("CLSTM_GEMM_BK64")) != 0;
+  // (64 contraction rows per barrier on the 256 x 256 tile -- 231 VGPRs, 130 KB LDS -- measured equal to the 32-row
+  // loop, 227 vs 226 us at 1544 x 2048 x 25600, and is gone)
   const bool big = gemm_tile256(R, Cn);
   int ksplit = (K + nsplit - 1) / nsplit;
-  const int kq = nsplit > 1 ? (big && bk64 ? 2 * 64 : GT_PF * GB_BK) : (big && bk64 ? 64 : GB_BK);   // whole ring rounds per slab
+  const int kq = nsplit > 1 ? GT_PF * GB_BK : GB_BK;   // whole ring rounds per slab
   ksplit = ((ksplit + kq - 1) / kq) * kq;
   if (big) {
     dim3 grid((Cn + 255) / 256, (R + 255) / 256, nsplit * nbatch);
-    if (bk64) CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 2>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
-    else CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 1>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+    CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 1>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
     return;
   }
   dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);
@@ -816,11 +802,8 @@ inline void gemm_x3_pair(hipStream_t stream, GemmProblem p1, FE1 fe1, GemmProble
   CLSTM_LAUNCH((gemm_x3_pair_kernel<A1, B1, FE1, A2, B2, FE2>), dim3(nb1 + nb2), dim3(256), 0, stream, p1, fe1, p2, fe2, nb1);
 }
 
-// shapes that fill 128 x 128 tiles reasonably (CLSTM_GEMM_BIG=0: always the 64 x 64 kernel)
-inline bool gemm_bf16_big(int R, int Cn) {
-  static const bool on = !(getenv("CLSTM_GEMM_BIG") && atoi(getenv("CLSTM_GEMM_BIG")) == 0);
-  return on && R >= 96 && Cn >= 96;
-}
+// shapes that fill 128 x 128 tiles reasonably
+inline bool gemm_bf16_big(int R, int Cn) { return R >= 96 && Cn >= 96; }
 
 // Operand slack: the second float4 of a KC row may run 7 floats past the row end (library buffers carry
 // >= 64 floats of slack; exact-size user arrays get a descriptor that ends at the last element).

@@ -41,9 +41,6 @@ struct GemmDwArgs {
   int R, Cn;
   unsigned gx, gy;          // output tiles along Cn, R
   int* timeouts;            // incremented when a slab gave up waiting (diagnostics; results are then wrong)
-  // persistent workers (lstm_bwd_dw.h): per-XCD work queues and the CUs the recurrence occupies
-  int* qhead;               // [8] next item of XCD x (zeroed between launches by k_reduce_scatter)
-  int* cu_busy;             // [8 * 256] = prog_base of this launch where a recurrence workgroup runs (hw_cu_slot())
   int* minprog;             // [ndir] (PROG_STRIDE apart): prog_base + iterations EVERY line of that direction has completed,
                             //   published by the monitor workgroup (gemm_dw_monitor); what the items poll
   int tcap;                 // value published once every line is complete (longest line + 32)
@@ -63,10 +60,7 @@ struct GemmDwArgs {
 
 // blocks of the x3 item in flight in registers (6 and 8 were measured: the fused launch then needs > 168 registers,
 // only one GEMM workgroup fits a CU, 142 / 148 us against 116)
-#ifndef CLSTM_DW_PF
-#define CLSTM_DW_PF 3
-#endif
-constexpr int DW_PF = CLSTM_DW_PF;
+constexpr int DW_PF = 3;
 constexpr int DW_SMEM_FLOATS = 8192 + 2048;   // + the slab's k-tile table (DW_STAB_MAX entries of 2 ints)
 constexpr int DW_STAB_MAX = 1024;   // 32 KB: two buffers of four 64 x 32 bf16 images (x3 path); the epilogue tile fits too
 static_assert(8192 >= GEMM_BT * GEMM_LDO, "epilogue tile");
@@ -428,35 +422,6 @@ DEVFN void gemm_dw_body(const GemmDwArgs& a, float* smem, unsigned block) {
 __global__ __launch_bounds__(256) void gemm_dw_kernel(GemmDwArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[DW_SMEM_FLOATS];
   gemm_dw_body(a, smem, blockIdx.x);
-}
-
-// persistent worker (a role of lstm_bwd_dw_kernel): pulls items of its XCD's queue until it is empty.  A worker that
-// finds itself on a CU where a recurrence workgroup runs would only get the issue slots that workgroup leaves and
-// hold its slab back; it waits until every line is complete and joins for the remainder.
-DEVFN void gemm_dw_worker(const GemmDwArgs& a, float* smem, int* lds_item) {
-  const int tid = threadIdx.x;
-  const unsigned tiles = a.gx * a.gy;
-  const int xcd = hw_xcc_id() & 7;
-  const int nslabs_x = (a.nslabs - xcd + 7) / 8;
-  const int nitems = nslabs_x * (int)tiles;
-  sleep_iterations(8);    // ~3 us: the recurrence workgroups (dispatched first) have marked their CUs by now
-  if (tid == 0) *lds_item = load_i32_wt(a.cu_busy + hw_cu_slot()) == a.prog_base ? 1 : 0;
-  __syncthreads();
-  const bool shared_cu = *lds_item != 0;
-  __syncthreads();
-  if (shared_cu) {
-    for (int d = 0; d < a.ndir; d++) gemm_dw_wait(a, d, 0x3fffffff);
-  }
-  for (;;) {
-    if (tid == 0) *lds_item = atomic_fetch_add_i32(a.qhead + xcd, 1);
-    __syncthreads();
-    const int item = *lds_item;
-    __syncthreads();
-    if (item >= nitems) break;
-    if (a.x3) gemm_dw_item_x3(a, smem, (unsigned)(item / (int)tiles) * 8u + (unsigned)xcd, (unsigned)item % tiles);
-    else gemm_dw_item(a, smem, (unsigned)(item / (int)tiles) * 8u + (unsigned)xcd, (unsigned)item % tiles);
-    __syncthreads();
-  }
 }
 
 }  // namespace clstm

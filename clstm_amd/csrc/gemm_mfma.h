@@ -26,17 +26,11 @@
 
 namespace clstm {
 
-#ifndef CLSTM_FEXP   // perf experiments only (results wrong)
-#define CLSTM_FEXP 0
-#endif
 enum { GEMM_KC = 0, GEMM_MC = 1 };
 constexpr int GEMM_BT = 64;   // tile rows / cols
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_LD = 80;
-#ifndef CLSTM_GEMM_PF
-#define CLSTM_GEMM_PF 3
-#endif
-constexpr int GEMM_PF = CLSTM_GEMM_PF;   // k-tiles prefetched in registers
+constexpr int GEMM_PF = 3;   // k-tiles prefetched in registers
 constexpr int GEMM_LDO = 68;  // LDS row stride of the output tile in the epilogue
 
 struct GemmOperand {
@@ -99,7 +93,7 @@ DEVFN void gemm_f32_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R
   auto load_tile = [&](int k0, f32x4 (&ra)[NP], f32x4 (&rb)[NP]) {
 #pragma unroll
     for (int h = 0; h < NP; h++) {
-      const bool live = k0 + 16 * h < kend && !(CLSTM_FEXP & 1);
+      const bool live = k0 + 16 * h < kend;
       ra[h] = buf_load4(abuf, live ? (a_base + (unsigned)(k0 + 16 * h) * a_kstep) * 4u : BUF_OOB);
       rb[h] = buf_load4(bbuf, live ? (b_base + (unsigned)(k0 + 16 * h) * b_kstep) * 4u : BUF_OOB);
     }
@@ -171,12 +165,11 @@ DEVFN void gemm_f32_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-          for (int j = 0; j < 2; j++) if (!(CLSTM_FEXP & 2) || (i == 0 && j == 0)) acc[i][j] = mfma16x16x4(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < 2; j++) acc[i][j] = mfma16x16x4(af[i], bf[j], acc[i][j]);
       }
       __syncthreads();
     }
   }
-  if ((CLSTM_FEXP & 4) && acc[0][0][0] != 12345.6f) return;
   if (fe.vec4()) {
     // Epilogue through LDS: the MFMA layout holds 16-float pieces of a row per lane group; transposed
     // through the tile every lane writes one 16-byte piece and a wave covers four whole 256-byte row

@@ -129,9 +129,6 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
   float* wrB = lead ? lds + hslot : lds + 2 * HB;
   float c_prev = 0.0f;
   if (T <= 0) return;
-#ifdef CLSTM_PRIO
-  if (wave >= CLSTM_PRIO) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the later-dispatched waves
-#endif
   // input pre-activations are fetched two steps ahead into two alternating registers (the loop is
   // unrolled by two so that no register rotation forces an early wait on an in-flight load)
   float gxA = buf_load(gbuf, gl + fr(0) * gstride4);
@@ -167,14 +164,11 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
   auto flush = [&](const int tp, float pa0, float pa1, float pa2) {
     const bool any = tp >= 0;
     const unsigned f = fr(tp < 0 ? 0 : tp);
-#ifndef CLSTM_EXP_NOSTORE   // (perf experiments only: bit mask of stores to leave out -- results are then wrong)
-#define CLSTM_EXP_NOSTORE 0
-#endif
-    if (!(CLSTM_EXP_NOSTORE & 1)) buf_store(gbuf, any ? gl + f * gstride4 : BUF_OOB, pa0);
-    if (!(CLSTM_EXP_NOSTORE & 2)) buf_store(cbuf, any ? cl + f * cstride4 : BUF_OOB, pa1);
-    if (!(CLSTM_EXP_NOSTORE & 4)) buf_store(hbuf, any ? hl + f * hstride4 : BUF_OOB, pa2);
+    buf_store(gbuf, any ? gl + f * gstride4 : BUF_OOB, pa0);
+    buf_store(cbuf, any ? cl + f * cstride4 : BUF_OOB, pa1);
+    buf_store(hbuf, any ? hl + f * hstride4 : BUF_OOB, pa2);
     // h_t is the recurrent part of the NEXT step's source row (dropped after the last step)
-    if (!(CLSTM_EXP_NOSTORE & 8)) buf_store(sbuf, any && tp + 1 < T ? sl + fr(tp + 1) * sstride4 : BUF_OOB, pa2);
+    buf_store(sbuf, any && tp + 1 < T ? sl + fr(tp + 1) * sstride4 : BUF_OOB, pa2);
   };
   // WHICH side of the barrier a wave stores on depends on its role (measured: the four stores of all seven waves
   // issued together right behind the barrier queue at the texture addresser -- 28 wave-instructions at ~10-16
@@ -182,13 +176,11 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
   // stores at all the kernel runs 91.6 us instead of 115.4).  The first-dispatched waves (one per SIMD, they win the
   // VALU arbitration and then sit ~400 cycles at the barrier) store at the END of their step; the later waves, whose
   // FMAs wait for the older wave of their SIMD anyway, store right behind the barrier.
-#ifndef CLSTM_EARLY_WAVES
-#define CLSTM_EARLY_WAVES 4
-#endif
+  constexpr int EARLY_WAVES = 4;
   // The two roles are two copies of the whole time loop (one wave-uniform branch in front): inside a copy the
   // stores sit at a fixed place in straight-line code, so hipcc still counts the VMEM queue exactly (a branch
   // inside the step made it wait with vmcnt(1), i.e. for the previous step's stores).
-  const bool early = wave_uniform(wave) < CLSTM_EARLY_WAVES;
+  const bool early = wave_uniform(wave) < EARLY_WAVES;
   auto run = [&](auto early_tag) {
   constexpr bool EARLY = decltype(early_tag)::value;
   auto step = [&](const int t, float& gxr, const float* hq, float* hw, float& ka0, float& ka1, float& ka2,
@@ -271,176 +263,6 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
 #endif
 }
 
-// ---- forward recurrence, second form: the first-dispatched waves store for everybody --------------------------------
-// Per-phase stamps of lstm_fwd_kernel (profiles/r02_lstm_fwd_phase_cycles.txt): the waves that define a step -- the
-// later-dispatched one of each SIMD -- spend ~220 of their ~1180 cycles issuing their four global stores, while the
-// first-dispatched waves sit ~350 cycles at the barrier.  Here EVERY result of a step also goes to LDS (h_t as before,
-// plus c_t and the four activations, all double-buffered like h), and at the end of step t -- in what would be their
-// barrier wait -- the first four waves read step t-1's values back and write them to G / C / H / S with flat stores
-// (any array per lane: 7*no values = three store instructions per wave).  The other waves issue no store at all.
-// Same arithmetic, same arrays, bit-identical results to lstm_fwd_kernel.
-template <int NK4, int KU>
-__global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd2_kernel(LstmSeqArgs a) {
-  constexpr int KQP = 4 * NK4;
-  constexpr int QS = KQP + ((NK4 & 1) ? 0 : 4);
-  constexpr int HB = 4 * QS;
-  constexpr int NT = 64 * NK4;                 // threads
-  constexpr int CP = 16 * NK4;                 // cell slots
-  constexpr int EWMAX = NK4 < 4 ? NK4 : 4;     // storing waves (the first-dispatched ones): at most four
-  constexpr int NI = (7 * 4 * KU + 64 * EWMAX - 1) / (64 * EWMAX);   // store items per storing thread (7*no values, no <= 4*KU)
-  float* lds = dyn_smem<float>();  // hb[2][HB] | cb[2][CP] | ab[2][NT] | dump
-  float* const hb = lds;
-  float* const cb = lds + 2 * HB;
-  float* const ab = cb + 2 * CP;
-  float* const dump = ab + 2 * NT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nthreads = blockDim.x;             // 64 * ceil(no / 16): may be fewer waves than NK4 provides for
-  const int nwaves = nthreads >> 6;
-  const int EW = nwaves < EWMAX ? nwaves : EWMAX, EWT = 64 * EW;
-  const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, dir = blockIdx.y;
-  const int no = a.no, nd = a.ndir;
-  const int q = lane & 3, cell = wave * 16 + (lane >> 2);
-  const bool valid = cell < no;
-  const bool lead = valid && q == 0;
-
-  f32x2 w01[KQP], w23[KQP];
-  {
-    const float* rp = a.Rpk + (size_t)dir * 4 * KQP * nthreads + tid;
-#pragma unroll
-    for (int kk = 0; kk < KQP; kk++) {
-      w01[kk] = (f32x2){rp[(size_t)(0 * KQP + kk) * nthreads], rp[(size_t)(1 * KQP + kk) * nthreads]};
-      w23[kk] = (f32x2){rp[(size_t)(2 * KQP + kk) * nthreads], rp[(size_t)(3 * KQP + kk) * nthreads]};
-    }
-  }
-  for (int i = tid; i < 2 * (HB + CP + NT) + 4; i += nthreads) lds[i] = 0.0f;
-
-  const int off = a.line_off[b];
-  const int T = a.line_off[b + 1] - off;
-  if (T <= 0) return;
-  const unsigned gstride4 = (unsigned)nd * 4 * no * 4, cstride4 = (unsigned)nd * no * 4;
-  const unsigned hstride4 = (unsigned)a.ldh * 4, sstride4 = (unsigned)a.lds * 4;
-  const BufF32 gbuf = make_buf(a.G + (size_t)off * (gstride4 / 4), (size_t)T * gstride4);
-  const unsigned gl = valid ? ((unsigned)dir * 4 * no + cell * 4 + q) * 4u : BUF_OOB_BASE;
-  auto fr = [&](int t) -> unsigned {  // clamped: prefetches past the end re-read the last frame
-    const int tc = t < T ? t : T - 1;
-    return (unsigned)(dir == 0 ? tc : T - 1 - tc);
-  };
-  const int hslot = (cell / KU) * QS + (cell % KU);
-  const float a_scale = q == 3 ? ACT_TANH_SCALE : ACT_SIG_SCALE, a_mul = q == 3 ? 2.0f : 1.0f, a_add = q == 3 ? -1.0f : 0.0f;
-  // parity A: a step that reads buffer 0 and writes buffer 1 (even steps); parity B the other way round
-  const float* rdA = hb + q * QS;
-  const float* rdB = hb + HB + q * QS;
-  float* whA = lead ? hb + HB + hslot : dump;   float* whB = lead ? hb + hslot : dump;
-  float* wcA = lead ? cb + CP + cell : dump;    float* wcB = lead ? cb + cell : dump;
-  float* waA = valid ? ab + NT + tid : dump;    float* waB = valid ? ab + tid : dump;
-
-  // store items of a storing thread: value index i = tid + j*EWT of [act (4*no) | c (no) | h -> H (no) | h -> S (no)]
-  const bool storer = wave_uniform(wave) < EW;
-  const float* src0[NI];        // where the value sits in the buffer-0 family; the buffer-1 copy is src1 floats further
-  int src1[NI];
-  char* gptr[NI];               // address for frame 0 of the line; per step + frame * fstr
-  unsigned fstr[NI];
-  bool isS[NI];
-  char* const dumpg = reinterpret_cast<char*>(a.H + (size_t)off * a.ldh);   // a pad column of this line's first H row
-#pragma unroll
-  for (int j = 0; j < NI; j++) {
-    const int i = tid + j * EWT;
-    src0[j] = dump; src1[j] = 0; gptr[j] = dumpg; fstr[j] = 0; isS[j] = false;
-    if (storer) {
-      if (i < 4 * no) {
-        src0[j] = ab + i; src1[j] = NT;
-        gptr[j] = reinterpret_cast<char*>(a.G + (size_t)off * (gstride4 / 4) + (size_t)dir * 4 * no + i); fstr[j] = gstride4;
-      } else if (i < 7 * no) {
-        const int k = (i - 4 * no) / no, c = (i - 4 * no) % no;
-        if (k == 0) {
-          src0[j] = cb + c; src1[j] = CP;
-          gptr[j] = reinterpret_cast<char*>(a.C + (size_t)off * (cstride4 / 4) + (size_t)dir * no + c); fstr[j] = cstride4;
-        } else {
-          src0[j] = hb + (c / KU) * QS + (c % KU); src1[j] = HB;
-          if (k == 1) { gptr[j] = reinterpret_cast<char*>(a.H + (size_t)off * a.ldh + a.hofs + (size_t)dir * no + c); fstr[j] = hstride4; }
-          else { gptr[j] = reinterpret_cast<char*>(a.S + (size_t)dir * a.sdir + (size_t)off * a.lds + a.sofs + c); fstr[j] = sstride4; isS[j] = true; }
-        }
-      }
-    }
-  }
-  // results of step tp (sitting in buffer family `par`) -> memory.  FINAL: the h of the last step has no next source row.
-  // v / p: this parity's own data and address registers.  A VMEM store reads its operands late and hipcc guards
-  // their re-use with vmcnt; pinned until the same parity's next flush (two steps on), the guard becomes a counted
-  // wait for stores issued two steps ago instead of a drain of the ones just issued.
-  auto flush = [&](const int tp, const int par, const bool final_, float (&v)[NI], char* (&pp)[NI]) {
-    const unsigned fc = fr(tp), fn = fr(tp + 1);
-#pragma unroll
-    for (int j = 0; j < NI; j++) { KEEP_ALIVE(v[j]); asm volatile("" ::"v"(pp[j])); }
-#pragma unroll
-    for (int j = 0; j < NI; j++) {
-      v[j] = src0[j][par ? src1[j] : 0];
-      pp[j] = gptr[j] + (size_t)(isS[j] ? fn : fc) * fstr[j];
-      if (final_ && isS[j]) pp[j] = dumpg;
-    }
-#pragma unroll
-    for (int j = 0; j < NI; j++) *reinterpret_cast<float*>(pp[j]) = v[j];
-  };
-  float fvA[NI], fvB[NI];
-  char *fpA[NI], *fpB[NI];
-#pragma unroll
-  for (int j = 0; j < NI; j++) { fvA[j] = fvB[j] = 0.0f; fpA[j] = fpB[j] = dumpg; }
-
-  float c_prev = 0.0f;
-  float gxA = buf_load(gbuf, gl + fr(0) * gstride4);
-  float gxB = buf_load(gbuf, gl + fr(1) * gstride4);
-  if (lead) a.S[(size_t)dir * a.sdir + (size_t)(off + fr(0)) * a.lds + a.sofs + cell] = 0.0f;   // h_{-1} = 0 (forward_stack_delay, last < 0)
-#pragma unroll
-  for (int kk = 0; kk < KQP; kk++) { KEEP_ALIVE2(w01[kk]); KEEP_ALIVE2(w23[kk]); }
-  KEEP_ALIVE(gxA); KEEP_ALIVE(gxB);
-  __syncthreads();
-
-  auto run = [&](auto storer_tag) {
-    constexpr bool STORER = decltype(storer_tag)::value;
-    // one step; FLUSH: this step also writes out step t-1 (not the very first step)
-    auto step = [&](const int t, float& gxr, const float* hq, float* wh, float* wc, float* wa, const int par, auto flush_tag) {
-      constexpr bool FLUSH = decltype(flush_tag)::value;
-      f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
-      float4 hv[NK4];
-#pragma unroll
-      for (int j = 0; j < NK4; j++) hv[j] = *reinterpret_cast<const float4*>(hq + 4 * j);
-      SCHED_FENCE();
-#pragma unroll
-      for (int j = 0; j < NK4; j++) {
-        if (4 * j < KU) { a01 = fma2(w01[4 * j], splat2(hv[j].x), a01); a23 = fma2(w23[4 * j], splat2(hv[j].x), a23); }
-        if (4 * j + 1 < KU) { a01 = fma2(w01[4 * j + 1], splat2(hv[j].y), a01); a23 = fma2(w23[4 * j + 1], splat2(hv[j].y), a23); }
-        if (4 * j + 2 < KU) { a01 = fma2(w01[4 * j + 2], splat2(hv[j].z), a01); a23 = fma2(w23[4 * j + 2], splat2(hv[j].z), a23); }
-        if (4 * j + 3 < KU) { a01 = fma2(w01[4 * j + 3], splat2(hv[j].w), a01); a23 = fma2(w23[4 * j + 3], splat2(hv[j].w), a23); }
-      }
-      const float k0 = a01[0] + quad_xor2(a23[0]);
-      const float k1 = a01[1] + quad_xor2(a23[1]);
-      const float k = k0 + quad_xor1(k1);
-      const float pre = k + gxr;
-      gxr = buf_load(gbuf, gl + fr(t + 2) * gstride4);
-      const float act = act_affine(pre, a_scale, a_mul, a_add);
-      const float cig = mul_quad_bcast<0>(act, quad_bcast<3>(act));
-      const float c = fmac_quad_bcast<1>(cig, act, c_prev);
-      const float h = mul_quad_bcast<2>(act, tanh_fast(c));
-      c_prev = c;
-      *wh = h; *wc = c; *wa = act;
-      if constexpr (STORER && FLUSH) {   // step t-1's values: the buffers this step READ
-        if (par) flush(t - 1, 1, false, fvB, fpB); else flush(t - 1, 0, false, fvA, fpA);
-      }
-      __syncthreads();
-    };
-    step(0, gxA, rdA, whA, wcA, waA, 0, std::false_type{});
-    int t = 1;
-    for (; t + 1 < T; t += 2) {
-      step(t, gxB, rdB, whB, wcB, waB, 1, std::true_type{});
-      step(t + 1, gxA, rdA, whA, wcA, waA, 0, std::true_type{});
-    }
-    if (t < T) { step(t, gxB, rdB, whB, wcB, waB, 1, std::true_type{}); t++; }
-    // the last step's values sit in the buffer family it wrote: parity of T
-    if constexpr (STORER) flush(T - 1, T & 1, true, fvA, fpA);
-  };
-  if (storer) run(std::true_type{}); else run(std::false_type{});
-}
-
-// (workgroup body: line b, direction dir -- also one of the two roles of lstm_bwd_dw_kernel below)
 template <int NK4, int KU>
 DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
   constexpr int SLP = 4 * NK4;
@@ -475,9 +297,6 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
     }
     return;
   }
-#ifdef CLSTM_PRIO
-  if (wave >= CLSTM_PRIO) __builtin_amdgcn_s_setprio(1);
-#endif
   const int pidx = g * no + cell;  // this lane's delta goes to pair (gate g, j = cell)
   const int dslot = (pidx / SL) * QS + (pidx % SL);
   const unsigned gstride4 = (unsigned)nd * 4 * no * 4, cstride4 = (unsigned)nd * no * 4;
@@ -487,11 +306,7 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
   // and writes, at iteration `it`, that iterations < it - 3 of this line are complete: every wave has passed the
   // barrier of iteration it-1, i.e. has consumed operands whose loads were issued behind its delta store of
   // iteration it-4, and VMEM operations of a wave complete in order (vmcnt).  Stores are written through.
-#ifdef CLSTM_NO_REPORT   // (experiment: the kernel without the progress-reporting lane)
-  const bool report = false;
-#else
   const bool report = a.prog_off >= 0;
-#endif
   const bool tagl = report && tid == nthreads - 1;            // requires cell(tid) >= no (checked by the host)
   const long long prog_rel = a.prog_off + ((long long)dir * a.bs + b) * PROG_STRIDE - (long long)off * (gstride4 / 4);
   const BufF32 dbuf = make_buf(a.D + (size_t)off * (gstride4 / 4), report ? (size_t)(prog_rel + 1) * 4 : (size_t)T * gstride4);
@@ -586,11 +401,7 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
     // (address and data by select: a per-lane stride through v_mad_u32_u24 made hipcc serialise the step's LDS reads)
     const float sdat = tagl ? __builtin_bit_cast(float, a.prog_base + (T - 1 - s) - 3) : delta;
     const unsigned soff = tagl ? ptag : gl + fr(s) * gstride4;
-#ifdef CLSTM_D_PLAIN   // (experiment: what the write-through costs; not valid with a concurrent consumer)
-    buf_store(dbuf, soff, sdat);
-#else
     buf_store_wt(dbuf, soff, sdat);
-#endif
     *dw = delta;
     ka = sdat;
     __syncthreads();

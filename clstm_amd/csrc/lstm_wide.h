@@ -2,9 +2,10 @@
 // register file of one workgroup (no > 128; BASELINE config "2 x BiLSTM(512)").
 //
 // Same arithmetic as lstm_seq.h (GenericNPLSTM::forward / ::backward, clstm.cc:600-653), different
-// parallelisation: the minibatch's lines advance in lock-step, one launch per time step, and the
-// recurrent product of a step is a (lines x no) . (no x 4no) MFMA GEMM spread over the whole chip
-// instead of a per-line mat-vec:
+// parallelisation: the minibatch's lines advance in lock-step -- ONE persistent launch per pass with a workgroup
+// group per XCD (lstm_xcd_*, the default), or one launch per time step (the fallback when the placement
+// check fails, and what CLSTM_XCD_REC=0 selects) -- and the recurrent product of a step is a
+// (lines x no) . (no x 4no) MFMA GEMM spread over the whole chip instead of a per-line mat-vec:
 //
 //   forward  step s : pre[m][cell,g] = G_x[frame_m(s)][cell,g] + sum_k h[frame_m(s-1)][k] R_g[cell][k]
 //   backward step s : dh_rec[m][k]   = sum_{g,j} delta_g[frame_m(s+1)][j] R_g[j][k]
@@ -43,16 +44,15 @@ struct LstmWideArgs {
   int no, ndir, bs;
   int kp;               // padded contraction length, multiple of 64
   int step;             // lock-step index: forward own step s = step, backward own step s = T-1-step
-  int tmax;             // cooperative kernels: number of lock-steps (longest line)
+  int tmax;             // persistent kernels: number of lock-steps (longest line)
   int zb0, zbn;         // persistent per-XCD kernels: this launch walks the 16-line blocks [zb0, zb0 + zbn), zbn * ndir <= 8
-  int* sync;            // cooperative kernels: [0] barrier ticket counter (zeroed per launch), [1] watchdog flag
+  int* sync;            // persistent kernels: XcdSyncLayout words (zeroed per launch)
   // bf16 MFMA operands (per-step kernels lstm_wide_*_step_bf16; BASELINE config "2 x BiLSTM(512), bf16 MFMA"):
   const unsigned short* Rw16;   // the same weight rows as Rw, bf16, row length kp16
   unsigned short* Hb;           // [N][nd][kp16]  bf16 copy of h (forward A operand), pad columns stay zero
   unsigned short* Db;           // [N][nd][kp16]  bf16 copy of the gate deltas at column 4*cell+gate (backward A operand)
   unsigned short* Hbf;          // persistent forward kernel: per-frame [N][hbf_ld] bf16 copy of h (dir d at column d*no): the next
   int hbf_ld;                   //   layer's W_x product reads it as its k-contiguous A operand; or null
-  unsigned epoch;               // persistent forward kernel with the tagged ring: launch number (tags = epoch << 12 | step)
   int skip_d;                   // persistent backward kernel: the f32 deltas D are not stored (every consumer reads Dbf; the host expands Dbf if one does not)
   unsigned short* Sbf;          // persistent forward kernel: bf16 source rows [x | h_{t-1} | 1] of THIS layer, [dir][N][sbf_ld] (h-part written here), or null
   int sbf_ld, sbf_ofs; long long sbf_dir;
@@ -62,7 +62,6 @@ struct LstmWideArgs {
 
 constexpr int WIDE_LDW = 20;  // LDS row stride of a partial tile (16 columns + pad, float4-aligned)
 constexpr int WIDE_PF = 4;    // 16-k groups in flight per wave, per-step kernels (8 measured slower: 200 VGPRs)
-constexpr int WIDE_PF_COOP = 8;  // cooperative kernels: all groups of a 512-cell layer in flight at once
 constexpr int WIDE_NW = 4;    // waves per workgroup = split-K factor (8 was measured on MI355X at 512 cells: 9.9 / 8.5 ms
                               // against 9.7 / 8.3 ms per pass -- the step is not bound by the MFMA/load rounds of a wave)
 constexpr int WIDE_THREADS = 64 * WIDE_NW;
@@ -70,13 +69,11 @@ constexpr int WIDE_WPAD = 4;  // LDS weight rows are kp + 4 floats: 16 rows x b1
 
 // acc[i] += A_i(16 rows x kslice) . B(kslice x 16 cols) for this wave's quarter of the contraction,
 // then the four waves' partial tiles are left in red[wave][row][col] (caller syncs).
-// COOP = false: B rows come from global memory (bbuf/brow), A rows by plain loads (per-step launches).
-// COOP = true : B rows are resident in LDS (wl, row stride kp + WIDE_WPAD), A rows were written by OTHER
-//               workgroups of the same launch -> device-scope (sc1) loads.
-template <int MT, int NT, bool COOP>
+// B rows come from global memory (bbuf/brow), A rows by plain loads (per-step launches).
+template <int MT, int NT>
 DEVFN void wide_tile(const BufF32 abuf, const unsigned (&arow)[MT], const BufF32 bbuf, const unsigned brow,
-                     const float* wl, const int kp, float* red) {
-  constexpr int PF = COOP ? WIDE_PF_COOP : WIDE_PF;
+                     const int kp, float* red) {
+  constexpr int PF = WIDE_PF;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int kw = kp / WIDE_NW;            // contraction range of one wave (multiple of 16)
   const int ngroups = kw >> 4;
@@ -95,14 +92,10 @@ DEVFN void wide_tile(const BufF32 abuf, const unsigned (&arow)[MT], const BufF32
     const unsigned ko = klane + (unsigned)g * 64u;
 #pragma unroll
     for (int i = 0; i < MT; i++)
-      a[i] = COOP ? buf_load4_dev(abuf, live ? arow[i] + ko : BUF_OOB) : buf_load4(abuf, live ? arow[i] + ko : BUF_OOB);
-    if (!COOP) {
+      a[i] = buf_load4(abuf, live ? arow[i] + ko : BUF_OOB);
 #pragma unroll
-      for (int j = 0; j < NT; j++) b[j] = buf_load4(bbuf, live ? brow + (unsigned)j * 16u * (unsigned)kp * 4u + ko : BUF_OOB);
-    }
+    for (int j = 0; j < NT; j++) b[j] = buf_load4(bbuf, live ? brow + (unsigned)j * 16u * (unsigned)kp * 4u + ko : BUF_OOB);
   };
-  const int ldw = kp + WIDE_WPAD;
-  const float* wrow = COOP ? wl + (lane & 15) * ldw + (klane >> 2) : nullptr;
 #pragma unroll
   for (int p = 0; p < PF; p++) {
     load_group(p, ra[p], rb[p]);
@@ -114,14 +107,8 @@ DEVFN void wide_tile(const BufF32 abuf, const unsigned (&arow)[MT], const BufF32
       f32x4 av[MT], bv[NT];
 #pragma unroll
       for (int i = 0; i < MT; i++) av[i] = ra[p][i];
-      if (COOP) {  // groups past the end multiply zero A rows: any in-range weight group will do
-        const int g = g0 + p < ngroups ? g0 + p : ngroups - 1;
 #pragma unroll
-        for (int j = 0; j < NT; j++) bv[j] = *reinterpret_cast<const f32x4*>(wrow + j * 16 * ldw + g * 16);
-      } else {
-#pragma unroll
-        for (int j = 0; j < NT; j++) bv[j] = rb[p][j];
-      }
+      for (int j = 0; j < NT; j++) bv[j] = rb[p][j];
 #pragma unroll
       for (int e = 0; e < 4; e++)
 #pragma unroll
@@ -194,9 +181,6 @@ DEVFN void wide_tile_bf16(const BufF32 abuf, const unsigned (&arow)[MT], const B
     for (int q = 0; q < 4; q++) red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * LDR + (lane & 15)] = acc[i][q];
 }
 
-#ifndef CLSTM_WEXP   // perf experiments only: bit mask of work to leave out of the forward step (results are then wrong)
-#define CLSTM_WEXP 0
-#endif
 // 16 lines x 64 columns (four 16-row weight tiles, `btile` bytes apart) on the same instruction: one A fragment serves
 // four MFMAs, so a workgroup pulls a quarter of the FRESH bytes (h_{t-1}: written one launch ago by other XCDs, an L2
 // miss) per product column; the weight rows it reads instead are L2-resident for the whole sequence.
@@ -268,10 +252,10 @@ DEVFN void wide_fwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int c
   const int no = a.no, nd = a.ndir;
   const int ncg = (no + 3) >> 2;
   const int m = zb * 16 + (lane & 15);
-  const unsigned arow = (sg >= 1 && m < a.bs && !(CLSTM_WEXP & 1)) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + m) * a.kp16) * 2u : BUF_OOB_BASE;
+  const unsigned arow = (sg >= 1 && m < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + m) * a.kp16) * 2u : BUF_OOB_BASE;
   const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * a.bs * a.kp16 * 2);
   const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(a.Rw16), (size_t)a.rw_elems * 2);
-  const unsigned brow = (CLSTM_WEXP & 2) ? BUF_OOB_BASE : (unsigned)(((long long)(dir * ncg + ct * 4) * 16 + (lane & 15)) * a.kp16) * 2u;   // rows past the
+  const unsigned brow = (unsigned)(((long long)(dir * ncg + ct * 4) * 16 + (lane & 15)) * a.kp16) * 2u;   // rows past the
   const unsigned btile = (unsigned)(16 * a.kp16) * 2u;                   // last cell group: dropped by the descriptor
 
   const int ml = tid >> 4, c16 = tid & 15;
@@ -291,7 +275,7 @@ DEVFN void wide_fwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int c
   wide_tile_bf16_n4<4>(abuf, arow, bbuf, brow, btile, a.kp16, red, [&]() {
     off = __builtin_bit_cast(int, lo0);
     T = __builtin_bit_cast(int, lo1) - off;
-    live = line < a.bs && cell < no && sg < T && !(CLSTM_WEXP & 32);
+    live = line < a.bs && cell < no && sg < T;
     n = off + (dir == 0 ? sg : T - 1 - sg);
     gx = buf_load4(gbuf, live ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB);
     c_prev = buf_load(cbuf, live && sg >= 1
@@ -300,8 +284,7 @@ DEVFN void wide_fwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int c
   __syncthreads();
 
   float h = 0.0f;
-  if (CLSTM_WEXP & 32) live = line < a.bs && cell < no && sg < T;
-  if (live && !(CLSTM_WEXP & 16)) {
+  if (live) {
     f32x4 k;
 #pragma unroll
     for (int q = 0; q < 4; q++) k[q] = 0.0f;
@@ -317,7 +300,6 @@ DEVFN void wide_fwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int c
     h = gate_act(c, true) * go;
     f32x4 act;
     act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
-    if ((CLSTM_WEXP & 8) && h != 12345.678f) return;
     *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
     a.C[(n * nd + dir) * no + cell] = c;
     a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
@@ -343,10 +325,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_fwd_step16_bf16(LstmWi
 }
 
 // ---- forward: one time step of 16*MT lines for one (cell group, direction) ------------------------
-// loff: line offsets (global for the per-step launch, an LDS copy in the cooperative kernel)
-template <int MT, bool COOP, bool BF16 = false>
+template <int MT>
 DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, const int dir, const int zb,
-                         const int* loff, const float* wl, float* red) {
+                         const int* loff, float* red) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int no = a.no, nd = a.ndir;
   const int ncg = (no + 3) >> 2;
@@ -360,19 +341,13 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
       const int off = loff[m], T = loff[m + 1] - off;
       if (sg >= 1 && sg < T) {
         const int fprev = dir == 0 ? sg - 1 : T - sg;   // frame of own step s-1
-        arow[i] = BF16 ? (unsigned)((((long long)(off + fprev) * nd + dir) * a.kp16) * 2)
-                       : (unsigned)((long long)(off + fprev) * a.ldh + a.hofs + dir * no) * 4u;
+        arow[i] = (unsigned)((long long)(off + fprev) * a.ldh + a.hofs + dir * no) * 4u;
       }
     }
-    if (CLSTM_WEXP & 1) arow[i] = BUF_OOB_BASE;
   }
-  const BufF32 abuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)a.N * nd * a.kp16 * 2)
-                            : make_buf(a.H, (size_t)a.N * a.ldh * 4);
-  const BufF32 bbuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Rw16), (size_t)a.rw_elems * 2)
-                            : make_buf(a.Rw, (size_t)a.rw_elems * 4);
-  const unsigned brow = (CLSTM_WEXP & 2) ? BUF_OOB_BASE
-                        : BF16 ? (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp16) * 2u
-                               : (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp) * 4u;
+  const BufF32 abuf = make_buf(a.H, (size_t)a.N * a.ldh * 4);
+  const BufF32 bbuf = make_buf(a.Rw, (size_t)a.rw_elems * 4);
+  const unsigned brow = (unsigned)(((long long)(dir * ncg + cg) * 16 + (lane & 15)) * a.kp) * 4u;
 
   // epilogue role of this thread: (line, cell); its operands are requested before the MFMA loop so
   // that their HBM latency hides under it (masked threads read nothing: out-of-range offsets)
@@ -388,19 +363,16 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
   const long long n = off + (dir == 0 ? sg : T - 1 - sg);
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
   const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
-  const unsigned goff = live && !(CLSTM_WEXP & 32) ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB;
+  const unsigned goff = live ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB;
   const f32x4 gx = buf_load4(gbuf, goff);
-  // c_{s-1} was written by this very thread one step ago (same (line, cell) role), so a plain load is
-  // coherent in the cooperative kernel as well
-  const float c_prev = buf_load(cbuf, live && sg >= 1 && !(CLSTM_WEXP & 32)
+  const float c_prev = buf_load(cbuf, live && sg >= 1
       ? (unsigned)((((long long)(off + (dir == 0 ? sg - 1 : T - sg)) * nd + dir) * no + cell) * 4) : BUF_OOB);
 
-  if (BF16) wide_tile_bf16<MT, 4>(abuf, arow, bbuf, brow, a.kp16, red, []() {});
-  else wide_tile<MT, 1, COOP>(abuf, arow, bbuf, brow, wl, a.kp, red);
+  wide_tile<MT, 1>(abuf, arow, bbuf, brow, a.kp, red);
   __syncthreads();
 
   // fused forward_full1 x4 + forward_statemem + forward_nonlingate for (line, cell)
-  if (live && !(CLSTM_WEXP & 16)) {
+  if (live) {
     f32x4 k;
 #pragma unroll
     for (int q = 0; q < 4; q++) k[q] = 0.0f;
@@ -416,13 +388,9 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
     const float h = gate_act(c, true) * go;
     f32x4 act;
     act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
-    if ((CLSTM_WEXP & 8) && h != 12345.678f) return;
     *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
     a.C[(n * nd + dir) * no + cell] = c;
-    // h_t is next step's A operand of every workgroup of this direction
-    if (COOP) buf_store_dev(abuf, (unsigned)(n * a.ldh + a.hofs + dir * no + cell) * 4u, h);
-    else a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
-    if (BF16) a.Hb[(n * nd + dir) * a.kp16 + cell] = (unsigned short)(bf16_pack2(h, 0.0f) & 0xFFFFu);   // next step's A operand
+    a.H[n * a.ldh + a.hofs + dir * no + cell] = h;   // next step's A operand of every workgroup of this direction
     float* srow = a.S + (size_t)dir * a.sdir;
     if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;                      // h_{-1} = 0
     if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
@@ -433,22 +401,12 @@ DEVFN void wide_fwd_tile(const LstmWideArgs& a, const int sg, const int cg, cons
 template <int MT>
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_fwd_step(LstmWideArgs a) {
   __shared__ __attribute__((aligned(16))) float red[WIDE_NW * MT * 16 * WIDE_LDW];
-  wide_fwd_tile<MT, false>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);
-}
-
-template <int MT>
-__global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_fwd_step_bf16(LstmWideArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[WIDE_NW * MT * 16 * WIDE_LDW];
-  wide_fwd_tile<MT, false, true>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);
+  wide_fwd_tile<MT>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, red);
 }
 
 // ---- backward: one time step of 16 lines for one (16-cell tile, direction) ------------------------
-#ifndef CLSTM_WEXPB   // perf experiments only: bit mask of work to leave out of the backward step (results are then wrong)
-#define CLSTM_WEXPB 0
-#endif
-template <bool COOP, bool BF16 = false>
 DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, const int dir, const int zb,
-                         const int* loff, const float* wl, float* red) {
+                         const int* loff, float* red) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int no = a.no, nd = a.ndir;
   const int nct = (no + 15) >> 4;
@@ -461,19 +419,13 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
       const int off = loff[m], T = loff[m + 1] - off;
       if (sg >= 1 && sg < T) {
         const int fnext = dir == 0 ? T - sg : sg - 1;   // frame of own step s+1, s = T-1-sg
-        arow[0] = BF16 ? (unsigned)((((long long)(off + fnext) * nd + dir) * a.kp16) * 2)
-                       : (unsigned)(((long long)(off + fnext) * nd + dir) * 4 * no) * 4u;
+        arow[0] = (unsigned)(((long long)(off + fnext) * nd + dir) * 4 * no) * 4u;
       }
     }
-    if (CLSTM_WEXPB & 1) arow[0] = BUF_OOB_BASE;
   }
-  const BufF32 abuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Db), (size_t)a.N * nd * a.kp16 * 2)
-                            : make_buf(a.D, (size_t)a.N * nd * 4 * no * 4);
-  const BufF32 bbuf = BF16 ? make_buf(reinterpret_cast<const float*>(a.Rw16), (size_t)a.rw_elems * 2)
-                            : make_buf(a.Rw, (size_t)a.rw_elems * 4);
-  const unsigned brow = (CLSTM_WEXPB & 2) ? BUF_OOB_BASE
-                        : BF16 ? (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp16) * 2u
-                               : (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp) * 4u;
+  const BufF32 abuf = make_buf(a.D, (size_t)a.N * nd * 4 * no * 4);
+  const BufF32 bbuf = make_buf(a.Rw, (size_t)a.rw_elems * 4);
+  const unsigned brow = (unsigned)(((long long)(dir * nct + ct) * 16 + (lane & 15)) * a.kp) * 4u;
 
   // epilogue operands of thread (line, cell), requested ahead of the MFMA loop
   const int ml = tid >> 4, c16 = tid & 15;
@@ -485,8 +437,6 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
     T = loff[line + 1] - off;
     live = sg < T;
   }
-  const bool lv = live;
-  if (CLSTM_WEXPB & 32) live = false;
   const int s = T - 1 - sg;
   const long long n = off + (dir == 0 ? s : sg);
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
@@ -502,12 +452,10 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
   const unsigned dcoff = (unsigned)((((long long)line * nd + dir) * no + cell) * 4);
   const float dc_carry = buf_load(dcbuf, live && sg >= 1 ? dcoff : BUF_OOB);   // own write of the previous step
 
-  if (BF16) wide_tile_bf16<1, 8>(abuf, arow, bbuf, brow, a.kp16, red, []() {});
-  else wide_tile<1, 1, COOP>(abuf, arow, bbuf, brow, wl, a.kp, red);
+  wide_tile<1, 1>(abuf, arow, bbuf, brow, a.kp, red);
   __syncthreads();
-  live = lv;
 
-  if (live && !(CLSTM_WEXPB & 16)) {
+  if (live) {
     float dh_rec = 0.0f;
 #pragma unroll
     for (int w = 0; w < WIDE_NW; w++) dh_rec += red[(w * 16 + ml) * WIDE_LDW + c16];
@@ -524,15 +472,8 @@ DEVFN void wide_bwd_tile(const LstmWideArgs& a, const int sg, const int ct, cons
     dl[1] = (gf * (-gf + 1.0f)) * d_gf;
     dl[2] = (go * (-go + 1.0f)) * d_go;
     dl[3] = (-ci * ci + 1.0f) * d_ci;
-    if ((CLSTM_WEXPB & 8) && dl[3] != 12345.678f) return;
     // the deltas are next step's A operand of every workgroup of this direction
-    if (COOP) buf_store4_dev(abuf, coff * 4u, dl);
-    else *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
-    if (BF16) {   // next step's A operand
-      unsigned* db = reinterpret_cast<unsigned*>(a.Db + (n * nd + dir) * a.kp16 + 4 * cell);
-      db[0] = bf16_pack2(dl[0], dl[1]);
-      db[1] = bf16_pack2(dl[2], dl[3]);
-    }
+    *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
   }
 }
 // ---- backward, bf16 operands: the same three measures as wide_fwd_tile16_bf16 (measured by leaving parts out: 7.75 us
@@ -619,163 +560,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_bwd_step16_bf16(LstmWi
   wide_bwd_tile16_bf16(a, a.step, ct, dir, zb, red);
 }
 
-__global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_bwd_step_bf16(LstmWideArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[WIDE_NW * 16 * WIDE_LDW];
-  wide_bwd_tile<false, true>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);
-}
-
 // per-step launch: grid (ceil(no/16), ndir, ceil(bs/16)), 256 threads
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_bwd_step(LstmWideArgs a) {
   __shared__ __attribute__((aligned(16))) float red[WIDE_NW * 16 * WIDE_LDW];
-  wide_bwd_tile<false>(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, nullptr, red);
-}
-
-// ---- cooperative persistent variants -----------------------------------------------------------------
-// ONE launch walks all time steps: every workgroup keeps its 16 weight rows in LDS for the whole
-// sequence, and the steps are separated by a grid-wide barrier instead of a kernel boundary.  All
-// workgroups must be co-resident (launched with hipLaunchCooperativeKernel, grid <= CU count).
-// Cross-workgroup data (h_t forward, the gate deltas backward) travels by device-scope (sc1) stores and
-// loads, so the barrier itself needs no cache maintenance: drain the stores, one relaxed agent-scope
-// ticket, relaxed polling (guide: "in-launch hand-off", sc1 variant).  The poll loop carries a watchdog:
-// a workgroup that waits longer than ~seconds raises sync[1] and every workgroup leaves, so a scheduling
-// accident surfaces as an error instead of a hung GPU.
-struct CoopLds {
-  int weights, red, loff, flag, words;
-};
-// nrows weight rows resident per workgroup, ncols = columns of its partial tile
-inline __host__ __device__ CoopLds coop_lds_layout(int kp, int nrows, int ncols, int bs) {
-  CoopLds l;
-  int o = 0;
-  l.weights = o; o += nrows * (kp + WIDE_WPAD);
-  l.red = o;     o += WIDE_NW * 16 * (ncols + 4);
-  l.loff = o;    o += ((bs + 1 + 3) / 4) * 4;
-  l.flag = o;    o += 4;
-  l.words = o;
-  return l;
-}
-// weight rows [row0, row0 + nrows) of the packed array (rows >= rows_total read as zero) and the line
-// offsets, once per launch
-DEVFN void coop_stage(const LstmWideArgs& a, const float* wbase, long long row0, long long rows_total, int nrows,
-                      float* wl, int* loff) {
-  const int tid = threadIdx.x;
-  const int k4 = a.kp >> 2;
-  for (int i = tid; i < nrows * k4; i += WIDE_THREADS) {
-    const int row = i / k4, c4 = i - row * k4;
-    f32x4 v;
-#pragma unroll
-    for (int q = 0; q < 4; q++) v[q] = 0.0f;
-    if (row0 + row < rows_total) v = *reinterpret_cast<const f32x4*>(wbase + (size_t)(row0 + row) * a.kp + c4 * 4);
-    *reinterpret_cast<f32x4*>(wl + row * (a.kp + WIDE_WPAD) + c4 * 4) = v;
-  }
-  for (int i = tid; i <= a.bs; i += WIDE_THREADS) loff[i] = a.line_off[i];
-  __syncthreads();
-}
-
-// Cooperative forward tile: 16 lines x (16 cells x 4 gates).  Compared with the per-step kernel's
-// 64 lines x 4 cells it quarters the h_{t-1} bytes a workgroup pulls per step (32 KB at no = 512) --
-// those come at the cross-XCD per-workgroup rate -- and instead keeps 64 weight rows (132 KB) in LDS.
-DEVFN void coop_fwd_tile(const LstmWideArgs& a, const int sg, const int ct, const int dir, const int zb,
-                         const int* loff, const float* wl, float* red) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int no = a.no, nd = a.ndir;
-  unsigned arow[1];
-  {
-    const int m = zb * 16 + (lane & 15);
-    arow[0] = BUF_OOB_BASE;
-    if (m < a.bs) {
-      const int off = loff[m], T = loff[m + 1] - off;
-      if (sg >= 1 && sg < T) {
-        const int fprev = dir == 0 ? sg - 1 : T - sg;   // frame of own step s-1
-        arow[0] = (unsigned)((long long)(off + fprev) * a.ldh + a.hofs + dir * no) * 4u;
-      }
-    }
-  }
-  const BufF32 abuf = make_buf(a.H, (size_t)a.N * a.ldh * 4);
-  const int ml = tid >> 4, c16 = tid & 15;
-  const int line = zb * 16 + ml, cell = ct * 16 + c16;
-  bool live = ml < 16 && line < a.bs && cell < no;
-  int off = 0, T = 0;
-  if (live) {
-    off = loff[line];
-    T = loff[line + 1] - off;
-    live = sg < T;
-  }
-  const long long n = off + (dir == 0 ? sg : T - 1 - sg);
-  const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
-  const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
-  const f32x4 gx = buf_load4(gbuf, live ? (unsigned)(((n * nd + dir) * no + cell) * 16) : BUF_OOB);
-  const float c_prev = buf_load(cbuf, live && sg >= 1    // own write of the previous step
-      ? (unsigned)((((long long)(off + (dir == 0 ? sg - 1 : T - sg)) * nd + dir) * no + cell) * 4) : BUF_OOB);
-
-  wide_tile<1, 4, true>(abuf, arow, abuf, 0u, wl, a.kp, red);
-  __syncthreads();
-
-  if (live) {
-    f32x4 k;
-#pragma unroll
-    for (int q = 0; q < 4; q++) k[q] = 0.0f;
-#pragma unroll
-    for (int w = 0; w < WIDE_NW; w++) {   // columns of cell c16: cell group c16>>2, slot (c16&3)*4 + gate
-      const f32x4 p = *reinterpret_cast<const f32x4*>(&red[(w * 16 + ml) * 68 + c16 * 4]);
-#pragma unroll
-      for (int q = 0; q < 4; q++) k[q] += p[q];
-    }
-    const float gi = gate_act(k[0] + gx[0], false), gf = gate_act(k[1] + gx[1], false),
-                go = gate_act(k[2] + gx[2], false), ci = gate_act(k[3] + gx[3], true);
-    const float c = ci * gi + gf * c_prev;
-    const float h = gate_act(c, true) * go;
-    f32x4 act;
-    act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
-    *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
-    a.C[(n * nd + dir) * no + cell] = c;
-    buf_store_dev(abuf, (unsigned)(n * a.ldh + a.hofs + dir * no + cell) * 4u, h);   // next step's A operand
-    float* srow = a.S + (size_t)dir * a.sdir;
-    if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;                      // h_{-1} = 0
-    if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
-  }
-}
-
-// grid (ceil(no/16), ndir, zsplit), 256 threads; workgroup z walks line blocks z, z + zsplit, ...
-__global__ __launch_bounds__(WIDE_THREADS) void lstm_coop_fwd(LstmWideArgs a) {
-  float* smem = dyn_smem<float>();
-  const CoopLds L = coop_lds_layout(a.kp, 64, 64, a.bs);
-  float* wl = smem + L.weights;
-  float* red = smem + L.red;
-  int* loff = reinterpret_cast<int*>(smem + L.loff);
-  const int ct = blockIdx.x, dir = blockIdx.y;
-  const int ncg = (a.no + 3) >> 2;
-  // packed rows of cell groups 4ct .. 4ct+3 of this direction (16 rows each: cell_local*4 + gate)
-  coop_stage(a, a.Rw + (size_t)dir * ncg * 16 * a.kp, (long long)ct * 64, (long long)ncg * 16, 64, wl, loff);
-  const int nzb = (a.bs + 15) / 16;
-  const int nwg = gridDim.x * gridDim.y * gridDim.z;
-  for (int sg = 0; sg < a.tmax; sg++) {
-    for (int zb = blockIdx.z; zb < nzb; zb += gridDim.z) {
-      coop_fwd_tile(a, sg, ct, dir, zb, loff, wl, red);
-      if (zb + (int)gridDim.z < nzb) __syncthreads();   // partial tiles are reused by the next line block
-    }
-    if (sg + 1 < a.tmax && !grid_barrier(a.sync, (sg + 1) * nwg, reinterpret_cast<int*>(smem + L.flag))) return;
-  }
-}
-
-// grid (ceil(no/16), ndir, zsplit), 256 threads; workgroup z walks line blocks z, z + zsplit, ...
-__global__ __launch_bounds__(WIDE_THREADS) void lstm_coop_bwd(LstmWideArgs a) {
-  float* smem = dyn_smem<float>();
-  const CoopLds L = coop_lds_layout(a.kp, 16, 16, a.bs);
-  float* wl = smem + L.weights;
-  float* red = smem + L.red;
-  int* loff = reinterpret_cast<int*>(smem + L.loff);
-  const int ct = blockIdx.x, dir = blockIdx.y;
-  const int nct = (a.no + 15) >> 4;
-  coop_stage(a, a.Rw + (size_t)dir * nct * 16 * a.kp, (long long)ct * 16, (long long)nct * 16, 16, wl, loff);
-  const int nzb = (a.bs + 15) / 16;
-  const int nwg = gridDim.x * gridDim.y * gridDim.z;
-  for (int sg = 0; sg < a.tmax; sg++) {
-    for (int zb = blockIdx.z; zb < nzb; zb += gridDim.z) {
-      wide_bwd_tile<true>(a, sg, ct, dir, zb, loff, wl, red);
-      if (zb + (int)gridDim.z < nzb) __syncthreads();
-    }
-    if (sg + 1 < a.tmax && !grid_barrier(a.sync, (sg + 1) * nwg, reinterpret_cast<int*>(smem + L.flag))) return;
-  }
+  wide_bwd_tile(a, a.step, blockIdx.x, blockIdx.y, blockIdx.z, a.line_off, red);
 }
 
 // ---- persistent forward recurrence, bf16 operands, one workgroup GROUP per XCD -------------------------------------------
@@ -819,20 +607,15 @@ DEVFN bool xcd_poll(int* word, int target, int* err, int* lds_flag, int code) {
   return ok;
 }
 
-// The per-step group barrier as STAMPS instead of a counter (CLSTM_XCD_STAMPS, default): an atomic arrival leaves the L2
-// (its line is dropped: the pollers' next look goes to memory, ~1 us); a plain store of "my tile has finished step s" into
-// the group's own 128-byte line stays in the XCD's L2, and the poller's lanes read all tiles' stamps with one L1-bypassing
-// load each.
-#ifndef CLSTM_XCD_STAMPS
-#define CLSTM_XCD_STAMPS 1
-#endif
+// The per-step group barrier is made of STAMPS, not a counter: an atomic arrival leaves the L2 (its line is dropped: the
+// pollers' next look goes to memory, ~1 us; measured 8.35 vs 7.6 ms per configs[4] minibatch); a plain store of "my tile
+// has finished step s" into the group's own 128-byte line stays in the XCD's L2, and the poller's lanes read all tiles'
+// stamps with one L1-bypassing load each.
 DEVFN void xcd_arrive(int* gwords, const int tile, const int step_done) {   // called by thread 0 behind drain + barrier
-  if (CLSTM_XCD_STAMPS) __hip_atomic_store(gwords + tile, step_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  else __hip_atomic_fetch_add(gwords, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(gwords + tile, step_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // every tile of the group has finished `steps_done` steps
 DEVFN bool xcd_wait_group(int* gwords, const int ntile, const int steps_done, int* err, int* lds_flag) {
-  if (!CLSTM_XCD_STAMPS) return xcd_poll(gwords, ntile * steps_done, err, lds_flag, 2);
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     int spins = 0, bad = 0;
@@ -855,19 +638,31 @@ DEVFN bool xcd_wait_group(int* gwords, const int ntile, const int steps_done, in
   return ok;
 }
 
-// LL = 1 (EXPERIMENT, CLSTM_XCD_LL=1; measured slower than the stamp barrier, see profiles/README.md) -- "flag in data",
-// the low-latency protocol of collective libraries: every 8-byte unit of the h ring carries
-// two bf16 cells AND a 32-bit tag (launch epoch << 12 | step); a consumer needs no barrier -- it loads the ring rows it is
-// going to multiply and checks the tags of what arrived, re-loading until every unit carries the tag of the step it waits
-// for.  An aligned 8-byte store is one L2 write, so a unit is never seen half-written.  Compared with the stamp barrier
-// (store, wait for the L2's acknowledgement, workgroup barrier, stamp store, poll, THEN load) the dependent chain between
-// two steps is one store and one load.  The ring doubles (8 bytes per cell pair); a slot is rewritten two steps later,
-// which a producer can only reach after it has consumed everybody's data of the step in between (so every consumer of
-// the old contents is done), and the epoch keeps a previous launch's units from matching.
-#ifndef CLSTM_LL_POLICY   // (diagnostics) cache policy of the tagged ring: 1 system-scope loads, 2 + system-scope stores
-#define CLSTM_LL_POLICY 0
-#endif
-template <bool LL>
+// role assignment + placement check shared by the persistent kernels; returns false if this workgroup has nothing to do (or the
+// launch is being abandoned)
+DEVFN bool xcd_claim(int* sync, int* flag, const int ntile, const int ngroups, int& xcd, int& slot) {
+  const int tid = threadIdx.x;
+  xcd = hw_xcc_id() & 7;
+  if (tid == 0) {
+    flag[1] = __hip_atomic_fetch_add(sync + XcdSyncLayout::SLOT0 + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(sync + XcdSyncLayout::ARRIVED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  slot = flag[1];
+  if (!xcd_poll(sync + XcdSyncLayout::ARRIVED, (int)gridDim.x, sync + XcdSyncLayout::ERROR, flag, 1)) return false;
+  if (tid == 0) {
+    int bad = 0;
+    for (int g = 0; g < ngroups; g++)
+      bad |= __hip_atomic_load(sync + XcdSyncLayout::SLOT0 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile;
+    if (bad) __hip_atomic_store(sync + XcdSyncLayout::ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag[0] = bad;
+  }
+  __syncthreads();
+  const bool ok = flag[0] == 0;
+  __syncthreads();
+  return ok && xcd < ngroups && slot < ntile;
+}
+
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a) {
   unsigned short* wl = dyn_smem<unsigned short>();                         // [64][XCD_LDW]
   float* red = reinterpret_cast<float*>(wl + 64 * XCD_LDW);                // [4][16][68]
@@ -877,24 +672,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   const int ntile = (no + 15) >> 4, nzb = a.zbn, ngroups = nd * nzb, ncg = (no + 3) >> 2;
   int* const sync = a.sync;
   // ---- claim a tile of this XCD's group, then check the placement of the whole grid ----
-  const int xcd = hw_xcc_id() & 7;
-  if (tid == 0) {
-    flag[1] = __hip_atomic_fetch_add(sync + XcdSyncLayout::SLOT0 + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(sync + XcdSyncLayout::ARRIVED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  const int ct = flag[1];
-  if (!xcd_poll(sync + XcdSyncLayout::ARRIVED, (int)gridDim.x, sync + XcdSyncLayout::ERROR, flag, 1)) return;
-  if (tid == 0) {
-    int bad = 0;
-    for (int g = 0; g < ngroups; g++)
-      bad |= __hip_atomic_load(sync + XcdSyncLayout::SLOT0 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile;
-    if (bad) __hip_atomic_store(sync + XcdSyncLayout::ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    flag[0] = bad;
-  }
-  __syncthreads();
-  if (flag[0] != 0) return;                       // uneven placement: nothing has been written yet
-  if (xcd >= ngroups || ct >= ntile) return;      // spare workgroup
+  int xcd, ct;
+  if (!xcd_claim(sync, flag, ntile, ngroups, xcd, ct)) return;   // (uneven placement: nothing has been written yet)
   const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
   int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
 
@@ -918,14 +697,12 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   if (line < a.bs) { off = a.line_off[line]; T = a.line_off[line + 1] - off; }
   const bool mine = line < a.bs && cell < no;
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
-  const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
-  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * a.bs * a.kp16 * (LL ? 4 : 2));
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * a.bs * a.kp16 * 2);
   // A fragment of this lane: line zb*16 + (lane&15), 8 k at wave*kw + 32 g + 8 (lane>>4)
   const int kw = a.kp16 / WIDE_NW, ngrp = kw >> 5;   // <= 4 groups of 32 per wave
   const int am = zb * 16 + (lane & 15);
-  const unsigned akl = (unsigned)(wave * kw + 8 * (lane >> 4)) * (LL ? 4u : 2u);   // (tagged ring: 4 bytes per cell)
+  const unsigned akl = (unsigned)(wave * kw + 8 * (lane >> 4)) * 2u;
   const unsigned short* wfrag = wl + (lane & 15) * XCD_LDW + wave * kw + 8 * (lane >> 4);
-  const int kprod = ntile * 16;   // cells that have a producer (the rest of kp16 is padding nobody writes)
   __syncthreads();
 
   // The gate pre-activations of step s come from HBM (~2 us) and VMEM returns in order: requested at the top of step s
@@ -940,34 +717,24 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   float c_prev = 0.0f;
   // the per-frame outputs of one step (nobody inside the pass reads them)
   auto store_frame = [&](const f32x4 act, const float c_new, const float h, const unsigned hp, const long long n, const int sg, const bool live) {
-    if (live && !(CLSTM_WEXP & 256)) {
+    if (live) {
       *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
-    }
-    if (live && !(CLSTM_WEXP & 256) && !((CLSTM_WEXP & 512) && (c16 & 3))) {
       a.C[(n * nd + dir) * no + cell] = c_new;
       a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
-      if (!(CLSTM_WEXP & 64)) {
       float* srow = a.S + (size_t)dir * a.sdir;
       if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
       if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
-      }
     }
     if (live && !(c16 & 1)) {
-      if constexpr (!LL) *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) = hp;
-      if (a.Hbf && !(CLSTM_WEXP & 256)) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
-      if (a.Sbf && !(CLSTM_WEXP & 256)) {   // h_{t-1} column block of the next frame's bf16 source row (weight-gradient operand, gemm_b16mc)
+      *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) = hp;
+      if (a.Hbf) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
+      if (a.Sbf) {   // h_{t-1} column block of the next frame's bf16 source row (weight-gradient operand, gemm_b16mc)
         unsigned short* sb = a.Sbf + (size_t)dir * a.sbf_dir + a.sbf_ofs + cell;
         if (sg == 0) *reinterpret_cast<unsigned*>(sb + (size_t)n * a.sbf_ld) = 0u;
         if (sg + 1 < T) *reinterpret_cast<unsigned*>(sb + (size_t)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.sbf_ld) = hp;
       }
     }
   };
-  f32x4 fr_act = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  float fr_c = 0.0f, fr_h = 0.0f;
-  unsigned fr_hp = 0u;
-  long long fr_n = 0;
-  int fr_sg = 0;
-  bool fr_live = false;
   for (int sg = 0; sg < a.tmax; sg++) {
     const bool live = mine && sg < T;
     const long long n = off + (dir == 0 ? sg : T - 1 - sg);
@@ -977,75 +744,6 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
 #pragma unroll
       for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
     f32x4 gx_next;
-    if constexpr (LL) {
-      // ---- tagged ring: load, check, re-load until every unit this lane multiplies carries this step's tag ----
-      const unsigned want = (a.epoch << 12) | (unsigned)sg;
-      const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 4u + akl : BUF_OOB_BASE;
-      const int kl = wave * kw + 8 * (lane >> 4);
-      U32x4 ra[4][2];
-      int spins = 0;
-      bool first = true;
-      for (;;) {
-        COMPILER_MEMORY_BARRIER();   // the loads below must be re-issued every round (nothing in the loop writes that memory as far as the compiler can see)
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-#pragma unroll
-          for (int hh = 0; hh < 2; hh++) ra[g][hh] = buf_load4u_dev(abuf, g < ngrp ? arow + (unsigned)g * 128u + (unsigned)hh * 16u : BUF_OOB);
-        SCHED_FENCE();
-        if (first) { gx_next = gx_load(sg + 1); store_frame(fr_act, fr_c, fr_h, fr_hp, fr_n, fr_sg, fr_live); first = false; }
-        SCHED_FENCE();
-        unsigned miss = 0u;
-        if (sg >= 1 && am < a.bs) {
-#pragma unroll
-          for (int g = 0; g < 4; g++)
-#pragma unroll
-            for (int hh = 0; hh < 2; hh++)
-#pragma unroll
-              for (int e = 0; e < 2; e++)
-                if (g < ngrp && kl + 32 * g + 4 * hh + 2 * e < kprod) miss |= ra[g][hh].v[2 * e + 1] ^ want;
-        }
-        if (wave_ballot(miss != 0u) == 0ull) break;
-        // Not all there yet.  Re-loading the whole operand (8 KB per wave and round, every wave of every workgroup) floods
-        // the L2 -- measured 3.0 us per step against 2.0 with the stamp barrier -- so wait on SAMPLES instead: one unit of
-        // every producer store instruction this wave depends on (its 8 tiles x the 4 producer waves = 32 lanes, 16 bytes
-        // each), and re-load the operand when they all carry the tag.
-        {
-          const int tl = ((wave * kw) >> 4) + (lane >> 2), sl = zb * 16 + 4 * (lane & 3);
-          const bool sv = lane < 32 && (lane >> 2) < (kw >> 4) && sl < a.bs && tl * 16 < kprod;
-          const unsigned soff = sv ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + sl) * a.kp16) * 4u + (unsigned)tl * 64u : BUF_OOB;
-          bool abandon = false;
-          for (;;) {
-            COMPILER_MEMORY_BARRIER();
-            const U32x4 sm = buf_load4u_dev(abuf, soff);
-            if (wave_ballot(sv && sm.v[1] != want) == 0ull) break;
-            poll_pause();
-            if ((++spins & 63) == 0) {
-              int bad = __hip_atomic_load(sync + XcdSyncLayout::ERROR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (!bad && spins > GRID_WATCHDOG_SPINS) {
-                bad = 2;
-                if (lane == 0) {   // diagnostics for the host's error message (sync words 2..6)
-                  sync[2] = sg; sync[3] = (int)sm.v[1]; sync[4] = (int)want; sync[5] = (wave << 16) | lane; sync[6] = (xcd << 8) | ct;
-                  __hip_atomic_store(sync + XcdSyncLayout::ERROR, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-              }
-              if (wave_uniform(bad)) { abandon = true; break; }
-            }
-          }
-          if (abandon) break;   // abandoned launch: run to the end on whatever is there, the host reports the error
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        if (g < ngrp) {
-          U32x4 d;
-          d.v[0] = ra[g][0].v[0]; d.v[1] = ra[g][0].v[2]; d.v[2] = ra[g][1].v[0]; d.v[3] = ra[g][1].v[2];
-          const u16x8 av = __builtin_bit_cast(u16x8, d);
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            acc[j] = mfma16x16x32_bf16(av, *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDW + g * 32), acc[j]);
-        }
-      }
-    } else {
     if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;   // h_{s-1} of the whole group is in the L2
     // ---- 16 lines x 64 columns, split-K over the four waves ----
     const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 2u + akl : BUF_OOB_BASE;
@@ -1064,14 +762,13 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
           acc[j] = mfma16x16x32_bf16(av, *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDW + g * 32), acc[j]);
       }
     }
-    }
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * 68 + j * 16 + (lane & 15)] = acc[j][q];
     __syncthreads();
     float h = 0.0f, c_new = 0.0f;
-    f32x4 act;
+    f32x4 act = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (live) {
       f32x4 k;
 #pragma unroll
@@ -1090,50 +787,31 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
     }
     const float hn = quad_xor1(h);
     const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);   // (h = 0 for a line that has ended)
-    if constexpr (LL) {   // every line of the block publishes every step (a finished line: zeros), or its consumers would wait
-      if (line < a.bs && !(c16 & 1)) {
-        // (workgroup-scope store, sc0, like the stamps of the barrier variant)
-        const unsigned long long unit = (unsigned long long)hp | ((unsigned long long)((a.epoch << 12) | (unsigned)(sg + 1)) << 32);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.Hb) + ((((size_t)((sg & 1) * nd + dir) * a.bs + line) * (a.kp16 >> 1)) + (cell >> 1)),
-                           unit, __ATOMIC_RELAXED, CLSTM_LL_POLICY >= 2 ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      // the per-frame outputs wait in registers until the next step's operand loads have been issued (store_frame in the
-      // wait loop above): the VMEM counter is in order, so a load issued behind them would also wait for THEIR acknowledgements
-      fr_act = act; fr_c = c_new; fr_h = h; fr_hp = hp; fr_n = n; fr_sg = sg; fr_live = live;
-    } else {
-      store_frame(act, c_new, h, hp, n, sg, live);
-    }
+    store_frame(act, c_new, h, hp, n, sg, live);
     // publish: every store of this workgroup acknowledged by the L2, then one arrival on the group's counter.  (Storing
     // the bf16 h first and the other arrays behind the arrival was measured SLOWER, 3.5 vs 3.2 us per step: VMEM
     // completes in order, so the next step's operand loads then wait behind those stores.)
     c_prev = c_new;
     gx = gx_next;
-    if constexpr (LL) {
-      __syncthreads();   // (the reduction buffer is rewritten by the next step)
-    } else {
     drain_vmem();
     __syncthreads();
     if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
-    }
   }
-  if constexpr (LL) store_frame(fr_act, fr_c, fr_h, fr_hp, fr_n, fr_sg, fr_live);   // the last step's outputs
 }
 
 // ---- persistent backward recurrence, same scheme: 16 lines x 16 cells per workgroup, its 16 weight rows (R^T, 2048 k)
 // resident in LDS, the group's bf16 delta ring exchanged through the XCD's L2, the carried state delta in a register ----
 constexpr int XCD_LDWB = 2048 + 8;      // halfs per resident weight row of the backward tile, kp16 <= 2048
-// NT: 16-cell tiles per workgroup.  Every workgroup of a group reads the group's WHOLE delta ring row block (16 lines x
-// 2048 k x 2 B = 64 KB) each step, so the step is bound by that L2's bandwidth (32 workgroups: 2 MB per step; the
-// forward kernel moves 0.5 MB and runs 2.9 us per step against 4.3): with two tiles per workgroup a group has 16
-// workgroups, half the traffic, and twice the MFMA work per wave (still < 0.3 us).
-template <int NT>
+// Every workgroup of a group reads the group's WHOLE delta ring row block (16 lines x 2048 k x 2 B = 64 KB) each step
+// (two 16-cell tiles per workgroup -- half that traffic per L2 -- was measured no faster: 7.51 vs 6.99 ms per minibatch).
 inline __host__ __device__ int xcd_bwd_lds_bytes() {
+  constexpr int NT = 1;
   const int need = NT * 16 * XCD_LDWB * 2 + WIDE_NW * 16 * (NT * 16 + 4) * 4 + 64;
   return need > 84 * 1024 ? need : 84 * 1024;   // > 80 KB: one workgroup per CU, whatever the tile needs
 }
 
-template <int NT>
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a) {
+  constexpr int NT = 1;   // 16-cell tiles per workgroup
   constexpr int LDR = NT * 16 + 4;
   unsigned short* wl = dyn_smem<unsigned short>();                         // [NT*16][XCD_LDWB]
   float* red = reinterpret_cast<float*>(wl + NT * 16 * XCD_LDWB);          // [4][16][LDR]
@@ -1142,24 +820,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
   const int no = a.no, nd = a.ndir;
   const int ntile = (no + 15) >> 4, ntile2 = (ntile + NT - 1) / NT, nzb = a.zbn, ngroups = nd * nzb;
   int* const sync = a.sync;
-  const int xcd = hw_xcc_id() & 7;
-  if (tid == 0) {
-    flag[1] = __hip_atomic_fetch_add(sync + XcdSyncLayout::SLOT0 + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(sync + XcdSyncLayout::ARRIVED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  const int slot = flag[1];
-  if (!xcd_poll(sync + XcdSyncLayout::ARRIVED, (int)gridDim.x, sync + XcdSyncLayout::ERROR, flag, 1)) return;
-  if (tid == 0) {
-    int bad = 0;
-    for (int g = 0; g < ngroups; g++)
-      bad |= __hip_atomic_load(sync + XcdSyncLayout::SLOT0 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile2;
-    if (bad) __hip_atomic_store(sync + XcdSyncLayout::ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    flag[0] = bad;
-  }
-  __syncthreads();
-  if (flag[0] != 0) return;
-  if (xcd >= ngroups || slot >= ntile2) return;
+  int xcd, slot;
+  if (!xcd_claim(sync, flag, ntile2, ngroups, xcd, slot)) return;
   const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
   int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
   {
@@ -1307,31 +969,6 @@ inline __host__ __device__ int xcd_fwd_f32_lds_bytes(int kp) { return (64 * (kp 
 inline __host__ __device__ int xcd_bwd_f32_lds_bytes(int kp) {
   const int need = (16 * (kp + WIDE_WPAD) + WIDE_NW * 16 * WIDE_LDW + 16) * 4;
   return need > 84 * 1024 ? need : 84 * 1024;
-}
-
-// role assignment + placement check shared by the f32 kernels; returns false if this workgroup has nothing to do (or the
-// launch is being abandoned)
-DEVFN bool xcd_claim(int* sync, int* flag, const int ntile, const int ngroups, int& xcd, int& slot) {
-  const int tid = threadIdx.x;
-  xcd = hw_xcc_id() & 7;
-  if (tid == 0) {
-    flag[1] = __hip_atomic_fetch_add(sync + XcdSyncLayout::SLOT0 + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(sync + XcdSyncLayout::ARRIVED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  slot = flag[1];
-  if (!xcd_poll(sync + XcdSyncLayout::ARRIVED, (int)gridDim.x, sync + XcdSyncLayout::ERROR, flag, 1)) return false;
-  if (tid == 0) {
-    int bad = 0;
-    for (int g = 0; g < ngroups; g++)
-      bad |= __hip_atomic_load(sync + XcdSyncLayout::SLOT0 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile;
-    if (bad) __hip_atomic_store(sync + XcdSyncLayout::ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    flag[0] = bad;
-  }
-  __syncthreads();
-  const bool ok = flag[0] == 0;
-  __syncthreads();
-  return ok && xcd < ngroups && slot < ntile;
 }
 
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a) {

@@ -13,13 +13,7 @@
 
 namespace clstm {
 
-#ifndef CLSTM_SMX_PF
-#define CLSTM_SMX_PF 3
-#endif
-constexpr int SMX_PF = CLSTM_SMX_PF;   // k-tiles in flight in registers
-#ifndef CLSTM_SEXP   // perf experiments only (results wrong)
-#define CLSTM_SEXP 0
-#endif
+constexpr int SMX_PF = 3;   // k-tiles in flight in registers
 constexpr int SMX_COLS = 96;   // classes per workgroup (6 MFMA column tiles)
 constexpr int SMX_LDB = 112;   // LDS row stride of the weight tile (112 mod 32 = 16, see gemm_mfma.h)
 
@@ -51,7 +45,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const f
 
   f32x4 ra[SMX_PF], rb0[SMX_PF], rb1[SMX_PF];
   auto load_tile = [&](int k0, f32x4& a, f32x4& b0, f32x4& b1) {
-    const bool live = k0 < K && !(CLSTM_SEXP & 1);
+    const bool live = k0 < K;
     a = buf_load4(abuf, live ? (a_base + (unsigned)k0) * 4u : BUF_OOB);
     b0 = buf_load4(bbuf, live ? ((unsigned)nc * (1 + k0 + b_k0) + b_c0) * 4u : BUF_OOB);
     b1 = buf_load4(bbuf, live && b_second ? ((unsigned)nc * (1 + k0 + b_k1) + b_c1) * 4u : BUF_OOB);
@@ -84,19 +78,18 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const f
         *reinterpret_cast<f32x4*>(&Bs[b_k0 * SMX_LDB + b_c0]) = v0;
         if (b_second) *reinterpret_cast<f32x4*>(&Bs[b_k1 * SMX_LDB + b_c1]) = v1;
       }
-      if (!(CLSTM_SEXP & 8)) __syncthreads();
+      __syncthreads();
       load_tile(k0 + SMX_PF * GEMM_BK, ra[p], rb0[p], rb1[p]);
       SCHED_FENCE();
 #pragma unroll
       for (int kk = 0; kk < GEMM_BK; kk += 4) {
         const float af = As[(kk + fk) * GEMM_LD + wave * 16 + fi];
 #pragma unroll
-        for (int j = 0; j < 6; j++) if (!(CLSTM_SEXP & 2) || j == 0) acc[j] = mfma16x16x4(af, Bs[(kk + fk) * SMX_LDB + j * 16 + fi], acc[j]);
+        for (int j = 0; j < 6; j++) acc[j] = mfma16x16x4(af, Bs[(kk + fk) * SMX_LDB + j * 16 + fi], acc[j]);
       }
       __syncthreads();
     }
   }
-  if ((CLSTM_SEXP & 4) && acc[0][0] != 12345.6f) return;
   // epilogue: lane holds rows (lane>>4)*4 + q and columns j*16 + (lane&15); a row's 96 columns sit in the
   // 16 lanes of one row group.  (The six biases of a lane were requested before the k loop: read inside this loop
   // they were 24 dependent L1 round trips -- the epilogue took 6.8 of the kernel's 21 us.)

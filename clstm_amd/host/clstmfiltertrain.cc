@@ -89,10 +89,6 @@ static int main1(int argc, char** argv) {
       clstm.model.attr["trial"] = std::to_string(trial);
       clstm.save(fname);
     }
-    if (samples[sample].out.size() > 1023) {   // the CTC kernel holds at most 2048 target states (2L+1) per line
-      std::cerr << "skipping sample " << sample << ": target of " << samples[sample].out.size() << " characters" << std::endl;
-      continue;
-    }
     ustring pred = clstm.train(samples[sample].in, samples[sample].out);
     if (trial % report_every == 0) {
       std::cout << "trial " << trial << std::endl;

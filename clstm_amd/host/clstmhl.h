@@ -5,6 +5,7 @@
 // runs on the MI355X.
 #pragma once
 #include "model.h"
+#include <future>
 #include <thread>
 #include "normalizer.h"
 #include "png_io.h"

@@ -75,47 +75,42 @@ static int main1(int argc, char** argv) {
   save_trigger.enable(save_name != "").skip0();
   Trigger report_trigger(getienv("report_every", 100), ntrain, start);
   const int batch = std::max(1, getienv("batch", 1));
-  // minibatch pipeline: `next` is read + normalised by a helper thread while the device trains on `cur`
+  // one training sample (clstmocrtrain.cc:160-166: `lrand48() % size`, readSample)
+  auto draw_one = [&](Image& raw, ustring& gt) {
+    const int sample = lrand48() % trainingset.size();
+    trainingset.readSample(raw, gt, sample);
+  };
+  // minibatch pipeline: `next` is read + normalised by a helper task while the device trains on `cur`.  The task is a
+  // std::future: an exception inside it (a missing file, a character outside the codec) is re-thrown by get() on the
+  // main thread, and if train_batch throws while the task is still running the future's destructor waits for it --
+  // either way the process ends through main()'s "FATAL: ..." handler with exit code 1, never through std::terminate.
   auto draw = [&](CLSTMOCR::Prepared& p) {
-    vector<Image> raws;
-    vector<ustring> gts;
-    while ((int)raws.size() < batch) {
-      int sample = lrand48() % trainingset.size();
-      Image raw;
-      ustring gt;
-      trainingset.readSample(raw, gt, sample);
-      if (gt.size() > 1023) {   // the CTC kernel holds at most 2048 target states (2L+1) per line
-        std::cerr << "skipping " << trainingset.fnames[sample] << ": transcript of " << gt.size() << " characters" << std::endl;
-        continue;
-      }
-      raws.push_back(std::move(raw));
-      gts.push_back(std::move(gt));
-    }
+    vector<Image> raws(batch);
+    vector<ustring> gts(batch);
+    for (int i = 0; i < batch; i++) draw_one(raws[i], gts[i]);
     clstm.prepare(p, raws, gts);
   };
   CLSTMOCR::Prepared cur, next;
-  std::thread helper;
+  std::future<void> helper;
   if (batch > 1) draw(next);
   for (int trial = start; trial < ntrain; trial += batch) {
+    // the last trial this update covers: the triggers look at it, so that the end-of-run save / test fire for any
+    // batch size (Trigger fires for good at count >= upto - 1; with batch = 8 and ntrain = 1000 the loop ends at 992)
+    const int tend = std::min(trial + batch - 1, ntrain - 1);
     ustring gt, pred;
     if (batch == 1) {   // the reference's loop, sample for sample
-      int sample = lrand48() % trainingset.size();
       Image raw;
-      trainingset.readSample(raw, gt, sample);
-      if (gt.size() > 1023) {
-        std::cerr << "skipping " << trainingset.fnames[sample] << ": transcript of " << gt.size() << " characters" << std::endl;
-        continue;
-      }
+      draw_one(raw, gt);
       pred = clstm.train(raw, gt);
     } else {
       std::swap(cur, next);
-      if (trial + batch < ntrain) helper = std::thread([&] { draw(next); });
+      if (trial + batch < ntrain) helper = std::async(std::launch::async, [&] { draw(next); });
       vector<ustring> preds = clstm.train_batch(cur);
-      if (helper.joinable()) helper.join();
+      if (helper.valid()) helper.get();
       gt = cur.targets.back();
       pred = preds.back();
     }
-    if (report_trigger(trial)) {
+    if (report_trigger(tend)) {
       std::cout << trial << std::endl;
       std::cout << "TRU " << utf32_to_utf8(gt) << std::endl;
       std::cout << "ALN " << clstm.aligned_utf8() << std::endl;
@@ -123,7 +118,7 @@ static int main1(int argc, char** argv) {
       if (trial > 0 && report_time) std::cout << "steptime " << (now() - start_time) / report_trigger.since() << std::endl;
       start_time = now();
     }
-    if (test_trigger(trial) && testset.size() > 0) {
+    if (test_trigger(tend) && testset.size() > 0) {
       double count = 0.0, errors = 0.0;
       for (int test = 0; test < testset.size(); test++) {
         Image traw;
@@ -139,14 +134,14 @@ static int main1(int argc, char** argv) {
         best_error = test_error;
         string fname = save_name + ".clstm";
         std::cout << "saving best performing network so far " << fname << " error rate:  " << best_error << std::endl;
-        clstm.model.attr["trial"] = std::to_string(trial);
+        clstm.model.attr["trial"] = std::to_string(tend);   // resume continues behind the last sample consumed
         clstm.save(fname);
       }
     }
-    if (save_trigger(trial) && save_trigger.enabled) {
+    if (save_trigger(tend) && save_trigger.enabled) {
       string fname = save_name + "-" + std::to_string(trial) + ".clstm";
       std::cout << "saving " << fname << std::endl;
-      clstm.model.attr["trial"] = std::to_string(trial);
+      clstm.model.attr["trial"] = std::to_string(tend);
       clstm.save(fname);
     }
   }

@@ -218,7 +218,7 @@ int clstm_net_train_step(clstm_net* net, const int* T_h, int bs, const float* x_
 
 /* State externalisation: n_states / get_states / set_states (clstm.cc:762-811; upstream test
  * test-lstm2.cc:79-142).  The reference walks every `Sequence` state of every layer (walk_states,
- * clstm.cc:64-67: per NPLSTM the std::map order ci, gf, gi, go, out, source, state, then the layer's
+ * clstm.cc:64-67: per NPLSTM the std::map order ci, gf, gi, go, source, state, then the layer's
  * inputs/outputs are NOT states) and copies the .v planes.  Here: the same order and contents for the
  * current minibatch, per layer: forward NPLSTM then the NPLSTM inside Reversed (in ITS time order, i.e.
  * frame T-1-t at its step t), each state as [T][rows][bs] flattened exactly as Sequence::v would be for a

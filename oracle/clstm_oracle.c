@@ -673,6 +673,83 @@ static void backward_reverse(Seq *y, Seq *x) {
   }
 }
 
+/* ------------------------------------------------------------------------- */
+/* 2-D plumbing operators on raw Sequence blocks (feature, batch, {v,d}, time), */
+/* batches.h:79-86: element (i, b, p, t) of a (n, m, 2, N) block at               */
+/* i + n*(b + m*(p + 2*t)).                                                       */
+/* ------------------------------------------------------------------------- */
+#define SEQ_AT(ptr, n, m, i, b, p, t) ((ptr)[(size_t)(i) + (size_t)(n) * ((size_t)(b) + (size_t)(m) * ((size_t)(p) + 2 * (size_t)(t)))])
+/* forward_btswitch (clstm_compute.cc:425-436): y4.chip(0,2) = x4.chip(0,2).shuffle({0,2,1}).
+ * x dims (rows, bs, 2, N) -> y dims (rows, N, 2, bs); chip(0,2) is the VALUE plane, shuffle
+ * {0,2,1} makes output axis 1 the input's axis 2 (time) and output axis 2 the input's axis 1
+ * (batch): y.v(i, t, b) = x.v(i, b, t).  The derivative plane of y is not touched. */
+void ora_forward_btswitch(Float *y, const Float *x, int rows, int bs, int N) {
+  for (int t = 0; t < N; t++)
+    for (int b = 0; b < bs; b++)
+      for (int i = 0; i < rows; i++) SEQ_AT(y, rows, N, i, t, 0, b) = SEQ_AT(x, rows, bs, i, b, 0, t);
+}
+/* backward_btswitch (:437-447): x4.chip(1,2) += y4.chip(1,2).shuffle({0,2,1}) -- derivative planes */
+void ora_backward_btswitch(const Float *y, Float *x, int rows, int bs, int N) {
+  for (int t = 0; t < N; t++)
+    for (int b = 0; b < bs; b++)
+      for (int i = 0; i < rows; i++) SEQ_AT(x, rows, bs, i, b, 1, t) += SEQ_AT(y, rows, N, i, t, 1, b);
+}
+/* forward_batchstack (:451-475): y (copies*d, bs, 2, N) = 0 (BOTH planes, :464), then for
+ * k = -pre..post: source = max(k,0), dest = max(-k,0), crimp = |k|;
+ * y[d*(pre+k) .. +d, dest .. dest+bs-crimp, v, :] = x[0..d, source .. source+bs-crimp, v, :]. */
+void ora_forward_batchstack(Float *y, const Float *x, int d, int bs, int N, int pre, int post) {
+  int copies = pre + post + 1;
+  memset(y, 0, sizeof(Float) * (size_t)copies * d * bs * 2 * N);
+  for (int k = -pre; k <= post; k++) {
+    int source = k > 0 ? k : 0, dest = -k > 0 ? -k : 0, crimp = k < 0 ? -k : k;
+    for (int t = 0; t < N; t++)
+      for (int j = 0; j < bs - crimp; j++)
+        for (int f = 0; f < d; f++)
+          SEQ_AT(y, copies * d, bs, d * (pre + k) + f, dest + j, 0, t) = SEQ_AT(x, d, bs, f, source + j, 0, t);
+  }
+}
+/* backward_batchstack (:476-500): x.d slices += y.d slices, same offsets, k ascending; x.d is
+ * NOT cleared first (the clearing line :489 is commented out in the reference). */
+void ora_backward_batchstack(const Float *y, Float *x, int d, int bs, int N, int pre, int post) {
+  int copies = pre + post + 1;
+  for (int k = -pre; k <= post; k++) {
+    int source = k > 0 ? k : 0, dest = -k > 0 ? -k : 0, crimp = k < 0 ? -k : k;
+    for (int t = 0; t < N; t++)
+      for (int j = 0; j < bs - crimp; j++)
+        for (int f = 0; f < d; f++)
+          SEQ_AT(x, d, bs, f, source + j, 1, t) += SEQ_AT(y, copies * d, bs, d * (pre + k) + f, dest + j, 1, t);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Full<NONLIN> (clstm.cc:354-389: LinearLayer / SigmoidLayer / TanhLayer /    */
+/* ReluLayer) and Stacked{Full<NONLIN>, SoftmaxLayer}: a per-frame MLP.        */
+/* forward: outputs[t] = forward_full1(W1, inputs[t]) for t ascending (:369-373) */
+/* backward: backward_full1 for t DESCENDING (:375-378), W1.d accumulates.      */
+/* Sequences as [T][bs][n] arrays of value / derivative planes.                 */
+/* ------------------------------------------------------------------------- */
+void ora_full_forward(Float *out_v, const Float *W1, const Float *in_v, int T, int no, int ni, int bs, int nl) {
+  for (int t = 0; t < T; t++)
+    ora_forward_full1(out_v + (size_t)t * no * bs, W1, in_v + (size_t)t * ni * bs, no, ni + 1, bs, nl);
+}
+void ora_full_backward(const Float *out_v, Float *out_d, const Float *W1, Float *W1d, const Float *in_v,
+                       Float *in_d, int T, int no, int ni, int bs, int nl) {
+  for (int t = T - 1; t >= 0; t--)
+    ora_backward_full1(out_v + (size_t)t * no * bs, out_d + (size_t)t * no * bs, W1, W1d,
+                       in_v + (size_t)t * ni * bs, in_d + (size_t)t * ni * bs, no, ni + 1, bs, nl);
+}
+/* SoftmaxLayer over a sequence (clstm.cc:405-417), same array conventions */
+void ora_softmax_seq_forward(Float *out_v, const Float *W1, const Float *in_v, int T, int no, int ni, int bs) {
+  for (int t = 0; t < T; t++)
+    ora_forward_softmax(out_v + (size_t)t * no * bs, W1, in_v + (size_t)t * ni * bs, no, ni + 1, bs);
+}
+void ora_softmax_seq_backward(const Float *out_d, const Float *W1, Float *W1d, const Float *in_v, Float *in_d,
+                              int T, int no, int ni, int bs) {
+  for (int t = T - 1; t >= 0; t--)
+    ora_backward_softmax(out_d + (size_t)t * no * bs, W1, W1d, in_v + (size_t)t * ni * bs,
+                         in_d + (size_t)t * ni * bs, no, ni + 1, bs);
+}
+
 /* One Parallel{ NPLSTM, Reversed{NPLSTM} } block (clstm_prefab.cc:52-68). */
 typedef struct {
   Seq inputs, outputs;         /* Parallel ports */
@@ -1019,4 +1096,51 @@ double ora_bench_lines(OraNet *net, const Float *x, const int *offs, const int *
   for (int i = 0; i < nthreads; i++) ora_net_free(clones[i]);
   free(clones);
   return t1 - t0;
+}
+
+/* Parity helper for full-size minibatches: the reference's semantics of a minibatch are nlines
+ * independent CLSTMOCR::train passes without the update in between (clstmhl.h:201-217), every
+ * line's fwd / CTC / bwd accumulating into Params.d.  Here every line runs on its own clone of
+ * the net (OpenMP over lines, as ora_bench_lines), its outputs / aligned posteriors / decode are
+ * written to the packed result arrays, and the per-line gradients are summed INTO net->derivs in
+ * line order afterwards (one float add per line and parameter -- the sequential accumulation of
+ * the reference interleaves those adds with the per-step ones; the difference is float rounding
+ * of a different summation order).  Lines listed in keep[] leave their clone alive in kept[] so
+ * that the caller can read every internal state with ora_net_get_state (free with ora_net_free).
+ * outputs / aligned: [sum T][nc] packed; dec_cls: [sum T] packed at offs[i], dec_n[i] its length. */
+void ora_minibatch_lines(OraNet *net, const Float *x, const int *offs, const int *labels, const int *loffs,
+                         int nlines, int nthreads, Float *outputs, Float *aligned, int *dec_cls, int *dec_n,
+                         const int *keep, int nkeep, OraNet **kept) {
+  if (nthreads < 1) nthreads = 1;
+  OraNet **clones = (OraNet **)calloc(nlines, sizeof(OraNet *));
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+#endif
+  for (int i = 0; i < nlines; i++) {
+    OraNet *c = ora_net_create(net->nlayers, net->unidirectional, net->ninput, net->nhidden, net->nclasses, 0);
+    ora_net_set_params(c, net->params);
+    const int T = offs[i + 1] - offs[i], nc = net->nclasses;
+    ora_net_set_inputs(c, x + (size_t)offs[i] * net->ninput, T, 1);
+    ora_net_forward(c);
+    if (outputs) ora_net_get_outputs(c, outputs + (size_t)offs[i] * nc);
+    if (dec_cls) {
+      int *cs = (int *)malloc(sizeof(int) * (T + 1));
+      int n = ora_net_decode(c, cs, NULL, 0);
+      memcpy(dec_cls + offs[i], cs, sizeof(int) * n);
+      dec_n[i] = n;
+      free(cs);
+    }
+    ora_net_ctc_deltas(c, labels + loffs[i], loffs[i + 1] - loffs[i], aligned ? aligned + (size_t)offs[i] * nc : NULL);
+    ora_net_backward(c);
+    clones[i] = c;
+  }
+  for (int i = 0; i < nlines; i++)
+    for (int k = 0; k < net->nparams; k++) net->derivs[k] += clones[i]->derivs[k];
+  for (int j = 0; j < nkeep; j++) {
+    kept[j] = clones[keep[j]];
+    clones[keep[j]] = NULL;
+  }
+  for (int i = 0; i < nlines; i++)
+    if (clones[i]) ora_net_free(clones[i]);
+  free(clones);
 }

@@ -114,6 +114,15 @@ class Oracle:
             "ora_net_get_state": (I, [P, I, I, I, I, P]),
             "ora_net_train_line": (I, [P, P, I, P, I, P, I]),
             "ora_bench_lines": (C.c_double, [P, P, P, P, P, I, I, I]),
+            "ora_minibatch_lines": (None, [P, P, P, P, P, I, I, P, P, P, P, P, I, P]),
+            "ora_forward_btswitch": (None, [P, P, I, I, I]),
+            "ora_backward_btswitch": (None, [P, P, I, I, I]),
+            "ora_forward_batchstack": (None, [P, P, I, I, I, I, I]),
+            "ora_backward_batchstack": (None, [P, P, I, I, I, I, I]),
+            "ora_full_forward": (None, [P, P, P, I, I, I, I, I]),
+            "ora_full_backward": (None, [P, P, P, P, P, P, I, I, I, I, I]),
+            "ora_softmax_seq_forward": (None, [P, P, P, I, I, I, I]),
+            "ora_softmax_seq_backward": (None, [P, P, P, P, P, I, I, I, I]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -274,6 +283,40 @@ class OracleNet:
         n = self.o.lib.ora_net_train_line(self.h, Oracle.p(x), x.shape[0], Oracle.p(tr), len(tr),
                                           Oracle.p(cs), int(update))
         return cs[:n].copy()
+
+    def minibatch(self, lines, transcripts, nthreads=None, keep=()):
+        """Reference semantics of a minibatch (every line an independent fwd/CTC/bwd accumulating into Params.d,
+        clstmhl.h:201-217) with OpenMP over lines -- for sizes where the sequential Python loop of
+        tests/common.py::oracle_minibatch takes minutes.  Returns a dict: outputs / aligned (lists of [T][nc]),
+        decode (list of int arrays), derivs (net.derivs after accumulating), kept {line: OracleNet view} whose
+        .state() reads that line's internals."""
+        Ts = [len(l) for l in lines]
+        offs = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int32)
+        x = self.o.arr(np.concatenate(lines, 0))
+        lab = Oracle.ints(np.concatenate(transcripts))
+        loffs = np.concatenate([[0], np.cumsum([len(t) for t in transcripts])]).astype(np.int32)
+        N, nc = int(offs[-1]), self.nclasses
+        outputs = np.zeros((N, nc), self.o.dtype)
+        aligned = np.zeros((N, nc), self.o.dtype)
+        dec = np.zeros(N + 1, np.int32)
+        decn = np.zeros(len(lines), np.int32)
+        keep = Oracle.ints(list(keep))
+        kept = (C.c_void_p * max(1, len(keep)))()
+        if nthreads is None:
+            nthreads = min(len(lines), os.cpu_count() or 1)
+        self.o.lib.ora_minibatch_lines(self.h, Oracle.p(x), Oracle.p(offs), Oracle.p(lab), Oracle.p(loffs), len(lines),
+                                       nthreads, Oracle.p(outputs), Oracle.p(aligned), Oracle.p(dec), Oracle.p(decn),
+                                       Oracle.p(keep), len(keep), kept)
+        views = {}
+        for j, b in enumerate(keep.tolist()):
+            v = OracleNet.__new__(OracleNet)
+            v.o, v.nhidden, v.ninput, v.nclasses, v.uni = self.o, self.nhidden, self.ninput, self.nclasses, self.uni
+            v.h, v.nparams, v.T, v.bs = kept[j], self.nparams, Ts[b], 1
+            views[b] = v
+        sp = lambda a: [a[offs[b]:offs[b + 1]] for b in range(len(lines))]
+        return {"outputs": sp(outputs), "aligned": sp(aligned),
+                "decode": [dec[offs[b]:offs[b] + decn[b]].copy() for b in range(len(lines))],
+                "derivs": self.get_derivs(), "kept": views}
 
     def bench_lines(self, x, offs, labels, loffs, nthreads=1, reps=1):
         x = self.o.arr(x)

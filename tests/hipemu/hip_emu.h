@@ -244,8 +244,6 @@ inline void buf_store_s(BufF32 b, unsigned lane_off, unsigned uni, float v) { if
 inline float max_f32(float x, float y) { return fmaxf(x, y); }
 #define KEEP_ALIVE2(x) (void)(x)
 inline f32x4 buf_load4_dev(BufF32 b, unsigned off) { return buf_load4(b, off); }
-struct U32x4 { unsigned v[4]; };
-inline U32x4 buf_load4u_dev(BufF32 b, unsigned off) { const f32x4 r = buf_load4(b, off); U32x4 o; memcpy(o.v, r.v, 16); return o; }
 #define COMPILER_MEMORY_BARRIER() asm volatile("" ::: "memory")
 inline void buf_store_wt(BufF32 b, unsigned off, float v) { buf_store(b, off, v); }
 inline f32x4 buf_load4_wt(BufF32 b, unsigned off) { return buf_load4(b, off); }
@@ -254,43 +252,19 @@ inline void store_i32_wt(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CS
 inline void atomic_add_i32(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline int atomic_fetch_add_i32(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline int hw_xcc_id() { return (int)(blockIdx.x & 7u); }   // the dispatcher's round-robin placement
-inline int hw_cu_slot() { return 0; }
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __HIP_MEMORY_SCOPE_WORKGROUP 1
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n(p, __ATOMIC_SEQ_CST)
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, __ATOMIC_SEQ_CST)
 constexpr int GRID_WATCHDOG_SPINS = 1 << 24;
-inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const unsigned*) { *s = nullptr; return 0; }
 inline void sleep_some() { emu_yield(); sched_yield(); }
 inline void poll_pause() { emu_yield(); sched_yield(); }
 inline void sleep_iterations(int) { emu_yield(); sched_yield(); }
 inline int wave_max_i(int x) { for (int m = 32; m >= 1; m >>= 1) { const int y = wave_shfl_i(x, emu_lane() ^ m); x = y > x ? y : x; } return x; }
 inline void drain_vmem() {}
 inline unsigned mad_u24(unsigned a, unsigned b, unsigned c) { return a * b + c; }
-inline void buf_store_dev(BufF32 b, unsigned off, float v) { buf_store(b, off, v); }
-inline void buf_store4_dev(BufF32 b, unsigned off, f32x4 v) { for (int i = 0; i < 4; i++) buf_store(b, off + 4 * i, v[i]); }
 template <typename T> inline T* dyn_smem() { return reinterpret_cast<T*>(emu_blk->smem); }
-
-// grid barrier of the cooperative kernels: blocks of an emu_launch_coop run concurrently
-inline bool grid_barrier(int* sync, int target, int* lds_flag) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __atomic_fetch_add(sync, 1, __ATOMIC_SEQ_CST);
-    long spins = 0;
-    int bad = 0;
-    while (__atomic_load_n(sync, __ATOMIC_SEQ_CST) < target) {
-      sched_yield();
-      bad = __atomic_load_n(sync + 1, __ATOMIC_SEQ_CST);
-      if (++spins > 200000000L) bad = 1;
-      if (bad) break;
-    }
-    if (bad) __atomic_store_n(sync + 1, 1, __ATOMIC_SEQ_CST);
-    *lds_flag = bad;
-  }
-  __syncthreads();
-  return *lds_flag == 0;
-}
 
 inline void emu_init_block(EmuBlock& blk, unsigned nthreads, std::vector<char>& sm, size_t smem) {
   if (nthreads % 64 != 0) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }

@@ -309,6 +309,131 @@ def test_full_shape_gradient_error_vs_float64(ora32, ora64):
     assert e_gpu < 1e-3 and e_f32 < 1e-3
 
 
+# ---- BASELINE configs[4] at its stated size, anchored on the oracle ---------------------------------------------------
+C4 = dict(ni=64, nh=[512, 512], nc=100, T=[400] * 64, L=50, scale=4.0, keep=(0, 21, 42, 63))
+
+
+@pytest.fixture(scope="module")
+def configs4_case(ora32, ora64):
+    """2 x BiLSTM(512), H = 64, 100 classes, 64 lines x 400 frames, transcripts of 50 labels (clstm_prefab.cc:86-109
+    `bidi2`, clstm.cc:600-653) through the f32 AND the f64 oracle, OpenMP over lines (oracle/clstm_oracle.c:
+    ora_minibatch_lines).  The f64 run qualifies what float32 summation order can do at this depth (2 x 400 dependent
+    steps per layer): a result is as good as the reference's own arithmetic when its distance from the f64 result is
+    no larger than the f32 oracle's."""
+    import time
+    from common import synth_lines
+    from clstm_amd.init import init_params
+    from oracle.oracle import OracleNet
+    c = C4
+    rng = np.random.default_rng(44)
+    params = init_params(c["ni"], c["nh"], c["nc"], seed=0.222) * c["scale"]
+    lines = synth_lines(rng, c["T"], c["ni"])
+    trs = [rng.integers(1, c["nc"], c["L"]).astype(np.int32) for _ in c["T"]]
+    res = {"params": params, "lines": lines, "trs": trs}
+    for name, ora in (("f32", ora32), ("f64", ora64)):
+        net = OracleNet(ora, c["ni"], c["nh"], c["nc"], init=False)
+        net.set_params(params)
+        t0 = time.time()
+        res[name] = net.minibatch(lines, trs, keep=c["keep"] if name == "f32" else ())
+        print("oracle %s: 64 lines x 400 frames of 2 x BiLSTM(512) fwd + CTC + bwd in %.1f s on %d host threads"
+              % (name, time.time() - t0, min(64, os.cpu_count() or 1)))
+    return res
+
+
+def _rel_excess(a, b, rtol, atol):
+    """largest |a - b| / (atol + rtol |b|): <= 1 means inside the bar"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float((np.abs(a - b) / (atol + rtol * np.abs(b))).max())
+
+
+@pytest.mark.gpu
+def test_configs4_full_shape_f32_vs_oracle(configs4_case):
+    """BASELINE configs[4] at FULL size, exact-f32 path of the library against the f32 oracle: softmax outputs of all
+    25,600 frames and every gate activation / cell state / output of both layers and directions on four of the lines
+    (first, last, two in between) at the north star's 1e-4 relative (+ 2e-6 absolute floor for values ~0), CTC argmax
+    decodes of all 64 lines identical, `aligned` and the minibatch gradient at the qualified tolerance of the B1
+    full-shape test (1e-3; the gradient is also required to be as close to the FLOAT64 oracle as the f32 oracle's own
+    result, factor 2)."""
+    from common import Backend
+    from clstm_amd.net import Network
+    c, r = C4, configs4_case
+    want, w64 = r["f32"], r["f64"]
+    net = Network(c["ni"], c["nh"], c["nc"], lib=Backend("hip").lib)
+    net.set_params(r["params"])
+    net.set_inputs(r["lines"])
+    net.forward()
+    got = net.split(net.outputs())
+    worst = max(_rel_excess(got[b], want["outputs"][b], 1e-4, 2e-6) for b in range(64))
+    e_gpu = max(float(np.abs(got[b] - w64["outputs"][b]).max()) for b in range(64))
+    e_f32 = max(float(np.abs(want["outputs"][b] - w64["outputs"][b]).max()) for b in range(64))
+    print("softmax outputs vs f32 oracle: worst excess %.3g of the 1e-4 bar; max |z - z64|: GPU %.3g, f32 oracle %.3g" % (worst, e_gpu, e_f32))
+    for b in range(64):
+        assert_close(got[b], want["outputs"][b], what="softmax outputs line %d" % b)
+    for layer in (0, 1):
+        for d in (0, 1):
+            for which in ("gi", "gf", "go", "ci", "state", "outputs"):
+                s = net.split(net.state(layer, d, which))
+                for b in c["keep"]:
+                    ref = want["kept"][b].state(layer, d, which)[:, 0, :]
+                    if d == 1:
+                        ref = ref[::-1]
+                    assert_close(s[b], ref, what="state (%d, %d, %s) line %d" % (layer, d, which, b))
+    dec = net.decode()
+    mism = [b for b in range(64) if dec[b].tolist() != want["decode"][b].tolist()]
+    print("CTC argmax decodes: %d / 64 identical to the oracle" % (64 - len(mism)))
+    assert not mism, mism
+    al = net.split(net.ctc(r["trs"], want_aligned=True))
+    for b in range(64):
+        assert_close(al[b], want["aligned"][b], rtol=1e-3, atol=1e-6, what="aligned line %d" % b)
+    net.backward()
+    g = net.get_grads().astype(np.float64)
+    g32, g64 = want["derivs"].astype(np.float64), w64["derivs"].astype(np.float64)
+    scale = np.abs(g64).max()
+    eg, e32 = np.abs(g - g64).max() / scale, np.abs(g32 - g64).max() / scale
+    print("minibatch gradient, max |g - g64| / max |g64|: GPU %.3g, f32 oracle %.3g; GPU vs f32 oracle %.3g"
+          % (eg, e32, np.abs(g - g32).max() / scale))
+    assert_close(g, g32, rtol=1e-3, atol=1e-9, scale_atol=1e-3, what="minibatch gradient")
+    assert eg <= max(2.0 * e32, 2e-5), (eg, e32)
+
+
+@pytest.mark.gpu
+def test_configs4_full_shape_bf16_vs_oracle(configs4_case):
+    """BASELINE configs[4] at FULL size in precision mode 2 (bf16 MFMA operands in the lock-step recurrence and the
+    hoisted GEMMs, f32 accumulation / state / softmax / CTC -- what `bench.py --config b2 --bf16` times) against the
+    ORACLE.  Stated tolerance, not parity (bf16 has 8 bits of mantissa): softmax outputs within 1e-2 absolute, per-frame
+    argmax differs in < 2 % of the frames, CTC decodes of >= 60 / 64 lines identical, minibatch gradient within 1.5e-3 of
+    its largest entry.  The measured values are printed (see profiles/README.md for the MI355X numbers)."""
+    from common import Backend
+    from clstm_amd.net import Network
+    c, r = C4, configs4_case
+    want = r["f32"]
+    be = Backend("hip")
+    net = Network(c["ni"], c["nh"], c["nc"], lib=be.lib)
+    net.set_params(r["params"])
+    net.set_gemm_precision(2)
+    net.set_inputs(r["lines"])
+    net.forward()
+    got = net.split(net.outputs())
+    dec = [d.tolist() for d in net.decode()]
+    net.ctc(r["trs"])
+    net.backward()
+    g = net.get_grads()
+    import ctypes
+    for which, idx in (("persistent forward", 0), ("persistent backward", 1), ("bf16-source W_x.x", 2), ("bf16-source x.d", 3),
+                       ("contraction-major W.d", 4)):
+        cnt = ctypes.c_longlong(0)
+        be.lib.call("clstm_debug_path_count", idx, ctypes.byref(cnt))
+        assert cnt.value > 0, "the %s kernel did not run" % which
+    assert np.isfinite(g).all() and all(np.isfinite(o).all() for o in got)
+    err = max(float(np.abs(got[b] - want["outputs"][b]).max()) for b in range(64))
+    flips = float(np.mean([(got[b].argmax(1) != want["outputs"][b].argmax(1)).mean() for b in range(64)]))
+    same = sum(dec[b] == want["decode"][b].tolist() for b in range(64))
+    gerr = float(np.abs(g - want["derivs"]).max() / np.abs(want["derivs"]).max())
+    print("configs[4] bf16 vs the f32 ORACLE: max |dz| %.3g, argmax flips %.3g %% of frames, %d / 64 decodes identical, "
+          "gradient error %.3g of max" % (err, 100 * flips, same, gerr))
+    assert err < 1e-2 and flips < 2e-2 and same >= 60 and gerr < 1.5e-3
+
+
 @pytest.mark.gpu
 def test_configs4_full_shape_bf16_vs_f32_path():
     """BASELINE configs[4] at FULL size -- 2 x BiLSTM(512), 64 input rows, 64 lines x 400 frames, 100 classes -- in

@@ -84,13 +84,12 @@ def test_bidi_uw3_shape_short(backend, ora32):
     (4, [7, 5], 4, [4, 6]),               # forced: two stacked layers
     (6, 21, 5, [3] * 18 + [5]),           # forced: 19 lines -> two 16-line blocks (MT = 2 forward tile)
 ])
-@pytest.mark.parametrize("coop", ["coop", "steps", "xcd"], ids=["cooperative", "per_step_launch", "persistent_per_xcd"])
+@pytest.mark.parametrize("coop", ["steps", "xcd"], ids=["per_step_launch", "persistent_per_xcd"])
 def test_lockstep_recurrence_forced(backend, ora32, monkeypatch, ni, nh, nc, T, coop):
-    # the lock-step MFMA recurrence of lstm_wide.h on sizes the register-resident kernels also handle: as ONE
-    # cooperative launch with grid barriers, as one launch per time step, and as ONE persistent launch with a workgroup
-    # group per XCD (lstm_xcd_fwd_f32 / lstm_xcd_bwd_f32: the default for wide layers)
+    # the lock-step MFMA recurrence of lstm_wide.h on sizes the register-resident kernels also handle: as one launch
+    # per time step, and as ONE persistent launch with a workgroup group per XCD (lstm_xcd_fwd_f32 / lstm_xcd_bwd_f32:
+    # the default for wide layers)
     monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
-    monkeypatch.setenv("CLSTM_COOP", "1" if coop == "coop" else "0")
     monkeypatch.setenv("CLSTM_XCD_REC", "1" if coop == "xcd" else "0")
     run_case(backend, ora32, ni, nh, nc, T)
 
@@ -100,7 +99,6 @@ def test_lockstep_persistent_chunks(backend, ora32, monkeypatch):
     # (four blocks + one); smaller weights and learning rate than the other cases -- with 70 lines of gradient sums the
     # update check's absolute floor (1e-7) is below lr x the gradient's own 1e-4 tolerance
     monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
-    monkeypatch.setenv("CLSTM_COOP", "0")
     monkeypatch.setenv("CLSTM_XCD_REC", "1")
     run_case(backend, ora32, 4, 20, 4, [1 + (7 * i) % 5 for i in range(70)], scale=8.0, lr=1e-3)
 
@@ -309,41 +307,6 @@ def _path_count(backend, which):
     out = ctypes.c_longlong(0)
     backend.lib.call("clstm_debug_path_count", which, ctypes.byref(out))
     return out.value
-
-
-def test_tagged_ring_variant_matches_in_a_subprocess(backend):
-    """The opt-in "flag in data" variant of the persistent forward kernel (CLSTM_XCD_LL=1: 8-byte ring units that carry a
-    step tag, consumers re-load until the tags match, no group barrier) must give the same forward outputs as the default
-    stamp-barrier kernel.  The switch is read once per process, hence the subprocess; ragged lines make finished lines
-    publish zeros."""
-    import subprocess, sys, json
-    if backend.kind != "emu":
-        pytest.skip("emulator-only check of an experiment path (the GPU run of it is in profiles/README.md)")
-    code = r"""
-import os, sys, json, numpy as np
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-os.environ["CLSTM_FORCE_WIDE"] = "1"
-import common
-from clstm_amd.net import Network
-lib = common.emu_lib()
-rng = np.random.default_rng(11)
-ni, nh, nc = 8, [32, 32], 5
-T = [9, 5, 7, 3, 1, 8]
-net = Network(ni, nh, nc, lib=lib)
-net.set_params(rng.normal(0, 0.3, net.nparams).astype(np.float32))
-net.set_gemm_precision(2)
-net.set_inputs(common.synth_lines(rng, T, ni))
-net.forward()
-print(json.dumps(net.outputs().astype(np.float64).round(7).tolist()))
-"""
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for ll in ("0", "1"):
-        env = dict(os.environ, CLSTM_XCD_LL=ll)
-        r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"))], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-800:]
-        outs.append(np.array(json.loads(r.stdout.strip().splitlines()[-1])))
-    assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
 
 
 def test_lazy_f32_source_columns_match_the_eager_build(backend):

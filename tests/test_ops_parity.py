@@ -149,6 +149,99 @@ def test_reverse(backend):
     assert_close(backend.down(x2), w.reshape(-1))
 
 
+@pytest.mark.parametrize("rows,bs,N", [(3, 2, 4), (5, 7, 1), (1, 1, 6), (4, 3, 3)])
+def test_btswitch(backend, ora32, rows, bs, N):
+    """forward_btswitch / backward_btswitch (clstm_compute.cc:425-447) against the oracle's restatement of the
+    Eigen chip + shuffle: only the value plane moves forward (y's derivative plane keeps what it held), the
+    derivative plane accumulates backward."""
+    oc = OraCall(ora32)
+    x = cosdata(rows * bs * 2 * N, 5)
+    y0 = cosdata(rows * N * 2 * bs, 700)                     # y is NOT cleared by forward: its d plane must survive
+    y_ref = y0.copy(); oc.forward_btswitch(y_ref, x, rows, bs, N)
+    y = backend.up(y0); xv = backend.up(x)
+    backend.lib.call("clstm_forward_btswitch", ptr(y), ptr(xv), rows, bs, N)
+    assert np.array_equal(backend.down(y), y_ref)
+    # spot-check the restatement itself: y.v(i, t, b) = x.v(i, b, t)
+    X = x.reshape(N, 2, bs, rows); Y = y_ref.reshape(bs, 2, N, rows)
+    assert np.array_equal(Y[:, 0].transpose(1, 0, 2), X[:, 0])
+    assert np.array_equal(Y[:, 1], y0.reshape(bs, 2, N, rows)[:, 1])
+    yd = cosdata(y0.size, 99)
+    x_ref = x.copy(); oc.backward_btswitch(yd, x_ref, rows, bs, N)
+    x2 = backend.up(x); ydv = backend.up(yd)
+    backend.lib.call("clstm_backward_btswitch", ptr(ydv), ptr(x2), rows, bs, N)
+    assert np.array_equal(backend.down(x2), x_ref)
+    assert np.array_equal(x_ref.reshape(N, 2, bs, rows)[:, 0], X[:, 0])       # value plane untouched
+
+
+@pytest.mark.parametrize("d,bs,N,pre,post", [(3, 4, 2, 1, 1), (2, 5, 3, 2, 1), (4, 1, 2, 1, 1), (2, 3, 1, 0, 2), (3, 2, 2, 3, 3)])
+def test_batchstack(backend, ora32, d, bs, N, pre, post):
+    """forward_batchstack / backward_batchstack (clstm_compute.cc:451-500) against the oracle's slice-by-slice
+    restatement: forward clears BOTH planes of y (:464) and fills the value plane block by block, backward
+    accumulates the derivative plane into x without clearing it (:489 is commented out upstream); pre + post
+    larger than the batch (crimp >= bs) leaves empty slices."""
+    oc = OraCall(ora32)
+    copies = pre + post + 1
+    x = cosdata(d * bs * 2 * N, 11)
+    y0 = cosdata(copies * d * bs * 2 * N, 300)
+    y_ref = y0.copy(); oc.forward_batchstack(y_ref, x, d, bs, N, pre, post)
+    y = backend.up(y0); xv = backend.up(x)
+    backend.lib.call("clstm_forward_batchstack", ptr(y), ptr(xv), d, bs, N, pre, post)
+    assert np.array_equal(backend.down(y), y_ref)
+    assert not y_ref.reshape(N, 2, bs, copies * d)[:, 1].any()               # derivative plane cleared
+    yd = cosdata(y0.size, 900)
+    x_ref = x.copy(); oc.backward_batchstack(yd, x_ref, d, bs, N, pre, post)
+    x2 = backend.up(x); ydv = backend.up(yd)
+    backend.lib.call("clstm_backward_batchstack", ptr(ydv), ptr(x2), d, bs, N, pre, post)
+    assert_close(backend.down(x2), x_ref, rtol=1e-6, atol=1e-6)             # (k summed in the reference's order: exact in practice)
+
+
+@pytest.mark.parametrize("nl", [SIG, TANH, RELU, LIN])
+def test_full_layer_network(backend, ora32, nl):
+    """Stacked{Full<NONLIN>(ni -> nh), SoftmaxLayer(nh -> nc)} (clstm.cc:354-419, 421-455: LinearLayer / SigmoidLayer /
+    TanhLayer / ReluLayer in front of a softmax) over a sequence of T batches: the per-op C ABI driven the way
+    INetwork::forward / backward drive it (forward_full1 per step ascending, backward_full1 per step descending,
+    W.d accumulating over the steps, Stacked's .d hand-off) against the oracle's layer-level restatement."""
+    oc = OraCall(ora32)
+    T, bs, ni, nh, nc = 5, 3, 6, 7, 4
+    x = cosdata(T * bs * ni, 3)
+    W1 = cosdata(nh * (ni + 1), 40) * 0.7; W2 = cosdata(nc * (nh + 1), 90)
+    # oracle: layer-level
+    h_ref = np.zeros(T * bs * nh, np.float32); oc.full_forward(h_ref, W1, x, T, nh, ni, bs, nl)
+    z_ref = np.zeros(T * bs * nc, np.float32); oc.softmax_seq_forward(z_ref, W2, h_ref, T, nc, nh, bs)
+    target = np.abs(cosdata(T * bs * nc, 500)); target /= target.reshape(T * bs, nc).sum(1).repeat(nc)
+    zd = (target - z_ref).astype(np.float32)                                  # set_targets, clstm.cc:142-150
+    W2d_ref = cosdata(W2.size, 600); W1d_ref = cosdata(W1.size, 650)
+    hd_ref = np.zeros_like(h_ref); xd_ref = np.zeros_like(x)
+    oc.softmax_seq_backward(zd, W2, W2d_ref, h_ref, hd_ref, T, nc, nh, bs)
+    hd_in = hd_ref.copy()
+    oc.full_backward(h_ref, hd_ref, W1, W1d_ref, x, xd_ref, T, nh, ni, bs, nl)
+    # the C ABI, one operator call per step
+    xv = backend.up(x); W1v = backend.up(W1); W2v = backend.up(W2)
+    h = backend.zeros(T * bs * nh); z = backend.zeros(T * bs * nc)
+    W1d = backend.up(cosdata(W1.size, 650)); W2d = backend.up(cosdata(W2.size, 600))
+    hd = backend.zeros(T * bs * nh); xd = backend.zeros(T * bs * ni); zdv = backend.up(zd)
+    fs = 4                                                                    # sizeof(float)
+
+    def at(buf, t, n):
+        return ptr(buf) + t * n * bs * fs
+    for t in range(T):
+        backend.lib.call("clstm_forward_full1", at(h, t, nh), ptr(W1v), at(xv, t, ni), nh, ni + 1, bs, nl)
+    for t in range(T):
+        backend.lib.call("clstm_forward_softmax", at(z, t, nc), ptr(W2v), at(h, t, nh), nc, nh + 1, bs)
+    assert_close(backend.down(h), h_ref, what="Full outputs")
+    assert_close(backend.down(z), z_ref, what="softmax outputs")
+    for t in range(T - 1, -1, -1):
+        backend.lib.call("clstm_backward_softmax", at(zdv, t, nc), ptr(W2v), ptr(W2d), at(h, t, nh), at(hd, t, nh), nc, nh + 1, bs)
+    assert_close(backend.down(hd), hd_in, rtol=1e-4, atol=1e-6, what="softmax x.d")
+    for t in range(T - 1, -1, -1):
+        backend.lib.call("clstm_backward_full1", at(h, t, nh), at(hd, t, nh), ptr(W1v), ptr(W1d), at(xv, t, ni), at(xd, t, ni),
+                         nh, ni + 1, bs, nl)
+    assert_close(backend.down(W2d), W2d_ref, rtol=1e-4, atol=1e-5, what="softmax W.d")
+    assert_close(backend.down(hd), hd_ref, rtol=1e-4, atol=1e-6, what="Full y.d after nonlin0 backward")
+    assert_close(backend.down(W1d), W1d_ref, rtol=1e-4, atol=1e-5, what="Full W.d")
+    assert_close(backend.down(xd), xd_ref, rtol=1e-4, atol=1e-6, what="Full x.d")
+
+
 def test_statemem_nonlingate(backend, ora32):
     oc = OraCall(ora32)
     n = 24
