@@ -13,6 +13,14 @@ Workload (BASELINE.json configs[2]/[3]): uw3-500 OCR shape -- BiLSTM(100) on 48-
 83 classes, T=200 frames, transcripts of 25 labels, minibatch = 64 lines per GPU, synthetic
 inputs (clip(N(0.2,0.3),0,1) smoothed along t), reference LCG init (seed 0.222, negbiased).
 A step = one pass of the hot path over one minibatch whose frames are already resident in HBM.
+
+Timing: W untimed warm-up steps (at least 0.3 s worth -- a 20-step command must not time clock ramp and first-touch
+effects), then the block of EXACTLY K steps, bracketed by barrier + synchronize on both sides and max-reduced over the
+ranks, is timed R times back to back (R such that the timed total is >= 0.5 s; `repeats` in the JSON) and the MEDIAN
+block is reported: `ms_per_step` = median block / K, `value` = lines of one block / median block.
+
+The default single-GPU line also carries `secondary`: BASELINE.json configs[4] (2 x BiLSTM(512), H = 64, T = 400,
+bf16 MFMA) timed in the same process with the same protocol and its own `roofline` (MFMA, 2.5 PFLOP/s dense bf16).
 """
 import argparse
 import json
@@ -26,55 +34,245 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-NI, NH, NC = 48, 100, 83
-LABELS = 25
-# --config b2: BASELINE.json configs[4] shape (2 x BiLSTM(512), H=64, T~400, 100 classes, 50 labels), f32
+# b1: BASELINE.json configs[1..3] (uw3 shape); b2: configs[4] (2 x BiLSTM(512), H=64, T~400, 100 classes, 50 labels)
 CONFIGS = {"b1": dict(ni=48, nh=[100], nc=83, T=200, L=25),
            "b2": dict(ni=64, nh=[512, 512], nc=100, T=400, L=50)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+BF16_MFMA_PEAK_TFS = 2500.0    # dense bf16 MFMA
 # algorithmic bytes per cell-step of the fused gate kernels
 BYTES_PER_CELL_STEP = {"lstm_fwd": 44.0, "lstm_bwd": 56.0}
+MIN_WARMUP_S, MIN_TIMED_S, MAX_REPEATS = 0.3, 0.5, 200
+KERNEL_NAMES = ("ingest", "gemm_gates_x", "lstm_fwd", "gemm_softmax", "softmax_norm", "ctc_align", "gemm_softmax_dw_dx",
+                "lstm_bwd", "gemm_gates_dw", "reduce_scatter", "gemm_gates_dx", "allreduce_grads", "sgd_update")
 
 
-def synth_batch(rng, bs, T, ragged):
+def synth_batch(rng, bs, T, ragged, ni, nc, L):
     Ts = [int(t) for t in (rng.integers(150, 251, bs) if ragged else [T] * bs)]
     xs = []
     for t in Ts:
-        x = np.clip(rng.normal(0.2, 0.3, (t + 2, NI)), 0, 1)
+        x = np.clip(rng.normal(0.2, 0.3, (t + 2, ni)), 0, 1)
         xs.append(((x[:-2] + x[1:-1] + x[2:]) / 3.0).astype(np.float32))
-    labels = [rng.integers(1, NC, LABELS).astype(np.int32) for _ in Ts]
+    labels = [rng.integers(1, nc, L).astype(np.int32) for _ in Ts]
     return Ts, np.concatenate(xs, 0), labels
 
 
-def cpu_baseline(params, seconds_target=12.0):
-    """The oracle (CPU restatement of the reference's Eigen path, `kind: port`) timed on this box's
-    host cores on a bounded sample of the same workload: fwd+CTC+bwd of T=200 lines, OpenMP over
-    lines (the generous 'Eigen/OpenMP' figure) and single-threaded."""
+def flops_per_line(cfg, T):
+    """48 T sum_l no(ni+no) + 6 T nc 2no_last"""
+    nis = [cfg["ni"]] + [2 * h for h in cfg["nh"][:-1]]
+    return 48.0 * T * sum(o * (i + o) for i, o in zip(nis, cfg["nh"])) + 6.0 * T * cfg["nc"] * 2 * cfg["nh"][-1]
+
+
+def cpu_baseline(params, cfg, seconds_target=12.0):
+    """The oracle (CPU restatement of the reference's Eigen path, `kind: port`) timed on this box's host cores on a
+    bounded sample of the same workload: fwd+CTC+bwd of T=200 lines, OpenMP over lines on every hardware thread (the
+    generous 'Eigen/OpenMP' figure; median of three runs) and single-threaded."""
     from oracle.oracle import Oracle, OracleNet
     ora = Oracle("f32")
-    net = OracleNet(ora, NI, NH, NC, init=False)
+    net = OracleNet(ora, cfg["ni"], cfg["nh"], cfg["nc"], init=False)
     net.set_params(params)
     rng = np.random.default_rng(123)
     cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_PROC_BIND", "close")     # (read by libgomp when its first parallel region starts)
+    os.environ.setdefault("OMP_PLACES", "threads")
     nlines = max(8, cores)
-    Ts, x, labels = synth_batch(rng, nlines, 200, False)
+    Ts, x, labels = synth_batch(rng, nlines, 200, False, cfg["ni"], cfg["nc"], cfg["L"])
     offs = np.concatenate([[0], np.cumsum(Ts)])
     loffs = np.concatenate([[0], np.cumsum([len(l) for l in labels])])
     lab = np.concatenate(labels)
     t1 = net.bench_lines(x, offs, lab, loffs, nthreads=1, reps=1)       # also warms the page cache
     single = nlines / t1
-    reps = max(1, int(seconds_target * single * min(cores, 4) / nlines))
-    tn = net.bench_lines(x, offs, lab, loffs, nthreads=cores, reps=reps)
-    multi = nlines * reps / tn
+    reps = max(1, int(seconds_target / 3.0 * single * min(cores, 4) / nlines))
+    runs = sorted(nlines * reps / net.bench_lines(x, offs, lab, loffs, nthreads=cores, reps=reps) for _ in range(3))
+    multi = runs[1]
     use_multi = multi >= single
     return {
         "value": round(multi if use_multi else single, 2), "unit": "lines/s",
         "cores": cores if use_multi else 1, "kind": "port",
-        "sample": "%d lines x %d reps of T=200 fwd+CTC+bwd, OpenMP over lines on %d threads "
-                  "(%.1f lines/s); single thread %.1f lines/s; gcc -O3 -march=native" %
-                  (nlines, reps, cores, multi, single),
+        "sample": "%d lines x %d reps of T=200 fwd+CTC+bwd, OpenMP over lines on %d threads, median of 3 runs "
+                  "(%.1f / %.1f / %.1f lines/s); single thread %.1f lines/s; gcc -O3 -march=native" %
+                  (nlines, reps, cores, runs[0], runs[1], runs[2], single),
     }
+
+
+class Workload:
+    """One network + a small rotating pool of synthetic minibatches resident in HBM."""
+
+    def __init__(self, lib, cfg, minibatch, T, ragged, precision, dev, rank, comm=None, dist=None):
+        import torch
+        from clstm_amd.init import init_params
+        from clstm_amd.net import Network
+        from clstm_amd.parallel import Trainer
+        self.cfg, self.minibatch, self.T, self.ragged, self.precision = cfg, minibatch, T, ragged, precision
+        nh = cfg["nh"][0] if len(cfg["nh"]) == 1 else cfg["nh"]
+        self.params_h = init_params(cfg["ni"], nh, cfg["nc"], seed=0.222)
+        n = self.params_h.size
+        self.params = torch.from_numpy(self.params_h).to(dev)
+        self.derivs = torch.zeros(n, device=dev)
+        self.grads = torch.zeros(n, device=dev)
+        self.net = Network(cfg["ni"], nh, cfg["nc"], lib=lib, params=self.params, derivs=self.derivs, grads=self.grads)
+        self.net.params_changed()
+        self.net.setLearningRate(1e-4, 0.9)
+        if precision:
+            self.net.set_gemm_precision(precision)
+        self.trainer = Trainer(self.net, grads_tensor=self.grads if (comm is None and dist is not None) else None, comm=comm)
+        rng = np.random.default_rng(1000 + rank)
+        self.pool = []
+        for _ in range(4):
+            Ts, x, labels = synth_batch(rng, minibatch, T, ragged, cfg["ni"], cfg["nc"], cfg["L"])
+            self.pool.append((Ts, torch.from_numpy(x).to(dev), labels, Network.prepare_step(Ts, labels)))
+        self.one_call = self.trainer.dist is None     # single GPU or library communicator: clstm_net_train_step
+
+    def step(self, i):
+        Ts, xd, labels, prep = self.pool[i % len(self.pool)]
+        if self.one_call:
+            self.net.train_step_prepared(prep, xd)     # CLSTMOCR::train for the minibatch: one C-ABI call, no host sync
+        else:
+            self.trainer.step_device(Ts, xd, labels)
+
+    def frames(self, i):
+        return sum(self.pool[i % len(self.pool)][0])
+
+
+def timed_blocks(w, steps, warmup, fence, reduce_max):
+    """warm-up (>= `warmup` steps and >= MIN_WARMUP_S), then R blocks of exactly `steps` steps; returns the block times"""
+    i = 0
+    t0 = time.perf_counter()
+    for _ in range(warmup):
+        w.step(i)
+        i += 1
+    fence()
+    # the time criterion looks at the max over ranks (a collective: every rank takes the same number of rounds)
+    while reduce_max(time.perf_counter() - t0) < MIN_WARMUP_S:
+        for _ in range(max(1, min(steps, 16))):
+            w.step(i)
+            i += 1
+        fence()
+    blocks = []
+    repeats = 1
+    k = 0
+    while k < repeats:
+        fence()
+        t0 = time.perf_counter()
+        for j in range(steps):
+            w.step(i + j)
+        fence()
+        dt = reduce_max(time.perf_counter() - t0)
+        i += steps
+        blocks.append(dt)
+        if k == 0:
+            repeats = int(min(MAX_REPEATS, max(1, np.ceil(MIN_TIMED_S / max(dt, 1e-9)))))   # identical on every rank: dt is max-reduced
+        k += 1
+    return blocks, i
+
+
+def kernel_times(w, steps, first_step):
+    """per-kernel device time over `steps` extra steps (HIP events on the library's stream)"""
+    import torch
+    net = w.net
+    net.enable_timing(True)
+    net.reset_timing()
+    frames = 0
+    for i in range(steps):
+        w.step(first_step + i)
+        frames += w.frames(first_step + i)
+    torch.cuda.synchronize()
+    kern = {}
+    for name in KERNEL_NAMES:
+        ms, n = net.kernel_time_ms(name)
+        if n:
+            kern[name] = {"ms_per_step": round(ms / steps, 4), "launches_per_step": n / steps}
+    net.enable_timing(False)
+    return kern, frames / steps
+
+
+def pmc_traffic(minibatch, T, ragged):
+    """HBM bytes per launch from the newest committed rocprofv3 PMC passes (same workload only)"""
+    try:
+        import glob
+        pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*.json")))[-1]
+        pmc = json.load(open(pmc_file))
+        if pmc["workload"]["minibatch_per_gpu"] == minibatch and pmc["workload"]["T"] == T and not ragged:
+            src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed -- "
+                   "not re-measured inside this run" % os.path.basename(pmc_file))
+            return {k.split(" ")[0]: v["hbm_bytes"] for k, v in pmc["kernels"].items()}, src
+    except Exception:
+        pass
+    return {}, None
+
+
+def roofline_b1(w, kern, frames_per_step, ms_per_step):
+    """Fused gate kernels against HBM (north star: 'achieved HBM GB/s for the fused gate kernel'), the batched gate GEMM
+    against the f32 MFMA peak ('MFMA utilisation for the batched gate GEMM').  Algorithmic bytes:
+    forward 44 B per cell-step; the backward recurrence 56 B per cell-step -- it shares its launch with the
+    weight-gradient GEMM (lstm_bwd_dw.h), whose operand reads (deltas once, source rows once, and for the top layer
+    the softmax layer's [1 | h] rows and output deltas) are added for that launch."""
+    cfg = w.cfg
+    ndir, N = 2, frames_per_step
+    cells = ndir * sum(cfg["nh"])
+    traffic, traffic_src = pmc_traffic(w.minibatch, w.T, w.ragged)
+    entries = {}
+    for name, key in (("lstm_fwd", "lstm_fwd"), ("lstm_bwd", "lstm_bwd_dw")):
+        if name not in kern:
+            continue
+        byts = BYTES_PER_CELL_STEP[name] * cells * N
+        fused = name == "lstm_bwd" and "gemm_gates_dw" not in kern
+        if fused:
+            no, ni = cfg["nh"][-1], cfg["ni"]
+            lds = (1 + ni + no + 15) // 16 * 16
+            ldh = (4 + ndir * no + 15) // 16 * 16
+            byts += 4.0 * N * (ndir * 4 * no + ndir * lds) + 4.0 * N * (ldh + cfg["nc"])
+        sec = kern[name]["ms_per_step"] * 1e-3
+        nl = kern[name]["launches_per_step"]
+        ach = byts / sec / 1e9
+        entries[key] = {"kernel": key if fused else name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(key, traffic.get(name)),
+                        "algorithmic_bytes": int(byts / nl), "avg_launch_ms": round(sec / nl * 1e3, 4)}
+    if "gemm_gates_x" in kern:
+        M = ndir * 4 * cfg["nh"][0]
+        fl = 2.0 * N * M * (cfg["ni"] + 1)
+        sec = kern["gemm_gates_x"]["ms_per_step"] * 1e-3
+        tf = fl / sec / 1e12
+        entries["gemm_gates_x"] = {"kernel": "gemm_gates_x", "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFS,
+                                   "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFS, 5), "traffic": traffic.get("gemm_gates_x"),
+                                   "algorithmic_flops": int(fl), "avg_launch_ms": round(sec * 1e3, 4),
+                                   "note": "batched gate GEMM W_x.x + b over every frame of the minibatch (f32 MFMA); "
+                                           "its 4 B x N x M output stream (%.0f MB) is what bounds it" % (4e-6 * N * M)}
+    cand = [k for k in ("lstm_fwd", "lstm_bwd_dw") if k in entries]
+    if not cand:
+        return None
+    dom = max(cand, key=lambda k: entries[k]["avg_launch_ms"])     # the dominant kernel of the step BY TIME
+    out = dict(entries[dom])
+    out["traffic_source"] = traffic_src if out["traffic"] is not None else None
+    sec = kern["lstm_fwd"]["ms_per_step"] * 1e-3 if "lstm_fwd" in kern else None
+    out["note"] = ("latency-bound recurrence: %d workgroups (lines x directions) on 256 CUs, one dependent step per frame; "
+                   "whole step %.1f GB/s of algorithmic bytes (SURVEY 8d: 3.62 MB/line + 2.17 MB/minibatch)"
+                   % (2 * w.minibatch, (3.62e6 * w.minibatch + 2.17e6) / (ms_per_step * 1e-3) / 1e9))
+    out["others"] = {k: v for k, v in entries.items() if k != dom}
+    return out
+
+
+def roofline_b2(w, kern, frames_per_step, ms_per_step):
+    """Lock-step recurrence of wide layers: a (lines x no).(no x 4no) product per step and direction, priced against
+    the matrix peak of the operand type (north star: 'MFMA utilisation ... against gfx950 peak')."""
+    cfg = w.cfg
+    bf16 = w.precision == 2
+    peak = BF16_MFMA_PEAK_TFS if bf16 else F32_MFMA_PEAK_TFS
+    cand = [k for k in ("lstm_fwd", "lstm_bwd") if k in kern]
+    if not cand:
+        return None
+    dom = max(cand, key=lambda k: kern[k]["ms_per_step"])
+    sec = kern[dom]["ms_per_step"] * 1e-3
+    nl = kern[dom]["launches_per_step"]
+    fl = 8.0 * sum(h * h for h in cfg["nh"]) * 2 * frames_per_step
+    tf = fl / sec / 1e12
+    whole = flops_per_line(cfg, w.T) * w.minibatch / (ms_per_step * 1e-3) / 1e12
+    return {"kernel": dom, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5),
+            "traffic": None, "algorithmic_flops": int(fl / nl), "avg_launch_ms": round(sec / nl * 1e3, 4),
+            "whole_step": {"achieved": round(whole, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(whole / peak, 5),
+                           "algorithmic_flops_per_line": int(flops_per_line(cfg, w.T))},
+            "note": "lock-step recurrence, one persistent launch per layer pass: a workgroup group per XCD, %d group-barrier-separated "
+                    "steps (latency-bound); whole step: SURVEY 8d flops (48 T sum no(ni+no) + 6 T nc 2no per line)" % w.T}
 
 
 def main():
@@ -92,15 +290,14 @@ def main():
                          "(BASELINE configs[4]: '2 x BiLSTM(512), bf16 MFMA'; not the parity path)")
     ap.add_argument("--ragged", action="store_true", help="T ~ U{150..250} instead of fixed T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[4] leg of the default line")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
     args = ap.parse_args()
-    global NI, NH, NC, LABELS
     cfg = CONFIGS[args.config]
-    NI, NH, NC, LABELS = cfg["ni"], cfg["nh"], cfg["nc"], cfg["L"]
     if args.T is None:
         args.T = cfg["T"]
-    nh_list = list(NH)
-    NH = NH[0] if len(NH) == 1 else NH
+    default_line = (args.config == "b1" and not args.bf16 and not args.bf16_gemm and not args.ragged
+                    and args.minibatch == 64 and args.T == 200)
     if args.config != "b1":
         args.no_cpu_baseline = True     # the bounded CPU sample is defined for the headline workload only
 
@@ -140,9 +337,7 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     from clstm_amd import abi
-    from clstm_amd.init import init_params
-    from clstm_amd.net import Comm, Network
-    from clstm_amd.parallel import Trainer
+    from clstm_amd.net import Comm
 
     lib = abi.load()   # raises if the HIP extension is missing -- there is no fallback path
     # a real (non-default) stream: the library replays launch-bound loops as hipGraphs, and the legacy
@@ -150,19 +345,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     lib.call("clstm_set_stream", stream.cuda_stream)
-    params_h = init_params(NI, NH, NC, seed=0.222)
-    nparams = params_h.size
     dev = torch.device("cuda", local_rank)
-    params = torch.from_numpy(params_h).to(dev)
-    derivs = torch.zeros(nparams, device=dev)
-    grads = torch.zeros(nparams, device=dev)
-    net = Network(NI, NH, NC, lib=lib, params=params, derivs=derivs, grads=grads)
-    net.params_changed()
-    net.setLearningRate(1e-4, 0.9)
-    if args.bf16:
-        net.set_gemm_precision(2)
-    elif args.bf16_gemm:
-        net.set_gemm_precision(1)
     # gradient exchange: the library's own RCCL communicator (all-reduce enqueued on the library stream right
     # before the update kernel, no cross-stream events); torch.distributed only carries the 128-byte id, the
     # barriers and the max-over-ranks of the timing.  If the communicator cannot be created the step falls back to
@@ -180,22 +363,6 @@ def main():
         except Exception as e:     # noqa: BLE001 -- report and fall back, never silently
             sys.stderr.write("bench.py: library communicator unavailable (%s); falling back to torch.distributed\n" % e)
             allreduce_impl = "torch.distributed.all_reduce (fallback: %s)" % type(e).__name__
-    trainer = Trainer(net, grads_tensor=grads if comm is None else None, comm=comm)
-
-    # synthetic minibatches resident in HBM before the timed region (a small rotating pool)
-    rng = np.random.default_rng(1000 + rank)
-    pool = []
-    for _ in range(4):
-        Ts, x, labels = synth_batch(rng, args.minibatch, args.T, args.ragged)
-        pool.append((Ts, torch.from_numpy(x).to(dev), labels, Network.prepare_step(Ts, labels)))
-    one_call = trainer.dist is None     # single GPU or library communicator: clstm_net_train_step
-
-    def step(i):
-        Ts, xd, labels, prep = pool[i % len(pool)]
-        if one_call:
-            net.train_step_prepared(prep, xd)     # CLSTMOCR::train for the minibatch: one C-ABI call, no host sync
-        else:
-            trainer.step_device(Ts, xd, labels)
 
     def fence():
         torch.cuda.synchronize()
@@ -203,106 +370,74 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
+    def reduce_max(dt):
+        if dist is None:
+            return dt
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    lines_total = args.minibatch * world * args.steps
-    value = lines_total / dt
-    # host-side cost of issuing a step (diagnostic: is the loop host-bound?): a short burst on an idle stream, few
-    # enough steps that the library's 8-slot pinned staging ring never makes the host wait for the GPU
-    t1 = time.perf_counter()
-    for i in range(4):
-        step(i)
-    t_enqueue = (time.perf_counter() - t1) / 4
-    fence()
+        return float(tt.item())
 
-    # per-kernel device time (HIP events on the library's stream) for the roofline object
-    kern = {}
+    def measure(w, steps, warmup, profile_steps):
+        blocks, nxt = timed_blocks(w, steps, warmup, fence, reduce_max)
+        dt = float(np.median(blocks))
+        # host-side cost of issuing a step (diagnostic: is the loop host-bound?): a short burst on an idle stream, few
+        # enough steps that the library's pinned staging ring never makes the host wait for the GPU
+        t1 = time.perf_counter()
+        for i in range(4):
+            w.step(nxt + i)
+        t_enq = (time.perf_counter() - t1) / 4
+        fence()
+        kern, fps = ({}, 0)
+        if rank == 0 and profile_steps > 0:
+            kern, fps = kernel_times(w, profile_steps, nxt + 4)
+        return {"dt": dt, "blocks": blocks, "enqueue": t_enq, "kern": kern, "frames_per_step": fps}
+
+    precision = 2 if args.bf16 else 1 if args.bf16_gemm else 0
+    w = Workload(lib, cfg, args.minibatch, args.T, args.ragged, precision, dev, rank, comm=comm, dist=dist)
+    m = measure(w, args.steps, args.warmup, args.profile_steps)
+    dt = m["dt"]
+    ms_per_step = dt / args.steps * 1e3
+    value = args.minibatch * world * args.steps / dt
     roofline = None
-    if rank == 0 and args.profile_steps > 0:
-        net.enable_timing(True)
-        net.reset_timing()
-        frames = 0
-        for i in range(args.profile_steps):
-            step(i)
-            frames += sum(pool[i % len(pool)][0])
-        torch.cuda.synchronize()
-        for name in ("gemm_gates_x", "lstm_fwd", "gemm_softmax", "softmax_norm", "ctc_align",
-                     "gemm_softmax_dw_dx", "gemm_softmax_dx", "gemm_softmax_dw", "lstm_bwd", "gemm_gates_dw", "gemm_gates_dx",
-                     "allreduce_grads", "sgd_update"):
-            ms, n = net.kernel_time_ms(name)
-            if n:
-                kern[name] = {"ms_per_step": round(ms / args.profile_steps, 4), "launches_per_step": n / args.profile_steps}
-        net.enable_timing(False)
-        dom = max(("lstm_fwd", "lstm_bwd"), key=lambda k: kern.get(k, {"ms_per_step": 0})["ms_per_step"])
-        if "gemm_gates_dw" not in kern:
-            dom = "lstm_fwd"     # the backward recurrence shares its launch with the weight-gradient GEMM (lstm_bwd_dw.h):
-                                 # the pure fused gate kernel of the step is the forward recurrence
-        traffic, traffic_src = None, None
-        try:   # HBM bytes per launch from the newest committed rocprofv3 PMC passes (same workload only)
-            import glob
-            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*.json")))[-1]
-            pmc = json.load(open(pmc_file))
-            if (pmc["workload"]["minibatch_per_gpu"] == args.minibatch and pmc["workload"]["T"] == args.T
-                    and not args.ragged and dom in pmc["kernels"]):
-                traffic = pmc["kernels"][dom]["hbm_bytes"]
-                traffic_src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                               "committed -- not re-measured inside this run" % os.path.basename(pmc_file))
-        except Exception:
-            traffic = None
-        if dom in kern:
-            frames_per_step = frames / args.profile_steps
-            cells = 2 * sum(nh_list)                                           # directions x cells, all layers
-            byts = BYTES_PER_CELL_STEP[dom] * cells * frames_per_step         # per minibatch, all layers
-            sec = kern[dom]["ms_per_step"] * 1e-3                              # same scope
-            nl = kern[dom]["launches_per_step"]
-            ach = byts / sec / 1e9
-            if max(nh_list) > 128:
-                # lock-step recurrence of a wide layer: a (lines x no).(no x 4no) product per step and direction --
-                # priced against the matrix peak of the operand type (north star: "MFMA utilisation ... against gfx950 peak")
-                peak = 2500.0 if args.bf16 else F32_MFMA_PEAK_TFS
-                fl = (8.0 if dom == "lstm_fwd" else 8.0) * sum(h * h for h in nh_list) * 2 * frames_per_step
-                tf = fl / sec / 1e12
-                roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                            "frac": round(tf / peak, 5), "traffic": None,
-                            "algorithmic_flops": int(fl / nl), "avg_launch_ms": round(sec / nl * 1e3, 4),
-                            "note": ("lock-step recurrence, ONE persistent launch per pass: a workgroup group per XCD, %d group-barrier-separated steps (latency-bound); "
-                                     if os.environ.get("CLSTM_XCD_REC", "1") != "0" and os.environ.get("CLSTM_COOP", "0") == "0" else
-                                     "lock-step recurrence, one launch per time step (latency-bound: %d dependent launches per pass); ") % args.T +
-                                    "whole step: %.1f TFLOP/s of algorithmic flops (SURVEY 8d: 48 T sum no(ni+no) + 6 T nc 2no per line)"
-                                    % ((48.0 * args.T * sum(o * (i + o) for i, o in zip([NI] + [2 * h for h in nh_list[:-1]], nh_list))
-                                                + 6.0 * args.T * NC * 2 * nh_list[-1]) * args.minibatch / (dt / args.steps) / 1e12)}
-            else:
-              roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "traffic_source": traffic_src,
-                        "algorithmic_bytes": int(byts / nl),
-                        "avg_launch_ms": round(sec / nl * 1e3, 4),
-                        "note": "latency-bound recurrence (%s); recurrent matmul rate %.2f TFLOP/s of %.1f f32 peak" %
-                                ("persistent, %d workgroups (lines x directions) on 256 CUs" % (2 * args.minibatch)
-                                 if max(nh_list) <= 128 else "lock-step, one MFMA launch per time step",
-                                 16.0 * sum(h * h for h in nh_list) * frames_per_step / sec / 1e12
-                                 * (1.0 if dom == "lstm_fwd" else 1.0), F32_MFMA_PEAK_TFS)}
+    if rank == 0 and m["kern"]:
+        roofline = (roofline_b1 if max(cfg["nh"]) <= 128 else roofline_b2)(w, m["kern"], m["frames_per_step"], ms_per_step)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(params_h)
+        cpu = cpu_baseline(w.params_h, cfg)
+
+    # BASELINE.json configs[4] in the same process (default single-GPU line only): 2 x BiLSTM(512), bf16 MFMA
+    secondary = None
+    if rank == 0 and world == 1 and default_line and not args.no_secondary:
+        c2 = CONFIGS["b2"]
+        if comm is not None:
+            w.net.set_comm(None)
+        w.net = w.trainer = None        # free the first workload's device arrays
+        w2 = Workload(lib, c2, 64, c2["T"], False, 2, dev, rank)
+        s2 = max(5, min(args.steps, 20))
+        m2 = measure(w2, s2, 3, 2)
+        ms2 = m2["dt"] / s2 * 1e3
+        secondary = {
+            "metric": "text-line images/sec (fwd+bwd+CTC), 2xBiLSTM(512) H=64 T~400 (bf16 MFMA)",
+            "value": round(64 * s2 / m2["dt"], 2), "unit": "lines/s", "n_gpus": 1, "steps": s2, "warmup": 3,
+            "repeats": len(m2["blocks"]), "ms_per_step": round(ms2, 4),
+            "dtype": "bf16 MFMA operands (hoisted gate GEMMs and lock-step recurrence), f32 accumulate / state / softmax / CTC",
+            "data": "synthetic",
+            "config": {"workload": "stacked 2xBiLSTM(512) H=64 nc=100, T=400, L=50, minibatch=64 lines on 1 GPU "
+                                   "(BASELINE.json configs[4] shape), fwd+CTC+bwd+update", "minibatch_per_gpu": 64},
+            "roofline": roofline_b2(w2, m2["kern"], m2["frames_per_step"], ms2) if m2["kern"] else None,
+            "kernels": m2["kern"],
+            "parity": "stated tolerance against the f32 oracle at this size: tests/test_gpu_e2e.py::test_configs4_full_shape_bf16_vs_oracle",
+        }
+        del w2
 
     if rank == 0:
+        b1 = args.config == "b1"
         out = {
-            "metric": "text-line images/sec (fwd+bwd+CTC), 100-unit BiLSTM H=48 T~200" if args.config == "b1" else
+            "metric": "text-line images/sec (fwd+bwd+CTC), 100-unit BiLSTM H=48 T~200" if b1 else
                       "text-line images/sec (fwd+bwd+CTC), 2xBiLSTM(512) H=64 T~400 (%s)" % ("bf16 MFMA" if args.bf16 else "f32"),
             "value": round(value, 2), "unit": "lines/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "warmup": args.warmup, "repeats": len(m["blocks"]), "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 MFMA operands (hoisted gate GEMMs and lock-step recurrence), f32 accumulate / state / softmax / CTC" if args.bf16
                       else "f32 (hoisted gate GEMMs: bf16 in, f32 accumulate)" if args.bf16_gemm else "f32"),
@@ -310,19 +445,24 @@ def main():
             "config": {"workload": ("uw3-500 OCR shape: BiLSTM(100) H=48 nc=83, T=%s, L=25, minibatch=%d lines/GPU "
                                     "(BASELINE.json configs[2]; x%d GPUs = configs[3] sharding), fwd+CTC+bwd+allreduce+update"
                                     % ("U{150..250}" if args.ragged else args.T, args.minibatch, world))
-                                   if args.config == "b1" else
+                                   if b1 else
                                    ("stacked 2xBiLSTM(512) H=64 nc=100, T=%s, L=50, minibatch=%d lines/GPU x%d GPUs "
                                     "(BASELINE.json configs[4] shape), fwd+CTC+bwd+allreduce+update"
                                     % (args.T, args.minibatch, world)),
                        "minibatch_per_gpu": args.minibatch, "global_minibatch": args.minibatch * world,
                        "parallelism": "dp%d" % world},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
-            "host_enqueue_ms_per_step": round(t_enqueue * 1e3, 4),   # host-side cost of issuing a step
+            "timing": {"protocol": "median of `repeats` blocks of exactly `steps` steps, each bracketed by barrier + synchronize "
+                                   "and max-reduced over ranks; warm-up >= %.1f s" % MIN_WARMUP_S,
+                       "block_ms_min": round(min(m["blocks"]) * 1e3, 3), "block_ms_max": round(max(m["blocks"]) * 1e3, 3)},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": m["kern"],
+            "host_enqueue_ms_per_step": round(m["enqueue"] * 1e3, 4),   # host-side cost of issuing a step
             "allreduce": allreduce_impl,
+            "secondary": secondary,
         }
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
-        net.set_comm(None)
+        if w.net is not None:
+            w.net.set_comm(None)
         comm.close()
     if dist is not None:
         dist.destroy_process_group()

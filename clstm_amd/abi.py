@@ -111,6 +111,7 @@ _SIGS = {
     "clstm_debug_ctc_cycles": [_P],
     "clstm_debug_gemm": [_I, _P, _P, _P, _I, _I, _I, _I],
     "clstm_debug_path_count": [_I, _P],
+    "clstm_debug_set_device_error": [_I, _I],
 }
 # functions whose int return value is a result, not a status
 _VALUE_RETURN = {"clstm_net_nparams_for", "clstm_net_nparams", "clstm_abi_version", "clstm_comm_rank", "clstm_comm_size"}

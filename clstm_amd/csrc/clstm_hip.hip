@@ -301,6 +301,17 @@ static void launch_steps(StepGraphCache& cache, int kind, const A& a, int tmax, 
 // good.  Later launches copy their error word into a pinned ring and are checked when the slot comes round again or at
 // the next host read-back: the host keeps enqueueing ahead of the GPU (four stream synchronisations per minibatch cost
 // ~0.1 ms of idle GPU at the configs[4] shape).
+// Device error words shared by every net of the process: [0] sticky outcome of persistent recurrence launches,
+// [1] weight-gradient items of the fused backward launch that gave up waiting (gemm_dw.h).  k_update skips the update
+// while either is set; the host throws at its next synchronisation point (clstm_synchronize, any read-back).
+static int* g_dev_err = nullptr;
+static int* dev_err_words() {
+  if (!g_dev_err) {
+    HIPCHECK(hipMalloc((void**)&g_dev_err, 16 * sizeof(int)));
+    zero_fill(g_dev_err, 16 * sizeof(int));
+  }
+  return g_dev_err;
+}
 struct XcdOutcome {
   static const int SLOTS = 16;
   int* pinned = nullptr;
@@ -311,9 +322,10 @@ struct XcdOutcome {
     if (!pending[i]) return;
     HIPCHECK(hipEventSynchronize(ev[i]));
     pending[i] = false;
+    if (pinned[i] != 0 && g_dev_err) (void)hipMemset(g_dev_err, 0, sizeof(int));   // reported once: updates resume (nothing was applied meanwhile)
     if (pinned[i] != 0)
-      throw Error(pinned[i] == 1 ? "persistent recurrence: workgroups were not spread evenly over the XCDs in a later launch; results since then are invalid -- set CLSTM_XCD_REC=0"
-                                 : "persistent recurrence: a group barrier timed out in the middle of the sequence; set CLSTM_XCD_REC=0");
+      throw Error(pinned[i] == 1 ? "persistent recurrence: workgroups were not spread evenly over the XCDs in a later launch; the minibatches since then were NOT applied (parameters and momentum are intact) -- set CLSTM_XCD_REC=0"
+                                 : "persistent recurrence: a group barrier timed out in the middle of the sequence; the minibatches since then were NOT applied -- set CLSTM_XCD_REC=0");
   }
   void check_all() { for (int i = 0; i < SLOTS; i++) check_slot(i); }
   // returns false if the launch failed its placement check and nothing was written (synchronous phase only)
@@ -341,7 +353,7 @@ struct XcdOutcome {
     next = (next + 1) % SLOTS;
     check_slot(i);
     if (!ev[i]) HIPCHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
-    HIPCHECK(hipMemcpyAsync(pinned + i, err_d, sizeof(int), hipMemcpyDeviceToHost, s));
+    CLSTM_LAUNCH(k_xcd_outcome, dim3(1), dim3(64), 0, s, err_d, dev_err_words(), pinned + i);
     HIPCHECK(hipEventRecord(ev[i], s));
     pending[i] = true;
     return true;
@@ -349,6 +361,18 @@ struct XcdOutcome {
   }
 };
 static XcdOutcome g_xcd_outcome;
+// after a stream synchronisation: everything enqueued so far has run -- report what the device flagged
+static void check_device_errors() {
+  g_xcd_outcome.check_all();
+  if (!g_dev_err) return;
+  int w[2] = {0, 0};
+  HIPCHECK(hipMemcpy(w, g_dev_err, sizeof(w), hipMemcpyDeviceToHost));
+  if ((w[0] | w[1]) == 0) return;
+  (void)hipMemset(g_dev_err, 0, sizeof(w));
+  if (w[0]) throw Error("persistent recurrence: a launch failed (code " + std::to_string(w[0]) + "); the minibatches since then were NOT applied -- set CLSTM_XCD_REC=0");
+  throw Error("fused backward launch: " + std::to_string(w[1]) + " weight-gradient item(s) gave up waiting for the recurrence (watchdog); the "
+              "minibatches since then were NOT applied -- set CLSTM_OVERLAP=0");
+}
 static bool g_wide_persistent = false;   // the last launch_lstm_wide call ran the persistent per-XCD kernels
 
 static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s, bool bf16 = false) {
@@ -589,7 +613,7 @@ struct Net {
   int overlap = getenv("CLSTM_OVERLAP") ? atoi(getenv("CLSTM_OVERLAP")) : 1;
   unsigned dw_done_total = 0;     // recurrence workgroups launched so far through the fused launch (GemmDwArgs::done)
   DevBuf<long long> dw_trace;
-  DevBuf<int> dw_ktab, dw_slabs, dw_timeouts, dw_queue;   // dw_queue: the monitor's published minima and the `done` counter, each on its own 128-byte line
+  DevBuf<int> dw_ktab, dw_slabs, dw_queue;   // dw_queue: the monitor's published minima and the `done` counter, each on its own 128-byte line
   std::vector<int> dw_key;        // line offsets the tables were built for
   // the softmax layer's W.d as independent items of the top layer's fused backward launch (gemm_dw.h, GemmDwArgs::x*)
   DevBuf<int> dwx_tab;            // [entries][2] contiguous 16-frame entries | slabs
@@ -983,7 +1007,6 @@ struct Net {
     const size_t nk = (size_t)ndir * dw_ntiles_max * 2, nsw = slabs.size() * sizeof(DwSlab) / sizeof(int);
     dw_ktab.reserve(nk + 8);
     dw_slabs.reserve(nsw + 8);
-    if (!dw_timeouts.p) dw_timeouts.reserve(4);
     hipStream_t s = stream();
     int* stage = (int*)ring.acquire((nk + nsw) * sizeof(int));
     for (int dir = 0; dir < ndir; dir++) {
@@ -1016,7 +1039,7 @@ struct Net {
     g.prog = (const int*)(y.D.p + prog_off); g.line_off = line_off.p; g.bs = bs; g.prog_base = prog_base;
     g.partial = partial.p; g.R = R; g.Cn = Cn;
     g.gx = (unsigned)((Cn + GEMM_BT - 1) / GEMM_BT); g.gy = (unsigned)((R + GEMM_BT - 1) / GEMM_BT);
-    g.timeouts = dw_timeouts.p;
+    g.timeouts = dev_err_words() + 1;
     if (!dw_queue.p) dw_queue.reserve(5 * PROG_STRIDE);
     g.ndir = ndir;
     g.minprog = dw_queue.p + PROG_STRIDE;   // own 128-byte lines
@@ -1226,7 +1249,7 @@ struct Net {
       timing.end(s);
     }
     timing.begin("sgd_update", s);
-    CLSTM_LAUNCH(k_update, dim3(nblocks(nparams)), dim3(256), 0, s, v, d, (const float*)g, (size_t)nparams, lr, mom, gclip);
+    CLSTM_LAUNCH(k_update, dim3(nblocks(nparams)), dim3(256), 0, s, v, d, (const float*)g, (size_t)nparams, lr, mom, gclip, (const int*)dev_err_words());
     timing.end(s);
     check_launch();
     packed_dirty = true;
@@ -1367,7 +1390,7 @@ extern "C" {
 const char* clstm_last_error(void) { return g_err.c_str(); }
 int clstm_abi_version(void) { return 1; }
 int clstm_set_stream(void* s) { g_stream = (hipStream_t)s; return 0; }
-int clstm_synchronize(void) { ABI_BEGIN HIPCHECK(hipStreamSynchronize(g_stream)); g_xcd_outcome.check_all(); ABI_END }
+int clstm_synchronize(void) { ABI_BEGIN HIPCHECK(hipStreamSynchronize(g_stream)); check_device_errors(); ABI_END }
 
 // ---- per-op entry points -------------------------------------------------------------------------
 int clstm_forward_nonlin0(float* y, int len, int nl) { ABI_BEGIN EW(k_forward_nonlin0, len, y, (size_t)len, nl) ABI_END }
@@ -1526,7 +1549,7 @@ static void copy_h2d(float* dst, const float* src, size_t n) {
 static void copy_d2h(float* dst, const float* src, size_t n) {
   HIPCHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, g_stream));
   HIPCHECK(hipStreamSynchronize(g_stream));
-  g_xcd_outcome.check_all();   // whatever is read back was produced by launches whose outcome is known now
+  check_device_errors();   // whatever is read back was produced by launches whose outcome is known now
 }
 int clstm_net_set_params_h(clstm_net* h, const float* p) { ABI_BEGIN copy_h2d(h->net.v, p, h->net.nparams); h->net.packed_dirty = true; ABI_END }
 int clstm_net_get_params_h(clstm_net* h, float* p) { ABI_BEGIN copy_d2h(p, h->net.v, h->net.nparams); ABI_END }
@@ -1911,9 +1934,9 @@ int clstm_net_overlap_stats(clstm_net* h, long long* launches, int* timeouts) {
   if (launches) *launches = n.dw_launches;
   if (timeouts) {
     *timeouts = 0;
-    if (n.dw_timeouts.p) {
+    if (g_dev_err) {   // (process-wide count; also reported -- and cleared -- by the next synchronisation point)
       HIPCHECK(hipStreamSynchronize(g_stream));
-      HIPCHECK(hipMemcpy(timeouts, n.dw_timeouts.p, sizeof(int), hipMemcpyDeviceToHost));
+      HIPCHECK(hipMemcpy(timeouts, g_dev_err + 1, sizeof(int), hipMemcpyDeviceToHost));
     }
   }
   ABI_END
@@ -1936,6 +1959,13 @@ int clstm_debug_lstm_cycles(clstm_net* h, long long* out_h) {   // diagnostics b
   ABI_END
 }
 #endif
+int clstm_debug_set_device_error(int which, int value) {   // tests: what a failed persistent launch / a timed-out item leaves behind
+  ABI_BEGIN
+  REQUIRE(which == 0 || which == 1, "bad error word");
+  HIPCHECK(hipStreamSynchronize(g_stream));
+  HIPCHECK(hipMemcpy(dev_err_words() + which, &value, sizeof(int), hipMemcpyHostToDevice));
+  ABI_END
+}
 int clstm_debug_path_count(int which, long long* out_h) {
   ABI_BEGIN
   REQUIRE(which >= 0 && which < 8 && out_h, "bad path index");

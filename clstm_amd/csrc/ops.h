@@ -197,14 +197,28 @@ __global__ void k_sgd(float* v, float* d, size_t len, float lr, float mom) {
     d[i] = di * mom;
   }
 }
-// fused: d += g ; clip ; v += lr*d ; d *= mom    (clstm.cc:201-217 on the flat buffers)
-__global__ void k_update(float* v, float* d, const float* g, size_t len, float lr, float mom, float clip) {
+// fused: d += g ; clip ; v += lr*d ; d *= mom    (clstm.cc:201-217 on the flat buffers).
+// `err` (may be null): the device error words of the library -- [0] outcome of the persistent recurrences of earlier
+// launches (workgroups misplaced / a group barrier timed out), [1] weight-gradient items that gave up waiting.  The
+// host learns about those asynchronously (it keeps enqueueing ahead of the GPU); the UPDATE must not: a gradient
+// computed from unwritten activations is not applied, parameters and momentum stay as they were.
+__global__ void k_update(float* v, float* d, const float* g, size_t len, float lr, float mom, float clip, const int* err) {
+  if (err && (err[0] | err[1]) != 0) return;
   CLSTM_GRID_STRIDE(i, len) {
     float di = d[i] + g[i];
     if (clip < 1e6f) di = fmaxf(-clip, fminf(clip, di));
     v[i] += di * lr;
     d[i] = di * mom;
   }
+}
+
+// outcome of a persistent recurrence launch: its error word goes into the sticky device word k_update looks at and into
+// the host's pinned slot (checked when the slot comes round again or at the next read-back)
+__global__ void k_xcd_outcome(const int* err, int* sticky, int* host_slot) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int e = *err;
+  if (e) *sticky = e;
+  *host_slot = e;
 }
 
 // ---- weight packing for the sequence kernels ---------------------------------------------------

@@ -271,6 +271,10 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* C, int R, 
  * 4 weight-gradient product from contraction-major bf16 operands (LDS transpose reads).  Tests use it to make sure the
  * path they mean to cover is the one that ran. */
 int clstm_debug_path_count(int which, long long* out_h);
+/* (tests) set a device error word: which = 0 the outcome word of the persistent recurrences, 1 the count of weight-gradient
+ * items that gave up waiting.  While either is non-zero clstm_net_update() applies nothing; the next synchronisation
+ * point (clstm_synchronize, any *_h read-back) reports the error and clears the words. */
+int clstm_debug_set_device_error(int which, int value);
 
 #ifdef __cplusplus
 }

@@ -182,3 +182,32 @@ def test_overlapped_weight_gradient_gemm(backend, ora32, nh, T):
         assert_close(grads[-1], want, rtol=1e-4, atol=1e-9, scale_atol=1e-4, what="gradient, overlap mode %d" % mode)
     for g in grads[1:]:
         assert_close(g, grads[0], rtol=1e-5, atol=1e-9, scale_atol=1e-5, what="overlapped vs plain")
+
+
+def test_update_is_skipped_while_a_device_error_is_pending(backend, ora32):
+    """A failed persistent recurrence launch (or a timed-out weight-gradient item) is reported to the host
+    asynchronously; until then the host keeps enqueueing minibatches.  None of them may be APPLIED: k_update looks at
+    the device error words and leaves parameters and momentum untouched, the next synchronisation point raises, and
+    training resumes afterwards."""
+    from clstm_amd.net import Network
+    rng = np.random.default_rng(5)
+    ni, nh, nc, T = 5, 6, 4, [7, 4]
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, 2).astype(np.int32) for _ in T]
+    net = Network(ni, nh, nc, lib=backend.lib)
+    net.set_params(params)
+    net.setLearningRate(1e-2, 0.9)
+
+    def step():
+        net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward(); net.update()
+    for which in (0, 1):
+        backend.lib.call("clstm_debug_set_device_error", which, 2)
+        net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
+        backend.lib.dll.clstm_net_update(net.h)            # enqueued; must not touch v or d
+        with pytest.raises(Exception, match="NOT applied"):
+            backend.lib.call("clstm_synchronize")
+        assert np.array_equal(net.get_params(), params.astype(np.float32))
+        assert not net.get_derivs().any()
+    step()                                                  # the words were cleared by the report: updates resume
+    assert not np.array_equal(net.get_params(), params.astype(np.float32))
