@@ -18,6 +18,7 @@
 #include "gemm_bf16.h"
 #include "gemm_dw.h"
 #include "lstm_bwd_dw.h"
+#include "lstm_fwd_fused.h"
 #include "softmax_fused.h"
 #include "lstm_seq.h"
 #include "lstm_wide.h"
@@ -196,6 +197,21 @@ template <int NK4, int KU>
 static void launch_bwd(const LstmSeqArgs& a, int bs, int nthreads, hipStream_t s) {
   const size_t smem = (2 * 16 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
   CLSTM_LAUNCH((lstm_bwd_kernel<NK4, KU>), dim3(bs, a.ndir), dim3(nthreads), smem, s, a);
+}
+template <int NK4, int KU>
+static void launch_fwd_fused(const FwdFusedKernelArgs& k, unsigned nblk, int nthreads, hipStream_t s) {
+  const size_t smem = (2 * 4 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
+#ifdef CLSTM_HIP_EMU
+  CLSTM_LAUNCH_COOP((lstm_fwd_fused_kernel<NK4, KU>), dim3(nblk), dim3(nthreads), smem, s, k);   // emulator: every workgroup live at once
+#else
+  CLSTM_LAUNCH((lstm_fwd_fused_kernel<NK4, KU>), dim3(nblk), dim3(nthreads), smem, s, k);
+#endif
+}
+static bool launch_lstm_fwd_fused(int nk4, int ku, const FwdFusedKernelArgs& k, unsigned nblk, int nthreads, hipStream_t s) {
+#define CASE_(N, K) if (nk4 == N && ku == K) { launch_fwd_fused<N, K>(k, nblk, nthreads, s); check_launch(); return true; }
+  CASE_(7, 25) CASE_(7, 28) CASE_(8, 32)    // (the fused form needs >= 5 waves: a polling wave among the first four, a reporting wave behind them)
+#undef CASE_
+  return false;
 }
 // k values per lane actually used: the padded 4*nk4 in general, exact for the 97..100-cell case (uw3 BiLSTM(100))
 static int pick_ku(int no, int nk4) { return (nk4 == 7 && (no + 3) / 4 == 25) ? 25 : 4 * nk4; }
@@ -539,6 +555,8 @@ struct Layer {
   long long nwf = 0, nwb = 0;
   PackDesc pd;
   float *Wt = nullptr, *bias = nullptr, *Rf = nullptr, *Rb = nullptr, *Rwf = nullptr, *Rwb = nullptr;
+  float* Wk = nullptr;        // k-contiguous W_x rows for the producer items of the fused forward launch (ops.h:PackFused)
+  int wk_kp = 0, wk_njp = 0;
   DevBuf<float> dCc;
   // bf16 recurrence of a wide layer (lstm_wide_bf16.h): packed weights and the bf16 copies of h / the deltas
   unsigned short *Rbf = nullptr, *Rbb = nullptr;
@@ -624,9 +642,23 @@ struct Net {
   int prog_base = 1024;           // grows with every backward launch: stale progress words never look complete
   long long dw_launches = 0;      // overlapped backward passes so far (tests check the path was taken)
   Comm* comm = nullptr;         // data-parallel ranks: all-reduce of g before the update (not owned)
+  // --- fused forward launch (lstm_fwd_fused.h): W_x GEMM producers + recurrence + softmax consumers ---
+  float* W1k = nullptr;         // k-contiguous softmax rows (PackFused)
+  int w1k_kps = 0;
+  DevBuf<int> fw_items, fw_flags;
+  std::vector<int> fw_key;      // line offsets the item lists were built for
+  int fw_npitems = 0, fw_ncitems = 0, fw_chunks = 0;
+  int fw_epoch = 0, fw_prog_base = 1024;
+  long long fw_launches = 0;
 
   hipStream_t stream() const { return g_stream; }
 
+  static bool l_is_only_layer(const clstm_net_desc& ds) { return ds.nlayers == 1; }
+  PackFused pack_fused_desc(const Layer& y) const {
+    PackFused f{};
+    if (y.Wk) { f.Wk = y.Wk; f.kp = y.wk_kp; f.njp = y.wk_njp; f.W1k = W1k; f.kps = w1k_kps; f.nc = desc.nclasses; f.sm_k = sm_ni; f.sm_off = sm_off; }
+    return f;
+  }
   void build(const clstm_net_desc& ds, float* pv, float* pd, float* pg) {
     desc = ds;
     REQUIRE(ds.nlayers >= 1 && ds.nlayers <= CLSTM_MAX_LAYERS, "nlayers out of range");
@@ -687,6 +719,12 @@ struct Net {
         HIPCHECK(hipMalloc((void**)&y.Rf, (size_t)ndir * 4 * KQP * y.nthreads * sizeof(float)));
         HIPCHECK(hipMalloc((void**)&y.Rb, (size_t)ndir * 4 * KQP * y.nthreads * sizeof(float)));
       }
+      if (!y.wide && l_is_only_layer(ds) && ds.nclasses <= SMX_COLS) {
+        y.wk_kp = (y.ni + 15) / 16 * 16; y.wk_njp = (4 * y.no + 15) / 16;
+        HIPCHECK(hipMalloc((void**)&y.Wk, ((size_t)ndir * y.wk_njp * 16 * y.wk_kp + 64) * sizeof(float)));
+        w1k_kps = (ndir * y.no + 15) / 16 * 16;
+        HIPCHECK(hipMalloc((void**)&W1k, ((size_t)96 * w1k_kps + 64) * sizeof(float)));
+      }
       HIPCHECK(hipMalloc((void**)&y.moff, (size_t)M * sizeof(long long)));
       std::vector<long long> mo(M);
       for (int m = 0; m < M; m++) {
@@ -699,10 +737,11 @@ struct Net {
   }
   ~Net() {
     for (auto& y : L) {
-      (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff);
+      (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff); (void)hipFree(y.Wk);
       (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release();
       y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false;
     }
+    (void)hipFree(W1k); fw_items.release(); fw_flags.release();
     if (own_v) (void)hipFree(v);
     if (own_d) (void)hipFree(d);
     if (own_g) (void)hipFree(g);
@@ -727,7 +766,7 @@ struct Net {
         CLSTM_LAUNCH(k_pack_wide, dim3(nblocks((size_t)(y.nwf + y.nwb))), dim3(256), 0, s, (const float*)v, y.Rwf, y.Rwb,
                      y.pd, y.kpf, y.kpb);
       CLSTM_LAUNCH(k_pack_layer, dim3(nblocks((size_t)(1 + y.ni) * M + 2 * nr)), dim3(256), 0, s, (const float*)v, y.Wt,
-                   y.bias, y.Rf, y.Rb, y.pd);
+                   y.bias, y.Rf, y.Rb, y.pd, pack_fused_desc(y));
       if (y.wide && bf16_rec) {   // bf16 copy of W_x^T for the bf16-source x.d product
         y.Wtb.reserve((size_t)y.ni * M + 64);
         CLSTM_LAUNCH(k_to_bf16, dim3(nblocks((size_t)y.ni * M)), dim3(256), 0, s, (const float*)y.Wt, y.Wtb.p, (size_t)y.ni * M);
@@ -771,9 +810,9 @@ struct Net {
       y.C.reserve((size_t)N * ndir * y.no);
       {
         const size_t cap0 = y.H.cap;
-        y.H.reserve((size_t)N * y.ldh + 64);
+        y.H.reserve((size_t)N * y.ldh + 64 + (y.Wk ? PROG_WORDS : 0));   // (fused forward: progress words behind the rows)
         if (y.H.cap != cap0) {
-          const size_t rows = y.H.cap / y.ldh;
+          const size_t rows = (y.H.cap - (y.Wk ? PROG_WORDS + 64 : 0)) / y.ldh;
           CLSTM_LAUNCH(k_fill_col0, dim3(nblocks(rows)), dim3(256), 0, s, y.H.p, rows, y.ldh, y.hofs - 1);
         }
       }
@@ -846,6 +885,7 @@ struct Net {
     flush_line_off();
     repack();
     hipStream_t s = stream();
+    if (forward_fused_eligible()) { forward_fused(); return; }
     for (int l = 0; l < (int)L.size(); l++) {
       Layer& y = L[l];
       const int M = ndir * 4 * y.no;
@@ -919,6 +959,96 @@ struct Net {
       CLSTM_LAUNCH(k_softmax_norm, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Z.p, nc, (size_t)N);
       timing.end(s);
       check_launch();
+    }
+  }
+
+  // ---- the forward half as one launch: W_x GEMM producers + recurrence + softmax consumers (lstm_fwd_fused.h) ----
+  bool forward_fused_eligible() {
+    if (!overlap || L.size() != 1 || bf16_gemm) return false;
+    const Layer& y = L[0];
+    if (!y.Wk || y.wide || y.nthreads < 64 * FWD_CW || y.no % 16 == 0 || y.wk_njp > FWD_JW * FWD_CW || w1k_kps > 16 * FWD_CG) return false;     // >= 5 waves, the last lane owns no cell
+    if (desc.nclasses > SMX_COLS || bs > PROG_LINES || bs >= (1 << 18) || tmax >= (1 << 16)) return false;
+    if ((overlap == 1) && (tmax < 64 || N < 2048)) return false;                 // too small to profit
+    if ((double)y.H.cap * 4.0 >= 2147483000.0) return false;                     // 32-bit byte offsets inside one descriptor
+    // the recurrence workgroups (one per CU, dispatched first) wait for producers: CUs must be left for those
+    return bs * ndir <= device_cu_count() - std::max(8, device_cu_count() / 8);
+  }
+  void build_fwd_items() {
+    if (fw_key == line_off_h && fw_ncitems > 0) return;
+    fw_chunks = (tmax + 15) / 16;
+    std::vector<int> items;
+    // producers: time order from chunk 1 on (chunk 0 is the recurrence workgroup's own), the longest lines of a chunk
+    // first; records of 4 ints: code, the line's first frame, its length, 0
+    for (int c = 1; c < fw_chunks; c += FWD_FT)
+      for (int i = 0; i < bs; i++) {
+        const int b = order_h[i], T = line_off_h[b + 1] - line_off_h[b];
+        if (T > 16 * c)
+          for (int dir = 0; dir < ndir; dir++) { items.push_back(b << 13 | dir << 12 | c); items.push_back(line_off_h[b]); items.push_back(T); items.push_back(0); }
+      }
+    fw_npitems = (int)items.size() / 4;
+    std::vector<std::pair<int, int>> cons;                    // (iteration at which the block is complete, code)
+    for (int b = 0; b < bs; b++) {
+      const int T = line_off_h[b + 1] - line_off_h[b];
+      for (int blk = 0; 16 * blk < T; blk++)
+        cons.push_back({std::max(std::min(16 * blk + 16, T), ndir > 1 ? T - 16 * blk : 0), b << 12 | blk});
+    }
+    std::stable_sort(cons.begin(), cons.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
+    fw_ncitems = (int)cons.size();
+    for (auto& c : cons) items.push_back(c.second);
+    fw_items.reserve(items.size() + 8);
+    fw_flags.reserve((size_t)ndir * bs * fw_chunks + 8);      // (zero-filled when it grows; flags carry the launch epoch)
+    hipStream_t s = stream();
+    int* stage = (int*)ring.acquire(items.size() * sizeof(int));
+    memcpy(stage, items.data(), items.size() * sizeof(int));
+    HIPCHECK(hipMemcpyAsync(fw_items.p, stage, items.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    ring.commit(s);
+    fw_key = line_off_h;
+  }
+  void forward_fused() {
+    hipStream_t s = stream();
+    Layer& y = L[0];
+    build_fwd_items();
+    if (++fw_epoch > (1 << 30)) fw_epoch = 1;
+    fw_prog_base += tmax + 64;
+    if (fw_prog_base > (1 << 30)) fw_prog_base = 1024;
+    fw_launches++;
+    g_path_count[5]++;
+    FwdFusedKernelArgs k{};
+    LstmSeqArgs& a = k.a;
+    a.Rpk = y.Rf; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.dH = nullptr; a.D = nullptr;
+    a.line_off = line_off.p; a.order = line_off.p + bs + 1; a.no = y.no; a.ndir = ndir; a.ldh = y.ldh; a.hofs = y.hofs;
+    a.S = y.S.p; a.lds = y.lds; a.sofs = 1 + y.ni; a.sdir = (long long)N * y.lds; a.bs = bs;
+    a.prog_off = (long long)y.H.cap - 64 - PROG_WORDS;
+    REQUIRE(a.prog_off >= (long long)N * y.ldh + 16, "internal: progress words overlap the output rows");
+    a.prog_base = fw_prog_base;
+    a.gflag = fw_flags.p; a.gchunks = fw_chunks; a.gepoch = fw_epoch; a.timeouts = dev_err_words() + 1;
+    FwdFusedArgs& h = k.h;
+    h.X = layer_input(0); h.ldx = layer_input_ld(0); h.x_elems = (long long)N * h.ldx + 32;
+    h.Wk = y.Wk; h.kp = y.wk_kp; h.njp = y.wk_njp; h.bias = y.bias;
+    h.pitems = fw_items.p; h.npitems = fw_npitems; h.gflag = fw_flags.p;
+    h.W1k = W1k; h.kps = w1k_kps; h.sm_k = sm_ni; h.b1 = v + sm_off; h.Z = Z.p; h.nc = desc.nclasses;
+    h.citems = fw_items.p + 4 * fw_npitems; h.ncitems = fw_ncitems;
+    h.prog = (const int*)(y.H.p + a.prog_off);
+    h.nrec = bs * ndir; h.npb = fw_npitems;
+    const unsigned nblk = (unsigned)(h.nrec + h.npb + fw_ncitems);   // one item per helper workgroup
+    y.sx_valid = src0_ready;
+    ensure_source_x(0);
+    static const char* trace_path = getenv("CLSTM_FW_TRACE");   // diagnostics: wall-clock stamps of every workgroup / item of the launch
+    const size_t trace_rows = (size_t)h.nrec + fw_npitems + fw_ncitems;
+    if (trace_path) { dw_trace.reserve(trace_rows * 4); HIPCHECK(hipMemsetAsync(dw_trace.p, 0, trace_rows * 4 * sizeof(long long), s)); h.trace = dw_trace.p; }
+    timing.begin("lstm_fwd", s);
+    REQUIRE(launch_lstm_fwd_fused(y.nk4, y.pd.ku, k, nblk, y.nthreads, s), "internal: no fused forward instantiation");
+    timing.end(s);
+    if (trace_path) {
+      HIPCHECK(hipStreamSynchronize(s));
+      std::vector<long long> t(trace_rows * 4);
+      HIPCHECK(hipMemcpy(t.data(), dw_trace.p, t.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(trace_path, "w")) {
+        fprintf(f, "# %d recurrence rows (start - end -), %d producer items (start - done chunk), %d consumer items (start ready done ready_iteration); 100 MHz ticks\n",
+                h.nrec, fw_npitems, fw_ncitems);
+        for (size_t i = 0; i < trace_rows; i++) fprintf(f, "%lld %lld %lld %lld\n", t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+        fclose(f);
+      }
     }
   }
 
@@ -1582,7 +1712,7 @@ static void net_set_inputs_d(clstm_net* h, const float* x, const CtcMetaCopy* au
     // optional trailing blocks read small host arrays straight from their pinned slots: the line offsets and -- in a
     // training step -- the CTC metadata (no DMA launches, no event records on the stream's critical path)
     CLSTM_LAUNCH(k_ingest_pack, dim3(nbi + nbp + (lo ? 1 : 0) + (ax ? (aux->nwords + 255) / 256 : 0)), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni, y.lds,
-                 n.ndir, (long long)n.N * y.lds, nbi, nbp, (const float*)n.v, y.Wt, y.bias, y.Rf, y.Rb, y.pd,
+                 n.ndir, (long long)n.N * y.lds, nbi, nbp, (const float*)n.v, y.Wt, y.bias, y.Rf, y.Rb, y.pd, n.pack_fused_desc(y),
                  lo ? n.lo_stage : nullptr, n.line_off.p, 2 * n.bs + 1, ax ? aux->src : nullptr, ax ? aux->dst : nullptr, ax ? aux->nwords : 0);
     if (lo) { n.ring.commit(g_stream); n.lo_pending = false; }
     if (ax) { h->ctc.ring.commit(g_stream); aux_done = true; }

@@ -251,6 +251,12 @@ DEVFN void buf_store_wt(BufF32 b, unsigned byte_off, float v) {
 DEVFN f32x4 buf_load4_wt(BufF32 b, unsigned byte_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, byte_off, 0, 17));
 }
+DEVFN float buf_load_wt(BufF32 b, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, byte_off, 0, 17));
+}
+DEVFN void buf_store4_wt(BufF32 b, unsigned byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b.r, byte_off, 0, 17);
+}
 DEVFN int load_i32_wt(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 DEVFN void store_i32_wt(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 DEVFN void atomic_add_i32(int* p, int v) { atomicAdd(p, v); }

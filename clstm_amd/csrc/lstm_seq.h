@@ -54,12 +54,18 @@ struct LstmSeqArgs {
   int lds, sofs;        //   the forward pass deposits h_{t-1} at column sofs = 1 + ni of the NEXT step's row
   long long sdir;       //   floats between the two directions' S arrays
   long long* prof;      // diagnostics build (-DCLSTM_LSTM_PROF) only: [8 waves][8] summed phase cycles of workgroup 0
-  // backward only -- progress words for a concurrently running consumer of D (gemm_dw.h): word (dir, line) lives
-  // prog_off floats behind D[0] (the tail of D's allocation, so that the per-step delta store reaches it through the
-  // same descriptor) and counts the iterations of that line whose deltas are complete in memory.  -1: none.
+  // Progress words for consumers that run CONCURRENTLY with the recurrence (backward: the weight-gradient items of
+  // gemm_dw.h reading D; forward, fused launch of lstm_fwd_fused.h: the softmax items reading H): word (dir, line) lives
+  // prog_off floats behind D[0] / H[0] (the tail of that array's allocation, so that the per-step store reaches it
+  // through the same descriptor) and counts the iterations of that line whose stores are complete in memory.  -1: none.
   long long prog_off;
   int prog_base;        // value that means "0 iterations complete" for this launch (monotonic across launches)
   int bs;               // lines in the batch (index stride of the progress words)
+  // forward, fused launch only -- the gate pre-activations G are PRODUCED inside the launch (16 iterations of one line
+  // and direction per item): flag (dir, line, chunk) == gepoch once that chunk's rows are in memory
+  const int* gflag;     // [ndir][bs][gchunks]
+  int gchunks, gepoch;
+  int* timeouts;        // watchdog count (device error word) for the waits above
 };
 
 // One workgroup per CU, at most two of its waves per SIMD: tell hipcc, or its scheduler trades the up-front issue of
@@ -74,15 +80,29 @@ constexpr int lstm_qstride(int nk4) { return 4 * nk4 + ((nk4 & 1) ? 0 : 4); }
 
 // NK4: float4 groups of k per lane (register / LDS capacity 4*NK4); KU <= 4*NK4: k values a lane really
 // owns = cells per quarter.  (7, 25) is the 100-cell instantiation: 50 instead of 56 packed FMAs per step.
-template <int NK4, int KU>
-__global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_kernel(LstmSeqArgs a) {
+// FUSED (lstm_fwd_fused.h): the same recurrence as one role of a launch whose other workgroups produce G ahead of it
+// and consume H behind it.  Three things change, none of them on the step's dependent chain:
+//  * G is read with system-scope loads (written through by the producers, per-XCD L2s are not coherent).  The workgroup
+//    computes the pre-activations of its OWN first 16 iterations before it starts (seven waves, ~3 us: waiting for a
+//    producer's chunk 0 cost 8-10 us); from then on ONE wave -- wave 3, the first-dispatched wave that has a SIMD to
+//    itself and idles ~350 cycles at every barrier -- makes sure the chunk of the loads about to be issued is there:
+//    it requests the chunk flag two steps before it needs the answer (the same software pipeline as the
+//    pre-activations) and, if the chunk is missing, spins in front of its barrier arrival, which holds the workgroup;
+//  * H is stored write-through, and the LAST lane of the workgroup, which owns no cell (4 no < threads), rides that
+//    store with its own address and data: at the flush of step tp it writes that iterations < tp - 2 are complete
+//    (every wave has passed the barrier of step tp, i.e. has waited for a load it issued behind its stores of step
+//    tp - 3; VMEM operations of a wave complete in order), exactly as the backward kernel reports its deltas.
+struct FwdFusedArgs;
+// (lstm_fwd_fused.h) the workgroup computes the gate pre-activations of its own first 16 iterations
+DEVFN void fwd_self_produce(const LstmSeqArgs& a, const FwdFusedArgs& h, int b, int dir, int off, int T);
+template <int NK4, int KU, bool FUSED>
+DEVFN void lstm_fwd_body(const LstmSeqArgs& a, const int b, const int dir, const FwdFusedArgs* fh = nullptr) {
   constexpr int KQP = 4 * NK4;
   constexpr int QS = KQP + ((NK4 & 1) ? 0 : 4);
   constexpr int HB = 4 * QS;
   float* lds = dyn_smem<float>();  // hbuf[2][HB] + dump word
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nthreads = blockDim.x;
-  const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, dir = blockIdx.y;
+  const int nthreads = blockDim.x;          // 64 * ceil(no / 16) <= 64 * NK4
   const int no = a.no;
   const int q = lane & 3, cell = wave * 16 + (lane >> 2);
   const bool valid = cell < no;
@@ -109,7 +129,11 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
   const BufF32 gbuf = make_buf(a.G + (size_t)off * (gstride4 / 4), (size_t)T * gstride4);
   const BufF32 cbuf = make_buf(a.C + (size_t)off * (cstride4 / 4), (size_t)T * cstride4);
   const unsigned hstride4 = (unsigned)a.ldh * 4;
-  const BufF32 hbuf = make_buf(a.H + (size_t)off * a.ldh, (size_t)T * hstride4);
+  // (fused: the descriptor reaches this line's progress word behind the array)
+  const long long prog_rel = FUSED ? a.prog_off + ((long long)dir * a.bs + b) * PROG_STRIDE - (long long)off * a.ldh : 0;
+  const BufF32 hbuf = make_buf(a.H + (size_t)off * a.ldh, FUSED ? (size_t)(prog_rel + 1) * 4 : (size_t)T * hstride4);
+  const bool tagl = FUSED && tid == nthreads - 1;          // requires cell(tid) >= no (checked by the host)
+  const unsigned ptag = (unsigned)prog_rel * 4u;
   const unsigned sstride4 = (unsigned)a.lds * 4;
   const BufF32 sbuf = make_buf(a.S + (size_t)dir * a.sdir + (size_t)off * a.lds, (size_t)T * sstride4);
   const unsigned gl = valid ? ((unsigned)dir * 4 * no + cell * 4 + q) * 4u : BUF_OOB_BASE;
@@ -128,11 +152,30 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
   float* wrA = lead ? lds + HB + hslot : lds + 2 * HB;
   float* wrB = lead ? lds + hslot : lds + 2 * HB;
   float c_prev = 0.0f;
-  if (T <= 0) return;
+  if (T <= 0) {   // an empty line is complete at once
+    if (FUSED && tid == 0) store_i32_wt(reinterpret_cast<int*>(a.H + a.prog_off) + ((size_t)dir * a.bs + b) * PROG_STRIDE, a.prog_base);
+    return;
+  }
+  const int nchunk = (T + 15) >> 4;
+  const int* gfl = FUSED ? a.gflag + ((size_t)dir * a.bs + b) * a.gchunks : nullptr;
+  auto gload = [&](unsigned o) -> float { return FUSED ? buf_load_wt(gbuf, o) : buf_load(gbuf, o); };
+  // fused: wait (every wave by itself, wave-uniform) until the chunk is there
+  auto wait_chunk = [&](int c) {
+    int spins = 0;
+    while (wave_uniform(load_i32_wt(gfl + c)) != a.gepoch) {
+      sleep_iterations(1);
+      if (++spins > (1 << 20)) { if (lane == 0) atomic_add_i32(a.timeouts, 1); break; }   // never hang the device
+    }
+  };
+  if constexpr (FUSED) {   // chunk 0 of this line and direction: computed here, written through, then visible to every wave
+    fwd_self_produce(a, *fh, b, dir, off, T);
+    drain_vmem();
+    __syncthreads();
+  }
   // input pre-activations are fetched two steps ahead into two alternating registers (the loop is
   // unrolled by two so that no register rotation forces an early wait on an in-flight load)
-  float gxA = buf_load(gbuf, gl + fr(0) * gstride4);
-  float gxB = buf_load(gbuf, gl + fr(1) * gstride4);
+  float gxA = gload(gl + fr(0) * gstride4);
+  float gxB = gload(gl + fr(1) * gstride4);
   float kaA0 = 0.f, kaA1 = 0.f, kaA2 = 0.f, kaB0 = 0.f, kaB1 = 0.f, kaB2 = 0.f;  // store-data pins
   buf_store(sbuf, sl + fr(0) * sstride4, 0.0f);  // h_{-1} = 0 (forward_stack_delay, last < 0)
   // Touch every value loaded so far HERE.  hipcc otherwise places the wait for the weight loads at their
@@ -161,12 +204,17 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
   // (pa*, pb*: data and offsets of the previous step = the other register set.)
   // (pa*: the previous step's activation, c and h = the other register set; tp: that step, -1 before the first.
   //  The offset arithmetic happens here too, off the tail.)
-  auto flush = [&](const int tp, float pa0, float pa1, float pa2) {
+  auto flush = [&](const int tp, float pa0, float pa1, float pa2, auto report_tag) {
+    constexpr bool REPORT = decltype(report_tag)::value;
     const bool any = tp >= 0;
     const unsigned f = fr(tp < 0 ? 0 : tp);
     buf_store(gbuf, any ? gl + f * gstride4 : BUF_OOB, pa0);
     buf_store(cbuf, any ? cl + f * cstride4 : BUF_OOB, pa1);
-    buf_store(hbuf, any ? hl + f * hstride4 : BUF_OOB, pa2);
+    if constexpr (REPORT) {   // (the wave with the reporting lane: address and data by select)
+      const float sdat = tagl ? __builtin_bit_cast(float, a.prog_base + (tp - 2 > 0 ? tp - 2 : 0)) : pa2;
+      buf_store_wt(hbuf, tagl ? (any ? ptag : BUF_OOB) : (any ? hl + f * hstride4 : BUF_OOB), sdat);
+    } else if constexpr (FUSED) buf_store_wt(hbuf, any ? hl + f * hstride4 : BUF_OOB, pa2);
+    else buf_store(hbuf, any ? hl + f * hstride4 : BUF_OOB, pa2);
     // h_t is the recurrent part of the NEXT step's source row (dropped after the last step)
     buf_store(sbuf, any && tp + 1 < T ? sl + fr(tp + 1) * sstride4 : BUF_OOB, pa2);
   };
@@ -181,13 +229,16 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
   // stores sit at a fixed place in straight-line code, so hipcc still counts the VMEM queue exactly (a branch
   // inside the step made it wait with vmcnt(1), i.e. for the previous step's stores).
   const bool early = wave_uniform(wave) < EARLY_WAVES;
-  auto run = [&](auto early_tag) {
-  constexpr bool EARLY = decltype(early_tag)::value;
-  auto step = [&](const int t, float& gxr, const float* hq, float* hw, float& ka0, float& ka1, float& ka2,
+  // fused roles: POLL = wave 3 (early), REPORT = the last wave (late); the host launches the fused form only for
+  // workgroups of at least five waves whose last lane owns no cell
+  auto run = [&](auto early_tag, auto poll_tag, auto report_tag) {
+  constexpr bool EARLY = decltype(early_tag)::value, POLL = decltype(poll_tag)::value;
+  int rdyA = a.gepoch, rdyB = a.gepoch;   // (POLL) chunk flags requested two steps ago
+  auto step = [&](const int t, float& gxr, int& rdy, const float* hq, float* hw, float& ka0, float& ka1, float& ka2,
                   float pa0, float pa1, float pa2) {
     if constexpr (!EARLY) {
       KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2);  // stores of step t-2 have long completed
-      flush(t - 1, pa0, pa1, pa2);
+      flush(t - 1, pa0, pa1, pa2, report_tag);
     }
     f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
     LSTM_STAMP(0);   // loop overhead since the barrier
@@ -221,7 +272,7 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
     LSTM_STAMP(2);   // quad reduce + wait for the prefetched pre-activation
     // re-issue into the SAME register only now that its old value is dead (no back-edge copy, so
     // the load really stays in flight for two steps)
-    gxr = buf_load(gbuf, gl + fr(t + 2) * gstride4);
+    gxr = gload(gl + fr(t + 2) * gstride4);
     const float act = act_affine(pre, a_scale, a_mul, a_add);
     // forward_statemem (clstm_compute.cc:504-508): c = ci*gi + gf*c_prev with the quad broadcasts folded into
     // the arithmetic (v_mul_f32_dpp, v_fmac_f32_dpp); c_prev = 0 at t = 0 makes the second term an exact +0, so
@@ -238,29 +289,53 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
       // store FROM the pinned registers: a VMEM store reads its data late, and a copy of the value in a register
       // that the next step's LDS reads overwrite would put s_waitcnt vmcnt(0) at the top of every step
       OPAQUE(ka0); OPAQUE(ka1); OPAQUE(ka2);
-      flush(t, ka0, ka1, ka2);
+      flush(t, ka0, ka1, ka2, report_tag);
     }
     LSTM_STAMP(5);   // LDS write issued
+    if constexpr (POLL) {
+      // behind this barrier the workgroup issues, in step t + 1, the loads for iteration t + 3: chunk (t + 3) >> 4 must
+      // be there.  Its flag was requested two steps ago; if it is not up yet, hold the barrier.  (Chunk 0 is the
+      // workgroup's own: no flag.)
+      const int c = (t + 3) >> 4;
+      if (c > 0 && __builtin_expect(wave_uniform(rdy) != a.gepoch, 0)) wait_chunk(c < nchunk ? c : nchunk - 1);
+      const int cn = (t + 5) >> 4;
+      rdy = load_i32_wt(gfl + (cn < nchunk ? cn : nchunk - 1));
+    }
     __syncthreads();
     LSTM_STAMP(6);   // barrier
   };
   int t = 0;
   for (; t + 1 < T; t += 2) {
-    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kaB0, kaB1, kaB2);
-    step(t + 1, gxB, rdB, wrB, kaB0, kaB1, kaB2, kaA0, kaA1, kaA2);
+    step(t, gxA, rdyA, rdA, wrA, kaA0, kaA1, kaA2, kaB0, kaB1, kaB2);
+    step(t + 1, gxB, rdyB, rdB, wrB, kaB0, kaB1, kaB2, kaA0, kaA1, kaA2);
   }
   if (t < T) {
-    step(t, gxA, rdA, wrA, kaA0, kaA1, kaA2, kaB0, kaB1, kaB2);
-    if constexpr (!EARLY) flush(t, kaA0, kaA1, kaA2);
+    step(t, gxA, rdyA, rdA, wrA, kaA0, kaA1, kaA2, kaB0, kaB1, kaB2);
+    if constexpr (!EARLY) flush(t, kaA0, kaA1, kaA2, report_tag);
   } else {
-    if constexpr (!EARLY) flush(t - 1, kaB0, kaB1, kaB2);
+    if constexpr (!EARLY) flush(t - 1, kaB0, kaB1, kaB2, report_tag);
   }
   };
-  if (early) run(std::true_type{}); else run(std::false_type{});
+  if constexpr (FUSED) {
+    if (wave_uniform(wave) == 3) run(std::true_type{}, std::true_type{}, std::false_type{});
+    else if (early) run(std::true_type{}, std::false_type{}, std::false_type{});
+    else if (wave_uniform(wave) == (nthreads >> 6) - 1) run(std::false_type{}, std::false_type{}, std::true_type{});
+    else run(std::false_type{}, std::false_type{}, std::false_type{});
+    // the line is complete: every store of every wave acknowledged, then the final word
+    drain_vmem();
+    __syncthreads();
+    if (tid == 0) store_i32_wt(reinterpret_cast<int*>(a.H + a.prog_off) + ((size_t)dir * a.bs + b) * PROG_STRIDE, a.prog_base + T);
+  } else {
+    if (early) run(std::true_type{}, std::false_type{}, std::false_type{}); else run(std::false_type{}, std::false_type{}, std::false_type{});
+  }
 #ifdef CLSTM_LSTM_PROF
   if (a.prof && b == 0 && dir == 0 && lane == 0)
     for (int k = 0; k < 8; k++) a.prof[wave * 8 + k] = pacc[k];
 #endif
+}
+template <int NK4, int KU>
+__global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_kernel(LstmSeqArgs a) {
+  lstm_fwd_body<NK4, KU, false>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, blockIdx.y, nullptr);
 }
 
 template <int NK4, int KU>

@@ -273,13 +273,39 @@ DEVFN void pack_rb(size_t e, const float* v, float* Rb, const PackDesc& p) {
   }
   Rb[e] = x;
 }
-__global__ void k_pack_layer(const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p) {
+// k-contiguous packs for the wave-sized items of the fused forward launch (lstm_fwd_fused.h), zero padded:
+//   Wk[dir][m = 4*cell + slot][k]   = W_slot[cell][k] (input columns only), njp*16 rows of kp floats per direction
+//   W1k[c][k]                       = W1[c][1 + k], 96 rows of kps floats (softmax layer, sm_off = its flat offset)
+struct PackFused {
+  float* Wk; int kp, njp;
+  float* W1k; int kps, nc, sm_k; long long sm_off;
+};
+DEVFN size_t pack_fused_count(const PackFused& f, const PackDesc& p) {
+  return f.Wk ? (size_t)p.ndir * f.njp * 16 * f.kp + (size_t)96 * f.kps : 0;
+}
+DEVFN void pack_fused(size_t e, const float* v, const PackFused& f, const PackDesc& p) {
+  const size_t nwk = (size_t)p.ndir * f.njp * 16 * f.kp;
+  if (e < nwk) {
+    const int k = e % f.kp;
+    const size_t r = e / f.kp;
+    const int m = r % (f.njp * 16), dir = r / (f.njp * 16);
+    const int cell = m >> 2, slot = m & 3;
+    f.Wk[e] = (cell < p.no && k < p.ni) ? v[p.p_off[dir][slot] + cell + (size_t)p.no * (1 + k)] : 0.0f;
+  } else {
+    const size_t e2 = e - nwk;
+    const int k = e2 % f.kps, c = e2 / f.kps;
+    f.W1k[e2] = (c < f.nc && k < f.sm_k) ? v[f.sm_off + c + (size_t)f.nc * (1 + k)] : 0.0f;
+  }
+}
+__global__ void k_pack_layer(const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p, PackFused pf) {
   const size_t nwx = (size_t)(1 + p.ni) * p.ndir * 4 * p.no;
   const size_t nr = (size_t)p.ndir * 4 * 4 * p.nk4 * p.nthreads;
-  CLSTM_GRID_STRIDE(e, nwx + 2 * nr) {
+  const size_t nf = pack_fused_count(pf, p);
+  CLSTM_GRID_STRIDE(e, nwx + 2 * nr + nf) {
     if (e < nwx) pack_wx(e, v, Wt, bias, p);
     else if (e < nwx + nr) pack_rf(e - nwx, v, Rf, p);
-    else pack_rb(e - nwx - nr, v, Rb, p);
+    else if (e < nwx + 2 * nr) pack_rb(e - nwx - nr, v, Rb, p);
+    else pack_fused(e - nwx - 2 * nr, v, pf, p);
   }
 }
 // k-contiguous, zero-padded recurrent weights of the lock-step recurrence (lstm_wide.h):
@@ -466,7 +492,7 @@ __global__ void k_transpose_to_bf16(const float* src, unsigned short* dst, int r
 // the last pack -- every training step): blocks [0, nbi) ingest, the rest repack.  The two jobs are independent
 // and each is far too small to fill the chip, so one launch ramp / tail instead of two.
 __global__ void k_ingest_pack(const float* x, float* X, float* S, size_t N, int ni, int lds, int ndir, long long sdir,
-                              int nbi, int nbp, const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p,
+                              int nbi, int nbp, const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p, PackFused pf,
                               const int* lo_src, int* lo_dst, int lo_n, const int* aux_src, int* aux_dst, int aux_n) {
   if ((int)blockIdx.x >= nbi + nbp) {   // optional trailing blocks: small host arrays, straight from their pinned slots
     // (one element per thread: a read of host memory takes microseconds, so they must all be in flight at once)
@@ -496,10 +522,12 @@ __global__ void k_ingest_pack(const float* x, float* X, float* S, size_t N, int 
   } else {
     const size_t nwx = (size_t)(1 + p.ni) * p.ndir * 4 * p.no;
     const size_t nr = (size_t)p.ndir * 4 * 4 * p.nk4 * p.nthreads;
-    for (size_t e = (size_t)(blockIdx.x - nbi) * blockDim.x + threadIdx.x; e < nwx + 2 * nr; e += (size_t)nbp * blockDim.x) {
+    const size_t nf = pack_fused_count(pf, p);
+    for (size_t e = (size_t)(blockIdx.x - nbi) * blockDim.x + threadIdx.x; e < nwx + 2 * nr + nf; e += (size_t)nbp * blockDim.x) {
       if (e < nwx) pack_wx(e, v, Wt, bias, p);
       else if (e < nwx + nr) pack_rf(e - nwx, v, Rf, p);
-      else pack_rb(e - nwx - nr, v, Rb, p);
+      else if (e < nwx + 2 * nr) pack_rb(e - nwx - nr, v, Rb, p);
+      else pack_fused(e - nwx - 2 * nr, v, pf, p);
     }
   }
 }

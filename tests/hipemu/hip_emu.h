@@ -247,6 +247,8 @@ inline f32x4 buf_load4_dev(BufF32 b, unsigned off) { return buf_load4(b, off); }
 #define COMPILER_MEMORY_BARRIER() asm volatile("" ::: "memory")
 inline void buf_store_wt(BufF32 b, unsigned off, float v) { buf_store(b, off, v); }
 inline f32x4 buf_load4_wt(BufF32 b, unsigned off) { return buf_load4(b, off); }
+inline float buf_load_wt(BufF32 b, unsigned off) { return buf_load(b, off); }
+inline void buf_store4_wt(BufF32 b, unsigned off, f32x4 v) { for (int i = 0; i < 4; i++) buf_store(b, off + 4 * i, v[i]); }
 inline int load_i32_wt(const int* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 inline void store_i32_wt(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 inline void atomic_add_i32(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
@@ -262,7 +264,7 @@ inline void sleep_some() { emu_yield(); sched_yield(); }
 inline void poll_pause() { emu_yield(); sched_yield(); }
 inline void sleep_iterations(int) { emu_yield(); sched_yield(); }
 inline int wave_max_i(int x) { for (int m = 32; m >= 1; m >>= 1) { const int y = wave_shfl_i(x, emu_lane() ^ m); x = y > x ? y : x; } return x; }
-inline void drain_vmem() {}
+inline void drain_vmem() { emu_wave_sync(); }   // hardware: covers every lane of the wave -- here the lanes are fibers that run apart
 inline unsigned mad_u24(unsigned a, unsigned b, unsigned c) { return a * b + c; }
 template <typename T> inline T* dyn_smem() { return reinterpret_cast<T*>(emu_blk->smem); }
 

@@ -15,7 +15,7 @@ DELTAS = ("d_gi", "d_gf", "d_go", "d_ci")
 
 
 def run_case(backend, ora32, ni, nh, nc, T, uni=False, scale=30.0, seed=1, lr=1e-2, check_dx=False,
-             ctc_rtol=1e-4, grad_tol=1e-4):
+             ctc_rtol=1e-4, grad_tol=1e-4, overlap=None):
     from clstm_amd.net import Network
     rng = np.random.default_rng(seed)
     nhl = nh if isinstance(nh, list) else [nh]
@@ -30,6 +30,8 @@ def run_case(backend, ora32, ni, nh, nc, T, uni=False, scale=30.0, seed=1, lr=1e
     net = Network(ni, nh, nc, unidirectional=uni, lib=backend.lib)
     net.set_params(params)
     net.setLearningRate(lr, 0.9)
+    if overlap is not None:
+        net.set_overlap(overlap)
     if check_dx:
         net.enable_input_deltas(True)
     net.set_inputs(lines)
@@ -71,6 +73,19 @@ def run_case(backend, ora32, ni, nh, nc, T, uni=False, scale=30.0, seed=1, lr=1e
 ])
 def test_bidi_small(backend, ora32, ni, nh, nc, T):
     run_case(backend, ora32, ni, nh, nc, T)
+
+
+@pytest.mark.parametrize("nh,T", [(100, [40, 23, 1, 70]), (90, [33, 17])])
+def test_forward_as_one_launch(backend, ora32, nh, T):
+    """The forward half as ONE launch with three workgroup roles (lstm_fwd_fused.h): producer waves compute the gate
+    pre-activations chunk by chunk ahead of the recurrence, consumer waves the softmax of finished frames behind it.
+    Forced onto short lines (overlap mode 2; the default takes it for minibatches of >= 2048 frames): every saved
+    activation, the softmax outputs, decodes, CTC and the gradient against the oracle, and the path must really have run.
+    On the emulator all workgroups of the launch are live at once (one OS thread each), so flags and progress words are
+    exercised as a protocol, not as a sequence of kernels."""
+    before = _path_count(backend, 5)
+    run_case(backend, ora32, 48, nh, 83, T, scale=10.0, overlap=2)
+    assert _path_count(backend, 5) > before
 
 
 def test_bidi_uw3_shape_short(backend, ora32):
