@@ -1410,8 +1410,9 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
   for (int b = 0; b < bs; b++) {
     const long long T = line_off_h[b + 1] - line_off_h[b], S = state_off_h[b + 1] - state_off_h[b];
     REQUIRE(T >= 0 && S >= 0, "bad offsets");
-    REQUIRE(S <= CTC_GROUP * CTC_RMAX, "more than 2048 target states (a transcript of more than 1023 labels) per line is not supported");
-    lo[b + 1] = lo[b] + 3 * T * S;
+    // three lattices; lines of more than CTC_SMAX_LDS states keep their per-state totals (S doubles) behind them
+    lo[b + 1] = lo[b] + 3 * T * S + (S > CTC_SMAX_LDS ? 2 * S + 2 : 0);
+    lo[b + 1] += lo[b + 1] & 1;   // (8-byte alignment of those doubles)
   }
   const int ns = state_off_h[bs];
   for (int i = 0; i < ns; i++) REQUIRE(states_h[i] >= 0 && states_h[i] < nc, "target class out of range");
@@ -1459,6 +1460,7 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
     smax = std::max(smax, state_off_h[b + 1] - state_off_h[b]);
     tmax = std::max(tmax, line_off_h[b + 1] - line_off_h[b]);
   }
+  if (smax > CTC_SMAX_LDS) smax = CTC_SMAX_LDS;     // (longer lines do not use the per-state LDS arrays)
   a.smax = smax;
   a.ncp = nc | 1;                                   // odd row stride: conflict-free row-per-lane access
   // frames per LDS tile: what the 160 KiB carve leaves after the tables and the per-state vectors

@@ -33,8 +33,11 @@ namespace clstm {
 
 constexpr int CTC_THREADS = 512;   // waves 0-3: forward recursion, waves 4-7: reversed-lattice recursion
 constexpr int CTC_GROUP = 256;     // lanes per recursion when S > 64
-constexpr int CTC_RMAX = 8;        // up to 2048 target states per line (transcripts of up to 1023 labels); lines with
-                                   // <= 512 states run the 2-states-per-lane instantiation
+constexpr int CTC_RMAX = 8;        // register-resident recursion: up to 2048 target states per line (transcripts of up to
+                                   // 1023 labels; <= 512 states run the 2-states-per-lane instantiation).  Longer
+                                   // transcripts -- the reference has no limit (ctc.cc:57-112) -- take ctc_lattice_huge:
+                                   // states in rounds of 256 per frame, the previous row read back from the lattice
+constexpr int CTC_SMAX_LDS = CTC_GROUP * CTC_RMAX;   // the per-state LDS arrays are carved for at most this many states
 constexpr int CTC_MLP = 8;         // independent global loads a thread keeps in flight in the streaming phases
 constexpr int CTC_MAX_TILE = 256;  // frames per LDS tile (phases A and E)
 
@@ -209,6 +212,32 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, float* 
     if (i < T) step(i, lmA, kaA);
     };
     if (R <= 2) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, CTC_RMAX>{});
+  }
+}
+
+// Phase B for lines of more than CTC_SMAX_LDS states: the same recursion (forward_algorithm, ctc.cc:24-40, on the
+// lattice and on its (t,s)-reversed image), every group of 256 lanes walking the label axis in rounds; the previous
+// frame's row is read back from the output lattice (system-scope accesses + one barrier per frame: the rows are written
+// and read by different waves).  Correctness path, not a tuned one: such transcripts exceed 1023 labels.
+DEVFN void ctc_lattice_huge(const float* lm, float* al, float* be, const CrTables tb, const int T, const int S) {
+  const int tid = threadIdx.x;
+  const int grp = tid >> 8, u = tid & (CTC_GROUP - 1);
+  const bool rev = grp == 1;
+  const size_t latbytes = (size_t)T * S * 4;
+  const BufF32 lmb = make_buf(lm, latbytes), outb = make_buf(rev ? be : al, latbytes);
+  auto loff = [&](int i, int j) -> unsigned {
+    return (unsigned)(rev ? (size_t)(T - 1 - i) * S + (S - 1 - j) : (size_t)i * S + j) * 4u;
+  };
+  __syncthreads();
+  for (int i = 0; i < T; i++) {
+    for (int j = u; j < S; j += CTC_GROUP) {
+      const float lmv = buf_load(lmb, loff(i, j));
+      const float vj = i == 0 ? (float)(-5.0 * j) : buf_load_wt(outb, loff(i - 1, j));
+      const float w = j == 0 ? (float)(-5.0 * i) : (i == 0 ? (float)(-5.0 * (j - 1)) : buf_load_wt(outb, loff(i - 1, j - 1)));
+      buf_store_wt(outb, loff(i, j), ctc_log_add(vj + lmv, w + lmv, tb));
+    }
+    drain_vmem();
+    __syncthreads();
   }
 }
 
@@ -624,8 +653,16 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
     ctc_short_line(a, lds, L, tb, b, off, T, S, treg, preg, flat);
     return;
   }
-  if (tid < S) stl[tid] = st0;
-  for (int s = tid + CTC_THREADS; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
+  // lines of more than CTC_SMAX_LDS states: the per-state arrays do not fit the LDS carve -- target states are read from
+  // memory, the per-state totals live behind the line's lattice, the projection reads the lattice directly
+  const bool huge = S > CTC_SMAX_LDS;
+  const int* stg = a.states + soff;
+  double* totg = reinterpret_cast<double*>(lm + (((size_t)3 * T * S + 1) & ~(size_t)1));   // (8-byte aligned: lat_off is even)
+  if (!huge) {
+    if (tid < S) stl[tid] = st0;
+    for (int s = tid + CTC_THREADS; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
+  }
+  auto state_at = [&](int s) -> int { return huge ? stg[s] : stl[s]; };
 #pragma unroll
   for (int k = 0; k < CTC_TREG; k++)
     if (tid + k * CTC_THREADS < CTC_TABLE_DOUBLES) tabs[tid + k * CTC_THREADS] = treg[k];
@@ -669,7 +706,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const bool in = i0 + u * CTC_THREADS < nt * S;
-          o[u] = in ? rowbuf[tq * ncp + stl[sq]] / asum[tq] : 1.0f;
+          o[u] = in ? rowbuf[tq * ncp + state_at(sq)] / asum[tq] : 1.0f;
           tq += dq; sq += dr;
           if (sq >= S) { sq -= S; tq++; }
         }
@@ -685,7 +722,8 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   CTC_STAMP(1);
 
   // ---- B: forward recursion and the same recursion on the (t,s)-reversed lattice
-  ctc_lattice<false>(lm, al, be, vx, nullptr, tb, T, S);
+  if (huge) ctc_lattice_huge(lm, al, be, tb, T, S);
+  else ctc_lattice<false>(lm, al, be, vx, nullptr, tb, T, S);
   __syncthreads();
   CTC_STAMP(2);
 
@@ -728,10 +766,11 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   //         (float)((double)x * (1/total)): equal to the reference's (Float)(x/total) except for
   //         ~1e-8 of the values (1 ulp of double before the rounding to float) -----------------------
   if (S > CTC_THREADS) {   // long transcripts (more states than threads): one thread per state, states in rounds
+    double* td = huge ? totg : tot;
     for (int s = tid; s < S; s += CTC_THREADS) {
       double acc = 0.0;
       for (int t = 0; t < T; t++) acc += (double)al[(size_t)t * S + s];
-      tot[s] = 1.0 / fmax(1e-9, acc);
+      td[s] = 1.0 / fmax(1e-9, acc);
     }
     __syncthreads();
   } else {
@@ -757,7 +796,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   const int sp = S | 1;
   for (int t0 = 0; t0 < T; t0 += TT) {
     const int nt = (T - t0) < TT ? (T - t0) : TT;
-    for (int s0 = lane; s0 < S; s0 += 64) {  // coalesced staging of the lattice tile, CTC_MLP frames in flight
+    for (int s0 = lane; s0 < S && !huge; s0 += 64) {  // coalesced staging of the lattice tile, CTC_MLP frames in flight
       const double it = tot[s0];
       for (int t = wave; t < nt; t += CTC_MLP * (CTC_THREADS / 64)) {
         float x[CTC_MLP];
@@ -779,9 +818,10 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
       float* row = rowbuf + tid * ncp;
       double blank = 0.0;  // class 0 collects L+1 states: keep the reference's double accumulator
       const float* e = etile + tid * sp;
+      const float* ag = al + (size_t)(t0 + tid) * S;
       for (int s0 = 0; s0 < S; s0++) {
-        const int c = stl[s0];
-        const float x = e[s0];
+        const int c = state_at(s0);
+        const float x = huge ? (float)((double)ag[s0] * totg[s0]) : e[s0];
         if (c == 0) blank += (double)x;
         else row[c] += x;   // (ds_add_f32 instead was measured 40 % slower for this phase)
       }

@@ -381,8 +381,43 @@ def test_ctc_long_transcripts(backend, ora32, T, L):
     want = ora32.ctc_align_classes(p.astype(np.float32), st)
     assert_close(al, want, rtol=1e-4, atol=1e-6, what="aligned, %d states" % st.size)
     assert_close(dz, want - p, rtol=1e-4, atol=2e-6, what="delta, %d states" % st.size)
-    with pytest.raises(Exception, match="2048"):
-        ctc_via_abi(backend, [p.astype(np.float32)], [ora32.mktargets(rng.integers(1, nc, 1100))])
+
+
+@pytest.mark.parametrize("T,L", [(16, 300), (10, 600), (20, 256)])
+def test_ctc_many_states_on_a_short_lattice(backend, ora32, T, L):
+    """T * S <= 12288 with S > 512: the lattice would fit the short-line path's LDS tile, but that path classifies one
+    target state per thread -- such lines must take the tiled path (an earlier version did not: max error 0.43)."""
+    rng = np.random.default_rng(T * 1000 + L)
+    nc = 40
+    p = rng.random((T, nc)).astype(np.float32) ** 2
+    p /= p.sum(1, keepdims=True)
+    st = ora32.mktargets(rng.integers(1, nc, L))
+    assert T * st.size <= 12288 and st.size > 512
+    al, dz, _ = ctc_via_abi(backend, [p.astype(np.float32)], [st])
+    want = ora32.ctc_align_classes(p.astype(np.float32), st)
+    assert_close(al, want, rtol=1e-4, atol=1e-6, what="aligned, %d states on %d frames" % (st.size, T))
+    assert_close(dz, want - p, rtol=1e-4, atol=2e-6, what="delta")
+
+
+@pytest.mark.parametrize("T,L", [(40, 1030), (7, 1500), pytest.param(2300, 1100, marks=pytest.mark.gpu)])
+def test_ctc_unbounded_label_axis(backend, ora32, T, L):
+    """More than 2048 target states per line (transcripts of more than 1023 labels): the reference's ctc_align_targets has
+    no limit (ctc.cc:57-112).  Such lines take the kernel's round-by-round recursion with the per-state totals in memory;
+    a minibatch mixes one with an ordinary line (the LDS carve is sized for the ordinary ones)."""
+    if T > 1000 and backend.kind == "emu":
+        pytest.skip("GPU-sized case")
+    rng = np.random.default_rng(L)
+    nc = 30
+    ps, sts = [], []
+    for (t, l) in ((T, L), (25, 6)):
+        p = rng.random((t, nc)).astype(np.float32) ** 2
+        p /= p.sum(1, keepdims=True)
+        ps.append(p.astype(np.float32)); sts.append(ora32.mktargets(rng.integers(1, nc, l)))
+    assert sts[0].size > 2048
+    al, dz, _ = ctc_via_abi(backend, ps, sts)
+    want = np.concatenate([ora32.ctc_align_classes(p, st) for p, st in zip(ps, sts)], 0)
+    assert_close(al, want, rtol=1e-4, atol=1e-6, what="aligned, %d states" % sts[0].size)
+    assert_close(dz, want - np.concatenate(ps, 0), rtol=1e-4, atol=2e-6, what="delta")
 
 
 def test_ctc_more_states_than_frames(backend, ora32):
