@@ -542,9 +542,70 @@ struct Comm {
   ~Comm() { if (comm) (void)RcclApi::get().CommDestroy(comm); }
 };
 #else
-struct Comm {   // emulator: a single rank only (the world-size-2 CPU tests exchange through gloo in Python)
+}  // namespace clstm
+#include <atomic>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+namespace clstm {
+// Host emulator: the ranks are host PROCESSES and the communicator is a POSIX shared-memory segment (one slot of
+// SLOT floats per rank + a sense-reversing barrier) -- so that the world-size-2 CPU test drives the same entry points
+// and the same in-library order (all-reduce of g -> d += g -> update) as the RCCL build.  Every rank sums the slots in
+// rank order: bit-identical results on all ranks, like a deterministic all-reduce.
+struct Comm {
+  static const long long SLOT = 1 << 18;
+  struct Shm { std::atomic<int> magic, arrived, gen; int pad; float slots[1]; };
   int rank = 0, nranks = 1;
-  void allreduce(float*, long long, hipStream_t) {}
+  Shm* shm = nullptr;
+  size_t bytes = 0;
+  std::string name;
+  void open(const char* id, int rank_, int nranks_) {
+    rank = rank_; nranks = nranks_;
+    if (nranks == 1) return;
+    name.assign(id, strnlen(id, CLSTM_COMM_ID_BYTES));
+    REQUIRE(!name.empty() && name[0] == '/', "emulator communicator: bad id");
+    bytes = sizeof(Shm) + (size_t)nranks * SLOT * sizeof(float);
+    int fd = -1;
+    if (rank == 0) {
+      fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      REQUIRE(fd >= 0 && ftruncate(fd, (off_t)bytes) == 0, "emulator communicator: cannot create the shared segment");
+    } else {
+      for (int tries = 0; tries < 20000 && fd < 0; tries++) { fd = shm_open(name.c_str(), O_RDWR, 0600); if (fd < 0) usleep(1000); }
+      REQUIRE(fd >= 0, "emulator communicator: rank 0's segment did not appear");
+      struct stat st;
+      for (int tries = 0; tries < 20000; tries++) { if (fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break; usleep(1000); }
+    }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    REQUIRE(p != MAP_FAILED, "emulator communicator: mmap failed");
+    shm = (Shm*)p;
+    if (rank == 0) { shm->arrived.store(0); shm->gen.store(0); shm->magic.store(0x434c5354); }
+    else for (int tries = 0; shm->magic.load() != 0x434c5354; tries++) { REQUIRE(tries < 20000, "emulator communicator: rank 0 never initialised the segment"); usleep(1000); }
+    barrier();
+    if (rank == 0) shm_unlink(name.c_str());   // every rank has it mapped: the name can go
+  }
+  void barrier() {
+    const int g = shm->gen.load();
+    if (shm->arrived.fetch_add(1) + 1 == nranks) { shm->arrived.store(0); shm->gen.store(g + 1); }
+    else while (shm->gen.load() == g) sched_yield();
+  }
+  void allreduce(float* buf, long long n, hipStream_t) {
+    if (nranks == 1) return;
+    for (long long o = 0; o < n; o += SLOT) {
+      const long long m = std::min(SLOT, n - o);
+      memcpy(shm->slots + (size_t)rank * SLOT, buf + o, (size_t)m * sizeof(float));
+      barrier();
+      for (long long i = 0; i < m; i++) {
+        float acc = shm->slots[i];
+        for (int r = 1; r < nranks; r++) acc += shm->slots[(size_t)r * SLOT + i];
+        buf[o + i] = acc;
+      }
+      barrier();
+    }
+  }
+  ~Comm() { if (shm) munmap(shm, bytes); }
 };
 #endif
 
@@ -2024,7 +2085,9 @@ int clstm_comm_unique_id(char* id_h) {
   RCCLCHECK(RcclApi::get().GetUniqueId(&id));
   memcpy(id_h, &id, sizeof(id));
 #else
+  static int counter = 0;
   memset(id_h, 0, CLSTM_COMM_ID_BYTES);
+  snprintf(id_h, CLSTM_COMM_ID_BYTES, "/clstm_emu_%d_%d", (int)getpid(), counter++);   // name of the shared segment
 #endif
   ABI_END
 }
@@ -2040,7 +2103,7 @@ int clstm_comm_create(clstm_comm** out, const char* id_h, int rank, int nranks) 
     RCCLCHECK(RcclApi::get().CommInitRank(&c->c.comm, nranks, id, rank));
   } catch (...) { delete c; throw; }
 #else
-  if (nranks != 1) { delete c; throw Error("the host emulator has no RCCL: single rank only"); }
+  try { c->c.open(id_h, rank, nranks); } catch (...) { delete c; throw; }
 #endif
   *out = c;
   ABI_END

@@ -1,5 +1,8 @@
-"""world_size-2 data-parallel step on CPU: gloo all-reduce of the fresh-gradient buffer, the
-kernels running through the host emulator.  Checks (a) both ranks end bit-identical, (b) the
+"""world_size-2 data-parallel step on CPU through the LIBRARY's communicator entry points (clstm_comm_create,
+clstm_net_set_comm; the emulator build backs them with a shared-memory all-reduce between the rank processes, the GPU
+build with RCCL): the in-library order all-reduce of g -> d += g -> update is what runs, the kernels through the host
+emulator; gloo only carries the 128-byte communicator id.  A second case keeps the torch.distributed fallback of
+clstm_amd/parallel.py alive.  Checks (a) both ranks end bit-identical, (b) the
 result equals the single-process oracle minibatch over ALL lines, including the second step where
 the carried momentum (Params.d, clstm_compute.cc:560-563) must NOT be multiplied by the replica
 count (the share_deltas artefact, clstm.cc:731-744 / SURVEY.md §8e)."""
@@ -22,7 +25,7 @@ def make_data(step):
     return lines, trs
 
 
-def worker(rank, world, port, outdir):
+def worker(rank, world, port, outdir, use_lib_comm):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -42,24 +45,40 @@ def worker(rank, world, port, outdir):
     net = Network(NI, NH, NC, lib=lib, params=params, derivs=derivs, grads=grads)
     net.params_changed()
     net.setLearningRate(5e-2, 0.9)
-    tr = Trainer(net, grads_tensor=grads)
-    assert tr.world_size() == world
+    if use_lib_comm:
+        from clstm_amd.net import Comm
+
+        def exchange(ident):
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = Comm(rank, world, exchange, lib=lib)
+        assert lib.call("clstm_comm_size", comm.h) == world and lib.call("clstm_comm_rank", comm.h) == rank
+        tr = Trainer(net, comm=comm)
+        assert tr.dist is None            # nothing goes through torch.distributed in the step
+    else:
+        tr = Trainer(net, grads_tensor=grads)
+        assert tr.world_size() == world
     for step in range(2):
         lines, trs = make_data(step)
         tr.train(shard(lines, rank, world), shard(trs, rank, world))
     np.save(os.path.join(outdir, "params_%d.npy" % rank), params.numpy())
     np.save(os.path.join(outdir, "derivs_%d.npy" % rank), derivs.numpy())
+    if use_lib_comm:
+        net.set_comm(None)
+        comm.close()
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_matches_single_process(tmp_path, ora32):
+@pytest.mark.parametrize("use_lib_comm", [True, False], ids=["library_communicator", "torch_distributed_fallback"])
+def test_two_rank_data_parallel_matches_single_process(tmp_path, ora32, use_lib_comm):
     import torch.multiprocessing as mp
     from common import assert_close, emu_lib
     from clstm_amd.init import init_params
     from oracle.oracle import OracleNet
     emu_lib()                                   # build once, before the workers race for it
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(worker, args=(2, port + int(use_lib_comm), str(tmp_path), use_lib_comm), nprocs=2, join=True)
     p = [np.load(tmp_path / ("params_%d.npy" % r)) for r in range(2)]
     d = [np.load(tmp_path / ("derivs_%d.npy" % r)) for r in range(2)]
     assert np.array_equal(p[0], p[1]) and np.array_equal(d[0], d[1])     # replicas stay identical
@@ -87,3 +106,77 @@ def test_shard_covers_everything():
     import pytest
     with pytest.raises(ValueError):
         shard([1, 2], 0, 4)
+
+
+def gpu_worker(rank, world, port, outdir):
+    """one rank per GPU: the library's RCCL communicator (clstm_comm_create + clstm_net_set_comm), gloo for the id"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from clstm_amd import abi
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Comm, Network
+    from clstm_amd.parallel import Trainer, shard
+    lib = abi.load()
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    lib.call("clstm_set_stream", stream.cuda_stream)
+    dev = torch.device("cuda", rank)
+    p0 = init_params(NI, NH, NC, seed=0.222) * 30
+    params = torch.from_numpy(p0.copy()).to(dev)
+    derivs = torch.zeros_like(params)
+    grads = torch.zeros_like(params)
+    net = Network(NI, NH, NC, lib=lib, params=params, derivs=derivs, grads=grads)
+    net.params_changed()
+    net.setLearningRate(5e-2, 0.9)
+
+    def exchange(ident):
+        box = [ident]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    comm = Comm(rank, world, exchange, lib=lib)
+    tr = Trainer(net, comm=comm)
+    for step in range(2):
+        lines, trs = make_data(step)
+        tr.train(shard(lines, rank, world), shard(trs, rank, world))
+    lib.call("clstm_synchronize")
+    np.save(os.path.join(outdir, "params_%d.npy" % rank), params.cpu().numpy())
+    np.save(os.path.join(outdir, "derivs_%d.npy" % rank), derivs.cpu().numpy())
+    net.set_comm(None)
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_gpus_library_communicator_matches_single_process(tmp_path, ora32):
+    """The same two-rank step on two MI355X through RCCL inside the library (ncclCommInitRank from clstm_comm_create,
+    ncclAllReduce on the library stream in front of k_update): replicas bit-identical, result = the oracle's
+    single-process minibatch.  Skips on a one-GPU box; lights up by itself where the driver has several."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % torch.cuda.device_count())
+    import torch.multiprocessing as mp
+    from common import assert_close
+    from clstm_amd.init import init_params
+    from oracle.oracle import OracleNet
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p = [np.load(tmp_path / ("params_%d.npy" % r)) for r in range(2)]
+    d = [np.load(tmp_path / ("derivs_%d.npy" % r)) for r in range(2)]
+    assert np.array_equal(p[0], p[1]) and np.array_equal(d[0], d[1])
+    ref = OracleNet(ora32, NI, NH, NC, init=False)
+    ref.set_params(init_params(NI, NH, NC, seed=0.222) * 30)
+    ref.set_lr(5e-2, 0.9)
+    for step in range(2):
+        lines, trs = make_data(step)
+        for x, t in zip(lines, trs):
+            ref.set_inputs(x); ref.forward(); ref.ctc_deltas(t); ref.backward()
+        ref.update()
+    assert_close(p[0], ref.get_params(), rtol=2e-5, atol=2e-7, what="params after 2 DP steps on 2 GPUs")
+    assert_close(d[0], ref.get_derivs(), rtol=1e-4, atol=1e-9, scale_atol=2e-4, what="momentum buffer after 2 DP steps on 2 GPUs")
