@@ -98,7 +98,7 @@ def cpu_baseline(params, cfg, seconds_target=12.0):
 class Workload:
     """One network + a small rotating pool of synthetic minibatches resident in HBM."""
 
-    def __init__(self, lib, cfg, minibatch, T, ragged, precision, dev, rank, comm=None, dist=None):
+    def __init__(self, lib, cfg, minibatch, T, ragged, precision, dev, rank, comm=None, dist=None, host_inputs=False):
         import torch
         from clstm_amd.init import init_params
         from clstm_amd.net import Network
@@ -120,12 +120,16 @@ class Workload:
         self.pool = []
         for _ in range(4):
             Ts, x, labels = synth_batch(rng, minibatch, T, ragged, cfg["ni"], cfg["nc"], cfg["L"])
-            self.pool.append((Ts, torch.from_numpy(x).to(dev), labels, Network.prepare_step(Ts, labels)))
+            xt = torch.from_numpy(x).pin_memory() if host_inputs else torch.from_numpy(x).to(dev)
+            self.pool.append((Ts, xt, labels, Network.prepare_step(Ts, labels)))
+        self.host_inputs = host_inputs
         self.one_call = self.trainer.dist is None     # single GPU or library communicator: clstm_net_train_step
 
     def step(self, i):
         Ts, xd, labels, prep = self.pool[i % len(self.pool)]
-        if self.one_call:
+        if self.host_inputs:
+            self.net.train_step_host(prep, xd)         # frames in (pinned) host memory: copy stream + double-buffered device input
+        elif self.one_call:
             self.net.train_step_prepared(prep, xd)     # CLSTMOCR::train for the minibatch: one C-ABI call, no host sync
         else:
             self.trainer.step_device(Ts, xd, labels)
@@ -289,6 +293,9 @@ def main():
                     help="--bf16-gemm plus bf16 MFMA operands inside the lock-step recurrence of wide layers "
                          "(BASELINE configs[4]: '2 x BiLSTM(512), bf16 MFMA'; not the parity path)")
     ap.add_argument("--ragged", action="store_true", help="T ~ U{150..250} instead of fixed T")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="frames start in pinned HOST memory every step (clstm_net_train_step_h): the PCIe-inclusive rate, "
+                         "not the headline `value` (bench contract: inputs resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[4] leg of the default line")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
@@ -297,7 +304,7 @@ def main():
     if args.T is None:
         args.T = cfg["T"]
     default_line = (args.config == "b1" and not args.bf16 and not args.bf16_gemm and not args.ragged
-                    and args.minibatch == 64 and args.T == 200)
+                    and args.minibatch == 64 and args.T == 200 and not args.host_inputs)
     if args.config != "b1":
         args.no_cpu_baseline = True     # the bounded CPU sample is defined for the headline workload only
 
@@ -393,7 +400,7 @@ def main():
         return {"dt": dt, "blocks": blocks, "enqueue": t_enq, "kern": kern, "frames_per_step": fps}
 
     precision = 2 if args.bf16 else 1 if args.bf16_gemm else 0
-    w = Workload(lib, cfg, args.minibatch, args.T, args.ragged, precision, dev, rank, comm=comm, dist=dist)
+    w = Workload(lib, cfg, args.minibatch, args.T, args.ragged, precision, dev, rank, comm=comm, dist=dist, host_inputs=args.host_inputs)
     m = measure(w, args.steps, args.warmup, args.profile_steps)
     dt = m["dt"]
     ms_per_step = dt / args.steps * 1e3
@@ -441,7 +448,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 MFMA operands (hoisted gate GEMMs and lock-step recurrence), f32 accumulate / state / softmax / CTC" if args.bf16
                       else "f32 (hoisted gate GEMMs: bf16 in, f32 accumulate)" if args.bf16_gemm else "f32"),
-            "data": "synthetic",
+            "data": "synthetic" + (" (frames fed from pinned host memory every step: PCIe-inclusive)" if args.host_inputs else ""),
             "config": {"workload": ("uw3-500 OCR shape: BiLSTM(100) H=48 nc=83, T=%s, L=25, minibatch=%d lines/GPU "
                                     "(BASELINE.json configs[2]; x%d GPUs = configs[3] sharding), fwd+CTC+bwd+allreduce+update"
                                     % ("U{150..250}" if args.ragged else args.T, args.minibatch, world))

@@ -95,6 +95,9 @@ _SIGS = {
     "clstm_net_kernel_time_ms": [_P, C.c_char_p, _P, _P],
     "clstm_net_reset_timing": [_P],
     "clstm_net_train_step": [_P, _P, _I, _P, _P, _P],
+    "clstm_net_train_step_h": [_P, _P, _I, _P, _P, _P],
+    "clstm_host_alloc": [_P, C.c_size_t],
+    "clstm_host_free": [_P],
     "clstm_net_n_states": [_P, _P],
     "clstm_net_get_states_h": [_P, _P, C.c_longlong],
     "clstm_net_set_states_h": [_P, _P, C.c_longlong],

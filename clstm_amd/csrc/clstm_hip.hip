@@ -25,6 +25,7 @@
 #include "ops.h"
 
 #include <algorithm>
+#include <sched.h>
 #include <cstring>
 #include <cstdlib>
 #include <map>
@@ -703,6 +704,20 @@ struct Net {
   int prog_base = 1024;           // grows with every backward launch: stale progress words never look complete
   long long dw_launches = 0;      // overlapped backward passes so far (tests check the path was taken)
   Comm* comm = nullptr;         // data-parallel ranks: all-reduce of g before the update (not owned)
+  // --- host-fed training steps (clstm_net_train_step_h): frames travel on a copy stream into one of two device input
+  // buffers while the previous step computes; the compute stream waits for the copy's event; a slot is rewritten only
+  // after the step that read it has ended -- that step's update kernel says so in a pinned host word (no event record on
+  // the compute stream: one costs ~5 us of stream time)
+  struct HostFeed {
+    hipStream_t cs = nullptr;
+    hipEvent_t copied[2] = {};
+    DevBuf<float> xin[2];
+    void* pin[2] = {nullptr, nullptr};     // staging for pageable sources
+    size_t pin_cap[2] = {0, 0};
+    int* step_done = nullptr;              // pinned: number of the last step whose update kernel has run
+    long long steps = 0;
+    bool ready = false;
+  } hf;
   // --- fused forward launch (lstm_fwd_fused.h): W_x GEMM producers + recurrence + softmax consumers ---
   float* W1k = nullptr;         // k-contiguous softmax rows (PackFused)
   int w1k_kps = 0;
@@ -803,6 +818,9 @@ struct Net {
       y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false;
     }
     (void)hipFree(W1k); fw_items.release(); fw_flags.release();
+    for (int i = 0; i < 2; i++) { hf.xin[i].release(); if (hf.pin[i]) (void)hipHostFree(hf.pin[i]); if (hf.copied[i]) (void)hipEventDestroy(hf.copied[i]); }
+    if (hf.step_done) (void)hipHostFree(hf.step_done);
+    if (hf.cs) (void)hipStreamDestroy(hf.cs);
     if (own_v) (void)hipFree(v);
     if (own_d) (void)hipFree(d);
     if (own_g) (void)hipFree(g);
@@ -1432,6 +1450,8 @@ struct Net {
     }
   }
 
+  int* update_step_word = nullptr;   // (host-fed steps) pinned word the update kernel writes update_step_id into
+  int update_step_id = 0;
   void update() {
     hipStream_t s = stream();
     if (comm) {   // sum of the ranks' fresh minibatch gradients, in place, on this stream (share_deltas, clstm.cc:731-744)
@@ -1440,7 +1460,8 @@ struct Net {
       timing.end(s);
     }
     timing.begin("sgd_update", s);
-    CLSTM_LAUNCH(k_update, dim3(nblocks(nparams)), dim3(256), 0, s, v, d, (const float*)g, (size_t)nparams, lr, mom, gclip, (const int*)dev_err_words());
+    CLSTM_LAUNCH(k_update, dim3(nblocks(nparams)), dim3(256), 0, s, v, d, (const float*)g, (size_t)nparams, lr, mom, gclip, (const int*)dev_err_words(), update_step_word, update_step_id);
+    update_step_word = nullptr;
     timing.end(s);
     check_launch();
     packed_dirty = true;
@@ -1914,6 +1935,61 @@ int clstm_net_train_step(clstm_net* h, const int* T_h, int bs, const float* x_d,
   h->net.update();   // all-reduces the fresh gradient first when a communicator is attached
   ABI_END
 }
+
+// host frames in, no host synchronisation: see Net::HostFeed
+int clstm_net_train_step_h(clstm_net* h, const int* T_h, int bs, const float* x_h, const int* labels_h, const int* L_h) {
+  ABI_BEGIN
+  REQUIRE(h && T_h && x_h && labels_h && L_h && bs > 0, "null argument");
+  Net& n = h->net;
+  Net::HostFeed& f = n.hf;
+  long long N = 0;
+  for (int b = 0; b < bs; b++) { REQUIRE(T_h[b] >= 0, "negative line length"); N += T_h[b]; }
+  REQUIRE(N > 0, "batch has no frames");
+  const size_t bytes = (size_t)N * n.desc.ninput * sizeof(float);
+  if (!f.ready) {
+    f.ready = true;
+    HIPCHECK(hipStreamCreateWithFlags(&f.cs, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) HIPCHECK(hipEventCreateWithFlags(&f.copied[i], hipEventDisableTiming));
+    HIPCHECK(hipHostMalloc((void**)&f.step_done, 64));
+    *f.step_done = 0;
+  }
+  const long long k = ++f.steps;              // this step's number (1, 2, ...)
+  const int slot = (int)(k & 1);
+  // the slot was read by step k - 2: its update kernel has run when the pinned word says so (the host is at most a few
+  // steps ahead of the GPU, so this rarely waits)
+  while (k > 2 && (int)((unsigned)(k - 2) - (unsigned)__atomic_load_n(f.step_done, __ATOMIC_ACQUIRE)) > 0) sched_yield();   // (wrap-safe)
+  f.xin[slot].reserve((size_t)N * n.desc.ninput + 64);
+  const void* src = x_h;
+#ifndef CLSTM_HIP_EMU
+  hipPointerAttribute_t attr;
+  const bool pinned = hipPointerGetAttributes(&attr, x_h) == hipSuccess && attr.type == hipMemoryTypeHost;
+  if (!pinned) {   // pageable memory: one host copy into the slot's pinned staging buffer, then the same DMA
+    (void)hipGetLastError();
+    if (f.pin_cap[slot] < bytes) {
+      if (f.pin[slot]) HIPCHECK(hipHostFree(f.pin[slot]));
+      f.pin_cap[slot] = bytes + bytes / 4;
+      HIPCHECK(hipHostMalloc(&f.pin[slot], f.pin_cap[slot]));
+    }
+    memcpy(f.pin[slot], x_h, bytes);
+    src = f.pin[slot];
+  }
+#endif
+  HIPCHECK(hipMemcpyAsync(f.xin[slot].p, src, bytes, hipMemcpyHostToDevice, f.cs));
+  HIPCHECK(hipEventRecord(f.copied[slot], f.cs));
+  HIPCHECK(hipStreamWaitEvent(g_stream, f.copied[slot], 0));
+  n.set_batch(T_h, bs);
+  CtcMetaCopy meta;
+  net_ctc(h, labels_h, L_h, nullptr, &meta, false);
+  net_set_inputs_d(h, f.xin[slot].p, &meta);
+  n.forward();
+  net_ctc_launch(h);
+  n.backward();
+  n.update_step_word = f.step_done; n.update_step_id = (int)(unsigned)k;
+  n.update();
+  ABI_END
+}
+int clstm_host_alloc(void** p, size_t bytes) { ABI_BEGIN REQUIRE(p, "null argument"); HIPCHECK(hipHostMalloc(p, bytes ? bytes : 1)); ABI_END }
+int clstm_host_free(void* p) { ABI_BEGIN if (p) HIPCHECK(hipHostFree(p)); ABI_END }
 
 // ---- state externalisation (clstm.cc:762-811) -----------------------------------------------------------
 namespace clstm {

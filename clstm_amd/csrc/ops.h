@@ -202,7 +202,11 @@ __global__ void k_sgd(float* v, float* d, size_t len, float lr, float mom) {
 // launches (workgroups misplaced / a group barrier timed out), [1] weight-gradient items that gave up waiting.  The
 // host learns about those asynchronously (it keeps enqueueing ahead of the GPU); the UPDATE must not: a gradient
 // computed from unwritten activations is not applied, parameters and momentum stay as they were.
-__global__ void k_update(float* v, float* d, const float* g, size_t len, float lr, float mom, float clip, const int* err) {
+// `step_word` (may be null; pinned host memory): set to step_id -- tells a host that feeds frames from its own memory
+// that every kernel of this step, the input ingest first of all, is behind it (clstm_net_train_step_h).
+__global__ void k_update(float* v, float* d, const float* g, size_t len, float lr, float mom, float clip, const int* err,
+                         int* step_word, int step_id) {
+  if (step_word && blockIdx.x == 0 && threadIdx.x == 0) store_i32_wt(step_word, step_id);
   if (err && (err[0] | err[1]) != 0) return;
   CLSTM_GRID_STRIDE(i, len) {
     float di = d[i] + g[i];

@@ -221,6 +221,16 @@ struct CLSTMOCR {
     if (bs > 1) aligned.erase(aligned.begin(), aligned.begin() + (size_t)(N - T) * nclasses);
     return out;
   }
+  // The same minibatch without any host synchronisation (clstm_net_train_step_h: frames on a copy stream, every kernel
+  // and the update enqueued): the training loop calls this for the minibatches whose result nobody prints, and
+  // train_batch() -- which reads the decode and the alignment back -- where a report is due.  `p` must stay untouched
+  // until the call after the next one (the frames are pageable memory: the library copies them before it returns).
+  void train_batch_async(const Prepared& p) {
+    Classes dummy(1, 1);
+    chk(clstm_net_train_step_h(net, p.T.data(), (int)p.T.size(), p.frames.data(), p.labels.empty() ? dummy.data() : p.labels.data(),
+                               p.L.data()), "clstm_net_train_step_h");
+  }
+  void synchronize() { chk(clstm_synchronize(), "clstm_synchronize"); }
   string aligned_utf8() {  // clstmhl.h:224-229
     Classes cs;
     trivial_decode_host(cs, aligned.data(), T, nclasses);

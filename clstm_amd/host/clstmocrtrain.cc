@@ -105,10 +105,16 @@ static int main1(int argc, char** argv) {
     } else {
       std::swap(cur, next);
       if (trial + batch < ntrain) helper = std::async(std::launch::async, [&] { draw(next); });
-      vector<ustring> preds = clstm.train_batch(cur);
+      // a minibatch whose result is printed reads decode + alignment back (synchronous); every other one is
+      // enqueued without a host synchronisation and the loop goes straight on to the next
+      if (report_trigger.peek(tend)) {
+        vector<ustring> preds = clstm.train_batch(cur);
+        pred = preds.back();
+      } else {
+        clstm.train_batch_async(cur);
+      }
       if (helper.valid()) helper.get();
       gt = cur.targets.back();
-      pred = preds.back();
     }
     if (report_trigger(tend)) {
       std::cout << trial << std::endl;

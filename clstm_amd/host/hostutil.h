@@ -95,6 +95,9 @@ struct Trigger {
     return false;
   }
   bool operator()(int current) { count = current; return check(); }
+  bool peek(int current) const {   // would operator()(current) fire?  (no state change)
+    return (upto > 0 && current >= upto - 1) || (every != 0 && current >= next);
+  }
 };
 
 // ---- text -------------------------------------------------------------------------------------

@@ -182,6 +182,13 @@ class Network:
         self.T, self.N = Tl, int(sum(Tl))
         self.lib.call("clstm_net_train_step", self.h, ptr(t), len(Tl), ptr(x_dev), ptr(labels), ptr(L))
 
+    def train_step_host(self, prep, x_host):
+        """The same step fed from host memory (numpy array or pinned torch tensor [sum T, ninput]): the frames travel on a
+        copy stream while the previous step computes (clstm_net_train_step_h)."""
+        Tl, t, labels, L = prep
+        self.T, self.N = Tl, int(sum(Tl))
+        self.lib.call("clstm_net_train_step_h", self.h, ptr(t), len(Tl), ptr(x_host), ptr(labels), ptr(L))
+
     def set_comm(self, comm):
         """Attach a `Comm` (RCCL): update()/train_step() all-reduce the fresh gradient first."""
         self._comm = comm

@@ -23,6 +23,7 @@
 #ifndef CLSTM_ABI_H_
 #define CLSTM_ABI_H_
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -215,6 +216,17 @@ int clstm_net_reset_timing(clstm_net* net);
  * x_d: DEVICE [sum T][ninput].  Decode with clstm_net_decode() afterwards if the caller wants the output. */
 int clstm_net_train_step(clstm_net* net, const int* T_h, int bs, const float* x_d, const int* labels_h,
                          const int* L_h);
+/* The same step fed from HOST memory (what clstmocrtrain has after read_png + CenterNormalizer, clstmocrtrain.cc:167-172,
+ * extras.cc:227-285): x_h: [sum T][ninput].  Asynchronous: the frames go to the device on a copy stream (a DMA from
+ * x_h itself if it is pinned -- clstm_host_alloc -- else through a pinned staging buffer of the library) into one of two
+ * device input buffers, overlapping the previous step's kernels; the call returns once everything is enqueued.  x_h may
+ * be reused when the call returns if it is pageable, after the NEXT call returns if it is pinned (two buffers in
+ * flight). */
+int clstm_net_train_step_h(clstm_net* net, const int* T_h, int bs, const float* x_h, const int* labels_h,
+                           const int* L_h);
+/* pinned host memory for the above */
+int clstm_host_alloc(void** p, size_t bytes);
+int clstm_host_free(void* p);
 
 /* State externalisation: n_states / get_states / set_states (clstm.cc:762-811; upstream test
  * test-lstm2.cc:79-142).  The reference walks every `Sequence` state of every layer (walk_states,

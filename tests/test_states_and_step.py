@@ -211,3 +211,30 @@ def test_update_is_skipped_while_a_device_error_is_pending(backend, ora32):
         assert not net.get_derivs().any()
     step()                                                  # the words were cleared by the report: updates resume
     assert not np.array_equal(net.get_params(), params.astype(np.float32))
+
+
+def test_train_step_from_host_memory(backend, ora32):
+    """clstm_net_train_step_h: the step fed from host frames (pageable numpy memory here; on the GPU the frames go through
+    the library's pinned staging buffer and a copy stream, double-buffered) must equal the device-resident
+    clstm_net_train_step bit for bit over several steps with changing batch shapes -- the slot hand-off (a step may only
+    overwrite the input buffer of the step two before it once that one has ended) included."""
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Network
+    ni, nh, nc = 6, 9, 5
+    rng = np.random.default_rng(17)
+    p0 = init_params(ni, nh, nc, seed=0.222) * 20
+    a, b = Network(ni, nh, nc, lib=backend.lib), Network(ni, nh, nc, lib=backend.lib)
+    for n in (a, b):
+        n.set_params(p0)
+        n.setLearningRate(1e-2, 0.9)
+    for step in range(6):
+        T = [int(t) for t in rng.integers(3, 12, 2 + step % 3)]
+        lines = synth_lines(rng, T, ni)
+        trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+        x = np.ascontiguousarray(np.concatenate(lines, 0), np.float32)
+        prep = Network.prepare_step(T, trs)
+        a.train_step_prepared(prep, backend.up(x))
+        b.train_step_host(prep, x)
+        x[:] = -7.0            # pageable source: free for reuse as soon as the call returns
+    assert np.array_equal(a.get_params(), b.get_params())
+    assert np.array_equal(a.get_derivs(), b.get_derivs())
