@@ -13,7 +13,7 @@
 //   D. per-state normalisation over t, floor 1e-9, double accumulator        (ctc.cc:83-88)
 //   E. aligned[t][c] = sum_s epath[t][s] [class_s == c]; per-frame normalise (ctc.cc:91-109)
 //      and the fused delta  d = aligned - p                                  (clstmhl.h:211-212)
-// Lines whose lattice fits in LDS (T <= tile, T*S <= 12288: the OCR benchmark shape) take ctc_short_line():
+// Lines whose lattice fits in LDS (T <= tile, T*S <= 13312: the OCR benchmark shape) take ctc_short_line():
 // the same arithmetic, organised for one CU -- match scores once per DISTINCT class (a blank-interleaved
 // target has L+1 equal blank columns), the lattice tile resident in LDS from C to E, branch-free guards
 // (clamped index + select, masked stores to a dump word) so that independent elements interleave instead
@@ -244,7 +244,9 @@ DEVFN void ctc_lattice_huge(const float* lm, float* al, float* be, const CrTable
 #define CTC_STAMP(k) do { if (a.prof && b == 0 && threadIdx.x == 0) a.prof[k] = dev_clock(); } while (0)
 constexpr int CTC_TREG = (CTC_TABLE_DOUBLES + CTC_THREADS - 1) / CTC_THREADS;
 constexpr int CTC_PREG = 34;    // posteriors per thread held in registers across the state classification
-constexpr int CTC_CCACHE = 24;  // lattice cells per thread kept in registers between the two passes of phase C
+constexpr int CTC_CCACHE = 26;  // lattice cells per thread kept in registers between the two passes of phase C (26 x 512 = 13312
+                                // cells: lines of up to 261 frames x 51 states -- a ragged OCR minibatch, T ~ U{150..250} -- stay on the short-line path;
+                                // at 24 the 10 % of such lines beyond 240 frames took the tiled path and the launch 107 us instead of 75)
 
 // ---- lines whose lattice fits in LDS: phases A..E on one CU, see the header ------------------------------
 // Guards are branch-free throughout: reads use a clamped index and a select, masked-off stores go to `dump`,

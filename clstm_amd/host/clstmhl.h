@@ -180,22 +180,34 @@ struct CLSTMOCR {
   };
   // GPU-free: may run on a helper thread while the device works on the previous minibatch (uses only its own
   // normaliser; `codec` is read-only after attach())
-  void prepare(Prepared& p, const vector<Image>& raws, const vector<ustring>& targets) const {
-    p.T.clear(); p.L.clear(); p.frames.clear(); p.labels.clear();
-    p.targets = targets;
+  struct Line {              // one normalised line + its encoded transcript (what a dataset cache keeps per file)
+    Image frames;            // (w = T, h = target_height)
+    Classes labels;
+    ustring target;
+  };
+  void prepare_line(Line& out, const Image& raw, const ustring& target) const {   // (thread-safe: own normaliser)
     CenterNormalizer nz;
     nz.target_height = target_height;
-    Image img;
-    for (size_t b = 0; b < raws.size(); b++) {
-      nz.measure(raws[b]);
-      nz.normalize(img, raws[b]);
-      p.T.push_back(img.w);
-      p.frames.insert(p.frames.end(), img.d.begin(), img.d.end());
-      Classes tr;
-      codec.encode(tr, targets[b]);
-      p.L.push_back((int)tr.size());
-      p.labels.insert(p.labels.end(), tr.begin(), tr.end());
+    nz.measure(raw);
+    nz.normalize(out.frames, raw);
+    codec.encode(out.labels, target);
+    out.target = target;
+  }
+  void pack(Prepared& p, const vector<const Line*>& lines) const {
+    p.T.clear(); p.L.clear(); p.frames.clear(); p.labels.clear(); p.targets.clear();
+    for (const Line* l : lines) {
+      p.T.push_back(l->frames.w);
+      p.frames.insert(p.frames.end(), l->frames.d.begin(), l->frames.d.end());
+      p.L.push_back((int)l->labels.size());
+      p.labels.insert(p.labels.end(), l->labels.begin(), l->labels.end());
+      p.targets.push_back(l->target);
     }
+  }
+  void prepare(Prepared& p, const vector<Image>& raws, const vector<ustring>& targets) const {
+    vector<Line> lines(raws.size());
+    vector<const Line*> ptrs;
+    for (size_t b = 0; b < raws.size(); b++) { prepare_line(lines[b], raws[b], targets[b]); ptrs.push_back(&lines[b]); }
+    pack(p, ptrs);
   }
   vector<ustring> train_batch(const Prepared& p) {
     const int bs = (int)p.T.size();

@@ -84,11 +84,47 @@ static int main1(int argc, char** argv) {
   // std::future: an exception inside it (a missing file, a character outside the codec) is re-thrown by get() on the
   // main thread, and if train_batch throws while the task is still running the future's destructor waits for it --
   // either way the process ends through main()'s "FATAL: ..." handler with exit code 1, never through std::terminate.
+  // Reading a PNG and normalising the line (CenterNormalizer: Gaussian filters as wide as the line is high) costs ~30 ms
+  // of host time per line -- four orders of magnitude more than the device needs for it.  So (batch > 1 only; the
+  // batch = 1 loop stays the reference's, sample for sample): the minibatch's samples are DRAWN in order (same lrand48
+  // sequence), then prepared on up to `prep_threads` threads, and a prepared line is kept per file (cache=1, default):
+  // from the second visit of a file on, a line costs one memcpy.  Preparation is deterministic, so neither changes what
+  // is trained on.
+  const bool use_cache = getienv("cache", 1) != 0;
+  const int prep_threads = std::max(1, std::min(getienv("prep_threads", 16), (int)std::thread::hardware_concurrency()));
+  vector<std::shared_ptr<CLSTMOCR::Line>> cache(use_cache ? trainingset.size() : 0);
   auto draw = [&](CLSTMOCR::Prepared& p) {
-    vector<Image> raws(batch);
-    vector<ustring> gts(batch);
-    for (int i = 0; i < batch; i++) draw_one(raws[i], gts[i]);
-    clstm.prepare(p, raws, gts);
+    vector<int> samples(batch);
+    for (int i = 0; i < batch; i++) samples[i] = lrand48() % trainingset.size();
+    vector<std::shared_ptr<CLSTMOCR::Line>> lines(batch);
+    vector<int> todo;   // first occurrence of every file that is not cached yet
+    for (int i = 0; i < batch; i++) {
+      if (use_cache && cache[samples[i]]) { lines[i] = cache[samples[i]]; continue; }
+      bool first = true;
+      for (int j : todo) if (samples[j] == samples[i]) first = false;
+      if (first) todo.push_back(i);
+    }
+    auto work = [&](int k0) {
+      for (size_t k = k0; k < todo.size(); k += prep_threads) {
+        const int i = todo[k];
+        Image raw;
+        ustring gt;
+        trainingset.readSample(raw, gt, samples[i]);
+        auto l = std::make_shared<CLSTMOCR::Line>();
+        clstm.prepare_line(*l, raw, gt);
+        lines[i] = l;
+      }
+    };
+    vector<std::future<void>> pool;
+    for (int t = 1; t < prep_threads && t < (int)todo.size(); t++) pool.push_back(std::async(std::launch::async, work, t));
+    work(0);
+    for (auto& f : pool) f.get();      // (rethrows a worker's exception)
+    for (int i : todo) if (use_cache) cache[samples[i]] = lines[i];
+    for (int i = 0; i < batch; i++)
+      if (!lines[i]) for (int j : todo) if (samples[j] == samples[i]) lines[i] = lines[j];
+    vector<const CLSTMOCR::Line*> ptrs;
+    for (auto& l : lines) ptrs.push_back(l.get());
+    clstm.pack(p, ptrs);
   };
   CLSTMOCR::Prepared cur, next;
   std::future<void> helper;

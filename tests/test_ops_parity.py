@@ -318,10 +318,11 @@ def test_ctc_reference_known_answers(backend):
     assert np.allclose(d2, a2 - o2, atol=1e-7)
 
 
-@pytest.mark.parametrize("T,L,nc", [(12, 3, 6), (40, 12, 30), (7, 3, 5), (3, 1, 83), (60, 40, 30), (100, 62, 70), (200, 70, 90)])
+@pytest.mark.parametrize("T,L,nc", [(12, 3, 6), (40, 12, 30), (7, 3, 5), (3, 1, 83), (60, 40, 30), (100, 62, 70), (200, 70, 90), (256, 25, 83)])
 def test_ctc_vs_oracle(backend, ora32, T, L, nc):
     # (12..40: short-line path, lattice resident in LDS; 60 x 81 states: the same with the wide recursion;
-    #  100 x 125 states and 200 x 141: the tiled path through HBM)
+    #  100 x 125 states and 200 x 141: the tiled path through HBM; 256 x 51 = 13056 cells: the largest OCR-shaped lattice of
+    #  the short-line path, 26 cells per thread)
     rng = np.random.default_rng(T)
     probs, states = [], []
     for b in range(3):
