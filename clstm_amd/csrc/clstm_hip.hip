@@ -224,18 +224,12 @@ static void launch_lstm(bool fwd, int nk4, int ku, LstmSeqArgs a, int bs, int nt
 }
 
 template <int NK4, int KU>
-static void launch_bwd_dw(const BwdDwKernelArgs& k, unsigned nblk, int nthreads, hipStream_t s, bool prod) {
+static void launch_bwd_dw(const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s) {
   const size_t smem = (2 * 16 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
-#ifdef CLSTM_HIP_EMU   // emulator: every workgroup live at once (the roles wait for each other)
-  if (prod) CLSTM_LAUNCH_COOP((lstm_bwd_dw_kernel<NK4, KU, true>), dim3(nblk), dim3(nthreads), smem, s, k);
-  else CLSTM_LAUNCH_COOP((lstm_bwd_dw_kernel<NK4, KU, false>), dim3(nblk), dim3(nthreads), smem, s, k);
-#else
-  if (prod) CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU, true>), dim3(nblk), dim3(nthreads), smem, s, k);
-  else CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU, false>), dim3(nblk), dim3(nthreads), smem, s, k);
-#endif
+  CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec);
 }
-static bool launch_lstm_bwd_dw(int nk4, int ku, const BwdDwKernelArgs& k, unsigned nblk, int nthreads, hipStream_t s, bool prod) {
-#define CASE_(N, K) if (nk4 == N && ku == K) { launch_bwd_dw<N, K>(k, nblk, nthreads, s, prod); check_launch(); return true; }
+static bool launch_lstm_bwd_dw(int nk4, int ku, const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s) {
+#define CASE_(N, K) if (nk4 == N && ku == K) { launch_bwd_dw<N, K>(a, g, nrec, ngemm, nthreads, s); check_launch(); return true; }
   CASE_(7, 25) CASE_(7, 28) CASE_(4, 16) CASE_(8, 32)    // (thread count must cover the GEMM role's 256)
 #undef CASE_
   return false;
@@ -732,11 +726,6 @@ struct Net {
   int fw_npitems = 0, fw_ncitems = 0, fw_chunks = 0;
   int fw_epoch = 0, fw_prog_base = 1024;
   long long fw_launches = 0;
-  // --- producers of the fused backward launch (lstm_bwd_dw.h: the softmax layer's x.d chunk by chunk) ---
-  DevBuf<int> bp_items, bp_flags;
-  std::vector<int> bp_key;
-  int bp_npitems = 0, bp_chunks = 0, bp_epoch = 0;
-  bool bp_active = false;       // this backward pass: the top layer's fused launch produces its own dH
 
   hipStream_t stream() const { return g_stream; }
 
@@ -828,7 +817,7 @@ struct Net {
       (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release();
       y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false;
     }
-    (void)hipFree(W1k); fw_items.release(); fw_flags.release(); bp_items.release(); bp_flags.release();
+    (void)hipFree(W1k); fw_items.release(); fw_flags.release();
     for (int i = 0; i < 2; i++) { hf.xin[i].release(); if (hf.pin[i]) (void)hipHostFree(hf.pin[i]); if (hf.copied[i]) (void)hipEventDestroy(hf.copied[i]); }
     if (hf.step_done) (void)hipHostFree(hf.step_done);
     if (hf.cs) (void)hipStreamDestroy(hf.cs);
@@ -1094,28 +1083,6 @@ struct Net {
     ring.commit(s);
     fw_key = line_off_h;
   }
-  void build_bwd_items() {
-    if (bp_key == line_off_h && bp_chunks > 0) return;
-    bp_chunks = (tmax + 15) / 16;
-    std::vector<int> items;
-    for (int c = 1; c < bp_chunks; c += BWD_FT)          // time order from chunk 1 on (chunk 0: the recurrence workgroup's own)
-      for (int i = 0; i < bs; i++) {
-        const int b = order_h[i], T = line_off_h[b + 1] - line_off_h[b];
-        if (T > 16 * c)
-          for (int dir = 0; dir < ndir; dir++) { items.push_back(b << 13 | dir << 12 | c); items.push_back(line_off_h[b]); items.push_back(T); items.push_back(0); }
-      }
-    bp_npitems = (int)items.size() / 4;
-    bp_items.reserve(items.size() + 8);
-    bp_flags.reserve((size_t)ndir * bs * bp_chunks + 8);
-    if (!items.empty()) {
-      hipStream_t s = stream();
-      int* stage = (int*)ring.acquire(items.size() * sizeof(int));
-      memcpy(stage, items.data(), items.size() * sizeof(int));
-      HIPCHECK(hipMemcpyAsync(bp_items.p, stage, items.size() * sizeof(int), hipMemcpyHostToDevice, s));
-      ring.commit(s);
-    }
-    bp_key = line_off_h;
-  }
   void forward_fused() {
     hipStream_t s = stream();
     Layer& y = L[0];
@@ -1302,28 +1269,13 @@ struct Net {
     const size_t trace_rows = (size_t)bs * ndir + (size_t)((dw_nslabs + 7) / 8) * 8 * g.gx * g.gy + 8;
     if (trace_path) { dw_trace.reserve(trace_rows * 4); g.trace = dw_trace.p; g.trace_base = bs * ndir; }
     const unsigned nblk = 1u + nextra + (unsigned)((dw_nslabs + 7) / 8) * 8u * g.gx * g.gy;   // the monitor + the independent items + one per item
-    const bool prod = bp_active && &y == &L.back();
 #ifndef CLSTM_HIP_EMU
-    const bool one_launch = y.nthreads >= 256;
-#else
-    const bool one_launch = prod;   // (emulator: the roles as concurrent host threads only where the producer role needs it)
-#endif
-    if (one_launch) {   // ONE launch: the recurrence's workgroups first, [the dH producers,] the GEMM's (one (slab, tile) item each) behind them
+    if (y.nthreads >= 256) {   // ONE launch: the recurrence's workgroups first, the GEMM's (one (slab, tile) item each) behind them
       timing.begin("lstm_bwd", s);
       g.done = g.minprog + 2 * PROG_STRIDE;   // own 128-byte line behind the monitor's words; zero-filled once, then only added to
       dw_done_total += (unsigned)(bs * ndir);
       g.done_target = (int)dw_done_total;
-      BwdDwKernelArgs k{};
-      k.a = a; k.g = g; k.nrec = bs * ndir;
-      if (prod) {
-        if (++bp_epoch > (1 << 30)) bp_epoch = 1;
-        k.a.gflag = bp_flags.p; k.a.gchunks = bp_chunks; k.a.gepoch = bp_epoch; k.a.timeouts = dev_err_words() + 1;
-        k.h.Dz = Dz.p; k.h.nc = desc.nclasses; k.h.dz_elems = (long long)N * desc.nclasses + 16;
-        k.h.W1 = v + sm_off; k.h.w1_elems = (long long)desc.nclasses * (1 + sm_ni);
-        k.h.dH = y.dH.p; k.h.pitems = bp_items.p; k.h.npitems = bp_npitems; k.h.hflag = bp_flags.p; k.h.npb = bp_npitems;
-        g_path_count[6]++;
-      }
-      REQUIRE(launch_lstm_bwd_dw(y.nk4, y.pd.ku, k, (unsigned)(bs * ndir) + (prod ? (unsigned)bp_npitems : 0u) + nblk, y.nthreads, s, prod), "internal: no fused instantiation");
+      REQUIRE(launch_lstm_bwd_dw(y.nk4, y.pd.ku, a, g, bs * ndir, nblk, y.nthreads, s), "internal: no fused instantiation");
       timing.end(s);
       if (trace_path) {
         HIPCHECK(hipStreamSynchronize(s));
@@ -1337,6 +1289,7 @@ struct Net {
       }
       return;
     }
+#endif
     // two launches one after the other (host emulator; layers too narrow for the GEMM role's 256 threads when the
     // tests force the path): the items find every progress word complete
     timing.begin("lstm_bwd", s);
@@ -1386,24 +1339,10 @@ struct Net {
         ns = dwx_nslabs;
       }
       partial_sm.reserve((size_t)ns * R * Cn);
-      // ... and x.d itself is produced INSIDE that launch, chunk by chunk ahead of the recurrence (lstm_bwd_dw.h,
-      // producer role), when the recurrence workgroups leave CUs for the producers they wait for
-      bp_active = false;
-      if (dwx_active && top.nthreads >= 256 && (top.no + 15) / 16 <= WT_JW * (top.nthreads / 64) && tmax < (1 << 16) && bs < (1 << 18) &&
-          bs * ndir <= device_cu_count() - std::max(8, device_cu_count() / 8)) {
-        build_dw_tables();
-        build_bwd_items();
-        bp_active = true;
-#ifdef CLSTM_HIP_EMU   // (the emulator runs every workgroup of that launch as a host thread)
-        bp_active = (size_t)bs * ndir + bp_npitems + 1 + (size_t)dwx_nslabs * ((nc + 63) / 64) * ((1 + sm_ni + 63) / 64) +
-                    (size_t)((dw_nslabs + 7) / 8) * 8 * ((4 * top.no + 63) / 64) * ((1 + top.ni + top.no + 63) / 64) <= 512;
-#endif
-      }
       // W.d (split-K slabs) and x.d in ONE launch: two small independent products, each mostly prologue and
       // epilogue latency on its own (13.9 + 12.4 us back to back)
       timing.begin("gemm_softmax_dw_dx", s);
-      if (bp_active) {}
-      else if (dwx_active)
+      if (dwx_active)
         gemm_x3<GEMM_KC, GEMM_KC>(s, gemm_kc(Dz.p, nc, N), gemm_kc(W1 + nc, nc, sm_ni, 0), StorePlain{top.dH.p, sm_ni}, (int)N, sm_ni, nc);
       else if (gemm_x3_on)
         gemm_x3_pair<GEMM_MC, GEMM_MC, StorePartial, GEMM_KC, GEMM_KC, StorePlain>(

@@ -29,7 +29,6 @@
 // the consumers in dispatch order; the host launches this form only when lines x directions leaves CUs free.
 #pragma once
 #include "lstm_seq.h"
-#include "wave_tiles.h"
 
 namespace clstm {
 
@@ -58,26 +57,81 @@ struct FwdFusedArgs {
 // Measured history (profiles/r03_fwd_timeline.txt): a whole item per WAVE behind twelve dependent rounds of loads took
 // 25 us and the recurrence started 28 us into the launch; one item per seven-wave workgroup with one group prefetched
 // took 6.2 us with one workgroup per CU -- barely faster than the recurrence consumes (a chunk per 8 us).
-constexpr int FWD_JW = WT_JW;   // column tiles per wave at most: ceil(28 / 6) (workgroups of >= 6 waves)
-constexpr int FWD_FT = 2;       // 16-frame tiles (chunks) per producer item: the weight fragments are loaded once for both
-DEVFN WaveTileProblem fwd_gx_problem(const LstmSeqArgs& a, const FwdFusedArgs& h, const int dir) {
-  const int no4 = 4 * a.no;
-  WaveTileProblem p;
-  p.xbuf = make_buf(h.X, (size_t)h.x_elems * 4); p.ldx = h.ldx;
-  p.wbuf = make_buf(h.Wk + (size_t)dir * h.njp * 16 * h.kp, (size_t)h.njp * 16 * h.kp * 4); p.ldw = h.kp;
-  p.ng = h.kp >> 4; p.kvalid = -1;
-  p.bbuf = make_buf(h.bias + (size_t)dir * no4, (size_t)no4 * 4);
-  p.obuf = make_buf(a.G, (size_t)(a.line_off[a.bs]) * a.ndir * no4 * 4); p.ldo = a.ndir * no4; p.ocol0 = dir * no4;
-  p.ncols = no4; p.ntiles = h.njp;
-  return p;
+constexpr int FWD_JW = 5;    // column tiles per wave at most: ceil(28 / 6) (workgroups of >= 6 waves)
+constexpr int FWD_FT = 2;    // 16-frame tiles (chunks) per producer item: the weight fragments are loaded once for both
+constexpr int FWD_KG = 4;    // 16-k groups held in registers at once (K <= 64 per pass; longer contractions loop)
+// wave `wave` of `pw` computes column tiles wave, wave + pw, ... (at most FWD_JW) for FT tiles of 16 frames starting at
+// f0[0..FT) of one line (a tile with f0 = INT_MIN/2 is skipped: every access masked)
+template <int FT>
+DEVFN void fwd_gx_tiles(const LstmSeqArgs& a, const FwdFusedArgs& h, const int dir, const int off, const int T, const int (&f0)[FT],
+                        const int wave, const int pw) {
+  constexpr int JW = FWD_JW;
+  const int lane = threadIdx.x & 63;
+  const int fi = lane & 15, kq = lane >> 4;
+  const int no4 = 4 * a.no, nd = a.ndir;
+  const BufF32 xbuf = make_buf(h.X, (size_t)h.x_elems * 4);
+  const BufF32 wbuf = make_buf(h.Wk + (size_t)dir * h.njp * 16 * h.kp, (size_t)h.njp * 16 * h.kp * 4);
+  const BufF32 bbuf = make_buf(h.bias + (size_t)dir * no4, (size_t)no4 * 4);
+  bool fok[FT];
+  unsigned xrow[FT];
+#pragma unroll
+  for (int t = 0; t < FT; t++) {
+    const int f = f0[t] + fi;
+    fok[t] = f >= 0 && f < T;
+    xrow[t] = fok[t] ? (unsigned)((long long)(off + f) * h.ldx + 4 * kq) * 4u : BUF_OOB_BASE;
+  }
+  unsigned wrow[JW];   // row fi of this wave's i-th tile
+  f32x4 bv[JW];        // (requested with the operands: behind the MFMAs it was one more round trip)
+  f32x4 acc[FT][JW];
+#pragma unroll
+  for (int i = 0; i < JW; i++) {
+    const int tile = wave + i * pw, col = 16 * tile + 4 * kq;
+    wrow[i] = tile < h.njp ? (unsigned)((tile * 16 + fi) * h.kp + 4 * kq) * 4u : BUF_OOB_BASE;
+    bv[i] = buf_load4(bbuf, tile < h.njp && col < no4 ? (unsigned)col * 4u : BUF_OOB);
+#pragma unroll
+    for (int t = 0; t < FT; t++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[t][i][q] = 0.0f;
+  }
+  const int ng = h.kp >> 4;
+  for (int g0 = 0; g0 < ng; g0 += FWD_KG) {
+    f32x4 xv[FWD_KG][FT], wv[FWD_KG][JW];
+#pragma unroll
+    for (int g = 0; g < FWD_KG; g++) {     // groups past the contraction read zeros (out-of-range offsets)
+      const bool live = g0 + g < ng;
+#pragma unroll
+      for (int t = 0; t < FT; t++) xv[g][t] = buf_load4(xbuf, live ? xrow[t] + (unsigned)(g0 + g) * 64u : BUF_OOB);
+#pragma unroll
+      for (int i = 0; i < JW; i++) wv[g][i] = buf_load4(wbuf, live ? wrow[i] + (unsigned)(g0 + g) * 64u : BUF_OOB);
+    }
+#pragma unroll
+    for (int g = 0; g < FWD_KG; g++)
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int i = 0; i < JW; i++)
+#pragma unroll
+          for (int t = 0; t < FT; t++) acc[t][i] = mfma16x16x4(wv[g][i][e], xv[g][t][e], acc[t][i]);   // transposed: lane = (frame fi, column quad kq)
+  }
+  // lane holds columns 16 j + 4 kq + (0..3) of frame fi = the four gates of cell 4 j + kq: one 16-byte store
+  const BufF32 gbuf = make_buf(a.G, (size_t)(a.line_off[a.bs]) * nd * no4 * 4);
+#pragma unroll
+  for (int t = 0; t < FT; t++)
+#pragma unroll
+    for (int i = 0; i < JW; i++) {
+      const int tile = wave + i * pw, col = 16 * tile + 4 * kq;
+      const bool cok = tile < h.njp && col < no4;
+      f32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; q++) o[q] = acc[t][i][q] + bv[i][q];
+      buf_store4_wt(gbuf, fok[t] && cok ? (unsigned)(((long long)(off + f0[t] + fi) * nd + dir) * no4 + col) * 4u : BUF_OOB, o);
+    }
 }
 // the recurrence workgroup's own chunk 0 (all its waves; the caller drains and synchronises)
 DEVFN void fwd_self_produce(const LstmSeqArgs& a, const FwdFusedArgs& h, const int b, const int dir, const int off, const int T) {
   const int wave = wave_uniform((int)threadIdx.x >> 6), nw = (int)blockDim.x >> 6;   // nw >= FWD_CW = 6: at most 5 tiles per wave
-  const int f0 = dir == 0 ? 0 : T - 16;
-  const long long fbase[1] = {(long long)off + f0};
-  const int flo[1] = {f0 < 0 ? -f0 : 0}, fhi[1] = {T - f0 < 16 ? T - f0 : 16};
-  wave_tiles<1>(fwd_gx_problem(a, h, dir), fbase, flo, fhi, wave, nw);
+  const int f0[1] = {dir == 0 ? 0 : T - 16};
+  fwd_gx_tiles<1>(a, h, dir, off, T, f0, wave, nw);
 }
 // producer item (one workgroup, all its waves): chunks c0 .. c0 + FWD_FT - 1 of one (line, direction)
 DEVFN void fwd_gx_item(const LstmSeqArgs& a, const FwdFusedArgs& h, const int it) {
@@ -90,16 +144,10 @@ DEVFN void fwd_gx_item(const LstmSeqArgs& a, const FwdFusedArgs& h, const int it
   const int nchunk = (T + 15) >> 4;
   // iterations [16 c, 16 c + 16): direction 0 visits frame it, direction 1 frame T - 1 - it (a negative first frame in a
   // line's last chunk: masked row by row)
-  long long fbase[FWD_FT];
-  int flo[FWD_FT], fhi[FWD_FT];
+  int f0[FWD_FT];
 #pragma unroll
-  for (int t = 0; t < FWD_FT; t++) {
-    const int f0 = dir == 0 ? 16 * (c0 + t) : T - 16 * (c0 + t) - 16;
-    fbase[t] = (long long)off + f0;
-    flo[t] = f0 < 0 ? -f0 : 0;
-    fhi[t] = c0 + t < nchunk ? (T - f0 < 16 ? T - f0 : 16) : 0;     // (a chunk past the line's end: nothing)
-  }
-  wave_tiles<FWD_FT>(fwd_gx_problem(a, h, dir), fbase, flo, fhi, wave, nw);
+  for (int t = 0; t < FWD_FT; t++) f0[t] = c0 + t < nchunk ? (dir == 0 ? 16 * (c0 + t) : T - 16 * (c0 + t) - 16) : -(1 << 30);
+  fwd_gx_tiles<FWD_FT>(a, h, dir, off, T, f0, wave, nw);
   drain_vmem();      // every storing wave: its rows are in memory ...
   __syncthreads();
   if (threadIdx.x == 0) {   // ... before the flags are

@@ -338,15 +338,8 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_fwd_ke
   lstm_fwd_body<NK4, KU, false>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, blockIdx.y, nullptr);
 }
 
-struct BwdProdArgs;
-// (lstm_bwd_dw.h) the workgroup computes the output deltas dH of its own first 16 iterations
-DEVFN void bwd_self_produce(const LstmSeqArgs& a, const BwdProdArgs& h, int dir, int off, int T);
-// PROD (fused launch of lstm_bwd_dw.h, top layer): the deltas dH on this layer's outputs -- the softmax layer's
-// x.d = W^T z.d -- are PRODUCED inside the launch, 16 iterations of one (line, direction) per flag, exactly as the
-// forward launch produces G (lstm_fwd_body<.., FUSED>): system-scope loads of dH, the workgroup's own first chunk
-// computed here, wave 3 checking the chunk flags two steps ahead of the loads.
-template <int NK4, int KU, bool PROD = false>
-DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir, const BwdProdArgs* ph = nullptr) {
+template <int NK4, int KU>
+DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
   constexpr int SLP = 4 * NK4;
   constexpr int QS = SLP + ((NK4 & 1) ? 0 : 4);
   constexpr int DB = 16 * QS;
@@ -415,23 +408,8 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir, const
   // the back-edge was requested at least a full step before.  c_{s-1} is the NEXT set's c (no extra load).
   struct Ops { float act, dh, cc; };
   Ops X0, X1, X2;
-  const int nchunk = (T + 15) >> 4;
-  const int* gfl = PROD ? a.gflag + ((size_t)dir * a.bs + b) * a.gchunks : nullptr;
-  auto dhload = [&](unsigned o) -> float { return PROD ? buf_load_wt(hbuf, o) : buf_load(hbuf, o); };
-  auto wait_chunk = [&](int c) {
-    int spins = 0;
-    while (wave_uniform(load_i32_wt(gfl + c)) != a.gepoch) {
-      sleep_iterations(1);
-      if (++spins > (1 << 20)) { if (lane == 0) atomic_add_i32(a.timeouts, 1); break; }   // never hang the device
-    }
-  };
-  if constexpr (PROD) {   // chunk 0 of this line and direction: computed here, written through, then visible to every wave
-    bwd_self_produce(a, *ph, dir, off, T);
-    drain_vmem();
-    __syncthreads();
-  }
   X0.act = buf_load(gbuf, gl + fr(T - 1) * gstride4); X1.act = buf_load(gbuf, gl + fr(T - 2) * gstride4);
-  X0.dh = dhload(cl + fr(T - 1) * cstride4);  X1.dh = dhload(cl + fr(T - 2) * cstride4);
+  X0.dh = buf_load(hbuf, cl + fr(T - 1) * cstride4);  X1.dh = buf_load(hbuf, cl + fr(T - 2) * cstride4);
   X0.cc = buf_load(cbuf, cl + fr(T - 1) * cstride4);  X1.cc = buf_load(cbuf, T >= 2 ? cl + fr(T - 2) * cstride4 : BUF_OOB);
   X2.act = X2.dh = X2.cc = 0.0f;
   float dc_carry = 0.0f;
@@ -440,13 +418,10 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir, const
   // cur: operands of step s; nxt: operands of step s-1 (its c is c_{s-1}); ld: set to refill for step s-2
   // (deferring the delta store to the next step like the forward kernel does was measured slower here:
   //  126 -> 137 us)
-  auto run = [&](auto poll_tag) {
-  constexpr bool POLL = decltype(poll_tag)::value;
-  int rdyA = a.gepoch, rdyB = a.gepoch;   // (POLL) chunk flags requested two steps ago
-  auto step = [&](const int s, Ops& cur, const Ops& nxt, Ops& ld, const float* dq, float* dw, float& ka, int& rdy) {
+  auto step = [&](const int s, Ops& cur, const Ops& nxt, Ops& ld, const float* dq, float* dw, float& ka) {
     KEEP_ALIVE(ka);
     ld.act = buf_load(gbuf, gl + fr(s - 2) * gstride4);
-    ld.dh = dhload(cl + fr(s - 2) * cstride4);
+    ld.dh = buf_load(hbuf, cl + fr(s - 2) * cstride4);
     ld.cc = buf_load(cbuf, s >= 2 ? cl + fr(s - 2) * cstride4 : BUF_OOB);   // before the first step: 0 = c_{-1}
     // Everything that does not depend on this step's mat-vec is computed BEFORE it (its operands were
     // requested two steps ago): tanh(c), the gate broadcasts, the derivative factor and the second factor
@@ -504,34 +479,23 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir, const
     buf_store_wt(dbuf, soff, sdat);
     *dw = delta;
     ka = sdat;
-    if constexpr (POLL) {
-      // iteration it = T - 1 - s: behind this barrier the workgroup issues, in iteration it + 1, the loads for iteration
-      // it + 3 -- chunk (it + 3) >> 4 must be there (chunk 0 is the workgroup's own); see lstm_fwd_body
-      const int it = T - 1 - s, c = (it + 3) >> 4;
-      if (c > 0 && __builtin_expect(wave_uniform(rdy) != a.gepoch, 0)) wait_chunk(c < nchunk ? c : nchunk - 1);
-      const int cn = (it + 5) >> 4;
-      rdy = load_i32_wt(gfl + (cn < nchunk ? cn : nchunk - 1));
-    }
     __syncthreads();
   };
   // 3 operand sets x 2 LDS phases: the pattern repeats every 6 steps
   int s = T - 1;
   for (; s >= 5; s -= 6) {
-    step(s, X0, X1, X2, rdA, wrA, ka0, rdyA);
-    step(s - 1, X1, X2, X0, rdB, wrB, ka1, rdyB);
-    step(s - 2, X2, X0, X1, rdA, wrA, ka2, rdyA);
-    step(s - 3, X0, X1, X2, rdB, wrB, ka0, rdyB);
-    step(s - 4, X1, X2, X0, rdA, wrA, ka1, rdyA);
-    step(s - 5, X2, X0, X1, rdB, wrB, ka2, rdyB);
+    step(s, X0, X1, X2, rdA, wrA, ka0);
+    step(s - 1, X1, X2, X0, rdB, wrB, ka1);
+    step(s - 2, X2, X0, X1, rdA, wrA, ka2);
+    step(s - 3, X0, X1, X2, rdB, wrB, ka0);
+    step(s - 4, X1, X2, X0, rdA, wrA, ka1);
+    step(s - 5, X2, X0, X1, rdB, wrB, ka2);
   }
-  if (s >= 0) step(s, X0, X1, X2, rdA, wrA, ka0, rdyA);
-  if (s >= 1) step(s - 1, X1, X2, X0, rdB, wrB, ka1, rdyB);
-  if (s >= 2) step(s - 2, X2, X0, X1, rdA, wrA, ka2, rdyA);
-  if (s >= 3) step(s - 3, X0, X1, X2, rdB, wrB, ka0, rdyB);
-  if (s >= 4) step(s - 4, X1, X2, X0, rdA, wrA, ka1, rdyA);
-  };
-  if constexpr (PROD) { if (wave_uniform(wave) == 3) run(std::true_type{}); else run(std::false_type{}); }
-  else run(std::false_type{});
+  if (s >= 0) step(s, X0, X1, X2, rdA, wrA, ka0);
+  if (s >= 1) step(s - 1, X1, X2, X0, rdB, wrB, ka1);
+  if (s >= 2) step(s - 2, X2, X0, X1, rdA, wrA, ka2);
+  if (s >= 3) step(s - 3, X0, X1, X2, rdB, wrB, ka0);
+  if (s >= 4) step(s - 4, X1, X2, X0, rdA, wrA, ka1);
   if (report) {   // the line is complete: drain this wave's stores, meet, publish "all T iterations"
     drain_vmem();
     __syncthreads();
@@ -540,7 +504,7 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir, const
 }
 template <int NK4, int KU>
 __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_kernel(LstmSeqArgs a) {
-  lstm_bwd_body<NK4, KU, false>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, blockIdx.y, nullptr);
+  lstm_bwd_body<NK4, KU>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, blockIdx.y);
 }
 
 }  // namespace clstm

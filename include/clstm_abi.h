@@ -281,8 +281,7 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* C, int R, 
 /* how often this process has taken an optional fast path (HOST out): which = 0 persistent per-XCD forward recurrence,
  * 1 persistent backward recurrence, 2 W_x.x from the lower layer's bf16 outputs, 3 x.d from the bf16 delta array,
  * 4 weight-gradient product from contraction-major bf16 operands (LDS transpose reads), 5 the forward half as one
- * launch (W_x producers + recurrence + softmax consumers, lstm_fwd_fused.h), 6 the softmax layer's x.d produced inside the
- * fused backward launch (lstm_bwd_dw.h).  Tests use it to make sure the
+ * launch (W_x producers + recurrence + softmax consumers, lstm_fwd_fused.h).  Tests use it to make sure the
  * path they mean to cover is the one that ran. */
 int clstm_debug_path_count(int which, long long* out_h);
 /* (tests) set a device error word: which = 0 the outcome word of the persistent recurrences, 1 the count of weight-gradient
