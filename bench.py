@@ -205,50 +205,61 @@ def pmc_traffic(minibatch, T, ragged):
     return {}, None
 
 
-def roofline_b1(w, kern, frames_per_step, ms_per_step):
+def roofline_b1(w, kern, kern_unfused, frames_per_step, ms_per_step):
     """Fused gate kernels against HBM (north star: 'achieved HBM GB/s for the fused gate kernel'), the batched gate GEMM
     against the f32 MFMA peak ('MFMA utilisation for the batched gate GEMM').  Algorithmic bytes:
-    forward 44 B per cell-step; the backward recurrence 56 B per cell-step -- it shares its launch with the
-    weight-gradient GEMM (lstm_bwd_dw.h), whose operand reads (deltas once, source rows once, and for the top layer
-    the softmax layer's [1 | h] rows and output deltas) are added for that launch."""
+    forward recurrence 44 B per cell-step, backward recurrence 56 B per cell-step.  In the default mode both recurrences
+    share their launch with the products around them -- forward: the W_x GEMM producers (read x, write G) and the softmax
+    consumers (read H rows, write Z), lstm_fwd_fused.h; backward: the weight-gradient items (read deltas and source rows
+    once, for the top layer also the softmax layer's [1 | h] rows and output deltas), lstm_bwd_dw.h -- whose bytes are
+    added for those launches.  `others` carries the PURE kernels, timed in a second short pass with the fusions off
+    (clstm_net_set_overlap 0): the recurrences alone and the batched gate GEMM."""
     cfg = w.cfg
     ndir, N = 2, frames_per_step
     cells = ndir * sum(cfg["nh"])
+    no, ni, nc = cfg["nh"][-1], cfg["ni"], cfg["nc"]
+    M = ndir * 4 * cfg["nh"][0]
+    lds = (1 + ni + no + 15) // 16 * 16
+    ldh = (4 + ndir * no + 15) // 16 * 16
     traffic, traffic_src = pmc_traffic(w.minibatch, w.T, w.ragged)
     entries = {}
-    for name, key in (("lstm_fwd", "lstm_fwd"), ("lstm_bwd", "lstm_bwd_dw")):
-        if name not in kern:
-            continue
-        byts = BYTES_PER_CELL_STEP[name] * cells * N
-        fused = name == "lstm_bwd" and "gemm_gates_dw" not in kern
-        if fused:
-            no, ni = cfg["nh"][-1], cfg["ni"]
-            lds = (1 + ni + no + 15) // 16 * 16
-            ldh = (4 + ndir * no + 15) // 16 * 16
-            byts += 4.0 * N * (ndir * 4 * no + ndir * lds) + 4.0 * N * (ldh + cfg["nc"])
-        sec = kern[name]["ms_per_step"] * 1e-3
-        nl = kern[name]["launches_per_step"]
+
+    def hbm_entry(key, label, byts, k):
+        sec = k["ms_per_step"] * 1e-3
+        nl = k["launches_per_step"]
         ach = byts / sec / 1e9
-        entries[key] = {"kernel": key if fused else name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(key, traffic.get(name)),
-                        "algorithmic_bytes": int(byts / nl), "avg_launch_ms": round(sec / nl * 1e3, 4)}
-    if "gemm_gates_x" in kern:
-        M = ndir * 4 * cfg["nh"][0]
-        fl = 2.0 * N * M * (cfg["ni"] + 1)
-        sec = kern["gemm_gates_x"]["ms_per_step"] * 1e-3
+        return {"kernel": label, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(key),
+                "algorithmic_bytes": int(byts / nl), "avg_launch_ms": round(sec / nl * 1e3, 4)}
+    if "lstm_fwd" in kern:
+        fused = "gemm_gates_x" not in kern
+        byts = 44.0 * cells * N + (4.0 * N * (ni + M) + 4.0 * N * (ndir * no + nc) if fused else 0.0)
+        entries["lstm_fwd_fused" if fused else "lstm_fwd"] = hbm_entry("lstm_fwd_fused" if fused else "lstm_fwd",
+            "lstm_fwd_fused (W_x producers + recurrence + softmax consumers)" if fused else "lstm_fwd", byts, kern["lstm_fwd"])
+    if "lstm_bwd" in kern:
+        fused = "gemm_gates_dw" not in kern
+        byts = 56.0 * cells * N + (4.0 * N * (ndir * 4 * no + ndir * lds) + 4.0 * N * (ldh + nc) if fused else 0.0)
+        entries["lstm_bwd_dw" if fused else "lstm_bwd"] = hbm_entry("lstm_bwd_dw" if fused else "lstm_bwd",
+            "lstm_bwd_dw (recurrence + weight-gradient items)" if fused else "lstm_bwd", byts, kern["lstm_bwd"])
+    dom_keys = list(entries)
+    for name, bpc in (("lstm_fwd", 44.0), ("lstm_bwd", 56.0)):      # the pure fused gate kernels
+        if name in kern_unfused and name not in entries:
+            entries[name] = hbm_entry(name, name + " (fusions off)", bpc * cells * N, kern_unfused[name])
+    kx = kern.get("gemm_gates_x") or kern_unfused.get("gemm_gates_x")
+    if kx:
+        fl = 2.0 * N * M * (ni + 1)
+        sec = kx["ms_per_step"] * 1e-3
         tf = fl / sec / 1e12
         entries["gemm_gates_x"] = {"kernel": "gemm_gates_x", "bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFS,
                                    "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFS, 5), "traffic": traffic.get("gemm_gates_x"),
                                    "algorithmic_flops": int(fl), "avg_launch_ms": round(sec * 1e3, 4),
                                    "note": "batched gate GEMM W_x.x + b over every frame of the minibatch (f32 MFMA); "
                                            "its 4 B x N x M output stream (%.0f MB) is what bounds it" % (4e-6 * N * M)}
-    cand = [k for k in ("lstm_fwd", "lstm_bwd_dw") if k in entries]
-    if not cand:
+    if not dom_keys:
         return None
-    dom = max(cand, key=lambda k: entries[k]["avg_launch_ms"])     # the dominant kernel of the step BY TIME
+    dom = max(dom_keys, key=lambda k: entries[k]["avg_launch_ms"])     # the dominant launch of the step BY TIME
     out = dict(entries[dom])
     out["traffic_source"] = traffic_src if out["traffic"] is not None else None
-    sec = kern["lstm_fwd"]["ms_per_step"] * 1e-3 if "lstm_fwd" in kern else None
     out["note"] = ("latency-bound recurrence: %d workgroups (lines x directions) on 256 CUs, one dependent step per frame; "
                    "whole step %.1f GB/s of algorithmic bytes (SURVEY 8d: 3.62 MB/line + 2.17 MB/minibatch)"
                    % (2 * w.minibatch, (3.62e6 * w.minibatch + 2.17e6) / (ms_per_step * 1e-3) / 1e9))
@@ -384,7 +395,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    def measure(w, steps, warmup, profile_steps):
+    def measure(w, steps, warmup, profile_steps, unfused_pass=False):
         blocks, nxt = timed_blocks(w, steps, warmup, fence, reduce_max)
         dt = float(np.median(blocks))
         # host-side cost of issuing a step (diagnostic: is the loop host-bound?): a short burst on an idle stream, few
@@ -394,20 +405,27 @@ def main():
             w.step(nxt + i)
         t_enq = (time.perf_counter() - t1) / 4
         fence()
-        kern, fps = ({}, 0)
+        kern, fps, kern_unfused = {}, 0, {}
         if rank == 0 and profile_steps > 0:
             kern, fps = kernel_times(w, profile_steps, nxt + 4)
-        return {"dt": dt, "blocks": blocks, "enqueue": t_enq, "kern": kern, "frames_per_step": fps}
+            if unfused_pass and world == 1:      # the pure kernels: the same steps with the fused launches off
+                w.net.set_overlap(0)
+                kern_unfused, _ = kernel_times(w, profile_steps, nxt + 4 + profile_steps)
+                w.net.set_overlap(1)
+        return {"dt": dt, "blocks": blocks, "enqueue": t_enq, "kern": kern, "kern_unfused": kern_unfused, "frames_per_step": fps}
 
     precision = 2 if args.bf16 else 1 if args.bf16_gemm else 0
     w = Workload(lib, cfg, args.minibatch, args.T, args.ragged, precision, dev, rank, comm=comm, dist=dist, host_inputs=args.host_inputs)
-    m = measure(w, args.steps, args.warmup, args.profile_steps)
+    m = measure(w, args.steps, args.warmup, args.profile_steps, unfused_pass=max(cfg["nh"]) <= 128)
     dt = m["dt"]
     ms_per_step = dt / args.steps * 1e3
     value = args.minibatch * world * args.steps / dt
     roofline = None
     if rank == 0 and m["kern"]:
-        roofline = (roofline_b1 if max(cfg["nh"]) <= 128 else roofline_b2)(w, m["kern"], m["frames_per_step"], ms_per_step)
+        if max(cfg["nh"]) <= 128:
+            roofline = roofline_b1(w, m["kern"], m["kern_unfused"], m["frames_per_step"], ms_per_step)
+        else:
+            roofline = roofline_b2(w, m["kern"], m["frames_per_step"], ms_per_step)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -461,7 +479,7 @@ def main():
             "timing": {"protocol": "median of `repeats` blocks of exactly `steps` steps, each bracketed by barrier + synchronize "
                                    "and max-reduced over ranks; warm-up >= %.1f s" % MIN_WARMUP_S,
                        "block_ms_min": round(min(m["blocks"]) * 1e3, 3), "block_ms_max": round(max(m["blocks"]) * 1e3, 3)},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": m["kern"],
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": m["kern"], "kernels_fusions_off": m["kern_unfused"],
             "host_enqueue_ms_per_step": round(m["enqueue"] * 1e3, 4),   # host-side cost of issuing a step
             "allreduce": allreduce_impl,
             "secondary": secondary,

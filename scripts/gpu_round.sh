@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call: GPU parity tests, smoke, bench lines, rocprof kernel stats, PMC passes, diagnostics.
 # Usage (from the build container):  gpurun --timeout 2400 -- 'bash scripts/gpu_round.sh r02'
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$ROOT"
 OUT="$ROOT/gpurun_out/$TAG"
@@ -20,19 +20,20 @@ B() { timeout 600 python bench.py "$@"; }
 echo "=== bench (default = minibatch 64, T=200)"
 B > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; cut -c1-400 "$OUT/bench_default.json"; tail -2 "$OUT/bench_default.err" | grep -v amdgpu
 for MB in 1 16 256 1024; do
-  B --minibatch $MB --no-cpu-baseline --steps 50 --warmup 10 > "$OUT/bench_mb$MB.json" 2> "$OUT/bench_mb$MB.err"; cut -c1-220 "$OUT/bench_mb$MB.json"
+  B --minibatch $MB --no-cpu-baseline --no-secondary --steps 50 --warmup 10 > "$OUT/bench_mb$MB.json" 2> "$OUT/bench_mb$MB.err"; cut -c1-220 "$OUT/bench_mb$MB.json"
 done
-B --ragged --no-cpu-baseline > "$OUT/bench_ragged.json" 2>/dev/null; cut -c1-220 "$OUT/bench_ragged.json"
-CLSTM_OVERLAP=0 B --no-cpu-baseline > "$OUT/bench_overlap0.json" 2>/dev/null; cut -c1-220 "$OUT/bench_overlap0.json"
-BENCH_FORCE_DIST=1 B --no-cpu-baseline > "$OUT/bench_forcedist.json" 2>/dev/null; cut -c1-220 "$OUT/bench_forcedist.json"
+B --ragged --no-cpu-baseline --no-secondary > "$OUT/bench_ragged.json" 2>/dev/null; cut -c1-220 "$OUT/bench_ragged.json"
+B --host-inputs --no-cpu-baseline --no-secondary > "$OUT/bench_host_inputs.json" 2>/dev/null; cut -c1-220 "$OUT/bench_host_inputs.json"
+B --steps 20 --warmup 5 > "$OUT/bench_driver_cmd.json" 2>/dev/null; cut -c1-220 "$OUT/bench_driver_cmd.json"
+CLSTM_OVERLAP=0 B --no-cpu-baseline --no-secondary > "$OUT/bench_overlap0.json" 2>/dev/null; cut -c1-220 "$OUT/bench_overlap0.json"
+BENCH_FORCE_DIST=1 B --no-cpu-baseline --no-secondary > "$OUT/bench_forcedist.json" 2>/dev/null; cut -c1-220 "$OUT/bench_forcedist.json"
 echo "=== bench 2xBiLSTM(512) shape: f32 / bf16 hoisted GEMMs / bf16 MFMA everywhere"
 B --config b2 --steps 10 --warmup 3 --profile-steps 2 > "$OUT/bench_b2.json" 2>/dev/null; cut -c1-200 "$OUT/bench_b2.json"
-B --config b2 --steps 10 --warmup 3 --profile-steps 2 --bf16-gemm > "$OUT/bench_b2_bf16gemm.json" 2>/dev/null; cut -c1-200 "$OUT/bench_b2_bf16gemm.json"
 B --config b2 --steps 10 --warmup 3 --profile-steps 2 --bf16 > "$OUT/bench_b2_bf16.json" 2>/dev/null; cut -c1-200 "$OUT/bench_b2_bf16.json"
 
 echo "=== rocprofv3 kernel stats + one-step timeline"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > "$OUT/rocprof.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof.log" 2>&1
 tail -1 "$OUT/rocprof.log" | cut -c1-200
 find "$OUT/prof" -name "*kernel_stats*" | head -1 | while read f; do head -16 "$f"; done
 F=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)
@@ -55,22 +56,23 @@ PY
 find "$OUT/prof" -name "*kernel_trace*" -size +20M -delete
 echo "=== rocprofv3 PMC passes (separate runs): FETCH_SIZE, WRITE_SIZE, MFMA busy, SQ wave states"
 for CNT in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_$CNT" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/rocprof_$CNT.log" 2>&1
+  timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_$CNT" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof_$CNT.log" 2>&1
   python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_$CNT" $CNT > "$OUT/pmc_${CNT}_summary.txt" 2>&1; head -14 "$OUT/pmc_${CNT}_summary.txt"
   find "$OUT/pmc_$CNT" -name "*.csv" -size +8M -delete
 done
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_MFMA" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/rocprof_MFMA.log" 2>&1
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_MFMA" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof_MFMA.log" 2>&1
 for CNT in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_MFMA" $CNT > "$OUT/pmc_${CNT}_summary.txt" 2>&1; head -8 "$OUT/pmc_${CNT}_summary.txt"
 done
 find "$OUT/pmc_MFMA" -name "*.csv" -size +8M -delete
 SQC="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU"
-timeout 600 rocprofv3 --pmc $SQC --kernel-trace --output-format csv -d "$OUT/pmc_SQ" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/rocprof_SQ.log" 2>&1
+timeout 600 rocprofv3 --pmc $SQC --kernel-trace --output-format csv -d "$OUT/pmc_SQ" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof_SQ.log" 2>&1
 for CNT in $SQC; do python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_SQ" $CNT | head -6; done > "$OUT/pmc_SQ_summary.txt" 2>&1
 head -12 "$OUT/pmc_SQ_summary.txt"
 find "$OUT/pmc_SQ" -name "*.csv" -size +8M -delete
 echo "=== diagnostics: per-phase cycles of the forward recurrence and of the CTC kernel"
 cd "$ROOT"
-CLSTM_HIP_VARIANT=prof timeout 300 python scripts/gpu_lstmprof.py > "$OUT/lstm_fwd_phase_cycles.txt" 2>&1; tail -9 "$OUT/lstm_fwd_phase_cycles.txt"
+CLSTM_FW_TRACE="$OUT/fw_trace.txt" timeout 300 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > /dev/null 2>&1
+python scripts/fwtrace_summary.py "$OUT/fw_trace.txt" > "$OUT/fwd_timeline.txt" 2>&1; head -3 "$OUT/fwd_timeline.txt"; tail -2 "$OUT/fwd_timeline.txt"
 timeout 300 python scripts/gpu_ctcprof.py > "$OUT/ctc_phase_cycles.txt" 2>&1; tail -6 "$OUT/ctc_phase_cycles.txt"
 echo "=== done"
