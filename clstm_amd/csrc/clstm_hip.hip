@@ -1001,7 +1001,7 @@ struct Net {
       a.line_off = line_off.p; a.order = line_off.p + bs + 1; a.no = y.no; a.ndir = ndir; a.ldh = y.ldh; a.hofs = y.hofs;
       a.S = y.S.p; a.lds = y.lds; a.sofs = 1 + y.ni; a.sdir = (long long)N * y.lds;
 #ifdef CLSTM_LSTM_PROF
-      lstm_prof.reserve(64); a.prof = lstm_prof.p;
+      lstm_prof.reserve(128); a.prof = lstm_prof.p;
 #endif
       timing.begin("lstm_fwd", s);
       if (y.wide) {
@@ -2226,7 +2226,7 @@ int clstm_debug_ctc_cycles(long long* out_h) {
 int clstm_debug_lstm_cycles(clstm_net* h, long long* out_h) {   // diagnostics build only (not in the product ABI)
   ABI_BEGIN
   HIPCHECK(hipStreamSynchronize(g_stream));
-  HIPCHECK(hipMemcpy(out_h, h->net.lstm_prof.p, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy(out_h, h->net.lstm_prof.p, 96 * sizeof(long long), hipMemcpyDeviceToHost));
   ABI_END
 }
 #endif

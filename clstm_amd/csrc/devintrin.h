@@ -307,6 +307,19 @@ DEVFN T* dyn_smem() {
 // progress words (lstm_seq.h -> gemm_dw.h) sit one per 128-byte line: a workgroup rewrites its word every step
 constexpr int PROG_STRIDE = 32;
 
+// ---- staggered recurrence (lstm_seq.h, workgroups of more than four waves): contraction order of a lane ----------
+// Waves 0..3 (cells 0..63, the first-dispatched wave of each SIMD) form group A, the rest group B.  A lane's slice of the
+// recurrent contraction is ordered [A part | B part] so that a step can start on the half of h_{t-1} that is ready:
+//   forward, lane quarter q, slot kk < ku:  kk < 16: cell k = 16 q + kk ;  else cell k = 64 + (ku - 16) q + (kk - 16)
+//   LDS position of cell c in the h vector (quarter stride qs): the same map inverted.
+constexpr int STAG_NA = 64, STAG_KA = 16;
+__host__ __device__ inline constexpr bool stag_on(int nk4) { return nk4 >= 5; }
+__host__ __device__ inline int stag_fwd_k(int q, int kk, int ku) { return kk < STAG_KA ? STAG_KA * q + kk : STAG_NA + (ku - STAG_KA) * q + (kk - STAG_KA); }
+__host__ __device__ inline int stag_fwd_slot(int cell, int ku, int qs) {
+  return cell < STAG_NA ? (cell / STAG_KA) * qs + (cell % STAG_KA)
+                        : ((cell - STAG_NA) / (ku - STAG_KA)) * qs + STAG_KA + (cell - STAG_NA) % (ku - STAG_KA);
+}
+
 // ---------------------------------------------------------------------------------------
 // activation functions shared by every kernel (and replicated in numpy by the CPU tests)
 // ---------------------------------------------------------------------------------------

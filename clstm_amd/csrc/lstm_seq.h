@@ -53,7 +53,7 @@ struct LstmSeqArgs {
   float* S;             // [ndir][N][lds] source rows [1 | x_t | h_{t-1}] for the weight-gradient GEMM;
   int lds, sofs;        //   the forward pass deposits h_{t-1} at column sofs = 1 + ni of the NEXT step's row
   long long sdir;       //   floats between the two directions' S arrays
-  long long* prof;      // diagnostics build (-DCLSTM_LSTM_PROF) only: [8 waves][8] summed phase cycles of workgroup 0
+  long long* prof;      // diagnostics build (-DCLSTM_LSTM_PROF) only: [8 waves][12] summed phase cycles of workgroup 0
   // Progress words for consumers that run CONCURRENTLY with the recurrence (backward: the weight-gradient items of
   // gemm_dw.h reading D; forward, fused launch of lstm_fwd_fused.h: the softmax items reading H): word (dir, line) lives
   // prog_off floats behind D[0] / H[0] (the tail of that array's allocation, so that the per-step store reaches it
@@ -144,7 +144,23 @@ DEVFN void lstm_fwd_body(const LstmSeqArgs& a, const int b, const int dir, const
     const int tc = t < T ? t : T - 1;
     return (unsigned)(dir == 0 ? tc : T - 1 - tc);
   };
-  const int hslot = (cell / KU) * QS + (cell % KU);
+  // Workgroups of more than four waves run STAGGERED: group A = waves 0..3 (cells 0..63, the first wave of every
+  // SIMD), group B = the rest (each shares a SIMD with an A wave); a lane's contraction slots are ordered
+  // [A cells | B cells] (devintrin.h:stag_*).  With ONE barrier per step the two waves of a SIMD issue their FMAs in the
+  // same window and then run their dependent tails side by side -- measured (scripts/gpu_width_sweep.py): 64 cells / 4
+  // waves 317 ns per step, 100 cells / 7 waves 505 ns, although a lane has only 50 instead of 32 packed FMAs.  Two
+  // barriers per step let the groups run half a step apart: X_{t+1} = "A's half of h_t is in LDS", Y_{t+1} = "B's half".
+  //   A, step t:  reads own half | stores of t-1 | FMAs own half | Y_t | reads B's half | FMAs | tail | write | X_{t+1}
+  //   B, step t:  reads all | stores of t-1 | FMAs | X_{t+1} | tail | write | Y_{t+1}
+  // so A's tail runs under B's FMAs and B's tail under A's first FMAs: 505 -> 465 ns per step at 100 cells (pure kernel
+  // 100.9 -> 92.9 us, the fused forward launch 118.5 -> 114.5).  What did NOT help (all measured, gpurun_out of round 3):
+  // moving the split (8 / 16 / 24 of A's 32 own FMAs in front of Y; X behind B's reduction or nonlinearity): +-1 us;
+  // raising the priority of a wave in its tail (s_setprio): +2..4 us; B fetching A's half right behind X into registers:
+  // +14 us; B's stores behind X instead of in front of its FMAs: +20 us; B's FMAs at raised priority: +17 us.  A lone wave's
+  // chain (LDS read -> 50 FMAs -> reduce, two transcendental rounds, LDS write -> barrier) is ~850 cycles; this runs 1120.
+  constexpr bool STAG = stag_on(NK4);
+  constexpr int NJA = STAG ? STAG_KA / 4 : NK4;   // float4 groups of a lane's slice that hold group A's cells
+  const int hslot = STAG ? stag_fwd_slot(valid ? cell : 0, KU, QS) : (cell / KU) * QS + (cell % KU);
   // lane q finishes gate q: q = 0 gi, 1 gf, 2 go (sigmoid), 3 ci (tanh) -- one affine form for both (act_affine)
   const float a_scale = q == 3 ? ACT_TANH_SCALE : ACT_SIG_SCALE, a_mul = q == 3 ? 2.0f : 1.0f, a_add = q == 3 ? -1.0f : 0.0f;
   const float* rdA = lds + q * QS;            // even steps read buffer 0, write buffer 1
@@ -189,7 +205,7 @@ DEVFN void lstm_fwd_body(const LstmSeqArgs& a, const int b, const int dir, const
   // diagnostics build only: per-phase cycle stamps (scripts/gpu_lstmprof.py).  Each stamp costs ~60 cycles
   // and drains lgkmcnt, so the instrumented step is ~25 % longer than the real one.
 #ifdef CLSTM_LSTM_PROF
-  long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long pt = 0;
 #define LSTM_STAMP(k) do { long long now_; SCHED_FENCE(); \
                            asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
@@ -236,31 +252,65 @@ DEVFN void lstm_fwd_body(const LstmSeqArgs& a, const int b, const int dir, const
   int rdyA = a.gepoch, rdyB = a.gepoch;   // (POLL) chunk flags requested two steps ago
   auto step = [&](const int t, float& gxr, int& rdy, const float* hq, float* hw, float& ka0, float& ka1, float& ka2,
                   float pa0, float pa1, float pa2) {
-    if constexpr (!EARLY) {
+    if constexpr (!EARLY && !STAG) {
       KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2);  // stores of step t-2 have long completed
       flush(t - 1, pa0, pa1, pa2, report_tag);
     }
+    if constexpr (STAG) { KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2); }
     f32x2 a01 = splat2(0.0f), a23 = splat2(0.0f);
     LSTM_STAMP(0);   // loop overhead since the barrier
     // (hipcc copies element w of every ds_read_b128 into a fresh pair -- 6 v_mov_b32 per step; spelling the
     //  FMAs as inline asm with op_sel removes them but serialises the LDS reads behind single waits: not kept)
     // All LDS reads of the step first, pinned in front of the FMAs (see the backward kernel).
     float4 hv[NK4];
+    auto fma_groups = [&](const int j0, const int j1) {
 #pragma unroll
-    for (int j = 0; j < NK4; j++) hv[j] = *reinterpret_cast<const float4*>(hq + 4 * j);
-    SCHED_FENCE();
+      for (int j = j0; j < j1; j++) {
+        if (4 * j < KU) { a01 = fma2(w01[4 * j], splat2(hv[j].x), a01); a23 = fma2(w23[4 * j], splat2(hv[j].x), a23); }
+        if (4 * j + 1 < KU) { a01 = fma2(w01[4 * j + 1], splat2(hv[j].y), a01); a23 = fma2(w23[4 * j + 1], splat2(hv[j].y), a23); }
+        if (4 * j + 2 < KU) { a01 = fma2(w01[4 * j + 2], splat2(hv[j].z), a01); a23 = fma2(w23[4 * j + 2], splat2(hv[j].z), a23); }
+        if (4 * j + 3 < KU) { a01 = fma2(w01[4 * j + 3], splat2(hv[j].w), a01); a23 = fma2(w23[4 * j + 3], splat2(hv[j].w), a23); }
+      }
+    };
+    if constexpr (STAG && EARLY) {
+      // group A: its own half of h_{t-1} has been visible since barrier X_t (the end of its previous step); group B's
+      // half becomes visible at barrier Y_t, which B reaches at the end of ITS step t-1 -- half a step behind.
+      // The previous step's global stores issue under the latency of the first LDS reads (both groups).
 #pragma unroll
-    for (int j = 0; j < NK4; j++) {
-      if (4 * j < KU) { a01 = fma2(w01[4 * j], splat2(hv[j].x), a01); a23 = fma2(w23[4 * j], splat2(hv[j].x), a23); }
-      if (4 * j + 1 < KU) { a01 = fma2(w01[4 * j + 1], splat2(hv[j].y), a01); a23 = fma2(w23[4 * j + 1], splat2(hv[j].y), a23); }
-      if (4 * j + 2 < KU) { a01 = fma2(w01[4 * j + 2], splat2(hv[j].z), a01); a23 = fma2(w23[4 * j + 2], splat2(hv[j].z), a23); }
-      if (4 * j + 3 < KU) { a01 = fma2(w01[4 * j + 3], splat2(hv[j].w), a01); a23 = fma2(w23[4 * j + 3], splat2(hv[j].w), a23); }
+      for (int j = 0; j < NJA; j++) hv[j] = *reinterpret_cast<const float4*>(hq + 4 * j);
+      SCHED_FENCE();
+      flush(t - 1, pa0, pa1, pa2, report_tag);
+      SCHED_FENCE();
+      fma_groups(0, NJA);
+      LSTM_STAMP(7);     // first LDS reads, deferred stores, the FMAs in front of Y
+      __syncthreads();   // Y_t
+      LSTM_STAMP(8);     // wait at Y
+#pragma unroll
+      for (int j = NJA; j < NK4; j++) hv[j] = *reinterpret_cast<const float4*>(hq + 4 * j);
+      SCHED_FENCE();
+      fma_groups(NJA, NK4);
+    } else if constexpr (STAG) {
+#pragma unroll
+      for (int j = 0; j < NK4; j++) hv[j] = *reinterpret_cast<const float4*>(hq + 4 * j);
+      SCHED_FENCE();
+      flush(t - 1, pa0, pa1, pa2, report_tag);
+      SCHED_FENCE();
+      fma_groups(0, NK4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NK4; j++) hv[j] = *reinterpret_cast<const float4*>(hq + 4 * j);
+      SCHED_FENCE();
+      fma_groups(0, NK4);
     }
     // (early role: the pins end only here, so that the LDS reads above cannot land in the store-data registers --
     //  hipcc guards an LDS return into such a register with s_waitcnt vmcnt(0), i.e. it would wait for the stores
     //  just issued)
-    if constexpr (EARLY) { KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2); }
+    if constexpr (EARLY && !STAG) { KEEP_ALIVE(ka0); KEEP_ALIVE(ka1); KEEP_ALIVE(ka2); }
     LSTM_STAMP(1);   // LDS reads + FMAs
+    if constexpr (STAG && !EARLY) {
+      __syncthreads();   // X_{t+1}: group A has written its half of h_t
+      LSTM_STAMP(9);     // wait at X
+    }
     // reduce-scatter over the quad: lane q ends with gate q's sum over the four k-quarters
     // (register slot s of lane q holds gate s^q -- pack_rf -- so what a lane keeps and what it sends sit
     // in fixed registers: three v_add_f32_dpp, no selects)
@@ -285,7 +335,7 @@ DEVFN void lstm_fwd_body(const LstmSeqArgs& a, const int b, const int dir, const
     LSTM_STAMP(4);   // state update + tanh(c)
     *hw = h;
     ka0 = act; ka1 = c; ka2 = h;                      // stored by the next step's flush (later waves)
-    if constexpr (EARLY) {
+    if constexpr (EARLY && !STAG) {
       // store FROM the pinned registers: a VMEM store reads its data late, and a copy of the value in a register
       // that the next step's LDS reads overwrite would put s_waitcnt vmcnt(0) at the top of every step
       OPAQUE(ka0); OPAQUE(ka1); OPAQUE(ka2);
@@ -304,6 +354,9 @@ DEVFN void lstm_fwd_body(const LstmSeqArgs& a, const int b, const int dir, const
     __syncthreads();
     LSTM_STAMP(6);   // barrier
   };
+  // staggered: barriers alternate Y_0 X_1 Y_1 X_2 ... ; group A runs [.. Y_t .. X_{t+1}] per step, group B [.. X_{t+1} .. Y_{t+1}]
+  // behind one leading Y_0, and A meets B's last Y_T after its loop -- every wave executes the same 2 T + 1 barriers
+  if constexpr (STAG && !EARLY) __syncthreads();   // Y_0
   int t = 0;
   for (; t + 1 < T; t += 2) {
     step(t, gxA, rdyA, rdA, wrA, kaA0, kaA1, kaA2, kaB0, kaB1, kaB2);
@@ -311,10 +364,11 @@ DEVFN void lstm_fwd_body(const LstmSeqArgs& a, const int b, const int dir, const
   }
   if (t < T) {
     step(t, gxA, rdyA, rdA, wrA, kaA0, kaA1, kaA2, kaB0, kaB1, kaB2);
-    if constexpr (!EARLY) flush(t, kaA0, kaA1, kaA2, report_tag);
+    if constexpr (!EARLY || STAG) flush(t, kaA0, kaA1, kaA2, report_tag);
   } else {
-    if constexpr (!EARLY) flush(t - 1, kaB0, kaB1, kaB2, report_tag);
+    if constexpr (!EARLY || STAG) flush(t - 1, kaB0, kaB1, kaB2, report_tag);
   }
+  if constexpr (STAG && EARLY) __syncthreads();    // Y_T
   };
   if constexpr (FUSED) {
     if (wave_uniform(wave) == 3) run(std::true_type{}, std::true_type{}, std::false_type{});
@@ -330,7 +384,7 @@ DEVFN void lstm_fwd_body(const LstmSeqArgs& a, const int b, const int dir, const
   }
 #ifdef CLSTM_LSTM_PROF
   if (a.prof && b == 0 && dir == 0 && lane == 0)
-    for (int k = 0; k < 8; k++) a.prof[wave * 8 + k] = pacc[k];
+    for (int k = 0; k < 12; k++) a.prof[wave * 12 + k] = pacc[k];
 #endif
 }
 template <int NK4, int KU>

@@ -252,7 +252,7 @@ DEVFN void pack_rf(size_t e, const float* v, float* Rf, const PackDesc& p) {
   const int g = gk / KQP, kk = gk % KQP;
   const int lane = tid & 63, wave = tid >> 6;
   const int cell = wave * 16 + (lane >> 2), q = lane & 3;
-  const int k = q * p.ku + kk;
+  const int k = stag_on(p.nk4) ? stag_fwd_k(q, kk, p.ku) : q * p.ku + kk;   // (staggered recurrence: [group A cells | group B cells])
   float x = 0.0f;
   // register slot g of lane q holds gate g^q: the quad reduce-scatter then needs no selects (lstm_seq.h)
   if (cell < p.no && kk < p.ku && k < p.no) x = v[p.p_off[dir][g ^ q] + cell + (size_t)p.no * (1 + p.ni + k)];

@@ -16,13 +16,14 @@ lines = [np.clip(rng.normal(0.2, 0.3, (T, NI)), 0, 1).astype(np.float32) for _ i
 net.set_inputs(lines)
 for _ in range(3):
     net.forward()
-out = (ctypes.c_longlong * 64)()
+out = (ctypes.c_longlong * 96)()
 fn = lib.dll.clstm_debug_lstm_cycles
 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 fn(net.h, out)
-v = np.array(list(out), dtype=np.float64).reshape(8, 8) / T
-names = ["loop/addr", "LDS read + FMA", "reduce + gx wait", "gate act + bcast", "c, tanh(c), h", "stores + LDS write", "barrier"]
+v = np.array(list(out), dtype=np.float64).reshape(8, 12) / T
+names = ["loop/addr", "LDS read + FMA", "reduce + gx wait", "gate act + bcast", "c, tanh(c), h", "stores + LDS write", "barrier (end of step)",
+         "A: reads, stores, FMAs < Y", "A: wait at Y", "B: wait at X (mid-tail)"]
 print("cycles per step (workgroup 0, waves 0..6; s_memtime ticks):")
 for k, n in enumerate(names):
-    print("  %-22s" % n + "".join("%8.0f" % v[w, k] for w in range(7)))
-print("  %-22s" % "total" + "".join("%8.0f" % v[w, :7].sum() for w in range(7)))
+    print("  %-28s" % n + "".join("%8.0f" % v[w, k] for w in range(7)))
+print("  %-22s" % "total" + "".join("%8.0f" % v[w, :10].sum() for w in range(7)))
