@@ -259,8 +259,14 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   const int nc = a.nc, ncp = a.ncp;
   double* part = reinterpret_cast<double*>(lds + L.part);   // 512 doubles, reused phase by phase
   double* tot = reinterpret_cast<double*>(lds + L.tot);
+  // One region (the carve's row buffer + lattice tile + row sums, `cap` words) is re-used phase by phase, so that a line
+  // needs max(T (ncp + nup), 2 T S, T (sp + nup)) words, not T (ncp + sp):
+  //   A: posteriors [T][ncp] | match scores per distinct class [T][nup]      B: alpha [T][S] | reversed alpha [T][S]
+  //   C..E: lattice tile [T][sp] | class columns [T][nup]
   float* rowbuf = lds + L.rowbuf;
-  float* etile = lds + L.etile;
+  float* lmu = rowbuf + T * ncp;
+  float* etile = rowbuf;
+  const int cap = L.asum + a.tile - L.rowbuf;
   int* stl = reinterpret_cast<int*>(lds + L.states);
   int* lists = reinterpret_cast<int*>(lds + L.lists);
   int* ucol = reinterpret_cast<int*>(lds + L.ucol);
@@ -386,7 +392,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
         const bool in = i0 + u * CTC_THREADS < n;
         const int tc = in ? tq : 0, uc = in ? uq : 0;
         q[u] = (float)((double)rowbuf[tc * ncp + ucls[uc]] * part[tc]);
-        w[u] = in ? &etile[tc * nup + uc] : dump;
+        w[u] = in ? &lmu[tc * nup + uc] : dump;
         tq += dq; uq += dr;
         if (uq >= nu) { uq -= nu; tq++; }
       }
@@ -401,7 +407,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
     for (int s0 = 0; s0 < S; s0 += 64) {   // one wave per frame, lanes over states
       const int st = s0 + lane;
       const bool sok = st < S;
-      const float* col = etile + ucol[sok ? st : 0];
+      const float* col = lmu + ucol[sok ? st : 0];
       for (int t0 = wave; t0 < T; t0 += 8 * (CTC_THREADS / 64)) {
         float x[8];
 #pragma unroll
@@ -420,7 +426,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   //         depend on the lattice: a class without a target state has aligned = 0, delta = -p.
   float* all = rowbuf;            // alpha / reversed alpha in LDS (row buffer + lattice tile are both free here)
   float* bel = rowbuf + TS;
-  const bool lds_lat = S <= 64 && 2 * TS <= L.asum - L.rowbuf;
+  const bool lds_lat = S <= 64 && 2 * TS <= cap;
   if (lds_lat) ctc_lattice<true>(lm, all, bel, lds + L.vx, dump, tb, T, S);
   else ctc_lattice<false>(lm, al, be, lds + L.vx, dump, tb, T, S);
   const BufF32 dzb = make_buf(a.Dz + (size_t)off * nc, (size_t)T * nc * 4);
@@ -518,7 +524,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   //         Waves 4-7: lane = one first-occurrence label state, looping over frames (plain stores).
   //         Waves 0-3: lane = one frame, the blank states summed in state order in double (class 0 collects
   //         L+1 states: the reference's double accumulator).
-  float* rowc = rowbuf;   // [T][nup]
+  float* rowc = rowbuf + T * sp;   // [T][nup], behind the lattice tile
   if (wave >= 4) {
     for (int f0 = 0; f0 < nf; f0 += 64) {
       const bool fok = f0 + lane < nf;
@@ -633,7 +639,10 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   // Request order = completion order (vmcnt counts in order): the target states first (needed at once), then the
   // tables and -- short lines -- the posteriors, whose latency overlaps the state classification.
   // (the short-line path classifies ONE target state per thread: transcripts of more than 255 labels take the tiled path)
-  const bool short_line = T <= TT && S <= CTC_THREADS && T * S <= CTC_THREADS * CTC_CCACHE && nc <= CTC_THREADS;   // uniform per workgroup
+  // (the region the short-line path re-uses phase by phase must hold the line: always true for T <= tile)
+  const int sl_cap = L.asum + TT - L.rowbuf, sl_nub = ((S + 1) / 2 < nc ? (S + 1) / 2 : nc) | 1;   // nub: bound of its class columns
+  const bool short_line = T <= CTC_THREADS && (long)T * (ncp + sl_nub) <= sl_cap && (long)T * ((S | 1) + sl_nub) <= sl_cap &&
+                          S <= CTC_THREADS && T * S <= CTC_THREADS * CTC_CCACHE && nc <= CTC_THREADS;   // uniform per workgroup
   const int st0 = a.states[soff + (tid < S ? tid : 0)];
   double treg[CTC_TREG];
 #pragma unroll
