@@ -1419,7 +1419,12 @@ struct Net {
         ReduceDesc extra{};   // empty unless this is the top layer
         if (l == (int)L.size() - 1) extra = sm_red;
         const size_t work = (size_t)ndir * R * Cn + (size_t)extra.R * extra.Cn * extra.nbatch;
-        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, g, (int*)nullptr, 0);
+        UpdateFuse uf{};
+        if (fuse_update) {   // (train_step without a communicator) this layer's parameters are updated by the reduction itself
+          uf = UpdateFuse{v, d, lr, mom, gclip, (const int*)dev_err_words(), l == 0 ? update_step_word : nullptr, update_step_id};
+          if (l == 0) update_step_word = nullptr;
+        }
+        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, g, (int*)nullptr, 0, uf);
         timing.end(q);
         check_launch();
       };
@@ -1452,8 +1457,14 @@ struct Net {
 
   int* update_step_word = nullptr;   // (host-fed steps) pinned word the update kernel writes update_step_id into
   int update_step_id = 0;
+  bool fuse_update = false;   // this backward pass applies the update inside its reductions (set by train_step)
   void update() {
     hipStream_t s = stream();
+    if (fuse_update) {   // done by the reductions of the backward pass just enqueued
+      fuse_update = false;
+      packed_dirty = true;
+      return;
+    }
     if (comm) {   // sum of the ranks' fresh minibatch gradients, in place, on this stream (share_deltas, clstm.cc:731-744)
       timing.begin("allreduce_grads", s);
       comm->allreduce(g, nparams, s);
@@ -1860,7 +1871,7 @@ int clstm_net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* alig
   net_ctc(h, labels_h, L_h, aligned_h);
   ABI_END
 }
-int clstm_net_backward(clstm_net* h) { ABI_BEGIN h->net.backward(); ABI_END }
+int clstm_net_backward(clstm_net* h) { ABI_BEGIN h->net.fuse_update = false; h->net.backward(); ABI_END }
 int clstm_net_enable_input_deltas(clstm_net* h, int on) { h->net.want_dx0 = on != 0; return 0; }
 int clstm_net_get_input_deltas_h(clstm_net* h, float* dx) {
   ABI_BEGIN
@@ -1931,6 +1942,7 @@ int clstm_net_train_step(clstm_net* h, const int* T_h, int bs, const float* x_d,
   net_set_inputs_d(h, x_d, &meta);
   h->net.forward();
   net_ctc_launch(h);
+  h->net.fuse_update = !h->net.comm;   // no exchange in between: the reductions of the backward pass apply the update themselves
   h->net.backward();
   h->net.update();   // all-reduces the fresh gradient first when a communicator is attached
   ABI_END
@@ -1983,8 +1995,9 @@ int clstm_net_train_step_h(clstm_net* h, const int* T_h, int bs, const float* x_
   net_set_inputs_d(h, f.xin[slot].p, &meta);
   n.forward();
   net_ctc_launch(h);
-  n.backward();
   n.update_step_word = f.step_done; n.update_step_id = (int)(unsigned)k;
+  n.fuse_update = !n.comm;
+  n.backward();
   n.update();
   ABI_END
 }
@@ -2261,7 +2274,7 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     part->reserve((size_t)nsplit * R * Cn);
     gemm_f32<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
-                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0);
+                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0, (UpdateFuse{}));
   } else if (mode == 10) gemm_bf16<GEMM_KC, GEMM_MC>(g_stream, gemm_kc(A, K, R, 0), gemm_mc(B, Cn, K, 0), StorePlain{Cm, Cn}, R, Cn, K);
   else if (mode == 11) gemm_bf16<GEMM_KC, GEMM_KC>(g_stream, gemm_kc(A, K, R, 0), gemm_kc(B, K, Cn, 0), StorePlain{Cm, Cn}, R, Cn, K);
   else if (mode == 12) {
@@ -2270,7 +2283,7 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     part->reserve((size_t)nsplit * R * Cn);
     gemm_bf16<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
-                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0);
+                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0, (UpdateFuse{}));
   } else if (mode == 30) {   // A: [R][K] bf16, B: [Cn][K] bf16 (the caller passes halfs in float-typed pointers)
     gemm_b16kk(g_stream, GemmOperand16{(const unsigned short*)A, K, (long long)R * K}, GemmOperand16{(const unsigned short*)B, K, (long long)Cn * K},
                StorePlain{Cm, Cn}, R, Cn, K);
@@ -2281,7 +2294,7 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     gemm_b16mc(g_stream, GemmOperand16B{(const unsigned short*)A, R, (long long)K * R, 0}, GemmOperand16B{(const unsigned short*)B, Cn, (long long)K * Cn, 0},
                StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
-                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0);
+                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0, (UpdateFuse{}));
   } else if (mode == 20) gemm_x3<GEMM_KC, GEMM_MC>(g_stream, gemm_kc(A, K, R, 0), gemm_mc(B, Cn, K, 0), StorePlain{Cm, Cn}, R, Cn, K);
   else if (mode == 21) gemm_x3<GEMM_KC, GEMM_KC>(g_stream, gemm_kc(A, K, R, 0), gemm_kc(B, K, Cn, 0), StorePlain{Cm, Cn}, R, Cn, K);
   else if (mode == 22) {
@@ -2290,7 +2303,7 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     part->reserve((size_t)nsplit * R * Cn);
     gemm_x3<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
-                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0);
+                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0, (UpdateFuse{}));
   } else throw Error("bad mode");
   check_launch();
   ABI_END

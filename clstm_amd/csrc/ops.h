@@ -380,7 +380,15 @@ struct ReduceDesc {
   long long base;
   int nsplit, nbatch, R, Cn, rs;
 };
-DEVFN void reduce_scatter_one(const ReduceDesc& d, size_t e, float* g) {
+// The SGD update folded into the reduction (clstm_net_train_step without a communicator: one launch less per step): the
+// thread that produces g[o] also applies k_update's arithmetic to element o -- every parameter is produced exactly once.
+struct UpdateFuse {
+  float* v; float* d;       // null v: reduce only
+  float lr, mom, clip;
+  const int* err;           // device error words (see k_update)
+  int* step_word; int step_id;
+};
+DEVFN void reduce_scatter_one(const ReduceDesc& d, size_t e, float* g, const UpdateFuse& u, const bool apply) {
   const size_t RC = (size_t)d.R * d.Cn;
   const int b = e / RC;
   const int rc = e - b * RC;
@@ -403,16 +411,25 @@ DEVFN void reduce_scatter_one(const ReduceDesc& d, size_t e, float* g) {
     for (int u = 0; u < 8; u++) s[u] += x[u];
   }
   const long long o = (d.moff ? d.moff[(size_t)b * d.Cn + c] : d.base + c) + (long long)d.rs * r;
-  g[o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  const float gv = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  g[o] = gv;
+  if (apply) {
+    float di = u.d[o] + gv;
+    if (u.clip < 1e6f) di = fmaxf(-u.clip, fminf(u.clip, di));
+    u.v[o] += di * u.lr;
+    u.d[o] = di * u.mom;
+  }
 }
 // up to two slab sets per launch (the softmax layer's weight gradient rides with the top LSTM layer's)
-__global__ void k_reduce_scatter(ReduceDesc d0, ReduceDesc d1, float* g, int* zero, int zero_n) {
+__global__ void k_reduce_scatter(ReduceDesc d0, ReduceDesc d1, float* g, int* zero, int zero_n, UpdateFuse u) {
   // (house-keeping that rides this launch: the work-queue heads of the fused backward launch return to zero)
   if (zero && blockIdx.x == 0 && (int)threadIdx.x < zero_n) zero[threadIdx.x] = 0;
+  if (u.step_word && blockIdx.x == 0 && threadIdx.x == 0) store_i32_wt(u.step_word, u.step_id);
+  const bool apply = u.v && !(u.err && (u.err[0] | u.err[1]) != 0);   // (a failed launch: the gradient is not applied)
   const size_t n0 = (size_t)d0.R * d0.Cn * d0.nbatch, n1 = (size_t)d1.R * d1.Cn * d1.nbatch;
   CLSTM_GRID_STRIDE(e, n0 + n1) {
-    if (e < n0) reduce_scatter_one(d0, e, g);
-    else reduce_scatter_one(d1, e - n0, g);
+    if (e < n0) reduce_scatter_one(d0, e, g, u, apply);
+    else reduce_scatter_one(d1, e - n0, g, u, apply);
   }
 }
 // diagnostics: the cross-lane primitives applied to the lane index (tests/test_intrinsics.py)

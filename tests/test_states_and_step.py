@@ -87,12 +87,14 @@ def test_states_need_rectangular_batch(backend):
         net.n_states()
 
 
-def test_train_step_is_the_sequence_of_calls(backend):
+@pytest.mark.parametrize("nh", [[10], [7, 5]])
+def test_train_step_is_the_sequence_of_calls(backend, nh):
     """clstm_net_train_step == set_batch; set_inputs_d; forward; ctc; backward; update -- bit for bit,
-    over several steps (momentum carried in derivs)."""
+    over several steps (momentum carried in derivs).  (Without a communicator train_step applies the update inside the
+    slab reductions of its backward pass, layer by layer: same arithmetic, one launch less.)"""
     from clstm_amd.init import init_params
     from clstm_amd.net import Network
-    ni, nh, nc = 6, [10], 7
+    ni, nc = 6, 7
     rng = np.random.default_rng(5)
     p0 = init_params(ni, nh, nc, seed=0.222) * 20
     a = Network(ni, nh, nc, lib=backend.lib)
