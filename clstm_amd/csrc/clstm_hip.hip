@@ -632,6 +632,8 @@ struct Layer {
   bool sbf_ready = false;      // ... complete for this forward pass
   bool d_f32_valid = true;     // D (f32 gate deltas) is current (a persistent bf16 backward pass may leave only Dbf)
   bool sx_valid = true;        // the [1 | x] columns of S (f32) are current (built lazily when the bf16 rows serve the weight gradient)
+  bool h_f32_valid = true;     // the f32 outputs H are current (a persistent bf16 forward pass of a lower layer leaves only Hbf)
+  bool sh_valid = true;        // the h_{t-1} columns of S (f32) are current (... only Sbf)
   DevBuf<unsigned short> Dbf;  // per-frame bf16 gate deltas written by the persistent backward kernel (A operand of the x.d GEMM)
   DevBuf<unsigned short> Wtb;  // bf16 copy of Wt ([ni][M], k = gate column contiguous): B operand of the bf16-source x.d product
   int lds = 0;
@@ -938,6 +940,16 @@ struct Net {
         w.Sbf = y.Sbf.p; w.sbf_ld = ldsb; w.sbf_ofs = y.ni; w.sbf_dir = (long long)N * ldsb;
       }
       if (fwd && (y.no & 1) == 0 && &y != &L.back()) { y.Hbf.reserve((size_t)N * ndir * y.no + 64); w.Hbf = y.Hbf.p; w.hbf_ld = ndir * y.no; }
+      // Stores nobody reads in this mode (the per-frame stores of the persistent kernel cost per INSTRUCTION, seven per wave
+      // and step): the f32 outputs of a layer whose consumer takes Hbf (the next layer's W_x product and source rows), the
+      // f32 h_{t-1} source columns when the weight gradient takes Sbf.  ensure_h_f32 / ensure_source rebuild them exactly.
+      if (fwd) {   // (measured at configs[4]: forward passes 1.647 -> 1.580 ms per minibatch)
+        const int l = (int)(&y - L.data());
+        const bool next_takes_hbf = w.Hbf && l + 1 < (int)L.size() && bf16_gemm && L[l + 1].WtbT.p &&
+                                    L[l + 1].ni == ndir * y.no && (L[l + 1].ni & 1) == 0;
+        w.skip_h = next_takes_hbf;
+        w.skip_s = w.Sbf != nullptr;
+      }
     }
     return w;
   }
@@ -948,9 +960,27 @@ struct Net {
     CLSTM_LAUNCH(k_bf16_to_f32, dim3(nblocks((size_t)N * ndir * 4 * y.no)), dim3(256), 0, stream(), y.Dbf.p, y.D.p, (size_t)N * ndir * 4 * y.no);
     y.d_f32_valid = true;
   }
+  void ensure_h_f32(int l) {   // exact: the kernel's own h = tanh(c) * go (ops.h:k_h_from_state)
+    Layer& y = L[l];
+    if (y.h_f32_valid) return;
+    CLSTM_LAUNCH(k_h_from_state, dim3(nblocks((size_t)N * ndir * y.no)), dim3(256), 0, stream(), y.H.p, (const float*)y.G.p, (const float*)y.C.p,
+                 (size_t)N, y.no, ndir, y.ldh, y.hofs);
+    y.h_f32_valid = true;
+  }
+  void ensure_source_h(int l) {
+    Layer& y = L[l];
+    if (y.sh_valid) return;
+    ensure_h_f32(l);
+    flush_line_off();
+    CLSTM_LAUNCH(k_source_h, dim3(nblocks((size_t)N * ndir * y.no)), dim3(256), 0, stream(), y.S.p, (const float*)y.H.p, (const int*)line_off.p, bs,
+                 (size_t)N, y.no, ndir, y.ldh, y.hofs, y.lds, 1 + y.ni, (long long)N * y.lds);
+    y.sh_valid = true;
+  }
+  void ensure_source(int l) { ensure_source_x(l); ensure_source_h(l); }   // whole f32 source rows [1 | x | h_prev]
   void ensure_source_x(int l) {
     Layer& y = L[l];
     if (y.sx_valid) return;
+    if (l > 0) ensure_h_f32(l - 1);   // (reads the layer below's f32 outputs)
     hipStream_t s = stream();
     timing.begin("build_source", s);
     CLSTM_LAUNCH(k_build_source, dim3(nblocks((size_t)N * (1 + y.ni))), dim3(256), 0, s, y.S.p, layer_input(l),
@@ -968,8 +998,10 @@ struct Net {
     for (int l = 0; l < (int)L.size(); l++) {
       Layer& y = L[l];
       const int M = ndir * 4 * y.no;
+      const bool x_from_hbf = bf16_gemm && bf16_rec && l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.WtbT.p && y.ni == ndir * L[l - 1].no && (y.ni & 1) == 0;
+      if (l > 0 && !x_from_hbf) ensure_h_f32(l - 1);   // the products below read the f32 outputs of the layer underneath
       timing.begin("gemm_gates_x", s);
-      if (bf16_gemm && bf16_rec && l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.WtbT.p && y.ni == ndir * L[l - 1].no && (y.ni & 1) == 0)
+      if (x_from_hbf)
       {
         // the layer below left its outputs as a k-contiguous bf16 array: both operands go to LDS as they are
         g_path_count[2]++;
@@ -1008,15 +1040,18 @@ struct Net {
         const LstmWideArgs w = wide_args(y, true);
         launch_lstm_wide(true, w, tmax, coop_sync, step_graphs, s, bf16_rec);
         y.fwd_persistent = g_wide_persistent && bf16_rec;
+        y.h_f32_valid = !(y.fwd_persistent && w.skip_h);   // (the per-step kernels store everything)
+        y.sh_valid = !(y.fwd_persistent && w.skip_s);
         if (g_wide_persistent) g_path_count[0]++;
         y.sbf_ready = y.fwd_persistent && w.Sbf;
         if (y.sbf_ready) {   // the non-recurrent columns of the bf16 source rows (the recurrence stored the h columns)
           const bool from16 = l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.ni == ndir * L[l - 1].no;
+          if (l > 0 && !from16) ensure_h_f32(l - 1);
           CLSTM_LAUNCH(k_source_x_bf16, dim3(nblocks((size_t)N * ((y.ni >> 3) + 1))), dim3(256), 0, s, y.Sbf.p, from16 ? nullptr : layer_input(l),
                        from16 ? L[l - 1].Hbf.p : nullptr, from16 ? y.ni : layer_input_ld(l), (size_t)N, y.ni, y.ni + y.no, w.sbf_ld, ndir, w.sbf_dir);
         }
       }
-      else launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
+      else { launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s); y.h_f32_valid = y.sh_valid = true; }
       timing.end(s);
       if (!y.sbf_ready) ensure_source_x(l);
     }
@@ -1393,7 +1428,7 @@ struct Net {
       if (bf16_gemm || !overlap_eligible(y))
         ns = dw_from_bf16 && gemm_tile256(R, Cn) ? pick_split(R, Cn, ndir, 256)
              : bf16_gemm && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
-      if (!dw_from_bf16) { ensure_source_x(l); ensure_delta_f32(l); }   // the f32-source products below read S and D
+      if (!dw_from_bf16) { ensure_source(l); ensure_delta_f32(l); }   // the f32-source products below read S and D
       DevBuf<float>& pbuf = partial;
       auto do_dw = [&](hipStream_t q) {
         if (bf16_gemm || !overlap_eligible(y)) {
@@ -1894,6 +1929,7 @@ int clstm_net_get_state_h(clstm_net* h, int layer, int dir, int which, float* ou
   Layer& y = n.L[layer];
   n.tmp.reserve((size_t)n.N * y.no);
   if (which >= 6) n.ensure_delta_f32(layer);   // (a persistent bf16 backward pass leaves the deltas as bf16 only)
+  if (which == 5) n.ensure_h_f32(layer);       // (... forward pass of a lower layer: the outputs as bf16 only)
   const float* src = which < 4 ? y.G.p : which == 4 ? y.C.p : y.D.p;
   const int slot = which < 4 ? which : which >= 6 ? which - 6 : -1;
   if (which == 5)
@@ -2105,7 +2141,7 @@ static void states_transfer(clstm_net* h, float* data, long long total, bool get
     Layer& y = n.L[l];
     a.G[l].resize(N * n.ndir * 4 * y.no); a.C[l].resize(N * n.ndir * y.no);
     a.H[l].resize(N * y.ldh); a.S[l].resize(N * n.ndir * y.lds);
-    n.ensure_source_x((int)l);
+    n.ensure_source((int)l); n.ensure_h_f32((int)l);
     copy_d2h(a.G[l].data(), y.G.p, a.G[l].size()); copy_d2h(a.C[l].data(), y.C.p, a.C[l].size());
     copy_d2h(a.H[l].data(), y.H.p, a.H[l].size()); copy_d2h(a.S[l].data(), y.S.p, a.S[l].size());
   }
@@ -2138,6 +2174,7 @@ static void states_transfer(clstm_net* h, float* data, long long total, bool get
       copy_h2d(y.G.p, a.G[l].data(), a.G[l].size()); copy_h2d(y.C.p, a.C[l].data(), a.C[l].size());
       copy_h2d(y.H.p, a.H[l].data(), a.H[l].size()); copy_h2d(y.S.p, a.S[l].data(), a.S[l].size());
       y.sbf_ready = false;   // the bf16 copies made by the forward pass no longer match these states
+      y.h_f32_valid = y.sh_valid = y.sx_valid = true;   // (the f32 arrays were just written whole)
       y.sx_valid = true;
     }
     n.src0_ready = true;

@@ -54,6 +54,9 @@ struct LstmWideArgs {
   unsigned short* Hbf;          // persistent forward kernel: per-frame [N][hbf_ld] bf16 copy of h (dir d at column d*no): the next
   int hbf_ld;                   //   layer's W_x product reads it as its k-contiguous A operand; or null
   int skip_d;                   // persistent backward kernel: the f32 deltas D are not stored (every consumer reads Dbf; the host expands Dbf if one does not)
+  int skip_h, skip_s;           // persistent bf16 forward kernel: the f32 outputs H / the h_{t-1} columns of the f32 source rows S are not
+                                //   stored -- every consumer of this pass reads Hbf / Sbf; the host rebuilds them exactly (h = tanh(c) go
+                                //   from C and G) if something still asks (ops.h:k_h_from_state, k_source_h)
   unsigned short* Sbf;          // persistent forward kernel: bf16 source rows [x | h_{t-1} | 1] of THIS layer, [dir][N][sbf_ld] (h-part written here), or null
   int sbf_ld, sbf_ofs; long long sbf_dir;
   unsigned short* Dbf;          // persistent backward kernel: per-frame [N][nd][kp16] bf16 deltas (operand of the x.d GEMM), or null
@@ -720,10 +723,12 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
     if (live) {
       *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
       a.C[(n * nd + dir) * no + cell] = c_new;
-      a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
-      float* srow = a.S + (size_t)dir * a.sdir;
-      if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
-      if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+      if (!a.skip_h) a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
+      if (!a.skip_s) {
+        float* srow = a.S + (size_t)dir * a.sdir;
+        if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
+        if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+      }
     }
     if (live && !(c16 & 1)) {
       *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) = hp;
@@ -935,9 +940,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
         dl[j][1] = (gf * (-gf + 1.0f)) * d_gf;
         dl[j][2] = (go * (-go + 1.0f)) * d_go;
         dl[j][3] = (-ci * ci + 1.0f) * d_ci;
-        unsigned* db = reinterpret_cast<unsigned*>(a.Db + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + 4 * cellj[j]);
-        db[0] = bf16_pack2(dl[j][0], dl[j][1]);   // what the group waits for goes first
-        db[1] = bf16_pack2(dl[j][2], dl[j][3]);
+        // (one 8-byte store: what the group waits for goes first)
+        *reinterpret_cast<u32x2*>(a.Db + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + 4 * cellj[j]) =
+            u32x2{bf16_pack2(dl[j][0], dl[j][1]), bf16_pack2(dl[j][2], dl[j][3])};
       }
     }
     drain_vmem();
@@ -948,9 +953,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
       if (live[j]) {
         if (!a.skip_d) *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cellj[j]) * 4) = dl[j];
         if (a.Dbf) {   // k-contiguous bf16 copy per frame: the ready-made A operand of the x.d product (gemm_b16kk)
-          unsigned* df = reinterpret_cast<unsigned*>(a.Dbf + (size_t)(n * nd + dir) * a.kp16 + 4 * cellj[j]);
-          df[0] = bf16_pack2(dl[j][0], dl[j][1]);
-          df[1] = bf16_pack2(dl[j][2], dl[j][3]);
+          *reinterpret_cast<u32x2*>(a.Dbf + (size_t)(n * nd + dir) * a.kp16 + 4 * cellj[j]) =
+              u32x2{bf16_pack2(dl[j][0], dl[j][1]), bf16_pack2(dl[j][2], dl[j][3])};
         }
       }
       c_s[j] = cur[j].c_m1;

@@ -372,6 +372,28 @@ __global__ void k_build_source(float* S, const float* x, size_t N, int ni, int l
     for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = v;
   }
 }
+// On-demand rebuilds of what a persistent bf16 forward pass of a wide layer does not store (lstm_wide.h: skip_h / skip_s),
+// exact: the kernel's own h = tanh(c) * go from the stored state and output gate; the recurrent columns of the f32 source
+// rows are the outputs of the line's previous own step (forward_stack_delay, clstm_compute.cc:398-410), 0 at its first.
+__global__ void k_h_from_state(float* H, const float* G, const float* C, size_t N, int no, int ndir, int ldh, int hofs) {
+  CLSTM_GRID_STRIDE(e, N * (size_t)ndir * no) {
+    const size_t n = e / ((size_t)ndir * no);
+    const int r = e % ((size_t)ndir * no);
+    H[n * ldh + hofs + r] = gate_act(C[e], true) * G[e * 4 + 2];
+  }
+}
+__global__ void k_source_h(float* S, const float* H, const int* line_off, int bs, size_t N, int no, int ndir, int ldh, int hofs,
+                           int lds, int sofs, long long sdir) {
+  CLSTM_GRID_STRIDE(e, N * (size_t)ndir * no) {
+    const size_t n = e / ((size_t)ndir * no);
+    const int r = e % ((size_t)ndir * no), dir = r / no, cell = r % no;
+    int lo = 0, hi = bs;                       // line of frame n: line_off[lo] <= n < line_off[lo + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((size_t)line_off[mid] <= n) lo = mid; else hi = mid; }
+    const long long off = line_off[lo], T = line_off[lo + 1] - off, t = (long long)n - off;
+    const long long prev = dir == 0 ? t - 1 : t + 1;   // frame of the own step before
+    S[(size_t)dir * sdir + n * lds + sofs + cell] = (prev >= 0 && prev < T) ? H[(off + prev) * ldh + hofs + r] : 0.0f;
+  }
+}
 // g[off(b, c) + rs*r] = sum_z partial[b*nsplit + z][r][c]   (deterministic split-K reduction + row scatter;
 // every parameter is produced by exactly one (b, r, c), so this assigns and g needs no clearing)
 struct ReduceDesc {

@@ -349,17 +349,22 @@ net.set_params(rng.normal(0, 0.3, net.nparams).astype(np.float32))
 net.set_gemm_precision(2)
 net.set_inputs(common.synth_lines(rng, T, ni))
 net.forward()
+st = np.concatenate([net.state(l, d, "outputs").ravel() for l in (0, 1) for d in (0, 1)])   # the f32 outputs of both layers
 net.set_gemm_precision(1)
 net.ctc([rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T])
 net.backward()
 g = net.get_grads()
-print(json.dumps([float(np.abs(g.astype(np.float64)).sum()), g.view(np.uint32).astype(np.uint64).sum().item()]))
+print(json.dumps([float(np.abs(g.astype(np.float64)).sum()), g.view(np.uint32).astype(np.uint64).sum().item(),
+                  st.view(np.uint32).astype(np.uint64).sum().item()]))
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for mc in ("1", "0"):
-        env = dict(os.environ, CLSTM_GEMM_B16MC=mc)
+    # third process: per-step launches (CLSTM_XCD_REC=0) store every f32 array themselves -- the persistent pass leaves the
+    # lower layer's f32 outputs and the h_{t-1} source columns to ensure_h_f32 / ensure_source_h, which must rebuild them
+    # bit for bit (h = tanh(c) * go from the stored state and gate)
+    for extra in ({"CLSTM_GEMM_B16MC": "1"}, {"CLSTM_GEMM_B16MC": "0"}, {"CLSTM_XCD_REC": "0"}):
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"))], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-800:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert outs[0][0] > 0 and outs[0] == outs[1], outs
+    assert outs[0][0] > 0 and outs[0] == outs[1] == outs[2], outs
