@@ -4,7 +4,75 @@
 // thread reads and normalises the next minibatch while the GPU works on the current one), nhidden2=M builds the
 // "bidi2" prefab.  With the defaults (batch=1, nhidden2=0) the run is the reference's, update for update.
 #include "clstmhl.h"
+#include <sys/wait.h>
+#include <unistd.h>
 using namespace clstmhost;
+
+// ---- ngpu=N: one process per GPU ---------------------------------------------------------------------------------
+// The parent forks N-1 rank processes BEFORE anything touches the device; rank r binds GPU r (the r-th entry of
+// HIP_VISIBLE_DEVICES if the caller set one), rank 0 creates the RCCL id and hands it to the others through pipes, every
+// rank joins the library communicator (clstm_comm_create) and attaches it to its network: update() then all-reduces the
+// fresh minibatch gradient before the identical parameter update (precedent: share_deltas, clstm.cc:731-744).  All
+// ranks draw the SAME minibatches (same lrand48 sequence) and train on their contiguous shard of each; only rank 0
+// reports, tests and saves.  With ngpu=N batch=B the run equals ngpu=1 batch=B up to the summation order of the gradient.
+struct Ranks;
+static Ranks* g_ranks = nullptr;
+struct Ranks {
+  int rank = 0, n = 1;
+  std::vector<pid_t> kids;
+  clstm_comm* comm = nullptr;
+  void start(int ngpu) {
+    n = ngpu;
+    if (n <= 1) return;
+    std::vector<int> wr(n, -1);
+    int rd = -1;
+    for (int r = 1; r < n; r++) {
+      int fd[2];
+      if (pipe(fd) != 0) fail("pipe() failed");
+      const pid_t pid = fork();
+      if (pid < 0) fail("fork() failed");
+      if (pid == 0) {   // rank r
+        rank = r; rd = fd[0]; close(fd[1]);
+        for (int q = 1; q < r; q++) close(wr[q]);
+        kids.clear();
+        break;
+      }
+      kids.push_back(pid); wr[r] = fd[1]; close(fd[0]);
+    }
+    {   // one GPU per rank
+      const char* vis = getenv("HIP_VISIBLE_DEVICES");
+      std::string dev = std::to_string(rank);
+      if (vis && *vis) {
+        std::vector<std::string> ids;
+        std::string cur;
+        for (const char* c = vis;; c++) { if (*c == ',' || !*c) { ids.push_back(cur); cur.clear(); if (!*c) break; } else cur.push_back(*c); }
+        if ((int)ids.size() < n) fail("ngpu exceeds the GPUs listed in HIP_VISIBLE_DEVICES");
+        dev = ids[rank];
+      }
+      if (!getenv("CLSTM_NGPU_SHARE_DEVICE")) setenv("HIP_VISIBLE_DEVICES", dev.c_str(), 1);   // (tests without N GPUs: ranks share the device of the host emulator)
+    }
+    char id[CLSTM_COMM_ID_BYTES];
+    if (rank == 0) {
+      chk(clstm_comm_unique_id(id), "clstm_comm_unique_id");
+      for (int r = 1; r < n; r++) { if (write(wr[r], id, sizeof id) != (ssize_t)sizeof id) fail("rank pipe write failed"); close(wr[r]); }
+    } else {
+      size_t got = 0;
+      while (got < sizeof id) { const ssize_t k = read(rd, id + got, sizeof id - got); if (k <= 0) fail("rank pipe read failed"); got += (size_t)k; }
+      close(rd);
+    }
+    chk(clstm_comm_create(&comm, id, rank, n), "clstm_comm_create");
+  }
+  // rank 0 waits for the others; a rank process leaves through here
+  int finish(int status) {
+    if (comm) { clstm_synchronize(); }
+    if (rank != 0) { fflush(nullptr); _exit(status); }
+    for (pid_t k : kids) {
+      int st = 0;
+      if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) status = status ? status : 1;
+    }
+    return status;
+  }
+};
 
 struct Dataset {  // clstmocrtrain.cc:56-76
   vector<string> fnames;
@@ -37,7 +105,7 @@ static int print_usage(char** argv) {
   std::cerr << "Usage: [VAR=VAL...] " << argv[0] << " TRAININGLIST [TESTLIST]\n"
             << "  Variables: load save_name nhidden lrate momentum target_height ntrain start charsep\n"
             << "             report_time test_every report_every save_every params   (clstmocrtrain.cc:99-115)\n"
-            << "             batch (lines per update, default 1)  nhidden2 (> 0: bidi2)   (not in the reference)\n";
+            << "             batch (lines per update, default 1)  nhidden2 (> 0: bidi2)  ngpu (processes, one GPU each; needs batch % ngpu == 0)   (not in the reference)\n";
   return EXIT_FAILURE;
 }
 
@@ -50,7 +118,17 @@ static int main1(int argc, char** argv) {
   trainingset.readFileList(argv[1]);
   if (trainingset.size() <= 0) fail("empty training list");
   if (argc > 2) testset.readFileList(argv[2]);
-  std::cout << "got " << trainingset.size() << " files, " << testset.size() << " tests" << std::endl;
+  const int batch = std::max(1, getienv("batch", 1));
+  const int ngpu = std::max(1, getienv("ngpu", 1));
+  if (ngpu > 1 && batch % ngpu != 0) fail("ngpu=N needs batch to be a multiple of N (every rank trains on batch / N lines per update)");
+  Ranks ranks;
+  g_ranks = &ranks;
+  ranks.start(ngpu);            // (forks: nothing above touched the device)
+  const bool lead = ranks.rank == 0;
+  std::ostream null_out(nullptr);
+  std::ostream& out = lead ? std::cout : null_out;   // only rank 0 talks
+  out << "got " << trainingset.size() << " files, " << testset.size() << " tests" << std::endl;
+  if (ngpu > 1) out << "ranks " << ngpu << " x " << batch / ngpu << " lines" << std::endl;
   string load_name = getsenv("load", "");
   CLSTMOCR clstm;
   if (load_name != "") {
@@ -58,23 +136,24 @@ static int main1(int argc, char** argv) {
   } else {
     Codec codec;
     trainingset.getCodec(codec);
-    std::cout << "got " << codec.size() << " classes" << std::endl;
+    out << "got " << codec.size() << " classes" << std::endl;
     clstm.target_height = int(getrenv("target_height", 48));
     const int nhidden2 = getienv("nhidden2", 0);
     if (nhidden2 > 0) clstm.createBidi2(codec.codec, getienv("nhidden", 100), nhidden2);
     else clstm.createBidi(codec.codec, getienv("nhidden", 100));
     clstm.setLearningRate(getdenv("lrate", 1e-4), getdenv("momentum", 0.9));
   }
+  if (ranks.comm) chk(clstm_net_set_comm(clstm.net, ranks.comm), "clstm_net_set_comm");
   double test_error = 9999.0, best_error = 1e38;
   double start_time = now();
   int start = atoi(clstm.attr_get("trial", std::to_string(getienv("start", -1))).c_str()) + 1;
-  if (start > 0) std::cout << "start " << start << std::endl;
+  if (start > 0) out << "start " << start << std::endl;
   Trigger test_trigger(getienv("test_every", 10000), -1, start);
   test_trigger.skip0();
   Trigger save_trigger(getienv("save_every", 10000), ntrain, start);
-  save_trigger.enable(save_name != "").skip0();
+  save_trigger.enable(save_name != "" && lead).skip0();
   Trigger report_trigger(getienv("report_every", 100), ntrain, start);
-  const int batch = std::max(1, getienv("batch", 1));
+  const int shard = batch / ngpu, shard0 = ranks.rank * shard;   // this rank's lines of every minibatch
   // one training sample (clstmocrtrain.cc:160-166: `lrand48() % size`, readSample)
   auto draw_one = [&](Image& raw, ustring& gt) {
     const int sample = lrand48() % trainingset.size();
@@ -98,7 +177,7 @@ static int main1(int argc, char** argv) {
     for (int i = 0; i < batch; i++) samples[i] = lrand48() % trainingset.size();
     vector<std::shared_ptr<CLSTMOCR::Line>> lines(batch);
     vector<int> todo;   // first occurrence of every file that is not cached yet
-    for (int i = 0; i < batch; i++) {
+    for (int i = shard0; i < shard0 + shard; i++) {
       if (use_cache && cache[samples[i]]) { lines[i] = cache[samples[i]]; continue; }
       bool first = true;
       for (int j : todo) if (samples[j] == samples[i]) first = false;
@@ -120,21 +199,22 @@ static int main1(int argc, char** argv) {
     work(0);
     for (auto& f : pool) f.get();      // (rethrows a worker's exception)
     for (int i : todo) if (use_cache) cache[samples[i]] = lines[i];
-    for (int i = 0; i < batch; i++)
+    for (int i = shard0; i < shard0 + shard; i++)
       if (!lines[i]) for (int j : todo) if (samples[j] == samples[i]) lines[i] = lines[j];
     vector<const CLSTMOCR::Line*> ptrs;
-    for (auto& l : lines) ptrs.push_back(l.get());
+    for (int i = shard0; i < shard0 + shard; i++) ptrs.push_back(lines[i].get());
     clstm.pack(p, ptrs);
   };
   CLSTMOCR::Prepared cur, next;
   std::future<void> helper;
-  if (batch > 1) draw(next);
+  const bool batched = batch > 1 || ngpu > 1;
+  if (batched) draw(next);
   for (int trial = start; trial < ntrain; trial += batch) {
     // the last trial this update covers: the triggers look at it, so that the end-of-run save / test fire for any
     // batch size (Trigger fires for good at count >= upto - 1; with batch = 8 and ntrain = 1000 the loop ends at 992)
     const int tend = std::min(trial + batch - 1, ntrain - 1);
     ustring gt, pred;
-    if (batch == 1) {   // the reference's loop, sample for sample
+    if (!batched) {   // the reference's loop, sample for sample
       Image raw;
       draw_one(raw, gt);
       pred = clstm.train(raw, gt);
@@ -153,14 +233,14 @@ static int main1(int argc, char** argv) {
       gt = cur.targets.back();
     }
     if (report_trigger(tend)) {
-      std::cout << trial << std::endl;
-      std::cout << "TRU " << utf32_to_utf8(gt) << std::endl;
-      std::cout << "ALN " << clstm.aligned_utf8() << std::endl;
-      std::cout << "OUT " << utf32_to_utf8(pred) << std::endl;
-      if (trial > 0 && report_time) std::cout << "steptime " << (now() - start_time) / report_trigger.since() << std::endl;
+      out << trial << std::endl;
+      out << "TRU " << utf32_to_utf8(gt) << std::endl;
+      out << "ALN " << clstm.aligned_utf8() << std::endl;
+      out << "OUT " << utf32_to_utf8(pred) << std::endl;
+      if (trial > 0 && report_time) out << "steptime " << (now() - start_time) / report_trigger.since() << std::endl;
       start_time = now();
     }
-    if (test_trigger(tend) && testset.size() > 0) {
+    if (test_trigger(tend) && testset.size() > 0 && lead) {
       double count = 0.0, errors = 0.0;
       for (int test = 0; test < testset.size(); test++) {
         Image traw;
@@ -187,10 +267,14 @@ static int main1(int argc, char** argv) {
       clstm.save(fname);
     }
   }
-  return 0;
+  return ranks.finish(0);
 }
 
 int main(int argc, char** argv) {
   try { return main1(argc, argv); }
-  catch (const std::exception& e) { std::cerr << "FATAL: " << e.what() << std::endl; return 1; }
+  catch (const std::exception& e) {
+    std::cerr << "FATAL: " << e.what() << std::endl;
+    if (g_ranks && g_ranks->rank != 0) { fflush(nullptr); _exit(1); }   // a rank process never runs the parent's exit path
+    return 1;
+  }
 }

@@ -7,6 +7,7 @@ result equals the single-process oracle minibatch over ALL lines, including the 
 the carried momentum (Params.d, clstm_compute.cc:560-563) must NOT be multiplied by the replica
 count (the share_deltas artefact, clstm.cc:731-744 / SURVEY.md §8e)."""
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -180,3 +181,80 @@ def test_two_gpus_library_communicator_matches_single_process(tmp_path, ora32):
         ref.update()
     assert_close(p[0], ref.get_params(), rtol=2e-5, atol=2e-7, what="params after 2 DP steps on 2 GPUs")
     assert_close(d[0], ref.get_derivs(), rtol=1e-4, atol=1e-9, scale_atol=2e-4, what="momentum buffer after 2 DP steps on 2 GPUs")
+
+
+# ---- the C++ driver with ngpu=N: rank processes forked by clstmocrtrain itself ---------------------------------------
+def _driver_fixture(tmp_path, n=2):
+    """two short text lines cut from the reference's fixture image (so the emulator finishes in seconds)"""
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    im = Image.open(os.path.join(root, "tests", "golden", "textline.bin.png"))
+    names = []
+    for i, (x0, x1, gt) in enumerate([(0, 70, "pe"), (60, 150, "rf")][:n]):
+        p = tmp_path / ("l%d.bin.png" % i)
+        im.crop((x0, 0, x1, im.size[1])).save(p)
+        (tmp_path / ("l%d.gt.txt" % i)).write_text(gt + "\n", encoding="utf-8")
+        names.append(str(p))
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(names) + "\n")
+    return lst
+
+
+def _model_params(tool, path, tmp_path, tag):
+    out = tmp_path / ("params_%s.bin" % tag)
+    subprocess.run([tool, "params", str(path), str(out)], check=True, capture_output=True)
+    return np.fromfile(out, np.float32)
+
+
+def test_cpp_driver_ngpu2_equals_single_process(tmp_path):
+    """clstmocrtrain ngpu=2 batch=2 (the driver forks a second rank, both join the library communicator through
+    clstm_comm_unique_id / clstm_comm_create, every rank trains on its half of each minibatch, update() all-reduces the
+    gradient) must leave the model of ngpu=1 batch=2 -- same draws, same summed gradient, two summation orders.
+    CPU run: the driver is linked against the host emulator, whose communicator is a shared-memory all-reduce between
+    the rank processes (CLSTM_NGPU_SHARE_DEVICE: there is no device to bind)."""
+    from common import emu_lib
+    emu_lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "clstm_amd", "csrc"), "-s", "all"])
+    subprocess.check_call(["make", "-C", os.path.join(root, "clstm_amd", "host"), "-s", "all"])
+    emu_dir = os.path.join(root, "tests", "hipemu", "build")
+    exe = tmp_path / "clstmocrtrain_emu"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", str(exe), os.path.join(root, "clstm_amd", "host", "clstmocrtrain.cc"),
+                           "-L" + emu_dir, "-lclstm_emu", "-Wl,-rpath," + emu_dir, "-lz", "-pthread"])
+    lst = _driver_fixture(tmp_path)
+    tool = os.path.join(root, "clstm_amd", "bin", "clstm_hosttool")
+    got = {}
+    for ngpu in (1, 2):
+        env = dict(os.environ, ngpu=str(ngpu), batch="2", ntrain="6", nhidden="6", target_height="12", lrate="1e-2",
+                   report_every="2", save_every="1000", save_name=str(tmp_path / ("m%d" % ngpu)), CLSTM_NGPU_SHARE_DEVICE="1")
+        r = subprocess.run([str(exe), str(lst)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+        if ngpu == 2:
+            assert "ranks 2 x 1 lines" in r.stdout
+        assert r.stdout.count("TRU ") == 3, r.stdout          # only rank 0 reports
+        model = tmp_path / ("m%d-4.clstm" % ngpu)
+        assert model.exists(), r.stdout[-800:]
+        got[ngpu] = _model_params(tool, model, tmp_path, str(ngpu))
+    assert got[1].size == got[2].size and np.abs(got[1]).max() > 0
+    assert np.allclose(got[1], got[2], rtol=1e-5, atol=1e-7), np.abs(got[1] - got[2]).max()
+
+
+@pytest.mark.gpu
+def test_cpp_driver_ngpu2_on_two_gpus(tmp_path):
+    """the same through RCCL on a box with two GPUs (skips on one)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "clstm_amd", "host"), "-s", "all"])
+    exe = os.path.join(root, "clstm_amd", "bin", "clstmocrtrain")
+    tool = os.path.join(root, "clstm_amd", "bin", "clstm_hosttool")
+    lst = _driver_fixture(tmp_path)
+    got = {}
+    for ngpu in (1, 2):
+        env = dict(os.environ, ngpu=str(ngpu), batch="2", ntrain="40", nhidden="20", lrate="1e-2", report_every="10",
+                   save_every="1000", save_name=str(tmp_path / ("g%d" % ngpu)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([exe, str(lst)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+        got[ngpu] = _model_params(tool, tmp_path / ("g%d-38.clstm" % ngpu), tmp_path, "g%d" % ngpu)
+    assert np.allclose(got[1], got[2], rtol=1e-4, atol=1e-6), np.abs(got[1] - got[2]).max()
