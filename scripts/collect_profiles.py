@@ -13,7 +13,8 @@ pre = "r%s_" % rnd
 for name in ("bench_default.json", "bench_mb1.json", "bench_mb16.json", "bench_mb256.json", "bench_mb1024.json",
              "bench_ragged.json", "bench_b2.json", "bench_b2_bf16gemm.json", "bench_b2_bf16.json", "bench_forcedist.json",
              "bench_overlap0.json", "bench_host_inputs.json", "bench_driver_cmd.json", "fwd_timeline.txt", "lstm_fwd_phase_cycles.txt", "ctc_phase_cycles.txt", "timeline.txt", "host.txt", "pmc_FETCH_SIZE_summary.txt", "pmc_WRITE_SIZE_summary.txt",
-             "pmc_SQ_VALU_MFMA_BUSY_CYCLES_summary.txt", "pmc_GRBM_GUI_ACTIVE_summary.txt", "pmc_SQ_summary.txt"):
+             "pmc_SQ_VALU_MFMA_BUSY_CYCLES_summary.txt", "pmc_GRBM_GUI_ACTIVE_summary.txt", "pmc_SQ_summary.txt",
+             "pmc_FETCH_SIZE_ov0_summary.txt", "pmc_WRITE_SIZE_ov0_summary.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, pre + name))
@@ -32,6 +33,9 @@ def summary(counter):
 
 
 fe, wr = summary("FETCH_SIZE"), summary("WRITE_SIZE")
+if os.path.exists(os.path.join(src, "pmc_FETCH_SIZE_ov0_summary.txt")):   # pure kernels (CLSTM_OVERLAP=0 passes): names do not clash
+    for k, v in summary("FETCH_SIZE_ov0").items(): fe.setdefault(k, v)
+    for k, v in summary("WRITE_SIZE_ov0").items(): wr.setdefault(k, v)
 names = {"lstm_fwd": "void clstm::lstm_fwd_kernel<", "lstm_bwd": "void clstm::lstm_bwd_kernel<",
          "lstm_fwd_fused (W_x producers + recurrence + softmax consumers, one launch)": "void clstm::lstm_fwd_fused_kernel<",
          "lstm_bwd_dw (recurrence + weight-gradient GEMM, one launch)": "void clstm::lstm_bwd_dw_kernel<",

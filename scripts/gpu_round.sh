@@ -60,6 +60,12 @@ for CNT in FETCH_SIZE WRITE_SIZE; do
   python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_$CNT" $CNT > "$OUT/pmc_${CNT}_summary.txt" 2>&1; head -14 "$OUT/pmc_${CNT}_summary.txt"
   find "$OUT/pmc_$CNT" -name "*.csv" -size +8M -delete
 done
+# the PURE kernels (fusions off: recurrences alone, the batched gate GEMM): HBM bytes per launch
+for CNT in FETCH_SIZE WRITE_SIZE; do
+  CLSTM_OVERLAP=0 timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_${CNT}_ov0" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof_${CNT}_ov0.log" 2>&1
+  python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_${CNT}_ov0" $CNT > "$OUT/pmc_${CNT}_ov0_summary.txt" 2>&1; head -6 "$OUT/pmc_${CNT}_ov0_summary.txt"
+  find "$OUT/pmc_${CNT}_ov0" -name "*.csv" -size +8M -delete
+done
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_MFMA" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof_MFMA.log" 2>&1
 for CNT in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_MFMA" $CNT > "$OUT/pmc_${CNT}_summary.txt" 2>&1; head -8 "$OUT/pmc_${CNT}_summary.txt"
