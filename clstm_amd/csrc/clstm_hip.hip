@@ -397,7 +397,11 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
   REQUIRE((double)a.N * a.ndir * 4 * a.no * 4 < 2147483000.0,
           "minibatch too large for the lock-step recurrence (frames x 4 x nhidden x ndir x 4 B must stay below 2 GiB)");
   const int no = a.no, ncu = device_cu_count();
-  const int ntile = (no + 15) / 16, nzb = (a.bs + 15) / 16;
+  const int ntile = (no + 15) / 16, nzb16 = (a.bs + 15) / 16;
+  // persistent bf16 kernels: 32-line groups (two 16-line MFMA tiles per workgroup) once 16-line groups would need more than
+  // one launch of 8 groups -- a step's barrier and ring round trip are then paid once for twice the lines
+  const int mt = !bf16 ? 1 : nzb16 * a.ndir > 16 ? 4 : nzb16 * a.ndir > 8 ? 2 : 1;
+  const int nzb = (a.bs + 16 * mt - 1) / (16 * mt);
   a.tmax = tmax;
   sync.reserve(XcdSyncLayout::WORDS);
   a.sync = sync.p;
@@ -425,25 +429,29 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
   const bool fits = xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16);
   if (fwd) {
     if (fits && !bf16 && (size_t)xcd_fwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_fwd_f32, (size_t)xcd_fwd_f32_lds_bytes(a.kp))) return;
-    if (fits && bf16 && a.kp16 <= 512 && persistent(lstm_xcd_fwd_bf16, (size_t)xcd_fwd_lds_bytes())) return;
-    const int mt = a.bs > 32 ? 4 : a.bs > 16 ? 2 : 1;
-    const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mt - 1) / (16 * mt));
-    const dim3 grid16(ntile * a.ndir * nzb);
+    if (fits && bf16 && a.kp16 <= 512 &&
+        (mt == 4 ? persistent(lstm_xcd_fwd_bf16<4>, (size_t)xcd_fwd_lds_bytes(4))
+         : mt == 2 ? persistent(lstm_xcd_fwd_bf16<2>, (size_t)xcd_fwd_lds_bytes(2)) : persistent(lstm_xcd_fwd_bf16<1>, (size_t)xcd_fwd_lds_bytes(1)))) return;
+    const int mts = a.bs > 32 ? 4 : a.bs > 16 ? 2 : 1;
+    const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mts - 1) / (16 * mts));
+    const dim3 grid16(ntile * a.ndir * nzb16);
     launch_steps(graphs, bf16 ? 2 : 0, a, tmax, s, [&]() {
       LstmWideArgs w = a;
       for (int t = 0; t < tmax; t++) {
         w.step = t;
         if (bf16) CLSTM_LAUNCH(lstm_wide_fwd_step16_bf16, grid16, dim3(WIDE_THREADS), 0, s, w);
-        else if (mt == 4) CLSTM_LAUNCH(lstm_wide_fwd_step<4>, grid, dim3(WIDE_THREADS), 0, s, w);
-        else if (mt == 2) CLSTM_LAUNCH(lstm_wide_fwd_step<2>, grid, dim3(WIDE_THREADS), 0, s, w);
+        else if (mts == 4) CLSTM_LAUNCH(lstm_wide_fwd_step<4>, grid, dim3(WIDE_THREADS), 0, s, w);
+        else if (mts == 2) CLSTM_LAUNCH(lstm_wide_fwd_step<2>, grid, dim3(WIDE_THREADS), 0, s, w);
         else CLSTM_LAUNCH(lstm_wide_fwd_step<1>, grid, dim3(WIDE_THREADS), 0, s, w);
       }
     });
   } else {
     if (fits && !bf16 && (size_t)xcd_bwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_bwd_f32, (size_t)xcd_bwd_f32_lds_bytes(a.kp))) return;
-    if (fits && bf16 && a.kp16 <= 2048 && persistent(lstm_xcd_bwd_bf16, (size_t)xcd_bwd_lds_bytes())) return;
-    const dim3 grid(ntile, a.ndir, nzb);
-    const dim3 grid16(ntile * a.ndir * nzb);
+    if (fits && bf16 && a.kp16 <= 2048 &&
+        (mt == 4 ? persistent(lstm_xcd_bwd_bf16<4>, (size_t)xcd_bwd_lds_bytes(4))
+         : mt == 2 ? persistent(lstm_xcd_bwd_bf16<2>, (size_t)xcd_bwd_lds_bytes(2)) : persistent(lstm_xcd_bwd_bf16<1>, (size_t)xcd_bwd_lds_bytes(1)))) return;
+    const dim3 grid(ntile, a.ndir, nzb16);
+    const dim3 grid16(ntile * a.ndir * nzb16);
     launch_steps(graphs, bf16 ? 3 : 1, a, tmax, s, [&]() {
       LstmWideArgs w = a;
       for (int t = 0; t < tmax; t++) {

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_bwd_step(LstmWideArgs 
 // anything is written (the host then runs the per-step path).  Every poll loop carries a watchdog.
 struct XcdSyncLayout { enum { ARRIVED = 0, ERROR = 1, SLOT0 = 8, GROUP0 = 32, GROUP_STRIDE = 32, WORDS = 32 + 8 * 32 }; };
 constexpr int XCD_LDW = 512 + 8;        // halfs per resident weight row (conflict-free ds_read_b128 fragments), kp16 <= 512
-inline __host__ __device__ int xcd_fwd_lds_bytes() { return 64 * XCD_LDW * 2 + WIDE_NW * 16 * 68 * 4 + 64; }
+inline __host__ __device__ int xcd_fwd_lds_bytes(int mt = 1) { return 64 * XCD_LDW * 2 + WIDE_NW * mt * 16 * 68 * 4 + 64; }
 
 // thread 0 polls, everybody learns the outcome; `code` is what a time-out writes into the error word (1: before anything
 // was written -- the host may fall back to the per-step path; 2: in the middle of the sequence -- fatal)
@@ -666,10 +666,14 @@ DEVFN bool xcd_claim(int* sync, int* flag, const int ntile, const int ngroups, i
   return ok && xcd < ngroups && slot < ntile;
 }
 
+// MT: 16-line tiles per group (1: a group = 16 lines; 2: 32 lines -- minibatches of more than 8 / ndir blocks of 16 lines walk
+// half as many sequential launches, every weight fragment read from LDS serves two MFMAs, and a step's barrier and ring round
+// trip -- what a step costs -- are paid once for twice the lines)
+template <int MT>
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a) {
   unsigned short* wl = dyn_smem<unsigned short>();                         // [64][XCD_LDW]
-  float* red = reinterpret_cast<float*>(wl + 64 * XCD_LDW);                // [4][16][68]
-  int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * 68);
+  float* red = reinterpret_cast<float*>(wl + 64 * XCD_LDW);                // [4][MT * 16][68]
+  int* flag = reinterpret_cast<int*>(red + WIDE_NW * MT * 16 * 68);
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int no = a.no, nd = a.ndir;
   const int ntile = (no + 15) >> 4, nzb = a.zbn, ngroups = nd * nzb, ncg = (no + 3) >> 2;
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   // ---- claim a tile of this XCD's group, then check the placement of the whole grid ----
   int xcd, ct;
   if (!xcd_claim(sync, flag, ntile, ngroups, xcd, ct)) return;   // (uneven placement: nothing has been written yet)
-  const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
+  const int dir = xcd % nd, zb = a.zb0 + xcd / nd;               // zb: block of 16 MT lines
   int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
 
   // ---- the tile's 64 weight rows: cell groups 4ct .. 4ct+3 of this direction, 16 rows (cell_local*4 + gate) each ----
@@ -693,17 +697,22 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
       *reinterpret_cast<u16x8*>(wl + row * XCD_LDW + c * 8) = v;
     }
   }
-  // epilogue role: (line, cell); the line's extent is fixed for the whole launch
+  // epilogue role: (line, cell) for each of the MT line tiles; a line's extent is fixed for the whole launch
   const int ml = tid >> 4, c16 = tid & 15;
-  const int line = zb * 16 + ml, cell = ct * 16 + c16;
-  int off = 0, T = 0;
-  if (line < a.bs) { off = a.line_off[line]; T = a.line_off[line + 1] - off; }
-  const bool mine = line < a.bs && cell < no;
+  const int cell = ct * 16 + c16;
+  int line[MT], off[MT], T[MT];
+  bool mine[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++) {
+    line[i] = (zb * MT + i) * 16 + ml;
+    off[i] = 0; T[i] = 0;
+    if (line[i] < a.bs) { off[i] = a.line_off[line[i]]; T[i] = a.line_off[line[i] + 1] - off[i]; }
+    mine[i] = line[i] < a.bs && cell < no;
+  }
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
   const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * a.bs * a.kp16 * 2);
-  // A fragment of this lane: line zb*16 + (lane&15), 8 k at wave*kw + 32 g + 8 (lane>>4)
+  // A fragment of this lane: line (zb MT + i) 16 + (lane&15), 8 k at wave*kw + 32 g + 8 (lane>>4)
   const int kw = a.kp16 / WIDE_NW, ngrp = kw >> 5;   // <= 4 groups of 32 per wave
-  const int am = zb * 16 + (lane & 15);
   const unsigned akl = (unsigned)(wave * kw + 8 * (lane >> 4)) * 2u;
   const unsigned short* wfrag = wl + (lane & 15) * XCD_LDW + wave * kw + 8 * (lane >> 4);
   __syncthreads();
@@ -711,15 +720,17 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   // The gate pre-activations of step s come from HBM (~2 us) and VMEM returns in order: requested at the top of step s
   // they would hold back the h rows requested behind them.  They are requested one step AHEAD, behind that step's h
   // loads; c_{s-1} is this thread's own result of the previous step and stays in a register.
-  auto gx_load = [&](int sg) -> f32x4 {
-    const bool lv = mine && sg < T;
-    const long long nn = off + (dir == 0 ? sg : T - 1 - sg);
+  auto gx_load = [&](int sg, int i) -> f32x4 {
+    const bool lv = mine[i] && sg < T[i];
+    const long long nn = off[i] + (dir == 0 ? sg : T[i] - 1 - sg);
     return buf_load4(gbuf, lv ? (unsigned)(((nn * nd + dir) * no + cell) * 16) : BUF_OOB);
   };
-  f32x4 gx = gx_load(0);
-  float c_prev = 0.0f;
+  f32x4 gx[MT];
+  float c_prev[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++) { gx[i] = gx_load(0, i); c_prev[i] = 0.0f; }
   // the per-frame outputs of one step (nobody inside the pass reads them)
-  auto store_frame = [&](const f32x4 act, const float c_new, const float h, const unsigned hp, const long long n, const int sg, const bool live) {
+  auto store_frame = [&](const int i, const f32x4 act, const float c_new, const float h, const unsigned hp, const long long n, const int sg, const bool live) {
     if (live) {
       *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
       a.C[(n * nd + dir) * no + cell] = c_new;
@@ -727,77 +738,91 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
       if (!a.skip_s) {
         float* srow = a.S + (size_t)dir * a.sdir;
         if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
-        if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+        if (sg + 1 < T[i]) srow[(long long)(off[i] + (dir == 0 ? sg + 1 : T[i] - 2 - sg)) * a.lds + a.sofs + cell] = h;
       }
     }
     if (live && !(c16 & 1)) {
-      *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + cell) = hp;
+      *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line[i]) * a.kp16 + cell) = hp;
       if (a.Hbf) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
       if (a.Sbf) {   // h_{t-1} column block of the next frame's bf16 source row (weight-gradient operand, gemm_b16mc)
         unsigned short* sb = a.Sbf + (size_t)dir * a.sbf_dir + a.sbf_ofs + cell;
         if (sg == 0) *reinterpret_cast<unsigned*>(sb + (size_t)n * a.sbf_ld) = 0u;
-        if (sg + 1 < T) *reinterpret_cast<unsigned*>(sb + (size_t)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.sbf_ld) = hp;
+        if (sg + 1 < T[i]) *reinterpret_cast<unsigned*>(sb + (size_t)(off[i] + (dir == 0 ? sg + 1 : T[i] - 2 - sg)) * a.sbf_ld) = hp;
       }
     }
   };
   for (int sg = 0; sg < a.tmax; sg++) {
-    const bool live = mine && sg < T;
-    const long long n = off + (dir == 0 ? sg : T - 1 - sg);
-    f32x4 acc[4];
+    f32x4 acc[4][MT];
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
-    f32x4 gx_next;
-    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;   // h_{s-1} of the whole group is in the L2
-    // ---- 16 lines x 64 columns, split-K over the four waves ----
-    const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 2u + akl : BUF_OOB_BASE;
-    f32x4 ra[4];
+      for (int i = 0; i < MT; i++)
 #pragma unroll
-    for (int g = 0; g < 4; g++) ra[g] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+        for (int q = 0; q < 4; q++) acc[j][i][q] = 0.0f;
+    f32x4 gx_next[MT];
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;   // h_{s-1} of the whole group is in the L2
+    // ---- 16 MT lines x 64 columns, split-K over the four waves ----
+    f32x4 ra[4][MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+      const int am = (zb * MT + i) * 16 + (lane & 15);
+      const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 2u + akl : BUF_OOB_BASE;
+#pragma unroll
+      for (int g = 0; g < 4; g++) ra[g][i] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+    }
     SCHED_FENCE();
-    gx_next = gx_load(sg + 1);
+#pragma unroll
+    for (int i = 0; i < MT; i++) gx_next[i] = gx_load(sg + 1, i);
     SCHED_FENCE();
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       if (g < ngrp) {
-        const u16x8 av = __builtin_bit_cast(u16x8, ra[g]);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          acc[j] = mfma16x16x32_bf16(av, *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDW + g * 32), acc[j]);
+        for (int j = 0; j < 4; j++) {
+          const u16x8 wv = *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDW + g * 32);
+#pragma unroll
+          for (int i = 0; i < MT; i++) acc[j][i] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[g][i]), wv, acc[j][i]);
+        }
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int i = 0; i < MT; i++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * 68 + j * 16 + (lane & 15)] = acc[j][q];
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * 68 + j * 16 + (lane & 15)] = acc[j][i][q];
     __syncthreads();
-    float h = 0.0f, c_new = 0.0f;
-    f32x4 act = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (live) {
-      f32x4 k;
 #pragma unroll
-      for (int q = 0; q < 4; q++) k[q] = 0.0f;
+    for (int i = 0; i < MT; i++) {
+      const bool live = mine[i] && sg < T[i];
+      const long long n = off[i] + (dir == 0 ? sg : T[i] - 1 - sg);
+      float h = 0.0f, c_new = 0.0f;
+      f32x4 act = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (live) {
+        f32x4 k;
 #pragma unroll
-      for (int w = 0; w < WIDE_NW; w++) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(&red[(w * 16 + ml) * 68 + c16 * 4]);
+        for (int q = 0; q < 4; q++) k[q] = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 4; q++) k[q] += p[q];
+        for (int w = 0; w < WIDE_NW; w++) {
+          const f32x4 p = *reinterpret_cast<const f32x4*>(&red[((w * MT + i) * 16 + ml) * 68 + c16 * 4]);
+#pragma unroll
+          for (int q = 0; q < 4; q++) k[q] += p[q];
+        }
+        const float gi = gate_act(k[0] + gx[i][0], false), gf = gate_act(k[1] + gx[i][1], false),
+                    go = gate_act(k[2] + gx[i][2], false), ci = gate_act(k[3] + gx[i][3], true);
+        c_new = ci * gi + gf * c_prev[i];
+        h = gate_act(c_new, true) * go;
+        act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
       }
-      const float gi = gate_act(k[0] + gx[0], false), gf = gate_act(k[1] + gx[1], false),
-                  go = gate_act(k[2] + gx[2], false), ci = gate_act(k[3] + gx[3], true);
-      c_new = ci * gi + gf * c_prev;
-      h = gate_act(c_new, true) * go;
-      act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
+      const float hn = quad_xor1(h);
+      const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);   // (h = 0 for a line that has ended)
+      store_frame(i, act, c_new, h, hp, n, sg, live);
+      c_prev[i] = c_new;
+      gx[i] = gx_next[i];
     }
-    const float hn = quad_xor1(h);
-    const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);   // (h = 0 for a line that has ended)
-    store_frame(act, c_new, h, hp, n, sg, live);
     // publish: every store of this workgroup acknowledged by the L2, then one arrival on the group's counter.  (Storing
     // the bf16 h first and the other arrays behind the arrival was measured SLOWER, 3.5 vs 3.2 us per step: VMEM
     // completes in order, so the next step's operand loads then wait behind those stores.)
-    c_prev = c_new;
-    gx = gx_next;
     drain_vmem();
     __syncthreads();
     if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
@@ -809,156 +834,156 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
 constexpr int XCD_LDWB = 2048 + 8;      // halfs per resident weight row of the backward tile, kp16 <= 2048
 // Every workgroup of a group reads the group's WHOLE delta ring row block (16 lines x 2048 k x 2 B = 64 KB) each step
 // (two 16-cell tiles per workgroup -- half that traffic per L2 -- was measured no faster: 7.51 vs 6.99 ms per minibatch).
-inline __host__ __device__ int xcd_bwd_lds_bytes() {
-  constexpr int NT = 1;
-  const int need = NT * 16 * XCD_LDWB * 2 + WIDE_NW * 16 * (NT * 16 + 4) * 4 + 64;
+inline __host__ __device__ int xcd_bwd_lds_bytes(int mt = 1) {
+  const int need = 16 * XCD_LDWB * 2 + WIDE_NW * mt * 16 * (16 + 4) * 4 + 64;
   return need > 84 * 1024 ? need : 84 * 1024;   // > 80 KB: one workgroup per CU, whatever the tile needs
 }
 
+// MT: 16-line tiles per group, as in the forward kernel (the delta ring block a workgroup reads per step doubles with it:
+// 128 KB at MT = 2 -- sixteen 16-byte loads per lane and line tile, all in flight at once)
+template <int MT>
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a) {
-  constexpr int NT = 1;   // 16-cell tiles per workgroup
-  constexpr int LDR = NT * 16 + 4;
-  unsigned short* wl = dyn_smem<unsigned short>();                         // [NT*16][XCD_LDWB]
-  float* red = reinterpret_cast<float*>(wl + NT * 16 * XCD_LDWB);          // [4][16][LDR]
-  int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * LDR);
+  constexpr int LDR = 16 + 4;
+  unsigned short* wl = dyn_smem<unsigned short>();                         // [16][XCD_LDWB]
+  float* red = reinterpret_cast<float*>(wl + 16 * XCD_LDWB);               // [4][MT * 16][LDR]
+  int* flag = reinterpret_cast<int*>(red + WIDE_NW * MT * 16 * LDR);
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int no = a.no, nd = a.ndir;
-  const int ntile = (no + 15) >> 4, ntile2 = (ntile + NT - 1) / NT, nzb = a.zbn, ngroups = nd * nzb;
+  const int ntile = (no + 15) >> 4, nzb = a.zbn, ngroups = nd * nzb;
   int* const sync = a.sync;
   int xcd, slot;
-  if (!xcd_claim(sync, flag, ntile2, ngroups, xcd, slot)) return;
-  const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
+  if (!xcd_claim(sync, flag, ntile, ngroups, xcd, slot)) return;
+  const int dir = xcd % nd, zb = a.zb0 + xcd / nd;                         // zb: block of 16 MT lines
   int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
   {
     const int c8 = a.kp16 >> 3;
-    for (int i = tid; i < NT * 16 * c8; i += WIDE_THREADS) {
+    for (int i = tid; i < 16 * c8; i += WIDE_THREADS) {
       const int row = i / c8, c = i - row * c8;
-      const int ct = slot * NT + (row >> 4);
-      u16x8 v;
-#pragma unroll
-      for (int e = 0; e < 8; e++) v[e] = 0;
-      if (ct < ntile) v = *reinterpret_cast<const u16x8*>(a.Rw16 + ((long long)(dir * ntile + ct) * 16 + (row & 15)) * a.kp16 + c * 8);
-      *reinterpret_cast<u16x8*>(wl + row * XCD_LDWB + c * 8) = v;
+      *reinterpret_cast<u16x8*>(wl + row * XCD_LDWB + c * 8) =
+          *reinterpret_cast<const u16x8*>(a.Rw16 + ((long long)(dir * ntile + slot) * 16 + row) * a.kp16 + c * 8);
     }
   }
   const int ml = tid >> 4, c16 = tid & 15;
-  const int line = zb * 16 + ml;
-  int off = 0, T = 0;
-  if (line < a.bs) { off = a.line_off[line]; T = a.line_off[line + 1] - off; }
-  int cellj[NT];
-  bool minej[NT];
+  const int cell = slot * 16 + c16;
+  int line[MT], off[MT], T[MT];
+  bool mine[MT];
 #pragma unroll
-  for (int j = 0; j < NT; j++) { cellj[j] = (slot * NT + j) * 16 + c16; minej[j] = line < a.bs && cellj[j] < no; }
+  for (int i = 0; i < MT; i++) {
+    line[i] = (zb * MT + i) * 16 + ml;
+    off[i] = 0; T[i] = 0;
+    if (line[i] < a.bs) { off[i] = a.line_off[line[i]]; T[i] = a.line_off[line[i] + 1] - off[i]; }
+    mine[i] = line[i] < a.bs && cell < no;
+  }
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
   const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
   const BufF32 hbuf = make_buf(a.dH, (size_t)a.N * nd * no * 4);
   const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Db), (size_t)2 * nd * a.bs * a.kp16 * 2);
   const int kw = a.kp16 / WIDE_NW, ngrp = kw >> 5;   // <= 16 groups of 32 per wave
-  const int am = zb * 16 + (lane & 15);
   const unsigned akl = (unsigned)(wave * kw + 8 * (lane >> 4)) * 2u;
   const unsigned short* wfrag = wl + (lane & 15) * XCD_LDWB + wave * kw + 8 * (lane >> 4);
-  float dc_carry[NT];      // dc_{s+1} * gf_{s+1} of this thread's (line, cell)s: carried in registers, not through memory
+  float dc_carry[MT];      // dc_{s+1} * gf_{s+1} of this thread's (line, cell)s: carried in registers, not through memory
 #pragma unroll
-  for (int j = 0; j < NT; j++) dc_carry[j] = 0.0f;
+  for (int i = 0; i < MT; i++) dc_carry[i] = 0.0f;
   __syncthreads();
 
   // Epilogue operands (forward-pass arrays, from HBM) are requested one step AHEAD and behind that step's delta loads, so
   // that they never sit in front of them in the in-order VMEM queue; c_s of a step is the c_{s-1} the previous step loaded.
   struct Ops { f32x4 act; float dh_in, c_m1; };
-  auto ops_load = [&](int sg, int j) -> Ops {
-    const bool lv = minej[j] && sg < T;
-    const int ss = T - 1 - sg;
-    const long long nn = off + (dir == 0 ? ss : sg);
+  auto ops_load = [&](int sg, int i) -> Ops {
+    const bool lv = mine[i] && sg < T[i];
+    const int ss = T[i] - 1 - sg;
+    const long long nn = off[i] + (dir == 0 ? ss : sg);
     Ops o;
-    o.act = buf_load4(gbuf, lv ? (unsigned)(((nn * nd + dir) * no + cellj[j]) * 16) : BUF_OOB);
-    o.dh_in = buf_load(hbuf, lv ? (unsigned)((nn * (nd * no) + dir * no + cellj[j]) * 4) : BUF_OOB);
+    o.act = buf_load4(gbuf, lv ? (unsigned)(((nn * nd + dir) * no + cell) * 16) : BUF_OOB);
+    o.dh_in = buf_load(hbuf, lv ? (unsigned)((nn * (nd * no) + dir * no + cell) * 4) : BUF_OOB);
     o.c_m1 = buf_load(cbuf, lv && ss >= 1
-        ? (unsigned)((((long long)(off + (dir == 0 ? ss - 1 : sg + 1)) * nd + dir) * no + cellj[j]) * 4) : BUF_OOB);
+        ? (unsigned)((((long long)(off[i] + (dir == 0 ? ss - 1 : sg + 1)) * nd + dir) * no + cell) * 4) : BUF_OOB);
     return o;
   };
-  Ops cur[NT];
-  float c_s[NT];
+  Ops cur[MT];
+  float c_s[MT];
 #pragma unroll
-  for (int j = 0; j < NT; j++) {
-    cur[j] = ops_load(0, j);
-    const bool lv = minej[j] && 0 < T;
-    c_s[j] = buf_load(cbuf, lv ? (unsigned)((((long long)(off + (dir == 0 ? T - 1 : 0)) * nd + dir) * no + cellj[j]) * 4) : BUF_OOB);
+  for (int i = 0; i < MT; i++) {
+    cur[i] = ops_load(0, i);
+    const bool lv = mine[i] && 0 < T[i];
+    c_s[i] = buf_load(cbuf, lv ? (unsigned)((((long long)(off[i] + (dir == 0 ? T[i] - 1 : 0)) * nd + dir) * no + cell) * 4) : BUF_OOB);
   }
   for (int sg = 0; sg < a.tmax; sg++) {
-    const int s = T - 1 - sg;
-    const long long n = off + (dir == 0 ? s : sg);
-    bool live[NT];
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;
+    f32x4 acc[MT];
 #pragma unroll
-    for (int j = 0; j < NT; j++) live[j] = minej[j] && sg < T;
-    if (sg >= 1 && !xcd_wait_group(gcount, ntile2, sg, sync + XcdSyncLayout::ERROR, flag)) return;
-    f32x4 acc[NT];
+    for (int i = 0; i < MT; i++)
 #pragma unroll
-    for (int j = 0; j < NT; j++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
-    const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 2u + akl : BUF_OOB_BASE;
-    Ops nxt[NT];
+      for (int q = 0; q < 4; q++) acc[i][q] = 0.0f;
+    Ops nxt[MT];
     {   // all sixteen 32-k groups of the wave's quarter requested at once: ONE L2 round trip per step (two rounds of
         // eight cost a second one: 4.3 vs 3.x us per step)
-      f32x4 ra[16];
+      f32x4 ra[16][MT];
 #pragma unroll
-      for (int g = 0; g < 16; g++) ra[g] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+      for (int i = 0; i < MT; i++) {
+        const int am = (zb * MT + i) * 16 + (lane & 15);
+        const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 2u + akl : BUF_OOB_BASE;
+#pragma unroll
+        for (int g = 0; g < 16; g++) ra[g][i] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+      }
       SCHED_FENCE();
 #pragma unroll
-      for (int j = 0; j < NT; j++) nxt[j] = ops_load(sg + 1, j);
+      for (int i = 0; i < MT; i++) nxt[i] = ops_load(sg + 1, i);
       SCHED_FENCE();
 #pragma unroll
       for (int g = 0; g < 16; g++)
         if (g < ngrp) {
-          const u16x8 av = __builtin_bit_cast(u16x8, ra[g]);
+          const u16x8 wv = *reinterpret_cast<const u16x8*>(wfrag + g * 32);
 #pragma unroll
-          for (int j = 0; j < NT; j++)
-            acc[j] = mfma16x16x32_bf16(av, *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDWB + g * 32), acc[j]);
+          for (int i = 0; i < MT; i++) acc[i] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[g][i]), wv, acc[i]);
         }
     }
 #pragma unroll
-    for (int j = 0; j < NT; j++)
+    for (int i = 0; i < MT; i++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * LDR + j * 16 + (lane & 15)] = acc[j][q];
+      for (int q = 0; q < 4; q++) red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * LDR + (lane & 15)] = acc[i][q];
     __syncthreads();
-    f32x4 dl[NT];
+    f32x4 dl[MT];
+    bool live[MT];
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-      if (live[j]) {
+    for (int i = 0; i < MT; i++) {
+      live[i] = mine[i] && sg < T[i];
+      if (live[i]) {
         float dh_rec = 0.0f;
 #pragma unroll
-        for (int w = 0; w < WIDE_NW; w++) dh_rec += red[(w * 16 + ml) * LDR + j * 16 + c16];
-        const float gi = cur[j].act[0], gf = cur[j].act[1], go = cur[j].act[2], ci = cur[j].act[3];
-        const float dh = cur[j].dh_in + dh_rec;
-        const float th = gate_act(c_s[j], true);
+        for (int w = 0; w < WIDE_NW; w++) dh_rec += red[((w * MT + i) * 16 + ml) * LDR + c16];
+        const float gi = cur[i].act[0], gf = cur[i].act[1], go = cur[i].act[2], ci = cur[i].act[3];
+        const float dh = cur[i].dh_in + dh_rec;
+        const float th = gate_act(c_s[i], true);
         const float d_go = th * dh;
-        const float dc = (sg >= 1 ? dc_carry[j] : 0.0f) + (-th * th + 1.0f) * (go * dh);
-        dc_carry[j] = dc * gf;
-        const float d_gf = dc * cur[j].c_m1;
+        const float dc = (sg >= 1 ? dc_carry[i] : 0.0f) + (-th * th + 1.0f) * (go * dh);
+        dc_carry[i] = dc * gf;
+        const float d_gf = dc * cur[i].c_m1;
         const float d_gi = dc * ci, d_ci = dc * gi;
-        dl[j][0] = (gi * (-gi + 1.0f)) * d_gi;
-        dl[j][1] = (gf * (-gf + 1.0f)) * d_gf;
-        dl[j][2] = (go * (-go + 1.0f)) * d_go;
-        dl[j][3] = (-ci * ci + 1.0f) * d_ci;
+        dl[i][0] = (gi * (-gi + 1.0f)) * d_gi;
+        dl[i][1] = (gf * (-gf + 1.0f)) * d_gf;
+        dl[i][2] = (go * (-go + 1.0f)) * d_go;
+        dl[i][3] = (-ci * ci + 1.0f) * d_ci;
         // (one 8-byte store: what the group waits for goes first)
-        *reinterpret_cast<u32x2*>(a.Db + ((size_t)((sg & 1) * nd + dir) * a.bs + line) * a.kp16 + 4 * cellj[j]) =
-            u32x2{bf16_pack2(dl[j][0], dl[j][1]), bf16_pack2(dl[j][2], dl[j][3])};
+        *reinterpret_cast<u32x2*>(a.Db + ((size_t)((sg & 1) * nd + dir) * a.bs + line[i]) * a.kp16 + 4 * cell) =
+            u32x2{bf16_pack2(dl[i][0], dl[i][1]), bf16_pack2(dl[i][2], dl[i][3])};
       }
     }
     drain_vmem();
     __syncthreads();
     if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, slot, sg + 1);
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-      if (live[j]) {
-        if (!a.skip_d) *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cellj[j]) * 4) = dl[j];
+    for (int i = 0; i < MT; i++) {
+      if (live[i]) {
+        const long long n = off[i] + (dir == 0 ? T[i] - 1 - sg : sg);
+        if (!a.skip_d) *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl[i];
         if (a.Dbf) {   // k-contiguous bf16 copy per frame: the ready-made A operand of the x.d product (gemm_b16kk)
-          *reinterpret_cast<u32x2*>(a.Dbf + (size_t)(n * nd + dir) * a.kp16 + 4 * cellj[j]) =
-              u32x2{bf16_pack2(dl[j][0], dl[j][1]), bf16_pack2(dl[j][2], dl[j][3])};
+          *reinterpret_cast<u32x2*>(a.Dbf + (size_t)(n * nd + dir) * a.kp16 + 4 * cell) =
+              u32x2{bf16_pack2(dl[i][0], dl[i][1]), bf16_pack2(dl[i][2], dl[i][3])};
         }
       }
-      c_s[j] = cur[j].c_m1;
-      cur[j] = nxt[j];
+      c_s[i] = cur[i].c_m1;
+      cur[i] = nxt[i];
     }
   }
 }

@@ -267,7 +267,14 @@ def test_bf16_gate_gemms_track_the_f32_path(backend, ora32):
                                   ([32, 32], [9, 5, 7, 3]),
                                   # persistent backward pass that stores only bf16 deltas + a weight-gradient product that falls back to
                                   # the f32-source kernel (12 inputs: no bf16 source rows): the deltas are expanded on demand
-                                  ([32], [9, 5, 7, 3])])
+                                  ([32], [9, 5, 7, 3]),
+                                  # 70 ragged lines = five blocks of 16 x two directions > 8 groups: the persistent kernels switch to
+                                  # 32-line groups (two MFMA line tiles per workgroup; the last group half empty)
+                                  ([32, 32], [1 + (7 * i) % 6 for i in range(70)]),
+                                  # 132 lines = nine blocks of 16 x two directions > 16 groups: 64-line groups (four line tiles)
+                                  ([16], [1 + (5 * i) % 4 for i in range(132)])],
+                         ids=["two_layers", "odd_cells", "twenty_lines", "all_bf16_paths", "f32_source_fallback", "seventy_lines",
+                              "hundred_thirty_two_lines"])
 def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatch, nh, T):
     """clstm_net_set_gemm_precision(2): bf16 MFMA operands (recurrent weights, h, gate deltas) inside the lock-step
     recurrence (lstm_wide.h, *_step_bf16) on top of the bf16 hoisted GEMMs -- BASELINE config "2 x BiLSTM(512), bf16 MFMA".
