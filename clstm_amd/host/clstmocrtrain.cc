@@ -4,6 +4,7 @@
 // thread reads and normalises the next minibatch while the GPU works on the current one), nhidden2=M builds the
 // "bidi2" prefab.  With the defaults (batch=1, nhidden2=0) the run is the reference's, update for update.
 #include "clstmhl.h"
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 using namespace clstmhost;
@@ -17,6 +18,17 @@ using namespace clstmhost;
 // reports, tests and saves.  With ngpu=N batch=B the run equals ngpu=1 batch=B up to the summation order of the gradient.
 struct Ranks;
 static Ranks* g_ranks = nullptr;
+// rank 0: a rank process that dies leaves the others waiting in the next all-reduce for ever -- end the run instead
+static void on_rank_exit(int) {
+  int st = 0;
+  pid_t p;
+  while ((p = waitpid(-1, &st, WNOHANG)) > 0)
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+      static const char msg[] = "FATAL: a rank process of ngpu=N ended abnormally\n";
+      if (write(2, msg, sizeof msg - 1) < 0) {}
+      _exit(1);
+    }
+}
 struct Ranks {
   int rank = 0, n = 1;
   std::vector<pid_t> kids;
@@ -38,6 +50,14 @@ struct Ranks {
         break;
       }
       kids.push_back(pid); wr[r] = fd[1]; close(fd[0]);
+    }
+    if (rank == 0) {
+      struct sigaction sa{};
+      sa.sa_handler = on_rank_exit;
+      sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
+      sigaction(SIGCHLD, &sa, nullptr);
+    } else {
+      signal(SIGCHLD, SIG_DFL);
     }
     {   // one GPU per rank
       const char* vis = getenv("HIP_VISIBLE_DEVICES");
@@ -66,9 +86,12 @@ struct Ranks {
   int finish(int status) {
     if (comm) { clstm_synchronize(); }
     if (rank != 0) { fflush(nullptr); _exit(status); }
+    signal(SIGCHLD, SIG_DFL);   // from here on the exits are collected below
     for (pid_t k : kids) {
       int st = 0;
-      if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) status = status ? status : 1;
+      const pid_t r = waitpid(k, &st, 0);
+      if (r < 0) continue;        // (already collected by the handler: it exited cleanly, or the handler would have ended the run)
+      if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) status = status ? status : 1;
     }
     return status;
   }
