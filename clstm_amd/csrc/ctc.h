@@ -90,10 +90,18 @@ DEVFN float ctc_log_add(float x, float y, const CrTables tb) {  // tensor.h:86-8
   const float lg = cr_softplusf(d, tb) + y;   // log(exp(x-y)+1)+y, every float rounding reproduced (cr_math.h)
   return fabsf(d) > 10.0f ? fmaxf(x, y) : lg; // a select (an asm v_max here turns it into an exec-masked branch)
 }
-DEVFN float ctc_limexp(float x, const CrTables tb) {  // tensor.h:78-82
-  if (x < -30.0f) return (float)0x1.a56e0c2b7ab97p-44;  // (Float)exp(-30.0)
-  if (x > 30.0f) return (float)0x1.37047090c0b53p+43;   // (Float)exp(30.0)
-  return cr_expf(x, tb);
+// limexp (tensor.h:78-82) = exp of the argument clamped to [-30, 30], for phase C.  Phase C is OUTSIDE the recursion: an
+// error of its exp is not amplified by anything (epath -> per-state totals -> projection), so the correctly rounded double
+// evaluation the recursion needs (cr_math.h: ~13 f64 operations at half rate + a table read, 20 calls per thread = 7.7k of the
+// kernel's 128k cycles) buys nothing here.  Float evaluation, <= 2 ulp: x log2 e as t + r with the product's rounding error
+// and the constant's low part in r, 2^t by v_exp_f32 (1 ulp), first-order correction 2^t (1 + r ln 2) (|r| < 3e-6).
+DEVFN float ctc_limexp(float x) {
+  const float xc = fminf(fmaxf(x, -30.0f), 30.0f);
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;   // log2 e = HI + LO
+  const float t = xc * L2E_HI;
+  const float r = fmaf(xc, L2E_LO, fmaf(xc, L2E_HI, -t));
+  const float e = fast_exp2(t);
+  return fmaf(e * 0.693147182464599609375f, r, e);
 }
 
 // Phase B of both paths: alpha into `al`, the reversed-lattice alpha into `be` ([T][S] each).  The match
@@ -481,10 +489,9 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
     int tq = tid / S, sq = tid - tq * S;
 #pragma unroll
     for (int k = 0; k < CTC_CCACHE; k++) {
-      // limexp (tensor.h:78-82): the clamp to [-30, 30] followed by the round-once exp gives its three cases
-      const float x = fminf(fmaxf(bo[k] - mx, -30.0f), 30.0f);
+      // limexp (tensor.h:78-82): the clamp to [-30, 30] followed by the exp gives its three cases
       float* w = (tid + k * CTC_THREADS < TS) ? &etile[tq * sp + sq] : dump;
-      *w = cr_expf(x, tb);
+      *w = ctc_limexp(bo[k] - mx);
       tq += dq; sq += dr;
       if (sq >= S) { sq -= S; tq++; }
     }
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
 #pragma unroll
     for (int k = 0; k < CCACHE; k++) {
       const int i = tid + k * CTC_THREADS;
-      if (i < TS) al[i] = ctc_limexp(bo[k] - mx, tb);
+      if (i < TS) al[i] = ctc_limexp(bo[k] - mx);
     }
   } else {
     float mx = -3.0e38f;
@@ -768,7 +775,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
     __syncthreads();
     mx = red[0];
     for (int i = 1; i < CTC_THREADS / 64; i++) mx = fmaxf(mx, red[i]);
-    for (int i = tid; i < TS; i += CTC_THREADS) al[i] = ctc_limexp((al[i] + be[i]) - mx, tb);
+    for (int i = tid; i < TS; i += CTC_THREADS) al[i] = ctc_limexp((al[i] + be[i]) - mx);
   }
   __syncthreads();
   CTC_STAMP(3);
