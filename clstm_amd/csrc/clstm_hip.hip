@@ -1346,6 +1346,9 @@ struct Net {
 
   void backward() {
     REQUIRE(N > 0, "set_batch first");
+    const bool fuse = fuse_update;   // consumed here: an exception below must not leave it set for a later pass
+    fuse_update = false;
+    update_applied = false;
     flush_line_off();
     repack();
     hipStream_t s = stream();
@@ -1463,9 +1466,9 @@ struct Net {
         if (l == (int)L.size() - 1) extra = sm_red;
         const size_t work = (size_t)ndir * R * Cn + (size_t)extra.R * extra.Cn * extra.nbatch;
         UpdateFuse uf{};
-        if (fuse_update) {   // (train_step without a communicator) this layer's parameters are updated by the reduction itself
+        if (fuse) {   // (train_step without a communicator) this layer's parameters are updated by the reduction itself
           uf = UpdateFuse{v, d, lr, mom, gclip, (const int*)dev_err_words(), l == 0 ? update_step_word : nullptr, update_step_id};
-          if (l == 0) update_step_word = nullptr;
+          if (l == 0) { update_step_word = nullptr; update_applied = true; }   // (the last reduction of the pass)
         }
         CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, g, (int*)nullptr, 0, uf);
         timing.end(q);
@@ -1500,11 +1503,12 @@ struct Net {
 
   int* update_step_word = nullptr;   // (host-fed steps) pinned word the update kernel writes update_step_id into
   int update_step_id = 0;
-  bool fuse_update = false;   // this backward pass applies the update inside its reductions (set by train_step)
+  bool fuse_update = false;   // the NEXT backward pass applies the update inside its reductions (set by train_step)
+  bool update_applied = false; // ... and has done so: update() has nothing left to launch
   void update() {
     hipStream_t s = stream();
-    if (fuse_update) {   // done by the reductions of the backward pass just enqueued
-      fuse_update = false;
+    if (update_applied) {   // done by the reductions of the backward pass just enqueued
+      update_applied = false;
       packed_dirty = true;
       return;
     }
