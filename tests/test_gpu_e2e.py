@@ -114,6 +114,16 @@ def test_full_bench_shape_minibatch_vs_oracle(ora32):
 
 
 @pytest.mark.gpu
+def test_full_bench_shape_128_lines_fill_the_chip(ora32):
+    """The same shape with 128 lines: 256 recurrence workgroups = one per CU, no idle half of the chip -- the forward pass
+    runs as separate launches (batched gate GEMM, recurrence, fused softmax), the backward recurrence shares its launch
+    with the weight-gradient items without spare CUs.  Same bars as the 64-line case."""
+    from common import Backend
+    from test_net_parity import run_case
+    run_case(Backend("hip"), ora32, 48, 100, 83, [200] * 128, scale=10.0, seed=13, lr=1e-4, ctc_rtol=1e-3, grad_tol=1e-3)
+
+
+@pytest.mark.gpu
 def test_full_bench_shape_ragged_lines(ora32):
     """Same architecture, ragged line lengths U{150..250} and a one-frame line in the same minibatch."""
     from common import Backend
