@@ -628,6 +628,7 @@ struct Layer {
   float* Wk = nullptr;        // k-contiguous W_x rows for the producer items of the fused forward launch (ops.h:PackFused)
   int wk_kp = 0, wk_njp = 0;
   DevBuf<float> dCc;
+  DevBuf<int> pack_tab;       // source index of every packed element (k_pack_index), narrow layers in training steps
   // bf16 recurrence of a wide layer (lstm_wide_bf16.h): packed weights and the bf16 copies of h / the deltas
   unsigned short *Rbf = nullptr, *Rbb = nullptr;
   DevBuf<unsigned short> Hb, Db;
@@ -740,6 +741,18 @@ struct Net {
   hipStream_t stream() const { return g_stream; }
 
   static bool l_is_only_layer(const clstm_net_desc& ds) { return ds.nlayers == 1; }
+  // source-index table of a narrow layer's per-step repack (ops.h:k_pack_index), built at first use
+  int* pack_table(Layer& y) {
+    if (!y.pack_tab.p) {
+      const PackFused pf = pack_fused_desc(y);
+      const size_t n = (size_t)(1 + y.ni) * ndir * 4 * y.no + 2 * ((size_t)ndir * 4 * 4 * y.nk4 * y.nthreads) +
+                       (pf.Wk ? (size_t)ndir * pf.njp * 16 * pf.kp + (size_t)96 * pf.kps : 0);
+      y.pack_tab.reserve(n);
+      CLSTM_LAUNCH(k_pack_index, dim3(nblocks(n)), dim3(256), 0, stream(), y.pack_tab.p, y.pd, pf);
+      check_launch();
+    }
+    return y.pack_tab.p;
+  }
   PackFused pack_fused_desc(const Layer& y) const {
     PackFused f{};
     if (y.Wk) { f.Wk = y.Wk; f.kp = y.wk_kp; f.njp = y.wk_njp; f.W1k = W1k; f.kps = w1k_kps; f.nc = desc.nclasses; f.sm_k = sm_ni; f.sm_off = sm_off; }
@@ -825,7 +838,7 @@ struct Net {
     for (auto& y : L) {
       (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff); (void)hipFree(y.Wk);
       (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release();
-      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false;
+      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false; y.pack_tab.release();
     }
     (void)hipFree(W1k); fw_items.release(); fw_flags.release();
     for (int i = 0; i < 2; i++) { hf.xin[i].release(); if (hf.pin[i]) (void)hipHostFree(hf.pin[i]); if (hf.copied[i]) (void)hipEventDestroy(hf.copied[i]); }
@@ -1855,7 +1868,8 @@ static void net_set_inputs_d(clstm_net* h, const float* x, const CtcMetaCopy* au
     // training step -- the CTC metadata (no DMA launches, no event records on the stream's critical path)
     CLSTM_LAUNCH(k_ingest_pack, dim3(nbi + nbp + (lo ? 1 : 0) + (ax ? (aux->nwords + 255) / 256 : 0)), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni, y.lds,
                  n.ndir, (long long)n.N * y.lds, nbi, nbp, (const float*)n.v, y.Wt, y.bias, y.Rf, y.Rb, y.pd, n.pack_fused_desc(y),
-                 lo ? n.lo_stage : nullptr, n.line_off.p, 2 * n.bs + 1, ax ? aux->src : nullptr, ax ? aux->dst : nullptr, ax ? aux->nwords : 0);
+                 lo ? n.lo_stage : nullptr, n.line_off.p, 2 * n.bs + 1, ax ? aux->src : nullptr, ax ? aux->dst : nullptr, ax ? aux->nwords : 0,
+                 (const int*)n.pack_table(y));
     if (lo) { n.ring.commit(g_stream); n.lo_pending = false; }
     if (ax) { h->ctc.ring.commit(g_stream); aux_done = true; }
     n.packed_dirty = false;

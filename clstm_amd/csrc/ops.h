@@ -235,15 +235,21 @@ struct PackDesc {
 //   Wt[k][m] (k < ni, m = dir*4no + 4*cell + slot) and bias[m] for the hoisted input GEMM,
 //   Rf[dir][(s*KQP + kk)][tid] = R_{s^q}[cell][q*KU + kk]        forward recurrence registers,
 //   Rb[dir][(i*SLP + pp)][tid] = R_g[j][4*kg + (i^Q)], (g,j) = pair js*SL+pp   backward recurrence registers.
-DEVFN void pack_wx(size_t e, const float* v, float* Wt, float* bias, const PackDesc& p) {
+// Every packed element is a COPY of one parameter (or a zero pad): `*_src` gives its flat index in v (-1: zero).  The maps
+// depend only on the layer's geometry, so the per-step repack of a training step reads them from a table built once
+// (k_pack_index; the integer divisions below then leave the step) -- k_pack_layer evaluates them in place.
+DEVFN long long pack_wx_src(size_t e, const PackDesc& p) {
   const int M = p.ndir * 4 * p.no;
   const int j = e / M, m = e % M;
   const int dir = m / (4 * p.no), c = (m % (4 * p.no)) >> 2, s = m & 3;
-  const float x = v[p.p_off[dir][s] + c + (size_t)p.no * j];
-  if (j == 0) bias[m] = x;
-  else Wt[(size_t)(j - 1) * M + m] = x;
+  return p.p_off[dir][s] + c + (long long)p.no * j;
 }
-DEVFN void pack_rf(size_t e, const float* v, float* Rf, const PackDesc& p) {
+DEVFN void pack_wx_store(size_t e, float x, float* Wt, float* bias, const PackDesc& p) {   // row 0 = bias, rows 1.. = Wt
+  const size_t M = (size_t)p.ndir * 4 * p.no;
+  if (e < M) bias[e] = x; else Wt[e - M] = x;
+}
+DEVFN void pack_wx(size_t e, const float* v, float* Wt, float* bias, const PackDesc& p) { pack_wx_store(e, v[pack_wx_src(e, p)], Wt, bias, p); }
+DEVFN long long pack_rf_src(size_t e, const PackDesc& p) {
   const int KQP = 4 * p.nk4;
   const size_t per_dir = (size_t)4 * KQP * p.nthreads;
   const int dir = e / per_dir;
@@ -253,12 +259,12 @@ DEVFN void pack_rf(size_t e, const float* v, float* Rf, const PackDesc& p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int cell = wave * 16 + (lane >> 2), q = lane & 3;
   const int k = stag_on(p.nk4) ? stag_fwd_k(q, kk, p.ku) : q * p.ku + kk;   // (staggered recurrence: [group A cells | group B cells])
-  float x = 0.0f;
   // register slot g of lane q holds gate g^q: the quad reduce-scatter then needs no selects (lstm_seq.h)
-  if (cell < p.no && kk < p.ku && k < p.no) x = v[p.p_off[dir][g ^ q] + cell + (size_t)p.no * (1 + p.ni + k)];
-  Rf[e] = x;
+  if (cell < p.no && kk < p.ku && k < p.no) return p.p_off[dir][g ^ q] + cell + (long long)p.no * (1 + p.ni + k);
+  return -1;
 }
-DEVFN void pack_rb(size_t e, const float* v, float* Rb, const PackDesc& p) {
+DEVFN void pack_rf(size_t e, const float* v, float* Rf, const PackDesc& p) { const long long s = pack_rf_src(e, p); Rf[e] = s >= 0 ? v[s] : 0.0f; }
+DEVFN long long pack_rb_src(size_t e, const PackDesc& p) {
   const int SLP = 4 * p.nk4;
   const int SL = (4 * p.no + 15) / 16;
   const size_t per_dir = (size_t)4 * SLP * p.nthreads;
@@ -270,13 +276,13 @@ DEVFN void pack_rb(size_t e, const float* v, float* Rb, const PackDesc& p) {
   const int js = lane & 15;
   const int kcell = 4 * (wave * 4 + (lane >> 4)) + (i ^ (js >> 2));   // slot i of quad Q holds cell i^Q
   const int pr = js * SL + pp;
-  float x = 0.0f;
   if (pp < SL && pr < 4 * p.no && kcell < p.no) {
     const int g = pr / p.no, j = pr % p.no;
-    x = v[p.p_off[dir][g] + j + (size_t)p.no * (1 + p.ni + kcell)];
+    return p.p_off[dir][g] + j + (long long)p.no * (1 + p.ni + kcell);
   }
-  Rb[e] = x;
+  return -1;
 }
+DEVFN void pack_rb(size_t e, const float* v, float* Rb, const PackDesc& p) { const long long s = pack_rb_src(e, p); Rb[e] = s >= 0 ? v[s] : 0.0f; }
 // k-contiguous packs for the wave-sized items of the fused forward launch (lstm_fwd_fused.h), zero padded:
 //   Wk[dir][m = 4*cell + slot][k]   = W_slot[cell][k] (input columns only), njp*16 rows of kp floats per direction
 //   W1k[c][k]                       = W1[c][1 + k], 96 rows of kps floats (softmax layer, sm_off = its flat offset)
@@ -287,18 +293,39 @@ struct PackFused {
 DEVFN size_t pack_fused_count(const PackFused& f, const PackDesc& p) {
   return f.Wk ? (size_t)p.ndir * f.njp * 16 * f.kp + (size_t)96 * f.kps : 0;
 }
-DEVFN void pack_fused(size_t e, const float* v, const PackFused& f, const PackDesc& p) {
+DEVFN long long pack_fused_src(size_t e, const PackFused& f, const PackDesc& p) {
   const size_t nwk = (size_t)p.ndir * f.njp * 16 * f.kp;
   if (e < nwk) {
     const int k = e % f.kp;
     const size_t r = e / f.kp;
     const int m = r % (f.njp * 16), dir = r / (f.njp * 16);
     const int cell = m >> 2, slot = m & 3;
-    f.Wk[e] = (cell < p.no && k < p.ni) ? v[p.p_off[dir][slot] + cell + (size_t)p.no * (1 + k)] : 0.0f;
-  } else {
-    const size_t e2 = e - nwk;
-    const int k = e2 % f.kps, c = e2 / f.kps;
-    f.W1k[e2] = (c < f.nc && k < f.sm_k) ? v[f.sm_off + c + (size_t)f.nc * (1 + k)] : 0.0f;
+    return (cell < p.no && k < p.ni) ? p.p_off[dir][slot] + cell + (long long)p.no * (1 + k) : -1;
+  }
+  const size_t e2 = e - nwk;
+  const int k = e2 % f.kps, c = e2 / f.kps;
+  return (c < f.nc && k < f.sm_k) ? f.sm_off + c + (long long)f.nc * (1 + k) : -1;
+}
+DEVFN void pack_fused_store(size_t e, float x, const PackFused& f, const PackDesc& p) {
+  const size_t nwk = (size_t)p.ndir * f.njp * 16 * f.kp;
+  if (e < nwk) f.Wk[e] = x; else f.W1k[e - nwk] = x;
+}
+DEVFN void pack_fused(size_t e, const float* v, const PackFused& f, const PackDesc& p) {
+  const long long s = pack_fused_src(e, f, p);
+  pack_fused_store(e, s >= 0 ? v[s] : 0.0f, f, p);
+}
+// tab[e] = source index of packed element e of the combined range [W_x rows | Rf | Rb | fused-forward packs] (-1: zero pad)
+__global__ void k_pack_index(int* tab, PackDesc p, PackFused pf) {
+  const size_t nwx = (size_t)(1 + p.ni) * p.ndir * 4 * p.no;
+  const size_t nr = (size_t)p.ndir * 4 * 4 * p.nk4 * p.nthreads;
+  const size_t nf = pack_fused_count(pf, p);
+  CLSTM_GRID_STRIDE(e, nwx + 2 * nr + nf) {
+    long long s;
+    if (e < nwx) s = pack_wx_src(e, p);
+    else if (e < nwx + nr) s = pack_rf_src(e - nwx, p);
+    else if (e < nwx + 2 * nr) s = pack_rb_src(e - nwx - nr, p);
+    else s = pack_fused_src(e - nwx - 2 * nr, pf, p);
+    tab[e] = (int)s;
   }
 }
 __global__ void k_pack_layer(const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p, PackFused pf) {
@@ -536,7 +563,7 @@ __global__ void k_transpose_to_bf16(const float* src, unsigned short* dst, int r
 // and each is far too small to fill the chip, so one launch ramp / tail instead of two.
 __global__ void k_ingest_pack(const float* x, float* X, float* S, size_t N, int ni, int lds, int ndir, long long sdir,
                               int nbi, int nbp, const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p, PackFused pf,
-                              const int* lo_src, int* lo_dst, int lo_n, const int* aux_src, int* aux_dst, int aux_n) {
+                              const int* lo_src, int* lo_dst, int lo_n, const int* aux_src, int* aux_dst, int aux_n, const int* tab) {
   if ((int)blockIdx.x >= nbi + nbp) {   // optional trailing blocks: small host arrays, straight from their pinned slots
     // (one element per thread: a read of host memory takes microseconds, so they must all be in flight at once)
     int blk = (int)blockIdx.x - (nbi + nbp);
@@ -552,29 +579,55 @@ __global__ void k_ingest_pack(const float* x, float* X, float* S, size_t N, int 
     return;
   }
   if ((int)blockIdx.x < nbi) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < N * (size_t)(1 + ni); e += (size_t)nbi * blockDim.x) {
-      const size_t n = e / (1 + ni);
-      const int j = e % (1 + ni);
-      float val = 1.0f;
-      if (j > 0) {
-        val = x[n * ni + (j - 1)];
-        X[n * ni + (j - 1)] = val;
+    if ((ni & 3) == 0 && (lds & 3) == 0 && ((size_t)x & 15) == 0) {
+      // 16 bytes per thread: chunk c of a frame = x[4c .. 4c+3] -> X as it is, and -- shifted by the bias column -- floats
+      // 4c .. 4c+3 of the source row [1 | x] = (x[4c-1] or the 1, x[4c], x[4c+1], x[4c+2]); the last chunk holds x[ni-1] alone
+      const size_t nch = (size_t)ni / 4 + 1;
+      for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < N * nch; e += (size_t)nbi * blockDim.x) {
+        const size_t n = e / nch;
+        const int c = (int)(e - n * nch);
+        const float prev = c == 0 ? 1.0f : x[n * ni + 4 * c - 1];
+        if (4 * c < ni) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(x + n * ni + 4 * c);
+          *reinterpret_cast<f32x4*>(X + n * ni + 4 * c) = xv;
+          const f32x4 sv = f32x4{prev, xv[0], xv[1], xv[2]};
+          for (int d = 0; d < ndir; d++) *reinterpret_cast<f32x4*>(S + (size_t)d * sdir + n * lds + 4 * c) = sv;
+        } else {
+          for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + 4 * c] = prev;
+        }
       }
-      for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = val;
+    } else {
+      for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < N * (size_t)(1 + ni); e += (size_t)nbi * blockDim.x) {
+        const size_t n = e / (1 + ni);
+        const int j = e % (1 + ni);
+        float val = 1.0f;
+        if (j > 0) {
+          val = x[n * ni + (j - 1)];
+          X[n * ni + (j - 1)] = val;
+        }
+        for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = val;
+      }
     }
   } else {
     const size_t nwx = (size_t)(1 + p.ni) * p.ndir * 4 * p.no;
     const size_t nr = (size_t)p.ndir * 4 * 4 * p.nk4 * p.nthreads;
     const size_t nf = pack_fused_count(pf, p);
     for (size_t e = (size_t)(blockIdx.x - nbi) * blockDim.x + threadIdx.x; e < nwx + 2 * nr + nf; e += (size_t)nbp * blockDim.x) {
-      if (e < nwx) pack_wx(e, v, Wt, bias, p);
+      if (tab) {   // source indices from the table built once per net (k_pack_index)
+        const int si = tab[e];
+        const float val = si >= 0 ? v[si] : 0.0f;
+        if (e < nwx) pack_wx_store(e, val, Wt, bias, p);
+        else if (e < nwx + nr) Rf[e - nwx] = val;
+        else if (e < nwx + 2 * nr) Rb[e - nwx - nr] = val;
+        else pack_fused_store(e - nwx - 2 * nr, val, pf, p);
+      }
+      else if (e < nwx) pack_wx(e, v, Wt, bias, p);
       else if (e < nwx + nr) pack_rf(e - nwx, v, Rf, p);
       else if (e < nwx + 2 * nr) pack_rb(e - nwx - nr, v, Rb, p);
       else pack_fused(e - nwx - 2 * nr, v, pf, p);
     }
   }
 }
-// constant-1 column of the output rows [1 | h] (written when the buffer grows; rows never move)
 __global__ void k_fill_col0(float* H, size_t rows, int ld, int col) {
   CLSTM_GRID_STRIDE(e, rows) H[e * ld + col] = 1.0f;
 }

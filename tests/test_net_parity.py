@@ -209,12 +209,15 @@ def test_errors_are_reported(backend):
         net.ctc([[7]])                             # class out of range
 
 
-def test_device_resident_inputs_match_host_inputs(backend, ora32):
+@pytest.mark.parametrize("ni,nh", [(6, 9), (8, 20)], ids=["scalar_ingest", "vector_ingest"])
+def test_device_resident_inputs_match_host_inputs(backend, ora32, ni, nh):
     # clstm_net_set_inputs_d (frames already in device memory: one pass copies them and lays down the first
     # layer's source rows) must give the same gradient as the host-buffer entry point
     from clstm_amd.net import Network
     rng = np.random.default_rng(5)
-    ni, nh, nc, T = 6, 9, 5, [5, 2, 4]
+    # (ni = 8: the ingest launch moves 16 bytes per thread; its weight repack reads the source-index table -- the host-buffer
+    #  path evaluates the same maps in place)
+    nc, T = 5, [5, 2, 4]
     params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
     lines = synth_lines(rng, T, ni)
     trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
