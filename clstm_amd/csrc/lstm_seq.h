@@ -346,8 +346,10 @@ DEVFN void lstm_fwd_body(const LstmSeqArgs& a, const int b, const int dir, const
       // behind this barrier the workgroup issues, in step t + 1, the loads for iteration t + 3: chunk (t + 3) >> 4 must
       // be there.  Its flag was requested two steps ago; if it is not up yet, hold the barrier.  (Chunk 0 is the
       // workgroup's own: no flag.)
-      const int c = (t + 3) >> 4;
-      if (c > 0 && __builtin_expect(wave_uniform(rdy) != a.gepoch, 0)) wait_chunk(c < nchunk ? c : nchunk - 1);
+      // (the chunk index is clamped to the line's last chunk FIRST: a line of 13..16 frames has only chunk 0, whose flag nobody
+      //  raises -- waiting for "chunk 1 clamped to 0" ran into the watchdog, scripts/gpu_stress_overlap.py)
+      const int c = (t + 3) >> 4 < nchunk ? (t + 3) >> 4 : nchunk - 1;
+      if (c > 0 && __builtin_expect(wave_uniform(rdy) != a.gepoch, 0)) wait_chunk(c);
       const int cn = (t + 5) >> 4;
       rdy = load_i32_wt(gfl + (cn < nchunk ? cn : nchunk - 1));
     }
@@ -472,7 +474,7 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
   // cur: operands of step s; nxt: operands of step s-1 (its c is c_{s-1}); ld: set to refill for step s-2
   // (deferring the delta store to the next step like the forward kernel does was measured slower here:
   //  126 -> 137 us)
-  auto step = [&](const int s, Ops& cur, const Ops& nxt, Ops& ld, const float* dq, float* dw, float& ka) {
+  auto step = [&](const int s, Ops& cur, const Ops& nxt, Ops& ld, const float* dq, float* dw, float& ka, float& kprev) {
     KEEP_ALIVE(ka);
     ld.act = buf_load(gbuf, gl + fr(s - 2) * gstride4);
     ld.dh = buf_load(hbuf, cl + fr(s - 2) * cstride4);
@@ -505,6 +507,12 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
 #pragma unroll
     for (int j = 0; j < NK4; j++) dv[j] = *reinterpret_cast<const float4*>(dq + 4 * j);
     SCHED_FENCE();
+    // the PREVIOUS step's delta store (and progress word), under the latency of the LDS reads -- the forward kernel's
+    // placement.  (Deferred to the TOP of the next step, in front of the reads, it was slower in round 1: 126 -> 137 us; here
+    // the pure kernel is equal, 98 us, and the fused launch, whose recurrence workgroups compete with the polling item
+    // workgroups for the memory pipeline, 120.4 -> 118.3 us: 0.2953 -> 0.2913 ms per step in three alternating runs.)
+    buf_store_wt(dbuf, s + 1 < T ? (tagl ? ptag : gl + fr(s + 1) * gstride4) : BUF_OOB, kprev);
+    SCHED_FENCE();
 #pragma unroll
     for (int j = 0; j < NK4; j++) {
       // pairs KU .. 4*NK4-1 of a slice are zero padding (SL = ceil(4 no / 16) <= KU)
@@ -526,11 +534,10 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
     const float dc = dc_carry + gth * dh;
     dc_carry = mul_quad_bcast_old<1>(actr, dc);   // c_{s-1}.d += c.d * gf (gf broadcast folded into the multiply)
     const float delta = (g == 2 ? dh : dc) * fb;
-    // (the reporting lane stores the progress word instead: iterations < it - 3 are complete)
+    // (the reporting lane stores the progress word instead: iterations < it - 3 are complete -- stored one step later with
+    //  the deltas, which only makes the claim older)
     // (address and data by select: a per-lane stride through v_mad_u32_u24 made hipcc serialise the step's LDS reads)
     const float sdat = tagl ? __builtin_bit_cast(float, a.prog_base + (T - 1 - s) - 3) : delta;
-    const unsigned soff = tagl ? ptag : gl + fr(s) * gstride4;
-    buf_store_wt(dbuf, soff, sdat);
     *dw = delta;
     ka = sdat;
     __syncthreads();
@@ -538,18 +545,23 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
   // 3 operand sets x 2 LDS phases: the pattern repeats every 6 steps
   int s = T - 1;
   for (; s >= 5; s -= 6) {
-    step(s, X0, X1, X2, rdA, wrA, ka0);
-    step(s - 1, X1, X2, X0, rdB, wrB, ka1);
-    step(s - 2, X2, X0, X1, rdA, wrA, ka2);
-    step(s - 3, X0, X1, X2, rdB, wrB, ka0);
-    step(s - 4, X1, X2, X0, rdA, wrA, ka1);
-    step(s - 5, X2, X0, X1, rdB, wrB, ka2);
+    step(s, X0, X1, X2, rdA, wrA, ka0, ka2);
+    step(s - 1, X1, X2, X0, rdB, wrB, ka1, ka0);
+    step(s - 2, X2, X0, X1, rdA, wrA, ka2, ka1);
+    step(s - 3, X0, X1, X2, rdB, wrB, ka0, ka2);
+    step(s - 4, X1, X2, X0, rdA, wrA, ka1, ka0);
+    step(s - 5, X2, X0, X1, rdB, wrB, ka2, ka1);
   }
-  if (s >= 0) step(s, X0, X1, X2, rdA, wrA, ka0);
-  if (s >= 1) step(s - 1, X1, X2, X0, rdB, wrB, ka1);
-  if (s >= 2) step(s - 2, X2, X0, X1, rdA, wrA, ka2);
-  if (s >= 3) step(s - 3, X0, X1, X2, rdB, wrB, ka0);
-  if (s >= 4) step(s - 4, X1, X2, X0, rdA, wrA, ka1);
+  if (s >= 0) step(s, X0, X1, X2, rdA, wrA, ka0, ka2);
+  if (s >= 1) step(s - 1, X1, X2, X0, rdB, wrB, ka1, ka0);
+  if (s >= 2) step(s - 2, X2, X0, X1, rdA, wrA, ka2, ka1);
+  if (s >= 3) step(s - 3, X0, X1, X2, rdB, wrB, ka0, ka2);
+  if (s >= 4) step(s - 4, X1, X2, X0, rdA, wrA, ka1, ka0);
+  {   // the last step's deltas (own step 0): the store data sits in slot (T - 1) mod 3
+    const int r = (T - 1) % 3;
+    const float last = r == 0 ? ka0 : r == 1 ? ka1 : ka2;
+    buf_store_wt(dbuf, tagl ? ptag : gl + fr(0) * gstride4, last);
+  }
   if (report) {   // the line is complete: drain this wave's stores, meet, publish "all T iterations"
     drain_vmem();
     __syncthreads();

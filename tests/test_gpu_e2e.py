@@ -503,3 +503,15 @@ def test_configs4_full_shape_bf16_vs_oracle(configs4_case):
     print("configs[4] bf16 vs the f32 ORACLE: max |dz| %.3g, argmax flips %.3g %% of frames, %d / 64 decodes identical, "
           "gradient error %.3g of max" % (err, 100 * flips, same, gerr))
     assert err < 1e-2 and flips < 2e-2 and same >= 62 and gerr < 1.5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [7, 11, 23])
+def test_fused_launches_randomised_stress(seed):
+    """scripts/gpu_stress_overlap.py: 60 random batch geometries (1..89 lines, longest line 8..260 frames, 33..120 cells) with both
+    fused launches forced (overlap mode 2) against the plain path of the same library: gradients within 5e-5 of the largest
+    entry, and no wait of either launch may run into its watchdog (seed 7, case 4 -- lines of 13..16 frames -- is the geometry
+    that caught the forward launch waiting for a flag nobody raises)."""
+    env = dict(os.environ, SEED=str(seed), NCASE="60")
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "scripts", "gpu_stress_overlap.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

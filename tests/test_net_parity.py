@@ -77,7 +77,9 @@ def test_bidi_small(backend, ora32, ni, nh, nc, T):
     run_case(backend, ora32, ni, nh, nc, T)
 
 
-@pytest.mark.parametrize("nh,T", [(100, [40, 23, 1, 70]), (90, [33, 17])])
+@pytest.mark.parametrize("nh,T", [(100, [40, 23, 1, 70]), (90, [33, 17]),
+                                  # lines of 13..16 frames: one chunk, computed by the recurrence workgroup itself -- no flag to wait for
+                                  (100, [14, 48, 16, 13])])
 def test_forward_as_one_launch(backend, ora32, nh, T):
     """The forward half as ONE launch with three workgroup roles (lstm_fwd_fused.h): producer waves compute the gate
     pre-activations chunk by chunk ahead of the recurrence, consumer waves the softmax of finished frames behind it.
@@ -86,8 +88,9 @@ def test_forward_as_one_launch(backend, ora32, nh, T):
     On the emulator all workgroups of the launch are live at once (one OS thread each), so flags and progress words are
     exercised as a protocol, not as a sequence of kernels."""
     before = _path_count(backend, 5)
-    run_case(backend, ora32, 48, nh, 83, T, scale=10.0, overlap=2)
+    net, _ = run_case(backend, ora32, 48, nh, 83, T, scale=10.0, overlap=2)
     assert _path_count(backend, 5) > before
+    assert net.overlap_stats()[1] == 0        # no wait of either fused launch ran into its watchdog
 
 
 def test_bidi_uw3_shape_short(backend, ora32):
