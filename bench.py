@@ -170,11 +170,18 @@ def timed_blocks(w, steps, warmup, fence, reduce_max):
     return blocks, i
 
 
-def kernel_times(w, steps, first_step):
-    """per-kernel device time over `steps` extra steps (HIP events on the library's stream)"""
+def kernel_times(w, steps, first_step, ms_per_step):
+    """per-kernel device time over `steps` extra steps: HIP events bound to each launch's own dispatch packet on the library's
+    stream (hipExtLaunchKernel start / stop events, csrc/devintrin.h) -- the packet time stamps rocprofv3 --kernel-trace reads"""
     import torch
     net = w.net
     net.enable_timing(True)
+    # lead-in with the timing on, not counted: ~25 ms of steps.  The first launches with profiled dispatch packets run slower
+    # (profiles/README.md: the fused launches read 116 us, settling at the rocprofv3 figure of 107 us within ~40 steps), and
+    # the lead-in fills the library's event pool, so the measured steps create no events
+    for i in range(int(min(100, max(3, np.ceil(25.0 / max(ms_per_step, 1e-3)))))):
+        w.step(first_step + i)
+    torch.cuda.synchronize()
     net.reset_timing()
     frames = 0
     for i in range(steps):
@@ -203,6 +210,23 @@ def pmc_traffic(minibatch, T, ragged):
     except Exception:
         pass
     return {}, None
+
+
+def rocprof_avg_ms(kernel, minibatch, T, ragged):
+    """average duration (ms) of `kernel` in the newest committed rocprofv3 --kernel-trace --stats summary of this command
+    (default workload only; None otherwise) -- for the reader to hold against avg_launch_ms"""
+    try:
+        import csv
+        import glob
+        if minibatch != 64 or T != 200 or ragged:
+            return None
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))[-1]
+        for row in csv.DictReader(open(f)):
+            if kernel in row["Name"]:
+                return round(float(row["AverageNs"]) * 1e-6, 4)
+    except Exception:
+        pass
+    return None
 
 
 def roofline_b1(w, kern, kern_unfused, frames_per_step, ms_per_step):
@@ -260,6 +284,12 @@ def roofline_b1(w, kern, kern_unfused, frames_per_step, ms_per_step):
     dom = max(dom_keys, key=lambda k: entries[k]["avg_launch_ms"])     # the dominant launch of the step BY TIME
     out = dict(entries[dom])
     out["traffic_source"] = traffic_src if out["traffic"] is not None else None
+    out["timing"] = ("avg_launch_ms: HIP start/stop events bound to the launch's own dispatch packet on the library's stream "
+                     "(hipExtLaunchKernel), measured live in this run; rocprof_avg_launch_ms: the committed rocprofv3 --kernel-trace "
+                     "--stats average of the same command (profiles/)")
+    out["rocprof_avg_launch_ms"] = rocprof_avg_ms({"lstm_bwd_dw": "lstm_bwd_dw_kernel", "lstm_fwd_fused": "lstm_fwd_fused_kernel",
+                                                   "lstm_fwd": "lstm_fwd_kernel", "lstm_bwd": "lstm_bwd_kernel"}.get(dom, dom),
+                                                  w.minibatch, w.T, w.ragged)
     out["note"] = ("latency-bound recurrence: %d workgroups (lines x directions) on 256 CUs, one dependent step per frame; "
                    "whole step %.1f GB/s of algorithmic bytes (SURVEY 8d: 3.62 MB/line + 2.17 MB/minibatch)"
                    % (2 * w.minibatch, (3.62e6 * w.minibatch + 2.17e6) / (ms_per_step * 1e-3) / 1e9))
@@ -309,11 +339,14 @@ def main():
                          "not the headline `value` (bench contract: inputs resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[4] leg of the default line")
-    ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel hipEvent timing")
+    ap.add_argument("--profile-steps", type=int, default=None,
+                    help="extra steps with per-kernel timing (events bound to each launch's dispatch packet); default 50 (b1) / 5 (b2)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.T is None:
         args.T = cfg["T"]
+    if args.profile_steps is None:
+        args.profile_steps = 50 if args.config == "b1" else 5
     default_line = (args.config == "b1" and not args.bf16 and not args.bf16_gemm and not args.ragged
                     and args.minibatch == 64 and args.T == 200 and not args.host_inputs)
     if args.config != "b1":
@@ -407,10 +440,10 @@ def main():
         fence()
         kern, fps, kern_unfused = {}, 0, {}
         if rank == 0 and profile_steps > 0:
-            kern, fps = kernel_times(w, profile_steps, nxt + 4)
+            kern, fps = kernel_times(w, profile_steps, nxt + 4, dt / steps * 1e3)
             if unfused_pass and world == 1:      # the pure kernels: the same steps with the fused launches off
                 w.net.set_overlap(0)
-                kern_unfused, _ = kernel_times(w, profile_steps, nxt + 4 + profile_steps)
+                kern_unfused, _ = kernel_times(w, profile_steps, nxt + 4 + profile_steps, dt / steps * 1e3)
                 w.net.set_overlap(1)
         return {"dt": dt, "blocks": blocks, "enqueue": t_enq, "kern": kern, "kern_unfused": kern_unfused, "frames_per_step": fps}
 

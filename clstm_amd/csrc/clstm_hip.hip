@@ -468,29 +468,35 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
 #ifndef CLSTM_HIP_EMU
 struct Timing {
   bool on = false;
-  struct Rec { std::string name; hipEvent_t a, b; };
+  struct Rec { std::string name; std::vector<ClstmLaunchEvents> launches; };
   std::vector<Rec> pending;
   std::map<std::string, std::pair<double, int>> acc;
-  void begin(const char* name, hipStream_t s) {
+  // a bracket names the launches issued inside it; each launch brings its own pair of events (devintrin.h, CLSTM_LAUNCH)
+  void begin(const char* name, hipStream_t) {
     if (!on) return;
-    Rec r; r.name = name;
-    HIPCHECK(hipEventCreate(&r.a)); HIPCHECK(hipEventCreate(&r.b));
-    HIPCHECK(hipEventRecord(r.a, s));
-    pending.push_back(r);
+    pending.emplace_back();
+    pending.back().name = name;
+    clstm_launch_sink = &pending.back().launches;
   }
-  void end(hipStream_t s) {
+  void end(hipStream_t) {
     if (!on) return;
-    HIPCHECK(hipEventRecord(pending.back().b, s));
+    clstm_launch_sink = nullptr;
   }
   void collect(hipStream_t s) {
+    clstm_launch_sink = nullptr;
     if (pending.empty()) return;
     HIPCHECK(hipStreamSynchronize(s));
     for (auto& r : pending) {
-      float ms = 0;
-      HIPCHECK(hipEventElapsedTime(&ms, r.a, r.b));
-      auto& e = acc[r.name];
-      e.first += ms; e.second += 1;
-      (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+      double sum = 0;
+      for (auto& e : r.launches) {
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, e.a, e.b));
+        sum += ms;
+        clstm_event_pool.push_back(e);
+      }
+      if (r.launches.empty()) continue;      // (a bracket around graph replays or copies only: nothing to report)
+      auto& a = acc[r.name];
+      a.first += sum; a.second += 1;
     }
     pending.clear();
   }

@@ -13,6 +13,8 @@
 #include "hip_emu.h"
 #else
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -278,10 +280,29 @@ DEVFN int wave_max_i(int x) {
 DEVFN void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // this wave's loads returned, stores acknowledged
 DEVFN unsigned mad_u24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }   // v_mad_u32_u24 (operands < 2^24)
 constexpr int GRID_WATCHDOG_SPINS = 1 << 21;   // ~seconds of polling before a stuck barrier is reported
+// bench.py's per-kernel timing.  While a Timing bracket of the host code is open (clstm_hip.hip), every launch carries a start /
+// stop event pair bound to its own dispatch packet (hipExtLaunchKernel): stop - start is the kernel's duration by the packet's own
+// time stamps -- the figure rocprofv3 --kernel-trace reports -- and nothing is inserted into the stream.  (An event RECORDED in
+// front of a launch makes the command processor finish the record before it looks at the launch, which exposes the launch's
+// set-up time, 5-7 us for the big fused launches, that normally hides behind the preceding kernel: brackets of recorded events
+// read 11 % above rocprofv3.)  Cooperative launches have no such variant and keep recorded events around them.
+struct ClstmLaunchEvents { hipEvent_t a, b; };
+inline thread_local std::vector<ClstmLaunchEvents>* clstm_launch_sink = nullptr;
+inline thread_local std::vector<ClstmLaunchEvents> clstm_event_pool;   // events of collected launches, re-used: creating a pair
+inline ClstmLaunchEvents clstm_launch_events() {                       // per launch makes the timed steps host-bound
+  ClstmLaunchEvents e{};
+  if (!clstm_event_pool.empty()) { e = clstm_event_pool.back(); clstm_event_pool.pop_back(); }
+  else { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
+  clstm_launch_sink->push_back(e);
+  return e;
+}
 #define CLSTM_LAUNCH_COOP(kernel, grid, block, smem, stream, argstruct)                                  \
   do {                                                                                                   \
     void* coop_args_[] = {(void*)&(argstruct)};                                                          \
+    ClstmLaunchEvents ev_{};                                                                             \
+    if (clstm_launch_sink) { ev_ = clstm_launch_events(); HIPCHECK(hipEventRecord(ev_.a, (hipStream_t)(stream))); } \
     HIPCHECK(hipLaunchCooperativeKernel((const void*)(kernel), grid, block, coop_args_, smem, (hipStream_t)(stream))); \
+    if (ev_.b) HIPCHECK(hipEventRecord(ev_.b, (hipStream_t)(stream)));                                   \
   } while (0)
 
 // A VMEM store reads its data VGPR when the memory pipeline executes it, so hipcc inserts a vmcnt
@@ -300,8 +321,13 @@ DEVFN T* dyn_smem() {
   return reinterpret_cast<T*>(clstm_dyn_smem_);
 }
 
-#define CLSTM_LAUNCH(kernel, grid, block, smem, stream, ...) \
-  hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+#define CLSTM_LAUNCH(kernel, grid, block, smem, stream, ...)                                                       \
+  do {                                                                                                             \
+    if (__builtin_expect(clstm_launch_sink != nullptr, 0)) {                                                       \
+      const ClstmLaunchEvents ev_ = clstm_launch_events();                                                         \
+      hipExtLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), ev_.a, ev_.b, 0, __VA_ARGS__);       \
+    } else hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__);                      \
+  } while (0)
 #endif  // CLSTM_HIP_EMU
 
 // progress words (lstm_seq.h -> gemm_dw.h) sit one per 128-byte line: a workgroup rewrites its word every step

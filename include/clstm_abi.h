@@ -192,9 +192,11 @@ int clstm_net_decode(clstm_net* net, int* classes_h, int* locs_h, int* counts_h)
  * dir 0 = forward NPLSTM, 1 = the NPLSTM inside Reversed.  out_h: HOST [N][nhidden] in FRAME
  * order (i.e. already un-reversed).  Blocking. */
 int clstm_net_get_state_h(clstm_net* net, int layer, int dir, int which, float* out_h);
-/* name and average device time (ms, hipEvent-timed on the library's stream) of the most
- * recent forward/backward kernels -- used by bench.py for the roofline object.
- * Enable with clstm_net_enable_timing(net, 1). */
+/* name and device time (ms) of the forward/backward kernels since the last reset -- used by bench.py for the roofline
+ * object.  Enable with clstm_net_enable_timing(net, 1).  While it is on, every launch carries a start / stop event pair
+ * bound to its own dispatch packet (hipExtLaunchKernel): the time is the kernel's duration by the packet's own time
+ * stamps, the figure rocprofv3 --kernel-trace reports; nothing is inserted into the stream.  total_ms sums the launches
+ * of every phase of that name, launches counts the phases. */
 /* The weight-gradient GEMM of a narrow BiLSTM layer runs beside the backward recurrence (csrc/gemm_dw.h):
  * mode 0: off (GEMM after the recurrence); 1 (default): both as two workgroup roles of ONE launch
  * (csrc/lstm_bwd_dw.h) for batches large enough to profit; 2: the same always (tests); 3: two launches on streams
