@@ -472,8 +472,6 @@ DEVFN void lstm_bwd_body(const LstmSeqArgs& a, const int b, const int dir) {
   float ka0 = 0.f, ka1 = 0.f, ka2 = 0.f;  // store-data pins (see KEEP_ALIVE)
   __syncthreads();
   // cur: operands of step s; nxt: operands of step s-1 (its c is c_{s-1}); ld: set to refill for step s-2
-  // (deferring the delta store to the next step like the forward kernel does was measured slower here:
-  //  126 -> 137 us)
   auto step = [&](const int s, Ops& cur, const Ops& nxt, Ops& ld, const float* dq, float* dw, float& ka, float& kprev) {
     KEEP_ALIVE(ka);
     ld.act = buf_load(gbuf, gl + fr(s - 2) * gstride4);

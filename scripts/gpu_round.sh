@@ -37,22 +37,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" 
 tail -1 "$OUT/rocprof.log" | cut -c1-200
 find "$OUT/prof" -name "*kernel_stats*" | head -1 | while read f; do head -16 "$f"; done
 F=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)
-python - "$F" "$OUT/timeline.txt" <<'PY'
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_ingest_pack" in r["Kernel_Name"]]
-a, b = idx[-2], idx[-1]
-t0 = int(rows[a]["Start_Timestamp"])
-out = open(sys.argv[2], "w")
-out.write("one training step under rocprofv3 --kernel-trace (us from the start of k_ingest_pack): start  end  duration  kernel\n")
-for r in rows[a:b]:
-    s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-    out.write("%9.2f %9.2f %8.2f  %s\n" % (s / 1e3, e / 1e3, (e - s) / 1e3, r["Kernel_Name"].split("(")[0][:80]))
-out.write("step length %.2f us\n" % ((int(rows[b]["Start_Timestamp"]) - t0) / 1e3))
-out.close()
-print(open(sys.argv[2]).read())
-PY
+python "$ROOT/scripts/step_timeline.py" "$F" "$OUT/timeline.txt"
 find "$OUT/prof" -name "*kernel_trace*" -size +20M -delete
 echo "=== rocprofv3 PMC passes (separate runs): FETCH_SIZE, WRITE_SIZE, MFMA busy, SQ wave states"
 for CNT in FETCH_SIZE WRITE_SIZE; do
