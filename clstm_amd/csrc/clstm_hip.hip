@@ -928,8 +928,8 @@ struct Net {
       y.dH.reserve((size_t)N * ndir * y.no);
       if (y.wide && bf16_rec) {
         // lock-step rings [step parity][dir][line][k] (lstm_wide.h); never smaller than the per-frame layout of the first version
-        y.Hb.reserve((size_t)std::max<long long>(N, 4LL * bs) * ndir * wide_kp16_fwd(y.no) + 64);   // (4 bs: the tagged ring of the persistent forward kernel)
-        y.Db.reserve((size_t)std::max<long long>(N, 2LL * bs) * ndir * wide_kp16_bwd(y.no) + 64);
+        y.Hb.reserve((size_t)std::max<long long>(N, 4LL * bs + 32) * ndir * wide_kp16_fwd(y.no) + 64);   // (2 x whole 16-line blocks: the tiled ring of the persistent kernels)
+        y.Db.reserve((size_t)std::max<long long>(N, 2LL * bs + 32) * ndir * wide_kp16_bwd(y.no) + 64);
       }
       y.S.reserve((size_t)N * ndir * y.lds + 64);
     }
@@ -978,6 +978,9 @@ struct Net {
         w.skip_s = w.Sbf != nullptr;
       }
     }
+#ifdef CLSTM_LSTM_PROF
+    lstm_prof.reserve(128); w.prof = lstm_prof.p;    // (the last pass launched before clstm_debug_lstm_cycles is what it reads)
+#endif
     return w;
   }
 
@@ -1984,8 +1987,8 @@ int clstm_net_set_gemm_precision(clstm_net* h, int mode) {
   if (n.N > 0 && rec)   // a batch is already declared: make room for the bf16 operand copies
     for (auto& y : n.L)
       if (y.wide) {
-        y.Hb.reserve((size_t)std::max<long long>(n.N, 4LL * n.bs) * n.ndir * wide_kp16_fwd(y.no) + 64);
-        y.Db.reserve((size_t)std::max<long long>(n.N, 2LL * n.bs) * n.ndir * wide_kp16_bwd(y.no) + 64);
+        y.Hb.reserve((size_t)std::max<long long>(n.N, 4LL * n.bs + 32) * n.ndir * wide_kp16_fwd(y.no) + 64);
+        y.Db.reserve((size_t)std::max<long long>(n.N, 2LL * n.bs + 32) * n.ndir * wide_kp16_bwd(y.no) + 64);
       }
   ABI_END
 }

@@ -61,6 +61,7 @@ struct LstmWideArgs {
   int sbf_ld, sbf_ofs; long long sbf_dir;
   unsigned short* Dbf;          // persistent backward kernel: per-frame [N][nd][kp16] bf16 deltas (operand of the x.d GEMM), or null
   int kp16;                     // padded contraction length of the bf16 rows, multiple of 32 * WIDE_NW
+  long long* prof;              // diagnostics build (CLSTM_LSTM_PROF) only: per-phase cycle sums, [2 workgroups][4 waves][12]; else null
 };
 
 constexpr int WIDE_LDW = 20;  // LDS row stride of a partial tile (16 columns + pad, float4-aligned)
@@ -585,6 +586,31 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_wide_bwd_step(LstmWideArgs 
 // groups = ndir x ceil(bs/16) <= 8.  Placement is CHECKED, not assumed: after claiming, every workgroup waits until all
 // have claimed and verifies that every group got its ceil(no/16) tiles; otherwise it raises sync[1] and leaves BEFORE
 // anything is written (the host then runs the per-step path).  Every poll loop carries a watchdog.
+// The lock-step rings Hb / Db of the PERSISTENT bf16 kernels are tiled: [step parity][dir][16-line block][32-k block][line][32 k].
+// The sixteen lines' 64-byte pieces of one 32-k block lie side by side (1 KB), so one A-fragment load instruction (lane = line +
+// 16 x 16-byte chunk) asks the L2 for eight WHOLE 128-byte lines; with row-major rows it asked for sixteen half lines, and the
+// backward step -- every workgroup of a group reads the group's whole 64 KB delta block -- spent 3,000 of its 6,100 cycles
+// issuing those loads (scripts/gpu_xcdprof.py).  Offsets in bf16 elements; nkb = kp16 / 32, nblk = ceil(bs / 16).
+DEVFN unsigned ring_block(const int parity, const int nd, const int dir, const int nblk, const int blk, const int nkb) {
+  return (unsigned)(((parity * nd + dir) * nblk + blk) * nkb) * 512u;
+}
+DEVFN unsigned ring_elem(const int kb, const int line16, const int k32) { return (unsigned)(kb * 512 + line16 * 32 + k32); }
+
+// diagnostics build only: per-phase cycle stamps of the persistent bf16 kernels (scripts/gpu_xcdprof.py); a stamp costs
+// ~60 cycles and drains lgkmcnt
+#ifdef CLSTM_LSTM_PROF
+#define XCD_PROF_DECL long long xacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long xpt; \
+  asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(xpt) :: "memory")
+#define XCD_STAMP(k) do { long long now_; SCHED_FENCE(); \
+                          asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+                          SCHED_FENCE(); xacc[k] += now_ - xpt; xpt = now_; } while (0)
+#define XCD_PROF_WRITE(xcd, slot, ntile) do { if (a.prof && (xcd) == 0 && ((slot) == 0 || (slot) == (ntile) - 1) && (threadIdx.x & 63) == 0) \
+    for (int k_ = 0; k_ < 12; k_++) a.prof[(((slot) == 0 ? 0 : 1) * 4 + (threadIdx.x >> 6)) * 12 + k_] = xacc[k_]; } while (0)
+#else
+#define XCD_PROF_DECL do {} while (0)
+#define XCD_STAMP(k) do {} while (0)
+#define XCD_PROF_WRITE(xcd, slot, ntile) do {} while (0)
+#endif
 struct XcdSyncLayout { enum { ARRIVED = 0, ERROR = 1, SLOT0 = 8, GROUP0 = 32, GROUP_STRIDE = 32, WORDS = 32 + 8 * 32 }; };
 constexpr int XCD_LDW = 512 + 8;        // halfs per resident weight row (conflict-free ds_read_b128 fragments), kp16 <= 512
 inline __host__ __device__ int xcd_fwd_lds_bytes(int mt = 1) { return 64 * XCD_LDW * 2 + WIDE_NW * mt * 16 * 68 * 4 + 64; }
@@ -710,10 +736,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
     mine[i] = line[i] < a.bs && cell < no;
   }
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
-  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * a.bs * a.kp16 * 2);
+  const int nblk = (a.bs + 15) >> 4, nkb = a.kp16 >> 5;
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * nblk * 16 * a.kp16 * 2);
   // A fragment of this lane: line (zb MT + i) 16 + (lane&15), 8 k at wave*kw + 32 g + 8 (lane>>4)
   const int kw = a.kp16 / WIDE_NW, ngrp = kw >> 5;   // <= 4 groups of 32 per wave
-  const unsigned akl = (unsigned)(wave * kw + 8 * (lane >> 4)) * 2u;
+  const unsigned akl = ring_elem(wave * ngrp, lane & 15, 8 * (lane >> 4)) * 2u;
   const unsigned short* wfrag = wl + (lane & 15) * XCD_LDW + wave * kw + 8 * (lane >> 4);
   __syncthreads();
 
@@ -742,7 +769,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
       }
     }
     if (live && !(c16 & 1)) {
-      *reinterpret_cast<unsigned*>(a.Hb + ((size_t)((sg & 1) * nd + dir) * a.bs + line[i]) * a.kp16 + cell) = hp;
+      *reinterpret_cast<unsigned*>(a.Hb + ring_block(sg & 1, nd, dir, nblk, zb * MT + i, nkb) + ring_elem(cell >> 5, ml, cell & 31)) = hp;
       if (a.Hbf) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
       if (a.Sbf) {   // h_{t-1} column block of the next frame's bf16 source row (weight-gradient operand, gemm_b16mc)
         unsigned short* sb = a.Sbf + (size_t)dir * a.sbf_dir + a.sbf_ofs + cell;
@@ -751,6 +778,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
       }
     }
   };
+  XCD_PROF_DECL;
   for (int sg = 0; sg < a.tmax; sg++) {
     f32x4 acc[4][MT];
 #pragma unroll
@@ -760,20 +788,23 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
 #pragma unroll
         for (int q = 0; q < 4; q++) acc[j][i][q] = 0.0f;
     f32x4 gx_next[MT];
+    XCD_STAMP(0);   // loop top
     if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;   // h_{s-1} of the whole group is in the L2
+    XCD_STAMP(1);   // group wait
     // ---- 16 MT lines x 64 columns, split-K over the four waves ----
     f32x4 ra[4][MT];
 #pragma unroll
     for (int i = 0; i < MT; i++) {
       const int am = (zb * MT + i) * 16 + (lane & 15);
-      const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 2u + akl : BUF_OOB_BASE;
+      const unsigned arow = (sg >= 1 && am < a.bs) ? ring_block((sg - 1) & 1, nd, dir, nblk, zb * MT + i, nkb) * 2u + akl : BUF_OOB_BASE;
 #pragma unroll
-      for (int g = 0; g < 4; g++) ra[g][i] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+      for (int g = 0; g < 4; g++) ra[g][i] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 1024u : BUF_OOB);
     }
     SCHED_FENCE();
 #pragma unroll
     for (int i = 0; i < MT; i++) gx_next[i] = gx_load(sg + 1, i);
     SCHED_FENCE();
+    XCD_STAMP(2);   // loads issued
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       if (g < ngrp) {
@@ -791,7 +822,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int q = 0; q < 4; q++) red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * 68 + j * 16 + (lane & 15)] = acc[j][i][q];
+    XCD_STAMP(3);   // ring loads returned + MFMAs + partial tile to LDS
     __syncthreads();
+    XCD_STAMP(4);   // barrier
 #pragma unroll
     for (int i = 0; i < MT; i++) {
       const bool live = mine[i] && sg < T[i];
@@ -823,10 +856,14 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
     // publish: every store of this workgroup acknowledged by the L2, then one arrival on the group's counter.  (Storing
     // the bf16 h first and the other arrays behind the arrival was measured SLOWER, 3.5 vs 3.2 us per step: VMEM
     // completes in order, so the next step's operand loads then wait behind those stores.)
+    XCD_STAMP(5);   // epilogue + stores issued
     drain_vmem();
+    XCD_STAMP(6);   // stores acknowledged
     __syncthreads();
     if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
+    XCD_STAMP(7);   // barrier + arrival
   }
+  XCD_PROF_WRITE(xcd, ct, ntile);
 }
 
 // ---- persistent backward recurrence, same scheme: 16 lines x 16 cells per workgroup, its 16 weight rows (R^T, 2048 k)
@@ -877,9 +914,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
   const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
   const BufF32 hbuf = make_buf(a.dH, (size_t)a.N * nd * no * 4);
-  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Db), (size_t)2 * nd * a.bs * a.kp16 * 2);
+  const int nblk = (a.bs + 15) >> 4, nkb = a.kp16 >> 5;
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Db), (size_t)2 * nd * nblk * 16 * a.kp16 * 2);
   const int kw = a.kp16 / WIDE_NW, ngrp = kw >> 5;   // <= 16 groups of 32 per wave
-  const unsigned akl = (unsigned)(wave * kw + 8 * (lane >> 4)) * 2u;
+  const unsigned akl = ring_elem(wave * ngrp, lane & 15, 8 * (lane >> 4)) * 2u;
   const unsigned short* wfrag = wl + (lane & 15) * XCD_LDWB + wave * kw + 8 * (lane >> 4);
   float dc_carry[MT];      // dc_{s+1} * gf_{s+1} of this thread's (line, cell)s: carried in registers, not through memory
 #pragma unroll
@@ -908,8 +946,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
     const bool lv = mine[i] && 0 < T[i];
     c_s[i] = buf_load(cbuf, lv ? (unsigned)((((long long)(off[i] + (dir == 0 ? T[i] - 1 : 0)) * nd + dir) * no + cell) * 4) : BUF_OOB);
   }
+  XCD_PROF_DECL;
   for (int sg = 0; sg < a.tmax; sg++) {
+    XCD_STAMP(0);   // loop top
     if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;
+    XCD_STAMP(1);   // group wait
     f32x4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; i++)
@@ -922,14 +963,15 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
 #pragma unroll
       for (int i = 0; i < MT; i++) {
         const int am = (zb * MT + i) * 16 + (lane & 15);
-        const unsigned arow = (sg >= 1 && am < a.bs) ? (unsigned)(((((sg - 1) & 1) * nd + dir) * a.bs + am) * a.kp16) * 2u + akl : BUF_OOB_BASE;
+        const unsigned arow = (sg >= 1 && am < a.bs) ? ring_block((sg - 1) & 1, nd, dir, nblk, zb * MT + i, nkb) * 2u + akl : BUF_OOB_BASE;
 #pragma unroll
-        for (int g = 0; g < 16; g++) ra[g][i] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+        for (int g = 0; g < 16; g++) ra[g][i] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 1024u : BUF_OOB);
       }
       SCHED_FENCE();
 #pragma unroll
       for (int i = 0; i < MT; i++) nxt[i] = ops_load(sg + 1, i);
       SCHED_FENCE();
+      XCD_STAMP(2);   // loads issued
 #pragma unroll
       for (int g = 0; g < 16; g++)
         if (g < ngrp) {
@@ -942,7 +984,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
     for (int i = 0; i < MT; i++)
 #pragma unroll
       for (int q = 0; q < 4; q++) red[((wave * MT + i) * 16 + (lane >> 4) * 4 + q) * LDR + (lane & 15)] = acc[i][q];
+    XCD_STAMP(3);   // ring loads returned + MFMAs + partial tile to LDS
     __syncthreads();
+    XCD_STAMP(4);   // barrier
     f32x4 dl[MT];
     bool live[MT];
 #pragma unroll
@@ -965,13 +1009,16 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
         dl[i][2] = (go * (-go + 1.0f)) * d_go;
         dl[i][3] = (-ci * ci + 1.0f) * d_ci;
         // (one 8-byte store: what the group waits for goes first)
-        *reinterpret_cast<u32x2*>(a.Db + ((size_t)((sg & 1) * nd + dir) * a.bs + line[i]) * a.kp16 + 4 * cell) =
+        *reinterpret_cast<u32x2*>(a.Db + ring_block(sg & 1, nd, dir, nblk, zb * MT + i, nkb) + ring_elem(cell >> 3, ml, (4 * cell) & 31)) =
             u32x2{bf16_pack2(dl[i][0], dl[i][1]), bf16_pack2(dl[i][2], dl[i][3])};
       }
     }
+    XCD_STAMP(5);   // epilogue + ring store issued
     drain_vmem();
+    XCD_STAMP(6);   // stores acknowledged
     __syncthreads();
     if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, slot, sg + 1);
+    XCD_STAMP(7);   // barrier + arrival
 #pragma unroll
     for (int i = 0; i < MT; i++) {
       if (live[i]) {
@@ -985,7 +1032,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
       c_s[i] = cur[i].c_m1;
       cur[i] = nxt[i];
     }
+    XCD_STAMP(8);   // per-frame stores issued
   }
+  XCD_PROF_WRITE(xcd, slot, ntile);
 }
 
 // ---- the same persistent per-XCD scheme with f32 operands (the parity-grade path of wide layers) -----------------------
