@@ -743,6 +743,13 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   const unsigned akl = ring_elem(wave * ngrp, lane & 15, 8 * (lane >> 4)) * 2u;
   const unsigned short* wfrag = wl + (lane & 15) * XCD_LDW + wave * kw + 8 * (lane >> 4);
   __syncthreads();
+  // this wave's B fragments -- 64 columns x its quarter of the contraction = 16 x 16 bytes per lane -- stay in REGISTERS for the
+  // whole sequence (a wave has a SIMD's register file to itself): no LDS read on a step's path
+  u16x8 wreg[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) wreg[g][j] = *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDW + (g < ngrp ? g : 0) * 32);
 
   // The gate pre-activations of step s come from HBM (~2 us) and VMEM returns in order: requested at the top of step s
   // they would hold back the h rows requested behind them.  They are requested one step AHEAD, behind that step's h
@@ -810,9 +817,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
       if (g < ngrp) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const u16x8 wv = *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDW + g * 32);
 #pragma unroll
-          for (int i = 0; i < MT; i++) acc[j][i] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[g][i]), wv, acc[j][i]);
+          for (int i = 0; i < MT; i++) acc[j][i] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[g][i]), wreg[g][j], acc[j][i]);
         }
       }
     }
@@ -923,6 +929,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
 #pragma unroll
   for (int i = 0; i < MT; i++) dc_carry[i] = 0.0f;
   __syncthreads();
+  u16x8 wreg[16];   // this wave's B fragments (16 rows x its quarter of the contraction) in registers for the whole sequence
+#pragma unroll
+  for (int g = 0; g < 16; g++) wreg[g] = *reinterpret_cast<const u16x8*>(wfrag + (g < ngrp ? g : 0) * 32);
 
   // Epilogue operands (forward-pass arrays, from HBM) are requested one step AHEAD and behind that step's delta loads, so
   // that they never sit in front of them in the in-order VMEM queue; c_s of a step is the c_{s-1} the previous step loaded.
@@ -975,9 +984,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
 #pragma unroll
       for (int g = 0; g < 16; g++)
         if (g < ngrp) {
-          const u16x8 wv = *reinterpret_cast<const u16x8*>(wfrag + g * 32);
 #pragma unroll
-          for (int i = 0; i < MT; i++) acc[i] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[g][i]), wv, acc[i]);
+          for (int i = 0; i < MT; i++) acc[i] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[g][i]), wreg[g], acc[i]);
         }
     }
 #pragma unroll
