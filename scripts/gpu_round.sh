@@ -66,4 +66,7 @@ cd "$ROOT"
 CLSTM_FW_TRACE="$OUT/fw_trace.txt" timeout 300 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > /dev/null 2>&1
 python scripts/fwtrace_summary.py "$OUT/fw_trace.txt" > "$OUT/fwd_timeline.txt" 2>&1; head -3 "$OUT/fwd_timeline.txt"; tail -2 "$OUT/fwd_timeline.txt"
 timeout 300 python scripts/gpu_ctcprof.py > "$OUT/ctc_phase_cycles.txt" 2>&1; tail -6 "$OUT/ctc_phase_cycles.txt"
+# per-phase stamps of the persistent bf16 recurrences of wide layers (diagnostics build; built here if it is missing)
+[ -f clstm_amd/lib/libclstm_hip_prof.so ] || make -s -C clstm_amd/csrc ../lib/libclstm_hip_prof.so > /dev/null 2>&1
+CLSTM_HIP_VARIANT=prof timeout 300 python scripts/gpu_xcdprof.py 2>&1 | grep -v amdgpu.ids > "$OUT/xcd_phase_cycles.txt"; head -11 "$OUT/xcd_phase_cycles.txt"
 echo "=== done"
