@@ -638,6 +638,7 @@ struct Layer {
   // bf16 recurrence of a wide layer (lstm_wide_bf16.h): packed weights and the bf16 copies of h / the deltas
   unsigned short *Rbf = nullptr, *Rbb = nullptr;
   DevBuf<unsigned short> Hb, Db;
+  DevBuf<float> Rf32;          // tiled lock-step ring of the persistent f32 recurrences (one pass at a time uses it)
   long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
   DevBuf<float> G, C, H, D, dH, S;
   DevBuf<unsigned short> Hbf;  // per-frame bf16 h of both directions written by the persistent forward kernel (A operand of the next layer's W_x product)
@@ -843,7 +844,7 @@ struct Net {
   ~Net() {
     for (auto& y : L) {
       (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff); (void)hipFree(y.Wk);
-      (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release();
+      (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release(); y.Rf32.release();
       y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false; y.pack_tab.release();
     }
     (void)hipFree(W1k); fw_items.release(); fw_flags.release();
@@ -949,6 +950,7 @@ struct Net {
     w.dC = y.dCc.p; w.line_off = line_off.p; w.S = y.S.p; w.sdir = (long long)N * y.lds; w.N = N;
     w.lds = y.lds; w.sofs = 1 + y.ni; w.ldh = y.ldh; w.hofs = y.hofs; w.no = y.no; w.ndir = ndir; w.bs = bs;
     w.kp = fwd ? y.kpf : y.kpb;
+    if (!bf16_rec) { y.Rf32.reserve(ring32_floats(ndir, bs, std::max(y.kpf, y.kpb)) + 64); w.Rf = y.Rf32.p; }
     if (bf16_rec) {
       w.Rw16 = fwd ? y.Rbf : y.Rbb;
       w.kp16 = fwd ? wide_kp16_fwd(y.no) : wide_kp16_bwd(y.no);

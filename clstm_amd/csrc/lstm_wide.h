@@ -61,6 +61,7 @@ struct LstmWideArgs {
   int sbf_ld, sbf_ofs; long long sbf_dir;
   unsigned short* Dbf;          // persistent backward kernel: per-frame [N][nd][kp16] bf16 deltas (operand of the x.d GEMM), or null
   int kp16;                     // padded contraction length of the bf16 rows, multiple of 32 * WIDE_NW
+  float* Rf;                    // persistent f32 kernels: tiled lock-step ring of h (forward) / the gate deltas (backward), ring32_* below
   long long* prof;              // diagnostics build (CLSTM_LSTM_PROF) only: per-phase cycle sums, [2 workgroups][4 waves][12]; else null
 };
 
@@ -596,6 +597,14 @@ DEVFN unsigned ring_block(const int parity, const int nd, const int dir, const i
 }
 DEVFN unsigned ring_elem(const int kb, const int line16, const int k32) { return (unsigned)(kb * 512 + line16 * 32 + k32); }
 
+// The f32 kernels' ring, same idea with 16-k blocks of floats: [step parity][dir][16-line block][16-k block][line][16 k]; a lane
+// group's load (lane = line + 16 x four consecutive k) again covers 1 KB of whole lines.  Offsets in floats; nkb = kp / 16.
+DEVFN unsigned ring32_block(const int parity, const int nd, const int dir, const int nblk, const int blk, const int nkb) {
+  return (unsigned)(((parity * nd + dir) * nblk + blk) * nkb) * 256u;
+}
+DEVFN unsigned ring32_elem(const int kb, const int line16, const int k16) { return (unsigned)(kb * 256 + line16 * 16 + k16); }
+inline __host__ __device__ size_t ring32_floats(int nd, int bs, int kp) { return (size_t)2 * nd * ((bs + 15) / 16) * 16 * kp; }
+
 // diagnostics build only: per-phase cycle stamps of the persistent bf16 kernels (scripts/gpu_xcdprof.py); a stamp costs
 // ~60 cycles and drains lgkmcnt
 #ifdef CLSTM_LSTM_PROF
@@ -1091,9 +1100,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a)
   int aoff = 0, aT = 0;
   if (am < a.bs) { aoff = a.line_off[am]; aT = a.line_off[am + 1] - aoff; }
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
-  const BufF32 hbuf = make_buf(a.H, (size_t)a.N * a.ldh * 4);
+  const int nblk = (a.bs + 15) >> 4, nkb = a.kp >> 4;
+  const BufF32 hbuf = make_buf(a.Rf, ring32_floats(nd, a.bs, a.kp) * 4);
   const int kw = a.kp / WIDE_NW, ngrp = kw >> 4;     // 16-k groups per wave (<= 8 at 512 cells)
-  const unsigned klane = (unsigned)(wave * kw + 4 * (lane >> 4)) * 4u;
+  const unsigned klane = ring32_elem(wave * ngrp, lane & 15, 4 * (lane >> 4)) * 4u;
   const float* wrow = wl + (lane & 15) * ldw + wave * kw + 4 * (lane >> 4);
   auto gx_load = [&](int sg) -> f32x4 {
     const bool lv = mine && sg < T;
@@ -1113,11 +1123,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a)
     for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
-    const unsigned arow = (sg >= 1 && am < a.bs && sg < aT)
-        ? (unsigned)((long long)(aoff + (dir == 0 ? sg - 1 : aT - sg)) * a.ldh + a.hofs + dir * no) * 4u + klane : BUF_OOB_BASE;
+    const unsigned arow = (sg >= 1 && am < a.bs && sg < aT) ? ring32_block((sg - 1) & 1, nd, dir, nblk, zb, nkb) * 4u + klane : BUF_OOB_BASE;
     f32x4 ra[8];
 #pragma unroll
-    for (int g = 0; g < 8; g++) ra[g] = buf_load4_dev(hbuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+    for (int g = 0; g < 8; g++) ra[g] = buf_load4_dev(hbuf, g < ngrp ? arow + (unsigned)g * 1024u : BUF_OOB);
     SCHED_FENCE();
     const f32x4 gx_next = gx_load(sg + 1);
     SCHED_FENCE();
@@ -1155,7 +1164,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a)
       const float h = gate_act(c_new, true) * go;
       f32x4 act;
       act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
-      a.H[n * a.ldh + a.hofs + dir * no + cell] = h;     // next step's A operand of the whole group
+      a.Rf[ring32_block(sg & 1, nd, dir, nblk, zb, nkb) + ring32_elem(cell >> 4, ml, cell & 15)] = h;   // next step's A operand of the whole group
+      a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
       *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
       a.C[(n * nd + dir) * no + cell] = c_new;
       float* srow = a.S + (size_t)dir * a.sdir;
@@ -1201,9 +1211,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a)
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * nd * no * 16);
   const BufF32 cbuf = make_buf(a.C, (size_t)a.N * nd * no * 4);
   const BufF32 hbuf = make_buf(a.dH, (size_t)a.N * nd * no * 4);
-  const BufF32 dbuf = make_buf(a.D, (size_t)a.N * nd * 4 * no * 4);
+  const int nblk = (a.bs + 15) >> 4, nkb = a.kp >> 4;
+  const BufF32 dbuf = make_buf(a.Rf, ring32_floats(nd, a.bs, a.kp) * 4);
   const int kw = a.kp / WIDE_NW, ngrp = kw >> 4;     // 16-k groups per wave (32 at 512 cells), walked in rounds of 8
-  const unsigned klane = (unsigned)(wave * kw + 4 * (lane >> 4)) * 4u;
+  const unsigned klane = ring32_elem(wave * ngrp, lane & 15, 4 * (lane >> 4)) * 4u;
   const float* wrow = wl + (lane & 15) * ldw + wave * kw + 4 * (lane >> 4);
   struct Ops { f32x4 act; float dh_in, c_m1; };
   auto ops_load = [&](int sg) -> Ops {
@@ -1230,12 +1241,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a)
     f32x4 acc;
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] = 0.0f;
-    const unsigned arow = (sg >= 1 && am < a.bs && sg < aT)
-        ? (unsigned)(((long long)(aoff + (dir == 0 ? aT - sg : sg - 1)) * nd + dir) * 4 * no) * 4u + klane : BUF_OOB_BASE;
+    const unsigned arow = (sg >= 1 && am < a.bs && sg < aT) ? ring32_block((sg - 1) & 1, nd, dir, nblk, zb, nkb) * 4u + klane : BUF_OOB_BASE;
     // rounds of 8 groups, the next round's loads requested before this round's MFMAs
     f32x4 ra[2][8];
 #pragma unroll
-    for (int g = 0; g < 8; g++) ra[0][g] = buf_load4_dev(dbuf, g < ngrp ? arow + (unsigned)g * 64u : BUF_OOB);
+    for (int g = 0; g < 8; g++) ra[0][g] = buf_load4_dev(dbuf, g < ngrp ? arow + (unsigned)g * 1024u : BUF_OOB);
     SCHED_FENCE();
     Ops nxt = ops_load(sg + 1);
     SCHED_FENCE();
@@ -1244,7 +1254,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a)
       for (int half = 0; half < 2; half++) {
         const int gb = r0 + half * 8;
 #pragma unroll
-        for (int g = 0; g < 8; g++) ra[half ^ 1][g] = buf_load4_dev(dbuf, gb + 8 + g < ngrp ? arow + (unsigned)(gb + 8 + g) * 64u : BUF_OOB);
+        for (int g = 0; g < 8; g++) ra[half ^ 1][g] = buf_load4_dev(dbuf, gb + 8 + g < ngrp ? arow + (unsigned)(gb + 8 + g) * 1024u : BUF_OOB);
         SCHED_FENCE();
 #pragma unroll
         for (int g = 0; g < 8; g++) {
@@ -1275,7 +1285,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a)
       dl[1] = (gf * (-gf + 1.0f)) * d_gf;
       dl[2] = (go * (-go + 1.0f)) * d_go;
       dl[3] = (-ci * ci + 1.0f) * d_ci;
-      *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;   // next step's A operand of the whole group
+      *reinterpret_cast<f32x4*>(a.Rf + ring32_block(sg & 1, nd, dir, nblk, zb, nkb) + ring32_elem(cell >> 2, ml, 4 * (cell & 3))) = dl;   // next step's A operand of the whole group
+      *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl;
     }
     c_s = cur.c_m1;
     cur = nxt;
