@@ -1056,9 +1056,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
 
 // ---- the same persistent per-XCD scheme with f32 operands (the parity-grade path of wide layers) -----------------------
 // v_mfma_f32_16x16x4_f32, weight rows f32 in LDS (64 x (kp + 4) forward = 132 KB at 512 cells, 16 x (kp + 4) backward),
-// h_{t-1} / delta_{t+1} rows read straight from the per-frame arrays H / D (plain stores by the group's workgroups,
-// L1-bypassing loads -- one L2), fragments as in wide_tile: lane (i, kq) loads four consecutive k of row i, MFMA e of a
-// 16-k group uses element e of both operands' float4.  Arithmetic identical to the per-step kernels (same tile, same
+// h_{t-1} / delta_{t+1} exchanged through the tiled f32 ring Rf (ring32_*: written beside the per-frame store into H / D; plain
+// stores by the group's workgroups, L1-bypassing loads -- one L2; until round 3 the rows were read from H / D themselves: sixteen
+// 64-byte pieces of sixteen frames per load instruction), fragments as in wide_tile: lane (i, kq) loads four consecutive k of
+// row i, MFMA e of a 16-k group uses element e of both operands' float4.  Arithmetic identical to the per-step kernels (same tile, same
 // split-K order), so the results are bit-identical to them.
 inline __host__ __device__ int xcd_fwd_f32_lds_bytes(int kp) { return (64 * (kp + WIDE_WPAD) + WIDE_NW * 16 * 68 + 16) * 4; }
 inline __host__ __device__ int xcd_bwd_f32_lds_bytes(int kp) {
