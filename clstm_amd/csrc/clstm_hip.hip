@@ -418,7 +418,15 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
       HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
       coop_set_smem(kernel, smem);
+      // An ORDINARY launch: one workgroup per CU (LDS), at most as many workgroups as CUs, the stream's previous kernel complete --
+      // they are all resident, and if they ever were not, the placement check of xcd_claim times out with error 1 before anything
+      // has been written (the per-step path then redoes the pass).  hipLaunchCooperativeKernel cost ~20 us of gaps around every
+      // one of the four launches of a configs[4] step.  (The host emulator needs its "all workgroups live" launch.)
+#ifdef CLSTM_HIP_EMU
       CLSTM_LAUNCH_COOP(kernel, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+#else
+      CLSTM_LAUNCH(kernel, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
+#endif
       check_launch();
       ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
       REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");

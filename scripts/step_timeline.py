@@ -2,14 +2,14 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_ingest_pack" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "clstm::k_ingest" in r["Kernel_Name"]]     # (k_ingest_pack or k_ingest: the first launch of a step)
 # the step of MEDIAN length (the first step behind every fence of the timed blocks and the host-paced enqueue burst at the end are longer)
 length = lambda j: int(rows[idx[j + 1]]["Start_Timestamp"]) - int(rows[idx[j]]["Start_Timestamp"])
 j = sorted(range(len(idx) - 1), key=length)[(len(idx) - 1) // 2]
 a, b = idx[j], idx[j + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 out = open(sys.argv[2], "w")
-out.write("one training step under rocprofv3 --kernel-trace (us from the start of k_ingest_pack): start  end  duration  kernel\n")
+out.write("one training step under rocprofv3 --kernel-trace (us from the start of the step's first launch): start  end  duration  kernel\n")
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     out.write("%9.2f %9.2f %8.2f  %s\n" % (s / 1e3, e / 1e3, (e - s) / 1e3, r["Kernel_Name"].split("(")[0][:80]))
