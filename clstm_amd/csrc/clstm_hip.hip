@@ -25,6 +25,7 @@
 #include "ops.h"
 
 #include <algorithm>
+#include <chrono>
 #include <sched.h>
 #include <cstring>
 #include <cstdlib>
@@ -319,8 +320,11 @@ static void launch_steps(StepGraphCache& cache, int kind, const A& a, int tmax, 
 // the next host read-back: the host keeps enqueueing ahead of the GPU (four stream synchronisations per minibatch cost
 // ~0.1 ms of idle GPU at the configs[4] shape).
 // Device error words shared by every net of the process: [0] sticky outcome of persistent recurrence launches,
-// [1] weight-gradient items of the fused backward launch that gave up waiting (gemm_dw.h).  k_update skips the update
-// while either is set; the host throws at its next synchronisation point (clstm_synchronize, any read-back).
+// [1] weight-gradient items of the fused backward launch that gave up waiting (gemm_dw.h), [2] waits of the fused FORWARD
+// launch that gave up (lstm_fwd_fused.h, lstm_seq.h:wait_chunk), [3] number of the training step whose gradient had a
+// non-finite entry (ops.h:k_update; the reference asserts on NaN in every backward step, clstm.cc:630-649).  The update
+// kernels skip the update while any is set; the host throws at its next synchronisation point (clstm_synchronize, any
+// read-back).
 static int* g_dev_err = nullptr;
 static int* dev_err_words() {
   if (!g_dev_err) {
@@ -329,6 +333,7 @@ static int* dev_err_words() {
   }
   return g_dev_err;
 }
+static bool g_xcd_failed = false;   // a persistent launch failed its placement check: wide layers use the per-step launches from now on
 struct XcdOutcome {
   static const int SLOTS = 16;
   int* pinned = nullptr;
@@ -339,10 +344,14 @@ struct XcdOutcome {
     if (!pending[i]) return;
     HIPCHECK(hipEventSynchronize(ev[i]));
     pending[i] = false;
-    if (pinned[i] != 0 && g_dev_err) (void)hipMemset(g_dev_err, 0, sizeof(int));   // reported once: updates resume (nothing was applied meanwhile)
+    if (pinned[i] != 0 && g_dev_err) (void)hipMemset(g_dev_err, 0, sizeof(int));   // reported once: updates resume
+    if (pinned[i] == 1) g_xcd_failed = true;   // not all workgroups were resident (another tenant on the device): per-step launches from now on
     if (pinned[i] != 0)
-      throw Error(pinned[i] == 1 ? "persistent recurrence: workgroups were not spread evenly over the XCDs in a later launch; the minibatches since then were NOT applied (parameters and momentum are intact) -- set CLSTM_XCD_REC=0"
-                                 : "persistent recurrence: a group barrier timed out in the middle of the sequence; the minibatches since then were NOT applied -- set CLSTM_XCD_REC=0");
+      throw Error(pinned[i] == 1 ? "persistent recurrence: the workgroups of a later launch were not all resident / not spread evenly over the XCDs (another process or stream on the device?); "
+                                   "the minibatches enqueued since then were NOT applied -- every later update was skipped; in a multi-layer net the layers above the failing one may "
+                                   "have taken their update of that one minibatch -- and the library has switched to the per-step launches (CLSTM_XCD_REC=0) for the rest of the process"
+                                 : "persistent recurrence: a group barrier timed out in the middle of the sequence; the minibatches enqueued since then were NOT applied (layers above the "
+                                   "failing one may have taken their update of that one minibatch) -- set CLSTM_XCD_REC=0");
   }
   void check_all() { for (int i = 0; i < SLOTS; i++) check_slot(i); }
   // returns false if the launch failed its placement check and nothing was written (synchronous phase only)
@@ -382,11 +391,18 @@ static XcdOutcome g_xcd_outcome;
 static void check_device_errors() {
   g_xcd_outcome.check_all();
   if (!g_dev_err) return;
-  int w[2] = {0, 0};
+  int w[4] = {0, 0, 0, 0};
   HIPCHECK(hipMemcpy(w, g_dev_err, sizeof(w), hipMemcpyDeviceToHost));
-  if ((w[0] | w[1]) == 0) return;
+  if ((w[0] | w[1] | w[2] | w[3]) == 0) return;
   (void)hipMemset(g_dev_err, 0, sizeof(w));
-  if (w[0]) throw Error("persistent recurrence: a launch failed (code " + std::to_string(w[0]) + "); the minibatches since then were NOT applied -- set CLSTM_XCD_REC=0");
+  if (w[3]) throw Error("non-finite gradient (NaN or Inf) in training step " + std::to_string(w[3]) + " of a net (counted per net from 1): that update was NOT applied -- no "
+                        "non-finite entry ever reaches the parameters or the momentum -- and neither was any update enqueued since; the parameters are those of the step "
+                        "before.  The reference aborts here (clstm.cc:630-649).  Lower the learning rate, or CLSTM_NANCHECK=0 to train on regardless");
+  if (w[2]) throw Error("fused forward launch: " + std::to_string(w[2]) + " wait(s) for a gate-GEMM chunk / a finished frame block gave up (watchdog): outputs read back since then are "
+                        "not valid and the minibatches enqueued since then were NOT applied -- set CLSTM_OVERLAP=0");
+  if (w[0] == 1) g_xcd_failed = true;
+  if (w[0]) throw Error("persistent recurrence: a launch failed (code " + std::to_string(w[0]) + (w[0] == 1 ? ": workgroups not all resident; per-step launches from now on" : "") +
+                        "); the minibatches enqueued since then were NOT applied (layers above the failing one may have taken their update of that one minibatch) -- set CLSTM_XCD_REC=0");
   throw Error("fused backward launch: " + std::to_string(w[1]) + " weight-gradient item(s) gave up waiting for the recurrence (watchdog); the "
               "minibatches since then were NOT applied -- set CLSTM_OVERLAP=0");
 }
@@ -409,7 +425,6 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
   // CLSTM_XCD_REC=0 selects the per-step launches below; they are also the fallback when the placement check of the
   // first launch fails (workgroups not spread evenly over the XCDs: nothing has been written at that point).
   const bool xcd_on = !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
-  static bool xcd_failed = false;
   // (minibatches of more than 8 / ndir line blocks: one launch per chunk of line blocks)
   const int zb_per = std::max(1, 8 / a.ndir);
   auto persistent = [&](auto kernel, size_t smem) {
@@ -420,7 +435,9 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       coop_set_smem(kernel, smem);
       // An ORDINARY launch: one workgroup per CU (LDS), at most as many workgroups as CUs, the stream's previous kernel complete --
       // they are all resident, and if they ever were not, the placement check of xcd_claim times out with error 1 before anything
-      // has been written (the per-step path then redoes the pass).  hipLaunchCooperativeKernel cost ~20 us of gaps around every
+      // has been written.  The first four launches of a process are checked synchronously and the per-step path redoes such a pass;
+      // a later failure is found asynchronously (XcdOutcome): the updates since then are skipped on the device, the host reports it
+      // at its next check and uses the per-step launches from then on.  hipLaunchCooperativeKernel cost ~20 us of gaps around every
       // one of the four launches of a configs[4] step.  (The host emulator needs its "all workgroups live" launch.)
 #ifdef CLSTM_HIP_EMU
       CLSTM_LAUNCH_COOP(kernel, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
@@ -431,10 +448,10 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
       REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
     }
-    if (ok) g_wide_persistent = true; else xcd_failed = true;
+    if (ok) g_wide_persistent = true; else g_xcd_failed = true;
     return ok;
   };
-  const bool fits = xcd_on && !xcd_failed && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16);
+  const bool fits = xcd_on && !g_xcd_failed && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16);
   if (fwd) {
     if (fits && !bf16 && (size_t)xcd_fwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_fwd_f32, (size_t)xcd_fwd_f32_lds_bytes(a.kp))) return;
     if (fits && bf16 && a.kp16 <= 512 &&
@@ -519,6 +536,44 @@ struct Timing {
 };
 #endif
 
+
+// ---- roctx ranges (a rocprofv3 --marker-trace of a drop-in run should read ingest / forward / ctc / backward /
+// allreduce / update) ----------------------------------------------------------------------------------------------------
+// librocprofiler-sdk-roctx is bound at first use like RCCL; ranges are emitted when a profiler tool is attached to the
+// process (rocprofv3 exports ROCP_TOOL_LIBRARIES) or CLSTM_ROCTX=1 asks for them; CLSTM_ROCTX=0 switches them off.
+#ifndef CLSTM_HIP_EMU
+}  // namespace clstm
+#include <dlfcn.h>
+namespace clstm {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  static Roctx& get() {
+    static Roctx r = [] {
+      Roctx x;
+      const char* e = getenv("CLSTM_ROCTX");
+      const bool want = e ? atoi(e) != 0 : getenv("ROCP_TOOL_LIBRARIES") != nullptr;
+      if (!want) return x;
+      void* h = nullptr;
+      for (const char* name : {"librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"})
+        if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+      if (!h) return x;
+      x.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      x.pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (!x.push || !x.pop) x.push = nullptr;
+      return x;
+    }();
+    return r;
+  }
+};
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char* name) : on(Roctx::get().push != nullptr) { if (on) Roctx::get().push(name); }
+  ~RoctxRange() { if (on) Roctx::get().pop(); }
+};
+#else
+struct RoctxRange { explicit RoctxRange(const char*) {} };
+#endif
 
 // ---- RCCL communicator (data-parallel gradient exchange) ----------------------------------------------
 // librccl.so.1 is bound at first use (dlopen): the library loads and runs single-GPU on a box without RCCL,
@@ -1031,6 +1086,7 @@ struct Net {
 
   void forward() {
     REQUIRE(N > 0, "set_batch first");
+    RoctxRange range_("clstm:forward");
     flush_line_off();
     repack();
     hipStream_t s = stream();
@@ -1175,7 +1231,7 @@ struct Net {
     a.prog_off = (long long)y.H.cap - 64 - PROG_WORDS;
     REQUIRE(a.prog_off >= (long long)N * y.ldh + 16, "internal: progress words overlap the output rows");
     a.prog_base = fw_prog_base;
-    a.gflag = fw_flags.p; a.gchunks = fw_chunks; a.gepoch = fw_epoch; a.timeouts = dev_err_words() + 1;
+    a.gflag = fw_flags.p; a.gchunks = fw_chunks; a.gepoch = fw_epoch; a.timeouts = dev_err_words() + 2;   // (the forward launch's own error word)
     FwdFusedArgs& h = k.h;
     h.X = layer_input(0); h.ldx = layer_input_ld(0); h.x_elems = (long long)N * h.ldx + 32;
     h.Wk = y.Wk; h.kp = y.wk_kp; h.njp = y.wk_njp; h.bias = y.bias;
@@ -1380,6 +1436,8 @@ struct Net {
     REQUIRE(N > 0, "set_batch first");
     const bool fuse = fuse_update;   // consumed here: an exception below must not leave it set for a later pass
     fuse_update = false;
+    nbackward++;
+    RoctxRange range_("clstm:backward");
     update_applied = false;
     flush_line_off();
     repack();
@@ -1498,8 +1556,9 @@ struct Net {
         if (l == (int)L.size() - 1) extra = sm_red;
         const size_t work = (size_t)ndir * R * Cn + (size_t)extra.R * extra.Cn * extra.nbatch;
         UpdateFuse uf{};
+        uf.nanflag = nanflag(); uf.step_no = step_no();
         if (fuse) {   // (train_step without a communicator) this layer's parameters are updated by the reduction itself
-          uf = UpdateFuse{v, d, lr, mom, gclip, (const int*)dev_err_words(), l == 0 ? update_step_word : nullptr, update_step_id};
+          uf = UpdateFuse{v, d, lr, mom, gclip, (const int*)dev_err_words(), l == 0 ? update_step_word : nullptr, update_step_id, nanflag(), step_no()};
           if (l == 0) { update_step_word = nullptr; update_applied = true; }   // (the last reduction of the pass)
         }
         CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, g, (int*)nullptr, 0, uf);
@@ -1533,24 +1592,33 @@ struct Net {
     }
   }
 
+  long long nbackward = 0;           // backward passes of this net so far = the number of the current training step (from 1)
+  int step_no() const { return (int)std::min<long long>(nbackward, 2147483647LL); }
+  static int* nanflag() {            // device error word [3], or null when CLSTM_NANCHECK=0
+    static const bool on = !(getenv("CLSTM_NANCHECK") && atoi(getenv("CLSTM_NANCHECK")) == 0);
+    return on ? dev_err_words() + 3 : nullptr;
+  }
   int* update_step_word = nullptr;   // (host-fed steps) pinned word the update kernel writes update_step_id into
   int update_step_id = 0;
   bool fuse_update = false;   // the NEXT backward pass applies the update inside its reductions (set by train_step)
   bool update_applied = false; // ... and has done so: update() has nothing left to launch
   void update() {
     hipStream_t s = stream();
+    RoctxRange range_("clstm:update");
     if (update_applied) {   // done by the reductions of the backward pass just enqueued
       update_applied = false;
       packed_dirty = true;
       return;
     }
     if (comm) {   // sum of the ranks' fresh minibatch gradients, in place, on this stream (share_deltas, clstm.cc:731-744)
+      RoctxRange range2_("clstm:allreduce");
       timing.begin("allreduce_grads", s);
       comm->allreduce(g, nparams, s);
       timing.end(s);
     }
     timing.begin("sgd_update", s);
-    CLSTM_LAUNCH(k_update, dim3(nblocks(nparams)), dim3(256), 0, s, v, d, (const float*)g, (size_t)nparams, lr, mom, gclip, (const int*)dev_err_words(), update_step_word, update_step_id);
+    CLSTM_LAUNCH(k_update, dim3(nblocks(nparams)), dim3(256), 0, s, v, d, (const float*)g, (size_t)nparams, lr, mom, gclip, (const int*)dev_err_words(), update_step_word, update_step_id,
+                 nanflag(), step_no());
     update_step_word = nullptr;
     timing.end(s);
     check_launch();
@@ -1876,6 +1944,7 @@ int clstm_net_set_inputs_h(clstm_net* h, const float* x) {
 static void net_set_inputs_d(clstm_net* h, const float* x, const CtcMetaCopy* aux = nullptr) {
   Net& n = h->net;
   REQUIRE(n.N > 0, "set_batch first");
+  RoctxRange range_("clstm:ingest");
   Layer& y = n.L[0];
   bool aux_done = false;
   if (n.packed_dirty && n.L.size() == 1 && !y.wide) {   // the training step: ingest + weight repack in one launch
@@ -1933,6 +2002,7 @@ static void net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* al
   }
   float* al = nullptr;
   if (aligned_h) { n.aligned.reserve((size_t)n.N * n.desc.nclasses); al = n.aligned.p; }
+  RoctxRange range_(launch ? "clstm:ctc" : "clstm:ctc_prepare");
   if (launch) n.timing.begin("ctc_align", g_stream);
   run_ctc(h->ctc, n.Z.p, n.Dz.p, al, n.desc.nclasses, n.line_off_h.data(), states.data(), soff.data(), n.bs, g_stream, defer, launch);
   if (launch) n.timing.end(g_stream);
@@ -1941,6 +2011,7 @@ static void net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* al
 // the alignment prepared by net_ctc(..., launch = false)
 static void net_ctc_launch(clstm_net* h) {
   Net& n = h->net;
+  RoctxRange range_("clstm:ctc");
   n.timing.begin("ctc_align", g_stream);
   CLSTM_LAUNCH(ctc_align_kernel, dim3(h->ctc.pending_bs), dim3(CTC_THREADS), h->ctc.pending_smem, g_stream, h->ctc.pending);
   check_launch();
@@ -2046,11 +2117,27 @@ int clstm_net_train_step_h(clstm_net* h, const int* T_h, int bs, const float* x_
     HIPCHECK(hipHostMalloc((void**)&f.step_done, 64));
     *f.step_done = 0;
   }
-  const long long k = ++f.steps;              // this step's number (1, 2, ...)
+  // This step's number (1, 2, ...) is COMMITTED only when its last kernel -- the one that publishes it in the pinned word --
+  // has been enqueued: a call that fails on the way (a bad label, a launch error) leaves f.steps where it was, so the next
+  // call reuses number and slot and never waits for a step that was not enqueued (two failed calls in a row used to spin
+  // here for ever).
+  const long long k = f.steps + 1;
   const int slot = (int)(k & 1);
   // the slot was read by step k - 2: its update kernel has run when the pinned word says so (the host is at most a few
-  // steps ahead of the GPU, so this rarely waits)
-  while (k > 2 && (int)((unsigned)(k - 2) - (unsigned)__atomic_load_n(f.step_done, __ATOMIC_ACQUIRE)) > 0) sched_yield();   // (wrap-safe)
+  // steps ahead of the GPU, so this rarely waits).  Bounded: after ~2 s of yielding the stream is drained instead --
+  // everything enqueued has then run, whatever the word says.
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (k > 2 && (int)((unsigned)(k - 2) - (unsigned)__atomic_load_n(f.step_done, __ATOMIC_ACQUIRE)) > 0) {   // (wrap-safe)
+      sched_yield();
+      if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+        HIPCHECK(hipStreamSynchronize(g_stream));
+        check_device_errors();
+        break;
+      }
+    }
+  }
   f.xin[slot].reserve((size_t)N * n.desc.ninput + 64);
   const void* src = x_h;
 #ifndef CLSTM_HIP_EMU
@@ -2078,8 +2165,12 @@ int clstm_net_train_step_h(clstm_net* h, const int* T_h, int bs, const float* x_
   net_ctc_launch(h);
   n.update_step_word = f.step_done; n.update_step_id = (int)(unsigned)k;
   n.fuse_update = !n.comm;
-  n.backward();
-  n.update();
+  try {
+    n.backward();
+    n.update();
+  } catch (...) { n.update_step_word = nullptr; throw; }
+  REQUIRE(n.update_step_word == nullptr, "internal: no kernel of the step took the step word");
+  f.steps = k;
   ABI_END
 }
 int clstm_host_alloc(void** p, size_t bytes) { ABI_BEGIN REQUIRE(p, "null argument"); HIPCHECK(hipHostMalloc(p, bytes ? bytes : 1)); ABI_END }
@@ -2327,7 +2418,7 @@ int clstm_debug_lstm_cycles(clstm_net* h, long long* out_h) {   // diagnostics b
 #endif
 int clstm_debug_set_device_error(int which, int value) {   // tests: what a failed persistent launch / a timed-out item leaves behind
   ABI_BEGIN
-  REQUIRE(which == 0 || which == 1, "bad error word");
+  REQUIRE(which >= 0 && which <= 3, "bad error word");
   HIPCHECK(hipStreamSynchronize(g_stream));
   HIPCHECK(hipMemcpy(dev_err_words() + which, &value, sizeof(int), hipMemcpyHostToDevice));
   ABI_END

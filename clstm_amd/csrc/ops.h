@@ -204,12 +204,21 @@ __global__ void k_sgd(float* v, float* d, size_t len, float lr, float mom) {
 // computed from unwritten activations is not applied, parameters and momentum stay as they were.
 // `step_word` (may be null; pinned host memory): set to step_id -- tells a host that feeds frames from its own memory
 // that every kernel of this step, the input ingest first of all, is behind it (clstm_net_train_step_h).
+// `nanflag` (may be null: CLSTM_NANCHECK=0): device error word [3].  The reference aborts on a NaN in any backward step
+// (clstm.cc:630-649, nine assert scans per time step); here every gradient entry passes through exactly one thread of the
+// slab reduction / of this kernel anyway: a non-finite entry is never applied, the word takes the number of the training
+// step, every later update is skipped (dev_err_set) and the host reports it at its next synchronisation point.
+DEVFN bool dev_err_set(const int* err) { return err && (err[0] | err[1] | err[2] | err[3]) != 0; }
+DEVFN bool f32_finite(float x) { return (__builtin_bit_cast(unsigned, x) & 0x7f800000u) != 0x7f800000u; }
+DEVFN void raise_nonfinite(int* nanflag, int step_no) { if (*nanflag == 0) *nanflag = step_no; }   // (every writer of a launch stores the same value)
 __global__ void k_update(float* v, float* d, const float* g, size_t len, float lr, float mom, float clip, const int* err,
-                         int* step_word, int step_id) {
+                         int* step_word, int step_id, int* nanflag, int step_no) {
   if (step_word && blockIdx.x == 0 && threadIdx.x == 0) store_i32_wt(step_word, step_id);
-  if (err && (err[0] | err[1]) != 0) return;
+  if (dev_err_set(err)) return;
   CLSTM_GRID_STRIDE(i, len) {
-    float di = d[i] + g[i];
+    const float gi = g[i];
+    if (nanflag && !f32_finite(gi)) { raise_nonfinite(nanflag, step_no); continue; }   // (after an all-reduce every rank sees the same g: same decisions)
+    float di = d[i] + gi;
     if (clip < 1e6f) di = fmaxf(-clip, fminf(clip, di));
     v[i] += di * lr;
     d[i] = di * mom;
@@ -436,6 +445,7 @@ struct UpdateFuse {
   float lr, mom, clip;
   const int* err;           // device error words (see k_update)
   int* step_word; int step_id;
+  int* nanflag; int step_no; // non-finite gradient entries: see k_update (checked whether or not the update is fused: v may be null)
 };
 DEVFN void reduce_scatter_one(const ReduceDesc& d, size_t e, float* g, const UpdateFuse& u, const bool apply) {
   const size_t RC = (size_t)d.R * d.Cn;
@@ -462,7 +472,9 @@ DEVFN void reduce_scatter_one(const ReduceDesc& d, size_t e, float* g, const Upd
   const long long o = (d.moff ? d.moff[(size_t)b * d.Cn + c] : d.base + c) + (long long)d.rs * r;
   const float gv = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   g[o] = gv;
-  if (apply) {
+  bool fin = true;
+  if (u.nanflag && !f32_finite(gv)) { raise_nonfinite(u.nanflag, u.step_no); fin = false; }
+  if (apply && fin) {
     float di = u.d[o] + gv;
     if (u.clip < 1e6f) di = fmaxf(-u.clip, fminf(u.clip, di));
     u.v[o] += di * u.lr;
@@ -474,7 +486,7 @@ __global__ void k_reduce_scatter(ReduceDesc d0, ReduceDesc d1, float* g, int* ze
   // (house-keeping that rides this launch: the work-queue heads of the fused backward launch return to zero)
   if (zero && blockIdx.x == 0 && (int)threadIdx.x < zero_n) zero[threadIdx.x] = 0;
   if (u.step_word && blockIdx.x == 0 && threadIdx.x == 0) store_i32_wt(u.step_word, u.step_id);
-  const bool apply = u.v && !(u.err && (u.err[0] | u.err[1]) != 0);   // (a failed launch: the gradient is not applied)
+  const bool apply = u.v && !dev_err_set(u.err);   // (a failed launch / a non-finite gradient earlier on: the gradient is not applied)
   const size_t n0 = (size_t)d0.R * d0.Cn * d0.nbatch, n1 = (size_t)d1.R * d1.Cn * d1.nbatch;
   CLSTM_GRID_STRIDE(e, n0 + n1) {
     if (e < n0) reduce_scatter_one(d0, e, g, u, apply);

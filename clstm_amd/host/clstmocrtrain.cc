@@ -14,20 +14,26 @@ using namespace clstmhost;
 // HIP_VISIBLE_DEVICES if the caller set one), rank 0 creates the RCCL id and hands it to the others through pipes, every
 // rank joins the library communicator (clstm_comm_create) and attaches it to its network: update() then all-reduces the
 // fresh minibatch gradient before the identical parameter update (precedent: share_deltas, clstm.cc:731-744).  All
-// ranks draw the SAME minibatches (same lrand48 sequence) and train on their contiguous shard of each; only rank 0
+// ranks draw the SAME minibatches (same lrand48 sequence) and train on their share of each (dealt longest line first, see deal()); only rank 0
 // reports, tests and saves.  With ngpu=N batch=B the run equals ngpu=1 batch=B up to the summation order of the gradient.
 struct Ranks;
 static Ranks* g_ranks = nullptr;
 // rank 0: a rank process that dies leaves the others waiting in the next all-reduce for ever -- end the run instead
+// (only the recorded rank pids are reaped -- never another child of the process)
+static volatile pid_t g_rank_pids[256];
+static volatile int g_nrank_pids = 0;
 static void on_rank_exit(int) {
-  int st = 0;
-  pid_t p;
-  while ((p = waitpid(-1, &st, WNOHANG)) > 0)
+  for (int i = 0; i < g_nrank_pids; i++) {
+    int st = 0;
+    const pid_t k = g_rank_pids[i];
+    if (k <= 0 || waitpid(k, &st, WNOHANG) != k) continue;
+    g_rank_pids[i] = 0;   // collected
     if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
       static const char msg[] = "FATAL: a rank process of ngpu=N ended abnormally\n";
       if (write(2, msg, sizeof msg - 1) < 0) {}
       _exit(1);
     }
+  }
 }
 struct Ranks {
   int rank = 0, n = 1;
@@ -38,6 +44,19 @@ struct Ranks {
     if (n <= 1) return;
     std::vector<int> wr(n, -1);
     int rd = -1;
+    if (n > 256) fail("ngpu too large");
+    // SIGCHLD is blocked while the ranks are forked and recorded and the handler is installed BEFORE the first fork: a rank
+    // that dies at once (a bad HIP_VISIBLE_DEVICES entry, an early fail()) is seen when the signal is unblocked below --
+    // installed after the loop, the handler missed it and rank 0 waited for ever in clstm_comm_create
+    sigset_t chld, old_mask;
+    sigemptyset(&chld); sigaddset(&chld, SIGCHLD);
+    sigprocmask(SIG_BLOCK, &chld, &old_mask);
+    {
+      struct sigaction sa{};
+      sa.sa_handler = on_rank_exit;
+      sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
+      sigaction(SIGCHLD, &sa, nullptr);
+    }
     for (int r = 1; r < n; r++) {
       int fd[2];
       if (pipe(fd) != 0) fail("pipe() failed");
@@ -50,15 +69,10 @@ struct Ranks {
         break;
       }
       kids.push_back(pid); wr[r] = fd[1]; close(fd[0]);
+      g_rank_pids[g_nrank_pids] = pid; g_nrank_pids = g_nrank_pids + 1;
     }
-    if (rank == 0) {
-      struct sigaction sa{};
-      sa.sa_handler = on_rank_exit;
-      sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
-      sigaction(SIGCHLD, &sa, nullptr);
-    } else {
-      signal(SIGCHLD, SIG_DFL);
-    }
+    if (rank != 0) { g_nrank_pids = 0; signal(SIGCHLD, SIG_DFL); }
+    sigprocmask(SIG_SETMASK, &old_mask, nullptr);   // (rank 0: a pending SIGCHLD is delivered here)
     {   // one GPU per rank
       const char* vis = getenv("HIP_VISIBLE_DEVICES");
       std::string dev = std::to_string(rank);
@@ -176,7 +190,32 @@ static int main1(int argc, char** argv) {
   Trigger save_trigger(getienv("save_every", 10000), ntrain, start);
   save_trigger.enable(save_name != "" && lead).skip0();
   Trigger report_trigger(getienv("report_every", 100), ntrain, start);
-  const int shard = batch / ngpu, shard0 = ranks.rank * shard;   // this rank's lines of every minibatch
+  // ngpu > 1: the lines of a minibatch are dealt to the ranks LONGEST FIRST, round-robin, so that every rank's longest line
+  // (= the length of its recurrence and CTC launches: one workgroup per line and direction) is the same to within one
+  // position of the sorted order -- with contiguous shards the all-reduce waits for whichever rank drew the longest lines
+  // (ragged T ~ U{150..250} costs a single GPU 18 %).  The key is the image WIDTH from the PNG header (24 bytes
+  // per file, cached per sample): every rank computes the same deal without preparing the other ranks' lines; the
+  // normalised length is the width scaled by the line's own height, i.e. monotone in it for lines of one source.
+  vector<int> width_of(trainingset.size(), -1);
+  auto sample_width = [&](int sample) {
+    if (width_of[sample] < 0) {
+      unsigned char h[24] = {0};
+      std::ifstream f(trainingset.fnames[sample], std::ios::binary);
+      f.read((char*)h, 24);
+      width_of[sample] = f.gcount() == 24 ? (int)((unsigned)h[16] << 24 | (unsigned)h[17] << 16 | (unsigned)h[18] << 8 | (unsigned)h[19]) : 0;
+    }
+    return width_of[sample];
+  };
+  auto deal = [&](const vector<int>& samples) {   // positions of the minibatch this rank trains on
+    vector<int> mine;
+    if (ngpu <= 1) { for (int i = 0; i < batch; i++) mine.push_back(i); return mine; }
+    vector<int> order(batch);
+    for (int i = 0; i < batch; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sample_width(samples[x]) > sample_width(samples[y]); });
+    for (int k = ranks.rank; k < batch; k += ngpu) mine.push_back(order[k]);
+    std::sort(mine.begin(), mine.end());
+    return mine;
+  };
   // one training sample (clstmocrtrain.cc:160-166: `lrand48() % size`, readSample)
   auto draw_one = [&](Image& raw, ustring& gt) {
     const int sample = lrand48() % trainingset.size();
@@ -199,8 +238,9 @@ static int main1(int argc, char** argv) {
     vector<int> samples(batch);
     for (int i = 0; i < batch; i++) samples[i] = lrand48() % trainingset.size();
     vector<std::shared_ptr<CLSTMOCR::Line>> lines(batch);
+    const vector<int> mine = deal(samples);
     vector<int> todo;   // first occurrence of every file that is not cached yet
-    for (int i = shard0; i < shard0 + shard; i++) {
+    for (int i : mine) {
       if (use_cache && cache[samples[i]]) { lines[i] = cache[samples[i]]; continue; }
       bool first = true;
       for (int j : todo) if (samples[j] == samples[i]) first = false;
@@ -222,10 +262,10 @@ static int main1(int argc, char** argv) {
     work(0);
     for (auto& f : pool) f.get();      // (rethrows a worker's exception)
     for (int i : todo) if (use_cache) cache[samples[i]] = lines[i];
-    for (int i = shard0; i < shard0 + shard; i++)
+    for (int i : mine)
       if (!lines[i]) for (int j : todo) if (samples[j] == samples[i]) lines[i] = lines[j];
     vector<const CLSTMOCR::Line*> ptrs;
-    for (int i = shard0; i < shard0 + shard; i++) ptrs.push_back(lines[i].get());
+    for (int i : mine) ptrs.push_back(lines[i].get());
     clstm.pack(p, ptrs);
   };
   CLSTMOCR::Prepared cur, next;

@@ -240,3 +240,75 @@ def test_train_step_from_host_memory(backend, ora32):
         x[:] = -7.0            # pageable source: free for reuse as soon as the call returns
     assert np.array_equal(a.get_params(), b.get_params())
     assert np.array_equal(a.get_derivs(), b.get_derivs())
+
+
+def test_failed_host_steps_do_not_block_the_next_one(backend, ora32):
+    """a clstm_net_train_step_h call that fails on the host side (label out of range) used to burn its step
+    number; after two such calls the next valid call waited for ever for a step that was never enqueued.  A step number is
+    committed only when the step's last kernel is enqueued: failed calls leave no trace and the valid step equals the
+    device-resident clstm_net_train_step bit for bit."""
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Network
+    ni, nh, nc = 6, 9, 5
+    rng = np.random.default_rng(23)
+    p0 = init_params(ni, nh, nc, seed=0.222) * 20
+    a, b = Network(ni, nh, nc, lib=backend.lib), Network(ni, nh, nc, lib=backend.lib)
+    for n in (a, b):
+        n.set_params(p0)
+        n.setLearningRate(1e-2, 0.9)
+    for step in range(5):
+        T = [int(t) for t in rng.integers(3, 12, 3)]
+        lines = synth_lines(rng, T, ni)
+        trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+        x = np.ascontiguousarray(np.concatenate(lines, 0), np.float32)
+        bad = [t.copy() for t in trs]
+        bad[1][0] = nc + 3                                   # target class out of range
+        for _ in range(3):                                   # three failures in a row
+            with pytest.raises(Exception, match="out of range"):
+                b.train_step_host(Network.prepare_step(T, bad), x)
+        prep = Network.prepare_step(T, trs)
+        a.train_step_prepared(prep, backend.up(x))
+        b.train_step_host(prep, x)                           # must return (pytest-timeout guards the old behaviour)
+    assert np.array_equal(a.get_params(), b.get_params())
+    assert np.array_equal(a.get_derivs(), b.get_derivs())
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_non_finite_gradient_is_never_applied(backend, ora32, fused):
+    """The reference asserts on NaN in every backward step (clstm.cc:630-649).  Here the update path checks every gradient
+    entry it touches anyway: a non-finite minibatch gradient is not applied (parameters and momentum stay finite and
+    unchanged), the device error word takes the step number, later updates are skipped until the host has reported it
+    (clstm_last_error names the step), and training resumes afterwards.  fused: clstm_net_train_step (update inside the slab
+    reduction); not fused: the sequence of calls (k_update)."""
+    from clstm_amd.net import Network
+    rng = np.random.default_rng(5)
+    ni, nh, nc, T = 5, 6, 4, [7, 4]
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, 2).astype(np.int32) for _ in T]
+    net = Network(ni, nh, nc, lib=backend.lib)
+    net.set_params(params)
+    net.setLearningRate(1e-2, 0.9)
+    prep = Network.prepare_step(T, trs)
+
+    def step(ls):
+        x = np.ascontiguousarray(np.concatenate(ls, 0), np.float32)
+        if fused:
+            net.train_step_prepared(prep, backend.up(x))
+        else:
+            net.set_inputs(ls); net.forward(); net.ctc(trs); net.backward(); net.update()
+    step(lines)                                              # step 1: fine
+    backend.sync()
+    p1, d1 = net.get_params(), net.get_derivs()
+    assert np.isfinite(p1).all() and not np.array_equal(p1, params.astype(np.float32))
+    poisoned = [l.copy() for l in lines]
+    poisoned[1][2, 3] = np.nan
+    step(poisoned)                                           # step 2: NaN reaches every gradient entry of the layer
+    step(lines)                                              # step 3: enqueued behind it, must be skipped too
+    with pytest.raises(Exception, match="non-finite gradient .* training step 2"):
+        backend.sync()
+    assert np.array_equal(net.get_params(), p1) and np.array_equal(net.get_derivs(), d1)
+    step(lines)                                              # reported: updates resume
+    backend.sync()
+    p4 = net.get_params()
+    assert np.isfinite(p4).all() and not np.array_equal(p4, p1)
