@@ -408,7 +408,10 @@ static void check_device_errors() {
 }
 static bool g_wide_persistent = false;   // the last launch_lstm_wide call ran the persistent per-XCD kernels
 
-static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s, bool bf16 = false) {
+// fx_ngx > 0 (forward, bf16): try ONLY the persistent kernel with the input projection folded in (lstm_xcd_fwd_bf16_fx<fx_ngx>);
+// returns false -- nothing launched or nothing written -- if it does not apply or its placement check failed: the caller then
+// runs the hoisted product and calls again with fx_ngx = 0.
+static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s, bool bf16 = false, int fx_ngx = 0) {
   g_wide_persistent = false;
   REQUIRE((double)a.N * a.ndir * 4 * a.no * 4 < 2147483000.0,
           "minibatch too large for the lock-step recurrence (frames x 4 x nhidden x ndir x 4 B must stay below 2 GiB)");
@@ -452,11 +455,17 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     return ok;
   };
   const bool fits = xcd_on && !g_xcd_failed && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16);
+  if (fx_ngx > 0) {
+    if (!(fwd && bf16 && fits && mt == 1 && a.kp16 <= 512 && (no & 3) == 0 && a.x_ni <= 128 * fx_ngx && a.x_ni <= 2048)) return false;
+    const size_t smem = (size_t)xcd_fwd_lds_bytes(1);
+    return fx_ngx == 1 ? persistent(lstm_xcd_fwd_bf16_fx<1>, smem) : fx_ngx == 4 ? persistent(lstm_xcd_fwd_bf16_fx<4>, smem)
+         : fx_ngx == 8 ? persistent(lstm_xcd_fwd_bf16_fx<8>, smem) : false;
+  }
   if (fwd) {
-    if (fits && !bf16 && (size_t)xcd_fwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_fwd_f32, (size_t)xcd_fwd_f32_lds_bytes(a.kp))) return;
+    if (fits && !bf16 && (size_t)xcd_fwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_fwd_f32, (size_t)xcd_fwd_f32_lds_bytes(a.kp))) return true;
     if (fits && bf16 && a.kp16 <= 512 &&
         (mt == 4 ? persistent(lstm_xcd_fwd_bf16<4>, (size_t)xcd_fwd_lds_bytes(4))
-         : mt == 2 ? persistent(lstm_xcd_fwd_bf16<2>, (size_t)xcd_fwd_lds_bytes(2)) : persistent(lstm_xcd_fwd_bf16<1>, (size_t)xcd_fwd_lds_bytes(1)))) return;
+         : mt == 2 ? persistent(lstm_xcd_fwd_bf16<2>, (size_t)xcd_fwd_lds_bytes(2)) : persistent(lstm_xcd_fwd_bf16<1>, (size_t)xcd_fwd_lds_bytes(1)))) return true;
     const int mts = a.bs > 32 ? 4 : a.bs > 16 ? 2 : 1;
     const dim3 grid((no + 3) / 4, a.ndir, (a.bs + 16 * mts - 1) / (16 * mts));
     const dim3 grid16(ntile * a.ndir * nzb16);
@@ -471,10 +480,10 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       }
     });
   } else {
-    if (fits && !bf16 && (size_t)xcd_bwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_bwd_f32, (size_t)xcd_bwd_f32_lds_bytes(a.kp))) return;
+    if (fits && !bf16 && (size_t)xcd_bwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_bwd_f32, (size_t)xcd_bwd_f32_lds_bytes(a.kp))) return true;
     if (fits && bf16 && a.kp16 <= 2048 &&
         (mt == 4 ? persistent(lstm_xcd_bwd_bf16<4>, (size_t)xcd_bwd_lds_bytes(4))
-         : mt == 2 ? persistent(lstm_xcd_bwd_bf16<2>, (size_t)xcd_bwd_lds_bytes(2)) : persistent(lstm_xcd_bwd_bf16<1>, (size_t)xcd_bwd_lds_bytes(1)))) return;
+         : mt == 2 ? persistent(lstm_xcd_bwd_bf16<2>, (size_t)xcd_bwd_lds_bytes(2)) : persistent(lstm_xcd_bwd_bf16<1>, (size_t)xcd_bwd_lds_bytes(1)))) return true;
     const dim3 grid(ntile, a.ndir, nzb16);
     const dim3 grid16(ntile * a.ndir * nzb16);
     launch_steps(graphs, bf16 ? 3 : 1, a, tmax, s, [&]() {
@@ -487,6 +496,7 @@ static void launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     });
   }
   check_launch();
+  return true;
 }
 
 // ---- per-kernel device timing (bench.py roofline) ---------------------------------------------
@@ -1095,6 +1105,52 @@ struct Net {
       Layer& y = L[l];
       const int M = ndir * 4 * y.no;
       const bool x_from_hbf = bf16_gemm && bf16_rec && l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.WtbT.p && y.ni == ndir * L[l - 1].no && (y.ni & 1) == 0;
+      // the lock-step recurrence of a wide layer + what follows it (bf16 source rows for the weight gradient); fx_ngx > 0: the
+      // persistent kernel with the input projection folded in (lstm_wide.h:lstm_xcd_fwd_bf16_fx) -- false if it did not run
+      auto run_wide = [&](LstmWideArgs w, int fx_ngx) {
+        timing.begin("lstm_fwd", s);
+        const bool ran = launch_lstm_wide(true, w, tmax, coop_sync, step_graphs, s, bf16_rec, fx_ngx);
+        timing.end(s);
+        if (!ran) return false;
+        y.fwd_persistent = g_wide_persistent && bf16_rec;
+        y.h_f32_valid = !(y.fwd_persistent && w.skip_h);   // (the per-step kernels store everything)
+        y.sh_valid = !(y.fwd_persistent && w.skip_s);
+        if (g_wide_persistent) g_path_count[0]++;
+        if (fx_ngx) g_path_count[6]++;
+        y.sbf_ready = y.fwd_persistent && w.Sbf;
+        if (y.sbf_ready) {   // the non-recurrent columns of the bf16 source rows (the recurrence stored the h columns)
+          const bool from16 = l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.ni == ndir * L[l - 1].no;
+          if (l > 0 && !from16) ensure_h_f32(l - 1);
+          CLSTM_LAUNCH(k_source_x_bf16, dim3(nblocks((size_t)N * ((y.ni >> 3) + 1))), dim3(256), 0, s, y.Sbf.p, from16 ? nullptr : layer_input(l),
+                       from16 ? L[l - 1].Hbf.p : nullptr, from16 ? y.ni : layer_input_ld(l), (size_t)N, y.ni, y.ni + y.no, w.sbf_ld, ndir, w.sbf_dir);
+        }
+        return true;
+      };
+      // bf16 mode, wide layer: no hoisted product at all when the persistent recurrence can take the input projection with it
+      // (its operands are the bf16 rows the layer below left, or a bf16 copy of the input frames)
+      bool fx_done = false;
+      // CLSTM_FUSE_WX: 0 never, 1 (default) layers of up to 128 inputs, 2 every eligible layer.  Measured at configs[4]
+      // (profiles/r04_xcd_phase_cycles_fused_wx.txt): there is no idle shadow to hide the x-part in -- a step's "group wait" is
+      // one L2 round trip of the poll, not waiting for late tiles -- so the fused work lands on the chain: +400 cycles per step
+      // for 64 inputs (67 us per pass against the 121 us of product + bf16 copy it replaces: kept), +2,950 for 1024 inputs
+      // (490 us against 321: not kept).  (read per pass: tests switch it inside one process)
+      const int fx_mode = getenv("CLSTM_FUSE_WX") ? atoi(getenv("CLSTM_FUSE_WX")) : 1;
+      if (fx_mode > 0 && (fx_mode > 1 || y.ni <= 128) && y.wide && bf16_gemm && bf16_rec && y.WtbT.p && (y.ni & 31) == 0 && (l == 0 || x_from_hbf)) {
+        const int ngx = y.ni <= 128 ? 1 : y.ni <= 512 ? 4 : y.ni <= 1024 ? 8 : 0;
+        if (ngx) {
+          const unsigned short* xb = l > 0 ? L[l - 1].Hbf.p : nullptr;
+          if (l == 0) {
+            xbf.reserve((size_t)N * y.ni + 64);
+            CLSTM_LAUNCH(k_to_bf16, dim3(nblocks((size_t)N * y.ni)), dim3(256), 0, s, layer_input(0), xbf.p, (size_t)N * y.ni);
+            xb = xbf.p;
+          }
+          LstmWideArgs w = wide_args(y, true);
+          w.Xb = xb; w.x_ld = y.ni; w.x_ni = y.ni; w.Wxb = y.WtbT.p; w.bias = y.bias;
+          y.sx_valid = l == 0 && src0_ready;
+          fx_done = run_wide(w, ngx);
+        }
+      }
+      if (fx_done) { if (!y.sbf_ready) ensure_source_x(l); continue; }
       if (l > 0 && !x_from_hbf) ensure_h_f32(l - 1);   // the products below read the f32 outputs of the layer underneath
       timing.begin("gemm_gates_x", s);
       if (x_from_hbf)
@@ -1131,24 +1187,12 @@ struct Net {
 #ifdef CLSTM_LSTM_PROF
       lstm_prof.reserve(128); a.prof = lstm_prof.p;
 #endif
-      timing.begin("lstm_fwd", s);
-      if (y.wide) {
-        const LstmWideArgs w = wide_args(y, true);
-        launch_lstm_wide(true, w, tmax, coop_sync, step_graphs, s, bf16_rec);
-        y.fwd_persistent = g_wide_persistent && bf16_rec;
-        y.h_f32_valid = !(y.fwd_persistent && w.skip_h);   // (the per-step kernels store everything)
-        y.sh_valid = !(y.fwd_persistent && w.skip_s);
-        if (g_wide_persistent) g_path_count[0]++;
-        y.sbf_ready = y.fwd_persistent && w.Sbf;
-        if (y.sbf_ready) {   // the non-recurrent columns of the bf16 source rows (the recurrence stored the h columns)
-          const bool from16 = l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.ni == ndir * L[l - 1].no;
-          if (l > 0 && !from16) ensure_h_f32(l - 1);
-          CLSTM_LAUNCH(k_source_x_bf16, dim3(nblocks((size_t)N * ((y.ni >> 3) + 1))), dim3(256), 0, s, y.Sbf.p, from16 ? nullptr : layer_input(l),
-                       from16 ? L[l - 1].Hbf.p : nullptr, from16 ? y.ni : layer_input_ld(l), (size_t)N, y.ni, y.ni + y.no, w.sbf_ld, ndir, w.sbf_dir);
-        }
+      if (y.wide) run_wide(wide_args(y, true), 0);
+      else {
+        timing.begin("lstm_fwd", s);
+        launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s); y.h_f32_valid = y.sh_valid = true;
+        timing.end(s);
       }
-      else { launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s); y.h_f32_valid = y.sh_valid = true; }
-      timing.end(s);
       if (!y.sbf_ready) ensure_source_x(l);
     }
     const int nc = desc.nclasses;

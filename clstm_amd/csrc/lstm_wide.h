@@ -62,6 +62,11 @@ struct LstmWideArgs {
   unsigned short* Dbf;          // persistent backward kernel: per-frame [N][nd][kp16] bf16 deltas (operand of the x.d GEMM), or null
   int kp16;                     // padded contraction length of the bf16 rows, multiple of 32 * WIDE_NW
   float* Rf;                    // persistent f32 kernels: tiled lock-step ring of h (forward) / the gate deltas (backward), ring32_* below
+  // persistent bf16 forward kernel with the input projection folded in (lstm_xcd_fwd_bf16_fx): the layer's input frames as
+  // bf16 rows [N][x_ld] (k contiguous), W_x as bf16 rows [ndir * 4 no][ni] in gate-column order (Layer::WtbT) and the bias
+  const unsigned short* Xb; int x_ld, x_ni;
+  const unsigned short* Wxb;
+  const float* bias;
   long long* prof;              // diagnostics build (CLSTM_LSTM_PROF) only: per-phase cycle sums, [2 workgroups][4 waves][12]; else null
 };
 
@@ -880,6 +885,222 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   }
   XCD_PROF_WRITE(xcd, ct, ntile);
 }
+
+// ---- the same kernel with the layer's INPUT PROJECTION folded in (MT = 1) -------------------------------------------------
+// The hoisted product G = W_x x + b writes 4 no x ndir floats per frame (419 MB per layer at configs[4]) that the recurrence
+// reads back once: 116 us (layer 1, K = 64: purely the store stream) + 321 us (layer 2, 215 GFLOP at 670 TFLOP/s) of a 4.83 ms
+// step.  Neither the product nor its operands depend on the recurrence, so here the workgroup that owns a (16 lines x 64 gate
+// columns) tile computes its x-part itself, in the SHADOW of the group hand-off: a step waits ~1,000 cycles for the other
+// tiles' h (scripts/gpu_xcdprof.py) -- time in which the waves were idle.
+//   * W_x fragments of the tile (64 columns x the wave's share of ni) stay in registers for the whole sequence, like R's;
+//   * the 16 lines' input rows of step s+1 are requested as WHOLE rows one step ahead (lane = 16 bytes, a wave instruction
+//     = 1 KB of one row: full 128-byte lines), parked in registers, written to LDS behind the arrival of step s, and read back
+//     as A fragments (conflict-free ds_read_b128: row stride ni + 8 halfs) at the top of step s+1 BEFORE the group wait;
+//   * their MFMAs start the step's accumulators; the recurrent MFMAs continue them behind the wait; the bias is added in the
+//     epilogue.  G never holds pre-activations -- the epilogue writes the activations as before.
+// Same products, f32 accumulation, one summation order per tile: the results differ from the hoisted form only by the order of
+// the f32 additions.  NGX = 32-k groups of the input contraction per wave: wave w takes groups [w NGX, (w+1) NGX) of ni / 32.
+template <int NGX>
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16_fx(LstmWideArgs a) {
+  constexpr int NX = NGX;                                     // 16-byte row chunks a thread stages per step: 16 lines x ni / 8 chunks over 256 threads (ni <= 128 NGX)
+  unsigned short* wl = dyn_smem<unsigned short>();            // [64][XCD_LDW] while the weights are staged, then the x rows [16][ni + 8]
+  float* red = reinterpret_cast<float*>(wl + 64 * XCD_LDW);   // [4][16][68]
+  int* flag = reinterpret_cast<int*>(red + WIDE_NW * 16 * 68);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int no = a.no, nd = a.ndir, ni = a.x_ni;
+  const int ntile = (no + 15) >> 4, nzb = a.zbn, ngroups = nd * nzb, ncg = (no + 3) >> 2;
+  int* const sync = a.sync;
+  int xcd, ct;
+  if (!xcd_claim(sync, flag, ntile, ngroups, xcd, ct)) return;
+  const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
+  int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
+  {
+    const int c8 = a.kp16 >> 3;
+    for (int i = tid; i < 64 * c8; i += WIDE_THREADS) {
+      const int row = i / c8, c = i - row * c8;
+      const long long grow = (long long)(dir * ncg + ct * 4) * 16 + row;
+      u16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = 0;
+      if ((ct * 4) * 16 + row < ncg * 16) v = *reinterpret_cast<const u16x8*>(a.Rw16 + grow * a.kp16 + c * 8);
+      *reinterpret_cast<u16x8*>(wl + row * XCD_LDW + c * 8) = v;
+    }
+  }
+  const int ml = tid >> 4, c16 = tid & 15;
+  const int cell = ct * 16 + c16;
+  const int line = zb * 16 + ml;
+  int off = 0, T = 0;
+  if (line < a.bs) { off = a.line_off[line]; T = a.line_off[line + 1] - off; }
+  const bool mine = line < a.bs && cell < no;
+  const int nblk = (a.bs + 15) >> 4, nkb = a.kp16 >> 5;
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * nblk * 16 * a.kp16 * 2);
+  const int kw = a.kp16 / WIDE_NW, ngrp = kw >> 5;
+  const unsigned akl = ring_elem(wave * ngrp, lane & 15, 8 * (lane >> 4)) * 2u;
+  const unsigned short* wfrag = wl + (lane & 15) * XCD_LDW + wave * kw + 8 * (lane >> 4);
+  __syncthreads();
+  u16x8 wreg[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) wreg[g][j] = *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDW + (g < ngrp ? g : 0) * 32);
+  // ---- the input projection's operands ----
+  const int ngx = ni >> 5;                                   // 32-k groups of the input contraction
+  const int gx0 = wave * NGX;                                // this wave's first group
+  u16x8 wxreg[NGX][4];
+  {
+    const BufF32 wxbuf = make_buf(reinterpret_cast<const float*>(a.Wxb), (size_t)nd * 4 * no * ni * 2);
+#pragma unroll
+    for (int g = 0; g < NGX; g++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int col = ct * 64 + j * 16 + (lane & 15);      // gate column of this direction: 4 cell + gate
+        const bool lv = col < 4 * no && gx0 + g < ngx;
+        wxreg[g][j] = __builtin_bit_cast(u16x8, buf_load4(wxbuf, lv ? (unsigned)(((dir * 4 * no + col) * ni + (gx0 + g) * 32 + 8 * (lane >> 4)) * 2) : BUF_OOB));
+      }
+  }
+  f32x4 bias4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (mine) bias4 = *reinterpret_cast<const f32x4*>(a.bias + dir * 4 * no + 4 * cell);
+  // staging role: chunk c = tid + 256 i of the [16 lines][ni / 8] chunk grid
+  const int XLD = ni + 8;                                    // halfs per LDS row
+  unsigned short* xs = wl;
+  const BufF32 xbuf = make_buf(reinterpret_cast<const float*>(a.Xb), (size_t)a.N * a.x_ld * 2);
+  const int cpr = ni >> 3;
+  int xoff[NX], xT[NX], xcol[NX], xlds[NX];
+#pragma unroll
+  for (int i = 0; i < NX; i++) {
+    const int c = tid + WIDE_THREADS * i;
+    const int row = c / cpr, cc = c - row * cpr;
+    const int ln = zb * 16 + row;
+    xoff[i] = 0; xT[i] = 0;
+    if (row < 16 && ln < a.bs) { xoff[i] = a.line_off[ln]; xT[i] = a.line_off[ln + 1] - xoff[i]; }
+    xcol[i] = cc * 8;
+    xlds[i] = row < 16 ? row * XLD + cc * 8 : -1;
+  }
+  auto x_load = [&](const int sg, f32x4 (&r)[NX]) {          // the rows of step sg (zeros for lines that have ended)
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      const bool lv = sg < xT[i];
+      const int fr = xoff[i] + (dir == 0 ? sg : xT[i] - 1 - sg);
+      r[i] = buf_load4(xbuf, lv ? (unsigned)(fr * a.x_ld + xcol[i]) * 2u : BUF_OOB);
+    }
+  };
+  auto x_stage = [&](const f32x4 (&r)[NX]) {
+#pragma unroll
+    for (int i = 0; i < NX; i++)
+      if (xlds[i] >= 0) *reinterpret_cast<f32x4*>(xs + xlds[i]) = r[i];
+  };
+  const unsigned short* xfrag = xs + (lane & 15) * XLD + gx0 * 32 + 8 * (lane >> 4);
+  f32x4 xr[NX];
+  x_load(0, xr);
+  __syncthreads();                                           // every wave has its weight fragments: the staging area is free
+  x_stage(xr);
+  x_load(1, xr);
+  float c_prev = 0.0f;
+  auto store_frame = [&](const f32x4 act, const float c_new, const float h, const unsigned hp, const long long n, const int sg, const bool live) {
+    if (live) {
+      *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
+      a.C[(n * nd + dir) * no + cell] = c_new;
+      if (!a.skip_h) a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
+      if (!a.skip_s) {
+        float* srow = a.S + (size_t)dir * a.sdir;
+        if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
+        if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+      }
+    }
+    if (live && !(c16 & 1)) {
+      *reinterpret_cast<unsigned*>(a.Hb + ring_block(sg & 1, nd, dir, nblk, zb, nkb) + ring_elem(cell >> 5, ml, cell & 31)) = hp;
+      if (a.Hbf) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
+      if (a.Sbf) {
+        unsigned short* sb = a.Sbf + (size_t)dir * a.sbf_dir + a.sbf_ofs + cell;
+        if (sg == 0) *reinterpret_cast<unsigned*>(sb + (size_t)n * a.sbf_ld) = 0u;
+        if (sg + 1 < T) *reinterpret_cast<unsigned*>(sb + (size_t)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.sbf_ld) = hp;
+      }
+    }
+  };
+  XCD_PROF_DECL;
+  for (int sg = 0; sg < a.tmax; sg++) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
+    XCD_STAMP(0);   // loop top
+    __syncthreads();                                         // the rows of this step are in LDS (written behind the previous arrival)
+    {
+      u16x8 xa[NGX];
+#pragma unroll
+      for (int g = 0; g < NGX; g++) xa[g] = *reinterpret_cast<const u16x8*>(xfrag + (gx0 + g < ngx ? g : 0) * 32);
+#pragma unroll
+      for (int g = 0; g < NGX; g++)
+        if (gx0 + g < ngx) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[j] = mfma16x16x32_bf16(xa[g], wxreg[g][j], acc[j]);
+        }
+    }
+    XCD_STAMP(8);   // x-part: fragments + MFMAs (in the shadow of the hand-off)
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;
+    XCD_STAMP(1);   // group wait
+    f32x4 ra[4];
+    {
+      const int am = zb * 16 + (lane & 15);
+      const unsigned arow = (sg >= 1 && am < a.bs) ? ring_block((sg - 1) & 1, nd, dir, nblk, zb, nkb) * 2u + akl : BUF_OOB_BASE;
+#pragma unroll
+      for (int g = 0; g < 4; g++) ra[g] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 1024u : BUF_OOB);
+    }
+    SCHED_FENCE();
+    XCD_STAMP(2);   // loads issued
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (g < ngrp) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[g]), wreg[g][j], acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * 68 + j * 16 + (lane & 15)] = acc[j][q];
+    XCD_STAMP(3);
+    __syncthreads();
+    XCD_STAMP(4);
+    {
+      const bool live = mine && sg < T;
+      const long long n = off + (dir == 0 ? sg : T - 1 - sg);
+      float h = 0.0f, c_new = 0.0f;
+      f32x4 act = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (live) {
+        f32x4 k = bias4;
+#pragma unroll
+        for (int w = 0; w < WIDE_NW; w++) {
+          const f32x4 p = *reinterpret_cast<const f32x4*>(&red[(w * 16 + ml) * 68 + c16 * 4]);
+#pragma unroll
+          for (int q = 0; q < 4; q++) k[q] += p[q];
+        }
+        const float gi = gate_act(k[0], false), gf = gate_act(k[1], false), go = gate_act(k[2], false), ci = gate_act(k[3], true);
+        c_new = ci * gi + gf * c_prev;
+        h = gate_act(c_new, true) * go;
+        act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
+      }
+      const float hn = quad_xor1(h);
+      const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);
+      store_frame(act, c_new, h, hp, n, sg, live);
+      c_prev = c_new;
+    }
+    XCD_STAMP(5);
+    drain_vmem();                                            // (also: the rows of step sg + 1, requested a step ago, are in registers)
+    XCD_STAMP(6);
+    __syncthreads();
+    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
+    XCD_STAMP(7);
+    // in the shadow of the hand-off: next step's rows into LDS (every wave read this step's fragments two barriers ago), the
+    // rows of the step after that requested
+    x_stage(xr);
+    x_load(sg + 2, xr);
+    XCD_STAMP(9);
+  }
+  XCD_PROF_WRITE(xcd, ct, ntile);
+}
+// (LDS: xcd_fwd_lds_bytes(1) -- the 16 x (ni + 8) halfs of input rows re-use the weight staging area: ni <= 2048)
 
 // ---- persistent backward recurrence, same scheme: 16 lines x 16 cells per workgroup, its 16 weight rows (R^T, 2048 k)
 // resident in LDS, the group's bf16 delta ring exchanged through the XCD's L2, the carried state delta in a register ----

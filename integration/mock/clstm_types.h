@@ -21,7 +21,9 @@
 
 namespace ocropus {
 typedef float Float;
+#ifndef THROW
 #define THROW(X) throw(X)
+#endif
 
 inline Float* device_alloc(size_t n) {
 #ifdef CLSTM_INTEGRATION_HIP
@@ -40,6 +42,63 @@ inline void device_free(Float* p) {
   free(p);
 #endif
 }
+
+// ---- TensorMap2 stand-in (tensor.h:60-68: Eigen::TensorMap<Eigen::Tensor<Float, 2>>) -----------------------------------
+// A non-owning column-major view with exactly the expression forms the reference's high-level code writes on it
+// (clstmhl.h:129,211, clstmocrtrain.cc:73: `d() = a.v() - b.v()`, `raw() = -raw() + Float(1)`), element access,
+// dimension(), data() and setZero().  Expressions are evaluated element by element on assignment, like Eigen's.
+template <class E>
+struct TExpr {
+  const E& self() const { return static_cast<const E&>(*this); }
+};
+template <class A>
+struct TNeg : TExpr<TNeg<A>> {
+  A a;
+  explicit TNeg(const A& a_) : a(a_) {}
+  int dimension(int i) const { return a.dimension(i); }
+  Float at(int i, int j) const { return -a.at(i, j); }
+};
+template <class A, class B>
+struct TSub : TExpr<TSub<A, B>> {
+  A a; B b;
+  TSub(const A& a_, const B& b_) : a(a_), b(b_) {}
+  int dimension(int i) const { return a.dimension(i); }
+  Float at(int i, int j) const { return a.at(i, j) - b.at(i, j); }
+};
+template <class A>
+struct TAddScalar : TExpr<TAddScalar<A>> {
+  A a; Float s;
+  TAddScalar(const A& a_, Float s_) : a(a_), s(s_) {}
+  int dimension(int i) const { return a.dimension(i); }
+  Float at(int i, int j) const { return a.at(i, j) + s; }
+};
+struct TensorMap2 : TExpr<TensorMap2> {
+  Float* p = nullptr;
+  int n = 0, m = 0;
+  TensorMap2() {}
+  TensorMap2(Float* p_, int n_, int m_) : p(p_), n(n_), m(m_) {}
+  int dimension(int i) const { return i == 0 ? n : m; }
+  Float* data() const { return p; }
+  Float at(int i, int j) const { return p[i + (size_t)n * j]; }
+  Float& operator()(int i, int j) const { return p[i + (size_t)n * j]; }
+  void setZero() const { if (p) memset(p, 0, sizeof(Float) * n * m); }
+  template <class E>
+  const TensorMap2& operator=(const TExpr<E>& e) const {
+    const E& x = e.self();
+    assert(x.dimension(0) == n && x.dimension(1) == m);
+    for (int j = 0; j < m; j++)
+      for (int i = 0; i < n; i++) p[i + (size_t)n * j] = x.at(i, j);
+    return *this;
+  }
+  const TensorMap2& operator=(const TensorMap2& o) const {   // element-wise copy like Eigen (NOT a rebind)
+    if (o.p != p) { assert(o.n == n && o.m == m); memcpy(p, o.p, sizeof(Float) * n * m); }
+    return *this;
+  }
+  TensorMap2(const TensorMap2& o) : TExpr<TensorMap2>(), p(o.p), n(o.n), m(o.m) {}
+};
+template <class A> TNeg<A> operator-(const TExpr<A>& a) { return TNeg<A>(a.self()); }
+template <class A, class B> TSub<A, B> operator-(const TExpr<A>& a, const TExpr<B>& b) { return TSub<A, B>(a.self(), b.self()); }
+template <class A> TAddScalar<A> operator+(const TExpr<A>& a, Float s) { return TAddScalar<A>(a.self(), s); }
 
 struct Tensor2 {   // tensor.h:176-330
   int dims[2] = {0, 0};
@@ -67,6 +126,13 @@ struct Tensor2 {   // tensor.h:176-330
   }
   void setZero() { if (ptr) memset(ptr, 0, sizeof(Float) * dims[0] * dims[1]); }
   void setZero(int n, int m) { resize(n, m); setZero(); }
+  void like(const TensorMap2& o) { resize(o.dimension(0), o.dimension(1)); }                 // tensor.h:231-233
+  void operator=(const TensorMap2& o) { resize(o.n, o.m); if (ptr) memcpy(ptr, o.p, sizeof(Float) * o.n * o.m); }   // :311-315
+  TensorMap2 operator*() const { return TensorMap2(ptr, dims[0], dims[1]); }                // :249-251: *x, x(), x.map()
+  TensorMap2 operator()() { return **this; }
+  TensorMap2 map() { return **this; }
+  Float* data() { return ptr; }
+  int total_size() const { return dims[0] * dims[1]; }
   int getGpu() const { return 0; }
   int dimension(int i) const { return dims[i]; }
   int rows() const { return dims[0]; }
@@ -80,6 +146,7 @@ struct Batch {     // batches.h:12-24
   virtual ~Batch() {}
   int rows() const { return v.dimension(0); }
   int cols() const { return v.dimension(1); }
+  void clear() { v.setZero(); d.setZero(); }            // batches.h:19-22
   void zeroGrad() { d.setZero(rows(), cols()); }
 };
 struct BatchStorage : Batch {   // batches.h:26-41
@@ -125,6 +192,9 @@ struct Sequence {  // batches.h:45-148
   }
   void operator=(const Sequence& o) { copy(o); }
   Batch& operator[](int i) { return steps[i]; }
+  const Batch& operator[](int i) const { return steps[i]; }
+  void check() const { assert(dims[3] == 0 ? !data : data != nullptr); }   // batches.h:91-113 (the layout holds by construction here)
+  void zero() { for (auto& s : steps) s.clear(); }
   void zeroGrad() { for (auto& s : steps) s.zeroGrad(); }
 };
 }  // namespace ocropus

