@@ -28,7 +28,12 @@ import os
 import sys
 import time
 
-import numpy as np
+# thread placement of the cpu_baseline leg (the oracle's OpenMP loop over lines): fixed BEFORE numpy -- whose BLAS may start an
+# OpenMP runtime at import -- so that libgomp reads it; set after, the figure moved 707...960 lines/s between runs of one box
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "threads")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -42,7 +47,7 @@ F32_MFMA_PEAK_TFS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = f32 vecto
 BF16_MFMA_PEAK_TFS = 2500.0    # dense bf16 MFMA
 # algorithmic bytes per cell-step of the fused gate kernels
 BYTES_PER_CELL_STEP = {"lstm_fwd": 44.0, "lstm_bwd": 56.0}
-MIN_WARMUP_S, MIN_TIMED_S, MAX_REPEATS = 0.3, 0.5, 200
+MIN_WARMUP_S, MIN_TIMED_S, MAX_REPEATS = 0.3, 2.0, 400   # (2 s timed: the driver's 5-s GPU-busy sampler sees the work)
 KERNEL_NAMES = ("ingest", "gemm_gates_x", "lstm_fwd", "gemm_softmax", "softmax_norm", "ctc_align", "gemm_softmax_dw_dx",
                 "lstm_bwd", "gemm_gates_dw", "reduce_scatter", "gemm_gates_dx", "allreduce_grads", "sgd_update")
 
@@ -73,8 +78,6 @@ def cpu_baseline(params, cfg, seconds_target=12.0):
     net.set_params(params)
     rng = np.random.default_rng(123)
     cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_PROC_BIND", "close")     # (read by libgomp when its first parallel region starts)
-    os.environ.setdefault("OMP_PLACES", "threads")
     nlines = max(8, cores)
     Ts, x, labels = synth_batch(rng, nlines, 200, False, cfg["ni"], cfg["nc"], cfg["L"])
     offs = np.concatenate([[0], np.cumsum(Ts)])
@@ -98,7 +101,7 @@ def cpu_baseline(params, cfg, seconds_target=12.0):
 class Workload:
     """One network + a small rotating pool of synthetic minibatches resident in HBM."""
 
-    def __init__(self, lib, cfg, minibatch, T, ragged, precision, dev, rank, comm=None, dist=None, host_inputs=False):
+    def __init__(self, lib, cfg, minibatch, T, ragged, precision, dev, rank, comm=None, dist=None, host_inputs=False, strict_f32=False):
         import torch
         from clstm_amd.init import init_params
         from clstm_amd.net import Network
@@ -115,6 +118,8 @@ class Workload:
         self.net.setLearningRate(1e-4, 0.9)
         if precision:
             self.net.set_gemm_precision(precision)
+        if strict_f32:
+            self.net.set_strict_f32(True)
         self.trainer = Trainer(self.net, grads_tensor=self.grads if (comm is None and dist is not None) else None, comm=comm)
         rng = np.random.default_rng(1000 + rank)
         self.pool = []
@@ -138,7 +143,7 @@ class Workload:
         return sum(self.pool[i % len(self.pool)][0])
 
 
-def timed_blocks(w, steps, warmup, fence, reduce_max):
+def timed_blocks(w, steps, warmup, fence, reduce_max, min_timed_s=None):
     """warm-up (>= `warmup` steps and >= MIN_WARMUP_S), then R blocks of exactly `steps` steps; returns the block times"""
     i = 0
     t0 = time.perf_counter()
@@ -165,7 +170,7 @@ def timed_blocks(w, steps, warmup, fence, reduce_max):
         i += steps
         blocks.append(dt)
         if k == 0:
-            repeats = int(min(MAX_REPEATS, max(1, np.ceil(MIN_TIMED_S / max(dt, 1e-9)))))   # identical on every rank: dt is max-reduced
+            repeats = int(min(MAX_REPEATS, max(1, np.ceil((MIN_TIMED_S if min_timed_s is None else min_timed_s) / max(dt, 1e-9)))))   # identical on every rank: dt is max-reduced
         k += 1
     return blocks, i
 
@@ -227,6 +232,18 @@ def rocprof_avg_ms(kernel, minibatch, T, ragged):
     except Exception:
         pass
     return None
+
+
+def rocprof_b2_avg_ms():
+    """average duration (ms) of the configs[4] step's dominant launch, lstm_xcd_bwd_bf16, in the newest committed one-step kernel
+    trace (profiles/r*_b2_timeline.txt: rocprofv3 --kernel-trace of `bench.py --config b2 --bf16`)"""
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_b2_timeline.txt")))[-1]
+        d = [float(l.split()[2]) for l in open(f) if "lstm_xcd_bwd_bf16" in l]
+        return round(sum(d) / len(d) * 1e-3, 4) if d else None
+    except Exception:
+        return None
 
 
 def roofline_b1(w, kern, kern_unfused, frames_per_step, ms_per_step):
@@ -402,6 +419,7 @@ def main():
     # barriers and the max-over-ranks of the timing.  If the communicator cannot be created the step falls back to
     # torch.distributed.all_reduce on the gradient tensor and the JSON line says so.
     allreduce_impl = None
+    allreduce_ranks = None
     comm = None
     if dist is not None:
         def exchange(ident):
@@ -411,9 +429,11 @@ def main():
         try:
             comm = Comm(rank, world, exchange, lib=lib)
             allreduce_impl = "clstm_allreduce_flat (RCCL ncclAllReduce on the library stream)"
+            allreduce_ranks = int(lib.dll.clstm_comm_size(comm.h))      # what the LIBRARY's communicator spans
         except Exception as e:     # noqa: BLE001 -- report and fall back, never silently
             sys.stderr.write("bench.py: library communicator unavailable (%s); falling back to torch.distributed\n" % e)
             allreduce_impl = "torch.distributed.all_reduce (fallback: %s)" % type(e).__name__
+            allreduce_ranks = world
 
     def fence():
         torch.cuda.synchronize()
@@ -428,8 +448,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    def measure(w, steps, warmup, profile_steps, unfused_pass=False):
-        blocks, nxt = timed_blocks(w, steps, warmup, fence, reduce_max)
+    def measure(w, steps, warmup, profile_steps, unfused_pass=False, min_timed_s=None):
+        blocks, nxt = timed_blocks(w, steps, warmup, fence, reduce_max, min_timed_s)
         dt = float(np.median(blocks))
         # host-side cost of issuing a step (diagnostic: is the loop host-bound?): a short burst on an idle stream, few
         # enough steps that the library's pinned staging ring never makes the host wait for the GPU
@@ -460,9 +480,41 @@ def main():
         else:
             roofline = roofline_b2(w, m["kern"], m["frames_per_step"], ms_per_step)
 
+    # the gradient exchange on its own: the library's all-reduce of the flat gradient buffer, back to back on the library stream
+    allreduce = None
+    if allreduce_impl is not None:
+        ar_ms = None
+        if comm is not None:
+            n = int(w.grads.numel())
+            for _ in range(5):
+                comm.allreduce(w.grads, n)
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                comm.allreduce(w.grads, n)
+            e1.record()
+            torch.cuda.synchronize()
+            ar_ms = reduce_max(e0.elapsed_time(e1) / 50.0)
+        allreduce = {"impl": allreduce_impl, "ranks": allreduce_ranks, "bytes": int(w.grads.numel()) * 4,
+                     "ms_per_call_isolated": None if ar_ms is None else round(ar_ms, 4),
+                     "note": "ranks = clstm_comm_size of the communicator the step all-reduces on; the isolated figure is 50 calls back "
+                             "to back on the library stream (max over ranks) -- inside a step the call sits between the last reduction and the update"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w.params_h, cfg)
+
+    # the same workload with EVERY product on the exact f32 MFMA (clstm_net_set_strict_f32: the default computes the backward
+    # weight-gradient / softmax-backward products as f32-grade bf16 x 3 split products); default single-GPU line only
+    strict = None
+    if rank == 0 and world == 1 and default_line:
+        ws = Workload(lib, cfg, args.minibatch, args.T, args.ragged, 0, dev, rank, strict_f32=True)
+        ms_ = measure(ws, args.steps, 5, 0, min_timed_s=0.5)
+        strict = {"value": round(args.minibatch * args.steps / ms_["dt"], 2), "unit": "lines/s", "ms_per_step": round(ms_["dt"] / args.steps * 1e3, 4),
+                  "repeats": len(ms_["blocks"]), "dtype": "f32 (every product on the f32 MFMA: CLSTM_DW_X3=0 CLSTM_GEMM_X3=0)"}
+        ws.net = ws.trainer = None
+        del ws
 
     # BASELINE.json configs[4] in the same process (default single-GPU line only): 2 x BiLSTM(512), bf16 MFMA
     secondary = None
@@ -483,11 +535,24 @@ def main():
             "data": "synthetic",
             "config": {"workload": "stacked 2xBiLSTM(512) H=64 nc=100, T=400, L=50, minibatch=64 lines on 1 GPU "
                                    "(BASELINE.json configs[4] shape), fwd+CTC+bwd+update", "minibatch_per_gpu": 64},
-            "roofline": roofline_b2(w2, m2["kern"], m2["frames_per_step"], ms2) if m2["kern"] else None,
+            "roofline": dict(roofline_b2(w2, m2["kern"], m2["frames_per_step"], ms2), rocprof_avg_launch_ms=rocprof_b2_avg_ms()) if m2["kern"] else None,
             "kernels": m2["kern"],
             "parity": "stated tolerance against the f32 oracle at this size: tests/test_gpu_e2e.py::test_configs4_full_shape_bf16_vs_oracle",
         }
         del w2
+    # ... and its parity-grade form: every gate activation inside 1e-4 of the oracle at this size
+    # (tests/test_gpu_e2e.py::test_configs4_full_shape_f32_vs_oracle); 3 steps x 2 repeats
+    secondary_f32 = None
+    if rank == 0 and world == 1 and default_line and not args.no_secondary:
+        c2 = CONFIGS["b2"]
+        w3 = Workload(lib, c2, 64, c2["T"], False, 0, dev, rank)
+        m3 = measure(w3, 3, 2, 0, min_timed_s=0.08)
+        secondary_f32 = {"metric": "text-line images/sec (fwd+bwd+CTC), 2xBiLSTM(512) H=64 T~400 (f32)", "value": round(64 * 3 / m3["dt"], 2),
+                         "unit": "lines/s", "steps": 3, "repeats": len(m3["blocks"]), "ms_per_step": round(m3["dt"] / 3 * 1e3, 4),
+                         "dtype": "f32 (forward, recurrences, CTC, decode: exact f32; backward weight-gradient / input-delta products of the wide "
+                                  "layers: f32-grade bf16x3 split, < 2^-16 per product)",
+                         "parity": "tests/test_gpu_e2e.py::test_configs4_full_shape_f32_vs_oracle, ..._strict_at_reference_init"}
+        del w3
 
     if rank == 0:
         b1 = args.config == "b1"
@@ -498,7 +563,9 @@ def main():
             "warmup": args.warmup, "repeats": len(m["blocks"]), "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 MFMA operands (hoisted gate GEMMs and lock-step recurrence), f32 accumulate / state / softmax / CTC" if args.bf16
-                      else "f32 (hoisted gate GEMMs: bf16 in, f32 accumulate)" if args.bf16_gemm else "f32"),
+                      else "f32 (hoisted gate GEMMs: bf16 in, f32 accumulate)" if args.bf16_gemm
+                      else "f32 (forward, recurrences, CTC, decode: exact f32; backward weight-gradient / softmax-backward products: "
+                           "bf16x3 split, < 2^-16 per product -- `strict_f32` carries the all-f32-MFMA figure)"),
             "data": "synthetic" + (" (frames fed from pinned host memory every step: PCIe-inclusive)" if args.host_inputs else ""),
             "config": {"workload": ("uw3-500 OCR shape: BiLSTM(100) H=48 nc=83, T=%s, L=25, minibatch=%d lines/GPU "
                                     "(BASELINE.json configs[2]; x%d GPUs = configs[3] sharding), fwd+CTC+bwd+allreduce+update"
@@ -514,8 +581,10 @@ def main():
                        "block_ms_min": round(min(m["blocks"]) * 1e3, 3), "block_ms_max": round(max(m["blocks"]) * 1e3, 3)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": m["kern"], "kernels_fusions_off": m["kern_unfused"],
             "host_enqueue_ms_per_step": round(m["enqueue"] * 1e3, 4),   # host-side cost of issuing a step
-            "allreduce": allreduce_impl,
+            "allreduce": allreduce,
+            "strict_f32": strict,
             "secondary": secondary,
+            "secondary_f32": secondary_f32,
         }
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:

@@ -395,9 +395,10 @@ static void check_device_errors() {
   HIPCHECK(hipMemcpy(w, g_dev_err, sizeof(w), hipMemcpyDeviceToHost));
   if ((w[0] | w[1] | w[2] | w[3]) == 0) return;
   (void)hipMemset(g_dev_err, 0, sizeof(w));
-  if (w[3]) throw Error("non-finite gradient (NaN or Inf) in training step " + std::to_string(w[3]) + " of a net (counted per net from 1): that update was NOT applied -- no "
-                        "non-finite entry ever reaches the parameters or the momentum -- and neither was any update enqueued since; the parameters are those of the step "
-                        "before.  The reference aborts here (clstm.cc:630-649).  Lower the learning rate, or CLSTM_NANCHECK=0 to train on regardless");
+  if (w[3]) throw Error("non-finite value (NaN or Inf) in the softmax logits or the gradient of training step " + std::to_string(w[3]) + " of a net (forward passes counted per net "
+                        "from 1): no non-finite entry reaches the parameters or the momentum -- a diverged forward pass skips the whole update, a non-finite gradient entry is "
+                        "skipped -- and no update enqueued since was applied.  The reference aborts here (clstm.cc:630-649).  Lower the learning rate, or CLSTM_NANCHECK=0 "
+                        "to train on regardless");
   if (w[2]) throw Error("fused forward launch: " + std::to_string(w[2]) + " wait(s) for a gate-GEMM chunk / a finished frame block gave up (watchdog): outputs read back since then are "
                         "not valid and the minibatches enqueued since then were NOT applied -- set CLSTM_OVERLAP=0");
   if (w[0] == 1) g_xcd_failed = true;
@@ -407,6 +408,7 @@ static void check_device_errors() {
               "minibatches since then were NOT applied -- set CLSTM_OVERLAP=0");
 }
 static bool g_wide_persistent = false;   // the last launch_lstm_wide call ran the persistent per-XCD kernels
+static int g_debug_fail_claims = 0;      // tests: this many upcoming persistent launches fail their placement check
 
 // fx_ngx > 0 (forward, bf16): try ONLY the persistent kernel with the input projection folded in (lstm_xcd_fwd_bf16_fx<fx_ngx>);
 // returns false -- nothing launched or nothing written -- if it does not apply or its placement check failed: the caller then
@@ -434,6 +436,7 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     bool ok = true;
     for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
       a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
+      a.debug_fail_claim = g_debug_fail_claims > 0 ? (g_debug_fail_claims--, 1) : 0;
       HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
       coop_set_smem(kernel, smem);
       // An ORDINARY launch: one workgroup per CU (LDS), at most as many workgroups as CUs, the stream's previous kernel complete --
@@ -1200,7 +1203,7 @@ struct Net {
     // the top layer's output rows are [1 | h]: they ARE the softmax layer's source rows
     if (nc <= SMX_COLS) {   // logits, limexp and normalisation in one kernel (softmax_fused.h)
       timing.begin("gemm_softmax", s);
-      softmax_fwd(s, gemm_kc(L.back().hrow(), L.back().ldh, N), W1, (long long)nc * (1 + sm_ni), Z.p, (int)N, nc, sm_ni);
+      softmax_fwd(s, gemm_kc(L.back().hrow(), L.back().ldh, N), W1, (long long)nc * (1 + sm_ni), Z.p, (int)N, nc, sm_ni, nanflag(), step_no() + 1);
       timing.end(s);
       check_launch();
     } else {
@@ -1210,7 +1213,7 @@ struct Net {
       timing.end(s);
       check_launch();
       timing.begin("softmax_norm", s);
-      CLSTM_LAUNCH(k_softmax_norm, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Z.p, nc, (size_t)N);
+      CLSTM_LAUNCH(k_softmax_norm, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Z.p, nc, (size_t)N, nanflag(), step_no() + 1);
       timing.end(s);
       check_launch();
     }
@@ -1282,6 +1285,7 @@ struct Net {
     h.pitems = fw_items.p; h.npitems = fw_npitems; h.gflag = fw_flags.p;
     h.W1k = W1k; h.kps = w1k_kps; h.sm_k = sm_ni; h.b1 = v + sm_off; h.Z = Z.p; h.nc = desc.nclasses;
     h.citems = fw_items.p + 4 * fw_npitems; h.ncitems = fw_ncitems;
+    h.nanflag = nanflag(); h.step_no = step_no() + 1;
     h.prog = (const int*)(y.H.p + a.prog_off);
     h.nrec = bs * ndir; h.npb = fw_npitems;
     const unsigned nblk = (unsigned)(h.nrec + h.npb + fw_ncitems);   // one item per helper workgroup
@@ -1570,9 +1574,12 @@ struct Net {
       if (bwd_persistent) g_path_count[1]++;
       }
       const bool dw_from_bf16 = bf16_gemm && bf16_rec && bwd_persistent && y.sbf_ready && y.Dbf.p && gemm_bf16_big(R, Cn);
+      // exact-f32 mode, wide layer: the backward products as f32-grade bf16 x 3 on 128 x 128 tiles (gemm_x3_128_kernel) -- what
+      // narrow layers already do inside their fused backward launch; CLSTM_GEMM_X3=0 / clstm_net_set_strict_f32: the f32 MFMA
+      const bool x3_big = !bf16_gemm && y.wide && gemm_x3_on && gemm_bf16_big(R, Cn);
       if (bf16_gemm || !overlap_eligible(y))
         ns = dw_from_bf16 && gemm_tile256(R, Cn) ? pick_split(R, Cn, ndir, 256)
-             : bf16_gemm && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
+             : (bf16_gemm || x3_big) && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
       if (!dw_from_bf16) { ensure_source(l); ensure_delta_f32(l); }   // the f32-source products below read S and D
       DevBuf<float>& pbuf = partial;
       auto do_dw = [&](hipStream_t q) {
@@ -1590,6 +1597,9 @@ struct Net {
             gemm_bf16<GEMM_MC, GEMM_MC>(q, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
                                         gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
                                         StorePartial{pbuf.p, R, Cn}, R, Cn, (int)N, ns, ndir);
+          else if (x3_big)
+            gemm_x3_big<GEMM_MC, GEMM_MC>(q, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
+                                          gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1), StorePartial{pbuf.p, R, Cn}, R, Cn, (int)N, ns, ndir);
           else
             gemm_f32<GEMM_MC, GEMM_MC, StorePartial, GEMM_BK_DW>(q, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
                                                                  gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
@@ -1625,6 +1635,8 @@ struct Net {
         } else if (ensure_delta_f32(l), bf16_gemm)
           gemm_bf16<GEMM_KC, GEMM_KC>(s, gemm_kc(y.D.p, M, N, 32), gemm_kc(y.Wt, M, y.ni, y.wt_slack), StorePlain{dx, y.ni},
                                       (int)N, y.ni, M);
+        else if (y.wide && gemm_x3_on && gemm_bf16_big((int)N, y.ni))
+          gemm_x3_big<GEMM_KC, GEMM_KC>(s, gemm_kc(y.D.p, M, N, 32), gemm_kc(y.Wt, M, y.ni, y.wt_slack), StorePlain{dx, y.ni}, (int)N, y.ni, M);
         else
           gemm_f32<GEMM_KC, GEMM_KC>(s, gemm_kc(y.D.p, M, N), gemm_kc(y.Wt, M, y.ni, 0), StorePlain{dx, y.ni}, (int)N,
                                      y.ni, M);
@@ -1841,7 +1853,7 @@ int clstm_forward_softmax(float* z, const float* W, const float* x, int n, int m
   ABI_BEGIN
   REQUIRE(n >= 2, "Softmax requires n>=2 (clstm_compute.cc:328)");
   EW(k_forward_lin1, (size_t)n * bs, z, W, x, n, m, bs, -1)
-  CLSTM_LAUNCH(k_softmax_norm, dim3((bs + 3) / 4), dim3(256), 0, g_stream, z, n, (size_t)bs);
+  CLSTM_LAUNCH(k_softmax_norm, dim3((bs + 3) / 4), dim3(256), 0, g_stream, z, n, (size_t)bs, (int*)nullptr, 0);
   check_launch();
   ABI_END
 }
@@ -2429,6 +2441,16 @@ int clstm_net_set_overlap(clstm_net* h, int mode) {
   h->net.overlap = mode;
   ABI_END
 }
+int clstm_net_set_strict_f32(clstm_net* h, int on) {
+  ABI_BEGIN
+  Net& n = h->net;
+  if (on) { n.dw_x3 = 0; n.gemm_x3_on = false; }
+  else {
+    n.dw_x3 = getenv("CLSTM_DW_X3") ? atoi(getenv("CLSTM_DW_X3")) : 1;
+    n.gemm_x3_on = !(getenv("CLSTM_GEMM_X3") && atoi(getenv("CLSTM_GEMM_X3")) == 0);
+  }
+  ABI_END
+}
 int clstm_net_overlap_stats(clstm_net* h, long long* launches, int* timeouts) {
   ABI_BEGIN
   Net& n = h->net;
@@ -2462,8 +2484,15 @@ int clstm_debug_lstm_cycles(clstm_net* h, long long* out_h) {   // diagnostics b
 #endif
 int clstm_debug_set_device_error(int which, int value) {   // tests: what a failed persistent launch / a timed-out item leaves behind
   ABI_BEGIN
-  REQUIRE(which >= 0 && which <= 3, "bad error word");
+  REQUIRE(which >= 0 && which <= 5, "bad error word");
   HIPCHECK(hipStreamSynchronize(g_stream));
+  if (which == 4) { g_debug_fail_claims = value; return 0; }       // the next `value` persistent launches fail their placement check
+  if (which == 5) {                                                  // forget a placement failure: persistent launches again, `value` of them verified synchronously
+    g_xcd_failed = false;
+    g_xcd_outcome.check_all();
+    g_xcd_outcome.verified = value ? 4 : 0;
+    return 0;
+  }
   HIPCHECK(hipMemcpy(dev_err_words() + which, &value, sizeof(int), hipMemcpyHostToDevice));
   ABI_END
 }
@@ -2519,6 +2548,15 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     if (nsplit < 1) nsplit = 1;
     part->reserve((size_t)nsplit * R * Cn);
     gemm_x3<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
+    CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
+                 (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0, (UpdateFuse{}));
+  } else if (mode == 23) gemm_x3_big<GEMM_KC, GEMM_MC>(g_stream, gemm_kc(A, K, R, 0), gemm_mc(B, Cn, K, 0), StorePlain{Cm, Cn}, R, Cn, K);
+  else if (mode == 24) gemm_x3_big<GEMM_KC, GEMM_KC>(g_stream, gemm_kc(A, K, R, 0), gemm_kc(B, K, Cn, 0), StorePlain{Cm, Cn}, R, Cn, K);
+  else if (mode == 25) {
+    if (!part) part = new DevBuf<float>();
+    if (nsplit < 1) nsplit = 1;
+    part->reserve((size_t)nsplit * R * Cn);
+    gemm_x3_big<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
                  (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0, (UpdateFuse{}));
   } else throw Error("bad mode");

@@ -327,6 +327,172 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
   gb2_store(fe, acc, r0 + wm * 64, c0 + wn * 64, lane, R, Cn, z);
 }
 
+// ---- the same 128 x 128 tile with f32-GRADE products: hi + lo split operands, three MFMAs per product ------------------
+// (gemm_x3_body's arithmetic -- x = hi + lo, hi = bf16(x), lo = bf16(x - hi), product = hi.hi + hi.lo + lo.hi, < 2^-16 |x||y|
+// dropped per product, f32 accumulation -- on the big tile: the backward products of WIDE layers in the exact-f32 mode.
+// Their f32-MFMA form runs near its own roof (96-114 TFLOP/s of 157) and was 6.5 of the 15.2 ms of a configs[4] step; three
+// bf16 MFMAs of 16 cycles replace eight f32 MFMAs of 32.)  Each operand block lives in LDS as a hi and a lo image
+// (4 x 8 KB per buffer, two buffers = 64 KB: one workgroup per CU by LDS... two by registers).
+template <int AMODE, int BMODE, class FE>
+__global__ __launch_bounds__(256, 2) void gemm_x3_128_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
+                                                             int K, int ksplit, int nsplit) {
+  unsigned short* const x3_smem = dyn_smem<unsigned short>();   // [A hi | A lo | B hi | B lo] x 2 buffers
+  unsigned short* const As = x3_smem;                 // hi images: As[cur], lo images: As[cur + 2 * GB2_TILE]
+  unsigned short* const Bs = x3_smem + 4 * GB2_TILE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int bx, by, z;   // XCD-aware tile order, see gemm_mfma.h
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = lin & 7u, idx = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = (int)(v % gx);
+    by = (int)((v / gx) % gy);
+    z = (int)(v / (gx * gy));
+  }
+  const int r0 = by * GB2_BT, c0 = bx * GB2_BT;
+  const int batch = z / nsplit;
+  const int kbeg = (z - batch * nsplit) * ksplit;
+  const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
+
+  const int a_mn = AMODE == GEMM_KC ? (tid >> 1) : wave * 32 + (lane & 7) * 4;
+  const int a_k = AMODE == GEMM_KC ? (tid & 1) * 16 : (lane >> 3) * 4;
+  const int b_mn = BMODE == GEMM_KC ? (tid >> 1) : wave * 32 + (lane & 7) * 4;
+  const int b_k = BMODE == GEMM_KC ? (tid & 1) * 16 : (lane >> 3) * 4;
+  const BufF32 abuf = make_buf(A.p + batch * A.bstride, (size_t)(A.elems - batch * A.bstride) * 4);
+  const BufF32 bbuf = make_buf(B.p + batch * B.bstride, (size_t)(B.elems - batch * B.bstride) * 4);
+  const unsigned a_base = AMODE == GEMM_KC ? (unsigned)(r0 + a_mn) * A.ld + a_k : (unsigned)a_k * A.ld + r0 + a_mn;
+  const unsigned b_base = BMODE == GEMM_KC ? (unsigned)(c0 + b_mn) * B.ld + b_k : (unsigned)b_k * B.ld + c0 + b_mn;
+  const unsigned a_kstep = AMODE == GEMM_KC ? 1u : (unsigned)A.ld, b_kstep = BMODE == GEMM_KC ? 1u : (unsigned)B.ld;
+  const unsigned a_next = AMODE == GEMM_KC ? 4u : (unsigned)A.ld, b_next = BMODE == GEMM_KC ? 4u : (unsigned)B.ld;
+
+  // Block addresses: per-lane byte offsets of the four float4 (fixed) + the block's offset (one add per load, the sum
+  // stays inside the descriptor's bounds check).  Blocks past the slab re-read its last block (their products are
+  // zeroed when staged): no select per load.
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    aoff[j] = (a_base + (unsigned)j * a_next) * 4u;
+    boff[j] = (b_base + (unsigned)j * b_next) * 4u;
+  }
+  const int klast = kbeg + ((kend - kbeg - 1) / GB_BK) * GB_BK;   // first k of the slab's last block (kend > kbeg)
+  f32x4 ra[GB2_PF][4], rb[GB2_PF][4];
+  auto load_tile = [&](int k0, f32x4 (&a)[4], f32x4 (&b)[4]) {
+    const unsigned kc = (unsigned)wave_uniform(k0 < klast ? k0 : klast);
+    const unsigned ao = kc * a_kstep * 4u, bo = kc * b_kstep * 4u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) a[j] = buf_load4(abuf, aoff[j] + ao);
+#pragma unroll
+    for (int j = 0; j < 4; j++) b[j] = buf_load4(bbuf, boff[j] + bo);
+  };
+  // round to bf16 and store k-contiguous.  Whole blocks take the plain path; the slab's last block (and the
+  // zero blocks behind it) mask contraction indices >= kend per element (one wave-uniform branch per block).
+  auto stage = [&](const int MODE, unsigned short* S, const int mn, const int kk, const int k0, const f32x4 (&r)[4]) {
+    const bool whole = wave_uniform(k0 + GB_BK <= kend ? 1 : 0) != 0;
+    if (MODE == GEMM_KC) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        float x[8];
+        if (whole) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) x[i] = r[2 * h + (i >> 2)][i & 3];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i++) x[i] = (k0 + kk + 8 * h + i < kend) ? r[2 * h + (i >> 2)][i & 3] : 0.0f;
+        }
+        const u16x8 hi = bf16_pack8(x);
+        float y[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) y[i] = x[i] - __builtin_bit_cast(float, (unsigned)hi[i] << 16);   // exact
+        const int at = mn * GB2_LDH + ((((kk >> 3) + h) ^ gb2_sw(mn)) << 3);
+        *reinterpret_cast<u16x8*>(&S[at]) = hi;
+        *reinterpret_cast<u16x8*>(&S[at + 2 * GB2_TILE]) = bf16_pack8(y);
+      }
+    } else {
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = r[j];
+      if (!whole) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[j][i] = (k0 + kk + j < kend) ? v[j][i] : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        u32x2 w2, l2;
+        w2[0] = bf16_pack2(v[0][i], v[1][i]);
+        w2[1] = bf16_pack2(v[2][i], v[3][i]);
+        l2[0] = bf16_pack2(v[0][i] - __builtin_bit_cast(float, w2[0] << 16), v[1][i] - __builtin_bit_cast(float, w2[0] & 0xFFFF0000u));
+        l2[1] = bf16_pack2(v[2][i] - __builtin_bit_cast(float, w2[1] << 16), v[3][i] - __builtin_bit_cast(float, w2[1] & 0xFFFF0000u));
+        const int at = (mn + i) * GB2_LDH + (((kk >> 3) ^ gb2_sw(mn + i)) << 3) + (kk & 4);
+        *reinterpret_cast<u32x2*>(&S[at]) = w2;
+        *reinterpret_cast<u32x2*>(&S[at + 2 * GB2_TILE]) = l2;
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+
+#pragma unroll
+  for (int p = 0; p < GB2_PF; p++) {
+    load_tile(kbeg + p * GB_BK, ra[p], rb[p]);
+    SCHED_FENCE();
+  }
+  // block 0 -> buffer 0
+  stage(AMODE, As, a_mn, a_k, kbeg, ra[0]);
+  stage(BMODE, Bs, b_mn, b_k, kbeg, rb[0]);
+  load_tile(kbeg + GB2_PF * GB_BK, ra[0], rb[0]);
+  SCHED_FENCE();
+  __syncthreads();
+  const int fk = lane >> 4, fi = lane & 15;
+  const int fsw = (fk ^ gb2_sw(fi)) << 3;   // this lane's chunk position (rows 16 apart share the swizzle)
+  int cur = 0;   // LDS buffer (in halfs) that holds the block the MFMAs are about to consume
+  for (int kb = kbeg; kb < kend; kb += GB2_PF * GB_BK) {
+#pragma unroll
+    for (int p = 0; p < GB2_PF; p++) {
+      const int k0 = kb + p * GB_BK;   // block in LDS buffer `cur` (phases past the slab multiply zeros)
+      constexpr int pn_of[3] = {1, 2, 0};
+      const int pn = pn_of[p];         // register set of block k0 + 32: convert it into the other buffer ...
+      {
+      stage(AMODE, As + (cur ^ GB2_TILE), a_mn, a_k, k0 + GB_BK, ra[pn]);
+      stage(BMODE, Bs + (cur ^ GB2_TILE), b_mn, b_k, k0 + GB_BK, rb[pn]);
+      }
+      load_tile(k0 + GB_BK + GB2_PF * GB_BK, ra[pn], rb[pn]);   // ... and re-use the set for the block three ahead
+      SCHED_FENCE();
+      u16x8 af[4], bf[4], al[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        af[i] = *reinterpret_cast<const u16x8*>(&As[cur + (wm * 64 + i * 16 + fi) * GB2_LDH + fsw]);
+        bf[i] = *reinterpret_cast<const u16x8*>(&Bs[cur + (wn * 64 + i * 16 + fi) * GB2_LDH + fsw]);
+        al[i] = *reinterpret_cast<const u16x8*>(&As[cur + 2 * GB2_TILE + (wm * 64 + i * 16 + fi) * GB2_LDH + fsw]);
+        bl[i] = *reinterpret_cast<const u16x8*>(&Bs[cur + 2 * GB2_TILE + (wn * 64 + i * 16 + fi) * GB2_LDH + fsw]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {   // small terms first (transposed: see gb2_store)
+          acc[i][j] = mfma16x16x32_bf16(bl[j], af[i], acc[i][j]);
+          acc[i][j] = mfma16x16x32_bf16(bf[j], al[i], acc[i][j]);
+          acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);
+        }
+      __syncthreads();
+      cur ^= GB2_TILE;
+    }
+  }
+  gb2_store(fe, acc, r0 + wm * 64, c0 + wn * 64, lane, R, Cn, z);
+}
+
 // ---- 128 x 128 tile, BOTH operands already bf16 and k-contiguous in memory ------------------------------------------
 //   out(r, c) = sum_k A16[r * lda + k] * B16[c * ldb + k]
 // What the f32-source kernel spends most of its time on -- 15 GB of f32 operands through the L2s per configs[4] step, the
@@ -804,6 +970,25 @@ inline void gemm_x3_pair(hipStream_t stream, GemmProblem p1, FE1 fe1, GemmProble
 
 // shapes that fill 128 x 128 tiles reasonably
 inline bool gemm_bf16_big(int R, int Cn) { return R >= 96 && Cn >= 96; }
+// f32-grade product on 128 x 128 tiles (gemm_x3_128_kernel); same signature as gemm_f32 / gemm_bf16
+template <int AMODE, int BMODE, class FE>
+inline void gemm_x3_big(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1) {
+  if (R <= 0 || Cn <= 0 || K <= 0) return;
+  if (nsplit < 1) nsplit = 1;
+  int ksplit = (K + nsplit - 1) / nsplit;
+  const int kq = nsplit > 1 ? GB2_PF * GB_BK : GB_BK;   // whole ring rounds per slab
+  ksplit = ((ksplit + kq - 1) / kq) * kq;
+  const size_t smem = (size_t)8 * GB2_TILE * sizeof(unsigned short);   // 64 KB
+#ifndef CLSTM_HIP_EMU
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_x3_128_kernel<AMODE, BMODE, FE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+#endif
+  dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);
+  CLSTM_LAUNCH((gemm_x3_128_kernel<AMODE, BMODE, FE>), grid, dim3(256), smem, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+}
 
 // Operand slack: the second float4 of a KC row may run 7 floats past the row end (library buffers carry
 // >= 64 floats of slack; exact-size user arrays get a descriptor that ends at the last element).

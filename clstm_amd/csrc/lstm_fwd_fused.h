@@ -47,6 +47,7 @@ struct FwdFusedArgs {
   const int* prog;                               // progress words (see LstmSeqArgs::prog_off)
   int nrec, npb;                                 // recurrence workgroups, producer workgroups
   long long* trace;                              // diagnostics (CLSTM_FW_TRACE): [nrec + npitems + ncitems][4] wall-clock stamps
+  int* nanflag; int step_no;                      // non-finite logits (ops.h:raise_nonfinite), or null
 };
 
 // ---- producer item (one WORKGROUP): G[frames f0 .. f0+15 of line b][dir][:] = W_x . x + b  -------------------------
@@ -215,9 +216,11 @@ DEVFN void fwd_softmax_item(const LstmSeqArgs& a, const FwdFusedArgs& h, const i
     for (int e = 0; e < 4; e++) acc = mfma16x16x4(hv[g][e], wv[g][e], acc);   // rows = frames 4 kq + q, column = class fi of the tile
   // limexp and the row sums: a frame's 16 classes of this tile sit in the 16 lanes of one row group
   float ev[4];
+  bool nonfinite = false;   // limexp's clamp would swallow a NaN logit: looked at before it (k_update, ops.h)
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const float x = acc[q] + bias;
+    nonfinite |= cok && f0 + 4 * kq + q < T && !f32_finite(x);
     float v = expf(fminf(fmaxf(x, -30.0f), 30.0f));
     v = x < -30.0f ? (float)0x1.a56e0c2b7ab97p-44 : v;   // (Float)exp(-30.0), tensor.h:78-82
     v = x > 30.0f ? (float)0x1.37047090c0b53p+43 : v;    // (Float)exp(30.0)
@@ -239,6 +242,7 @@ DEVFN void fwd_softmax_item(const LstmSeqArgs& a, const FwdFusedArgs& h, const i
     for (int w = 0; w < FWD_CW; w++) s += part[w * 16 + 4 * kq + q];   // fixed order: deterministic
     buf_store(zbuf, fr < T && cok ? ((unsigned)(off + fr) * (unsigned)h.nc + (unsigned)(wave * 16 + fi)) * 4u : BUF_OOB, ev[q] / s);
   }
+  if (h.nanflag && nonfinite) raise_nonfinite(h.nanflag, h.step_no);
   if (h.trace && threadIdx.x == 0) {
     long long* tr = h.trace + (size_t)(h.nrec + h.npitems + it) * 4;
     tr[0] = t_start; tr[1] = t_ready; tr[2] = wall_clock(); tr[3] = (fhi > T - f0 ? fhi : T - f0);

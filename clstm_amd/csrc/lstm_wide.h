@@ -67,6 +67,7 @@ struct LstmWideArgs {
   const unsigned short* Xb; int x_ld, x_ni;
   const unsigned short* Wxb;
   const float* bias;
+  int debug_fail_claim;         // tests: the placement check of the persistent kernels reports failure (clstm_debug_set_device_error 4)
   long long* prof;              // diagnostics build (CLSTM_LSTM_PROF) only: per-phase cycle sums, [2 workgroups][4 waves][12]; else null
 };
 
@@ -683,7 +684,7 @@ DEVFN bool xcd_wait_group(int* gwords, const int ntile, const int steps_done, in
 
 // role assignment + placement check shared by the persistent kernels; returns false if this workgroup has nothing to do (or the
 // launch is being abandoned)
-DEVFN bool xcd_claim(int* sync, int* flag, const int ntile, const int ngroups, int& xcd, int& slot) {
+DEVFN bool xcd_claim(int* sync, int* flag, const int ntile, const int ngroups, int& xcd, int& slot, const int debug_fail = 0) {
   const int tid = threadIdx.x;
   xcd = hw_xcc_id() & 7;
   if (tid == 0) {
@@ -694,7 +695,7 @@ DEVFN bool xcd_claim(int* sync, int* flag, const int ntile, const int ngroups, i
   slot = flag[1];
   if (!xcd_poll(sync + XcdSyncLayout::ARRIVED, (int)gridDim.x, sync + XcdSyncLayout::ERROR, flag, 1)) return false;
   if (tid == 0) {
-    int bad = 0;
+    int bad = debug_fail;
     for (int g = 0; g < ngroups; g++)
       bad |= __hip_atomic_load(sync + XcdSyncLayout::SLOT0 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntile;
     if (bad) __hip_atomic_store(sync + XcdSyncLayout::ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
   int* const sync = a.sync;
   // ---- claim a tile of this XCD's group, then check the placement of the whole grid ----
   int xcd, ct;
-  if (!xcd_claim(sync, flag, ntile, ngroups, xcd, ct)) return;   // (uneven placement: nothing has been written yet)
+  if (!xcd_claim(sync, flag, ntile, ngroups, xcd, ct, a.debug_fail_claim)) return;   // (uneven placement: nothing has been written yet)
   const int dir = xcd % nd, zb = a.zb0 + xcd / nd;               // zb: block of 16 MT lines
   int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
 
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16_fx(LstmWideArg
   const int ntile = (no + 15) >> 4, nzb = a.zbn, ngroups = nd * nzb, ncg = (no + 3) >> 2;
   int* const sync = a.sync;
   int xcd, ct;
-  if (!xcd_claim(sync, flag, ntile, ngroups, xcd, ct)) return;
+  if (!xcd_claim(sync, flag, ntile, ngroups, xcd, ct, a.debug_fail_claim)) return;
   const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
   int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
   {
@@ -1125,7 +1126,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a
   const int ntile = (no + 15) >> 4, nzb = a.zbn, ngroups = nd * nzb;
   int* const sync = a.sync;
   int xcd, slot;
-  if (!xcd_claim(sync, flag, ntile, ngroups, xcd, slot)) return;
+  if (!xcd_claim(sync, flag, ntile, ngroups, xcd, slot, a.debug_fail_claim)) return;
   const int dir = xcd % nd, zb = a.zb0 + xcd / nd;                         // zb: block of 16 MT lines
   int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
   {
@@ -1297,7 +1298,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a)
   const int no = a.no, nd = a.ndir;
   const int ntile = (no + 15) >> 4, nzb = a.zbn, ncg = (no + 3) >> 2;
   int xcd, ct;
-  if (!xcd_claim(a.sync, flag, ntile, nd * nzb, xcd, ct)) return;
+  if (!xcd_claim(a.sync, flag, ntile, nd * nzb, xcd, ct, a.debug_fail_claim)) return;
   const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
   int* const gcount = a.sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
   {
@@ -1411,7 +1412,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a)
   const int no = a.no, nd = a.ndir;
   const int ntile = (no + 15) >> 4, nzb = a.zbn;
   int xcd, ct;
-  if (!xcd_claim(a.sync, flag, ntile, nd * nzb, xcd, ct)) return;
+  if (!xcd_claim(a.sync, flag, ntile, nd * nzb, xcd, ct, a.debug_fail_claim)) return;
   const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
   int* const gcount = a.sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
   {

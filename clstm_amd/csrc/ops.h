@@ -79,17 +79,21 @@ DEVFN float limexp_dev(float x) {  // tensor.h:78-82
   if (x > 30.0f) return (float)exp(30.0);
   return expf(x);
 }
-__global__ __launch_bounds__(256) void k_softmax_norm(float* z, int n, size_t cols) {
+__global__ __launch_bounds__(256) void k_softmax_norm(float* z, int n, size_t cols, int* nanflag = nullptr, int step_no = 0) {
   const int lane = threadIdx.x & 63;
   const size_t col = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const bool ok = col < cols;   // keep whole waves alive for the wave reduction
   float* p = z + (ok ? col : 0) * n;
   float s = 0.0f;
+  bool nonfinite = false;   // limexp's clamp would swallow a NaN logit: looked at before it (k_update)
   for (int i = lane; i < n; i += 64) {
-    const float e = limexp_dev(p[i]);
+    const float x = p[i];
+    nonfinite |= ok && !f32_finite(x);
+    const float e = limexp_dev(x);
     if (ok) p[i] = e;
     s += e;
   }
+  if (nanflag && nonfinite) raise_nonfinite(nanflag, step_no);
   s = wave_sum(s);
   if (ok)
     for (int i = lane; i < n; i += 64) p[i] = p[i] / s;
@@ -205,12 +209,13 @@ __global__ void k_sgd(float* v, float* d, size_t len, float lr, float mom) {
 // `step_word` (may be null; pinned host memory): set to step_id -- tells a host that feeds frames from its own memory
 // that every kernel of this step, the input ingest first of all, is behind it (clstm_net_train_step_h).
 // `nanflag` (may be null: CLSTM_NANCHECK=0): device error word [3].  The reference aborts on a NaN in any backward step
-// (clstm.cc:630-649, nine assert scans per time step); here every gradient entry passes through exactly one thread of the
-// slab reduction / of this kernel anyway: a non-finite entry is never applied, the word takes the number of the training
-// step, every later update is skipped (dev_err_set) and the host reports it at its next synchronisation point.
-DEVFN bool dev_err_set(const int* err) { return err && (err[0] | err[1] | err[2] | err[3]) != 0; }
-DEVFN bool f32_finite(float x) { return (__builtin_bit_cast(unsigned, x) & 0x7f800000u) != 0x7f800000u; }
-DEVFN void raise_nonfinite(int* nanflag, int step_no) { if (*nanflag == 0) *nanflag = step_no; }   // (every writer of a launch stores the same value)
+// (clstm.cc:630-649, nine assert scans per time step).  Here (a) the forward pass looks at every softmax logit BEFORE limexp's
+// clamp (which would turn a NaN into exp(-30)): a NaN / Inf anywhere in the recurrent state reaches the logits of its frame,
+// so a diverged forward pass raises the word before the backward pass starts and the WHOLE update is skipped; (b) every
+// gradient entry passes through exactly one thread of the slab reduction / of this kernel anyway: a non-finite entry born
+// in the backward pass is never applied (entry by entry when the update is fused into the reduction).  The word takes the
+// number of the training step, every later update is skipped (dev_err_set) and the host reports it at its next
+// synchronisation point.
 __global__ void k_update(float* v, float* d, const float* g, size_t len, float lr, float mom, float clip, const int* err,
                          int* step_word, int step_id, int* nanflag, int step_no) {
   if (step_word && blockIdx.x == 0 && threadIdx.x == 0) store_i32_wt(step_word, step_id);

@@ -27,7 +27,7 @@ DEVFN float smx_limexp(float x) {  // tensor.h:78-82
 // 4 waves x 16 frames per workgroup.  (A one-wave-per-workgroup variant -- 800 instead of 200 workgroups, no
 // barriers -- was measured slower, 31 vs 22 us: every wave then stages the whole 16 x 96 weight tile itself.)
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const float* W1, long long w1_elems,
-                                                         float* Z, int N, int nc, int K) {
+                                                         float* Z, int N, int nc, int K, int* nanflag, int step_no) {
   __shared__ __attribute__((aligned(16))) float As[GEMM_BK * GEMM_LD];
   __shared__ __attribute__((aligned(16))) float Bs[GEMM_BK * SMX_LDB];
   const int tid = threadIdx.x;
@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const f
   bool cok[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) cok[j] = j * 16 + (lane & 15) < nc;
+  bool nonfinite = false;   // limexp's clamp would swallow a NaN logit: looked at before it (k_update, ops.h)
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int r = r0 + wave * 16 + (lane >> 4) * 4 + q;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const f
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       const float x = acc[j][q] + bias[j];
+      nonfinite |= r < N && cok[j] && !f32_finite(x);
       float v = expf(fminf(fmaxf(x, -30.0f), 30.0f));
       v = x < -30.0f ? (float)0x1.a56e0c2b7ab97p-44 : v;   // (Float)exp(-30.0), tensor.h:78-82
       v = x > 30.0f ? (float)0x1.37047090c0b53p+43 : v;    // (Float)exp(30.0)
@@ -122,12 +124,13 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(GemmOperand A, const f
     for (int j = 0; j < 6; j++)
       buf_store(zbuf, r < N && cok[j] ? (rowoff + (unsigned)(j * 16 + (lane & 15))) * 4u : BUF_OOB, e[j] / s);
   }
+  if (nanflag && nonfinite) raise_nonfinite(nanflag, step_no);
 }
 
 inline void softmax_fwd(hipStream_t stream, GemmOperand A, const float* W1, long long w1_elems, float* Z, int N, int nc,
-                        int K) {
+                        int K, int* nanflag = nullptr, int step_no = 0) {
   if (N <= 0) return;
-  CLSTM_LAUNCH(softmax_fwd_kernel, dim3((N + GEMM_BT - 1) / GEMM_BT), dim3(256), 0, stream, A, W1, w1_elems, Z, N, nc, K);
+  CLSTM_LAUNCH(softmax_fwd_kernel, dim3((N + GEMM_BT - 1) / GEMM_BT), dim3(256), 0, stream, A, W1, w1_elems, Z, N, nc, K, nanflag, step_no);
 }
 
 }  // namespace clstm

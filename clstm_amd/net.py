@@ -242,6 +242,11 @@ class Network:
         """0: weight-gradient GEMM after the backward recurrence; 1: beside it where it pays (default); 2: always."""
         self.lib.call("clstm_net_set_overlap", self.h, int(mode))
 
+    def set_strict_f32(self, on=True):
+        """every product of the step on the exact f32 MFMA (the default computes the backward weight-gradient / softmax-backward
+        products as f32-grade bf16 x 3 split products)"""
+        self.lib.call("clstm_net_set_strict_f32", self.h, int(bool(on)))
+
     def overlap_stats(self):
         n, t = C.c_longlong(), C.c_int()
         self.lib.call("clstm_net_overlap_stats", self.h, C.byref(n), C.byref(t))

@@ -207,6 +207,10 @@ int clstm_net_get_state_h(clstm_net* net, int layer, int dir, int which, float* 
  * layer's W.d.  stats: overlapped backward passes so far; slabs that gave up waiting for the recurrence
  * (must stay 0). */
 int clstm_net_set_overlap(clstm_net* net, int mode);
+/* on != 0: every product of the training step on the exact f32 MFMA -- the backward products that default to f32-grade
+ * bf16 x 3 split products (weight gradients, the softmax layer's W.d / x.d; < 2^-16 |x||y| per product instead of 2^-24)
+ * included.  Same as the environment CLSTM_DW_X3=0 CLSTM_GEMM_X3=0, per net (bench.py's `strict_f32` leg). */
+int clstm_net_set_strict_f32(clstm_net* net, int on);
 int clstm_net_overlap_stats(clstm_net* net, long long* launches, int* timeouts);
 int clstm_net_enable_timing(clstm_net* net, int on);
 int clstm_net_kernel_time_ms(clstm_net* net, const char* kernel_name, double* total_ms, int* launches);

@@ -134,6 +134,72 @@ def test_full_bench_shape_ragged_lines(ora32):
 
 
 @pytest.mark.gpu
+def test_full_bench_shape_ragged_64_lines(ora32):
+    """The ragged minibatch `bench.py --ragged` times: 64 lines of T ~ U{150..250} (the 16-line test above is not
+    the shape the bench line runs).  Same bars as the fixed-T full-shape test."""
+    from common import Backend
+    from test_net_parity import run_case
+    rng = np.random.default_rng(1000)
+    T = [int(t) for t in rng.integers(150, 251, 64)]
+    run_case(Backend("hip"), ora32, 48, 100, 83, T, scale=10.0, seed=14, lr=1e-4, ctc_rtol=1e-3, grad_tol=1e-3)
+
+
+@pytest.mark.gpu
+def test_configs4_ragged_lines_both_precisions(ora32):
+    """BASELINE configs[4] architecture on RAGGED lines, T ~ U{300..500}, 32 lines (two 16-line blocks x two directions = four
+    groups of the persistent kernels, lines dropping out of the lock-step at different steps), weights at 2 x the reference's
+    init (contractive: float32 rounding is not amplified, see ..._strict_at_reference_init).  Exact-f32 path: every saved
+    activation of four lines and all softmax outputs inside the 1e-4 bar, decodes identical, gradient at the qualified 1e-3.
+    bf16 mode: the stated tolerances of test_configs4_full_shape_bf16_vs_oracle."""
+    from common import Backend, synth_lines
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Network
+    from oracle.oracle import OracleNet
+    c = C4
+    rng = np.random.default_rng(46)
+    T = [int(t) for t in rng.integers(300, 501, 32)]
+    keep = (0, 11, 21, 31)
+    params = init_params(c["ni"], c["nh"], c["nc"], seed=0.222) * 2.0
+    lines = synth_lines(rng, T, c["ni"])
+    trs = [rng.integers(1, c["nc"], c["L"]).astype(np.int32) for _ in T]
+    ref = OracleNet(ora32, c["ni"], c["nh"], c["nc"], init=False)
+    ref.set_params(params)
+    want = ref.minibatch(lines, trs, keep=keep)
+    be = Backend("hip")
+    for precision in (0, 2):
+        net = Network(c["ni"], c["nh"], c["nc"], lib=be.lib)
+        net.set_params(params)
+        if precision:
+            net.set_gemm_precision(precision)
+        net.set_inputs(lines)
+        net.forward()
+        got = net.split(net.outputs())
+        dec = [d.tolist() for d in net.decode()]
+        same = sum(dec[b] == want["decode"][b].tolist() for b in range(len(T)))
+        if precision == 0:
+            for b in range(len(T)):
+                assert_close(got[b], want["outputs"][b], rtol=1e-4, atol=2e-6, what="softmax outputs line %d" % b)
+            for layer in (0, 1):
+                for d in (0, 1):
+                    for which in ("gi", "gf", "go", "ci", "state", "outputs"):
+                        s = net.split(net.state(layer, d, which))
+                        for b in keep:
+                            assert_close(s[b], _c4_state(want["kept"][b], layer, d, which), rtol=1e-4, atol=2e-6,
+                                         what="L%d dir%d %s line %d" % (layer, d, which, b))
+            assert same == len(T)
+        net.ctc(trs)
+        net.backward()
+        g = net.get_grads()
+        gerr = float(np.abs(g - want["derivs"]).max() / np.abs(want["derivs"]).max())
+        if precision == 0:
+            assert gerr < 1e-3, gerr
+        else:
+            err = max(float(np.abs(got[b] - want["outputs"][b]).max()) for b in range(len(T)))
+            print("ragged configs[4] bf16 vs the f32 oracle: max |dz| %.3g, %d / %d decodes identical, gradient error %.3g of max" % (err, same, len(T), gerr))
+            assert np.isfinite(g).all() and err < 1e-2 and same >= len(T) - 1 and gerr < 1.5e-3
+
+
+@pytest.mark.gpu
 def test_stacked_bilstm512_shape_vs_oracle(ora32):
     """BASELINE configs[4] architecture (2 x BiLSTM(512), H=64, 100 classes) on a few short lines: the
     lock-step MFMA recurrence and the stacked dX GEMM at their real widths (K = 512 / 2048 / 4096)."""
@@ -368,8 +434,10 @@ def test_configs4_full_shape_f32_vs_oracle(configs4_case):
     last, two in between), CTC argmax decodes of all 64 lines IDENTICAL, `aligned` and the minibatch gradient at the
     qualified tolerance of the B1 full-shape test.
 
-    The bar for activations is the north star's 1e-4 relative (+ 2e-6 absolute floor) against the f32 oracle -- or,
-    where the two float32 results are further apart than that, the float64 oracle decides: at this depth (2 layers x 400
+    The bar for every gate activation, cell state and layer output is the north star's 1e-4 relative (+ 2e-6 absolute
+    floor) against the f32 oracle, STRICTLY (round 4: a regression in the gates can no longer hide behind the float64
+    criterion).  For the softmax outputs only, where the two float32 results are further apart than that, the float64 oracle
+    decides: at this depth (2 layers x 400
     dependent steps of 512 cells whose recurrent gain is close to 1) float32 rounding is amplified until the f32 ORACLE
     itself sits 7e-6 (outputs of ~1e-2, i.e. 7e-4 relative) from the float64 result, so no float32 implementation can
     be within 1e-4 of another.  There the GPU must be as close to float64 as the reference's own float32 arithmetic is
@@ -384,26 +452,29 @@ def test_configs4_full_shape_f32_vs_oracle(configs4_case):
     net.forward()
     report, bad = [], []
 
-    def judge(name, got, f32, f64):
-        """got / f32 / f64: lists of arrays"""
+    def judge(name, got, f32, f64, strict):
+        """got / f32 / f64: lists of arrays.  strict: the north star's 1e-4 bar against the f32 oracle, nothing else (every
+        gate activation, cell state and layer output); not strict (the softmax outputs only: values of ~1e-2 behind two
+        layers x 400 dependent steps, where the f32 oracle itself sits 7e-4 relative from float64): inside the bar OR as
+        close to float64 as the f32 oracle is (factor 2)."""
         ex = max(_rel_excess(g, a, 1e-4, 2e-6) for g, a in zip(got, f32))
         e_gpu = max(float(np.abs(g - b).max()) for g, b in zip(got, f64))
         e_f32 = max(float(np.abs(a.astype(np.float64) - b).max()) for a, b in zip(f32, f64))
-        ok = ex <= 1.0 or e_gpu <= 2.0 * e_f32
+        ok = ex <= 1.0 or (not strict and e_gpu <= 2.0 * e_f32)
         report.append("%-22s excess over the 1e-4 bar vs f32 oracle %7.3g | max dist from f64: GPU %.3g, f32 oracle %.3g%s"
                       % (name, ex, e_gpu, e_f32, "" if ok else "   <-- FAIL"))
         if not ok:
             bad.append(name)
 
     got = net.split(net.outputs())
-    judge("softmax outputs", got, want["outputs"], w64["outputs"])
+    judge("softmax outputs", got, want["outputs"], w64["outputs"], strict=False)
     for layer in (0, 1):
         for d in (0, 1):
             for which in ("gi", "gf", "go", "ci", "state", "outputs"):
                 s = net.split(net.state(layer, d, which))
                 judge("L%d dir%d %s" % (layer, d, which), [s[b] for b in c["keep"]],
                       [_c4_state(want["kept"][b], layer, d, which) for b in c["keep"]],
-                      [_c4_state(w64["kept"][b], layer, d, which) for b in c["keep"]])
+                      [_c4_state(w64["kept"][b], layer, d, which) for b in c["keep"]], strict=True)
     print("\n".join(report))
     assert not bad, bad
     dec = net.decode()

@@ -64,6 +64,28 @@ def test_gemm_x3_modes(backend, mode, R, Cn, K, ns):
     assert (np.abs(got - want) <= 1e-5 * scale + 1e-6).all(), float(err.max())
 
 
+@pytest.mark.parametrize("mode", [23, 24, 25])
+@pytest.mark.parametrize("R,Cn,K,ns", [(128, 128, 32, 1), (256, 256, 64, 1), (97, 200, 31, 1), (300, 130, 1000, 2), (577, 260, 129, 3)])
+def test_gemm_x3_big_tile_modes(backend, mode, R, Cn, K, ns):
+    """the same f32-grade product on 128 x 128 tiles (gemm_x3_128_kernel: the backward products of wide layers in the exact-f32
+    mode): whole tiles, ragged edges, k tails, split-K slabs; asymmetric random operands, so a transposed fragment or a
+    swapped hi / lo image would show.  Same bar as the 64 x 64 kernel: 1e-5 of sum |a||b| against the float64 product."""
+    rng = np.random.default_rng(R * 1000 + Cn + 11)
+    A = rng.normal(size=(R, K)).astype(np.float32)
+    B = rng.normal(size=(K, Cn)).astype(np.float32)
+    want = A.astype(np.float64) @ B.astype(np.float64)
+    Ad = backend.up(A if mode < 25 else A.T)
+    Bd = backend.up(B if mode != 24 else B.T)
+    Cd = backend.zeros((R, Cn))
+    backend.lib.call("clstm_debug_gemm", mode, ptr(Ad), ptr(Bd), ptr(Cd), R, Cn, K, ns if mode == 25 else 1)
+    got = backend.down(Cd)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    err = np.abs(got - want) / (scale + 1e-30)
+    assert (np.abs(got - want) <= 1e-5 * scale + 1e-6).all(), float(err.max())
+    # (a plain bf16 product of the same operands sits at ~4e-3 of that scale: a swapped or missing lo image would show)
+    assert float(err.max()) < 1.5e-5, float(err.max())
+
+
 @pytest.mark.parametrize("mode", [10, 11, 12])
 @pytest.mark.parametrize("R,Cn,K,ns", [(64, 64, 32, 1), (70, 45, 37, 1), (149, 400, 333, 5), (5, 3, 2, 1),
                                        (130, 83, 200, 3),
