@@ -496,6 +496,9 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ar_ms = reduce_max(e0.elapsed_time(e1) / 50.0)
+        if comm is not None and int(lib.dll.clstm_comm_peer_active(comm.h)):
+            allreduce_impl = ("one-shot peer-read all-reduce fused into the update kernel (HIP IPC mappings of the ranks' gradient buffers over "
+                              "xGMI, flag handshake; ops.h:k_peer_allreduce_update) inside clstm_net_train_step; clstm_allreduce_flat = RCCL")
         allreduce = {"impl": allreduce_impl, "ranks": allreduce_ranks, "bytes": int(w.grads.numel()) * 4,
                      "ms_per_call_isolated": None if ar_ms is None else round(ar_ms, 4),
                      "note": "ranks = clstm_comm_size of the communicator the step all-reduces on; the isolated figure is 50 calls back "

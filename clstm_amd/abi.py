@@ -106,6 +106,7 @@ _SIGS = {
     "clstm_comm_destroy": [_P],
     "clstm_comm_rank": [_P],
     "clstm_comm_size": [_P],
+    "clstm_comm_peer_active": [_P],
     "clstm_allreduce_flat": [_P, _P, C.c_longlong],
     "clstm_net_set_comm": [_P, _P],
     "clstm_net_set_overlap": [_P, _I],
@@ -118,7 +119,7 @@ _SIGS = {
     "clstm_debug_set_device_error": [_I, _I],
 }
 # functions whose int return value is a result, not a status
-_VALUE_RETURN = {"clstm_net_nparams_for", "clstm_net_nparams", "clstm_abi_version", "clstm_comm_rank", "clstm_comm_size"}
+_VALUE_RETURN = {"clstm_net_nparams_for", "clstm_net_nparams", "clstm_abi_version", "clstm_comm_rank", "clstm_comm_size", "clstm_comm_peer_active"}
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["clstm_last_error", "clstm_abi_version"])
 
 

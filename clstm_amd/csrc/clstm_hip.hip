@@ -601,6 +601,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   static RcclApi& get() {
     static RcclApi api = [] {
@@ -613,6 +614,7 @@ struct RcclApi {
       a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
       a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
       a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
+      a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
       a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
       return a;
     }();
@@ -624,13 +626,141 @@ struct RcclApi {
     ncclResult_t r_ = (expr);                                                                   \
     if (r_ != ncclSuccess) throw Error(std::string(#expr) + " failed: " + RcclApi::get().GetErrorString(r_)); \
   } while (0)
-struct Comm {
-  ncclComm_t comm = nullptr;
-  int rank = 0, nranks = 1;
-  void allreduce(float* buf, long long n, hipStream_t s) {
-    RCCLCHECK(RcclApi::get().AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, comm, s));
+// One-shot peer-read all-reduce (ops.h: k_peer_barrier / k_peer_allreduce_update): every rank owns an exchange buffer of two
+// slots (step parity) and a flag array; the other ranks map both through HIP IPC (hipIpcGetMemHandle / hipIpcOpenMemHandle:
+// between GPUs the mapping goes over xGMI; two rank processes on ONE device work the same way, which is how a one-GPU box
+// tests the protocol).  IPC mappings exist between processes of one host only, so the handles travel through a POSIX
+// shared-memory rendezvous named after the communicator's id (no RCCL involved: RCCL refuses two ranks on one device, and
+// the test needs exactly that); every rank publishes whether it could export and map, and the peer path is used only if ALL
+// ranks could -- otherwise all stay on ncclAllReduce.  Buffers up to PEER_MAX_FLOATS (4 MB): the 35 MB gradient of configs[4]
+// is bandwidth-bound and stays with RCCL.
+constexpr size_t PEER_MAX_FLOATS = 1u << 20;
+struct PeerExchange {
+  bool tried = false, ok = false;
+  size_t cap = 0;                       // floats per slot
+  float* xbuf = nullptr;                // own exchange buffer [2][cap]
+  int* flags = nullptr;                 // own flag array [2][PEER_MAX_RANKS]
+  float* px[PEER_MAX_RANKS] = {};       // every rank's buffer / flags as mapped here (own rank: the own pointers)
+  int* pf[PEER_MAX_RANKS] = {};
+  int seq = 0;                          // all-reduces so far (identical on every rank)
+  float* slot_ptr(int sq) const { return xbuf + (size_t)(sq & 1) * cap; }
+  PeerArgs args(int sq, int rank, int nranks) const {
+    PeerArgs a{};
+    a.nranks = nranks; a.rank = rank;
+    for (int r = 0; r < nranks; r++) { a.x[r] = px[r] + (size_t)(sq & 1) * cap; a.f[r] = pf[r] + (sq & 1) * PEER_MAX_RANKS; }
+    return a;
   }
-  ~Comm() { if (comm) (void)RcclApi::get().CommDestroy(comm); }
+};
+}  // namespace clstm
+#include <atomic>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+namespace clstm {
+struct Comm {
+  ncclComm_t comm = nullptr;            // null: a communicator WITHOUT RCCL (CLSTM_COMM_NO_RCCL=1, tests) -- peer path only
+  int rank = 0, nranks = 1;
+  char id[CLSTM_COMM_ID_BYTES] = {};
+  PeerExchange peer;
+  void allreduce(float* buf, long long n, hipStream_t s) {
+    if (comm) { RCCLCHECK(RcclApi::get().AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, comm, s)); return; }
+    if (nranks == 1) return;
+    // no RCCL: the peer path as a plain in-place all-reduce (copy into the exchange slot, barrier, rank-ordered sum)
+    REQUIRE(peer_ready((size_t)n, s), "communicator without RCCL: the ranks could not map each other's exchange buffers (HIP IPC)");
+    const int sq = ++peer.seq;
+    HIPCHECK(hipMemcpyAsync(peer.slot_ptr(sq), buf, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const PeerArgs pa = peer.args(sq, rank, nranks);
+    CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, dev_err_words());
+    CLSTM_LAUNCH(k_peer_allreduce_update, dim3(nblocks((size_t)(n + 3) / 4)), dim3(256), 0, s, pa, (float*)nullptr, (float*)nullptr, buf, (size_t)n, 0.0f, 0.0f, 0.0f,
+                 (const int*)nullptr, (int*)nullptr, 0, (int*)nullptr, 0);
+    check_launch();
+  }
+  // rendezvous of the ranks of this host: a shared segment named after the communicator id
+  struct Handles { hipIpcMemHandle_t x, f; int ok; int pad[3]; };
+  struct Rendezvous { std::atomic<int> magic, arrived, mapped, good; Handles h[PEER_MAX_RANKS]; };
+  static bool wait_for(std::atomic<int>& w, int target, double seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (w.load() < target) {
+      usleep(200);
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+    }
+    return true;
+  }
+  // collective (every rank calls it at the same point of its first one-call training step): true if the peer path is up
+  bool peer_ready(size_t n, hipStream_t s) {
+    PeerExchange& p = peer;
+    if (p.tried) return p.ok && n <= p.cap;
+    p.tried = true;
+    static const bool on = !(getenv("CLSTM_PEER_ALLREDUCE") && atoi(getenv("CLSTM_PEER_ALLREDUCE")) == 0);
+    if (!on || nranks < 2 || nranks > PEER_MAX_RANKS || n > PEER_MAX_FLOATS) return false;
+    HIPCHECK(hipStreamSynchronize(s));
+    Handles mine{};
+    mine.ok = 1;
+    p.cap = (PEER_MAX_FLOATS < ((n + 63) / 64 * 64) ? PEER_MAX_FLOATS : (n + 63) / 64 * 64);
+    if (hipMalloc((void**)&p.xbuf, 2 * p.cap * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); mine.ok = 0; p.xbuf = nullptr; }
+    if (hipExtMallocWithFlags((void**)&p.flags, 2 * PEER_MAX_RANKS * sizeof(int), hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hipMalloc((void**)&p.flags, 2 * PEER_MAX_RANKS * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); mine.ok = 0; p.flags = nullptr; }
+    }
+    if (mine.ok) {
+      HIPCHECK(hipMemset(p.xbuf, 0, 2 * p.cap * sizeof(float)));
+      HIPCHECK(hipMemset(p.flags, 0, 2 * PEER_MAX_RANKS * sizeof(int)));
+      HIPCHECK(hipDeviceSynchronize());
+      if (hipIpcGetMemHandle(&mine.x, p.xbuf) != hipSuccess || hipIpcGetMemHandle(&mine.f, p.flags) != hipSuccess) { (void)hipGetLastError(); mine.ok = 0; }
+    }
+    // the segment: whoever comes first creates it (ranks of another host never arrive here: time-out -> RCCL for everybody)
+    unsigned long long hsh = 1469598103934665603ull;
+    for (int i = 0; i < CLSTM_COMM_ID_BYTES; i++) hsh = (hsh ^ (unsigned char)id[i]) * 1099511628211ull;
+    char name[64];
+    snprintf(name, sizeof name, "/clstm_px_%016llx", hsh);
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    Rendezvous* rv = nullptr;
+    if (fd >= 0 && ftruncate(fd, sizeof(Rendezvous)) == 0) {
+      void* m = mmap(nullptr, sizeof(Rendezvous), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      if (m != MAP_FAILED) rv = (Rendezvous*)m;
+    }
+    if (fd >= 0) close(fd);
+    bool good = rv != nullptr;
+    if (rv) {
+      rv->h[rank] = mine;
+      rv->arrived.fetch_add(1);
+      good = wait_for(rv->arrived, nranks, 20.0);
+      for (int r = 0; good && r < nranks; r++) good = rv->h[r].ok != 0;
+      for (int r = 0; good && r < nranks; r++) {
+        if (r == rank) { p.px[r] = p.xbuf; p.pf[r] = p.flags; continue; }
+        void *x = nullptr, *f = nullptr;
+        if (hipIpcOpenMemHandle(&x, rv->h[r].x, hipIpcMemLazyEnablePeerAccess) != hipSuccess ||
+            hipIpcOpenMemHandle(&f, rv->h[r].f, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); good = false; }
+        p.px[r] = (float*)x; p.pf[r] = (int*)f;
+      }
+      // ... and they agree: the peer path only if EVERY rank mapped every other rank
+      if (good) rv->good.fetch_add(1);
+      rv->mapped.fetch_add(1);
+      const bool all_here = wait_for(rv->mapped, nranks, 20.0);
+      good = all_here && rv->good.load() == nranks;
+      if (rank == 0) shm_unlink(name);          // (every rank that will ever come has it open or has given up)
+      munmap(rv, sizeof(Rendezvous));
+    }
+    p.ok = good;
+    if (!p.ok) peer_release();
+    return p.ok && n <= p.cap;
+  }
+  void peer_release() {
+    PeerExchange& p = peer;
+    for (int r = 0; r < PEER_MAX_RANKS; r++) {
+      if (r != rank && p.px[r]) (void)hipIpcCloseMemHandle(p.px[r]);
+      if (r != rank && p.pf[r]) (void)hipIpcCloseMemHandle(p.pf[r]);
+      p.px[r] = nullptr; p.pf[r] = nullptr;
+    }
+    if (p.xbuf) (void)hipFree(p.xbuf);
+    if (p.flags) (void)hipFree(p.flags);
+    p.xbuf = nullptr; p.flags = nullptr; p.ok = false;
+  }
+  ~Comm() {
+    peer_release();
+    if (comm) (void)RcclApi::get().CommDestroy(comm);
+  }
 };
 #else
 }  // namespace clstm
@@ -645,10 +775,45 @@ namespace clstm {
 // SLOT floats per rank + a sense-reversing barrier) -- so that the world-size-2 CPU test drives the same entry points
 // and the same in-library order (all-reduce of g -> d += g -> update) as the RCCL build.  Every rank sums the slots in
 // rank order: bit-identical results on all ranks, like a deterministic all-reduce.
+constexpr size_t PEER_MAX_FLOATS = 1u << 18;
+struct PeerExchange {   // (host emulator: the "mapped" buffers and flags of the ranks are regions of the shared segment)
+  bool tried = false, ok = false;
+  size_t cap = 0;
+  float* xbuf = nullptr;
+  int* flags = nullptr;
+  float* px[PEER_MAX_RANKS] = {};
+  int* pf[PEER_MAX_RANKS] = {};
+  int seq = 0;
+  float* slot_ptr(int sq) const { return xbuf + (size_t)(sq & 1) * cap; }
+  PeerArgs args(int sq, int rank, int nranks) const {
+    PeerArgs a{};
+    a.nranks = nranks; a.rank = rank;
+    for (int r = 0; r < nranks; r++) { a.x[r] = px[r] + (size_t)(sq & 1) * cap; a.f[r] = pf[r] + (sq & 1) * PEER_MAX_RANKS; }
+    return a;
+  }
+};
 struct Comm {
   static const long long SLOT = 1 << 18;
   struct Shm { std::atomic<int> magic, arrived, gen; int pad; float slots[1]; };
   int rank = 0, nranks = 1;
+  PeerExchange peer;
+  // per rank behind the all-reduce slots: exchange buffer [2][SLOT] floats, then flags [2][PEER_MAX_RANKS] ints (zero pages)
+  static size_t peer_region_bytes() { return (size_t)2 * SLOT * sizeof(float) + 2 * PEER_MAX_RANKS * sizeof(int) + 64; }
+  bool peer_ready(size_t n, hipStream_t) {
+    PeerExchange& p = peer;
+    if (p.tried) return p.ok && n <= p.cap;
+    p.tried = true;
+    const bool on = !(getenv("CLSTM_PEER_ALLREDUCE") && atoi(getenv("CLSTM_PEER_ALLREDUCE")) == 0);
+    if (!on || nranks < 2 || nranks > PEER_MAX_RANKS || n > (size_t)SLOT || !shm) return false;
+    char* base = (char*)shm + sizeof(Shm) + (size_t)nranks * SLOT * sizeof(float);
+    for (int r = 0; r < nranks; r++) {
+      p.px[r] = (float*)(base + (size_t)r * peer_region_bytes());
+      p.pf[r] = (int*)(base + (size_t)r * peer_region_bytes() + (size_t)2 * SLOT * sizeof(float));
+    }
+    p.cap = SLOT; p.xbuf = p.px[rank]; p.flags = p.pf[rank];
+    p.ok = true;
+    return true;
+  }
   Shm* shm = nullptr;
   size_t bytes = 0;
   std::string name;
@@ -657,7 +822,7 @@ struct Comm {
     if (nranks == 1) return;
     name.assign(id, strnlen(id, CLSTM_COMM_ID_BYTES));
     REQUIRE(!name.empty() && name[0] == '/', "emulator communicator: bad id");
-    bytes = sizeof(Shm) + (size_t)nranks * SLOT * sizeof(float);
+    bytes = sizeof(Shm) + (size_t)nranks * SLOT * sizeof(float) + (size_t)nranks * peer_region_bytes();
     int fd = -1;
     if (rank == 0) {
       fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
@@ -1484,6 +1649,10 @@ struct Net {
     REQUIRE(N > 0, "set_batch first");
     const bool fuse = fuse_update;   // consumed here: an exception below must not leave it set for a later pass
     fuse_update = false;
+    const bool peer = peer_step && comm;
+    peer_step = false; peer_pending = false;
+    float* const g_local = g;
+    float* const gdst = peer ? comm->peer.slot_ptr(comm->peer.seq + 1) : g_local;   // where the reductions leave the fresh gradient
     nbackward++;
     RoctxRange range_("clstm:backward");
     update_applied = false;
@@ -1615,7 +1784,8 @@ struct Net {
           uf = UpdateFuse{v, d, lr, mom, gclip, (const int*)dev_err_words(), l == 0 ? update_step_word : nullptr, update_step_id, nanflag(), step_no()};
           if (l == 0) { update_step_word = nullptr; update_applied = true; }   // (the last reduction of the pass)
         }
-        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, g, (int*)nullptr, 0, uf);
+        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, gdst, (int*)nullptr, 0, uf);
+        if (peer && l == 0) peer_pending = true;
         timing.end(q);
         check_launch();
       };
@@ -1656,6 +1826,9 @@ struct Net {
   }
   int* update_step_word = nullptr;   // (host-fed steps) pinned word the update kernel writes update_step_id into
   int update_step_id = 0;
+  bool peer_step = false;     // the NEXT backward pass writes its gradient into the communicator's exchange slot and update() runs the
+                              //   peer-read all-reduce fused with the update (set by train_step when a communicator of > 1 ranks is attached)
+  bool peer_pending = false;  // ... this backward pass did so
   bool fuse_update = false;   // the NEXT backward pass applies the update inside its reductions (set by train_step)
   bool update_applied = false; // ... and has done so: update() has nothing left to launch
   void update() {
@@ -1666,7 +1839,25 @@ struct Net {
       packed_dirty = true;
       return;
     }
-    if (comm) {   // sum of the ranks' fresh minibatch gradients, in place, on this stream (share_deltas, clstm.cc:731-744)
+    if (peer_pending && comm) {   // one-shot peer-read all-reduce fused into the update (ops.h: k_peer_barrier / k_peer_allreduce_update)
+      peer_pending = false;
+      RoctxRange range2_("clstm:allreduce+update");
+      const int sq = ++comm->peer.seq;
+      const PeerArgs pa = comm->peer.args(sq, comm->rank, comm->nranks);
+      timing.begin("allreduce_grads", s);
+      CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, dev_err_words());
+      timing.end(s);
+      timing.begin("sgd_update", s);
+      CLSTM_LAUNCH(k_peer_allreduce_update, dim3(nblocks((size_t)(nparams + 3) / 4)), dim3(256), 0, s, pa, v, d, g, (size_t)nparams, lr, mom, gclip,
+                   (const int*)dev_err_words(), update_step_word, update_step_id, nanflag(), step_no());
+      update_step_word = nullptr;
+      timing.end(s);
+      check_launch();
+      g_path_count[7]++;
+      packed_dirty = true;
+      return;
+    }
+    if (comm && comm->nranks > 1) {   // sum of the ranks' fresh minibatch gradients, in place, on this stream (share_deltas, clstm.cc:731-744)
       RoctxRange range2_("clstm:allreduce");
       timing.begin("allreduce_grads", s);
       comm->allreduce(g, nparams, s);
@@ -2078,7 +2269,7 @@ int clstm_net_ctc(clstm_net* h, const int* labels_h, const int* L_h, float* alig
   net_ctc(h, labels_h, L_h, aligned_h);
   ABI_END
 }
-int clstm_net_backward(clstm_net* h) { ABI_BEGIN h->net.fuse_update = false; h->net.backward(); ABI_END }
+int clstm_net_backward(clstm_net* h) { ABI_BEGIN h->net.fuse_update = false; h->net.peer_step = false; h->net.backward(); ABI_END }
 int clstm_net_enable_input_deltas(clstm_net* h, int on) { h->net.want_dx0 = on != 0; return 0; }
 int clstm_net_get_input_deltas_h(clstm_net* h, float* dx) {
   ABI_BEGIN
@@ -2150,7 +2341,11 @@ int clstm_net_train_step(clstm_net* h, const int* T_h, int bs, const float* x_d,
   net_set_inputs_d(h, x_d, &meta);
   h->net.forward();
   net_ctc_launch(h);
-  h->net.fuse_update = !h->net.comm;   // no exchange in between: the reductions of the backward pass apply the update themselves
+  // no exchange in between (no communicator, or one of a single rank): the reductions of the backward pass apply the update
+  // themselves; a communicator of several ranks: the peer-read all-reduce fused into the update where the ranks could map each
+  // other (else ncclAllReduce + k_update)
+  h->net.fuse_update = !h->net.comm || h->net.comm->nranks == 1;
+  h->net.peer_step = h->net.comm && h->net.comm->nranks > 1 && h->net.comm->peer_ready((size_t)h->net.nparams, g_stream);
   h->net.backward();
   h->net.update();   // all-reduces the fresh gradient first when a communicator is attached
   ABI_END
@@ -2220,7 +2415,8 @@ int clstm_net_train_step_h(clstm_net* h, const int* T_h, int bs, const float* x_
   n.forward();
   net_ctc_launch(h);
   n.update_step_word = f.step_done; n.update_step_id = (int)(unsigned)k;
-  n.fuse_update = !n.comm;
+  n.fuse_update = !n.comm || n.comm->nranks == 1;
+  n.peer_step = n.comm && n.comm->nranks > 1 && n.comm->peer_ready((size_t)n.nparams, g_stream);
   try {
     n.backward();
     n.update();
@@ -2398,6 +2594,12 @@ int clstm_comm_unique_id(char* id_h) {
   ABI_BEGIN
   REQUIRE(id_h, "null argument");
 #ifndef CLSTM_HIP_EMU
+  if (getenv("CLSTM_COMM_NO_RCCL") && atoi(getenv("CLSTM_COMM_NO_RCCL")) != 0) {   // (tests: ranks that share one device)
+    FILE* f = fopen("/dev/urandom", "rb");
+    REQUIRE(f && fread(id_h, 1, CLSTM_COMM_ID_BYTES, f) == (size_t)CLSTM_COMM_ID_BYTES, "cannot read /dev/urandom");
+    fclose(f);
+    return 0;
+  }
   ncclUniqueId id;
   static_assert(sizeof(id) == CLSTM_COMM_ID_BYTES, "ncclUniqueId size");
   RCCLCHECK(RcclApi::get().GetUniqueId(&id));
@@ -2416,9 +2618,14 @@ int clstm_comm_create(clstm_comm** out, const char* id_h, int rank, int nranks) 
   c->c.rank = rank; c->c.nranks = nranks;
 #ifndef CLSTM_HIP_EMU
   try {
-    ncclUniqueId id;
-    memcpy(&id, id_h, sizeof(id));
-    RCCLCHECK(RcclApi::get().CommInitRank(&c->c.comm, nranks, id, rank));
+    memcpy(c->c.id, id_h, CLSTM_COMM_ID_BYTES);
+    // CLSTM_COMM_NO_RCCL=1 (tests): no RCCL communicator -- the exchange is the peer-read path alone, which also works
+    // between rank processes that share ONE device (RCCL refuses that: "duplicate GPU")
+    if (!(getenv("CLSTM_COMM_NO_RCCL") && atoi(getenv("CLSTM_COMM_NO_RCCL")) != 0)) {
+      ncclUniqueId id;
+      memcpy(&id, id_h, sizeof(id));
+      RCCLCHECK(RcclApi::get().CommInitRank(&c->c.comm, nranks, id, rank));
+    }
   } catch (...) { delete c; throw; }
 #else
   try { c->c.open(id_h, rank, nranks); } catch (...) { delete c; throw; }
@@ -2429,6 +2636,7 @@ int clstm_comm_create(clstm_comm** out, const char* id_h, int rank, int nranks) 
 int clstm_comm_destroy(clstm_comm* c) { ABI_BEGIN delete c; ABI_END }
 int clstm_comm_rank(clstm_comm* c) { return c ? c->c.rank : 0; }
 int clstm_comm_size(clstm_comm* c) { return c ? c->c.nranks : 1; }
+int clstm_comm_peer_active(clstm_comm* c) { return c && c->c.peer.ok ? 1 : 0; }
 int clstm_allreduce_flat(clstm_comm* c, float* buf_d, long long n) {
   ABI_BEGIN
   REQUIRE(c && buf_d && n >= 0, "bad all-reduce arguments");

@@ -230,6 +230,62 @@ __global__ void k_update(float* v, float* d, const float* g, size_t len, float l
   }
 }
 
+// ---- one-shot peer-read all-reduce fused into the update (clstm_hip.hip: PeerExchange) --------------------
+// Every rank's fresh minibatch gradient lies in an exchange buffer of its own that the other ranks have mapped (HIP IPC;
+// over xGMI between GPUs).  k_peer_barrier: one workgroup; lane r stores this step's sequence number into rank r's flag
+// array (my slot of it) and lane r waits until rank r's number has arrived in mine -- after that every rank's buffer of
+// this step is complete (the stores of the producing kernels were released at their kernel boundaries) and nobody still
+// reads the buffers of two steps ago (the slot this step's reductions wrote).  k_peer_allreduce_update: thread i sums
+// element i of all ranks' buffers IN RANK ORDER (every rank forms the same sum: replicas stay bit-identical, like a
+// deterministic all-reduce), leaves it in g and applies k_update's arithmetic -- the 0.54 MB ncclAllReduce (tens of us of
+// exposed latency between the last reduction and the update) and the separate update launch become one barrier of one
+// workgroup plus one pass.  System-scope (sc0 sc1) loads on the reader side: a rank's L2 must not serve the same slot's
+// lines of two steps ago.
+constexpr int PEER_MAX_RANKS = 16;
+struct PeerArgs {
+  const float* x[PEER_MAX_RANKS];   // the ranks' exchange buffers (this step's slot), own rank included
+  int* f[PEER_MAX_RANKS];           // the ranks' flag arrays (this step's slot): f[r][q] = last sequence number rank q announced to r
+  int nranks, rank;
+};
+__global__ void k_peer_barrier(PeerArgs p, int seq, int* err) {
+  const int r = threadIdx.x;
+  if (blockIdx.x != 0 || r >= p.nranks) return;
+  store_i32_wt(p.f[r] + p.rank, seq);
+  int spins = 0;
+  while (load_i32_wt(p.f[p.rank] + r) != seq) {
+    poll_pause();
+    if (++spins > (1 << 24)) { atomic_add_i32(err, 1); break; }   // never hang the device: the update is skipped (dev_err_set)
+  }
+}
+__global__ void k_peer_allreduce_update(PeerArgs p, float* v, float* d, float* g, size_t len, float lr, float mom, float clip, const int* err,
+                                        int* step_word, int step_id, int* nanflag, int step_no) {
+  if (step_word && blockIdx.x == 0 && threadIdx.x == 0) store_i32_wt(step_word, step_id);
+  const bool apply = v != nullptr && !dev_err_set(err);   // (v null: a plain in-place all-reduce into g)
+  BufF32 xb[PEER_MAX_RANKS];
+  for (int r = 0; r < p.nranks; r++) xb[r] = make_buf(p.x[r], len * 4);
+  const size_t n4 = (len + 3) / 4;
+  CLSTM_GRID_STRIDE(q, n4) {
+    f32x4 acc = buf_load4_wt(xb[0], (unsigned)(q * 16));          // (past the end: zeros, the descriptor ends at len)
+    for (int r = 1; r < p.nranks; r++) {
+      const f32x4 t = buf_load4_wt(xb[r], (unsigned)(q * 16));
+      acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const size_t i = q * 4 + e;
+      if (i >= len) break;
+      const float gi = acc[e];
+      g[i] = gi;
+      if (!apply) continue;
+      if (nanflag && !f32_finite(gi)) { raise_nonfinite(nanflag, step_no); continue; }
+      float di = d[i] + gi;
+      if (clip < 1e6f) di = fmaxf(-clip, fminf(clip, di));
+      v[i] += di * lr;
+      d[i] = di * mom;
+    }
+  }
+}
+
 // outcome of a persistent recurrence launch: its error word goes into the sticky device word k_update looks at and into
 // the host's pinned slot (checked when the slot comes round again or at the next read-back)
 __global__ void k_xcd_outcome(const int* err, int* sticky, int* host_slot) {

@@ -262,6 +262,10 @@ int clstm_comm_create(clstm_comm** out, const char* id_h, int rank, int nranks);
 int clstm_comm_destroy(clstm_comm* comm);
 int clstm_comm_rank(clstm_comm* comm);
 int clstm_comm_size(clstm_comm* comm);
+/* 1 once the ranks have mapped each other's exchange buffers (HIP IPC; decided collectively at the first clstm_net_train_step with
+ * the communicator attached): clstm_net_train_step then runs the one-shot peer-read all-reduce fused into the update kernel
+ * (gradient buffers up to 4 MB; environment CLSTM_PEER_ALLREDUCE=0: always ncclAllReduce + update).  0: ncclAllReduce. */
+int clstm_comm_peer_active(clstm_comm* comm);
 /* in-place sum over ranks of buf_d[0..n) (DEVICE, f32), enqueued on the library stream: no cross-stream
  * event, no host synchronisation. */
 int clstm_allreduce_flat(clstm_comm* comm, float* buf_d, long long n);
