@@ -157,7 +157,7 @@ struct StoreBias {  // out[r*ld + c] = val + bias[c]
     *reinterpret_cast<f32x4*>(out + (long long)r * ld + c) = o;
   }
 };
-static long long g_path_count[8];   // clstm_debug_path_count (diagnostics)
+static long long g_path_count[16];   // clstm_debug_path_count (diagnostics)
 struct StorePlain {
   float* out; long long ld;
   DEVMFN void operator()(int r, int c, float v, int) const { out[(long long)r * ld + c] = v; }
@@ -335,53 +335,65 @@ static int* dev_err_words() {
 }
 static bool g_xcd_failed = false;   // a persistent launch failed its placement check: wide layers use the per-step launches from now on
 struct XcdOutcome {
+  // The persistent kernels publish their own outcome (lstm_wide.h:xcd_finish): the last workgroup to leave stores the launch's
+  // error word into a pinned host word and -- if non-zero -- into the sticky device word the update kernels look at.  The host
+  // marks the slot pending (-1) before the launch; a slot is looked at when the ring comes round to it again (16 launches
+  // later: long finished) or at a synchronisation point.  No event record, no extra kernel on the stream.
   static const int SLOTS = 16;
-  int* pinned = nullptr;
-  hipEvent_t ev[SLOTS] = {};
+  volatile int* pinned = nullptr;
   bool pending[SLOTS] = {};
   int next = 0, verified = 0;
   void check_slot(int i) {
     if (!pending[i]) return;
-    HIPCHECK(hipEventSynchronize(ev[i]));
+    if (pinned[i] == -1) {   // (only when the ring wraps within one un-synchronised burst: wait for that launch)
+      const auto t0 = std::chrono::steady_clock::now();
+      while (pinned[i] == -1 && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20)) sched_yield();
+      if (pinned[i] == -1) { HIPCHECK(hipDeviceSynchronize()); }
+    }
     pending[i] = false;
-    if (pinned[i] != 0 && g_dev_err) (void)hipMemset(g_dev_err, 0, sizeof(int));   // reported once: updates resume
-    if (pinned[i] == 1) g_xcd_failed = true;   // not all workgroups were resident (another tenant on the device): per-step launches from now on
-    if (pinned[i] != 0)
-      throw Error(pinned[i] == 1 ? "persistent recurrence: the workgroups of a later launch were not all resident / not spread evenly over the XCDs (another process or stream on the device?); "
-                                   "the minibatches enqueued since then were NOT applied -- every later update was skipped; in a multi-layer net the layers above the failing one may "
-                                   "have taken their update of that one minibatch -- and the library has switched to the per-step launches (CLSTM_XCD_REC=0) for the rest of the process"
-                                 : "persistent recurrence: a group barrier timed out in the middle of the sequence; the minibatches enqueued since then were NOT applied (layers above the "
-                                   "failing one may have taken their update of that one minibatch) -- set CLSTM_XCD_REC=0");
+    const int e = pinned[i];
+    if (e > 0 && g_dev_err) (void)hipMemset(g_dev_err, 0, sizeof(int));   // reported once: updates resume
+    if (e == 1) g_xcd_failed = true;   // not all workgroups were resident (another tenant on the device): per-step launches from now on
+    if (e > 0)
+      throw Error(e == 1 ? "persistent recurrence: the workgroups of a later launch were not all resident / not spread evenly over the XCDs (another process or stream on the device?); "
+                           "the minibatches enqueued since then were NOT applied -- every later update was skipped; in a multi-layer net the layers above the failing one may "
+                           "have taken their update of that one minibatch -- and the library has switched to the per-step launches (CLSTM_XCD_REC=0) for the rest of the process"
+                         : "persistent recurrence: a group barrier timed out in the middle of the sequence; the minibatches enqueued since then were NOT applied (layers above the "
+                           "failing one may have taken their update of that one minibatch) -- set CLSTM_XCD_REC=0");
   }
   void check_all() { for (int i = 0; i < SLOTS; i++) check_slot(i); }
-  // returns false if the launch failed its placement check and nothing was written (synchronous phase only)
-  bool after_launch(const int* err_d, hipStream_t s) {
+  // before a launch: the pinned word the kernel reports to (null while launches are still verified synchronously / on the emulator)
+  int* prepare() {
 #ifdef CLSTM_HIP_EMU
-    if (*err_d == 2) throw Error("persistent recurrence: group barrier timed out");
-    return *err_d == 0;
+    return nullptr;
 #else
-    if (verified < 4) {
-      int w[32] = {0};   // sync words 0..31: [1] = error word, [2..7] = diagnostics of a timed-out wait (lstm_wide.h)
-      HIPCHECK(hipMemcpyAsync(w, err_d - 1, sizeof(w), hipMemcpyDeviceToHost, s));
-      HIPCHECK(hipStreamSynchronize(s));
-      const int flag = w[1];
-      if (flag == 0) { verified++; return true; }
-      if (flag != 1) {
-        char msg[640];
-        snprintf(msg, sizeof msg, "persistent recurrence: a group barrier timed out in the middle of the sequence; set CLSTM_XCD_REC=0 "
-                 "[step %d, saw tag 0x%x, waited for 0x%x, wave/lane 0x%x, xcd/tile 0x%x]", w[2], w[3], w[4], w[5], w[6]);
-        throw Error(msg);
-      }
-      return false;
-    }
-    if (!pinned) HIPCHECK(hipHostMalloc((void**)&pinned, SLOTS * sizeof(int)));
+    if (verified < 4) return nullptr;
+    if (!pinned) { int* p = nullptr; HIPCHECK(hipHostMalloc((void**)&p, SLOTS * sizeof(int))); pinned = p; }
     const int i = next;
     next = (next + 1) % SLOTS;
     check_slot(i);
-    if (!ev[i]) HIPCHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
-    CLSTM_LAUNCH(k_xcd_outcome, dim3(1), dim3(64), 0, s, err_d, dev_err_words(), pinned + i);
-    HIPCHECK(hipEventRecord(ev[i], s));
+    pinned[i] = -1;
     pending[i] = true;
+    return (int*)(pinned + i);
+#endif
+  }
+  // after it; returns false if the launch failed its placement check and nothing was written (synchronous phase only).
+  // last_err_d: the launch's surviving outcome word (XcdSyncLayout::LAST_ERROR)
+  bool after_launch(const int* last_err_d, hipStream_t s) {
+#ifdef CLSTM_HIP_EMU
+    if (*last_err_d != 0 && g_dev_err) g_dev_err[0] = 0;   // handled right here (emulator: device memory is host memory)
+    if (*last_err_d == 2) throw Error("persistent recurrence: group barrier timed out");
+    return *last_err_d == 0;
+#else
+    if (verified < 4) {
+      int flag = 0;
+      HIPCHECK(hipMemcpyAsync(&flag, last_err_d, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      if (flag == 0) { verified++; return true; }
+      if (g_dev_err) (void)hipMemset(g_dev_err, 0, sizeof(int));   // handled right here: nothing was written, the per-step path redoes the pass
+      if (flag != 1) throw Error("persistent recurrence: a group barrier timed out in the middle of the sequence; set CLSTM_XCD_REC=0");
+      return false;
+    }
     return true;
 #endif
   }
@@ -437,7 +449,9 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
       a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
       a.debug_fail_claim = g_debug_fail_claims > 0 ? (g_debug_fail_claims--, 1) : 0;
-      HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+      // (the sync words are zero: DevBuf zero-fills, and every persistent launch returns them to zero as its last act)
+      a.out_sticky = dev_err_words();
+      a.out_host = g_xcd_outcome.prepare();
       coop_set_smem(kernel, smem);
       // An ORDINARY launch: one workgroup per CU (LDS), at most as many workgroups as CUs, the stream's previous kernel complete --
       // they are all resident, and if they ever were not, the placement check of xcd_claim times out with error 1 before anything
@@ -451,7 +465,7 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       CLSTM_LAUNCH(kernel, dim3(8 * ntile), dim3(WIDE_THREADS), smem, s, a);
 #endif
       check_launch();
-      ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::ERROR, s);
+      ok = g_xcd_outcome.after_launch(sync.p + XcdSyncLayout::LAST_ERROR, s);
       REQUIRE(ok || zb0 == 0, "persistent recurrence: placement failed after the first chunk had run; set CLSTM_XCD_REC=0");
     }
     if (ok) g_wide_persistent = true; else g_xcd_failed = true;
@@ -887,6 +901,8 @@ struct Layer {
   bool fwd_persistent = false; // this forward pass ran the persistent kernel (Hbf is valid)
   DevBuf<unsigned short> Sbf;  // bf16 source rows [x | h_{t-1} | 1] per direction (x: k_source_x_bf16, h: the persistent forward kernel)
   bool sbf_ready = false;      // ... complete for this forward pass
+  bool sbf_x_external = false; // ... except their x columns: the weight-gradient GEMM reads those from the layer below's Hbf (gemm_b16mc A2)
+  long long sbf_one_key = -1;  // batch geometry (N) the constant bias column of Sbf was written for
   bool d_f32_valid = true;     // D (f32 gate deltas) is current (a persistent bf16 backward pass may leave only Dbf)
   bool sx_valid = true;        // the [1 | x] columns of S (f32) are current (built lazily when the bf16 rows serve the weight gradient)
   bool h_f32_valid = true;     // the f32 outputs H are current (a persistent bf16 forward pass of a lower layer leaves only Hbf)
@@ -1107,6 +1123,16 @@ struct Net {
     for (auto& y : L) {
       const int M = ndir * 4 * y.no, KQP = 4 * y.nk4;
       const size_t nr = y.wide ? 0 : (size_t)ndir * 4 * KQP * y.nthreads;
+      if (y.wide && bf16_rec && y.no % 128 == 0 && y.ni % 32 == 0 && wide_kp16_fwd(y.no) == y.no && wide_kp16_bwd(y.no) == 4 * y.no &&
+          !(getenv("CLSTM_PACK_TILES") && atoi(getenv("CLSTM_PACK_TILES")) == 0)) {
+        // every bf16-mode copy of the layer in one tiled pass (ops.h:k_pack_wide_tiles)
+        const int rf = (y.no + 3) / 4 * 16, kf = wide_kp16_fwd(y.no), rb = (y.no + 15) / 16 * 16, kb = wide_kp16_bwd(y.no);
+        y.Wtb.reserve((size_t)y.ni * M + 64);
+        y.WtbT.reserve((size_t)y.ni * M + 64);
+        const unsigned nblk = (unsigned)ndir * (unsigned)((y.ni + y.no) / 32) * (unsigned)(y.no / 32);
+        CLSTM_LAUNCH(k_pack_wide_tiles, dim3(nblk), dim3(256), 0, s, (const float*)v, y.pd, y.Wt, y.bias, y.Wtb.p, y.WtbT.p, y.Rbf, y.Rbb, kf, kb, rf, rb);
+        continue;
+      }
       if (y.wide && bf16_rec) {
         const int rf = (y.no + 3) / 4 * 16, kf = wide_kp16_fwd(y.no), rb = (y.no + 15) / 16 * 16, kb = wide_kp16_bwd(y.no);
         CLSTM_LAUNCH(k_pack_wide_bf16, dim3(nblocks((size_t)ndir * ((size_t)rf * kf + (size_t)rb * kb))), dim3(256), 0, s,
@@ -1206,7 +1232,7 @@ struct Net {
       static const bool b16mc_on = !(getenv("CLSTM_GEMM_B16MC") && atoi(getenv("CLSTM_GEMM_B16MC")) == 0);
       if (fwd && b16mc_on && bf16_gemm && (y.ni & 7) == 0 && (y.no & 7) == 0 && wide_kp16_bwd(y.no) == 4 * y.no) {
         const int ldsb = y.ni + y.no + 8;
-        y.Sbf.reserve((size_t)N * ndir * ldsb + 64);
+        { const size_t cap0 = y.Sbf.cap; y.Sbf.reserve((size_t)N * ndir * ldsb + 64); if (y.Sbf.cap != cap0) y.sbf_one_key = -1; }
         w.Sbf = y.Sbf.p; w.sbf_ld = ldsb; w.sbf_ofs = y.ni; w.sbf_dir = (long long)N * ldsb;
       }
       if (fwd && (y.no & 1) == 0 && &y != &L.back()) { y.Hbf.reserve((size_t)N * ndir * y.no + 64); w.Hbf = y.Hbf.p; w.hbf_ld = ndir * y.no; }
@@ -1289,8 +1315,19 @@ struct Net {
         if (y.sbf_ready) {   // the non-recurrent columns of the bf16 source rows (the recurrence stored the h columns)
           const bool from16 = l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.ni == ndir * L[l - 1].no;
           if (l > 0 && !from16) ensure_h_f32(l - 1);
-          CLSTM_LAUNCH(k_source_x_bf16, dim3(nblocks((size_t)N * ((y.ni >> 3) + 1))), dim3(256), 0, s, y.Sbf.p, from16 ? nullptr : layer_input(l),
-                       from16 ? L[l - 1].Hbf.p : nullptr, from16 ? y.ni : layer_input_ld(l), (size_t)N, y.ni, y.ni + y.no, w.sbf_ld, ndir, w.sbf_dir);
+          // x columns that fill whole tiles of the weight-gradient GEMM are not copied: the GEMM reads them from Hbf itself
+          const int R_ = 1 + y.ni + y.no, Cn_ = 4 * y.no;
+          y.sbf_x_external = from16 && y.ni % (gemm_tile256(R_, Cn_) ? 256 : GB2_BT) == 0;
+          if (y.sbf_x_external) {
+            if (y.sbf_one_key != (long long)N) {
+              CLSTM_LAUNCH(k_source_one_bf16, dim3(nblocks((size_t)N)), dim3(256), 0, s, y.Sbf.p, (size_t)N, y.ni + y.no, w.sbf_ld, ndir, w.sbf_dir);
+              y.sbf_one_key = (long long)N;
+            }
+          } else {
+            y.sbf_one_key = -1;
+            CLSTM_LAUNCH(k_source_x_bf16, dim3(nblocks((size_t)N * ((y.ni >> 3) + 1))), dim3(256), 0, s, y.Sbf.p, from16 ? nullptr : layer_input(l),
+                         from16 ? L[l - 1].Hbf.p : nullptr, from16 ? y.ni : layer_input_ld(l), (size_t)N, y.ni, y.ni + y.no, w.sbf_ld, ndir, w.sbf_dir);
+          }
         }
         return true;
       };
@@ -1761,7 +1798,10 @@ struct Net {
             const int ldsb = y.ni + y.no + 8;
             g_path_count[4]++;
             gemm_b16mc(q, GemmOperand16B{y.Sbf.p, ldsb, (long long)N * ndir * ldsb, (long long)N * ldsb},
-                       GemmOperand16B{y.Dbf.p, M, (long long)N * M, 4LL * y.no}, StorePartialRot{pbuf.p, R, Cn}, R, Cn, (int)N, ns, ndir);
+                       GemmOperand16B{y.Dbf.p, M, (long long)N * M, 4LL * y.no}, StorePartialRot{pbuf.p, R, Cn}, R, Cn, (int)N, ns, ndir,
+                       y.sbf_x_external ? GemmOperand16B{L[l - 1].Hbf.p, y.ni, (long long)N * y.ni, 0} : GemmOperand16B{nullptr, 0, 0, 0},
+                       y.sbf_x_external ? y.ni : 0);
+            if (y.sbf_x_external) g_path_count[8]++;
           } else if (bf16_gemm)
             gemm_bf16<GEMM_MC, GEMM_MC>(q, gemm_batched(gemm_mc(y.S.p, y.lds, N), (long long)N * y.lds, ndir),
                                         gemm_batched(gemm_mc(y.D.p, M, N, 0), 4LL * y.no, 1),
@@ -2194,20 +2234,23 @@ static void net_set_inputs_d(clstm_net* h, const float* x, const CtcMetaCopy* au
   RoctxRange range_("clstm:ingest");
   Layer& y = n.L[0];
   bool aux_done = false;
-  if (n.packed_dirty && n.L.size() == 1 && !y.wide) {   // the training step: ingest + weight repack in one launch
+  const bool with_pack = n.packed_dirty && n.L.size() == 1 && !y.wide;   // the training step of a narrow net: ingest + weight repack in one launch
+  if (with_pack || n.lo_pending || (aux && aux->nwords > 0)) {
+    // (any net: the small host arrays of the step ride the ingest launch -- a separate copy of the CTC metadata cost a
+    // configs[4] step ~25 us of DMA set-up in front of its first kernel)
     const int M = n.ndir * 4 * y.no, KQP = 4 * y.nk4;
     const size_t nr = (size_t)n.ndir * 4 * KQP * y.nthreads;
-    const int nbi = nblocks((size_t)n.N * (1 + y.ni)), nbp = nblocks((size_t)(1 + y.ni) * M + 2 * nr);
+    const int nbi = nblocks((size_t)n.N * (1 + y.ni)), nbp = with_pack ? nblocks((size_t)(1 + y.ni) * M + 2 * nr) : 0;
     const bool lo = n.lo_pending, ax = aux && aux->nwords > 0;
     // optional trailing blocks read small host arrays straight from their pinned slots: the line offsets and -- in a
     // training step -- the CTC metadata (no DMA launches, no event records on the stream's critical path)
     CLSTM_LAUNCH(k_ingest_pack, dim3(nbi + nbp + (lo ? 1 : 0) + (ax ? (aux->nwords + 255) / 256 : 0)), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni, y.lds,
                  n.ndir, (long long)n.N * y.lds, nbi, nbp, (const float*)n.v, y.Wt, y.bias, y.Rf, y.Rb, y.pd, n.pack_fused_desc(y),
                  lo ? n.lo_stage : nullptr, n.line_off.p, 2 * n.bs + 1, ax ? aux->src : nullptr, ax ? aux->dst : nullptr, ax ? aux->nwords : 0,
-                 (const int*)n.pack_table(y));
+                 with_pack ? (const int*)n.pack_table(y) : (const int*)nullptr);
     if (lo) { n.ring.commit(g_stream); n.lo_pending = false; }
     if (ax) { h->ctc.ring.commit(g_stream); aux_done = true; }
-    n.packed_dirty = false;
+    if (with_pack) n.packed_dirty = false;
   } else {
     CLSTM_LAUNCH(k_ingest, dim3(nblocks((size_t)n.N * (1 + y.ni))), dim3(256), 0, g_stream, x, n.X.p, y.S.p, (size_t)n.N, y.ni,
                  y.lds, n.ndir, (long long)n.N * y.lds);
@@ -2706,7 +2749,7 @@ int clstm_debug_set_device_error(int which, int value) {   // tests: what a fail
 }
 int clstm_debug_path_count(int which, long long* out_h) {
   ABI_BEGIN
-  REQUIRE(which >= 0 && which < 8 && out_h, "bad path index");
+  REQUIRE(which >= 0 && which < 16 && out_h, "bad path index");
   *out_h = g_path_count[which];
   ABI_END
 }

@@ -622,8 +622,11 @@ constexpr int GT_PF = 3;   // blocks in flight in registers (NB = 1; two with NB
 // waves 2 x 4, 128 x 64 each: half the LDS and vector-cache bytes per MFMA; one workgroup per CU).
 // NB = 32-row sub-blocks per barrier (contraction rows per LDS buffer = 32 NB).
 template <class FE, int WI, int NB>
+// A2 / a2_rows (optional): output rows r < a2_rows (a multiple of the tile height) take their A columns from a SECOND array
+// shared by all batches -- the weight gradient's x-part rows straight from the bf16 outputs of the layer below instead of a
+// copy of them inside the source rows (k_source_x_bf16: 30 us + 105 MB of traffic per configs[4] step for layer 2).
 __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K,
-                                                               int ksplit, int nsplit) {
+                                                               int ksplit, int nsplit, GemmOperand16B A2, int a2_rows) {
   constexpr int NWN = WI / 2, BT = 32 * WI, NSTRIP = 2 * WI, STRIP = NB * 512 + 16, TILE = NSTRIP * STRIP, CHUNKS = BT / 8;
   constexpr int BKB = 32 * NB, NL = 2 * NB, PF = NB == 1 ? GT_PF : 2;
   __shared__ __attribute__((aligned(16))) unsigned short As[2 * TILE];
@@ -648,12 +651,16 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
   const int kbeg = (z - batch * nsplit) * ksplit;
   const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
   const int s_c = tid % CHUNKS, s_k = tid / CHUNKS;   // 16-byte chunk of the row; contraction rows s_k + 16 h of the block
-  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(A.p + batch * A.bstride), (size_t)(A.elems - batch * A.bstride) * 2);
+  const bool use2 = wave_uniform(A2.p != nullptr && r0 < a2_rows ? 1 : 0) != 0;   // (a whole tile: a2_rows is a multiple of BT)
+  const unsigned short* const ap = use2 ? A2.p : A.p + batch * A.bstride;
+  const long long ael = use2 ? A2.elems : A.elems - batch * A.bstride;
+  const unsigned ald = (unsigned)(use2 ? A2.ld : A.ld);
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(ap), (size_t)ael * 2);
   const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(B.p + batch * B.bstride), (size_t)(B.elems - batch * B.bstride) * 2);
   // columns past R / Cn read whatever follows in the row (or the next row): they only reach outputs that are not stored
-  const unsigned aoff = ((unsigned)s_k * (unsigned)A.ld + (unsigned)(r0 + s_c * 8)) * 2u, a16 = 32u * (unsigned)A.ld;
+  const unsigned aoff = ((unsigned)s_k * ald + (unsigned)(r0 + s_c * 8)) * 2u, a16 = 32u * ald;
   const unsigned boff = ((unsigned)s_k * (unsigned)B.ld + (unsigned)(c0 + s_c * 8)) * 2u, b16 = 32u * (unsigned)B.ld;
-  const unsigned a_kstep = 2u * (unsigned)A.ld, b_kstep = 2u * (unsigned)B.ld;
+  const unsigned a_kstep = 2u * ald, b_kstep = 2u * (unsigned)B.ld;
   f32x4 ra[PF][NL], rb[PF][NL];
   // contraction rows past the slab load zeros: their offset is pushed out of the descriptor's range (one select per
   // load instead of one per staged element; nothing to mask when the block is staged)
@@ -742,7 +749,8 @@ inline bool gemm_tile256(int R, int Cn) {
   return 4 * w256 <= 5 * w128;
 }
 template <class FE>
-inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1) {
+inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1,
+                       GemmOperand16B A2 = GemmOperand16B{nullptr, 0, 0, 0}, int a2_rows = 0) {
   if (R <= 0 || Cn <= 0 || K <= 0) return;
   if (nsplit < 1) nsplit = 1;
   // (64 contraction rows per barrier on the 256 x 256 tile -- 231 VGPRs, 130 KB LDS -- measured equal to the 32-row
@@ -753,11 +761,13 @@ inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, F
   ksplit = ((ksplit + kq - 1) / kq) * kq;
   if (big) {
     dim3 grid((Cn + 255) / 256, (R + 255) / 256, nsplit * nbatch);
-    CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 1>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+    if (a2_rows % 256 != 0) A2.p = nullptr;
+    CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 1>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
     return;
   }
   dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);
-  CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 4, 1>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+  if (a2_rows % GB2_BT != 0) A2.p = nullptr;
+  CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 4, 1>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
 }
 
 // ---- f32-grade products on the bf16 MFMA: 64 x 64 tile, operands split hi + lo ------------------------------------------

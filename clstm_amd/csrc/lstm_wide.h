@@ -68,6 +68,8 @@ struct LstmWideArgs {
   const unsigned short* Wxb;
   const float* bias;
   int debug_fail_claim;         // tests: the placement check of the persistent kernels reports failure (clstm_debug_set_device_error 4)
+  int* out_sticky;              // persistent kernels: the process's sticky device error word (takes a non-zero outcome), or null
+  int* out_host;                // ... and a pinned host word that takes the outcome (0 = fine) when the launch has ended, or null
   long long* prof;              // diagnostics build (CLSTM_LSTM_PROF) only: per-phase cycle sums, [2 workgroups][4 waves][12]; else null
 };
 
@@ -626,7 +628,11 @@ inline __host__ __device__ size_t ring32_floats(int nd, int bs, int kp) { return
 #define XCD_STAMP(k) do {} while (0)
 #define XCD_PROF_WRITE(xcd, slot, ntile) do {} while (0)
 #endif
-struct XcdSyncLayout { enum { ARRIVED = 0, ERROR = 1, SLOT0 = 8, GROUP0 = 32, GROUP_STRIDE = 32, WORDS = 32 + 8 * 32 }; };
+// EXITED: workgroups that have left the kernel; the last one publishes the launch's outcome (LAST_ERROR -- the only word that
+// survives --, the process's sticky error word, a pinned host word) and returns every other word to zero for the next launch:
+// no memset, no outcome kernel and no event record around a pass (they cost ~15 us of stream time per pass, four passes per
+// configs[4] step).
+struct XcdSyncLayout { enum { ARRIVED = 0, ERROR = 1, SLOT0 = 8, EXITED = 16, LAST_ERROR = 17, GROUP0 = 32, GROUP_STRIDE = 32, WORDS = 32 + 8 * 32 }; };
 constexpr int XCD_LDW = 512 + 8;        // halfs per resident weight row (conflict-free ds_read_b128 fragments), kp16 <= 512
 inline __host__ __device__ int xcd_fwd_lds_bytes(int mt = 1) { return 64 * XCD_LDW * 2 + WIDE_NW * mt * 16 * 68 * 4 + 64; }
 
@@ -707,11 +713,24 @@ DEVFN bool xcd_claim(int* sync, int* flag, const int ntile, const int ngroups, i
   return ok && xcd < ngroups && slot < ntile;
 }
 
+// last act of every workgroup of a persistent launch (also of those that found nothing to do or bailed out): see EXITED
+DEVFN void xcd_finish(const LstmWideArgs& a) {
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  int* const sync = a.sync;
+  if (__hip_atomic_fetch_add(sync + XcdSyncLayout::EXITED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (int)gridDim.x - 1) return;
+  const int e = __hip_atomic_load(sync + XcdSyncLayout::ERROR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int w = 0; w < XcdSyncLayout::WORDS; w++)
+    __hip_atomic_store(sync + w, w == XcdSyncLayout::LAST_ERROR ? e : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (e && a.out_sticky) __hip_atomic_store(a.out_sticky, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.out_host) store_i32_wt(a.out_host, e);
+}
+
 // MT: 16-line tiles per group (1: a group = 16 lines; 2: 32 lines -- minibatches of more than 8 / ndir blocks of 16 lines walk
 // half as many sequential launches, every weight fragment read from LDS serves two MFMAs, and a step's barrier and ring round
 // trip -- what a step costs -- are paid once for twice the lines)
 template <int MT>
-__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a) {
+DEVFN void lstm_xcd_fwd_bf16_body(const LstmWideArgs& a) {
   unsigned short* wl = dyn_smem<unsigned short>();                         // [64][XCD_LDW]
   float* red = reinterpret_cast<float*>(wl + 64 * XCD_LDW);                // [4][MT * 16][68]
   int* flag = reinterpret_cast<int*>(red + WIDE_NW * MT * 16 * 68);
@@ -902,7 +921,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a
 // Same products, f32 accumulation, one summation order per tile: the results differ from the hoisted form only by the order of
 // the f32 additions.  NGX = 32-k groups of the input contraction per wave: wave w takes groups [w NGX, (w+1) NGX) of ni / 32.
 template <int NGX>
-__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16_fx(LstmWideArgs a) {
+DEVFN void lstm_xcd_fwd_bf16_fx_body(const LstmWideArgs& a) {
   constexpr int NX = NGX;                                     // 16-byte row chunks a thread stages per step: 16 lines x ni / 8 chunks over 256 threads (ni <= 128 NGX)
   unsigned short* wl = dyn_smem<unsigned short>();            // [64][XCD_LDW] while the weights are staged, then the x rows [16][ni + 8]
   float* red = reinterpret_cast<float*>(wl + 64 * XCD_LDW);   // [4][16][68]
@@ -1116,7 +1135,7 @@ inline __host__ __device__ int xcd_bwd_lds_bytes(int mt = 1) {
 // MT: 16-line tiles per group, as in the forward kernel (the delta ring block a workgroup reads per step doubles with it:
 // 128 KB at MT = 2 -- sixteen 16-byte loads per lane and line tile, all in flight at once)
 template <int MT>
-__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a) {
+DEVFN void lstm_xcd_bwd_bf16_body(const LstmWideArgs& a) {
   constexpr int LDR = 16 + 4;
   unsigned short* wl = dyn_smem<unsigned short>();                         // [16][XCD_LDWB]
   float* red = reinterpret_cast<float*>(wl + 16 * XCD_LDWB);               // [4][MT * 16][LDR]
@@ -1289,7 +1308,7 @@ inline __host__ __device__ int xcd_bwd_f32_lds_bytes(int kp) {
   return need > 84 * 1024 ? need : 84 * 1024;
 }
 
-__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a) {
+DEVFN void lstm_xcd_fwd_f32_body(const LstmWideArgs& a) {
   float* wl = dyn_smem<float>();                                   // [64][kp + 4]
   const int ldw = a.kp + WIDE_WPAD;
   float* red = wl + 64 * ldw;                                      // [4][16][68]
@@ -1403,7 +1422,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a)
   }
 }
 
-__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a) {
+DEVFN void lstm_xcd_bwd_f32_body(const LstmWideArgs& a) {
   float* wl = dyn_smem<float>();                                   // [16][kp + 4]
   const int ldw = a.kp + WIDE_WPAD;
   float* red = wl + 16 * ldw;                                      // [4][16][WIDE_LDW]
@@ -1525,5 +1544,15 @@ inline int wide_kp_bwd(int no) { return ((4 * no + 16 * WIDE_NW - 1) / (16 * WID
 // bf16 rows: every wave's quarter of the contraction is whole k32 groups
 inline int wide_kp16_fwd(int no) { return ((no + 32 * WIDE_NW - 1) / (32 * WIDE_NW)) * 32 * WIDE_NW; }
 inline int wide_kp16_bwd(int no) { return ((4 * no + 32 * WIDE_NW - 1) / (32 * WIDE_NW)) * 32 * WIDE_NW; }
+
+// ---- the persistent kernels: body + xcd_finish ----
+template <int MT>
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a) { lstm_xcd_fwd_bf16_body<MT>(a); xcd_finish(a); }
+template <int NGX>
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16_fx(LstmWideArgs a) { lstm_xcd_fwd_bf16_fx_body<NGX>(a); xcd_finish(a); }
+template <int MT>
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a) { lstm_xcd_bwd_bf16_body<MT>(a); xcd_finish(a); }
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a) { lstm_xcd_fwd_f32_body(a); xcd_finish(a); }
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a) { lstm_xcd_bwd_f32_body(a); xcd_finish(a); }
 
 }  // namespace clstm

@@ -286,15 +286,6 @@ __global__ void k_peer_allreduce_update(PeerArgs p, float* v, float* d, float* g
   }
 }
 
-// outcome of a persistent recurrence launch: its error word goes into the sticky device word k_update looks at and into
-// the host's pinned slot (checked when the slot comes round again or at the next read-back)
-__global__ void k_xcd_outcome(const int* err, int* sticky, int* host_slot) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int e = *err;
-  if (e) *sticky = e;
-  *host_slot = e;
-}
-
 // ---- weight packing for the sequence kernels ---------------------------------------------------
 struct PackDesc {
   long long p_off[2][4];  // flat offsets of (dir, slot) blocks; slot 0 gi,1 gf,2 go,3 ci
@@ -459,6 +450,77 @@ __global__ void k_pack_wide_bf16(const float* v, unsigned short* Rbf, unsigned s
   }
 }
 
+// Every packed copy a WIDE layer needs in bf16 mode, in ONE pass over its parameters (no % 128 == 0, ni % 32 == 0: no padding
+// anywhere): Wt / bias (f32, the hoisted product's fallback forms), Wtb [ni][M] and WtbT [M][ni] (bf16 W_x in both
+// orientations), Rbf (forward recurrence: rows (cell, gate), k contiguous) and Rbb (backward: rows k, columns (cell, gate)).
+// The five single-purpose kernels it replaces (k_pack_wide_bf16, k_pack_layer, k_to_bf16 x 2, k_transpose_to_bf16) read the
+// column-major parameter blocks with a 2 KB stride between neighbouring threads wherever their output was row-major: 102 us
+// per configs[4] step for 105 MB of traffic.  Here a workgroup moves a tile of 32 cells x 32 columns of all four gates
+// through LDS: reads are 128-byte runs along the cells, both kinds of output are written in whole 32- / 256-byte runs.
+__global__ __launch_bounds__(256) void k_pack_wide_tiles(const float* v, PackDesc p, float* Wt, float* bias, unsigned short* Wtb,
+                                                        unsigned short* WtbT, unsigned short* Rbf, unsigned short* Rbb, int kf, int kb,
+                                                        int rows_f, int rows_b) {
+  __shared__ __attribute__((aligned(16))) float tile[32 * 132];   // [column][cell * 4 + gate], row stride 132
+  const int no = p.no, ni = p.ni, M = p.ndir * 4 * no;
+  const int nct = no >> 5, nkx = ni >> 5, nk = nkx + (no >> 5);
+  int b = blockIdx.x;
+  const int ct = b % nct; b /= nct;
+  const int kt = b % nk, dir = b / nk;
+  const bool isx = kt < nkx;
+  const int k0 = (isx ? kt : kt - nkx) << 5, c0 = ct << 5;
+  const int tid = threadIdx.x;
+  {
+    const int cell = tid & 31, q = tid >> 5;
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int g = i & 3, cc = q + 8 * (i >> 2);
+      x[i] = v[p.p_off[dir][g] + (c0 + cell) + (size_t)no * (1 + (isx ? 0 : ni) + k0 + cc)];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) tile[(q + 8 * (i >> 2)) * 132 + cell * 4 + (i & 3)] = x[i];
+  }
+  if (isx && kt == 0 && tid < 128) bias[dir * 4 * no + 4 * c0 + tid] = v[p.p_off[dir][tid & 3] + c0 + (tid >> 2)];
+  __syncthreads();
+  {   // outputs whose rows are parameter COLUMNS: 16 consecutive (cell, gate) values of one column per thread
+    const int cc = tid >> 3, ch = tid & 7;
+    const int k = k0 + cc;
+    float x[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(&tile[cc * 132 + ch * 16 + j * 4]);
+      x[4 * j] = t[0]; x[4 * j + 1] = t[1]; x[4 * j + 2] = t[2]; x[4 * j + 3] = t[3];
+    }
+    float lo8[8], hi8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { lo8[j] = x[j]; hi8[j] = x[8 + j]; }
+    const int col0 = 4 * (c0 + 4 * ch);          // 4 cell + gate of the first value
+    if (isx) {
+      float* wt = Wt + (size_t)k * M + dir * 4 * no + col0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4*>(wt + 4 * j) = f32x4{x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]};
+      unsigned short* wb = Wtb + (size_t)k * M + dir * 4 * no + col0;
+      *reinterpret_cast<u16x8*>(wb) = bf16_pack8(lo8);
+      *reinterpret_cast<u16x8*>(wb + 8) = bf16_pack8(hi8);
+    } else {
+      unsigned short* rb = Rbb + ((size_t)dir * rows_b + k) * kb + col0;
+      *reinterpret_cast<u16x8*>(rb) = bf16_pack8(lo8);
+      *reinterpret_cast<u16x8*>(rb + 8) = bf16_pack8(hi8);
+    }
+  }
+  {   // outputs whose rows are (cell, gate): 16 consecutive columns of one row per thread
+    const int r = tid >> 1, hf = tid & 1;
+    float lo8[8], hi8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { lo8[j] = tile[(hf * 16 + j) * 132 + r]; hi8[j] = tile[(hf * 16 + 8 + j) * 132 + r]; }
+    const size_t row = (size_t)4 * c0 + r;        // 4 cell + gate within the direction
+    unsigned short* dst = isx ? WtbT + ((size_t)dir * 4 * no + row) * ni + k0 + hf * 16
+                              : Rbf + ((size_t)dir * rows_f + row) * kf + k0 + hf * 16;
+    *reinterpret_cast<u16x8*>(dst) = bf16_pack8(lo8);
+    *reinterpret_cast<u16x8*>(dst + 8) = bf16_pack8(hi8);
+  }
+}
+
 // S[dir][n][0] = 1, S[dir][n][1..ni] = x_n for every direction: the non-recurrent part of the source
 // rows [1 | x_t | h_{t-1}] (forward_stack_delay + the bias column of Params, tensor.h:263-264)
 __global__ void k_build_source(float* S, const float* x, size_t N, int ni, int ldx, int lds, int ndir, long long sdir) {
@@ -598,6 +660,16 @@ __global__ void k_to_bf16(const float* src, unsigned short* dst, size_t n) {
 // one_col = ni + no multiples of 8): the contraction-major operand of the weight-gradient GEMM (gemm_b16mc).  x comes from
 // the layer below's bf16 outputs (xb, 16-byte copies) or from f32 input frames (xf); the h-part is stored by the
 // persistent forward recurrence itself (lstm_wide.h).
+// the constant part of those rows alone: the bias column (1, followed by the row's zero padding) -- written once per batch
+// geometry when the x-part is not copied at all (the weight-gradient GEMM then reads it from the layer below's bf16 outputs)
+__global__ void k_source_one_bf16(unsigned short* Sbf, size_t N, int one_col, int ldsb, int ndir, long long sbdir) {
+  CLSTM_GRID_STRIDE(n, N) {
+    u16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (unsigned short)(i == 0 ? 0x3F80 : 0);
+    for (int d = 0; d < ndir; d++) *reinterpret_cast<u16x8*>(&Sbf[(size_t)d * sbdir + n * ldsb + one_col]) = v;
+  }
+}
 __global__ void k_source_x_bf16(unsigned short* Sbf, const float* xf, const unsigned short* xb, int ldx, size_t N, int ni, int one_col,
                                 int ldsb, int ndir, long long sbdir) {
   const int cpr = (ni >> 3) + 1;

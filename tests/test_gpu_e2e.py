@@ -562,7 +562,8 @@ def test_configs4_full_shape_bf16_vs_oracle(configs4_case):
     g = net.get_grads()
     import ctypes
     for which, idx in (("persistent forward", 0), ("persistent backward", 1), ("bf16-source W_x.x", 2), ("bf16-source x.d", 3),
-                       ("contraction-major W.d", 4)):
+                       ("contraction-major W.d", 4), ("input projection inside the persistent forward kernel (layer 1)", 6),
+                       ("W.d x-part read from the layer below's bf16 outputs (layer 2)", 8)):
         cnt = ctypes.c_longlong(0)
         be.lib.call("clstm_debug_path_count", idx, ctypes.byref(cnt))
         assert cnt.value > 0, "the %s kernel did not run" % which

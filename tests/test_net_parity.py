@@ -273,6 +273,9 @@ def test_bf16_gate_gemms_track_the_f32_path(backend, ora32):
                                   # 20 ragged lines = two line blocks x two directions = four XCD groups of the persistent kernels
                                   ([48, 32], [14, 9, 3, 11, 7, 14, 1, 8, 13, 5, 12, 6, 10, 2, 9, 14, 4, 11, 7, 13]),
                                   ([32, 32], [9, 5, 7, 3]),
+                                  # the upper layer's 128 input columns fill a whole tile of its weight-gradient GEMM: they are read from the
+                                  # lower layer's bf16 outputs directly (gemm_b16mc A2), not copied into the bf16 source rows
+                                  ([64, 32], [9, 5, 7, 3]),
                                   # persistent backward pass that stores only bf16 deltas + a weight-gradient product that falls back to
                                   # the f32-source kernel (12 inputs: no bf16 source rows): the deltas are expanded on demand
                                   ([32], [9, 5, 7, 3]),
@@ -281,7 +284,7 @@ def test_bf16_gate_gemms_track_the_f32_path(backend, ora32):
                                   ([32, 32], [1 + (7 * i) % 6 for i in range(70)]),
                                   # 132 lines = nine blocks of 16 x two directions > 16 groups: 64-line groups (four line tiles)
                                   ([16], [1 + (5 * i) % 4 for i in range(132)])],
-                         ids=["two_layers", "odd_cells", "twenty_lines", "all_bf16_paths", "f32_source_fallback", "seventy_lines",
+                         ids=["two_layers", "odd_cells", "twenty_lines", "all_bf16_paths", "x_part_from_the_layer_below", "f32_source_fallback", "seventy_lines",
                               "hundred_thirty_two_lines"])
 def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatch, nh, T):
     """clstm_net_set_gemm_precision(2): bf16 MFMA operands (recurrent weights, h, gate deltas) inside the lock-step
@@ -491,3 +494,33 @@ def test_persistent_recurrence_placement_fallback(backend, ora32, monkeypatch, p
     finally:
         lib.call("clstm_debug_set_device_error", 4, 0)
         lib.call("clstm_debug_set_device_error", 5, 0)
+
+
+def test_tiled_weight_pack_equals_the_single_purpose_kernels(backend, ora32, monkeypatch):
+    """Round 4: in bf16 mode a wide layer's packed copies (Wt, bias, Wtb, WtbT, Rbf, Rbb) come from ONE tiled pass over its
+    parameters (ops.h:k_pack_wide_tiles) instead of five gather kernels.  Same copies, so everything computed from them is
+    BIT-identical to a run on the old kernels (CLSTM_PACK_TILES=0): outputs, saved activations, gradient -- for a first
+    layer (32 inputs) and an upper layer (256 inputs), both directions."""
+    from clstm_amd.net import Network
+    monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
+    rng = np.random.default_rng(51)
+    ni, nh, nc, T = 32, [128, 128], 5, [3, 2]
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 10.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, 1).astype(np.int32) for _ in T]
+    res = []
+    for tiles in ("1", "0"):
+        monkeypatch.setenv("CLSTM_PACK_TILES", tiles)
+        net = Network(ni, nh, nc, lib=backend.lib)
+        net.set_params(params)
+        net.set_gemm_precision(2)
+        net.set_inputs(lines)
+        net.forward()
+        out = net.outputs()
+        st = [net.state(l, d, w) for l in range(2) for d in (0, 1) for w in ("gi", "ci", "state", "outputs")]
+        net.ctc(trs)
+        net.backward()
+        res.append((out, st, net.get_grads()))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+    assert np.array_equal(res[0][2], res[1][2]) and np.abs(res[0][2]).max() > 0
