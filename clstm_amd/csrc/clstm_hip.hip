@@ -1410,6 +1410,10 @@ struct Net {
       check_launch();
     } else {
       timing.begin("gemm_softmax", s);
+      if (bf16_gemm && gemm_x3_on && gemm_bf16_big((int)N, nc))   // bf16 modes: f32-grade bf16 x 3 on 128 x 128 tiles (88 -> ~30 us at configs[4])
+        gemm_x3_big<GEMM_KC, GEMM_MC>(s, gemm_kc(L.back().hrow(), L.back().ldh, N, 32), gemm_mc(W1 + nc, nc, sm_ni, 0),
+                                      StoreBias{Z.p, nc, W1}, (int)N, nc, sm_ni);
+      else
       gemm_f32<GEMM_KC, GEMM_MC>(s, gemm_kc(L.back().hrow(), L.back().ldh, N), gemm_mc(W1 + nc, nc, sm_ni, 0),
                                  StoreBias{Z.p, nc, W1}, (int)N, nc, sm_ni);
       timing.end(s);
@@ -1704,7 +1708,9 @@ struct Net {
     {  // (a side stream for this GEMM was measured on MI355X: no gain -- the recurrence workgroups it would
        // overlap with slow down by as much -- so everything stays on one stream)
       const int R = 1 + sm_ni, Cn = nc;
-      int ns = pick_split(R, Cn);
+      // (bf16 modes, shapes that fill 128 x 128 tiles: the two products as launches of the big-tile f32-grade kernel)
+      const bool sm_big = bf16_gemm && gemm_x3_on && gemm_bf16_big(R, Cn) && gemm_bf16_big((int)N, sm_ni);
+      int ns = sm_big ? pick_split(R, Cn, 1, GB2_BT) : pick_split(R, Cn);
       // W.d depends on nothing the backward recurrence produces: when the top layer's backward runs as the fused launch
       // (lstm_bwd_dw.h) its slabs are items of THAT launch -- they execute on the idle half of the chip during the ~14 us
       // before the recurrence's first chunk is released -- and only x.d stays in front of the recurrence.
@@ -1734,7 +1740,10 @@ struct Net {
       timing.begin("gemm_softmax_dw_dx", s);
       if (dwx_active)
         gemm_x3<GEMM_KC, GEMM_KC>(s, gemm_kc(Dz.p, nc, N), gemm_kc(W1 + nc, nc, sm_ni, 0), StorePlain{top.dH.p, sm_ni}, (int)N, sm_ni, nc);
-      else if (gemm_x3_on)
+      else if (sm_big) {
+        gemm_x3_big<GEMM_MC, GEMM_MC>(s, gemm_mc(top.srow(), top.ldh, N, 32), gemm_mc(Dz.p, nc, N, 32), StorePartial{partial_sm.p, R, Cn}, R, Cn, (int)N, ns);
+        gemm_x3_big<GEMM_KC, GEMM_KC>(s, gemm_kc(Dz.p, nc, N, 32), gemm_kc(W1 + nc, nc, sm_ni, 0), StorePlain{top.dH.p, sm_ni}, (int)N, sm_ni, nc);
+      } else if (gemm_x3_on)
         gemm_x3_pair<GEMM_MC, GEMM_MC, StorePartial, GEMM_KC, GEMM_KC, StorePlain>(
             s, gemm_problem(gemm_mc(top.srow(), top.ldh, N), gemm_mc(Dz.p, nc, N), R, Cn, (int)N, ns),
             StorePartial{partial_sm.p, R, Cn},

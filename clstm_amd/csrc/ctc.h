@@ -158,6 +158,51 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, float* 
       }
       if (i < T) step(i, lmA, kaA);
     }
+  } else if (S <= 128) {
+    // 65..128 states (transcripts of 33..63 labels: configs[4]'s 50 labels = 101 states): still ONE wave per direction and no
+    // barrier per frame -- lane u holds states 2u and 2u + 1; state 2u + 1 takes its j-1 neighbour from the lane's own other
+    // register, state 2u from lane u - 1's odd state by the DPP wave shift.  The two log_adds of a lane are independent, so a
+    // frame costs little more than the one-state chain; the 256-lane form below pays a workgroup barrier per frame
+    // (profiles/r04_ctc_phase_cycles.txt: phase B at T = 400, S = 101).
+    __syncthreads();  // lattice rows of phase A visible
+    if (wave < 2) {
+      const bool rev = wave == 1;
+      const BufF32 outb = make_buf(rev ? be : al, latbytes);
+      const int j0 = 2 * lane, j1 = 2 * lane + 1;
+      const unsigned lp0 = j0 < S ? (unsigned)(rev ? S - 1 - j0 : j0) * 4u : BUF_OOB_BASE;
+      const unsigned lp1 = j1 < S ? (unsigned)(rev ? S - 1 - j1 : j1) * 4u : BUF_OOB_BASE;
+      const unsigned rowbytes = (unsigned)S * 4u;
+      auto frame = [&](int i) -> unsigned {
+        const int ic = i < T ? i : T - 1;
+        return (unsigned)(rev ? T - 1 - ic : ic) * rowbytes;
+      };
+      float v0 = -5.0f * (float)j0, v1 = -5.0f * (float)j1;   // skip * j, exact in float
+      float skipi = 0.0f;
+      float a0 = buf_load_s(lmb, lp0, frame(0)), a1 = buf_load_s(lmb, lp1, frame(0));
+      float b0 = buf_load_s(lmb, lp0, frame(1)), b1 = buf_load_s(lmb, lp1, frame(1));
+      float ka0 = 0.0f, ka1 = 0.0f, kb0 = 0.0f, kb1 = 0.0f;
+      auto step = [&](const int i, float& l0, float& l1, float& k0, float& k1) {
+        KEEP_ALIVE(k0); KEEP_ALIVE(k1);
+        const float m0 = l0, m1 = l1;
+        const float same0 = v0 + m0, same1 = v1 + m1;
+        const float next1 = v0 + m1;                               // w = v_old[j - 1], the lane's own even state
+        const float next0 = add_wave_shr1(skipi + m0, v1, m0);     // ... lane u - 1's odd state (lane 0: skip * i)
+        skipi -= 5.0f;
+        l0 = buf_load_s(lmb, lp0, frame(i + 2));                    // two frames ahead
+        l1 = buf_load_s(lmb, lp1, frame(i + 2));
+        v0 = ctc_log_add(same0, next0, tb);
+        v1 = ctc_log_add(same1, next1, tb);
+        buf_store_s(outb, lp0, frame(i), v0);
+        buf_store_s(outb, lp1, frame(i), v1);
+        k0 = v0; k1 = v1;
+      };
+      int i = 0;
+      for (; i + 1 < T; i += 2) {
+        step(i, a0, a1, ka0, ka1);
+        step(i + 1, b0, b1, kb0, kb1);
+      }
+      if (i < T) step(i, a0, a1, ka0, ka1);
+    }
   } else {
     const int R = (S + CTC_GROUP - 1) / CTC_GROUP;
     // RM: states a lane can hold (2 for S <= 512, else CTC_RMAX): every frame issues RM prefetches and RM guarded updates

@@ -76,7 +76,7 @@ struct Ranks {
     {   // one GPU per rank
       const char* vis = getenv("HIP_VISIBLE_DEVICES");
       std::string dev = std::to_string(rank);
-      if (vis && *vis) {
+      if (vis && *vis && !getenv("CLSTM_NGPU_SHARE_DEVICE")) {
         std::vector<std::string> ids;
         std::string cur;
         for (const char* c = vis;; c++) { if (*c == ',' || !*c) { ids.push_back(cur); cur.clear(); if (!*c) break; } else cur.push_back(*c); }

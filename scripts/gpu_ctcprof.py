@@ -4,7 +4,7 @@ from clstm_amd import abi
 from clstm_amd.abi import ptr
 lib = abi.load()
 rng = np.random.default_rng(0)
-for (T, L, nc, bs) in [(200, 25, 83, 64), (200, 25, 83, 1), (400, 80, 83, 16)]:
+for (T, L, nc, bs) in [(200, 25, 83, 64), (200, 25, 83, 1), (400, 80, 83, 16), (400, 50, 100, 64)]:   # (the last: configs[4])
     probs = rng.random((bs * T, nc)).astype(np.float32) ** 3
     probs /= probs.sum(1, keepdims=True)
     S = 2 * L + 1

@@ -318,7 +318,10 @@ def test_ctc_reference_known_answers(backend):
     assert np.allclose(d2, a2 - o2, atol=1e-7)
 
 
-@pytest.mark.parametrize("T,L,nc", [(12, 3, 6), (40, 12, 30), (7, 3, 5), (3, 1, 83), (60, 40, 30), (100, 62, 70), (200, 70, 90), (256, 25, 83)])
+@pytest.mark.parametrize("T,L,nc", [(12, 3, 6), (40, 12, 30), (7, 3, 5), (3, 1, 83), (60, 40, 30), (100, 62, 70), (200, 70, 90), (256, 25, 83),
+                                    # 65..128 states: one wave per direction, two states per lane (round 4) -- the configs[4] transcript length
+                                    # (101 / 99 / 97 states) on the tiled path, 65 states (the smallest), 127 / 125 / 123 (the largest)
+                                    (400, 50, 100), (90, 32, 40), (150, 63, 70)])
 def test_ctc_vs_oracle(backend, ora32, T, L, nc):
     # (12..40: short-line path, lattice resident in LDS; 60 x 81 states: the same with the wide recursion;
     #  100 x 125 states and 200 x 141: the tiled path through HBM; 256 x 51 = 13056 cells: the largest OCR-shaped lattice of
