@@ -39,6 +39,7 @@ constexpr int CTC_RMAX = 8;        // register-resident recursion: up to 2048 ta
                                    // states in rounds of 256 per frame, the previous row read back from the lattice
 constexpr int CTC_SMAX_LDS = CTC_GROUP * CTC_RMAX;   // the per-state LDS arrays are carved for at most this many states
 constexpr int CTC_MLP = 8;         // independent global loads a thread keeps in flight in the streaming phases
+constexpr int CTC_MLPT = 20;       // ... in the tile staging / write-out loops of the tiled path (a tile's frames of one wave at once)
 constexpr int CTC_MAX_TILE = 256;  // frames per LDS tile (phases A and E)
 
 struct CtcArgs {
@@ -726,6 +727,30 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
     for (int s = tid + CTC_THREADS; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
   }
   auto state_at = [&](int s) -> int { return huge ? stg[s] : stl[s]; };
+  // blank states | label states, each in state order (phase E walks them on two threads per frame, branch-free)
+  int* lists = reinterpret_cast<int*>(lds + L.lists);
+  int nblank = 0;
+  if (!huge) {
+    __syncthreads();
+    int* cnt = reinterpret_cast<int*>(red + 32);
+    if (wave == 0) {   // one wave, rounds of 64 states: ballot + popcount ranks
+      int nb = 0;
+      for (int s0 = 0; s0 < S; s0 += 64) nb += __builtin_popcountll(wave_ballot(s0 + lane < S && stl[s0 + lane < S ? s0 + lane : 0] == 0));
+      int ib = 0, il = nb;
+      const unsigned long long below = (1ull << lane) - 1ull;
+      for (int s0 = 0; s0 < S; s0 += 64) {
+        const bool in = s0 + lane < S;
+        const bool isb = in && stl[in ? s0 + lane : 0] == 0;
+        const unsigned long long mb = wave_ballot(isb), ml = wave_ballot(in && !isb);
+        if (isb) lists[ib + __builtin_popcountll(mb & below)] = s0 + lane;
+        if (in && !isb) lists[il + __builtin_popcountll(ml & below)] = s0 + lane;
+        ib += __builtin_popcountll(mb); il += __builtin_popcountll(ml);
+      }
+      if (lane == 0) cnt[0] = nb;
+    }
+    __syncthreads();
+    nblank = cnt[0];
+  }
 #pragma unroll
   for (int k = 0; k < CTC_TREG; k++)
     if (tid + k * CTC_THREADS < CTC_TABLE_DOUBLES) tabs[tid + k * CTC_THREADS] = treg[k];
@@ -760,7 +785,9 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
     }
     __syncthreads();
     // (frame, state) pairs flattened over all threads (states need not be a multiple of the wave); the
-    // pair of the next element follows incrementally (no integer division in the loop)
+    // pair of the next element follows incrementally (no integer division in the loop).  (Measured and not kept, round 4: one
+    // log per frame for all blank states + one per label state -- half the logs -- left the phase at 78k -> 81k cycles at the
+    // configs[4] lattice: the logs are not what bounds it.)
     {
       const int dq = CTC_THREADS / S, dr = CTC_THREADS - dq * S;
       int tq = tid / S, sq = tid - tq * S;
@@ -813,14 +840,40 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
       if (i < TS) al[i] = ctc_limexp(bo[k] - mx);
     }
   } else {
+    // (CTC_MLP cells per thread in flight: as a plain loop each cell was a dependent round trip to the L2 -- 70k of the
+    // kernel's 590k cycles at the configs[4] lattice, 400 x 101)
+    const BufF32 alb = make_buf(al, (size_t)TS * 4), beb = make_buf(be, (size_t)TS * 4);
     float mx = -3.0e38f;
-    for (int i = tid; i < TS; i += CTC_THREADS) mx = fmaxf(mx, al[i] + be[i]);
+    for (int i0 = tid; i0 < TS; i0 += CTC_MLP * CTC_THREADS) {
+      float x[CTC_MLP], y[CTC_MLP];
+#pragma unroll
+      for (int u = 0; u < CTC_MLP; u++) {
+        const int i = i0 + u * CTC_THREADS;
+        x[u] = buf_load(alb, i < TS ? (unsigned)i * 4u : BUF_OOB);
+        y[u] = buf_load(beb, i < TS ? (unsigned)i * 4u : BUF_OOB);
+      }
+#pragma unroll
+      for (int u = 0; u < CTC_MLP; u++) mx = fmaxf(mx, i0 + u * CTC_THREADS < TS ? x[u] + y[u] : -3.0e38f);
+    }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = red[0];
     for (int i = 1; i < CTC_THREADS / 64; i++) mx = fmaxf(mx, red[i]);
-    for (int i = tid; i < TS; i += CTC_THREADS) al[i] = ctc_limexp((al[i] + be[i]) - mx);
+    for (int i0 = tid; i0 < TS; i0 += CTC_MLP * CTC_THREADS) {
+      float x[CTC_MLP], y[CTC_MLP];
+#pragma unroll
+      for (int u = 0; u < CTC_MLP; u++) {
+        const int i = i0 + u * CTC_THREADS;
+        x[u] = buf_load(alb, i < TS ? (unsigned)i * 4u : BUF_OOB);
+        y[u] = buf_load(beb, i < TS ? (unsigned)i * 4u : BUF_OOB);
+      }
+#pragma unroll
+      for (int u = 0; u < CTC_MLP; u++) {
+        const int i = i0 + u * CTC_THREADS;
+        buf_store(alb, i < TS ? (unsigned)i * 4u : BUF_OOB, ctc_limexp((x[u] + y[u]) - mx));
+      }
+    }
   }
   __syncthreads();
   CTC_STAMP(3);
@@ -840,8 +893,15 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
     const int Q = CTC_THREADS / S > 8 ? 8 : CTC_THREADS / S;  // time chunks per state (S <= 512)
     if (tid < S * Q) {
       const int s = tid % S, q = tid / S;
+      const BufF32 alb = make_buf(al, (size_t)TS * 4);
       double acc = 0.0;
-      for (int t = q; t < T; t += Q) acc += (double)al[(size_t)t * S + s];
+      for (int t0 = q; t0 < T; t0 += CTC_MLP * Q) {   // (same order of additions; the loads of a batch in flight together)
+        float x[CTC_MLP];
+#pragma unroll
+        for (int u = 0; u < CTC_MLP; u++) { const int t = t0 + u * Q; x[u] = buf_load(alb, t < T ? (unsigned)(t * S + s) * 4u : BUF_OOB); }
+#pragma unroll
+        for (int u = 0; u < CTC_MLP; u++) acc += (t0 + u * Q < T) ? (double)x[u] : 0.0;
+      }
       part[q * S + s] = acc;
     }
     __syncthreads();
@@ -857,64 +917,125 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   // ---- E: per-state normalisation applied on the fly; project states onto classes, normalise
   //         per frame, emit deltas ---------------------------------------------------------------
   const int sp = S | 1;
+  // (diagnostics: cycles of phase E's parts summed over the tiles, slots 6..9 -- scripts/gpu_ctcprof.py)
+#define CTC_ACC(k) do { if (a.prof && b == 0 && threadIdx.x == 0) { const long long now_ = dev_clock(); a.prof[k] += now_ - eprev; eprev = now_; } } while (0)
+  long long eprev = 0;
+  if (a.prof && b == 0 && threadIdx.x == 0) { eprev = dev_clock(); a.prof[6] = a.prof[7] = a.prof[8] = a.prof[9] = 0; }
   for (int t0 = 0; t0 < T; t0 += TT) {
     const int nt = (T - t0) < TT ? (T - t0) : TT;
     for (int s0 = lane; s0 < S && !huge; s0 += 64) {  // coalesced staging of the lattice tile, CTC_MLP frames in flight
       const double it = tot[s0];
-      for (int t = wave; t < nt; t += CTC_MLP * (CTC_THREADS / 64)) {
-        float x[CTC_MLP];
+      const BufF32 alb = make_buf(al + (size_t)t0 * S, (size_t)nt * S * 4);
+      for (int t = wave; t < nt; t += CTC_MLPT * (CTC_THREADS / 64)) {
+        float x[CTC_MLPT];
 #pragma unroll
-        for (int u = 0; u < CTC_MLP; u++) {
+        for (int u = 0; u < CTC_MLPT; u++) {
           const int tu = t + u * (CTC_THREADS / 64);
-          x[u] = tu < nt ? al[(size_t)(t0 + tu) * S + s0] : 0.0f;
+          x[u] = buf_load(alb, tu < nt ? (unsigned)(tu * S + s0) * 4u : BUF_OOB);
         }
 #pragma unroll
-        for (int u = 0; u < CTC_MLP; u++) {
+        for (int u = 0; u < CTC_MLPT; u++) {
           const int tu = t + u * (CTC_THREADS / 64);
-          if (tu < nt) etile[tu * sp + s0] = (float)((double)x[u] * it);
+          float* w = tu < nt ? &etile[tu * sp + s0] : lds + L.dump;
+          *w = (float)((double)x[u] * it);
         }
       }
     }
     for (int i = tid; i < nt * ncp; i += CTC_THREADS) rowbuf[i] = 0.0f;
     __syncthreads();
-    if (tid < nt) {
-      float* row = rowbuf + tid * ncp;
-      double blank = 0.0;  // class 0 collects L+1 states: keep the reference's double accumulator
-      const float* e = etile + tid * sp;
-      const float* ag = al + (size_t)(t0 + tid) * S;
-      for (int s0 = 0; s0 < S; s0++) {
-        const int c = state_at(s0);
-        const float x = huge ? (float)((double)ag[s0] * totg[s0]) : e[s0];
-        if (c == 0) blank += (double)x;
-        else row[c] += x;   // (ds_add_f32 instead was measured 40 % slower for this phase)
-      }
-      row[0] = (float)blank;
-      double total = 0.0;
-      for (int c = 0; c < nc; c++) total += (double)row[c];
-      part[tid] = 1.0 / fmax(total, 1e-9);
-    }
-    __syncthreads();
-    for (int c = lane; c < nc; c += 64) {  // coalesced write-out, one wave per frame, CTC_MLP frames in flight
-      for (int t = wave; t < nt; t += CTC_MLP * (CTC_THREADS / 64)) {
-        float p[CTC_MLP];
-#pragma unroll
-        for (int u = 0; u < CTC_MLP; u++) {
-          const int tu = t + u * (CTC_THREADS / 64);
-          p[u] = tu < nt ? P[(size_t)(t0 + tu) * nc + c] : 0.0f;
+    CTC_ACC(6);   // lattice tile staged, class rows cleared
+    if (huge) {
+      if (tid < nt) {
+        float* row = rowbuf + tid * ncp;
+        double blank = 0.0;  // class 0 collects L+1 states: keep the reference's double accumulator
+        const float* ag = al + (size_t)(t0 + tid) * S;
+        for (int s0 = 0; s0 < S; s0++) {
+          const int c = state_at(s0);
+          const float x = (float)((double)ag[s0] * totg[s0]);
+          if (c == 0) blank += (double)x;
+          else row[c] += x;   // (ds_add_f32 instead was measured 40 % slower for this phase)
         }
+        part[tid] = blank;
+      }
+    } else {
+      // Two threads per frame, on different waves (a tile holds <= 256 frames): thread f sums the blank states in state order
+      // in double (no memory dependence between its reads), thread 256 + f walks the label states and adds each into its class
+      // column -- a read-modify-write chain through LDS that used to run behind the blank sum on ONE thread with 2/3 of the
+      // workgroup idle (158k of the kernel's 590k cycles at the configs[4] lattice).  Classes and cells of a batch of 8 states
+      // are read before the batch's additions.
+      const int f = tid & 255;
+      if (f < nt) {
+        const float* e = etile + f * sp;
+        if (tid < 256) {
+          double blank = 0.0;
+          for (int i0 = 0; i0 < nblank; i0 += 8) {
+            float x[8];
 #pragma unroll
-        for (int u = 0; u < CTC_MLP; u++) {
-          const int tu = t + u * (CTC_THREADS / 64);
-          if (tu < nt) {
-            const float av = (float)((double)rowbuf[tu * ncp + c] * part[tu]);
-            const size_t g0 = (size_t)(t0 + tu) * nc + c;
-            if (a.aligned) a.aligned[(size_t)off * nc + g0] = av;
-            Dz[g0] = av - p[u];
+            for (int u = 0; u < 8; u++) x[u] = e[lists[i0 + u < nblank ? i0 + u : 0]];
+#pragma unroll
+            for (int u = 0; u < 8; u++) blank += (i0 + u < nblank) ? (double)x[u] : 0.0;   // (+ 0.0 is exact)
+          }
+          part[f] = blank;
+        } else {
+          float* row = rowbuf + f * ncp;
+          float* const sink = lds + L.dump;
+          for (int i0 = nblank; i0 < S; i0 += 8) {
+            float x[8];
+            float* w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const bool in = i0 + u < S;
+              const int st = lists[in ? i0 + u : nblank];
+              x[u] = e[st];
+              w[u] = in ? &row[stl[st]] : sink;   // branch-free: masked-off additions go to the dump word
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) *w[u] += x[u];   // state order within a class (ds_add_f32 was measured 40 % slower)
           }
         }
       }
     }
     __syncthreads();
+    CTC_ACC(7);   // states projected onto classes
+    if (tid < nt) {
+      float* row = rowbuf + tid * ncp;
+      row[0] = (float)part[tid];
+      double total = 0.0;
+      for (int c0 = 0; c0 < nc; c0 += 8) {   // class order, as the reference's double sum
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = row[c0 + u < nc ? c0 + u : 0];
+#pragma unroll
+        for (int u = 0; u < 8; u++) total += (c0 + u < nc) ? (double)x[u] : 0.0;
+      }
+      part[tid] = 1.0 / fmax(total, 1e-9);
+    }
+    __syncthreads();
+    CTC_ACC(8);   // frame totals
+    for (int c = lane; c < nc; c += 64) {  // coalesced write-out, one wave per frame, CTC_MLP frames in flight
+      const BufF32 pb = make_buf(P + (size_t)t0 * nc, (size_t)nt * nc * 4), db = make_buf(Dz + (size_t)t0 * nc, (size_t)nt * nc * 4);
+      const BufF32 ab = make_buf(a.aligned ? a.aligned + ((size_t)off + t0) * nc : Dz, a.aligned ? (size_t)nt * nc * 4 : 0);
+      for (int t = wave; t < nt; t += CTC_MLPT * (CTC_THREADS / 64)) {
+        float p[CTC_MLPT];
+        unsigned ofs[CTC_MLPT];
+#pragma unroll
+        for (int u = 0; u < CTC_MLPT; u++) {
+          const int tu = t + u * (CTC_THREADS / 64);
+          ofs[u] = tu < nt ? (unsigned)(tu * nc + c) * 4u : BUF_OOB;
+          p[u] = buf_load(pb, ofs[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < CTC_MLPT; u++) {
+          const int tu = t + u * (CTC_THREADS / 64);
+          const int tc = tu < nt ? tu : 0;
+          const float av = (float)((double)rowbuf[tc * ncp + c] * part[tc]);
+          buf_store(ab, ofs[u], av);
+          buf_store(db, ofs[u], av - p[u]);
+        }
+      }
+    }
+    __syncthreads();
+    CTC_ACC(9);   // aligned / deltas written
   }
   CTC_STAMP(5);
 }

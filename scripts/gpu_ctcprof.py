@@ -26,3 +26,5 @@ for (T, L, nc, bs) in [(200, 25, 83, 64), (200, 25, 83, 1), (400, 80, 83, 16), (
         names = ["classify", "A tile", "A row sums", "A log", "A rows->HBM", "B", "C load+max", "C max bcast", "C limexp", "D sums", "D totals",
                  "D normalise", "E project/blank", "E frame totals", "E write-out"]
         print("   " + ", ".join("%s %d" % (n, int(b - a)) for n, a, b in zip(names, seq[:-1], seq[1:])))
+    else:   # tiled path: the parts of phase E, summed over the tiles
+        print("   E: stage lattice tile + clear rows %d, project states onto classes %d, frame totals %d, write-out %d" % tuple(int(x) for x in cyc[6:10]))
