@@ -425,8 +425,7 @@ static int g_debug_fail_claims = 0;      // tests: this many upcoming persistent
 // fx_ngx > 0 (forward, bf16): try ONLY the persistent kernel with the input projection folded in (lstm_xcd_fwd_bf16_fx<fx_ngx>);
 // returns false -- nothing launched or nothing written -- if it does not apply or its placement check failed: the caller then
 // runs the hoisted product and calls again with fx_ngx = 0.
-static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s, bool bf16 = false, int fx_ngx = 0,
-                             bool fx_own_waves = false) {
+static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s, bool bf16 = false, int fx_ngx = 0) {
   g_wide_persistent = false;
   REQUIRE((double)a.N * a.ndir * 4 * a.no * 4 < 2147483000.0,
           "minibatch too large for the lock-step recurrence (frames x 4 x nhidden x ndir x 4 B must stay below 2 GiB)");
@@ -475,11 +474,6 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
   const bool fits = xcd_on && !g_xcd_failed && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16);
   if (fx_ngx > 0) {
     if (!(fwd && bf16 && fits && mt == 1 && a.kp16 <= 512 && (no & 3) == 0 && a.x_ni <= 128 * fx_ngx && a.x_ni <= 2048)) return false;
-    if (fx_own_waves) {   // the x-part on four waves of its own (lstm_xcd_fwd_bf16_fx2): eight waves per workgroup
-      const size_t smem2 = (size_t)xcd_fwd_fx2_lds_bytes();
-      return fx_ngx == 1 ? persistent(lstm_xcd_fwd_bf16_fx2<1>, smem2, 2 * WIDE_THREADS) : fx_ngx == 4 ? persistent(lstm_xcd_fwd_bf16_fx2<4>, smem2, 2 * WIDE_THREADS)
-           : fx_ngx == 8 ? persistent(lstm_xcd_fwd_bf16_fx2<8>, smem2, 2 * WIDE_THREADS) : false;
-    }
     const size_t smem = (size_t)xcd_fwd_lds_bytes(1);
     return fx_ngx == 1 ? persistent(lstm_xcd_fwd_bf16_fx<1>, smem) : fx_ngx == 4 ? persistent(lstm_xcd_fwd_bf16_fx<4>, smem)
          : fx_ngx == 8 ? persistent(lstm_xcd_fwd_bf16_fx<8>, smem) : false;
@@ -1307,9 +1301,9 @@ struct Net {
       const bool x_from_hbf = bf16_gemm && bf16_rec && l > 0 && L[l - 1].fwd_persistent && L[l - 1].Hbf.p && y.WtbT.p && y.ni == ndir * L[l - 1].no && (y.ni & 1) == 0;
       // the lock-step recurrence of a wide layer + what follows it (bf16 source rows for the weight gradient); fx_ngx > 0: the
       // persistent kernel with the input projection folded in (lstm_wide.h:lstm_xcd_fwd_bf16_fx) -- false if it did not run
-      auto run_wide = [&](LstmWideArgs w, int fx_ngx, bool fx_own_waves = false) {
+      auto run_wide = [&](LstmWideArgs w, int fx_ngx) {
         timing.begin("lstm_fwd", s);
-        const bool ran = launch_lstm_wide(true, w, tmax, coop_sync, step_graphs, s, bf16_rec, fx_ngx, fx_own_waves);
+        const bool ran = launch_lstm_wide(true, w, tmax, coop_sync, step_graphs, s, bf16_rec, fx_ngx);
         timing.end(s);
         if (!ran) return false;
         y.fwd_persistent = g_wide_persistent && bf16_rec;
@@ -1345,9 +1339,7 @@ struct Net {
       // one L2 round trip of the poll, not waiting for late tiles -- so the fused work lands on the chain: +400 cycles per step
       // for 64 inputs (67 us per pass against the 121 us of product + bf16 copy it replaces: kept), +2,950 for 1024 inputs
       // (490 us against 321: not kept).  (read per pass: tests switch it inside one process)
-      // 3: every eligible layer on x-waves of its own (lstm_xcd_fwd_bf16_fx2); 4: up to 128 inputs on the recurrence's waves, wider on own waves
       const int fx_mode = getenv("CLSTM_FUSE_WX") ? atoi(getenv("CLSTM_FUSE_WX")) : 1;
-      const bool fx_own = fx_mode == 3 || (fx_mode == 4 && y.ni > 128);
       if (fx_mode > 0 && (fx_mode > 1 || y.ni <= 128) && y.wide && bf16_gemm && bf16_rec && y.WtbT.p && (y.ni & 31) == 0 && (l == 0 || x_from_hbf)) {
         const int ngx = y.ni <= 128 ? 1 : y.ni <= 512 ? 4 : y.ni <= 1024 ? 8 : 0;
         if (ngx) {
@@ -1360,7 +1352,7 @@ struct Net {
           LstmWideArgs w = wide_args(y, true);
           w.Xb = xb; w.x_ld = y.ni; w.x_ni = y.ni; w.Wxb = y.WtbT.p; w.bias = y.bias;
           y.sx_valid = l == 0 && src0_ready;
-          fx_done = run_wide(w, ngx, fx_own);
+          fx_done = run_wide(w, ngx);
         }
       }
       if (fx_done) { if (!y.sbf_ready) ensure_source_x(l); continue; }

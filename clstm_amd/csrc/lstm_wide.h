@@ -1122,254 +1122,10 @@ DEVFN void lstm_xcd_fwd_bf16_fx_body(const LstmWideArgs& a) {
 }
 // (LDS: xcd_fwd_lds_bytes(1) -- the 16 x (ni + 8) halfs of input rows re-use the weight staging area: ni <= 2048)
 
-// ---- the input projection on waves of its OWN (MT = 1, eight waves) ---------------------------------------------------------
-// lstm_xcd_fwd_bf16_fx puts the x-part on the four waves that walk the recurrence: fine for 64 inputs (+400 cycles per step
-// against the 121 us the hoisted product cost), a loss for 1024 (+2,950 cycles: there is no idle window on those waves -- a
-// step's "group wait" is one L2 round trip of the poll).  Here the workgroup has EIGHT waves: waves 0-3 are the recurrence
-// exactly as in lstm_xcd_fwd_bf16 (minus the pre-activation loads), waves 4-7 compute the NEXT step's x-part beside them and
-// hand it over through LDS.  The two roles meet only at the workgroup's barriers, and the x-role's work of a segment is
-// shorter than the recurrence's (profiles/r04_xcd_phase_cycles_fx2.txt):
-//   poll segment   : x rows of step s+2 (requested one step earlier as whole 1 KB row pieces) -> LDS; rows of s+3 requested
-//   ring segment   : A fragments of step s+1's rows from LDS, W_x fragments from registers, MFMAs (the matrix pipe is idle
-//                    until the ring rows arrive), partial tiles (split-K over the four x-waves) -> LDS
-//   epilogue segm. : the four partial tiles summed -> xsum[(s+1) & 1]; the recurrence's epilogue of step s+1 adds it + bias.
-// Same products and f32 accumulation as the hoisted form; per tile the x-part is summed first, then the recurrent part.
-template <int NGX>
-DEVFN void lstm_xcd_fwd_bf16_fx2_body(const LstmWideArgs& a) {
-  constexpr int NX = NGX;                                     // 16-byte row chunks an x-role thread stages per step
-  unsigned short* wl = dyn_smem<unsigned short>();            // [64][XCD_LDW] while the weights are staged, then x rows [2][16][ni + 8]
-  float* red = reinterpret_cast<float*>(wl + 64 * XCD_LDW);   // [4][16][68]  recurrent partial tiles
-  float* xred = red + WIDE_NW * 16 * 68;                      // [4][16][68]  x-part partial tiles
-  float* xsum = xred + WIDE_NW * 16 * 68;                     // [2][16][68]  x-part of step parity
-  int* flag = reinterpret_cast<int*>(xsum + 2 * 16 * 68);
-  const int tid = threadIdx.x, lane = tid & 63, wave8 = wave_uniform(tid >> 6);
-  const bool xrole = wave8 >= WIDE_NW;
-  const int wave = wave8 & (WIDE_NW - 1);                     // wave within its role: the contraction quarter
-  const int rt = tid & (WIDE_THREADS - 1);                    // thread within its role
-  const int no = a.no, nd = a.ndir, ni = a.x_ni;
-  const int ntile = (no + 15) >> 4, nzb = a.zbn, ngroups = nd * nzb, ncg = (no + 3) >> 2;
-  int* const sync = a.sync;
-  int xcd, ct;
-  if (!xcd_claim(sync, flag, ntile, ngroups, xcd, ct, a.debug_fail_claim)) return;
-  const int dir = xcd % nd, zb = a.zb0 + xcd / nd;
-  int* const gcount = sync + XcdSyncLayout::GROUP0 + xcd * XcdSyncLayout::GROUP_STRIDE;
-  {
-    const int c8 = a.kp16 >> 3;
-    for (int i = tid; i < 64 * c8; i += 2 * WIDE_THREADS) {
-      const int row = i / c8, c = i - row * c8;
-      const long long grow = (long long)(dir * ncg + ct * 4) * 16 + row;
-      u16x8 v;
-#pragma unroll
-      for (int e = 0; e < 8; e++) v[e] = 0;
-      if ((ct * 4) * 16 + row < ncg * 16) v = *reinterpret_cast<const u16x8*>(a.Rw16 + grow * a.kp16 + c * 8);
-      *reinterpret_cast<u16x8*>(wl + row * XCD_LDW + c * 8) = v;
-    }
-  }
-  const int ml = rt >> 4, c16 = rt & 15;
-  const int cell = ct * 16 + c16;
-  const int line = zb * 16 + ml;
-  int off = 0, T = 0;
-  if (line < a.bs) { off = a.line_off[line]; T = a.line_off[line + 1] - off; }
-  const bool mine = line < a.bs && cell < no;
-  const int nblk = (a.bs + 15) >> 4, nkb = a.kp16 >> 5;
-  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Hb), (size_t)2 * nd * nblk * 16 * a.kp16 * 2);
-  const int kw = a.kp16 / WIDE_NW, ngrp = kw >> 5;
-  const unsigned akl = ring_elem(wave * ngrp, lane & 15, 8 * (lane >> 4)) * 2u;
-  const unsigned short* wfrag = wl + (lane & 15) * XCD_LDW + wave * kw + 8 * (lane >> 4);
-  __syncthreads();
-  // recurrence role: its B fragments of R; x role: its B fragments of W_x (both for the whole sequence)
-  u16x8 wreg[NGX > 4 ? NGX : 4][4];
-  const int ngx = ni >> 5, gx0 = wave * NGX;
-  if (!xrole) {
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) wreg[g][j] = *reinterpret_cast<const u16x8*>(wfrag + j * 16 * XCD_LDW + (g < ngrp ? g : 0) * 32);
-  } else {
-    const BufF32 wxbuf = make_buf(reinterpret_cast<const float*>(a.Wxb), (size_t)nd * 4 * no * ni * 2);
-#pragma unroll
-    for (int g = 0; g < NGX; g++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int col = ct * 64 + j * 16 + (lane & 15);
-        const bool lv = col < 4 * no && gx0 + g < ngx;
-        wreg[g][j] = __builtin_bit_cast(u16x8, buf_load4(wxbuf, lv ? (unsigned)(((dir * 4 * no + col) * ni + (gx0 + g) * 32 + 8 * (lane >> 4)) * 2) : BUF_OOB));
-      }
-  }
-  f32x4 bias4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  if (!xrole && mine) bias4 = *reinterpret_cast<const f32x4*>(a.bias + dir * 4 * no + 4 * cell);
-  // x role: staging of the 16 lines' input rows, chunk c = rt + 256 i of the [16 lines][ni / 8] chunk grid
-  const int XLD = ni + 8;
-  unsigned short* const xs0 = wl;                              // rows of even steps; odd steps: + 16 XLD
-  const BufF32 xbuf = make_buf(reinterpret_cast<const float*>(a.Xb), (size_t)a.N * a.x_ld * 2);
-  const int cpr = ni >> 3;
-  int xoff[NX], xT[NX], xcol[NX], xlds[NX];
-#pragma unroll
-  for (int i = 0; i < NX; i++) {
-    const int c = rt + WIDE_THREADS * i;
-    const int row = c / cpr, cc = c - row * cpr;
-    const int ln = zb * 16 + row;
-    xoff[i] = 0; xT[i] = 0;
-    if (xrole && row < 16 && ln < a.bs) { xoff[i] = a.line_off[ln]; xT[i] = a.line_off[ln + 1] - xoff[i]; }
-    xcol[i] = cc * 8;
-    xlds[i] = row < 16 ? row * XLD + cc * 8 : -1;
-  }
-  auto x_load = [&](const int sg, f32x4 (&r)[NX]) {
-#pragma unroll
-    for (int i = 0; i < NX; i++) {
-      const bool lv = sg < xT[i];
-      const int fr = xoff[i] + (dir == 0 ? sg : xT[i] - 1 - sg);
-      r[i] = buf_load4(xbuf, lv ? (unsigned)(fr * a.x_ld + xcol[i]) * 2u : BUF_OOB);
-    }
-  };
-  auto x_stage = [&](const int sg, const f32x4 (&r)[NX]) {
-    unsigned short* xs = xs0 + (sg & 1) * 16 * XLD;
-#pragma unroll
-    for (int i = 0; i < NX; i++)
-      if (xlds[i] >= 0) *reinterpret_cast<f32x4*>(xs + xlds[i]) = r[i];
-  };
-  // x-part of step sg: this wave's quarter of the contraction -> its partial tile
-  auto x_partial = [&](const int sg) {
-    const unsigned short* xfrag = xs0 + (sg & 1) * 16 * XLD + (lane & 15) * XLD + gx0 * 32 + 8 * (lane >> 4);
-    f32x4 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
-    u16x8 xa[NGX];
-#pragma unroll
-    for (int g = 0; g < NGX; g++) xa[g] = *reinterpret_cast<const u16x8*>(xfrag + (gx0 + g < ngx ? g : 0) * 32);
-#pragma unroll
-    for (int g = 0; g < NGX; g++)
-      if (gx0 + g < ngx) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[j] = mfma16x16x32_bf16(xa[g], wreg[g][j], acc[j]);
-      }
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) xred[(wave * 16 + (lane >> 4) * 4 + q) * 68 + j * 16 + (lane & 15)] = acc[j][q];
-  };
-  auto x_sum = [&](const int sg) {   // thread (line ml, cell c16): the four gates of its cell
-    f32x4 k = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int w = 0; w < WIDE_NW; w++) {
-      const f32x4 p = *reinterpret_cast<const f32x4*>(&xred[(w * 16 + ml) * 68 + c16 * 4]);
-#pragma unroll
-      for (int q = 0; q < 4; q++) k[q] += p[q];
-    }
-    *reinterpret_cast<f32x4*>(&xsum[((sg & 1) * 16 + ml) * 68 + c16 * 4]) = k;
-  };
-  // prologue of the x role: rows of steps 0 and 1 in LDS, x-part of step 0 summed, rows of step 2 requested
-  f32x4 xr[NX];
-  __syncthreads();                                             // every wave has its fragments: the staging area is free
-  if (xrole) { x_load(0, xr); x_stage(0, xr); x_load(1, xr); x_stage(1, xr); }
-  __syncthreads();
-  if (xrole) x_partial(0);
-  __syncthreads();
-  if (xrole) { x_sum(0); x_load(2, xr); }
-  float c_prev = 0.0f;
-  auto store_frame = [&](const f32x4 act, const float c_new, const float h, const unsigned hp, const long long n, const int sg, const bool live) {
-    if (live) {
-      *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
-      a.C[(n * nd + dir) * no + cell] = c_new;
-      if (!a.skip_h) a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
-      if (!a.skip_s) {
-        float* srow = a.S + (size_t)dir * a.sdir;
-        if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
-        if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
-      }
-    }
-    if (live && !(c16 & 1)) {
-      *reinterpret_cast<unsigned*>(a.Hb + ring_block(sg & 1, nd, dir, nblk, zb, nkb) + ring_elem(cell >> 5, ml, cell & 31)) = hp;
-      if (a.Hbf) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
-      if (a.Sbf) {
-        unsigned short* sb = a.Sbf + (size_t)dir * a.sbf_dir + a.sbf_ofs + cell;
-        if (sg == 0) *reinterpret_cast<unsigned*>(sb + (size_t)n * a.sbf_ld) = 0u;
-        if (sg + 1 < T) *reinterpret_cast<unsigned*>(sb + (size_t)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.sbf_ld) = hp;
-      }
-    }
-  };
-  XCD_PROF_DECL;
-  for (int sg = 0; sg < a.tmax; sg++) {
-    XCD_STAMP(0);   // loop top
-    __syncthreads();                                           // B0: xsum[sg & 1] complete; the x rows of step sg are consumed
-    if (xrole) {   // poll segment: rows of step sg + 2 into the buffer step sg's rows left, rows of sg + 3 requested
-      x_stage(sg + 2, xr);
-      x_load(sg + 3, xr);
-    }
-    XCD_STAMP(8);
-    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;   // (B1, B2)
-    XCD_STAMP(1);   // group wait
-    f32x4 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) acc[j][q] = 0.0f;
-    if (xrole) {
-      x_partial(sg + 1);                                       // ring segment: next step's x-part
-    } else {
-      f32x4 ra[4];
-      const int am = zb * 16 + (lane & 15);
-      const unsigned arow = (sg >= 1 && am < a.bs) ? ring_block((sg - 1) & 1, nd, dir, nblk, zb, nkb) * 2u + akl : BUF_OOB_BASE;
-#pragma unroll
-      for (int g = 0; g < 4; g++) ra[g] = buf_load4_dev(abuf, g < ngrp ? arow + (unsigned)g * 1024u : BUF_OOB);
-      SCHED_FENCE();
-      XCD_STAMP(2);   // loads issued
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        if (g < ngrp) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc[j] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[g]), wreg[g][j], acc[j]);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) red[(wave * 16 + (lane >> 4) * 4 + q) * 68 + j * 16 + (lane & 15)] = acc[j][q];
-    }
-    XCD_STAMP(3);
-    __syncthreads();                                           // B3
-    XCD_STAMP(4);
-    if (xrole) {
-      x_sum(sg + 1);                                           // epilogue segment: the partial tiles of step sg + 1 summed
-    } else {
-      const bool live = mine && sg < T;
-      const long long n = off + (dir == 0 ? sg : T - 1 - sg);
-      float h = 0.0f, c_new = 0.0f;
-      f32x4 act = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (live) {
-        const f32x4 xp = *reinterpret_cast<const f32x4*>(&xsum[((sg & 1) * 16 + ml) * 68 + c16 * 4]);
-        f32x4 k;
-#pragma unroll
-        for (int q = 0; q < 4; q++) k[q] = xp[q];
-#pragma unroll
-        for (int w = 0; w < WIDE_NW; w++) {
-          const f32x4 p = *reinterpret_cast<const f32x4*>(&red[(w * 16 + ml) * 68 + c16 * 4]);
-#pragma unroll
-          for (int q = 0; q < 4; q++) k[q] += p[q];
-        }
-        const float gi = gate_act(k[0] + bias4[0], false), gf = gate_act(k[1] + bias4[1], false),
-                    go = gate_act(k[2] + bias4[2], false), ci = gate_act(k[3] + bias4[3], true);
-        c_new = ci * gi + gf * c_prev;
-        h = gate_act(c_new, true) * go;
-        act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
-      }
-      const float hn = quad_xor1(h);
-      const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);
-      store_frame(act, c_new, h, hp, n, sg, live);
-      c_prev = c_new;
-      XCD_STAMP(5);
-      drain_vmem();
-      XCD_STAMP(6);
-    }
-    __syncthreads();                                           // B4
-    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
-    XCD_STAMP(7);
-  }
-  if (threadIdx.x < WIDE_THREADS) XCD_PROF_WRITE(xcd, ct, ntile);
-}
-inline __host__ __device__ int xcd_fwd_fx2_lds_bytes() { return 64 * XCD_LDW * 2 + (2 * WIDE_NW + 2) * 16 * 68 * 4 + 64; }
+// (Round 4, measured and not kept: the x-part of a 1024-input layer on FOUR EXTRA WAVES of the same workgroup -- recurrence and
+// x-role meeting only at the workgroup's barriers, x rows staged through LDS a step ahead -- ran the configs[4] forward passes
+// at 1.93 ms against 1.67 ms with the hoisted product: 256 VGPRs + spills for the x-role's 128 registers of W_x fragments,
+// and five barriers per step that couple the two roles.  profiles/r04_fused_wx_variants.txt; the kernel is in the history.)
 
 // ---- persistent backward recurrence, same scheme: 16 lines x 16 cells per workgroup, its 16 weight rows (R^T, 2048 k)
 // resident in LDS, the group's bf16 delta ring exchanged through the XCD's L2, the carried state delta in a register ----
@@ -1799,8 +1555,6 @@ template <int MT>
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16(LstmWideArgs a) { lstm_xcd_fwd_bf16_body<MT>(a); xcd_finish(a); }
 template <int NGX>
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16_fx(LstmWideArgs a) { lstm_xcd_fwd_bf16_fx_body<NGX>(a); xcd_finish(a); }
-template <int NGX>
-__global__ __launch_bounds__(2 * WIDE_THREADS) void lstm_xcd_fwd_bf16_fx2(LstmWideArgs a) { lstm_xcd_fwd_bf16_fx2_body<NGX>(a); xcd_finish(a); }
 template <int MT>
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a) { lstm_xcd_bwd_bf16_body<MT>(a); xcd_finish(a); }
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a) { lstm_xcd_fwd_f32_body(a); xcd_finish(a); }
