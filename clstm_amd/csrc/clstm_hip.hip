@@ -425,6 +425,7 @@ static int g_debug_fail_claims = 0;      // tests: this many upcoming persistent
 // fx_ngx > 0 (forward, bf16): try ONLY the persistent kernel with the input projection folded in (lstm_xcd_fwd_bf16_fx<fx_ngx>);
 // returns false -- nothing launched or nothing written -- if it does not apply or its placement check failed: the caller then
 // runs the hoisted product and calls again with fx_ngx = 0.
+static std::map<const void*, int> g_stamp_base;   // per sync buffer: where the group-barrier stamps of its next persistent launch start
 static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s, bool bf16 = false, int fx_ngx = 0) {
   g_wide_persistent = false;
   REQUIRE((double)a.N * a.ndir * 4 * a.no * 4 < 2147483000.0,
@@ -449,7 +450,17 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
       a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
       a.debug_fail_claim = g_debug_fail_claims > 0 ? (g_debug_fail_claims--, 1) : 0;
-      // (the sync words are zero: DevBuf zero-fills, and every persistent launch returns them to zero as its last act)
+      // (the counter words are zero: DevBuf zero-fills, and every persistent launch returns them to zero as its last act;
+      // the stamps of the group barriers keep counting up: lstm_wide.h:xcd_finish)
+      {
+        int& base = g_stamp_base[(const void*)sync.p];
+        if (base > (1 << 30)) {   // (once per ~2 million launches)
+          HIPCHECK(hipMemsetAsync(sync.p, 0, XcdSyncLayout::WORDS * sizeof(int), s));
+          base = 0;
+        }
+        a.stamp_base = base;
+        base += tmax + 2;
+      }
       a.out_sticky = dev_err_words();
       a.out_host = g_xcd_outcome.prepare();
       coop_set_smem(kernel, smem);

@@ -68,6 +68,7 @@ struct LstmWideArgs {
   const unsigned short* Wxb;
   const float* bias;
   int debug_fail_claim;         // tests: the placement check of the persistent kernels reports failure (clstm_debug_set_device_error 4)
+  int stamp_base;               // persistent kernels: the group barrier's stamps of this launch are stamp_base + steps finished (see xcd_finish)
   int* out_sticky;              // persistent kernels: the process's sticky device error word (takes a non-zero outcome), or null
   int* out_host;                // ... and a pinned host word that takes the outcome (0 = fine) when the launch has ended, or null
   long long* prof;              // diagnostics build (CLSTM_LSTM_PROF) only: per-phase cycle sums, [2 workgroups][4 waves][12]; else null
@@ -628,10 +629,16 @@ inline __host__ __device__ size_t ring32_floats(int nd, int bs, int kp) { return
 #define XCD_STAMP(k) do {} while (0)
 #define XCD_PROF_WRITE(xcd, slot, ntile) do {} while (0)
 #endif
-// EXITED: workgroups that have left the kernel; the last one publishes the launch's outcome (LAST_ERROR -- the only word that
-// survives --, the process's sticky error word, a pinned host word) and returns every other word to zero for the next launch:
+// EXITED: workgroups that have left the kernel; the last one publishes the launch's outcome (LAST_ERROR, the process's sticky
+// error word, a pinned host word) and returns the COUNTER words (ARRIVED, ERROR, SLOT0.., EXITED) to zero for the next launch:
 // no memset, no outcome kernel and no event record around a pass (they cost ~15 us of stream time per pass, four passes per
-// configs[4] step).
+// configs[4] step).  Those words are only ever touched by agent-scope atomics, which are coherent across the XCDs.  The
+// GROUP lines are NOT: a group's tiles write their stamps with plain stores that live (dirty) in their XCD's L2, and a zero
+// written by a workgroup of ANOTHER XCD would race with that line's write-back at the end of the kernel -- the next launch
+// could then find last launch's stamps and walk through its group barriers (seen once as a 2e-5 error in one of 30 runs of a
+// ragged f32 case).  So the stamps are never reset: every launch counts from its own base (LstmWideArgs::stamp_base, the host
+// adds tmax + 2 per launch), and a line has one writing XCD for ever.
+
 struct XcdSyncLayout { enum { ARRIVED = 0, ERROR = 1, SLOT0 = 8, EXITED = 16, LAST_ERROR = 17, GROUP0 = 32, GROUP_STRIDE = 32, WORDS = 32 + 8 * 32 }; };
 constexpr int XCD_LDW = 512 + 8;        // halfs per resident weight row (conflict-free ds_read_b128 fragments), kp16 <= 512
 inline __host__ __device__ int xcd_fwd_lds_bytes(int mt = 1) { return 64 * XCD_LDW * 2 + WIDE_NW * mt * 16 * 68 * 4 + 64; }
@@ -720,7 +727,7 @@ DEVFN void xcd_finish(const LstmWideArgs& a) {
   int* const sync = a.sync;
   if (__hip_atomic_fetch_add(sync + XcdSyncLayout::EXITED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (int)gridDim.x - 1) return;
   const int e = __hip_atomic_load(sync + XcdSyncLayout::ERROR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int w = 0; w < XcdSyncLayout::WORDS; w++)
+  for (int w = 0; w < XcdSyncLayout::GROUP0; w++)   // (the counter words; the groups' stamp lines keep counting)
     __hip_atomic_store(sync + w, w == XcdSyncLayout::LAST_ERROR ? e : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (e && a.out_sticky) __hip_atomic_store(a.out_sticky, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.out_host) store_i32_wt(a.out_host, e);
@@ -830,7 +837,7 @@ DEVFN void lstm_xcd_fwd_bf16_body(const LstmWideArgs& a) {
         for (int q = 0; q < 4; q++) acc[j][i][q] = 0.0f;
     f32x4 gx_next[MT];
     XCD_STAMP(0);   // loop top
-    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;   // h_{s-1} of the whole group is in the L2
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, a.stamp_base + sg, sync + XcdSyncLayout::ERROR, flag)) return;   // h_{s-1} of the whole group is in the L2
     XCD_STAMP(1);   // group wait
     // ---- 16 MT lines x 64 columns, split-K over the four waves ----
     f32x4 ra[4][MT];
@@ -900,7 +907,7 @@ DEVFN void lstm_xcd_fwd_bf16_body(const LstmWideArgs& a) {
     drain_vmem();
     XCD_STAMP(6);   // stores acknowledged
     __syncthreads();
-    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
+    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, a.stamp_base + sg + 1);
     XCD_STAMP(7);   // barrier + arrival
   }
   XCD_PROF_WRITE(xcd, ct, ntile);
@@ -1058,7 +1065,7 @@ DEVFN void lstm_xcd_fwd_bf16_fx_body(const LstmWideArgs& a) {
         }
     }
     XCD_STAMP(8);   // x-part: fragments + MFMAs (in the shadow of the hand-off)
-    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, a.stamp_base + sg, sync + XcdSyncLayout::ERROR, flag)) return;
     XCD_STAMP(1);   // group wait
     f32x4 ra[4];
     {
@@ -1110,7 +1117,7 @@ DEVFN void lstm_xcd_fwd_bf16_fx_body(const LstmWideArgs& a) {
     drain_vmem();                                            // (also: the rows of step sg + 1, requested a step ago, are in registers)
     XCD_STAMP(6);
     __syncthreads();
-    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
+    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, a.stamp_base + sg + 1);
     XCD_STAMP(7);
     // in the shadow of the hand-off: next step's rows into LDS (every wave read this step's fragments two barriers ago), the
     // rows of the step after that requested
@@ -1213,7 +1220,7 @@ DEVFN void lstm_xcd_bwd_bf16_body(const LstmWideArgs& a) {
   XCD_PROF_DECL;
   for (int sg = 0; sg < a.tmax; sg++) {
     XCD_STAMP(0);   // loop top
-    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, sync + XcdSyncLayout::ERROR, flag)) return;
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, a.stamp_base + sg, sync + XcdSyncLayout::ERROR, flag)) return;
     XCD_STAMP(1);   // group wait
     f32x4 acc[MT];
 #pragma unroll
@@ -1280,7 +1287,7 @@ DEVFN void lstm_xcd_bwd_bf16_body(const LstmWideArgs& a) {
     drain_vmem();
     XCD_STAMP(6);   // stores acknowledged
     __syncthreads();
-    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, slot, sg + 1);
+    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, slot, a.stamp_base + sg + 1);
     XCD_STAMP(7);   // barrier + arrival
 #pragma unroll
     for (int i = 0; i < MT; i++) {
@@ -1364,7 +1371,7 @@ DEVFN void lstm_xcd_fwd_f32_body(const LstmWideArgs& a) {
   for (int sg = 0; sg < a.tmax; sg++) {
     const bool live = mine && sg < T;
     const long long n = off + (dir == 0 ? sg : T - 1 - sg);
-    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, a.sync + XcdSyncLayout::ERROR, flag)) return;
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, a.stamp_base + sg, a.sync + XcdSyncLayout::ERROR, flag)) return;
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -1423,7 +1430,7 @@ DEVFN void lstm_xcd_fwd_f32_body(const LstmWideArgs& a) {
     gx = gx_next;
     drain_vmem();
     __syncthreads();
-    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
+    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, a.stamp_base + sg + 1);
   }
 }
 
@@ -1484,7 +1491,7 @@ DEVFN void lstm_xcd_bwd_f32_body(const LstmWideArgs& a) {
     const bool live = mine && sg < T;
     const int s = T - 1 - sg;
     const long long n = off + (dir == 0 ? s : sg);
-    if (sg >= 1 && !xcd_wait_group(gcount, ntile, sg, a.sync + XcdSyncLayout::ERROR, flag)) return;
+    if (sg >= 1 && !xcd_wait_group(gcount, ntile, a.stamp_base + sg, a.sync + XcdSyncLayout::ERROR, flag)) return;
     f32x4 acc;
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] = 0.0f;
@@ -1539,7 +1546,7 @@ DEVFN void lstm_xcd_bwd_f32_body(const LstmWideArgs& a) {
     cur = nxt;
     drain_vmem();
     __syncthreads();
-    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, sg + 1);
+    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, a.stamp_base + sg + 1);
   }
 }
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call: GPU parity tests, smoke, bench lines, rocprof kernel stats, PMC passes, diagnostics.
 # Usage (from the build container):  gpurun --timeout 2400 -- 'bash scripts/gpu_round.sh r02'
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$ROOT"
 OUT="$ROOT/gpurun_out/$TAG"
@@ -31,6 +31,11 @@ echo "=== bench 2xBiLSTM(512) shape: f32 / bf16 hoisted GEMMs / bf16 MFMA everyw
 B --config b2 --steps 10 --warmup 3 --profile-steps 2 > "$OUT/bench_b2.json" 2>/dev/null; cut -c1-200 "$OUT/bench_b2.json"
 B --config b2 --steps 10 --warmup 3 --profile-steps 2 --bf16 > "$OUT/bench_b2_bf16.json" 2>/dev/null; cut -c1-200 "$OUT/bench_b2_bf16.json"
 
+echo "=== one configs[4] step under rocprofv3 --kernel-trace"
+bash "$ROOT/scripts/gpu_b2timeline.sh" "$TAG" > "$OUT/b2_timeline.log" 2>&1; tail -3 "$OUT/b2_timeline.log"
+cd "$ROOT"
+echo "=== the reference's own drivers over the INetwork adapter (test-ocr.sh scenario): rate of the literal drop-in"
+timeout 300 python -m pytest tests/test_integration_shim.py -m gpu -q -s -k unmodified 2>&1 | grep -E "drop-in|passed|failed" | tee "$OUT/drop_in_rate.txt"
 echo "=== rocprofv3 kernel stats + one-step timeline"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof.log" 2>&1
@@ -67,6 +72,6 @@ CLSTM_FW_TRACE="$OUT/fw_trace.txt" timeout 300 python bench.py --steps 3 --warmu
 python scripts/fwtrace_summary.py "$OUT/fw_trace.txt" > "$OUT/fwd_timeline.txt" 2>&1; head -3 "$OUT/fwd_timeline.txt"; tail -2 "$OUT/fwd_timeline.txt"
 timeout 300 python scripts/gpu_ctcprof.py > "$OUT/ctc_phase_cycles.txt" 2>&1; tail -6 "$OUT/ctc_phase_cycles.txt"
 # per-phase stamps of the persistent bf16 recurrences of wide layers (diagnostics build; built here if it is missing)
-[ -f clstm_amd/lib/libclstm_hip_prof.so ] || make -s -C clstm_amd/csrc ../lib/libclstm_hip_prof.so > /dev/null 2>&1
+make -s -C clstm_amd/csrc ../lib/libclstm_hip_prof.so > /dev/null 2>&1   # (stale or missing: rebuilt here)
 CLSTM_HIP_VARIANT=prof timeout 300 python scripts/gpu_xcdprof.py 2>&1 | grep -v amdgpu.ids > "$OUT/xcd_phase_cycles.txt"; head -11 "$OUT/xcd_phase_cycles.txt"
 echo "=== done"
