@@ -227,7 +227,8 @@ static void launch_lstm(bool fwd, int nk4, int ku, LstmSeqArgs a, int bs, int nt
 template <int NK4, int KU>
 static void launch_bwd_dw(const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s) {
   const size_t smem = (2 * 16 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
-  CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec);
+  if (g.x3) CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU, true>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec);
+  else CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU, false>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec);
 }
 static bool launch_lstm_bwd_dw(int nk4, int ku, const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s) {
 #define CASE_(N, K) if (nk4 == N && ku == K) { launch_bwd_dw<N, K>(a, g, nrec, ngemm, nthreads, s); check_launch(); return true; }
@@ -1692,7 +1693,8 @@ struct Net {
     launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
     timing.end(s);
     timing.begin("gemm_gates_dw", s);
-    CLSTM_LAUNCH(gemm_dw_kernel, dim3(nblk), dim3(256), 0, s, g);
+    if (g.x3) CLSTM_LAUNCH(gemm_dw_kernel<true>, dim3(nblk), dim3(256), 0, s, g);
+    else CLSTM_LAUNCH(gemm_dw_kernel<false>, dim3(nblk), dim3(256), 0, s, g);
     timing.end(s);
     check_launch();
   }

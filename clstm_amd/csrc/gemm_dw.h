@@ -406,22 +406,26 @@ DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, 
 // grid mode: workgroup `block` computes one item.  Workgroup b runs on XCD b % 8: XCD x takes slabs x, x+8, ... (all
 // output tiles of a slab pull its frames through ONE L2), and because slabs are listed in readiness order every XCD
 // gets early and late ones alike
+// X3: the item form is a compile-time choice (and so part of the kernel's NAME: a profile of a process that runs both forms --
+// bench.py's strict_f32 leg -- keeps their launch statistics apart); it must agree with a.x3 != 0
+template <bool X3>
 DEVFN void gemm_dw_body(const GemmDwArgs& a, float* smem, unsigned block) {
   if (block == 0) { gemm_dw_monitor(a); return; }   // the first workgroup behind the recurrence's watches the lines
   block -= 1;
-  const unsigned nextra = a.x3 ? (unsigned)a.xnslabs * a.xgx * a.xgy : 0u;   // independent items first (see GemmDwArgs)
-  if (block < nextra) { gemm_dw_item_x3(a, smem, block / (a.xgx * a.xgy), block % (a.xgx * a.xgy), true); return; }
+  const unsigned nextra = X3 ? (unsigned)a.xnslabs * a.xgx * a.xgy : 0u;   // independent items first (see GemmDwArgs)
+  if (X3 && block < nextra) { gemm_dw_item_x3(a, smem, block / (a.xgx * a.xgy), block % (a.xgx * a.xgy), true); return; }
   block -= nextra;
   const unsigned tiles = a.gx * a.gy;
   const unsigned xcd = block & 7u, idx = block >> 3;
   const unsigned si = (idx / tiles) * 8u + xcd;
   if (si >= (unsigned)a.nslabs) return;
-  if (a.x3) gemm_dw_item_x3(a, smem, si, idx % tiles);
+  if constexpr (X3) gemm_dw_item_x3(a, smem, si, idx % tiles);
   else gemm_dw_item(a, smem, si, idx % tiles);
 }
+template <bool X3>
 __global__ __launch_bounds__(256) void gemm_dw_kernel(GemmDwArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[DW_SMEM_FLOATS];
-  gemm_dw_body(a, smem, blockIdx.x);
+  gemm_dw_body<X3>(a, smem, blockIdx.x);
 }
 
 }  // namespace clstm

@@ -14,7 +14,7 @@
 
 namespace clstm {
 
-template <int NK4, int KU>
+template <int NK4, int KU, bool X3>
 __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_dw_kernel(LstmSeqArgs a, GemmDwArgs g, int nrec) {
   __shared__ __attribute__((aligned(16))) float gsm[DW_SMEM_FLOATS];
   if ((int)blockIdx.x < nrec) {
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_dw
     if (g.trace && threadIdx.x == 0) { g.trace[blockIdx.x * 4] = t0; g.trace[blockIdx.x * 4 + 2] = wall_clock(); }
   } else {
     if (threadIdx.x >= 256) return;   // the GEMM role is four waves; the others retire (a barrier counts live waves only)
-    gemm_dw_body(g, gsm, blockIdx.x - (unsigned)nrec);   // the monitor, then one item per workgroup in dispatch order
+    gemm_dw_body<X3>(g, gsm, blockIdx.x - (unsigned)nrec);   // the monitor, then one item per workgroup in dispatch order
   }
 }
 
