@@ -9,9 +9,23 @@
 
 namespace clstmhost {
 
+// acc[i] += in[i + j] * mask[j] for every tap j in the reference's order: each output keeps its own double accumulator and
+// the sequence of roundings of extras.cc:76-84 (float product, double sum, taps ascending), but the outputs advance together,
+// so the loop runs at vector throughput instead of one dependent double add per tap (the masks are 2*(1+3*sigma)+1 =
+// 531 taps for an 88-pixel-high line: 30 ms per line otherwise).  No contraction (-ffp-contract=off in the Makefile).
+__attribute__((optimize("O3"), target_clones("avx512f", "avx2", "default")))
+static void gauss1d_taps(double* acc, const float* pad, const float* mask, int n, int m) {
+  for (int j = 0; j < m; j++) {
+    const float mj = mask[j];
+    const float* p = pad + j;
+    for (int i = 0; i < n; i++) acc[i] += (double)(p[i] * mj);
+  }
+}
+
 inline void gauss1d(vector<float>& out, const vector<float>& in, float sigma) {  // extras.cc:58-86
   const int n = (int)in.size();
   out.assign(n, 0.0f);
+  if (n == 0) return;
   const int range = 1 + int(3.0 * sigma);
   vector<float> mask(2 * range + 1);
   for (int i = 0; i <= range; i++) {
@@ -22,16 +36,14 @@ inline void gauss1d(vector<float>& out, const vector<float>& in, float sigma) { 
   for (float m : mask) total += m;
   for (float& m : mask) m /= total;
   const int m = (int)mask.size();
-  for (int i = 0; i < n; i++) {
-    double acc = 0.0;
-    for (int j = 0; j < m; j++) {
-      int index = i + j - range;
-      if (index < 0) index = 0;
-      if (index >= n) index = n - 1;
-      acc += in[index] * mask[j];
-    }
-    out[i] = (float)acc;
-  }
+  // the clamped index of :79-81 as a padded copy: pad[k] = in[clamp(k - range)]
+  static thread_local vector<float> pad;
+  static thread_local vector<double> acc;
+  pad.resize((size_t)n + 2 * range);
+  for (int k = 0; k < n + 2 * range; k++) pad[k] = in[std::min(std::max(k - range, 0), n - 1)];
+  acc.assign(n, 0.0);
+  gauss1d_taps(acc.data(), pad.data(), mask.data(), n, m);
+  for (int i = 0; i < n; i++) out[i] = (float)acc[i];
 }
 
 inline void gauss2d(Image& a, float sx, float sy) {  // extras.cc:108-121

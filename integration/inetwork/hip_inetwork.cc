@@ -9,6 +9,9 @@
 #include "utils.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <set>
 
 #include "../../clstm_amd/host/clstmhl.h"   // Model (prefab layout, rinit, model file), CenterNormalizer, PNG
@@ -74,6 +77,32 @@ void INetwork::setLearningRate(Float lr, Float momentum) {   // clstm.cc:163-166
   attr.set("momentum", momentum);
 }
 
+// ---- where a drop-in step spends its time (CLSTM_ADAPTER_TIMING=1: one line per section on stderr at exit) --------------
+// The reference's drivers prepare every sample on the host (read_png + CenterNormalizer, clstmocrtrain.cc:167-172) in front
+// of each forward(); this splits their `steptime` into that part and the part behind the INetwork surface.
+struct AdapterClock {
+  enum { FORWARD, CTC, BACKWARD, UPDATE, DECODE, NORMALIZE, PNG, NSEC };
+  double ms[NSEC] = {0}; long calls[NSEC] = {0};
+  bool on = false;
+  AdapterClock() { const char* e = getenv("CLSTM_ADAPTER_TIMING"); on = e && atoi(e) != 0; }
+  ~AdapterClock() {
+    if (!on) return;
+    static const char* names[NSEC] = {"forward", "ctc_align", "backward", "sgd_update", "trivial_decode", "normalizer", "read_png"};
+    for (int i = 0; i < NSEC; i++)
+      if (calls[i]) fprintf(stderr, "adapter_time %-14s %8ld calls %10.3f ms each %12.1f ms total\n", names[i], calls[i], ms[i] / calls[i], ms[i]);
+  }
+};
+static AdapterClock g_clock;
+struct Timed {
+  int which; std::chrono::steady_clock::time_point t0;
+  explicit Timed(int w) : which(w) { if (g_clock.on) t0 = std::chrono::steady_clock::now(); }
+  ~Timed() {
+    if (!g_clock.on) return;
+    g_clock.ms[which] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    g_clock.calls[which]++;
+  }
+};
+
 // ---- the network: a prefab of clstm_prefab.cc:23-109 inside the device library ----------------------------------------
 class HipNetwork : public INetwork {
  public:
@@ -112,6 +141,7 @@ class HipNetwork : public INetwork {
   }
   // inputs: Sequence (ninput x bs) x T  ->  bs packed lines of T frames; ONE fused forward for all of them
   void forward() override {
+    Timed timed(AdapterClock::FORWARD);
     T = inputs.size(); bs = inputs.cols();
     const int ni = inputs.rows(), nc = model.desc.nclasses;
     if (T <= 0 || bs <= 0) hip_raise("forward: empty input sequence");
@@ -133,6 +163,7 @@ class HipNetwork : public INetwork {
   }
   // outputs[t].d holds the deltas the caller computed (clstmhl.h:211-212): ONE fused backward
   void backward() override {
+    Timed timed(AdapterClock::BACKWARD);
     const int nc = model.desc.nclasses;
     if (outputs.size() != T || outputs.cols() != bs || T <= 0) hip_raise("backward without a matching forward");
     for (int b = 0; b < bs; b++)
@@ -142,6 +173,7 @@ class HipNetwork : public INetwork {
     chk(clstm_net_backward(h), "clstm_net_backward");
   }
   void update() {
+    Timed timed(AdapterClock::UPDATE);
     chk(clstm_net_update(h), "clstm_net_update");
     nseq = 0; nsteps = 0;
   }
@@ -258,6 +290,7 @@ void mktargets(Sequence& seq, Classes& transcript, int ndim) {   // ctc.cc:148-1
   }
 }
 static void align_states(Sequence& posteriors, Sequence& outputs, const vector<int>& states) {
+  Timed timed(AdapterClock::CTC);
   const int T = outputs.size(), nc = outputs.rows(), S = (int)states.size();
   if (outputs.cols() != 1) hip_raise("ctc_align_targets: batch size 1 (ctc.cc:59)");
   DevArr probs((size_t)T * nc), al((size_t)T * nc), dz((size_t)T * nc);
@@ -292,6 +325,7 @@ void trivial_decode(Classes& cs, Sequence& outputs, int batch, vector<int>* locs
   cs.clear();
   if (locs) locs->clear();
   if (T == 0) return;
+  Timed timed(AdapterClock::DECODE);
   DevArr probs((size_t)T * nc);
   for (int t = 0; t < T; t++)
     for (int c = 0; c < nc; c++) probs.p[(size_t)t * nc + c] = outputs[t].v(c, batch);
@@ -318,12 +352,14 @@ static void from_image(Tensor2& a, const clstmhost::Image& im) {
 struct HostCenterNormalizer : INormalizer {
   clstmhost::CenterNormalizer nz;
   void measure(TensorMap2 line) override {
+    Timed timed(AdapterClock::NORMALIZE);
     nz.target_height = target_height; nz.smooth2d = smooth2d; nz.smooth1d = smooth1d; nz.range = range;
     clstmhost::Image im;
     to_image(im, line);
     guarded([&] { nz.measure(im); });
   }
   void normalize(Tensor2& out, TensorMap2 in) override {
+    Timed timed(AdapterClock::NORMALIZE);
     clstmhost::Image im, o;
     to_image(im, in);
     guarded([&] { nz.normalize(o, im); });
@@ -336,6 +372,7 @@ INormalizer* make_Normalizer(const string& name) {
   hip_raise("unknown normalizer name: " + name + " (MI355X path: center)");
 }
 void read_png(Tensor2& image, const char* name) {
+  Timed timed(AdapterClock::PNG);
   clstmhost::Image im;
   guarded([&] { clstmhost::read_png(im, name); });
   from_image(image, im);

@@ -114,7 +114,8 @@ def test_reference_test_ocr_scenario_through_the_unmodified_reference_drivers(tm
     (tmp_path / "textline.gt.txt").write_text("performance analysis\n", encoding="utf-8")
     lst = tmp_path / "_ocrtest.txt"
     lst.write_text(str(png) + "\n")
-    env = dict(os.environ, ntrain="201", hidden="50", lrate="1e-2", save_name=str(tmp_path / "_ocrtest"), seed="0.222", report_time="1")
+    env = dict(os.environ, ntrain="201", hidden="50", lrate="1e-2", save_name=str(tmp_path / "_ocrtest"), seed="0.222", report_time="1",
+               CLSTM_ADAPTER_TIMING="1")
     r = subprocess.run([os.path.join(REFBIN, "clstmocrtrain_hip"), str(lst)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2000:])
     assert "TRU performance analysis" in r.stdout and "saving" in r.stdout and "steptime" in r.stdout
@@ -127,3 +128,7 @@ def test_reference_test_ocr_scenario_through_the_unmodified_reference_drivers(tm
     # the literal drop-in's rate, for INTEGRATION.md (one line per update, every Sequence through host memory)
     st = [float(l.split()[1]) for l in r.stdout.splitlines() if l.startswith("steptime")]
     print("drop-in (reference drivers + INetwork adapter): steptime %.2f ms per line (T = 447 frames)" % (1e3 * sorted(st)[len(st) // 2]))
+    # ... and where it goes (CLSTM_ADAPTER_TIMING=1): host preparation of the sample against the calls behind INetwork
+    split = [l for l in r.stderr.splitlines() if l.startswith("adapter_time")]
+    assert any("forward" in l for l in split) and any("normalizer" in l for l in split), r.stderr[-1500:]
+    for l in split: print("drop-in", l)
