@@ -27,14 +27,20 @@ inline void gauss1d(vector<float>& out, const vector<float>& in, float sigma) { 
   out.assign(n, 0.0f);
   if (n == 0) return;
   const int range = 1 + int(3.0 * sigma);
-  vector<float> mask(2 * range + 1);
-  for (int i = 0; i <= range; i++) {
-    double y = exp(-i * i / 2.0 / sigma / sigma);
-    mask[range + i] = mask[range - i] = (float)y;
+  // the mask of :61-71 depends on sigma only: gauss2d asks for the same one for every column / every row of a line
+  static thread_local vector<float> mask;
+  static thread_local float mask_sigma = -1.0f;
+  if (mask_sigma != sigma || (int)mask.size() != 2 * range + 1) {
+    mask.assign(2 * range + 1, 0.0f);
+    for (int i = 0; i <= range; i++) {
+      double y = exp(-i * i / 2.0 / sigma / sigma);
+      mask[range + i] = mask[range - i] = (float)y;
+    }
+    float total = 0.0f;
+    for (float m : mask) total += m;
+    for (float& m : mask) m /= total;
+    mask_sigma = sigma;
   }
-  float total = 0.0f;
-  for (float m : mask) total += m;
-  for (float& m : mask) m /= total;
   const int m = (int)mask.size();
   // the clamped index of :79-81 as a padded copy: pad[k] = in[clamp(k - range)]
   static thread_local vector<float> pad;

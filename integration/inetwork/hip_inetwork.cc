@@ -273,11 +273,37 @@ Network load_net(const string& file) {
 }
 
 // ---- CTC: ctc.cc:57-190 through the library's entry points --------------------------------------------------------------
-// (buffers from device_alloc: managed memory on the GPU build, so the host code around the calls reads them directly)
+// The per-op CTC entry points take device pointers: pinned host memory on the GPU build (device-visible, read by the host
+// code around the calls directly), plain memory on the emulator.  One buffer per role, grown on demand and kept.
+static Float* ctc_alloc(size_t n) {
+#ifdef CLSTM_INTEGRATION_HIP
+  void* p = nullptr;
+  if (hipHostMalloc(&p, n * sizeof(Float), hipHostMallocDefault) != hipSuccess) return nullptr;
+  return (Float*)p;
+#else
+  return (Float*)malloc(n * sizeof(Float));
+#endif
+}
+static void ctc_free(Float* p) {
+#ifdef CLSTM_INTEGRATION_HIP
+  if (p) (void)hipHostFree(p);
+#else
+  free(p);
+#endif
+}
 struct DevArr {
   Float* p = nullptr;
-  explicit DevArr(size_t n) : p(device_alloc(n)) { if (!p) hip_raise("device allocation failed"); }
-  ~DevArr() { device_free(p); }
+  DevArr(int role, size_t n) {
+    static Float* pool[4] = {nullptr, nullptr, nullptr, nullptr};
+    static size_t cap[4] = {0, 0, 0, 0};
+    if (n > cap[role]) {
+      ctc_free(pool[role]);
+      cap[role] = n + n / 2;
+      pool[role] = ctc_alloc(cap[role]);
+      if (!pool[role]) { cap[role] = 0; hip_raise("device allocation failed"); }
+    }
+    p = pool[role];
+  }
 };
 void mktargets(Sequence& seq, Classes& transcript, int ndim) {   // ctc.cc:148-157: blank-interleaved one-hot targets
   const int L = (int)transcript.size(), S = 2 * L + 1;
@@ -293,7 +319,7 @@ static void align_states(Sequence& posteriors, Sequence& outputs, const vector<i
   Timed timed(AdapterClock::CTC);
   const int T = outputs.size(), nc = outputs.rows(), S = (int)states.size();
   if (outputs.cols() != 1) hip_raise("ctc_align_targets: batch size 1 (ctc.cc:59)");
-  DevArr probs((size_t)T * nc), al((size_t)T * nc), dz((size_t)T * nc);
+  DevArr probs(0, (size_t)T * nc), al(1, (size_t)T * nc), dz(2, (size_t)T * nc);
   for (int t = 0; t < T; t++)
     for (int c = 0; c < nc; c++) probs.p[(size_t)t * nc + c] = outputs[t].v(c, 0);
   const int line_off[2] = {0, T}, state_off[2] = {0, S};
@@ -326,7 +352,7 @@ void trivial_decode(Classes& cs, Sequence& outputs, int batch, vector<int>* locs
   if (locs) locs->clear();
   if (T == 0) return;
   Timed timed(AdapterClock::DECODE);
-  DevArr probs((size_t)T * nc);
+  DevArr probs(3, (size_t)T * nc);
   for (int t = 0; t < T; t++)
     for (int c = 0; c < nc; c++) probs.p[(size_t)t * nc + c] = outputs[t].v(c, batch);
   const int line_off[2] = {0, T};

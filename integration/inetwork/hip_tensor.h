@@ -6,5 +6,6 @@
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
+#define CLSTM_TENSOR_HOST_MEMORY 1   // Sequences of the adapter stay on the host (see clstm_types.h)
 #include "clstm_types.h"
 namespace Eigen {}

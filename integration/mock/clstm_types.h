@@ -10,6 +10,8 @@
 //
 // Memory: device_alloc()/device_free() below.  Against the host emulator (CPU CI) that is calloc; against the GPU
 // library it is hipMallocManaged (-DCLSTM_INTEGRATION_HIP), so the test's host-side element accessors keep working.
+// The fused-level adapter (inetwork/hip_tensor.h) defines CLSTM_TENSOR_HOST_MEMORY: its Sequences never reach a kernel
+// (forward() / backward() stage them through the *_h entry points), so they are plain host memory there.
 #pragma once
 #include <assert.h>
 #include <stdlib.h>
@@ -26,7 +28,7 @@ typedef float Float;
 #endif
 
 inline Float* device_alloc(size_t n) {
-#ifdef CLSTM_INTEGRATION_HIP
+#if defined(CLSTM_INTEGRATION_HIP) && !defined(CLSTM_TENSOR_HOST_MEMORY)
   void* p = nullptr;
   if (hipMallocManaged(&p, n * sizeof(Float)) != hipSuccess) THROW("hipMallocManaged failed");
   memset(p, 0, n * sizeof(Float));
@@ -36,7 +38,7 @@ inline Float* device_alloc(size_t n) {
 #endif
 }
 inline void device_free(Float* p) {
-#ifdef CLSTM_INTEGRATION_HIP
+#if defined(CLSTM_INTEGRATION_HIP) && !defined(CLSTM_TENSOR_HOST_MEMORY)
   if (p) (void)hipFree(p);
 #else
   free(p);

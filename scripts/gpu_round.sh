@@ -36,6 +36,9 @@ bash "$ROOT/scripts/gpu_b2timeline.sh" "$TAG" > "$OUT/b2_timeline.log" 2>&1; tai
 cd "$ROOT"
 echo "=== the reference's own drivers over the INetwork adapter (test-ocr.sh scenario): rate of the literal drop-in"
 timeout 300 python -m pytest tests/test_integration_shim.py -m gpu -q -s -k unmodified 2>&1 | grep -E "drop-in|passed|failed" | tee "$OUT/drop_in_rate.txt"
+echo "=== this repo's driver from the same PNG files, batch=64"
+bash "$ROOT/scripts/gpu_driver_rate.sh" "$TAG" 2>&1 | tee "$OUT/driver_rate.txt"
+cd "$ROOT"
 echo "=== rocprofv3 kernel stats + one-step timeline"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof.log" 2>&1
