@@ -436,7 +436,7 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
   // persistent bf16 kernels: 32-line groups (two 16-line MFMA tiles per workgroup) once 16-line groups would need more than
   // one launch of 8 groups -- a step's barrier and ring round trip are then paid once for twice the lines
   const int mt = !bf16 ? 1 : nzb16 * a.ndir > 16 ? 4 : nzb16 * a.ndir > 8 ? 2 : 1;
-  const int nzb = (a.bs + 16 * mt - 1) / (16 * mt);
+  const int nzb_default = (a.bs + 16 * mt - 1) / (16 * mt);
   a.tmax = tmax;
   sync.reserve(XcdSyncLayout::WORDS);
   a.sync = sync.p;
@@ -445,9 +445,10 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
   // first launch fails (workgroups not spread evenly over the XCDs: nothing has been written at that point).
   const bool xcd_on = !(getenv("CLSTM_XCD_REC") && atoi(getenv("CLSTM_XCD_REC")) == 0);
   // (minibatches of more than 8 / ndir line blocks: one launch per chunk of line blocks)
-  const int zb_per = std::max(1, 8 / a.ndir);
-  auto persistent = [&](auto kernel, size_t smem, int nthreads = WIDE_THREADS) {
+  const int zb_per_default = std::max(1, 8 / a.ndir);
+  auto persistent = [&](auto kernel, size_t smem, int nthreads = WIDE_THREADS, int nzb_ = -1, int zb_per_ = -1) {
     bool ok = true;
+    const int nzb = nzb_ > 0 ? nzb_ : nzb_default, zb_per = zb_per_ > 0 ? zb_per_ : zb_per_default;
     for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
       a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
       a.debug_fail_claim = g_debug_fail_claims > 0 ? (g_debug_fail_claims--, 1) : 0;
@@ -483,7 +484,10 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     if (ok) g_wide_persistent = true; else g_xcd_failed = true;
     return ok;
   };
-  const bool fits = xcd_on && !g_xcd_failed && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16);
+  // (the persistent bf16 kernels address their per-frame arrays through 32-bit buffer offsets: G / C / D / Dbf are covered by the check
+  // above, the bf16 source rows -- ndir x N x (ni + no + 8) halfs -- must stay below 2 GiB too, or the per-step launches run)
+  const bool off32 = !bf16 || !a.Sbf || (double)a.ndir * a.N * a.sbf_ld * 2 < 2147483000.0;
+  const bool fits = xcd_on && !g_xcd_failed && off32 && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16);
   if (fx_ngx > 0) {
     if (!(fwd && bf16 && fits && mt == 1 && a.kp16 <= 512 && (no & 3) == 0 && a.x_ni <= 128 * fx_ngx && a.x_ni <= 2048)) return false;
     const size_t smem = (size_t)xcd_fwd_lds_bytes(1);
@@ -510,6 +514,22 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     });
   } else {
     if (fits && !bf16 && (size_t)xcd_bwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_bwd_f32, (size_t)xcd_bwd_f32_lds_bytes(a.kp))) return true;
+    // 32 cells per workgroup, two groups per XCD, groups of 8 / 16 / 32 lines (lstm_wide.h:lstm_xcd_bwd_bf16_c32): half the
+    // delta block per step and CU of the 16-cell kernel below, which stays for hidden sizes that are not multiples of 32
+    const bool c32_on = !(getenv("CLSTM_BWD_C32") && atoi(getenv("CLSTM_BWD_C32")) == 0);   // (read per pass: tests compare both kernels in one process)
+    if (fits && bf16 && a.kp16 <= 2048 && c32_on && no % 32 == 0 && a.ndir <= 2) {
+      const int per = 16 / a.ndir;   // line groups per launch
+      const int ept = a.bs <= 8 * per ? 1 : a.bs <= 16 * per ? 2 : 4;
+      const int ng = (a.bs + 8 * ept - 1) / (8 * ept);
+      const size_t smem = (size_t)xcd_bwd_c32_lds_bytes(ept);
+      const bool fullk = a.kp16 == 2048;
+      auto go = [&](auto k_full, auto k_any) { return fullk ? persistent(k_full, smem, WIDE_THREADS, ng, per) : persistent(k_any, smem, WIDE_THREADS, ng, per); };
+      if (ept == 1 ? go(lstm_xcd_bwd_bf16_c32<1, true>, lstm_xcd_bwd_bf16_c32<1, false>)
+          : ept == 2 ? go(lstm_xcd_bwd_bf16_c32<2, true>, lstm_xcd_bwd_bf16_c32<2, false>) : go(lstm_xcd_bwd_bf16_c32<4, true>, lstm_xcd_bwd_bf16_c32<4, false>)) {
+        g_path_count[9]++;
+        return true;
+      }
+    } else
     if (fits && bf16 && a.kp16 <= 2048 &&
         (mt == 4 ? persistent(lstm_xcd_bwd_bf16<4>, (size_t)xcd_bwd_lds_bytes(4))
          : mt == 2 ? persistent(lstm_xcd_bwd_bf16<2>, (size_t)xcd_bwd_lds_bytes(2)) : persistent(lstm_xcd_bwd_bf16<1>, (size_t)xcd_bwd_lds_bytes(1)))) return true;

@@ -228,6 +228,17 @@ DEVFN float buf_load_s(BufF32 b, unsigned lane_off, unsigned uniform_off) {
 DEVFN void buf_store_s(BufF32 b, unsigned lane_off, unsigned uniform_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.r, lane_off, uniform_off, 0);
 }
+// wider / integer forms of the same (byte offsets; a lane at BUF_OOB drops its store)
+DEVFN void buf_store4(BufF32 b, unsigned byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b.r, byte_off, 0, 0);
+}
+DEVFN void buf_store_u32(BufF32 b, unsigned byte_off, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32((int)v, b.r, byte_off, 0, 0); }
+DEVFN void buf_store_u32x2_s(BufF32 b, unsigned lane_off, unsigned uniform_off, u32x2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, v), b.r, lane_off, uniform_off, 0);
+}
+DEVFN void buf_store_u32_s(BufF32 b, unsigned lane_off, unsigned uniform_off, unsigned v) {
+  __builtin_amdgcn_raw_buffer_store_b32((int)v, b.r, lane_off, uniform_off, 0);
+}
 DEVFN float max_f32(float x, float y) {   // v_max_f32 without the canonicalising self-max of fmaxf (operands are never sNaN)
   float r;
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));

@@ -46,6 +46,7 @@ struct LstmWideArgs {
   int step;             // lock-step index: forward own step s = step, backward own step s = T-1-step
   int tmax;             // persistent kernels: number of lock-steps (longest line)
   int zb0, zbn;         // persistent per-XCD kernels: this launch walks the 16-line blocks [zb0, zb0 + zbn), zbn * ndir <= 8
+                        //   (lstm_xcd_bwd_bf16_c32: groups of 8 EPT lines, zbn * ndir <= 16)
   int* sync;            // persistent kernels: XcdSyncLayout words (zeroed per launch)
   // bf16 MFMA operands (per-step kernels lstm_wide_*_step_bf16; BASELINE config "2 x BiLSTM(512), bf16 MFMA"):
   const unsigned short* Rw16;   // the same weight rows as Rw, bf16, row length kp16
@@ -308,10 +309,12 @@ DEVFN void wide_fwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int c
 #pragma unroll
       for (int q = 0; q < 4; q++) k[q] += p[q];
     }
-    const float gi = gate_act(k[0] + gx[0], false), gf = gate_act(k[1] + gx[1], false),
-                go = gate_act(k[2] + gx[2], false), ci = gate_act(k[3] + gx[3], true);
+    // (bf16 mode: the five-operation affine forms, devintrin.h:act_affine -- every bf16-mode kernel of a wide layer uses them, so the
+    // persistent pass, the per-step launches and the on-demand rebuild of h agree bit for bit)
+    const float gi = act_affine(k[0] + gx[0], ACT_SIG_SCALE, 1.0f, 0.0f), gf = act_affine(k[1] + gx[1], ACT_SIG_SCALE, 1.0f, 0.0f),
+                go = act_affine(k[2] + gx[2], ACT_SIG_SCALE, 1.0f, 0.0f), ci = tanh_fast(k[3] + gx[3]);
     const float c = ci * gi + gf * c_prev;      // c_prev reads 0 at the first step
-    h = gate_act(c, true) * go;
+    h = tanh_fast(c) * go;
     f32x4 act;
     act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
     *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
@@ -547,7 +550,7 @@ DEVFN void wide_bwd_tile16_bf16(const LstmWideArgs& a, const int sg, const int c
     for (int w = 0; w < WIDE_NW; w++) dh_rec += red[(w * 16 + ml) * WIDE_LDW + c16];
     const float gi = act[0], gf = act[1], go = act[2], ci = act[3];
     const float dh = dh_in + dh_rec;           // out[s].d, clstm.cc:626-628 + :646
-    const float th = gate_act(c_s, true);      // backward_nonlingate recomputes tanh(state)
+    const float th = tanh_fast(c_s);           // backward_nonlingate recomputes tanh(state)
     const float d_go = th * dh;
     const float dc = dc_carry + (-th * th + 1.0f) * (go * dh);
     a.dC[dcoff / 4] = dc * gf;                 // backward_statemem (clstm_compute.cc:509-515)
@@ -639,7 +642,7 @@ inline __host__ __device__ size_t ring32_floats(int nd, int bs, int kp) { return
 // ragged f32 case).  So the stamps are never reset: every launch counts from its own base (LstmWideArgs::stamp_base, the host
 // adds tmax + 2 per launch), and a line has one writing XCD for ever.
 
-struct XcdSyncLayout { enum { ARRIVED = 0, ERROR = 1, SLOT0 = 8, EXITED = 16, LAST_ERROR = 17, GROUP0 = 32, GROUP_STRIDE = 32, WORDS = 32 + 8 * 32 }; };
+struct XcdSyncLayout { enum { ARRIVED = 0, ERROR = 1, SLOT0 = 8, EXITED = 16, LAST_ERROR = 17, GROUP0 = 32, GROUP_STRIDE = 32, WORDS = 32 + 16 * 32 }; };   // (up to 16 groups: lstm_xcd_bwd_bf16_c32)
 constexpr int XCD_LDW = 512 + 8;        // halfs per resident weight row (conflict-free ds_read_b128 fragments), kp16 <= 512
 inline __host__ __device__ int xcd_fwd_lds_bytes(int mt = 1) { return 64 * XCD_LDW * 2 + WIDE_NW * mt * 16 * 68 * 4 + 64; }
 
@@ -733,6 +736,64 @@ DEVFN void xcd_finish(const LstmWideArgs& a) {
   if (a.out_host) store_i32_wt(a.out_host, e);
 }
 
+// ---- per-frame outputs of the persistent bf16 forward kernels --------------------------------------------------------------
+// One (line, cell) per thread and line tile; a step stores the activations (G), c (C), the bf16 h into the lock-step ring, into
+// Hbf and into the next frame's bf16 source row (Sbf) -- five stores whose addresses used to be recomputed from the frame
+// number each step (64-bit multiply-adds, ~60 VALU operations and ten branches on a wave that has its SIMD to itself: a third
+// of the 1,330-cycle epilogue, scripts/gpu_xcdprof.py).  Here every array is a buffer resource, a thread keeps its byte offset
+// in each and advances it by one frame per step, and a lane without a live element stores out of range (dropped by the
+// bounds check) instead of branching.  32-bit offsets: the host keeps every array of this path below 2 GiB.
+struct FwdOutBufs { BufF32 g, c, ring, hbf, sbf; unsigned s4, shb, ssb, ring_parity; };
+struct FwdOutOfs { unsigned o4, ohb, osb, rofs; };
+DEVFN FwdOutBufs fwd_out_bufs(const LstmWideArgs& a, const int dir, const BufF32 ring, const int nblk, const int nkb) {
+  const int nd = a.ndir, fstep = dir == 0 ? 1 : -1;   // the forward walk: frames 0 .. T-1 of direction 0, T-1 .. 0 of the reversed one
+  const size_t gbytes = (size_t)a.N * nd * a.no * 16;
+  FwdOutBufs b;
+  b.g = make_buf(a.G, gbytes);
+  b.c = make_buf(a.C, gbytes / 4);
+  b.ring = ring;
+  b.hbf = make_buf(reinterpret_cast<const float*>(a.Hbf), a.Hbf ? (size_t)a.N * a.hbf_ld * 2 : 0);
+  b.sbf = make_buf(reinterpret_cast<const float*>(a.Sbf), a.Sbf ? ((size_t)(nd - 1) * a.sbf_dir + (size_t)a.N * a.sbf_ld) * 2 : 0);
+  b.s4 = (unsigned)(fstep * nd * a.no * 4);
+  b.shb = (unsigned)(fstep * a.hbf_ld * 2);
+  b.ssb = (unsigned)(fstep * a.sbf_ld * 2);
+  b.ring_parity = ring_block(1, nd, 0, nblk, 0, nkb) * 2u;
+  return b;
+}
+DEVFN FwdOutOfs fwd_out_ofs(const LstmWideArgs& a, const int dir, const int cell, const int line, const int off, const int T, const int nblk, const int nkb) {
+  const int nd = a.ndir;
+  const long long n0 = off + (dir == 0 ? 0 : T - 1);
+  FwdOutOfs o;
+  o.o4 = (unsigned)(((n0 * nd + dir) * a.no + cell) * 4);
+  o.ohb = (unsigned)((n0 * a.hbf_ld + dir * a.no + cell) * 2);
+  o.osb = (unsigned)(((long long)dir * a.sbf_dir + n0 * a.sbf_ld + a.sbf_ofs + cell) * 2);
+  o.rofs = (ring_block(0, nd, dir, nblk, line >> 4, nkb) + ring_elem(cell >> 5, line & 15, cell & 31)) * 2u;
+  return o;
+}
+// live: this thread's (line, cell) has a frame at step sg; pair: ... and it is the even cell of a pair (hp = its h and the next cell's)
+DEVFN void fwd_out_store(const LstmWideArgs& a, const FwdOutBufs& b, FwdOutOfs& o, const f32x4 act, const float c_new, const float h, const unsigned hp,
+                         const int sg, const bool live, const bool pair, const int dir, const int cell, const int off, const int T) {
+  buf_store4(b.g, live ? o.o4 << 2 : BUF_OOB, act);
+  buf_store(b.c, live ? o.o4 : BUF_OOB, c_new);
+  buf_store_u32_s(b.ring, pair ? o.rofs : BUF_OOB_BASE, (sg & 1) ? b.ring_parity : 0u, hp);
+  buf_store_u32(b.hbf, pair ? o.ohb : BUF_OOB, hp);
+  // h_{t-1} column block of the NEXT frame's bf16 source row (weight-gradient operand, gemm_b16mc); the first frame's is zero
+  if (sg == 0) buf_store_u32(b.sbf, pair ? o.osb : BUF_OOB, 0u);
+  buf_store_u32(b.sbf, pair && sg + 1 < T ? o.osb + b.ssb : BUF_OOB, hp);
+  if (!a.skip_h || !a.skip_s) {   // f32 outputs somebody asked for (not the training step's path): addressed the long way
+    if (live) {
+      const long long n = off + (dir == 0 ? sg : T - 1 - sg);
+      if (!a.skip_h) a.H[n * a.ldh + a.hofs + dir * a.no + cell] = h;
+      if (!a.skip_s) {
+        float* srow = a.S + (size_t)dir * a.sdir;
+        if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
+        if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
+      }
+    }
+  }
+  o.o4 += b.s4; o.ohb += b.shb; o.osb += b.ssb;
+}
+
 // MT: 16-line tiles per group (1: a group = 16 lines; 2: 32 lines -- minibatches of more than 8 / ndir blocks of 16 lines walk
 // half as many sequential launches, every weight fragment read from LDS serves two MFMAs, and a step's barrier and ring round
 // trip -- what a step costs -- are paid once for twice the lines)
@@ -804,28 +865,11 @@ DEVFN void lstm_xcd_fwd_bf16_body(const LstmWideArgs& a) {
   float c_prev[MT];
 #pragma unroll
   for (int i = 0; i < MT; i++) { gx[i] = gx_load(0, i); c_prev[i] = 0.0f; }
-  // the per-frame outputs of one step (nobody inside the pass reads them)
-  auto store_frame = [&](const int i, const f32x4 act, const float c_new, const float h, const unsigned hp, const long long n, const int sg, const bool live) {
-    if (live) {
-      *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
-      a.C[(n * nd + dir) * no + cell] = c_new;
-      if (!a.skip_h) a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
-      if (!a.skip_s) {
-        float* srow = a.S + (size_t)dir * a.sdir;
-        if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
-        if (sg + 1 < T[i]) srow[(long long)(off[i] + (dir == 0 ? sg + 1 : T[i] - 2 - sg)) * a.lds + a.sofs + cell] = h;
-      }
-    }
-    if (live && !(c16 & 1)) {
-      *reinterpret_cast<unsigned*>(a.Hb + ring_block(sg & 1, nd, dir, nblk, zb * MT + i, nkb) + ring_elem(cell >> 5, ml, cell & 31)) = hp;
-      if (a.Hbf) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
-      if (a.Sbf) {   // h_{t-1} column block of the next frame's bf16 source row (weight-gradient operand, gemm_b16mc)
-        unsigned short* sb = a.Sbf + (size_t)dir * a.sbf_dir + a.sbf_ofs + cell;
-        if (sg == 0) *reinterpret_cast<unsigned*>(sb + (size_t)n * a.sbf_ld) = 0u;
-        if (sg + 1 < T[i]) *reinterpret_cast<unsigned*>(sb + (size_t)(off[i] + (dir == 0 ? sg + 1 : T[i] - 2 - sg)) * a.sbf_ld) = hp;
-      }
-    }
-  };
+  // the per-frame outputs of one step (nobody inside the pass reads them): fwd_out_store
+  const FwdOutBufs ob = fwd_out_bufs(a, dir, abuf, nblk, nkb);
+  FwdOutOfs oo[MT];
+#pragma unroll
+  for (int i = 0; i < MT; i++) oo[i] = fwd_out_ofs(a, dir, cell, line[i], off[i], T[i], nblk, nkb);
   XCD_PROF_DECL;
   for (int sg = 0; sg < a.tmax; sg++) {
     f32x4 acc[4][MT];
@@ -875,7 +919,6 @@ DEVFN void lstm_xcd_fwd_bf16_body(const LstmWideArgs& a) {
 #pragma unroll
     for (int i = 0; i < MT; i++) {
       const bool live = mine[i] && sg < T[i];
-      const long long n = off[i] + (dir == 0 ? sg : T[i] - 1 - sg);
       float h = 0.0f, c_new = 0.0f;
       f32x4 act = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (live) {
@@ -888,15 +931,17 @@ DEVFN void lstm_xcd_fwd_bf16_body(const LstmWideArgs& a) {
 #pragma unroll
           for (int q = 0; q < 4; q++) k[q] += p[q];
         }
-        const float gi = gate_act(k[0] + gx[i][0], false), gf = gate_act(k[1] + gx[i][1], false),
-                    go = gate_act(k[2] + gx[i][2], false), ci = gate_act(k[3] + gx[i][3], true);
+        // (sigmoid / tanh as r = 1 / (1 + 2^(x scale)), act = r A + B: five VALU operations each, absolute error <= 3e-7 -- far
+        // inside this mode's bf16 operands -- where gate_act spends ~25 on a wave that has its SIMD to itself)
+        const float gi = act_affine(k[0] + gx[i][0], ACT_SIG_SCALE, 1.0f, 0.0f), gf = act_affine(k[1] + gx[i][1], ACT_SIG_SCALE, 1.0f, 0.0f),
+                    go = act_affine(k[2] + gx[i][2], ACT_SIG_SCALE, 1.0f, 0.0f), ci = tanh_fast(k[3] + gx[i][3]);
         c_new = ci * gi + gf * c_prev[i];
-        h = gate_act(c_new, true) * go;
+        h = tanh_fast(c_new) * go;
         act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
       }
       const float hn = quad_xor1(h);
       const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);   // (h = 0 for a line that has ended)
-      store_frame(i, act, c_new, h, hp, n, sg, live);
+      fwd_out_store(a, ob, oo[i], act, c_new, h, hp, sg, live, live && !(c16 & 1), dir, cell, off[i], T[i]);
       c_prev[i] = c_new;
       gx[i] = gx_next[i];
     }
@@ -1023,27 +1068,8 @@ DEVFN void lstm_xcd_fwd_bf16_fx_body(const LstmWideArgs& a) {
   x_stage(xr);
   x_load(1, xr);
   float c_prev = 0.0f;
-  auto store_frame = [&](const f32x4 act, const float c_new, const float h, const unsigned hp, const long long n, const int sg, const bool live) {
-    if (live) {
-      *reinterpret_cast<f32x4*>(a.G + ((n * nd + dir) * no + cell) * 4) = act;
-      a.C[(n * nd + dir) * no + cell] = c_new;
-      if (!a.skip_h) a.H[n * a.ldh + a.hofs + dir * no + cell] = h;
-      if (!a.skip_s) {
-        float* srow = a.S + (size_t)dir * a.sdir;
-        if (sg == 0) srow[n * a.lds + a.sofs + cell] = 0.0f;
-        if (sg + 1 < T) srow[(long long)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.lds + a.sofs + cell] = h;
-      }
-    }
-    if (live && !(c16 & 1)) {
-      *reinterpret_cast<unsigned*>(a.Hb + ring_block(sg & 1, nd, dir, nblk, zb, nkb) + ring_elem(cell >> 5, ml, cell & 31)) = hp;
-      if (a.Hbf) *reinterpret_cast<unsigned*>(a.Hbf + (size_t)n * a.hbf_ld + dir * no + cell) = hp;
-      if (a.Sbf) {
-        unsigned short* sb = a.Sbf + (size_t)dir * a.sbf_dir + a.sbf_ofs + cell;
-        if (sg == 0) *reinterpret_cast<unsigned*>(sb + (size_t)n * a.sbf_ld) = 0u;
-        if (sg + 1 < T) *reinterpret_cast<unsigned*>(sb + (size_t)(off + (dir == 0 ? sg + 1 : T - 2 - sg)) * a.sbf_ld) = hp;
-      }
-    }
-  };
+  const FwdOutBufs ob = fwd_out_bufs(a, dir, abuf, nblk, nkb);
+  FwdOutOfs oo = fwd_out_ofs(a, dir, cell, line, off, T, nblk, nkb);
   XCD_PROF_DECL;
   for (int sg = 0; sg < a.tmax; sg++) {
     f32x4 acc[4];
@@ -1092,7 +1118,6 @@ DEVFN void lstm_xcd_fwd_bf16_fx_body(const LstmWideArgs& a) {
     XCD_STAMP(4);
     {
       const bool live = mine && sg < T;
-      const long long n = off + (dir == 0 ? sg : T - 1 - sg);
       float h = 0.0f, c_new = 0.0f;
       f32x4 act = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (live) {
@@ -1103,14 +1128,15 @@ DEVFN void lstm_xcd_fwd_bf16_fx_body(const LstmWideArgs& a) {
 #pragma unroll
           for (int q = 0; q < 4; q++) k[q] += p[q];
         }
-        const float gi = gate_act(k[0], false), gf = gate_act(k[1], false), go = gate_act(k[2], false), ci = gate_act(k[3], true);
+        const float gi = act_affine(k[0], ACT_SIG_SCALE, 1.0f, 0.0f), gf = act_affine(k[1], ACT_SIG_SCALE, 1.0f, 0.0f),
+                    go = act_affine(k[2], ACT_SIG_SCALE, 1.0f, 0.0f), ci = tanh_fast(k[3]);   // (see lstm_xcd_fwd_bf16_body)
         c_new = ci * gi + gf * c_prev;
-        h = gate_act(c_new, true) * go;
+        h = tanh_fast(c_new) * go;
         act[0] = gi; act[1] = gf; act[2] = go; act[3] = ci;
       }
       const float hn = quad_xor1(h);
       const unsigned hp = bf16_pack2(h, cell + 1 < no ? hn : 0.0f);
-      store_frame(act, c_new, h, hp, n, sg, live);
+      fwd_out_store(a, ob, oo, act, c_new, h, hp, sg, live, live && !(c16 & 1), dir, cell, off, T);
       c_prev = c_new;
     }
     XCD_STAMP(5);
@@ -1268,7 +1294,7 @@ DEVFN void lstm_xcd_bwd_bf16_body(const LstmWideArgs& a) {
         for (int w = 0; w < WIDE_NW; w++) dh_rec += red[((w * MT + i) * 16 + ml) * LDR + c16];
         const float gi = cur[i].act[0], gf = cur[i].act[1], go = cur[i].act[2], ci = cur[i].act[3];
         const float dh = cur[i].dh_in + dh_rec;
-        const float th = gate_act(c_s[i], true);
+        const float th = tanh_fast(c_s[i]);   // (2 sigmoid(2x) - 1: <= 3e-7 absolute, five VALU operations; see lstm_xcd_bwd_bf16_c32)
         const float d_go = th * dh;
         const float dc = (sg >= 1 ? dc_carry[i] : 0.0f) + (-th * th + 1.0f) * (go * dh);
         dc_carry[i] = dc * gf;
@@ -1301,6 +1327,264 @@ DEVFN void lstm_xcd_bwd_bf16_body(const LstmWideArgs& a) {
       }
       c_s[i] = cur[i].c_m1;
       cur[i] = nxt[i];
+    }
+    XCD_STAMP(8);   // per-frame stores issued
+  }
+  XCD_PROF_WRITE(xcd, slot, ntile);
+}
+
+// ---- backward, 32 cells per workgroup: TWO groups per XCD (round 4) ----------------------------------------------------------
+// A step of lstm_xcd_bwd_bf16 moves the group's whole delta block -- (lines of the group) x 4 no bf16 -- into EVERY workgroup of
+// the group: 64 KB per step and CU at 16 lines x 512 cells = 1,024 cycles of a CU's 64 B/clk fill path, 2 MB per step out of
+// one XCD's L2 (scripts/gpu_xcdprof.py: 1,350 cycles of load issue and 1,150 more until the last MFMA, of a 5,180-cycle step).
+// That block scales with the LINES of a group, not with the cells of a workgroup.  Here a workgroup owns 32 cells (two MFMA
+// column tiles; B fragments 2 x 64 VGPRs per lane, still resident for the whole sequence), a group is half as many workgroups,
+// and the chip holds twice as many groups of half as many lines: 8 EPT lines per group (EPT = epilogue elements per thread:
+// 256 threads = 8 lines x 32 cells), two groups per XCD, both in its L2.  EPT = 1 (up to 16 / ndir x 8 = 64 lines at two
+// directions): eight lines -- the MFMA's rows 8..15 are requested out of range (zeros, no traffic) and a step fills 32 KB;
+// EPT = 2 / 4: 16 / 32 lines per group where the 16-cell kernel needs 32 / 64.  The k split over the four waves, the order of
+// a wave's MFMAs and the cross-wave sum are those of lstm_xcd_bwd_bf16: bit-identical results.  Needs no % 32 == 0.
+inline __host__ __device__ int xcd_bwd_c32_lds_bytes(int ept) {
+  const int lt = ept >= 2 ? ept / 2 : 1;
+  const int need = 16 * XCD_LDWB * 2 + WIDE_NW * lt * 16 * (32 + 4) * 4 + 64;
+  return need > 84 * 1024 ? need : 84 * 1024;   // > 80 KB: one workgroup per CU
+}
+// FULLK: the wave's quarter of the contraction is all sixteen 32-k groups (4 no = 2048): no per-group branches in the step
+template <int EPT, bool FULLK>
+DEVFN void lstm_xcd_bwd_bf16_c32_body(const LstmWideArgs& a) {
+  constexpr int LT = EPT >= 2 ? EPT / 2 : 1;   // 16-row MFMA line tiles per group
+  constexpr int LG = 8 * EPT;                  // lines per group
+  constexpr int LDR = 32 + 4;
+  unsigned short* wl = dyn_smem<unsigned short>();                         // [16][XCD_LDWB]: one 16-cell tile's rows at a time
+  float* red = reinterpret_cast<float*>(wl + 16 * XCD_LDWB);               // [4][LT * 16][LDR]
+  int* flag = reinterpret_cast<int*>(red + WIDE_NW * LT * 16 * LDR);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int no = a.no, nd = a.ndir;
+  const int ntile = (no + 15) >> 4, nt32 = ntile >> 1;   // workgroups per XCD | per group
+  const int ngroups = nd * a.zbn;                        // groups of this launch: <= 16, two per XCD
+  int* const sync = a.sync;
+  int xcd, slot;
+  if (!xcd_claim(sync, flag, ntile, (ngroups + 1) >> 1, xcd, slot, a.debug_fail_claim)) return;
+  const int sub = slot >= nt32 ? 1 : 0, ct = slot - sub * nt32;
+  const int grp = xcd * 2 + sub;
+  if (grp >= ngroups) return;
+  const int dir = grp % nd, lg = a.zb0 + grp / nd;                         // lg: group of LG lines
+  int* const gcount = sync + XcdSyncLayout::GROUP0 + grp * XcdSyncLayout::GROUP_STRIDE;
+  const int kw = a.kp16 / WIDE_NW, ngrp = kw >> 5;   // <= 16 groups of 32 per wave
+  // this wave's B fragments -- 2 x (16 cells x its quarter of the contraction) -- in registers for the whole sequence
+  u16x8 wreg[2][16];
+  {
+    const int c8 = a.kp16 >> 3;
+    const unsigned short* wfrag = wl + (lane & 15) * XCD_LDWB + wave * kw + 8 * (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      for (int i = tid; i < 16 * c8; i += WIDE_THREADS) {
+        const int row = i / c8, c = i - row * c8;
+        *reinterpret_cast<u16x8*>(wl + row * XCD_LDWB + c * 8) =
+            *reinterpret_cast<const u16x8*>(a.Rw16 + ((long long)(dir * ntile + 2 * ct + j) * 16 + row) * a.kp16 + c * 8);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < 16; g++) wreg[j][g] = *reinterpret_cast<const u16x8*>(wfrag + (g < ngrp ? g : 0) * 32);
+      __syncthreads();
+    }
+  }
+  // epilogue role: cell c32 of the tile, lines lrow + 8 e of the group
+  const int lrow = tid >> 5, c32 = tid & 31;
+  const int cell = ct * 32 + c32;
+  int line[EPT], off[EPT], T[EPT];
+  bool mine[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; e++) {
+    line[e] = lg * LG + lrow + 8 * e;
+    off[e] = 0; T[e] = 0;
+    if (line[e] < a.bs) { off[e] = a.line_off[line[e]]; T[e] = a.line_off[line[e] + 1] - off[e]; }
+    mine[e] = line[e] < a.bs && cell < no;
+  }
+  const size_t gbytes = (size_t)a.N * nd * no * 16;
+  const BufF32 gbuf = make_buf(a.G, gbytes);
+  const BufF32 cbuf = make_buf(a.C, gbytes / 4);
+  const BufF32 hbuf = make_buf(a.dH, gbytes / 4);
+  const BufF32 dbuf = make_buf(a.skip_d ? nullptr : a.D, a.skip_d ? 0 : gbytes);                                  // (no records: every store dropped)
+  const BufF32 dbfbuf = make_buf(reinterpret_cast<const float*>(a.Dbf), a.Dbf ? (size_t)a.N * nd * a.kp16 * 2 : 0);
+  const int nblk = (a.bs + 15) >> 4, nkb = a.kp16 >> 5;
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(a.Db), (size_t)2 * nd * nblk * 16 * a.kp16 * 2);
+  // A fragment of this lane in line tile i: line lg LG + 16 i + (lane & 15) -- a row of the 16-line ring block it lies in
+  unsigned aoff[LT];
+  int ablk[LT];
+  bool aval[LT];
+#pragma unroll
+  for (int i = 0; i < LT; i++) {
+    const int rl = 16 * i + (lane & 15), am = lg * LG + rl;
+    aval[i] = rl < LG && am < a.bs;
+    ablk[i] = am >> 4;
+    aoff[i] = ring_elem(wave * ngrp, am & 15, 8 * (lane >> 4)) * 2u;
+  }
+  // EPT = 1, dense form: lane (r, kc) holds row r & 7 of the eight lines, 32-k group 2p + (r >> 3) in its p-th load
+  const int dhalf = (lane & 15) >> 3;
+  const int dline = lg * LG + (lane & 7);
+  const bool dval = dline < a.bs;
+  const int dblk = dline >> 4;
+  const unsigned doff = ring_elem(wave * ngrp + dhalf, dline & 15, 8 * (lane >> 4)) * 2u;
+  float dc_carry[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; e++) dc_carry[e] = 0.0f;
+
+  // Byte offsets of a thread's element in the per-frame arrays, advanced by one frame per step instead of recomputed (a 64-bit
+  // multiply-add chain per access; the arrays stay below 2 GiB -- host check -- so 32 bits carry them): o4 = ((n nd + dir) no + cell) 4
+  // addresses C and dH, o4 << 2 addresses G and D; ol runs one step ahead (the operand loads), os / ob with the step (D / Dbf).
+  const int fstep = dir == 0 ? -1 : 1;   // the backward walk: frames T-1 .. 0 of direction 0, 0 .. T-1 of the reversed one
+  const unsigned s4 = (unsigned)(fstep * nd * no * 4), sB = (unsigned)(fstep * nd * a.kp16 * 2);
+  unsigned ol[EPT], os[EPT], ob[EPT], rofs[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; e++) {
+    const long long n0 = off[e] + (dir == 0 ? T[e] - 1 : 0);
+    ol[e] = os[e] = (unsigned)(((n0 * nd + dir) * no + cell) * 4);
+    ob[e] = (unsigned)(((n0 * nd + dir) * a.kp16 + 4 * cell) * 2);
+    rofs[e] = (ring_block(0, nd, dir, nblk, line[e] >> 4, nkb) + ring_elem(cell >> 3, line[e] & 15, (4 * cell) & 31)) * 2u;
+  }
+  const unsigned ring_parity = ring_block(1, nd, 0, nblk, 0, nkb) * 2u;   // bytes between the two halves of the ring
+
+  // Epilogue operands (forward-pass arrays, from HBM) are requested one step AHEAD and behind that step's delta loads, so
+  // that they never sit in front of them in the in-order VMEM queue; c_s of a step is the c_{s-1} the previous step loaded.
+  struct Ops { f32x4 act; float dh_in, c_m1; };
+  auto ops_load = [&](int sg, int e) -> Ops {   // (called once per step, in order: advances ol)
+    const bool lv = mine[e] && sg < T[e];
+    Ops o;
+    o.act = buf_load4(gbuf, lv ? ol[e] << 2 : BUF_OOB);
+    o.dh_in = buf_load(hbuf, lv ? ol[e] : BUF_OOB);
+    ol[e] += s4;
+    o.c_m1 = buf_load(cbuf, lv && sg + 1 < T[e] ? ol[e] : BUF_OOB);
+    return o;
+  };
+  Ops cur[EPT];
+  float c_s[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; e++) {
+    c_s[e] = buf_load(cbuf, mine[e] && 0 < T[e] ? ol[e] : BUF_OOB);
+    cur[e] = ops_load(0, e);
+  }
+  XCD_PROF_DECL;
+  for (int sg = 0; sg < a.tmax; sg++) {
+    XCD_STAMP(0);   // loop top
+    if (sg >= 1 && !xcd_wait_group(gcount, nt32, a.stamp_base + sg, sync + XcdSyncLayout::ERROR, flag)) return;
+    XCD_STAMP(1);   // group wait
+    f32x4 acc[LT][2];
+#pragma unroll
+    for (int i = 0; i < LT; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+    Ops nxt[EPT];
+    if constexpr (EPT == 1) {
+      // Eight lines: a load instruction costs the CU's address path its 64 lanes whether or not they hit memory, so the lanes
+      // of MFMA rows 8..15 are not parked out of range but fetch the NEXT 32-k group of rows 0..7 -- eight dense loads instead
+      // of sixteen half-empty ones.  Group 2p multiplies the registers as they are (its rows 8..15 hold the other group's
+      // deltas: they only reach output rows 8..15, which nobody reads), group 2p+1 after a row rotation by eight lanes (DPP).
+      // Same groups in the same order: the sums are those of the sixteen-load form.
+      // (All eight loads first: issuing them a few ahead with the arrived pair's MFMAs in between was measured SLOWER -- 1.64 /
+      // 1.60 / 1.53 ms for 3 / 4 / 6 ahead against 1.46 for all at once, two backward passes of configs[4]: the wait in front of
+      // each MFMA group is for the data's round trip, and only all loads in flight together hide it.  Leave-out builds: the loads
+      // cost 630 cycles of a step, the MFMAs + rotations another 630, additively.)
+      f32x4 ra[8];
+      const unsigned arow = (sg >= 1 && dval) ? ring_block((sg - 1) & 1, nd, dir, nblk, dblk, nkb) * 2u + doff : BUF_OOB_BASE;
+#pragma unroll
+      for (int p = 0; p < 8; p++) ra[p] = buf_load4_dev(abuf, FULLK || 2 * p + dhalf < ngrp ? arow + (unsigned)p * 2048u : BUF_OOB);
+      SCHED_FENCE();
+      nxt[0] = ops_load(sg + 1, 0);
+      SCHED_FENCE();
+      XCD_STAMP(2);   // loads issued
+#pragma unroll
+      for (int p = 0; p < 8; p++) {
+        if (FULLK || 2 * p < ngrp) {
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[0][j] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[p]), wreg[j][2 * p], acc[0][j]);
+        }
+        if (FULLK || 2 * p + 1 < ngrp) {
+          f32x4 t;
+#pragma unroll
+          for (int q = 0; q < 4; q++) t[q] = row_ror<8>(ra[p][q]);
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[0][j] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, t), wreg[j][2 * p + 1], acc[0][j]);
+        }
+      }
+    } else
+    {   // all sixteen 32-k groups of the wave's quarter requested at once: one L2 round trip per step
+      f32x4 ra[16][LT];
+#pragma unroll
+      for (int i = 0; i < LT; i++) {
+        const unsigned arow = (sg >= 1 && aval[i]) ? ring_block((sg - 1) & 1, nd, dir, nblk, ablk[i], nkb) * 2u + aoff[i] : BUF_OOB_BASE;
+#pragma unroll
+        for (int g = 0; g < 16; g++) ra[g][i] = buf_load4_dev(abuf, FULLK || g < ngrp ? arow + (unsigned)g * 1024u : BUF_OOB);
+      }
+      SCHED_FENCE();
+#pragma unroll
+      for (int e = 0; e < EPT; e++) nxt[e] = ops_load(sg + 1, e);
+      SCHED_FENCE();
+      XCD_STAMP(2);   // loads issued
+#pragma unroll
+      for (int g = 0; g < 16; g++)
+        if (FULLK || g < ngrp) {
+#pragma unroll
+          for (int i = 0; i < LT; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = mfma16x16x32_bf16(__builtin_bit_cast(u16x8, ra[g][i]), wreg[j][g], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LT; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) red[((wave * LT + i) * 16 + (lane >> 4) * 4 + q) * LDR + j * 16 + (lane & 15)] = acc[i][j][q];
+    XCD_STAMP(3);   // ring loads returned + MFMAs + partial tile to LDS
+    __syncthreads();
+    XCD_STAMP(4);   // barrier
+    f32x4 dl[EPT];
+    bool live[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      live[e] = mine[e] && sg < T[e];
+      dl[e] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (live[e]) {
+        const int ll = lrow + 8 * e;
+        float dh_rec = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WIDE_NW; w++) dh_rec += red[((w * LT + (ll >> 4)) * 16 + (ll & 15)) * LDR + c32];
+        const float gi = cur[e].act[0], gf = cur[e].act[1], go = cur[e].act[2], ci = cur[e].act[3];
+        const float dh = cur[e].dh_in + dh_rec;
+        // (tanh as 2 sigmoid(2x) - 1: absolute error <= 3e-7, far inside this mode's bf16 operands; five VALU operations
+        // instead of gate_act's ~25 on a wave that has the SIMD to itself)
+        const float th = tanh_fast(c_s[e]);
+        const float d_go = th * dh;
+        const float dc = (sg >= 1 ? dc_carry[e] : 0.0f) + (-th * th + 1.0f) * (go * dh);
+        dc_carry[e] = dc * gf;
+        const float d_gf = dc * cur[e].c_m1;
+        const float d_gi = dc * ci, d_ci = dc * gi;
+        dl[e][0] = (gi * (-gi + 1.0f)) * d_gi;
+        dl[e][1] = (gf * (-gf + 1.0f)) * d_gf;
+        dl[e][2] = (go * (-go + 1.0f)) * d_go;
+        dl[e][3] = (-ci * ci + 1.0f) * d_ci;
+      }
+      // (one 8-byte store: what the group waits for goes first; a lane without a live element stores out of range)
+      buf_store_u32x2_s(abuf, live[e] ? rofs[e] : BUF_OOB_BASE, (sg & 1) ? ring_parity : 0u,
+                        u32x2{bf16_pack2(dl[e][0], dl[e][1]), bf16_pack2(dl[e][2], dl[e][3])});
+    }
+    XCD_STAMP(5);   // epilogue + ring store issued
+    drain_vmem();
+    XCD_STAMP(6);   // stores acknowledged
+    __syncthreads();
+    if (tid == 0 && sg + 1 < a.tmax) xcd_arrive(gcount, ct, a.stamp_base + sg + 1);
+    XCD_STAMP(7);   // barrier + arrival
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+      if (!a.skip_d) buf_store4(dbuf, live[e] ? os[e] << 2 : BUF_OOB, dl[e]);
+      // k-contiguous bf16 copy per frame: the ready-made A operand of the x.d product (gemm_b16kk)
+      buf_store_u32x2_s(dbfbuf, live[e] ? ob[e] : BUF_OOB, 0u, u32x2{bf16_pack2(dl[e][0], dl[e][1]), bf16_pack2(dl[e][2], dl[e][3])});
+      os[e] += s4; ob[e] += sB;
+      c_s[e] = cur[e].c_m1;
+      cur[e] = nxt[e];
     }
     XCD_STAMP(8);   // per-frame stores issued
   }
@@ -1564,6 +1848,8 @@ template <int NGX>
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_bf16_fx(LstmWideArgs a) { lstm_xcd_fwd_bf16_fx_body<NGX>(a); xcd_finish(a); }
 template <int MT>
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16(LstmWideArgs a) { lstm_xcd_bwd_bf16_body<MT>(a); xcd_finish(a); }
+template <int EPT, bool FULLK>
+__global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_bf16_c32(LstmWideArgs a) { lstm_xcd_bwd_bf16_c32_body<EPT, FULLK>(a); xcd_finish(a); }
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_fwd_f32(LstmWideArgs a) { lstm_xcd_fwd_f32_body(a); xcd_finish(a); }
 __global__ __launch_bounds__(WIDE_THREADS) void lstm_xcd_bwd_f32(LstmWideArgs a) { lstm_xcd_bwd_f32_body(a); xcd_finish(a); }
 

@@ -538,7 +538,7 @@ __global__ void k_h_from_state(float* H, const float* G, const float* C, size_t 
   CLSTM_GRID_STRIDE(e, N * (size_t)ndir * no) {
     const size_t n = e / ((size_t)ndir * no);
     const int r = e % ((size_t)ndir * no);
-    H[n * ldh + hofs + r] = gate_act(C[e], true) * G[e * 4 + 2];
+    H[n * ldh + hofs + r] = tanh_fast(C[e]) * G[e * 4 + 2];   // (the bf16-mode kernels' own form of tanh)
   }
 }
 __global__ void k_source_h(float* S, const float* H, const int* line_off, int bs, size_t N, int no, int ndir, int ldh, int hofs,

@@ -241,6 +241,14 @@ inline f32x4 buf_load4(BufF32 b, unsigned off) { f32x4 r; for (int i = 0; i < 4;
 inline void buf_store(BufF32 b, unsigned off, float v) { if ((size_t)off + 4 <= b.bytes) b.base[off / 4] = v; }
 inline float buf_load_s(BufF32 b, unsigned lane_off, unsigned uni) { return ((size_t)lane_off + 4 <= b.bytes) ? b.base[(lane_off + uni) / 4] : 0.0f; }
 inline void buf_store_s(BufF32 b, unsigned lane_off, unsigned uni, float v) { if ((size_t)lane_off + 4 <= b.bytes) b.base[(lane_off + uni) / 4] = v; }
+inline void buf_store4(BufF32 b, unsigned off, f32x4 v) { for (int i = 0; i < 4; i++) buf_store(b, off + 4 * i, v[i]); }
+inline void buf_store_u32(BufF32 b, unsigned off, unsigned v) { if ((size_t)off + 4 <= b.bytes) reinterpret_cast<unsigned*>(b.base)[off / 4] = v; }
+inline void buf_store_u32_s(BufF32 b, unsigned lane_off, unsigned uni, unsigned v) {
+  if ((size_t)lane_off + 4 <= b.bytes) reinterpret_cast<unsigned*>(b.base)[(lane_off + uni) / 4] = v;
+}
+inline void buf_store_u32x2_s(BufF32 b, unsigned lane_off, unsigned uni, u32x2 v) {
+  if ((size_t)lane_off + 8 <= b.bytes) { unsigned* p = reinterpret_cast<unsigned*>(b.base) + (lane_off + uni) / 4; p[0] = v[0]; p[1] = v[1]; }
+}
 inline float max_f32(float x, float y) { return fmaxf(x, y); }
 #define KEEP_ALIVE2(x) (void)(x)
 inline f32x4 buf_load4_dev(BufF32 b, unsigned off) { return buf_load4(b, off); }

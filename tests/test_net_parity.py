@@ -7,6 +7,7 @@ Tolerances: 1e-4 relative on activations (BASELINE.json north_star), CTC argmax 
 import numpy as np
 import pytest
 
+from common import ROOT
 from common import assert_close, oracle_minibatch, synth_lines
 from oracle.oracle import OracleNet
 
@@ -336,6 +337,76 @@ def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatc
         # persistent forward kernel, path 6; as a product of its own, path 2, with CLSTM_FUSE_WX=0), x.d from the bf16 delta
         # array, and the weight gradient from contraction-major bf16 operands through the LDS transpose reads
         assert all(t > 0 for t in took[:2] + took[3:5]) and took[2] + took[6] > 0, took
+
+
+@pytest.mark.parametrize("nh,nlines", [([32, 32], 4), ([32], 20), ([32, 32], 70), ([32], 140)],
+                         ids=["eight_line_groups", "three_groups", "sixteen_line_groups", "thirty_two_line_groups"])
+def test_backward_recurrence_with_32_cells_per_workgroup_is_bit_identical(backend, ora32, monkeypatch, nh, nlines):
+    """lstm_xcd_bwd_bf16_c32 (round 4: 32 cells per workgroup, two groups per XCD, groups of 8 / 16 / 32 lines -- half the
+    delta block per step and CU) against lstm_xcd_bwd_bf16 (CLSTM_BWD_C32=0): same k split over the waves, same MFMA order,
+    same cross-wave sum -- the gradient and the stored deltas must be IDENTICAL, ragged lines and a half-empty last group
+    included."""
+    from clstm_amd.net import Network
+    monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
+    rng = np.random.default_rng(41)
+    ni, nc = 12, 6
+    T = [1 + (7 * i + 3) % 9 for i in range(nlines)]
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CLSTM_BWD_C32", mode)
+        before = _path_count(backend, 9)
+        net = Network(ni, nh, nc, lib=backend.lib)
+        net.set_params(params)
+        net.set_gemm_precision(2)
+        net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
+        took = _path_count(backend, 9) - before
+        assert (took > 0) == (mode == "1"), (mode, took)
+        out[mode] = (net.get_grads().copy(), [net.state(l, d, "d_" + w).copy() for l in range(len(nh)) for d in (0, 1) for w in ("gi", "ci")])
+    assert np.abs(out["1"][0]).max() > 0
+    assert np.array_equal(out["1"][0], out["0"][0])
+    for x, y in zip(out["1"][1], out["0"][1]):
+        assert np.array_equal(x, y)
+
+
+def test_backward_32_cells_dense_eight_line_loads_on_a_larger_emulated_chip(ora32):
+    """The eight-line form of lstm_xcd_bwd_bf16_c32 loads two 32-k groups per instruction and rotates the second one into
+    place (DPP row_ror:8); a layer needs >= 64 cells for a wave to own more than one group, i.e. 32 workgroups -- more than the
+    emulator's default 16 CUs: a child process with CLSTM_EMU_CUS=48 runs BiLSTM(64) and BiLSTM(96 -> odd group count per
+    wave) both ways and must find identical gradients."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, ctypes
+        import numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        from common import Backend, synth_lines
+        from oracle.oracle import Oracle, OracleNet
+        from clstm_amd.net import Network
+        backend = Backend("emu"); ora = Oracle("f32")
+        def count():
+            out = ctypes.c_longlong(0); backend.lib.call("clstm_debug_path_count", 9, ctypes.byref(out)); return out.value
+        rng = np.random.default_rng(5)
+        for nh in ([64], [96]):
+            ni, nc, T = 12, 6, [5, 3, 6, 1, 4, 6, 2, 5, 3, 6, 4]
+            params = OracleNet(ora, ni, nh, nc, seed=0.222).get_params() * 20.0
+            lines = synth_lines(rng, T, ni)
+            trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+            got = {}
+            for mode in ("1", "0"):
+                os.environ["CLSTM_BWD_C32"] = mode
+                c0 = count()
+                net = Network(ni, nh, nc, lib=backend.lib); net.set_params(params); net.set_gemm_precision(2)
+                net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
+                assert (count() > c0) == (mode == "1"), (nh, mode)
+                got[mode] = net.get_grads().copy()
+            assert np.abs(got["1"]).max() > 0 and np.array_equal(got["1"], got["0"]), nh
+        print("IDENTICAL")
+    """ % (ROOT, ROOT))
+    env = dict(os.environ, CLSTM_EMU_CUS="48", CLSTM_FORCE_WIDE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
 def _path_count(backend, which):
