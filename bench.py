@@ -234,13 +234,17 @@ def rocprof_avg_ms(kernel, minibatch, T, ragged):
     return None
 
 
-def rocprof_b2_avg_ms():
-    """average duration (ms) of the configs[4] step's dominant launch, lstm_xcd_bwd_bf16, in the newest committed one-step kernel
-    trace (profiles/r*_b2_timeline.txt: rocprofv3 --kernel-trace of `bench.py --config b2 --bf16`)"""
+def rocprof_b2_avg_ms(dominant):
+    """average duration (ms) of the configs[4] step's dominant launch (`dominant`: "lstm_fwd" | "lstm_bwd" -> the persistent
+    lstm_xcd_fwd_bf16* / lstm_xcd_bwd_bf16* kernels) in the newest committed one-step kernel trace
+    (profiles/r*_b2_timeline.txt: rocprofv3 --kernel-trace of `bench.py --config b2 --bf16`)"""
     try:
         import glob
+        pat = {"lstm_fwd": "lstm_xcd_fwd_bf16", "lstm_bwd": "lstm_xcd_bwd_bf16"}.get(dominant)
+        if not pat:
+            return None
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_b2_timeline.txt")))[-1]
-        d = [float(l.split()[2]) for l in open(f) if "lstm_xcd_bwd_bf16" in l]
+        d = [float(l.split()[2]) for l in open(f) if pat in l]
         return round(sum(d) / len(d) * 1e-3, 4) if d else None
     except Exception:
         return None
@@ -538,7 +542,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "stacked 2xBiLSTM(512) H=64 nc=100, T=400, L=50, minibatch=64 lines on 1 GPU "
                                    "(BASELINE.json configs[4] shape), fwd+CTC+bwd+update", "minibatch_per_gpu": 64},
-            "roofline": dict(roofline_b2(w2, m2["kern"], m2["frames_per_step"], ms2), rocprof_avg_launch_ms=rocprof_b2_avg_ms()) if m2["kern"] else None,
+            "roofline": (lambda r: dict(r, rocprof_avg_launch_ms=rocprof_b2_avg_ms(r.get("kernel"))))(roofline_b2(w2, m2["kern"], m2["frames_per_step"], ms2)) if m2["kern"] else None,
             "kernels": m2["kern"],
             "parity": "stated tolerance against the f32 oracle at this size: tests/test_gpu_e2e.py::test_configs4_full_shape_bf16_vs_oracle",
         }
