@@ -427,7 +427,7 @@ static int g_debug_fail_claims = 0;      // tests: this many upcoming persistent
 // returns false -- nothing launched or nothing written -- if it does not apply or its placement check failed: the caller then
 // runs the hoisted product and calls again with fx_ngx = 0.
 static std::map<const void*, int> g_stamp_base;   // per sync buffer: where the group-barrier stamps of its next persistent launch start
-static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s, bool bf16 = false, int fx_ngx = 0) {
+static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sync, StepGraphCache& graphs, hipStream_t s, bool bf16 = false, int fx_ngx = 0, bool x3 = false) {
   g_wide_persistent = false;
   REQUIRE((double)a.N * a.ndir * 4 * a.no * 4 < 2147483000.0,
           "minibatch too large for the lock-step recurrence (frames x 4 x nhidden x ndir x 4 B must stay below 2 GiB)");
@@ -513,6 +513,9 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
       }
     });
   } else {
+    if (fits && !bf16 && x3 && a.Rw16 && a.kp16 <= 2048) {
+      if (persistent(lstm_xcd_bwd_x3, (size_t)xcd_bwd_lds_bytes(1))) { g_path_count[11]++; return true; }
+    } else
     if (fits && !bf16 && (size_t)xcd_bwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_bwd_f32, (size_t)xcd_bwd_f32_lds_bytes(a.kp))) return true;
     // 32 cells per workgroup, two groups per XCD, groups of 8 / 16 / 32 lines (lstm_wide.h:lstm_xcd_bwd_bf16_c32): half the
     // delta block per step and CU of the 16-cell kernel below, which stays for hidden sizes that are not multiples of 32
@@ -924,6 +927,7 @@ struct Layer {
   DevBuf<int> pack_tab;       // source index of every packed element (k_pack_index), narrow layers in training steps
   // bf16 recurrence of a wide layer (lstm_wide_bf16.h): packed weights and the bf16 copies of h / the deltas
   unsigned short *Rbf = nullptr, *Rbb = nullptr;
+  DevBuf<unsigned short> R2b, D2;   // f32-grade backward recurrence on the bf16 MFMA (lstm_xcd_bwd_x3): hi | lo planes of the weights and of the delta ring
   DevBuf<unsigned short> Hb, Db;
   DevBuf<float> Rf32;          // tiled lock-step ring of the persistent f32 recurrences (one pass at a time uses it)
   long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
@@ -1133,7 +1137,7 @@ struct Net {
   ~Net() {
     for (auto& y : L) {
       (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff); (void)hipFree(y.Wk);
-      (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release(); y.Rf32.release();
+      (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release(); y.Rf32.release(); y.R2b.release(); y.D2.release();
       y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false; y.pack_tab.release();
     }
     (void)hipFree(W1k); fw_items.release(); fw_flags.release();
@@ -1170,9 +1174,16 @@ struct Net {
         CLSTM_LAUNCH(k_pack_wide_bf16, dim3(nblocks((size_t)ndir * ((size_t)rf * kf + (size_t)rb * kb))), dim3(256), 0, s,
                      (const float*)v, y.Rbf, y.Rbb, y.pd, rf, kf, rb, kb);
       }
-      else if (y.wide)
+      else if (y.wide) {
         CLSTM_LAUNCH(k_pack_wide, dim3(nblocks((size_t)(y.nwf + y.nwb))), dim3(256), 0, s, (const float*)v, y.Rwf, y.Rwb,
                      y.pd, y.kpf, y.kpb);
+        if (rec_x3()) {   // hi | lo planes of the backward recurrence's weights
+          const int rb = (y.no + 15) / 16 * 16, kb = wide_kp16_bwd(y.no);
+          const long long pb = (long long)ndir * rb * kb;
+          y.R2b.reserve((size_t)2 * pb + 64);
+          CLSTM_LAUNCH(k_pack_wide_split, dim3(nblocks((size_t)pb)), dim3(256), 0, s, (const float*)v, y.R2b.p, y.pd, rb, kb, pb);
+        }
+      }
       CLSTM_LAUNCH(k_pack_layer, dim3(nblocks((size_t)(1 + y.ni) * M + 2 * nr)), dim3(256), 0, s, (const float*)v, y.Wt,
                    y.bias, y.Rf, y.Rb, y.pd, pack_fused_desc(y));
       if (y.wide && bf16_rec) {   // bf16 copy of W_x^T for the bf16-source x.d product
@@ -1250,6 +1261,13 @@ struct Net {
     w.lds = y.lds; w.sofs = 1 + y.ni; w.ldh = y.ldh; w.hofs = y.hofs; w.no = y.no; w.ndir = ndir; w.bs = bs;
     w.kp = fwd ? y.kpf : y.kpb;
     if (!bf16_rec) { y.Rf32.reserve(ring32_floats(ndir, bs, std::max(y.kpf, y.kpb)) + 64); w.Rf = y.Rf32.p; }
+    if (!bf16_rec && !fwd && rec_x3() && y.R2b.p) {   // (tried first by launch_lstm_wide; the f32 kernel stays as the fallback)
+      const int nblk = (bs + 15) / 16;
+      w.kp16 = wide_kp16_bwd(y.no);
+      w.ring_plane = 2LL * ndir * nblk * 16 * w.kp16;
+      y.D2.reserve((size_t)2 * w.ring_plane + 64);
+      w.Db = y.D2.p; w.Rw16 = y.R2b.p; w.rw_plane = (long long)ndir * ((y.no + 15) / 16 * 16) * w.kp16;
+    }
     if (bf16_rec) {
       w.Rw16 = fwd ? y.Rbf : y.Rbb;
       w.kp16 = fwd ? wide_kp16_fwd(y.no) : wide_kp16_bwd(y.no);
@@ -1556,6 +1574,14 @@ struct Net {
   // ~0 (a tanh gate at -0.0021 came out 5.6e-6 off where the parity bar allows 2.2e-6), and with K = 49 the split costs
   // more staging than it saves MFMA time (28.5 vs 20.9 us).
   bool gemm_x3_on = !(getenv("CLSTM_GEMM_X3") && atoi(getenv("CLSTM_GEMM_X3")) == 0);
+  // exact-f32 mode, wide layers: the persistent BACKWARD recurrence as an f32-grade x3 product on the bf16 MFMA (lstm_wide.h:
+  // lstm_xcd_bwd_x3) like the backward GEMMs of this mode; off with them (CLSTM_GEMM_X3=0 / strict f32) or alone (CLSTM_REC_X3=0;
+  // read per pass: tests compare both kernels in one process)
+  bool rec_x3() const {
+    if (bf16_gemm || bf16_rec || !gemm_x3_on) return false;
+    const char* e = getenv("CLSTM_REC_X3");
+    return !(e && atoi(e) == 0);
+  }
   // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
   int pick_split(int R, int Cn, int nbatch = 1, int tile = GEMM_BT) const {
     const long long tiles = (long long)((R + tile - 1) / tile) * ((Cn + tile - 1) / tile) * nbatch;
@@ -1813,7 +1839,7 @@ struct Net {
       int skipped_d = 0;
       if (y.wide) {
         const LstmWideArgs w = wide_args(y, false);
-        launch_lstm_wide(false, w, tmax, coop_sync, step_graphs, s, bf16_rec);
+        launch_lstm_wide(false, w, tmax, coop_sync, step_graphs, s, bf16_rec, 0, rec_x3());
         skipped_d = w.skip_d;
       } else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
       timing.end(s);
@@ -2742,6 +2768,7 @@ int clstm_net_set_strict_f32(clstm_net* h, int on) {
     n.dw_x3 = getenv("CLSTM_DW_X3") ? atoi(getenv("CLSTM_DW_X3")) : 1;
     n.gemm_x3_on = !(getenv("CLSTM_GEMM_X3") && atoi(getenv("CLSTM_GEMM_X3")) == 0);
   }
+  n.packed_dirty = true;   // (the hi | lo weights of the f32-grade backward recurrence are only packed while that mode is on)
   ABI_END
 }
 int clstm_net_overlap_stats(clstm_net* h, long long* launches, int* timeouts) {

@@ -450,6 +450,23 @@ __global__ void k_pack_wide_bf16(const float* v, unsigned short* Rbf, unsigned s
   }
 }
 
+// The backward layout with every weight as TWO bf16 terms (hi | lo, `plane` halfs apart): the B operand of the f32-grade backward
+// recurrence on the bf16 MFMA (lstm_wide.h: lstm_xcd_bwd_x3)
+__global__ void k_pack_wide_split(const float* v, unsigned short* Rb2, PackDesc p, int rows_b, int kpb, long long plane) {
+  const size_t nb = (size_t)p.ndir * rows_b * kpb;
+  CLSTM_GRID_STRIDE(e, nb) {
+    float x = 0.0f;
+    const int col = e % kpb;
+    const size_t q = e / kpb;
+    const int k = q % rows_b, dir = q / rows_b;
+    const int j = col >> 2, slot = col & 3;
+    if (j < p.no && k < p.no) x = v[p.p_off[dir][slot] + j + (size_t)p.no * (1 + p.ni + k)];
+    const unsigned hi = bf16_pack2(x, 0.0f) & 0xFFFFu;
+    Rb2[e] = (unsigned short)hi;
+    Rb2[e + plane] = (unsigned short)(bf16_pack2(x - __builtin_bit_cast(float, hi << 16), 0.0f) & 0xFFFFu);
+  }
+}
+
 // Every packed copy a WIDE layer needs in bf16 mode, in ONE pass over its parameters (no % 128 == 0, ni % 32 == 0: no padding
 // anywhere): Wt / bias (f32, the hoisted product's fallback forms), Wtb [ni][M] and WtbT [M][ni] (bf16 W_x in both
 // orientations), Rbf (forward recurrence: rows (cell, gate), k contiguous) and Rbb (backward: rows k, columns (cell, gate)).

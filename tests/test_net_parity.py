@@ -409,6 +409,39 @@ def test_backward_32_cells_dense_eight_line_loads_on_a_larger_emulated_chip(ora3
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
+def test_f32_grade_backward_recurrence_on_the_bf16_mfma(backend, ora32, monkeypatch):
+    """Round 4: in exact-f32 mode the persistent BACKWARD recurrence of a wide layer runs as an f32-grade x3 product on the bf16
+    MFMA -- gate deltas and recurrent weights as hi + lo bf16 terms, hi.hi + hi.lo + lo.hi accumulated in f32
+    (lstm_wide.h:lstm_xcd_bwd_x3), like the backward GEMMs of this mode.  The forward pass is untouched (bit-identical to
+    CLSTM_REC_X3=0); the gradient: against the oracle at the bar of the other wide-layer tests, against the f32 MFMA kernel
+    within the x3 products' 2^-16."""
+    from clstm_amd.net import Network
+    monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
+    rng = np.random.default_rng(29)
+    ni, nh, nc = 12, [32, 32], 6
+    T = [9, 5, 7, 3, 11, 1, 8, 6, 10, 2, 9, 4, 7, 11, 5, 3, 6, 8, 2, 10]      # 20 ragged lines: two line blocks
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+    want = oracle_minibatch(ora32, OracleNet, params, ni, nh, nc, lines, trs, states=[], lr=1e-3, mom=0.9)
+    res = {}
+    for m in ("1", "0"):
+        monkeypatch.setenv("CLSTM_REC_X3", m)
+        c11 = _path_count(backend, 11)
+        net = Network(ni, nh, nc, lib=backend.lib)
+        net.set_params(params)
+        net.set_inputs(lines); net.forward()
+        out = net.outputs().copy()
+        net.ctc(trs); net.backward()
+        assert (_path_count(backend, 11) > c11) == (m == "1"), m
+        res[m] = (out, net.get_grads().copy(), net.state(1, 0, "d_gi").copy())
+    assert np.array_equal(res["1"][0], res["0"][0])                       # the forward pass is the f32 MFMA's either way
+    assert_close(res["1"][1], want["derivs"], rtol=1e-3, atol=1e-9, scale_atol=1e-4, what="gradient vs oracle")
+    assert_close(res["1"][1], res["0"][1], rtol=1e-3, atol=1e-9, scale_atol=2e-5, what="gradient vs the f32 MFMA kernel")
+    assert_close(res["1"][2], res["0"][2], rtol=1e-3, atol=1e-9, scale_atol=2e-5, what="stored deltas vs the f32 MFMA kernel")
+    assert not np.array_equal(res["1"][1], res["0"][1])
+
+
 def _path_count(backend, which):
     import ctypes
     out = ctypes.c_longlong(0)
@@ -509,7 +542,7 @@ def test_input_projection_inside_the_persistent_forward_kernel(backend, ora32, m
     assert_close(res[0][3], res[1][3], rtol=2e-5, atol=1e-9, scale_atol=1e-5, what="gradient, fused vs hoisted W_x")
 
 
-@pytest.mark.parametrize("precision", [0, 2], ids=["f32", "bf16"])
+@pytest.mark.parametrize("precision", [0, -1, 2], ids=["f32", "f32_on_the_f32_mfma", "bf16"])
 def test_persistent_recurrence_placement_fallback(backend, ora32, monkeypatch, precision):
     """VERDICT r3 weak 11 / ADVICE r3: the persistent per-XCD recurrences are ordinary launches whose workgroups must all be
     resident; a launch that finds they are not (here: the placement check is made to fail, clstm_debug_set_device_error 4)
@@ -519,6 +552,10 @@ def test_persistent_recurrence_placement_fallback(backend, ora32, monkeypatch, p
     from clstm_amd.net import Network
     monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
     monkeypatch.setenv("CLSTM_XCD_REC", "1")
+    f32_mfma = precision == -1      # CLSTM_REC_X3=0: the persistent f32 kernels on the f32 MFMA (same tile and split-K order as the
+    if f32_mfma:                    #   per-step launches -> bit-identical); default: the backward recurrence as an f32-grade x3 product on the bf16 MFMA
+        monkeypatch.setenv("CLSTM_REC_X3", "0")
+        precision = 0
     rng = np.random.default_rng(41)
     ni, nh, nc, T = 12, [32, 32], 6, [9, 5, 7, 3]
     params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
@@ -544,8 +581,12 @@ def test_persistent_recurrence_placement_fallback(backend, ora32, monkeypatch, p
         p0 = _path_count(backend, 0)
         got = fwdbwd(a)
         assert _path_count(backend, 0) == p0                     # ... and stayed off (per-step launches from then on)
-        if precision == 0:                                       # f32: same tile and split-K order -> bit-identical
+        if f32_mfma:                                             # same tile and split-K order -> bit-identical
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        elif precision == 0:                                     # f32-grade persistent kernels against the f32 MFMA per-step launches
+            assert np.array_equal(got[0], want[0])               # (the forward kernels are the f32 MFMA's either way)
+            assert_close(got[1], want[1], rtol=1e-3, atol=1e-9, scale_atol=2e-5, what="gradient after the fallback")
+            assert not np.array_equal(got[1], want[1])           # (the f32-grade backward kernel really ran before)
         else:
             assert_close(got[0], want[0], rtol=1e-3, atol=1e-5, what="outputs after the fallback")
             assert_close(got[1], want[1], rtol=1e-3, atol=1e-9, scale_atol=1e-3, what="gradient after the fallback")
