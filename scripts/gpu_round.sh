@@ -41,7 +41,7 @@ bash "$ROOT/scripts/gpu_driver_rate.sh" "$TAG" 2>&1 | tee "$OUT/driver_rate.txt"
 cd "$ROOT"
 echo "=== rocprofv3 kernel stats + one-step timeline"
 cd /tmp
-CLSTM_ROCTX=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof.log" 2>&1
 tail -1 "$OUT/rocprof.log" | cut -c1-200
 find "$OUT/prof" -name "*kernel_stats*" | head -1 | while read f; do head -16 "$f"; done
 F=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)
