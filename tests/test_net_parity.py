@@ -442,6 +442,38 @@ def test_f32_grade_backward_recurrence_on_the_bf16_mfma(backend, ora32, monkeypa
     assert not np.array_equal(res["1"][1], res["0"][1])
 
 
+@pytest.mark.parametrize("nlines,precision", [(11, 2), (75, 2), (11, 0)], ids=["bf16_eight_line_groups", "bf16_sixteen_line_groups", "f32_x3"])
+def test_unidirectional_wide_layer_takes_the_round4_backward_kernels(backend, monkeypatch, nlines, precision):
+    """One direction (lstm1 prefab): sixteen groups of one direction per launch instead of eight of two -- the 32-cell bf16
+    backward kernel must stay bit-identical to the 16-cell one, the f32-grade x3 backward kernel within float noise of the
+    f32 MFMA one."""
+    from clstm_amd.net import Network
+    monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
+    rng = np.random.default_rng(5)
+    ni, nh, nc = 12, [32], 6
+    T = [1 + (7 * i + 3) % 9 for i in range(nlines)]
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+    params = None
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CLSTM_BWD_C32", mode); monkeypatch.setenv("CLSTM_REC_X3", mode)
+        which = 9 if precision == 2 else 11
+        before = _path_count(backend, which)
+        net = Network(ni, nh, nc, unidirectional=True, lib=backend.lib)
+        if params is None:
+            params = np.random.default_rng(1).normal(0, 0.3, net.nparams).astype(np.float32)
+        net.set_params(params); net.set_gemm_precision(precision)
+        net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
+        assert (_path_count(backend, which) > before) == (mode == "1")
+        got[mode] = net.get_grads().copy()
+    assert np.abs(got["0"]).max() > 0
+    if precision == 2:
+        assert np.array_equal(got["1"], got["0"])
+    else:
+        assert_close(got["1"], got["0"], rtol=1e-3, atol=1e-9, scale_atol=2e-5, what="gradient, x3 vs f32 MFMA backward recurrence")
+
+
 def _path_count(backend, which):
     import ctypes
     out = ctypes.c_longlong(0)
