@@ -727,7 +727,7 @@ struct Comm {
   }
   // rendezvous of the ranks of this host: a shared segment named after the communicator id
   struct Handles { hipIpcMemHandle_t x, f; int ok; int pad[3]; };
-  struct Rendezvous { std::atomic<int> magic, arrived, mapped, good; Handles h[PEER_MAX_RANKS]; };
+  struct Rendezvous { std::atomic<int> magic, arrived, mapped, good, probed, probe_good; Handles h[PEER_MAX_RANKS]; };
   static bool wait_for(std::atomic<int>& w, int target, double seconds) {
     const auto t0 = std::chrono::steady_clock::now();
     while (w.load() < target) {
@@ -788,6 +788,31 @@ struct Comm {
       rv->mapped.fetch_add(1);
       const bool all_here = wait_for(rv->mapped, nranks, 20.0);
       good = all_here && rv->good.load() == nranks;
+      // ... and the mappings WORK: one handshake through the mapped flag arrays and one look at every rank's buffer through this
+      // rank's mapping of it (pattern rank + 1), with a probe sequence number no training step uses -- a path that maps but does
+      // not deliver (flags that never arrive, stale or foreign data) falls back to RCCL here instead of failing at the first step
+      if (good) {
+        int* perr = nullptr;
+        bool ran = hipMalloc((void**)&perr, sizeof(int)) == hipSuccess;
+        if (ran) {
+          const float pat = (float)(rank + 1);
+          const PeerArgs pa = p.args(-2, rank, nranks);
+          ran = hipMemsetAsync(perr, 0, sizeof(int), s) == hipSuccess &&
+                hipMemcpyAsync(p.slot_ptr(-2), &pat, sizeof(float), hipMemcpyHostToDevice, s) == hipSuccess &&
+                hipStreamSynchronize(s) == hipSuccess;
+          if (ran) {
+            CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, -2, perr);
+            CLSTM_LAUNCH(k_peer_probe, dim3(1), dim3(64), 0, s, pa, perr);
+            int e = 1;
+            ran = hipMemcpyAsync(&e, perr, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && e == 0;
+          }
+          (void)hipFree(perr);
+        }
+        if (!ran) (void)hipGetLastError();
+        if (ran) rv->probe_good.fetch_add(1);
+        rv->probed.fetch_add(1);
+        good = wait_for(rv->probed, nranks, 40.0) && rv->probe_good.load() == nranks;
+      }
       if (rank == 0) shm_unlink(name);          // (every rank that will ever come has it open or has given up)
       munmap(rv, sizeof(Rendezvous));
     }

@@ -257,6 +257,14 @@ __global__ void k_peer_barrier(PeerArgs p, int seq, int* err) {
     if (++spins > (1 << 24)) { atomic_add_i32(err, 1); break; }   // never hang the device: the update is skipped (dev_err_set)
   }
 }
+// set-up probe of the mapped buffers (clstm_hip.hip: Comm::peer_ready): behind one k_peer_barrier every rank's buffer must show
+// the pattern that rank wrote (rank + 1 in its first word) through THIS rank's mapping of it
+__global__ void k_peer_probe(PeerArgs p, int* err) {
+  const int r = threadIdx.x;
+  if (blockIdx.x != 0 || r >= p.nranks) return;
+  const BufF32 b = make_buf(p.x[r], 4);
+  if (buf_load_wt(b, 0u) != (float)(r + 1)) atomic_add_i32(err, 1);
+}
 __global__ void k_peer_allreduce_update(PeerArgs p, float* v, float* d, float* g, size_t len, float lr, float mom, float clip, const int* err,
                                         int* step_word, int step_id, int* nanflag, int step_no) {
   if (step_word && blockIdx.x == 0 && threadIdx.x == 0) store_i32_wt(step_word, step_id);
