@@ -485,8 +485,10 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     return ok;
   };
   // (the persistent bf16 kernels address their per-frame arrays through 32-bit buffer offsets: G / C / D / Dbf are covered by the check
-  // above, the bf16 source rows -- ndir x N x (ni + no + 8) halfs -- must stay below 2 GiB too, or the per-step launches run)
-  const bool off32 = !bf16 || !a.Sbf || (double)a.ndir * a.N * a.sbf_ld * 2 < 2147483000.0;
+  // above, the bf16 and f32 source rows -- ndir x N x (ni + no + 8) halfs / (1 + ni + no) floats -- and the output rows must stay below 2 GiB
+  // too, or the per-step launches run)
+  const bool off32 = !bf16 || ((!a.Sbf || (double)a.ndir * a.N * a.sbf_ld * 2 < 2147483000.0) &&
+                               (a.skip_s || (double)a.ndir * a.N * a.lds * 4 < 2147483000.0) && (double)a.N * a.ldh * 4 < 2147483000.0);
   const bool fits = xcd_on && !g_xcd_failed && off32 && tmax > 1 && ntile <= 32 && 8 * ntile <= std::max(ncu, 16);
   if (fx_ngx > 0) {
     if (!(fwd && bf16 && fits && mt == 1 && a.kp16 <= 512 && (no & 3) == 0 && a.x_ni <= 128 * fx_ngx && a.x_ni <= 2048)) return false;
