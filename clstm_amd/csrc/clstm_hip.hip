@@ -955,6 +955,7 @@ struct Layer {
   // bf16 recurrence of a wide layer (lstm_wide_bf16.h): packed weights and the bf16 copies of h / the deltas
   unsigned short *Rbf = nullptr, *Rbb = nullptr;
   DevBuf<unsigned short> R2b, D2;   // f32-grade backward recurrence on the bf16 MFMA (lstm_xcd_bwd_x3): hi | lo planes of the weights and of the delta ring
+  bool r2b_ready = false;           // ... R2b holds the CURRENT weights (set / cleared by every repack)
   DevBuf<unsigned short> Hb, Db;
   DevBuf<float> Rf32;          // tiled lock-step ring of the persistent f32 recurrences (one pass at a time uses it)
   long long* moff = nullptr;  // [ndir*4no] flat offset of packed row m (column 0)
@@ -1204,7 +1205,9 @@ struct Net {
       else if (y.wide) {
         CLSTM_LAUNCH(k_pack_wide, dim3(nblocks((size_t)(y.nwf + y.nwb))), dim3(256), 0, s, (const float*)v, y.Rwf, y.Rwb,
                      y.pd, y.kpf, y.kpb);
+        y.r2b_ready = false;
         if (rec_x3()) {   // hi | lo planes of the backward recurrence's weights
+          y.r2b_ready = true;
           const int rb = (y.no + 15) / 16 * 16, kb = wide_kp16_bwd(y.no);
           const long long pb = (long long)ndir * rb * kb;
           y.R2b.reserve((size_t)2 * pb + 64);
@@ -1288,7 +1291,7 @@ struct Net {
     w.lds = y.lds; w.sofs = 1 + y.ni; w.ldh = y.ldh; w.hofs = y.hofs; w.no = y.no; w.ndir = ndir; w.bs = bs;
     w.kp = fwd ? y.kpf : y.kpb;
     if (!bf16_rec) { y.Rf32.reserve(ring32_floats(ndir, bs, std::max(y.kpf, y.kpb)) + 64); w.Rf = y.Rf32.p; }
-    if (!bf16_rec && !fwd && rec_x3() && y.R2b.p) {   // (tried first by launch_lstm_wide; the f32 kernel stays as the fallback)
+    if (!bf16_rec && !fwd && rec_x3() && y.r2b_ready) {   // (tried first by launch_lstm_wide; the f32 kernel stays as the fallback)
       const int nblk = (bs + 15) / 16;
       w.kp16 = wide_kp16_bwd(y.no);
       w.ring_plane = 2LL * ndir * nblk * 16 * w.kp16;
