@@ -236,13 +236,23 @@ def rocprof_avg_ms(kernel, minibatch, T, ragged):
 
 def rocprof_b2_avg_ms(dominant):
     """average duration (ms) of the configs[4] step's dominant launch (`dominant`: "lstm_fwd" | "lstm_bwd" -> the persistent
-    lstm_xcd_fwd_bf16* / lstm_xcd_bwd_bf16* kernels) in the newest committed one-step kernel trace
-    (profiles/r*_b2_timeline.txt: rocprofv3 --kernel-trace of `bench.py --config b2 --bf16`)"""
+    lstm_xcd_fwd_bf16* / lstm_xcd_bwd_bf16* kernels) in the newest committed rocprofv3 --kernel-trace --stats summary of
+    `bench.py --config b2 --bf16` (profiles/r*_b2_kernel_stats.csv: call-weighted over the matching kernels), else in the one-step
+    timeline of the same trace (profiles/r*_b2_timeline.txt)"""
     try:
+        import csv
         import glob
         pat = {"lstm_fwd": "lstm_xcd_fwd_bf16", "lstm_bwd": "lstm_xcd_bwd_bf16"}.get(dominant)
         if not pat:
             return None
+        fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_b2_kernel_stats.csv")))
+        if fs:
+            tot = calls = 0.0
+            for row in csv.DictReader(open(fs[-1])):
+                if pat in row["Name"]:
+                    tot += float(row["TotalDurationNs"]); calls += float(row["Calls"])
+            if calls:
+                return round(tot / calls * 1e-6, 4)
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_b2_timeline.txt")))[-1]
         d = [float(l.split()[2]) for l in open(f) if pat in l]
         return round(sum(d) / len(d) * 1e-3, 4) if d else None

@@ -14,7 +14,7 @@ for name in ("bench_default.json", "bench_mb1.json", "bench_mb16.json", "bench_m
              "bench_ragged.json", "bench_b2.json", "bench_b2_bf16gemm.json", "bench_b2_bf16.json", "bench_forcedist.json",
              "bench_overlap0.json", "bench_host_inputs.json", "bench_driver_cmd.json", "fwd_timeline.txt", "lstm_fwd_phase_cycles.txt", "ctc_phase_cycles.txt", "xcd_phase_cycles.txt", "timeline.txt", "host.txt", "pmc_FETCH_SIZE_summary.txt", "pmc_WRITE_SIZE_summary.txt",
              "pmc_SQ_VALU_MFMA_BUSY_CYCLES_summary.txt", "pmc_GRBM_GUI_ACTIVE_summary.txt", "pmc_SQ_summary.txt",
-             "pmc_FETCH_SIZE_ov0_summary.txt", "pmc_WRITE_SIZE_ov0_summary.txt", "b2_timeline.txt", "drop_in_rate.txt", "driver_rate.txt", "pytest_gpu.log"):
+             "pmc_FETCH_SIZE_ov0_summary.txt", "pmc_WRITE_SIZE_ov0_summary.txt", "b2_timeline.txt", "b2_kernel_stats.csv", "drop_in_rate.txt", "driver_rate.txt", "pytest_gpu.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, pre + name))
