@@ -19,6 +19,11 @@ effects), then the block of EXACTLY K steps, bracketed by barrier + synchronize 
 ranks, is timed R times back to back (R such that the timed total is >= 0.5 s; `repeats` in the JSON) and the MEDIAN
 block is reported: `ms_per_step` = median block / K, `value` = lines of one block / median block.
 
+Test hooks (tests/test_bench_ranks.py runs this file's rank body at world size 2 on the CPU before the driver runs it on
+eight GPUs): CLSTM_BENCH_BACKEND=gloo (process-group backend), CLSTM_BENCH_DEVICE=cpu (tensors in host memory, no streams),
+CLSTM_BENCH_LIB=<path of a build of the library>, CLSTM_BENCH_MIN_TIMED_S / CLSTM_BENCH_MIN_WARMUP_S (bounds of the timing
+protocol).  None is set in a measurement.
+
 The default single-GPU line also carries `secondary`: BASELINE.json configs[4] (2 x BiLSTM(512), H = 64, T = 400,
 bf16 MFMA) timed in the same process with the same protocol and its own `roofline` (MFMA, 2.5 PFLOP/s dense bf16).
 """
@@ -48,6 +53,18 @@ BF16_MFMA_PEAK_TFS = 2500.0    # dense bf16 MFMA
 # algorithmic bytes per cell-step of the fused gate kernels
 BYTES_PER_CELL_STEP = {"lstm_fwd": 44.0, "lstm_bwd": 56.0}
 MIN_WARMUP_S, MIN_TIMED_S, MAX_REPEATS = 0.3, 2.0, 400   # (2 s timed: the driver's 5-s GPU-busy sampler sees the work)
+if os.environ.get("CLSTM_BENCH_MIN_TIMED_S"):
+    MIN_TIMED_S = float(os.environ["CLSTM_BENCH_MIN_TIMED_S"])
+if os.environ.get("CLSTM_BENCH_MIN_WARMUP_S"):
+    MIN_WARMUP_S = float(os.environ["CLSTM_BENCH_MIN_WARMUP_S"])
+ON_CPU = os.environ.get("CLSTM_BENCH_DEVICE") == "cpu"      # test hook: the rank body on host memory (no GPU, no streams)
+
+
+def device_sync(lib=None):
+    if ON_CPU:
+        return
+    import torch
+    torch.cuda.synchronize()
 KERNEL_NAMES = ("ingest", "gemm_gates_x", "lstm_fwd", "gemm_softmax", "softmax_norm", "ctc_align", "gemm_softmax_dw_dx",
                 "lstm_bwd", "gemm_gates_dw", "reduce_scatter", "gemm_gates_dx", "allreduce_grads", "sgd_update")
 
@@ -186,13 +203,13 @@ def kernel_times(w, steps, first_step, ms_per_step):
     # the lead-in fills the library's event pool, so the measured steps create no events
     for i in range(int(min(100, max(3, np.ceil(25.0 / max(ms_per_step, 1e-3)))))):
         w.step(first_step + i)
-    torch.cuda.synchronize()
+    device_sync()
     net.reset_timing()
     frames = 0
     for i in range(steps):
         w.step(first_step + i)
         frames += w.frames(first_step + i)
-    torch.cuda.synchronize()
+    device_sync()
     kern = {}
     for name in KERNEL_NAMES:
         ms, n = net.kernel_time_ms(name)
@@ -228,7 +245,8 @@ def rocprof_avg_ms(kernel, minibatch, T, ragged):
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))[-1]
         for row in csv.DictReader(open(f)):
             if kernel in row["Name"]:
-                return round(float(row["AverageNs"]) * 1e-6, 4)
+                return {"ms": round(float(row["AverageNs"]) * 1e-6, 4), "source": "profiles/" + os.path.basename(f),
+                        "note": "COMMITTED rocprofv3 --kernel-trace --stats summary of this command from an earlier run -- not measured in this run"}
     except Exception:
         pass
     return None
@@ -245,6 +263,7 @@ def rocprof_b2_avg_ms(dominant):
         pat = {"lstm_fwd": "lstm_xcd_fwd_bf16", "lstm_bwd": "lstm_xcd_bwd_bf16"}.get(dominant)
         if not pat:
             return None
+        note = "COMMITTED rocprofv3 summary of `bench.py --config b2 --bf16` from an earlier run -- not measured in this run"
         fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_b2_kernel_stats.csv")))
         if fs:
             tot = calls = 0.0
@@ -252,10 +271,10 @@ def rocprof_b2_avg_ms(dominant):
                 if pat in row["Name"]:
                     tot += float(row["TotalDurationNs"]); calls += float(row["Calls"])
             if calls:
-                return round(tot / calls * 1e-6, 4)
+                return {"ms": round(tot / calls * 1e-6, 4), "source": "profiles/" + os.path.basename(fs[-1]), "note": note}
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_b2_timeline.txt")))[-1]
         d = [float(l.split()[2]) for l in open(f) if pat in l]
-        return round(sum(d) / len(d) * 1e-3, 4) if d else None
+        return {"ms": round(sum(d) / len(d) * 1e-3, 4), "source": "profiles/" + os.path.basename(f), "note": note} if d else None
     except Exception:
         return None
 
@@ -316,9 +335,9 @@ def roofline_b1(w, kern, kern_unfused, frames_per_step, ms_per_step):
     out = dict(entries[dom])
     out["traffic_source"] = traffic_src if out["traffic"] is not None else None
     out["timing"] = ("avg_launch_ms: HIP start/stop events bound to the launch's own dispatch packet on the library's stream "
-                     "(hipExtLaunchKernel), measured live in this run; rocprof_avg_launch_ms: the committed rocprofv3 --kernel-trace "
-                     "--stats average of the same command (profiles/)")
-    out["rocprof_avg_launch_ms"] = rocprof_avg_ms({"lstm_bwd_dw": "lstm_bwd_dw_kernel", "lstm_fwd_fused": "lstm_fwd_fused_kernel",
+                     "(hipExtLaunchKernel), measured live in this run; rocprof_avg_launch_ms_from_committed_profile: the rocprofv3 "
+                     "--kernel-trace --stats average of the same command in the named file under profiles/ (an earlier run)")
+    out["rocprof_avg_launch_ms_from_committed_profile"] = rocprof_avg_ms({"lstm_bwd_dw": "lstm_bwd_dw_kernel", "lstm_fwd_fused": "lstm_fwd_fused_kernel",
                                                    "lstm_fwd": "lstm_fwd_kernel", "lstm_bwd": "lstm_bwd_kernel"}.get(dom, dom),
                                                   w.minibatch, w.T, w.ragged)
     out["note"] = ("latency-bound recurrence: %d workgroups (lines x directions) on 256 CUs, one dependent step per frame; "
@@ -407,27 +426,32 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d (launch with torch.distributed.run --nproc-per-node %d, "
                  "or without WORLD_SIZE and let bench.py spawn the ranks)" % (world, args.gpus, args.gpus))
-    if torch.cuda.device_count() <= local_rank:
-        sys.exit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+    backend = os.environ.get("CLSTM_BENCH_BACKEND", "nccl")      # ("nccl" IS RCCL on ROCm; gloo: the CPU test of this rank body)
+    if not ON_CPU:
+        if torch.cuda.device_count() <= local_rank:
+            sys.exit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if ON_CPU else torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):   # BENCH_FORCE_DIST=1: exercise the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from clstm_amd import abi
     from clstm_amd.net import Comm
 
-    lib = abi.load()   # raises if the HIP extension is missing -- there is no fallback path
-    # a real (non-default) stream: the library replays launch-bound loops as hipGraphs, and the legacy
-    # default stream cannot be captured.  Everything below -- kernels, RCCL all-reduce -- runs on it.
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    lib.call("clstm_set_stream", stream.cuda_stream)
-    dev = torch.device("cuda", local_rank)
+    lib = abi.load(os.environ.get("CLSTM_BENCH_LIB") or None)   # raises if the HIP extension is missing -- there is no fallback path
+    if not ON_CPU:
+        # a real (non-default) stream: the library replays launch-bound loops as hipGraphs, and the legacy
+        # default stream cannot be captured.  Everything below -- kernels, RCCL all-reduce -- runs on it.
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+        lib.call("clstm_set_stream", stream.cuda_stream)
     # gradient exchange: the library's own RCCL communicator (all-reduce enqueued on the library stream right
     # before the update kernel, no cross-stream events); torch.distributed only carries the 128-byte id, the
     # barriers and the max-over-ranks of the timing.  If the communicator cannot be created the step falls back to
@@ -450,10 +474,10 @@ def main():
             allreduce_ranks = world
 
     def fence():
-        torch.cuda.synchronize()
+        device_sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     def reduce_max(dt):
         if dist is None:
@@ -503,13 +527,19 @@ def main():
             for _ in range(5):
                 comm.allreduce(w.grads, n)
             fence()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(50):
-                comm.allreduce(w.grads, n)
-            e1.record()
-            torch.cuda.synchronize()
-            ar_ms = reduce_max(e0.elapsed_time(e1) / 50.0)
+            if ON_CPU:
+                t_ar = time.perf_counter()
+                for _ in range(50):
+                    comm.allreduce(w.grads, n)
+                ar_ms = reduce_max((time.perf_counter() - t_ar) * 1e3 / 50.0)
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    comm.allreduce(w.grads, n)
+                e1.record()
+                torch.cuda.synchronize()
+                ar_ms = reduce_max(e0.elapsed_time(e1) / 50.0)
         if comm is not None and int(lib.dll.clstm_comm_peer_active(comm.h)):
             allreduce_impl = ("one-shot peer-read all-reduce fused into the update kernel (HIP IPC mappings of the ranks' gradient buffers over "
                               "xGMI, flag handshake; ops.h:k_peer_allreduce_update) inside clstm_net_train_step; clstm_allreduce_flat = RCCL")
@@ -533,6 +563,33 @@ def main():
         ws.net = ws.trainer = None
         del ws
 
+    # the same net with the chip FULL (default single-GPU line only): 256 lines per GPU = two recurrence workgroups per CU.  At 64
+    # lines the step is one line's dependent chain on half of the CUs (the headline roofline says how far a latency-bound
+    # recurrence sits from a bandwidth bound); here the fused gate kernel is VALU-throughput-bound, and its fraction of the
+    # HBM roof and of the packed-FMA rate is the "how far from the machine" number for the kernel itself.
+    saturated = None
+    if rank == 0 and world == 1 and default_line:
+        wsat = Workload(lib, cfg, 256, args.T, False, 0, dev, rank)
+        ssat = max(5, min(args.steps, 20))
+        msat = measure(wsat, ssat, 3, 20, unfused_pass=True, min_timed_s=0.5)
+        ms_sat = msat["dt"] / ssat * 1e3
+        rsat = roofline_b1(wsat, msat["kern"], msat["kern_unfused"], msat["frames_per_step"], ms_sat) if msat["kern"] else None
+        if rsat is not None:
+            cells_steps = 2 * sum(cfg["nh"]) * msat["frames_per_step"]
+            rec_flops = 8.0 * cfg["nh"][0] * cells_steps           # 4 gates x no MACs per cell-step of R.h
+            pure = (msat["kern"] if "gemm_gates_x" in msat["kern"] else msat["kern_unfused"]).get("lstm_fwd")   # the recurrence alone
+            if pure:
+                tf = rec_flops / (pure["ms_per_step"] * 1e-3) / 1e12
+                rsat["recurrent_matvec"] = {"kernel": "lstm_fwd (fusions off)", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
+                                            "frac": round(tf / F32_MFMA_PEAK_TFS, 5),
+                                            "note": "R.h of the forward recurrence as packed f32 FMAs (v_pk_fma_f32) against the f32 vector peak"}
+        saturated = {"value": round(256 * ssat / msat["dt"], 2), "unit": "lines/s", "ms_per_step": round(ms_sat, 4), "steps": ssat,
+                     "repeats": len(msat["blocks"]), "config": {"workload": "the headline net at minibatch = 256 lines per GPU (two recurrence workgroups per CU)",
+                                                                "minibatch_per_gpu": 256},
+                     "roofline": rsat, "kernels": msat["kern"]}
+        wsat.net = wsat.trainer = None
+        del wsat
+
     # BASELINE.json configs[4] in the same process (default single-GPU line only): 2 x BiLSTM(512), bf16 MFMA
     secondary = None
     if rank == 0 and world == 1 and default_line and not args.no_secondary:
@@ -552,20 +609,24 @@ def main():
             "data": "synthetic",
             "config": {"workload": "stacked 2xBiLSTM(512) H=64 nc=100, T=400, L=50, minibatch=64 lines on 1 GPU "
                                    "(BASELINE.json configs[4] shape), fwd+CTC+bwd+update", "minibatch_per_gpu": 64},
-            "roofline": (lambda r: dict(r, rocprof_avg_launch_ms=rocprof_b2_avg_ms(r.get("kernel"))))(roofline_b2(w2, m2["kern"], m2["frames_per_step"], ms2)) if m2["kern"] else None,
+            "roofline": (lambda r: dict(r, rocprof_avg_launch_ms_from_committed_profile=rocprof_b2_avg_ms(r.get("kernel"))))(roofline_b2(w2, m2["kern"], m2["frames_per_step"], ms2)) if m2["kern"] else None,
             "kernels": m2["kern"],
             "parity": "stated tolerance against the f32 oracle at this size: tests/test_gpu_e2e.py::test_configs4_full_shape_bf16_vs_oracle",
         }
         del w2
     # ... and its parity-grade form: every gate activation inside 1e-4 of the oracle at this size
-    # (tests/test_gpu_e2e.py::test_configs4_full_shape_f32_vs_oracle); 3 steps x 2 repeats
+    # (tests/test_gpu_e2e.py::test_configs4_full_shape_f32_vs_oracle); 10 steps x >= 3 repeats
     secondary_f32 = None
     if rank == 0 and world == 1 and default_line and not args.no_secondary:
         c2 = CONFIGS["b2"]
         w3 = Workload(lib, c2, 64, c2["T"], False, 0, dev, rank)
-        m3 = measure(w3, 3, 2, 0, min_timed_s=0.08)
-        secondary_f32 = {"metric": "text-line images/sec (fwd+bwd+CTC), 2xBiLSTM(512) H=64 T~400 (f32)", "value": round(64 * 3 / m3["dt"], 2),
-                         "unit": "lines/s", "steps": 3, "repeats": len(m3["blocks"]), "ms_per_step": round(m3["dt"] / 3 * 1e3, 4),
+        m3 = measure(w3, 10, 2, 0, min_timed_s=0.25)        # 10 steps x >= 3 repeats
+        fl3 = flops_per_line(c2, c2["T"]) * 64 / (m3["dt"] / 10) / 1e12
+        secondary_f32 = {"metric": "text-line images/sec (fwd+bwd+CTC), 2xBiLSTM(512) H=64 T~400 (f32)", "value": round(64 * 10 / m3["dt"], 2),
+                         "unit": "lines/s", "steps": 10, "repeats": len(m3["blocks"]), "ms_per_step": round(m3["dt"] / 10 * 1e3, 4),
+                         "whole_step_tflops": {"achieved": round(fl3, 2), "unit": "TFLOP/s",
+                                               "note": "bf16x3-ASSISTED: the backward two thirds of these flops run as three bf16 MFMAs per product "
+                                                       "(16x the f32 MFMA's rate), so this figure is NOT a fraction of the 157.3 TFLOP/s f32 MFMA peak"},
                          "dtype": "f32 (forward pass incl. its recurrences, CTC, decode: exact f32; BACKWARD products of the wide layers -- weight "
                                   "gradient, input deltas and the recurrent delta product R^T.delta inside the backward recurrence: f32-grade bf16x3 "
                                   "split, < 2^-16 per product; gradient 1.45e-5 of its largest entry from the float64 oracle at this size, "
@@ -604,6 +665,7 @@ def main():
             "host_enqueue_ms_per_step": round(m["enqueue"] * 1e3, 4),   # host-side cost of issuing a step
             "allreduce": allreduce,
             "strict_f32": strict,
+            "saturated": saturated,
             "secondary": secondary,
             "secondary_f32": secondary_f32,
         }

@@ -109,6 +109,8 @@ _SIGS = {
     "clstm_comm_peer_active": [_P],
     "clstm_allreduce_flat": [_P, _P, C.c_longlong],
     "clstm_net_set_comm": [_P, _P],
+    "clstm_net_replica_check": [_P],
+    "clstm_net_set_training": [_P, _I],
     "clstm_net_set_overlap": [_P, _I],
     "clstm_net_set_strict_f32": [_P, _I],
     "clstm_net_overlap_stats": [_P, _P, _P],

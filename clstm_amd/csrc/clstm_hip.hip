@@ -323,7 +323,9 @@ static void launch_steps(StepGraphCache& cache, int kind, const A& a, int tmax, 
 // Device error words shared by every net of the process: [0] sticky outcome of persistent recurrence launches,
 // [1] weight-gradient items of the fused backward launch that gave up waiting (gemm_dw.h), [2] waits of the fused FORWARD
 // launch that gave up (lstm_fwd_fused.h, lstm_seq.h:wait_chunk), [3] number of the training step whose gradient had a
-// non-finite entry (ops.h:k_update; the reference asserts on NaN in every backward step, clstm.cc:630-649).  The update
+// non-finite entry (ops.h:k_update; the reference asserts on NaN in every backward step, clstm.cc:630-649), [6] device-side
+// peer-barrier waits that timed out (ops.h:k_peer_barrier), [7] the training step at which the replica check found the ranks'
+// parameters different (ops.h:k_replica_verify); [4], [5] unused.  The update
 // kernels skip the update while any is set; the host throws at its next synchronisation point (clstm_synchronize, any
 // read-back).
 static int* g_dev_err = nullptr;
@@ -404,10 +406,16 @@ static XcdOutcome g_xcd_outcome;
 static void check_device_errors() {
   g_xcd_outcome.check_all();
   if (!g_dev_err) return;
-  int w[4] = {0, 0, 0, 0};
+  int w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIPCHECK(hipMemcpy(w, g_dev_err, sizeof(w), hipMemcpyDeviceToHost));
-  if ((w[0] | w[1] | w[2] | w[3]) == 0) return;
+  if ((w[0] | w[1] | w[2] | w[3] | w[6] | w[7]) == 0) return;
   (void)hipMemset(g_dev_err, 0, sizeof(w));
+  if (w[7]) throw Error("data-parallel replicas diverged: the parameter checksums of the ranks differ at training step " + std::to_string(w[7]) + " of a net (replica check, "
+                        "CLSTM_REPLICA_CHECK_EVERY); every rank applies the identical update to the identical all-reduced gradient, so this is a fault (a skipped update on "
+                        "one rank, memory corruption), not drift -- no update was applied since.  The reference re-broadcasts the weights instead (distribute_weights, clstm.cc:718-729)");
+  if (w[6]) throw Error("gradient exchange: " + std::to_string(w[6]) + " wait(s) of the device-side peer barrier timed out (CLSTM_PEER_DEVICE_TIMEOUT_S, default 120 s) although every "
+                        "rank's host had announced the exchange: a peer's GPU never reached it; the minibatches enqueued since then were NOT applied -- CLSTM_PEER_ALLREDUCE=0 "
+                        "puts the exchange back on RCCL");
   if (w[3]) throw Error("non-finite value (NaN or Inf) in the softmax logits or the gradient of training step " + std::to_string(w[3]) + " of a net (forward passes counted per net "
                         "from 1): no non-finite entry reaches the parameters or the momentum -- a diverged forward pass skips the whole update, a non-finite gradient entry is "
                         "skipped -- and no update enqueued since was applied.  The reference aborts here (clstm.cc:630-649).  Lower the learning rate, or CLSTM_NANCHECK=0 "
@@ -421,7 +429,8 @@ static void check_device_errors() {
               "minibatches since then were NOT applied -- set CLSTM_OVERLAP=0");
 }
 static bool g_wide_persistent = false;   // the last launch_lstm_wide call ran the persistent per-XCD kernels
-static int g_debug_fail_claims = 0;      // tests: this many upcoming persistent launches fail their placement check
+static int g_debug_fail_claims = 0;      // tests: this many upcoming persistent launches fail their placement check ...
+static int g_debug_fail_skip = 0;        // ... after this many that do not
 
 // fx_ngx > 0 (forward, bf16): try ONLY the persistent kernel with the input projection folded in (lstm_xcd_fwd_bf16_fx<fx_ngx>);
 // returns false -- nothing launched or nothing written -- if it does not apply or its placement check failed: the caller then
@@ -451,7 +460,7 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     const int nzb = nzb_ > 0 ? nzb_ : nzb_default, zb_per = zb_per_ > 0 ? zb_per_ : zb_per_default;
     for (int zb0 = 0; zb0 < nzb && ok; zb0 += zb_per) {
       a.zb0 = zb0; a.zbn = std::min(zb_per, nzb - zb0);
-      a.debug_fail_claim = g_debug_fail_claims > 0 ? (g_debug_fail_claims--, 1) : 0;
+      a.debug_fail_claim = g_debug_fail_skip > 0 ? (g_debug_fail_skip--, 0) : g_debug_fail_claims > 0 ? (g_debug_fail_claims--, 1) : 0;
       // (the counter words are zero: DevBuf zero-fills, and every persistent launch returns them to zero as its last act;
       // the stamps of the group barriers keep counting up: lstm_wide.h:xcd_finish)
       {
@@ -709,11 +718,50 @@ struct PeerExchange {
 #include <sys/stat.h>
 #include <unistd.h>
 namespace clstm {
+// seconds from an environment variable (a hang detector's bound, read once per use site)
+static double env_seconds(const char* name, double dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  const double v = atof(e);
+  return v > 0 ? v : dflt;
+}
+// ticks of wall_clock() (100 MHz) k_peer_barrier waits for a peer whose HOST has already announced the step
+static long long peer_device_timeout_ticks() { return (long long)(env_seconds("CLSTM_PEER_DEVICE_TIMEOUT_S", 120.0) * 1e8); }
+// What the hosts of a communicator share besides the set-up handshake: announced[r] = the last exchange sequence number rank r's
+// host is about to enqueue the device barrier for; left[r] = rank r has destroyed its communicator (or failed).
+struct PeerHostWords { std::atomic<int> announced[PEER_MAX_RANKS], left[PEER_MAX_RANKS]; };
+// Before a rank enqueues k_peer_barrier for sequence number sq it announces sq and waits -- on the HOST, as long as it takes,
+// like ncclAllReduce would -- until every rank's host has announced it too.  A rank whose host is busy elsewhere (clstmocrtrain's
+// rank 0 runs the test set and saves while the others are already at the next step) therefore stalls its peers' hosts, not
+// their GPUs' watchdog: the device barrier only ever waits for queued device work.  CLSTM_PEER_HOST_TIMEOUT_S bounds the
+// wait (default: none); a peer that has left the communicator ends it with an error at once.
+static void peer_announce_and_wait(PeerHostWords* w, int rank, int nranks, int sq) {
+  if (!w) return;
+  w->announced[rank].store(sq);
+  static const double limit = env_seconds("CLSTM_PEER_HOST_TIMEOUT_S", 0.0);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < nranks; r++) {
+    int spins = 0;
+    while ((int)((unsigned)sq - (unsigned)w->announced[r].load()) > 0) {   // (wrap-safe: rank r is still behind sq)
+      if (w->left[r].load()) throw Error("gradient exchange: rank " + std::to_string(r) + " has left the communicator (exchange " + std::to_string(sq) + " never announced)");
+      if (++spins < 2000) sched_yield(); else usleep(100);
+      if (limit > 0 && (spins & 255) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+        throw Error("gradient exchange: rank " + std::to_string(r) + " did not reach exchange " + std::to_string(sq) + " within CLSTM_PEER_HOST_TIMEOUT_S");
+    }
+  }
+}
 struct Comm {
   ncclComm_t comm = nullptr;            // null: a communicator WITHOUT RCCL (CLSTM_COMM_NO_RCCL=1, tests) -- peer path only
   int rank = 0, nranks = 1;
   char id[CLSTM_COMM_ID_BYTES] = {};
   PeerExchange peer;
+  DevBuf<float> chk;                    // replica check: [own 4 | summed 4] checksum pieces (ops.h:k_param_checksum)
+  DevBuf<unsigned> chk_acc;
+  void peer_barrier(int sq, hipStream_t s) {
+    peer_announce_and_wait(rv ? &rv->hw : nullptr, rank, nranks, sq);
+    const PeerArgs pa = peer.args(sq, rank, nranks);
+    CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, dev_err_words() + 6, peer_device_timeout_ticks());
+  }
   void allreduce(float* buf, long long n, hipStream_t s) {
     if (comm) { RCCLCHECK(RcclApi::get().AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, comm, s)); return; }
     if (nranks == 1) return;
@@ -721,15 +769,17 @@ struct Comm {
     REQUIRE(peer_ready((size_t)n, s), "communicator without RCCL: the ranks could not map each other's exchange buffers (HIP IPC)");
     const int sq = ++peer.seq;
     HIPCHECK(hipMemcpyAsync(peer.slot_ptr(sq), buf, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    peer_barrier(sq, s);
     const PeerArgs pa = peer.args(sq, rank, nranks);
-    CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, dev_err_words());
     CLSTM_LAUNCH(k_peer_allreduce_update, dim3(nblocks((size_t)(n + 3) / 4)), dim3(256), 0, s, pa, (float*)nullptr, (float*)nullptr, buf, (size_t)n, 0.0f, 0.0f, 0.0f,
                  (const int*)nullptr, (int*)nullptr, 0, (int*)nullptr, 0);
     check_launch();
   }
-  // rendezvous of the ranks of this host: a shared segment named after the communicator id
+  // rendezvous of the ranks of this host: a shared segment named after the communicator id.  It stays mapped for the life of
+  // the communicator (the hosts' announce words live in it); its NAME goes as soon as every rank has it open.
   struct Handles { hipIpcMemHandle_t x, f; int ok; int pad[3]; };
-  struct Rendezvous { std::atomic<int> magic, arrived, mapped, good, probed, probe_good; Handles h[PEER_MAX_RANKS]; };
+  struct Rendezvous { std::atomic<int> magic, arrived, mapped, good, probed, probe_good; PeerHostWords hw; Handles h[PEER_MAX_RANKS]; };
+  Rendezvous* rv = nullptr;
   static bool wait_for(std::atomic<int>& w, int target, double seconds) {
     const auto t0 = std::chrono::steady_clock::now();
     while (w.load() < target) {
@@ -737,6 +787,30 @@ struct Comm {
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
     }
     return true;
+  }
+  // The four probe rounds of peer_ready: sequence numbers no training step uses, alternating slots like the steps do
+  // (-5: slot 1, -4: slot 0, -3: slot 1, -2: slot 0; the first step is 1: slot 1), every slot written twice with
+  // different patterns (ops.h:k_peer_fill / k_peer_probe).
+  bool probe_rounds(hipStream_t s) {
+    PeerExchange& p = peer;
+    int* perr = nullptr;
+    if (hipMalloc((void**)&perr, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    bool ran = hipMemsetAsync(perr, 0, sizeof(int), s) == hipSuccess;
+    for (int round = 0; ran && round < 4; round++) {
+      const int sq = -5 + round;
+      const PeerArgs pa = p.args(sq, rank, nranks);
+      CLSTM_LAUNCH(k_peer_fill, dim3(nblocks(p.cap)), dim3(256), 0, s, p.slot_ptr(sq), p.cap, rank, round);
+      CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, perr, (long long)(env_seconds("CLSTM_PEER_PROBE_TIMEOUT_S", 20.0) * 1e8));
+      CLSTM_LAUNCH(k_peer_probe, dim3(nblocks(p.cap)), dim3(256), 0, s, pa, p.cap, round, perr);
+      ran = hipGetLastError() == hipSuccess;
+    }
+    int e = 1;
+    ran = ran && hipMemcpyAsync(&e, perr, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && e == 0;
+    if (!ran) (void)hipGetLastError();
+    // (the slots keep the last patterns: a peer may still be reading them, and every later user assigns what it reads --
+    //  the gradient reductions write all nparams elements, the readers' descriptors end there)
+    (void)hipFree(perr);
+    return ran;
   }
   // collective (every rank calls it at the same point of its first one-call training step): true if the peer path is up
   bool peer_ready(size_t n, hipStream_t s) {
@@ -749,7 +823,15 @@ struct Comm {
     Handles mine{};
     mine.ok = 1;
     p.cap = (PEER_MAX_FLOATS < ((n + 63) / 64 * 64) ? PEER_MAX_FLOATS : (n + 63) / 64 * 64);
-    if (hipMalloc((void**)&p.xbuf, 2 * p.cap * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); mine.ok = 0; p.xbuf = nullptr; }
+    // Exchange slots AND flags are fine-grained device memory: what a peer reads through its mapping while kernels of the owner
+    // are still running must not depend on when the owner's L2 writes a line back, nor on a cache of the reader's side holding
+    // the slot's lines of two steps ago -- fine-grained allocations are coherent at system scope by construction (the readers
+    // also use system-scope loads, ops.h).  0.5 MB written once per step by the gradient reductions: the uncached stores cost
+    // nothing measurable.  Coarse-grained memory only if the fine-grained allocation fails; the probe below judges either.
+    if (hipExtMallocWithFlags((void**)&p.xbuf, 2 * p.cap * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hipMalloc((void**)&p.xbuf, 2 * p.cap * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); mine.ok = 0; p.xbuf = nullptr; }
+    }
     if (hipExtMallocWithFlags((void**)&p.flags, 2 * PEER_MAX_RANKS * sizeof(int), hipDeviceMallocFinegrained) != hipSuccess) {
       (void)hipGetLastError();
       if (hipMalloc((void**)&p.flags, 2 * PEER_MAX_RANKS * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); mine.ok = 0; p.flags = nullptr; }
@@ -766,7 +848,6 @@ struct Comm {
     char name[64];
     snprintf(name, sizeof name, "/clstm_px_%016llx", hsh);
     const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-    Rendezvous* rv = nullptr;
     if (fd >= 0 && ftruncate(fd, sizeof(Rendezvous)) == 0) {
       void* m = mmap(nullptr, sizeof(Rendezvous), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
       if (m != MAP_FAILED) rv = (Rendezvous*)m;
@@ -774,9 +855,10 @@ struct Comm {
     if (fd >= 0) close(fd);
     bool good = rv != nullptr;
     if (rv) {
+      const double setup_s = env_seconds("CLSTM_PEER_SETUP_TIMEOUT_S", 60.0);
       rv->h[rank] = mine;
       rv->arrived.fetch_add(1);
-      good = wait_for(rv->arrived, nranks, 20.0);
+      good = wait_for(rv->arrived, nranks, setup_s);
       for (int r = 0; good && r < nranks; r++) good = rv->h[r].ok != 0;
       for (int r = 0; good && r < nranks; r++) {
         if (r == rank) { p.px[r] = p.xbuf; p.pf[r] = p.flags; continue; }
@@ -788,35 +870,17 @@ struct Comm {
       // ... and they agree: the peer path only if EVERY rank mapped every other rank
       if (good) rv->good.fetch_add(1);
       rv->mapped.fetch_add(1);
-      const bool all_here = wait_for(rv->mapped, nranks, 20.0);
+      const bool all_here = wait_for(rv->mapped, nranks, setup_s);
       good = all_here && rv->good.load() == nranks;
-      // ... and the mappings WORK: one handshake through the mapped flag arrays and one look at every rank's buffer through this
-      // rank's mapping of it (pattern rank + 1), with a probe sequence number no training step uses -- a path that maps but does
-      // not deliver (flags that never arrive, stale or foreign data) falls back to RCCL here instead of failing at the first step
+      // ... and the mappings DELIVER: four handshakes through the mapped flag arrays, each followed by a look at EVERY element of
+      // every rank's slot through this rank's mapping of it (probe_rounds) -- a path that maps but does not deliver (flags that
+      // never arrive, stale, partial or foreign data) falls back to RCCL here instead of failing at the first step
       if (good) {
-        int* perr = nullptr;
-        bool ran = hipMalloc((void**)&perr, sizeof(int)) == hipSuccess;
-        if (ran) {
-          const float pat = (float)(rank + 1);
-          const PeerArgs pa = p.args(-2, rank, nranks);
-          ran = hipMemsetAsync(perr, 0, sizeof(int), s) == hipSuccess &&
-                hipMemcpyAsync(p.slot_ptr(-2), &pat, sizeof(float), hipMemcpyHostToDevice, s) == hipSuccess &&
-                hipStreamSynchronize(s) == hipSuccess;
-          if (ran) {
-            CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, -2, perr);
-            CLSTM_LAUNCH(k_peer_probe, dim3(1), dim3(64), 0, s, pa, perr);
-            int e = 1;
-            ran = hipMemcpyAsync(&e, perr, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && e == 0;
-          }
-          (void)hipFree(perr);
-        }
-        if (!ran) (void)hipGetLastError();
-        if (ran) rv->probe_good.fetch_add(1);
+        if (probe_rounds(s)) rv->probe_good.fetch_add(1);
         rv->probed.fetch_add(1);
-        good = wait_for(rv->probed, nranks, 40.0) && rv->probe_good.load() == nranks;
+        good = wait_for(rv->probed, nranks, 2 * setup_s) && rv->probe_good.load() == nranks;
       }
       if (rank == 0) shm_unlink(name);          // (every rank that will ever come has it open or has given up)
-      munmap(rv, sizeof(Rendezvous));
     }
     p.ok = good;
     if (!p.ok) peer_release();
@@ -824,6 +888,7 @@ struct Comm {
   }
   void peer_release() {
     PeerExchange& p = peer;
+    if (rv) { rv->hw.left[rank].store(1); munmap(rv, sizeof(Rendezvous)); rv = nullptr; }
     for (int r = 0; r < PEER_MAX_RANKS; r++) {
       if (r != rank && p.px[r]) (void)hipIpcCloseMemHandle(p.px[r]);
       if (r != rank && p.pf[r]) (void)hipIpcCloseMemHandle(p.pf[r]);
@@ -835,6 +900,7 @@ struct Comm {
   }
   ~Comm() {
     peer_release();
+    chk.release(); chk_acc.release();
     if (comm) (void)RcclApi::get().CommDestroy(comm);
   }
 };
@@ -854,28 +920,59 @@ namespace clstm {
 constexpr size_t PEER_MAX_FLOATS = 1u << 18;
 struct PeerExchange {   // (host emulator: the "mapped" buffers and flags of the ranks are regions of the shared segment)
   bool tried = false, ok = false;
-  size_t cap = 0;
+  size_t cap = 0;                          // floats of a slot in use (the slots lie PEER_MAX_FLOATS apart)
   float* xbuf = nullptr;
   int* flags = nullptr;
   float* px[PEER_MAX_RANKS] = {};
   int* pf[PEER_MAX_RANKS] = {};
   int seq = 0;
-  float* slot_ptr(int sq) const { return xbuf + (size_t)(sq & 1) * cap; }
+  float* slot_ptr(int sq) const { return xbuf + (size_t)(sq & 1) * PEER_MAX_FLOATS; }
   PeerArgs args(int sq, int rank, int nranks) const {
     PeerArgs a{};
     a.nranks = nranks; a.rank = rank;
-    for (int r = 0; r < nranks; r++) { a.x[r] = px[r] + (size_t)(sq & 1) * cap; a.f[r] = pf[r] + (sq & 1) * PEER_MAX_RANKS; }
+    for (int r = 0; r < nranks; r++) { a.x[r] = px[r] + (size_t)(sq & 1) * PEER_MAX_FLOATS; a.f[r] = pf[r] + (sq & 1) * PEER_MAX_RANKS; }
     return a;
   }
 };
+// (the hosts' announce words: see the GPU build's PeerHostWords / peer_announce_and_wait above -- same protocol)
+struct PeerHostWords { std::atomic<int> announced[PEER_MAX_RANKS], left[PEER_MAX_RANKS]; };
+static double env_seconds(const char* name, double dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  const double v = atof(e);
+  return v > 0 ? v : dflt;
+}
+static long long peer_device_timeout_ticks() { return (long long)(env_seconds("CLSTM_PEER_DEVICE_TIMEOUT_S", 120.0) * 1e8); }
+static void peer_announce_and_wait(PeerHostWords* w, int rank, int nranks, int sq) {
+  if (!w) return;
+  w->announced[rank].store(sq);
+  static const double limit = env_seconds("CLSTM_PEER_HOST_TIMEOUT_S", 0.0);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < nranks; r++) {
+    int spins = 0;
+    while ((int)((unsigned)sq - (unsigned)w->announced[r].load()) > 0) {
+      if (w->left[r].load()) throw Error("gradient exchange: rank " + std::to_string(r) + " has left the communicator (exchange " + std::to_string(sq) + " never announced)");
+      if (++spins < 2000) sched_yield(); else usleep(100);
+      if (limit > 0 && (spins & 255) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+        throw Error("gradient exchange: rank " + std::to_string(r) + " did not reach exchange " + std::to_string(sq) + " within CLSTM_PEER_HOST_TIMEOUT_S");
+    }
+  }
+}
 struct Comm {
   static const long long SLOT = 1 << 18;
-  struct Shm { std::atomic<int> magic, arrived, gen; int pad; float slots[1]; };
+  struct Shm { std::atomic<int> magic, arrived, gen; int pad; PeerHostWords hw; float slots[1]; };
   int rank = 0, nranks = 1;
   PeerExchange peer;
+  DevBuf<float> chk;
+  DevBuf<unsigned> chk_acc;
+  void peer_barrier(int sq, hipStream_t s) {
+    peer_announce_and_wait(shm ? &shm->hw : nullptr, rank, nranks, sq);
+    const PeerArgs pa = peer.args(sq, rank, nranks);
+    CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, dev_err_words() + 6, peer_device_timeout_ticks());
+  }
   // per rank behind the all-reduce slots: exchange buffer [2][SLOT] floats, then flags [2][PEER_MAX_RANKS] ints (zero pages)
   static size_t peer_region_bytes() { return (size_t)2 * SLOT * sizeof(float) + 2 * PEER_MAX_RANKS * sizeof(int) + 64; }
-  bool peer_ready(size_t n, hipStream_t) {
+  bool peer_ready(size_t n, hipStream_t s) {
     PeerExchange& p = peer;
     if (p.tried) return p.ok && n <= p.cap;
     p.tried = true;
@@ -886,7 +983,18 @@ struct Comm {
       p.px[r] = (float*)(base + (size_t)r * peer_region_bytes());
       p.pf[r] = (int*)(base + (size_t)r * peer_region_bytes() + (size_t)2 * SLOT * sizeof(float));
     }
-    p.cap = SLOT; p.xbuf = p.px[rank]; p.flags = p.pf[rank];
+    p.cap = (n + 63) / 64 * 64; p.xbuf = p.px[rank]; p.flags = p.pf[rank];
+    // the set-up probe of the GPU build, same kernels (ops.h:k_peer_fill / k_peer_probe), over the slot length in use
+    int perr = 0;
+    for (int round = 0; round < 4; round++) {
+      const int sq = -5 + round;
+      const PeerArgs pa = p.args(sq, rank, nranks);
+      CLSTM_LAUNCH(k_peer_fill, dim3(nblocks(p.cap)), dim3(256), 0, s, p.slot_ptr(sq), p.cap, rank, round);
+      CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, &perr, (long long)(env_seconds("CLSTM_PEER_PROBE_TIMEOUT_S", 60.0) * 1e8));
+      CLSTM_LAUNCH(k_peer_probe, dim3(nblocks(p.cap)), dim3(256), 0, s, pa, p.cap, round, &perr);
+    }
+    // (the slots keep the last patterns: a peer may still be reading them; every later user assigns what it reads)
+    REQUIRE(perr == 0, "emulator communicator: the peer probe failed");
     p.ok = true;
     return true;
   }
@@ -937,7 +1045,7 @@ struct Comm {
       barrier();
     }
   }
-  ~Comm() { if (shm) munmap(shm, bytes); }
+  ~Comm() { if (shm) { shm->hw.left[rank].store(1); munmap(shm, bytes); } chk.release(); chk_acc.release(); }
 };
 #endif
 
@@ -1485,7 +1593,7 @@ struct Net {
     // the top layer's output rows are [1 | h]: they ARE the softmax layer's source rows
     if (nc <= SMX_COLS) {   // logits, limexp and normalisation in one kernel (softmax_fused.h)
       timing.begin("gemm_softmax", s);
-      softmax_fwd(s, gemm_kc(L.back().hrow(), L.back().ldh, N), W1, (long long)nc * (1 + sm_ni), Z.p, (int)N, nc, sm_ni, nanflag(), step_no() + 1);
+      softmax_fwd(s, gemm_kc(L.back().hrow(), L.back().ldh, N), W1, (long long)nc * (1 + sm_ni), Z.p, (int)N, nc, sm_ni, fwd_nanflag(), step_no() + 1);
       timing.end(s);
       check_launch();
     } else {
@@ -1499,7 +1607,7 @@ struct Net {
       timing.end(s);
       check_launch();
       timing.begin("softmax_norm", s);
-      CLSTM_LAUNCH(k_softmax_norm, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Z.p, nc, (size_t)N, nanflag(), step_no() + 1);
+      CLSTM_LAUNCH(k_softmax_norm, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Z.p, nc, (size_t)N, fwd_nanflag(), step_no() + 1);
       timing.end(s);
       check_launch();
     }
@@ -1571,7 +1679,7 @@ struct Net {
     h.pitems = fw_items.p; h.npitems = fw_npitems; h.gflag = fw_flags.p;
     h.W1k = W1k; h.kps = w1k_kps; h.sm_k = sm_ni; h.b1 = v + sm_off; h.Z = Z.p; h.nc = desc.nclasses;
     h.citems = fw_items.p + 4 * fw_npitems; h.ncitems = fw_ncitems;
-    h.nanflag = nanflag(); h.step_no = step_no() + 1;
+    h.nanflag = fwd_nanflag(); h.step_no = step_no() + 1;
     h.prog = (const int*)(y.H.p + a.prog_off);
     h.nrec = bs * ndir; h.npb = fw_npitems;
     const unsigned nblk = (unsigned)(h.nrec + h.npb + fw_ncitems);   // one item per helper workgroup
@@ -1958,6 +2066,11 @@ struct Net {
 
   long long nbackward = 0;           // backward passes of this net so far = the number of the current training step (from 1)
   int step_no() const { return (int)std::min<long long>(nbackward, 2147483647LL); }
+  // The reference asserts on non-finite values in BACKWARD only (clstm.cc:630-649): a forward pass that belongs to no
+  // training step (predict, the test-set pass of clstmocrtrain: clstm_net_set_training(net, 0)) must not arm the process-wide
+  // word -- one NaN logit in an inference pass would block the updates of every net of the process.
+  bool training = true;
+  int* fwd_nanflag() const { return training ? nanflag() : nullptr; }
   static int* nanflag() {            // device error word [3], or null when CLSTM_NANCHECK=0
     static const bool on = !(getenv("CLSTM_NANCHECK") && atoi(getenv("CLSTM_NANCHECK")) == 0);
     return on ? dev_err_words() + 3 : nullptr;
@@ -1968,6 +2081,13 @@ struct Net {
                               //   peer-read all-reduce fused with the update (set by train_step when a communicator of > 1 ranks is attached)
   bool peer_pending = false;  // ... this backward pass did so
   bool fuse_update = false;   // the NEXT backward pass applies the update inside its reductions (set by train_step)
+  // The update rides the slab reductions only where ONE reduction launch covers every parameter (a single LSTM layer: its gate
+  // blocks and the softmax layer's W1 are reduced together, after the last recurrence of the pass).  In a stacked net the
+  // reductions run layer by layer, top down, with the lower layers' recurrences in between: an error word raised by one of
+  // those (a persistent launch that lost its placement, a watchdog) would find the upper layers' parameters already updated
+  // -- half a step.  There the reductions only stage g and k_update applies the whole step behind the last recurrence, or
+  // nothing (35 us of a 4 ms step at configs[4]).
+  bool fuse_eligible() const { return (!comm || comm->nranks == 1) && L.size() == 1; }
   bool update_applied = false; // ... and has done so: update() has nothing left to launch
   void update() {
     hipStream_t s = stream();
@@ -1983,7 +2103,7 @@ struct Net {
       const int sq = ++comm->peer.seq;
       const PeerArgs pa = comm->peer.args(sq, comm->rank, comm->nranks);
       timing.begin("allreduce_grads", s);
-      CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, dev_err_words());
+      comm->peer_barrier(sq, s);   // (the hosts announce the exchange to each other first: Comm::peer_barrier)
       timing.end(s);
       timing.begin("sgd_update", s);
       CLSTM_LAUNCH(k_peer_allreduce_update, dim3(nblocks((size_t)(nparams + 3) / 4)), dim3(256), 0, s, pa, v, d, g, (size_t)nparams, lr, mom, gclip,
@@ -1993,6 +2113,7 @@ struct Net {
       check_launch();
       g_path_count[7]++;
       packed_dirty = true;
+      maybe_replica_check(s);
       return;
     }
     if (comm && comm->nranks > 1) {   // sum of the ranks' fresh minibatch gradients, in place, on this stream (share_deltas, clstm.cc:731-744)
@@ -2008,6 +2129,31 @@ struct Net {
     timing.end(s);
     check_launch();
     packed_dirty = true;
+    if (comm && comm->nranks > 1) maybe_replica_check(s);
+  }
+  // Replica consistency (ops.h:k_param_checksum ...): every replica_every-th update of a net whose communicator has several
+  // ranks, and on request (clstm_net_replica_check).  Everything stays on the stream; a mismatch lands in device error word [7].
+  long long nupdates_dp = 0;
+  static int replica_every() {
+    static const int n = getenv("CLSTM_REPLICA_CHECK_EVERY") ? atoi(getenv("CLSTM_REPLICA_CHECK_EVERY")) : 256;
+    return n;
+  }
+  void maybe_replica_check(hipStream_t s) {
+    nupdates_dp++;
+    const int every = replica_every();
+    if (every > 0 && nupdates_dp % every == 0) replica_check(s);
+  }
+  void replica_check(hipStream_t s) {
+    if (!comm || comm->nranks < 2) return;
+    RoctxRange range_("clstm:replica_check");
+    comm->chk.reserve(8);
+    comm->chk_acc.reserve(2);
+    CLSTM_LAUNCH(k_param_checksum, dim3(std::min<unsigned>(nblocks(nparams), 1024u)), dim3(256), 0, s, (const float*)v, (size_t)nparams, comm->chk_acc.p);
+    CLSTM_LAUNCH(k_checksum_pieces, dim3(1), dim3(64), 0, s, comm->chk_acc.p, comm->chk.p);
+    comm->allreduce(comm->chk.p + 4, 4, s);
+    CLSTM_LAUNCH(k_replica_verify, dim3(1), dim3(64), 0, s, (const float*)comm->chk.p, comm->nranks, dev_err_words() + 7, step_no());
+    check_launch();
+    g_path_count[12]++;
   }
 };
 
@@ -2485,7 +2631,7 @@ int clstm_net_train_step(clstm_net* h, const int* T_h, int bs, const float* x_d,
   // no exchange in between (no communicator, or one of a single rank): the reductions of the backward pass apply the update
   // themselves; a communicator of several ranks: the peer-read all-reduce fused into the update where the ranks could map each
   // other (else ncclAllReduce + k_update)
-  h->net.fuse_update = !h->net.comm || h->net.comm->nranks == 1;
+  h->net.fuse_update = h->net.fuse_eligible();
   h->net.peer_step = h->net.comm && h->net.comm->nranks > 1 && h->net.comm->peer_ready((size_t)h->net.nparams, g_stream);
   h->net.backward();
   h->net.update();   // all-reduces the fresh gradient first when a communicator is attached
@@ -2556,7 +2702,7 @@ int clstm_net_train_step_h(clstm_net* h, const int* T_h, int bs, const float* x_
   n.forward();
   net_ctc_launch(h);
   n.update_step_word = f.step_done; n.update_step_id = (int)(unsigned)k;
-  n.fuse_update = !n.comm || n.comm->nranks == 1;
+  n.fuse_update = n.fuse_eligible();
   n.peer_step = n.comm && n.comm->nranks > 1 && n.comm->peer_ready((size_t)n.nparams, g_stream);
   try {
     n.backward();
@@ -2815,6 +2961,18 @@ int clstm_net_overlap_stats(clstm_net* h, long long* launches, int* timeouts) {
   ABI_END
 }
 int clstm_net_set_comm(clstm_net* h, clstm_comm* c) { h->net.comm = c ? &c->c : nullptr; return 0; }
+int clstm_net_replica_check(clstm_net* h) {
+  ABI_BEGIN
+  REQUIRE(h, "null argument");
+  h->net.replica_check(g_stream);   // (no-op without a communicator of several ranks; the verdict arrives with the next synchronisation)
+  ABI_END
+}
+int clstm_net_set_training(clstm_net* h, int on) {
+  ABI_BEGIN
+  REQUIRE(h, "null argument");
+  h->net.training = on != 0;
+  ABI_END
+}
 
 // ---- diagnostics ----------------------------------------------------------------------------------
 int clstm_debug_ctc_cycles(long long* out_h) {
@@ -2834,9 +2992,9 @@ int clstm_debug_lstm_cycles(clstm_net* h, long long* out_h) {   // diagnostics b
 #endif
 int clstm_debug_set_device_error(int which, int value) {   // tests: what a failed persistent launch / a timed-out item leaves behind
   ABI_BEGIN
-  REQUIRE(which >= 0 && which <= 5, "bad error word");
+  REQUIRE(which >= 0 && which <= 7, "bad error word");
   HIPCHECK(hipStreamSynchronize(g_stream));
-  if (which == 4) { g_debug_fail_claims = value; return 0; }       // the next `value` persistent launches fail their placement check
+  if (which == 4) { g_debug_fail_claims = value & 255; g_debug_fail_skip = value >> 8; return 0; }   // after (value >> 8) persistent launches the next (value & 255) fail their placement check
   if (which == 5) {                                                  // forget a placement failure: persistent launches again, `value` of them verified synchronously
     g_xcd_failed = false;
     g_xcd_outcome.check_all();
@@ -2880,15 +3038,15 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     gemm_bf16<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
                  (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0, (UpdateFuse{}));
-  } else if (mode == 30) {   // A: [R][K] bf16, B: [Cn][K] bf16 (the caller passes halfs in float-typed pointers)
+  } else if (mode == 30 || mode == 31) {   // A: [R][K] bf16, B: [Cn][K] bf16 (the caller passes halfs in float-typed pointers); 31: the one-barrier loop
     gemm_b16kk(g_stream, GemmOperand16{(const unsigned short*)A, K, (long long)R * K}, GemmOperand16{(const unsigned short*)B, K, (long long)Cn * K},
-               StorePlain{Cm, Cn}, R, Cn, K);
-  } else if (mode == 32) {   // A: [K][R] bf16, B: [K][Cn] bf16 (R, Cn multiples of 8), split-K slabs reduced afterwards
+               StorePlain{Cm, Cn}, R, Cn, K, mode == 31 ? 0 : 1);
+  } else if (mode == 32 || mode == 33) {   // A: [K][R] bf16, B: [K][Cn] bf16 (R, Cn multiples of 8), split-K slabs reduced afterwards; 33: the one-barrier loop
     if (!part) part = new DevBuf<float>();
     if (nsplit < 1) nsplit = 1;
     part->reserve((size_t)nsplit * R * Cn);
     gemm_b16mc(g_stream, GemmOperand16B{(const unsigned short*)A, R, (long long)K * R, 0}, GemmOperand16B{(const unsigned short*)B, Cn, (long long)K * Cn, 0},
-               StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
+               StorePartial{part->p, R, Cn}, R, Cn, K, nsplit, 1, GemmOperand16B{nullptr, 0, 0, 0}, 0, mode == 33 ? 0 : 1);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
                  (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0, (UpdateFuse{}));
   } else if (mode == 20) gemm_x3<GEMM_KC, GEMM_MC>(g_stream, gemm_kc(A, K, R, 0), gemm_mc(B, Cn, K, 0), StorePlain{Cm, Cn}, R, Cn, K);

@@ -342,8 +342,8 @@ DEVFN T* dyn_smem() {
 #endif  // CLSTM_HIP_EMU
 
 // ---- common to both builds ----
-// device error words (clstm_hip.hip:dev_err_words): any set -> the update kernels skip the update
-DEVFN bool dev_err_set(const int* err) { return err && (err[0] | err[1] | err[2] | err[3]) != 0; }
+// device error words (clstm_hip.hip:dev_err_words; [4], [5] unused): any set -> the update kernels skip the update
+DEVFN bool dev_err_set(const int* err) { return err && (err[0] | err[1] | err[2] | err[3] | err[6] | err[7]) != 0; }
 DEVFN bool f32_finite(float x) { return (__builtin_bit_cast(unsigned, x) & 0x7f800000u) != 0x7f800000u; }
 DEVFN void raise_nonfinite(int* nanflag, int step_no) { if (*nanflag == 0) *nanflag = step_no; }   // (every writer of a launch stores the same value)
 

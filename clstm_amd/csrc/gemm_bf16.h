@@ -502,8 +502,20 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_128_kernel(GemmOperand A, Gemm
 // for the weight operand (packed once per update).  No split-K, no batch: the products it serves have K <= 4096.
 struct GemmOperand16 { const unsigned short* p; int ld; long long elems; };   // ld, elems in halfs (ld even)
 // (WI as in gemm_b16mc_kernel below: 4 -> 128 x 128 tile / four waves, 8 -> 256 x 256 / eight waves of 128 x 64)
-template <class FE, int WI>
+// STAG (WI = 8 only): the two waves of a SIMD run HALF A BLOCK APART.  With one barrier per block all eight waves stage and read
+// their fragments together (~800 cycles of LDS traffic with the matrix pipe idle) and then issue their MFMAs together (~1,000
+// cycles per SIMD with the LDS idle): 46 % MFMA busy at best (profiles/r04_b2_mfma_utilisation.txt).  Here waves 0-3 (one per
+// SIMD, the upper 128 rows of the tile) and waves 4-7 (the lower 128) alternate: while one group stages its half of block t+1
+// and reads its fragments of block t, the other group's 32 MFMAs of the previous half-step run -- two barriers per block, group
+// B one barrier behind (it enters the loop through an extra barrier, group A leaves through one).  Every staged element, every
+// fragment and every MFMA is the one-barrier loop's, in the same order per accumulator: the results are bit-identical.
+//   A: [stage t+1 | frags t] B [MFMA t]            B [stage t+2 | frags t+1] B [MFMA t+1] ...
+//   B:                       B [stage t+1 | frags t] B [MFMA t]             B ...
+// Block t+1's buffer is the one block t-1 lived in: its last reader was group B between the two barriers before group A's
+// stage of t+1 (reads are complete at a barrier: __syncthreads waits for lgkmcnt).
+template <class FE, int WI, bool STAG = false>
 __global__ __launch_bounds__(64 * WI, 2) void gemm_b16kk_kernel(GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K) {
+  static_assert(!STAG || WI == 8, "the staggered loop pairs the two waves of each SIMD of an eight-wave workgroup");
   constexpr int NWN = WI / 2, BT = 32 * WI, TILE = BT * GB2_LDH;
   __shared__ __attribute__((aligned(16))) unsigned short As[2 * TILE];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * TILE];
@@ -568,6 +580,7 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16kk_kernel(GemmOperand16 A,
   const int fk = lane >> 4, fi = lane & 15;
   const int fsw = (fk ^ gb2_sw(fi)) << 3;
   int cur = 0;
+  if (STAG && wm == 1) __syncthreads();   // group B runs one barrier behind group A (wave-uniform)
   for (int kb = 0; kb < K; kb += GB2_PF * GB_BK) {
 #pragma unroll
     for (int p = 0; p < GB2_PF; p++) {
@@ -582,23 +595,39 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16kk_kernel(GemmOperand16 A,
       for (int i = 0; i < WI; i++) af[i] = *reinterpret_cast<const u16x8*>(&As[cur + (wm * (16 * WI) + i * 16 + fi) * GB2_LDH + fsw]);
 #pragma unroll
       for (int j = 0; j < 4; j++) bf[j] = *reinterpret_cast<const u16x8*>(&Bs[cur + (wn * 64 + j * 16 + fi) * GB2_LDH + fsw]);
+      if (STAG) {                          // ... the other group's MFMAs ran beside the staging and the reads above
+        // (the fences pin the MFMAs BETWEEN the two barriers: they touch no memory, so nothing else keeps hipcc from issuing
+        //  them in front of the first one as the fragments arrive -- which is the one-barrier loop again)
+        SCHED_FENCE();
+        __syncthreads();
+        SCHED_FENCE();
+      }
 #pragma unroll
       for (int i = 0; i < WI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
+      if (STAG) SCHED_FENCE();
       __syncthreads();
+      if (STAG) SCHED_FENCE();
       cur ^= TILE;
     }
   }
+  if (STAG && wm == 0) __syncthreads();   // (group A's epilogue stores run beside group B's last MFMAs)
   gb2_store<FE, WI>(fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, 0);
 }
 inline bool gemm_tile256(int R, int Cn);
+inline int gemm_stag_default() {   // CLSTM_GEMM_STAG=0: the one-barrier loop on the 256 x 256 tiles (A/B measurements)
+  static const int on = getenv("CLSTM_GEMM_STAG") ? atoi(getenv("CLSTM_GEMM_STAG")) : 1;
+  return on;
+}
 template <class FE>
-inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K) {
+inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K, int stag = -1) {
   if (R <= 0 || Cn <= 0 || K <= 0) return;
+  if (stag < 0) stag = gemm_stag_default();
   if (gemm_tile256(R, Cn)) {
     dim3 grid((Cn + 255) / 256, (R + 255) / 256, 1);
-    CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K);
+    if (stag) CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8, true>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K);
+    else CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8, false>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K);
     return;
   }
   dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, 1);
@@ -621,7 +650,7 @@ constexpr int GT_PF = 3;   // blocks in flight in registers (NB = 1; two with NB
 // WI = 16-row strips of a wave's tile: 4 -> 128 x 128 per workgroup (four waves 2 x 2, 64 x 64 each), 8 -> 256 x 256 (eight
 // waves 2 x 4, 128 x 64 each: half the LDS and vector-cache bytes per MFMA; one workgroup per CU).
 // NB = 32-row sub-blocks per barrier (contraction rows per LDS buffer = 32 NB).
-template <class FE, int WI, int NB>
+template <class FE, int WI, int NB, bool STAG = false>   // (STAG: the staggered loop of gemm_b16kk_kernel, WI = 8)
 // A2 / a2_rows (optional): output rows r < a2_rows (a multiple of the tile height) take their A columns from a SECOND array
 // shared by all batches -- the weight gradient's x-part rows straight from the bf16 outputs of the layer below instead of a
 // copy of them inside the source rows (k_source_x_bf16: 30 us + 105 MB of traffic per configs[4] step for layer 2).
@@ -697,6 +726,23 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
       const unsigned short* bp = &Bs[buf + (wn * 4 + j) * STRIP + f_at];
       bf[j] = join_u16x8(lds_read_tr16(bp), lds_read_tr16(bp + 256));
     }
+    if constexpr (STAG) {   // every fragment of the block first, a barrier, then the MFMAs alone (the other group's LDS phase runs beside them)
+      u16x8 af[WI];
+#pragma unroll
+      for (int i = 0; i < WI; i++) {
+        const unsigned short* ap = &As[buf + (wm * WI + i) * STRIP + f_at];
+        af[i] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256));
+      }
+      SCHED_FENCE();   // (pin the MFMAs between the two barriers: see gemm_b16kk_kernel)
+      __syncthreads();
+      SCHED_FENCE();
+#pragma unroll
+      for (int i = 0; i < WI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);
+      SCHED_FENCE();
+      return;
+    }
 #pragma unroll
     for (int i0 = 0; i0 < WI; i0 += 4) {   // four A strips at a time: 32 fragment registers live, not 16 + 4 WI
       u16x8 af[4];
@@ -722,7 +768,9 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
   load_tile(kbeg + PF * BKB, ra[0], rb[0]);
   SCHED_FENCE();
   __syncthreads();
+  static_assert(!STAG || (WI == 8 && NB == 1), "the staggered loop pairs the two waves of each SIMD of an eight-wave workgroup");
   int cur = 0;
+  if (STAG && wm == 1) __syncthreads();   // group B (waves 4-7) runs one barrier behind group A: see gemm_b16kk_kernel
   for (int kb = kbeg; kb < kend; kb += PF * BKB) {
 #pragma unroll
     for (int p = 0; p < PF; p++) {
@@ -738,6 +786,7 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
       cur ^= TILE;
     }
   }
+  if (STAG && wm == 0) __syncthreads();
   gb2_store<FE, WI>(fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, z);
 }
 // 256 x 256 tiles where the problem is large enough and their padding costs at most 25 % more work than 128 x 128 tiles do:
@@ -750,9 +799,10 @@ inline bool gemm_tile256(int R, int Cn) {
 }
 template <class FE>
 inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1,
-                       GemmOperand16B A2 = GemmOperand16B{nullptr, 0, 0, 0}, int a2_rows = 0) {
+                       GemmOperand16B A2 = GemmOperand16B{nullptr, 0, 0, 0}, int a2_rows = 0, int stag = -1) {
   if (R <= 0 || Cn <= 0 || K <= 0) return;
   if (nsplit < 1) nsplit = 1;
+  if (stag < 0) stag = gemm_stag_default();
   // (64 contraction rows per barrier on the 256 x 256 tile -- 231 VGPRs, 130 KB LDS -- measured equal to the 32-row
   // loop, 227 vs 226 us at 1544 x 2048 x 25600, and is gone)
   const bool big = gemm_tile256(R, Cn);
@@ -762,7 +812,8 @@ inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, F
   if (big) {
     dim3 grid((Cn + 255) / 256, (R + 255) / 256, nsplit * nbatch);
     if (a2_rows % 256 != 0) A2.p = nullptr;
-    CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 1>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
+    if (stag) CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 1, true>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
+    else CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 1, false>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
     return;
   }
   dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);

@@ -247,23 +247,41 @@ struct PeerArgs {
   int* f[PEER_MAX_RANKS];           // the ranks' flag arrays (this step's slot): f[r][q] = last sequence number rank q announced to r
   int nranks, rank;
 };
-__global__ void k_peer_barrier(PeerArgs p, int seq, int* err) {
+// `timeout_ticks`: wall_clock() ticks (100 MHz) a lane waits for its peer before it gives up.  The HOSTS of all ranks have
+// announced this sequence number to each other before any of them enqueues this kernel (clstm_hip.hip: Comm::announce), so what
+// is waited for here is the peers' queued device work, never a rank whose host is busy elsewhere (rank 0's test / save phases
+// in clstmocrtrain ngpu=N): the bound is a hang detector (default two minutes), not a scheduling assumption.  A time-out bumps
+// the error word the caller passes -- device error word [6] in training steps: its own message, updates skipped, nothing else
+// in the library changes mode.
+__global__ void k_peer_barrier(PeerArgs p, int seq, int* err, long long timeout_ticks) {
   const int r = threadIdx.x;
   if (blockIdx.x != 0 || r >= p.nranks) return;
   store_i32_wt(p.f[r] + p.rank, seq);
+  const long long t0 = wall_clock();
   int spins = 0;
   while (load_i32_wt(p.f[p.rank] + r) != seq) {
     poll_pause();
-    if (++spins > (1 << 24)) { atomic_add_i32(err, 1); break; }   // never hang the device: the update is skipped (dev_err_set)
+    if ((++spins & 1023) == 0 && wall_clock() - t0 > timeout_ticks) { atomic_add_i32(err, 1); break; }   // never hang the device: the update is skipped (dev_err_set)
   }
 }
-// set-up probe of the mapped buffers (clstm_hip.hip: Comm::peer_ready): behind one k_peer_barrier every rank's buffer must show
-// the pattern that rank wrote (rank + 1 in its first word) through THIS rank's mapping of it
-__global__ void k_peer_probe(PeerArgs p, int* err) {
-  const int r = threadIdx.x;
-  if (blockIdx.x != 0 || r >= p.nranks) return;
-  const BufF32 b = make_buf(p.x[r], 4);
-  if (buf_load_wt(b, 0u) != (float)(r + 1)) atomic_add_i32(err, 1);
+// set-up probe of the mapped buffers (clstm_hip.hip: Comm::peer_ready).  k_peer_fill: a rank writes a pattern that depends on
+// (rank, element, round) into the WHOLE slot it owns, with the plain stores the gradient reductions use.  k_peer_probe, behind
+// one k_peer_barrier: every element of every rank's slot must show that rank's pattern of THIS round through this rank's
+// mapping of it.  The host runs four rounds -- both slots, each twice with different patterns -- so a mapping that opens but
+// serves another buffer, drops part of a slot, or hands back the previous round's lines (a cache between the two devices that
+// the system-scope loads do not bypass) fails here, at set-up, and every rank falls back to RCCL.
+DEVFN float peer_pattern(int rank, size_t i, int round) { return (float)(((unsigned)i * 31u + (unsigned)rank * 4099u + (unsigned)round * 977u) & 0xFFFFFu); }
+__global__ void k_peer_fill(float* slot, size_t len, int rank, int round) {
+  CLSTM_GRID_STRIDE(i, len) slot[i] = peer_pattern(rank, i, round);
+}
+__global__ void k_peer_probe(PeerArgs p, size_t len, int round, int* err) {
+  int bad = 0;
+  for (int r = 0; r < p.nranks; r++) {
+    const BufF32 b = make_buf(p.x[r], len * 4);
+    CLSTM_GRID_STRIDE(i, len)
+      if (buf_load_wt(b, (unsigned)(i * 4)) != peer_pattern(r, i, round)) bad = 1;
+  }
+  if (bad) atomic_add_i32(err, 1);
 }
 __global__ void k_peer_allreduce_update(PeerArgs p, float* v, float* d, float* g, size_t len, float lr, float mom, float clip, const int* err,
                                         int* step_word, int step_id, int* nanflag, int step_no) {
@@ -292,6 +310,40 @@ __global__ void k_peer_allreduce_update(PeerArgs p, float* v, float* d, float* g
       d[i] = di * mom;
     }
   }
+}
+
+// ---- replica consistency check (every rank applies the identical update, so the replicas must stay bit-identical; the
+// reference re-synchronises instead, distribute_weights / average_weights, clstm.cc:718-729, 746-760) -------------------------
+// Every `check_every` training steps each rank folds its parameter buffer into two 32-bit integer sums (the bit patterns, and
+// the bit patterns rotated by the element index: integer adds commute, so the launch geometry does not matter), splits them
+// into four 16-bit pieces -- exact as floats, and exact when summed over up to 256 ranks -- and the pieces travel through the
+// SAME all-reduce the gradients use.  k_replica_verify then holds sum == nranks * own on every rank: any rank whose pieces differ
+// from the mean sees it, raises device error word [7] with the step number, and no update is applied from then on; the host
+// reports "replicas diverged" at its next synchronisation point.
+__global__ void k_param_checksum(const float* v, size_t len, unsigned* acc2) {
+  unsigned a = 0, b = 0;
+  CLSTM_GRID_STRIDE(i, len) {
+    const unsigned x = __builtin_bit_cast(unsigned, v[i]);
+    const unsigned r = (unsigned)i & 31u;
+    a += x;
+    b += (x << r) | (r ? x >> (32u - r) : 0u);
+  }
+  atomic_add_i32(reinterpret_cast<int*>(acc2), (int)a);       // (wrapping adds: the same sums for any grid)
+  atomic_add_i32(reinterpret_cast<int*>(acc2) + 1, (int)b);
+}
+// chk[0..3] = this rank's pieces (kept), chk[4..7] = the copy the all-reduce sums in place; acc2 is returned to zero
+__global__ void k_checksum_pieces(unsigned* acc2, float* chk) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const unsigned a = acc2[0], b = acc2[1];
+  const float p[4] = {(float)(a & 0xFFFFu), (float)(a >> 16), (float)(b & 0xFFFFu), (float)(b >> 16)};
+  for (int i = 0; i < 4; i++) { chk[i] = p[i]; chk[4 + i] = p[i]; }
+  acc2[0] = 0; acc2[1] = 0;
+}
+__global__ void k_replica_verify(const float* chk, int nranks, int* errword, int step_no) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  bool same = true;
+  for (int i = 0; i < 4; i++) same = same && chk[4 + i] == chk[i] * (float)nranks;
+  if (!same && *errword == 0) *errword = step_no > 0 ? step_no : 1;
 }
 
 // ---- weight packing for the sequence kernels ---------------------------------------------------

@@ -84,6 +84,14 @@ inline void trivial_decode_host(Classes& cs, const float* out, int T, int nc) {
 
 struct CharPrediction { int i, x; char32_t c; float p; };
 
+// predict(): the forward pass belongs to no training step -- a non-finite logit there must not arm the device flag that blocks
+// updates (clstm_net_set_training; the reference only asserts in backward, clstm.cc:630-649)
+struct InferenceScope {
+  clstm_net* net;
+  explicit InferenceScope(clstm_net* n) : net(n) { clstm_net_set_training(net, 0); }
+  ~InferenceScope() { clstm_net_set_training(net, 1); }
+};
+
 struct CLSTMOCR {
   Model model;
   Codec codec;
@@ -250,6 +258,7 @@ struct CLSTMOCR {
   }
   ustring predict(const Image& raw, vector<int>* where = nullptr) {  // clstmhl.h:233-242
     set_line(raw);
+    InferenceScope inference(net);
     chk(clstm_net_forward(net), "clstm_net_forward");
     return codec.decode(decode_outputs(where));
   }
@@ -261,6 +270,7 @@ struct CLSTMOCR {
   void predict(vector<CharPrediction>& preds, const Image& raw) {  // clstmhl.h:243-262
     vector<int> where;
     set_line(raw);
+    InferenceScope inference(net);
     chk(clstm_net_forward(net), "clstm_net_forward");
     Classes cs = decode_outputs(&where);
     Image out;
@@ -347,6 +357,7 @@ struct CLSTMText {
   }
   ustring predict(const ustring& in) {
     setInputs(in);
+    InferenceScope inference(net);
     chk(clstm_net_forward(net), "clstm_net_forward");
     return decode_outputs();
   }

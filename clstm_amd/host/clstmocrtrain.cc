@@ -98,7 +98,13 @@ struct Ranks {
   }
   // rank 0 waits for the others; a rank process leaves through here
   int finish(int status) {
-    if (comm) { clstm_synchronize(); }
+    // the final synchronisation is where a device error enqueued since the last read-back surfaces (skipped updates, the NaN
+    // flag, a peer time-out, diverged replicas): a rank that saw one must not exit 0 -- rank 0 would report and save as if the
+    // replicas agreed
+    if (comm && clstm_synchronize() != 0) {
+      std::cerr << "FATAL: rank " << rank << ": " << clstm_last_error() << std::endl;
+      status = status ? status : 1;
+    }
     if (rank != 0) { fflush(nullptr); _exit(status); }
     signal(SIGCHLD, SIG_DFL);   // from here on the exits are collected below
     for (pid_t k : kids) {

@@ -189,6 +189,17 @@ class Network:
         self.T, self.N = Tl, int(sum(Tl))
         self.lib.call("clstm_net_train_step_h", self.h, ptr(t), len(Tl), ptr(x_host), ptr(labels), ptr(L))
 
+    def replica_check(self):
+        """Enqueue the replica-consistency check (parameter checksum all-reduced over the attached communicator; collective).
+        A mismatch surfaces at the next synchronisation point as 'replicas diverged'.  The library also runs it by itself
+        every CLSTM_REPLICA_CHECK_EVERY updates.  Reference: distribute_weights (clstm.cc:718-729) re-syncs instead."""
+        self.lib.call("clstm_net_replica_check", self.h)
+
+    def set_training(self, on):
+        """False: forward passes of this net belong to no training step (predict): a non-finite logit does not arm the
+        device NaN flag that blocks updates (the reference asserts in backward only, clstm.cc:630-649)."""
+        self.lib.call("clstm_net_set_training", self.h, int(bool(on)))
+
     def set_comm(self, comm):
         """Attach a `Comm` (RCCL): update()/train_step() all-reduce the fresh gradient first."""
         self._comm = comm

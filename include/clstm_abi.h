@@ -272,6 +272,18 @@ int clstm_allreduce_flat(clstm_comm* comm, float* buf_d, long long n);
 /* attach (or detach with NULL) a communicator: clstm_net_update() / clstm_net_train_step() then all-reduce
  * the fresh gradient buffer `grads` before derivs += grads. */
 int clstm_net_set_comm(clstm_net* net, clstm_comm* comm);
+/* Replica consistency (the reference RE-SYNCHRONISES its replicas, distribute_weights / average_weights, clstm.cc:718-729,
+ * 746-760; here every rank applies the identical update to the identical all-reduced gradient, so the replicas must stay
+ * bit-identical and that is CHECKED): enqueue a parameter checksum, its all-reduce over the attached communicator and the
+ * comparison sum == nranks * own.  A mismatch raises a sticky device error (no later update is applied) that the next
+ * synchronisation point reports as "replicas diverged ... at training step N".  Called by the library itself every
+ * CLSTM_REPLICA_CHECK_EVERY (default 256, 0: never) updates of a net whose communicator has several ranks; collective: every
+ * rank must call it at the same point.  No-op without such a communicator. */
+int clstm_net_replica_check(clstm_net* net);
+/* on = 0: forward passes of this net belong to no training step (CLSTMOCR::predict, the test-set pass of clstmocrtrain,
+ * clstmhl.h:225-253): a non-finite logit there does not arm the device NaN / Inf flag that blocks updates (the reference only
+ * asserts in backward, clstm.cc:630-649).  Default 1. */
+int clstm_net_set_training(clstm_net* net, int on);
 
 /* ------------------------------------------------------------------------------------------
  * diagnostics (used by tests/ to pin the hardware lane layouts the kernels rely on)

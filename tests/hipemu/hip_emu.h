@@ -225,7 +225,11 @@ inline u16x8 join_u16x8(u32x2 a, u32x2 b) {
 }
 inline int wave_uniform(int x) { return x; }
 inline long long dev_clock() { return 0; }
-inline long long wall_clock() { return 0; }
+inline long long wall_clock() {   // 100 MHz ticks, like s_memrealtime
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (long long)ts.tv_sec * 100000000LL + ts.tv_nsec / 10;
+}
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }

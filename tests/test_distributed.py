@@ -17,16 +17,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NI, NH, NC = 4, 5, 4
 
 
-def make_data(step):
+def make_data(step, world=2):
+    """four lines for two ranks (the original case); world lines + 3 beyond that: uneven shards, every rank owns a line"""
     from common import synth_lines
     rng = np.random.default_rng(100 + step)
-    T = [5, 3, 4, 6]
+    T = [5, 3, 4, 6] if world <= 2 else [3 + (7 * i + step) % 4 for i in range(world + 3)]
     lines = synth_lines(rng, T, NI)
     trs = [rng.integers(1, NC, 2).astype(np.int32) for _ in T]
     return lines, trs
 
 
-def worker(rank, world, port, outdir, use_lib_comm):
+def oracle_after(ora32, nsteps, world):
+    from clstm_amd.init import init_params
+    from oracle.oracle import OracleNet
+    ref = OracleNet(ora32, NI, NH, NC, init=False)
+    ref.set_params(init_params(NI, NH, NC, seed=0.222) * 30)
+    ref.set_lr(5e-2, 0.9)
+    for step in range(nsteps):
+        lines, trs = make_data(step, world)
+        for x, t in zip(lines, trs):
+            ref.set_inputs(x); ref.forward(); ref.ctc_deltas(t); ref.backward()
+        ref.update()
+    return ref
+
+
+def worker(rank, world, port, outdir, use_lib_comm, slow_rank0_s=0.0, sabotage=False):
+    if slow_rank0_s:
+        os.environ["CLSTM_PEER_DEVICE_TIMEOUT_S"] = "1"      # far below the time rank 0 stays away: the HOST wait must cover it
+    os.environ["CLSTM_REPLICA_CHECK_EVERY"] = "1" if use_lib_comm else "0"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -61,17 +79,35 @@ def worker(rank, world, port, outdir, use_lib_comm):
         tr = Trainer(net, grads_tensor=grads)
         assert tr.world_size() == world
     import ctypes
+    import time
     for step in range(2):
-        lines, trs = make_data(step)
+        lines, trs = make_data(step, world)
+        if slow_rank0_s and rank == 0 and step == 1:
+            time.sleep(slow_rank0_s)       # clstmocrtrain's rank 0 in its test / save phase: the others are already at the next exchange
+        if sabotage and rank == world - 1 and step == 1:
+            params.view(-1)[3] += 1e-3     # one replica's parameters silently change (what a skipped update / a bit flip leaves)
+            net.params_changed()
         if use_lib_comm == "one_call":    # clstm_net_train_step: the peer-read all-reduce fused into the update
             mine_l, mine_t = shard(lines, rank, world), shard(trs, rank, world)
             net.train_step([len(l) for l in mine_l], np.ascontiguousarray(np.concatenate(mine_l, 0), np.float32), mine_t)
         else:
             tr.train(shard(lines, rank, world), shard(trs, rank, world))
+    if sabotage:                          # every rank must be told, with the step number
+        try:
+            lib.call("clstm_synchronize")
+            verdict = "no error"
+        except Exception as e:            # noqa: BLE001
+            verdict = str(e)
+        open(os.path.join(outdir, "verdict_%d.txt" % rank), "w").write(verdict)
     if use_lib_comm == "one_call":
         cnt = ctypes.c_longlong(0)
         lib.call("clstm_debug_path_count", 7, ctypes.byref(cnt))
         assert cnt.value == 2, "the fused peer-read all-reduce + update did not run (%d)" % cnt.value
+    if use_lib_comm and not sabotage:
+        cnt = ctypes.c_longlong(0)
+        lib.call("clstm_debug_path_count", 12, ctypes.byref(cnt))
+        assert cnt.value == 2, "the replica check did not run after every update (%d)" % cnt.value
+        lib.call("clstm_synchronize")     # ... and found the replicas identical (a mismatch would raise here)
     np.save(os.path.join(outdir, "params_%d.npy" % rank), params.numpy())
     np.save(os.path.join(outdir, "derivs_%d.npy" % rank), derivs.numpy())
     if use_lib_comm:
@@ -80,28 +116,65 @@ def worker(rank, world, port, outdir, use_lib_comm):
     dist.destroy_process_group()
 
 
+def _port(base):
+    _port.n = getattr(_port, "n", 0) + 1
+    return base + (os.getpid() % 1500) + 13 * _port.n
+
+
+def _check_replicas_and_oracle(tmp_path, ora32, world, what):
+    from common import assert_close
+    p = [np.load(tmp_path / ("params_%d.npy" % r)) for r in range(world)]
+    d = [np.load(tmp_path / ("derivs_%d.npy" % r)) for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(p[0], p[r]) and np.array_equal(d[0], d[r]), "rank %d differs from rank 0" % r    # replicas stay identical
+    ref = oracle_after(ora32, 2, world)
+    # (the minibatch gradient is summed shard by shard, then over ranks in rank order: with more shards the float32 sum is
+    #  grouped differently from the oracle's line-by-line accumulation -- lr x 1e-5 of a gradient entry of order 1)
+    assert_close(p[0], ref.get_params(), rtol=2e-5, atol=2e-7 if world <= 2 else 1e-6, what="params after 2 DP steps, " + what)
+    assert_close(d[0], ref.get_derivs(), rtol=1e-4, atol=1e-9, scale_atol=2e-4, what="momentum buffer after 2 DP steps, " + what)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("use_lib_comm", [True, "one_call", False], ids=["library_communicator", "library_communicator_one_call_peer_allreduce", "torch_distributed_fallback"])
-def test_two_rank_data_parallel_matches_single_process(tmp_path, ora32, use_lib_comm):
+def test_two_rank_data_parallel_matches_single_process(tmp_path, ora32, use_lib_comm, world):
+    """(the name is historical: world sizes 2, 4 and 8 -- VERDICT r4 'Missing 2': PEER_MAX_RANKS is 16, k_peer_barrier uses one
+    lane per rank, the rendezvous counts to nranks, and none of it had seen more than two)"""
     import torch.multiprocessing as mp
-    from common import assert_close, emu_lib
-    from clstm_amd.init import init_params
-    from oracle.oracle import OracleNet
+    from common import emu_lib
+    if world > 2 and use_lib_comm is False:
+        pytest.skip("the torch.distributed fallback has no world-size-dependent code of its own")
     emu_lib()                                   # build once, before the workers race for it
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(worker, args=(2, port + [False, True, "one_call"].index(use_lib_comm), str(tmp_path), use_lib_comm), nprocs=2, join=True)
-    p = [np.load(tmp_path / ("params_%d.npy" % r)) for r in range(2)]
-    d = [np.load(tmp_path / ("derivs_%d.npy" % r)) for r in range(2)]
-    assert np.array_equal(p[0], p[1]) and np.array_equal(d[0], d[1])     # replicas stay identical
-    ref = OracleNet(ora32, NI, NH, NC, init=False)
-    ref.set_params(init_params(NI, NH, NC, seed=0.222) * 30)
-    ref.set_lr(5e-2, 0.9)
-    for step in range(2):
-        lines, trs = make_data(step)
-        for x, t in zip(lines, trs):
-            ref.set_inputs(x); ref.forward(); ref.ctc_deltas(t); ref.backward()
-        ref.update()
-    assert_close(p[0], ref.get_params(), rtol=2e-5, atol=2e-7, what="params after 2 DP steps")
-    assert_close(d[0], ref.get_derivs(), rtol=1e-4, atol=1e-9, scale_atol=2e-4, what="momentum buffer after 2 DP steps")
+    mp.spawn(worker, args=(world, _port(29500), str(tmp_path), use_lib_comm), nprocs=world, join=True)
+    _check_replicas_and_oracle(tmp_path, ora32, world, "%d ranks" % world)
+
+
+def test_slow_rank_does_not_trip_the_device_barrier(tmp_path, ora32):
+    """ADVICE r4 (medium) / VERDICT r4 weak 7: in clstmocrtrain ngpu=N only rank 0 runs the test set and saves while the others
+    are already at the next step's exchange.  The device-side barrier used to give up after 2^24 polls and every later update
+    was skipped.  Now the HOSTS announce an exchange to each other before any of them enqueues the device barrier
+    (Comm::peer_barrier): rank 0 stays away for far longer than the device time-out (forced down to 1 s here) and the run
+    must still end with identical replicas that match the oracle."""
+    import torch.multiprocessing as mp
+    from common import emu_lib
+    emu_lib()
+    mp.spawn(worker, args=(2, _port(27500), str(tmp_path), "one_call", 6.0), nprocs=2, join=True)
+    _check_replicas_and_oracle(tmp_path, ora32, 2, "rank 0 late by 6 s")
+
+
+@pytest.mark.parametrize("use_lib_comm", [True, "one_call"], ids=["separate_calls", "one_call_peer_allreduce"])
+def test_replica_check_reports_a_diverged_rank(tmp_path, use_lib_comm):
+    """VERDICT r4 'Missing 2': nothing ever compared the replicas.  One of four ranks has a parameter changed behind the
+    library's back before the second step: the check that follows that step's update (CLSTM_REPLICA_CHECK_EVERY=1) must make
+    EVERY rank's next synchronisation fail with the step number (reference: distribute_weights re-syncs, clstm.cc:718-729)."""
+    import torch.multiprocessing as mp
+    from common import emu_lib
+    emu_lib()
+    world = 4
+    mp.spawn(worker, args=(world, _port(26000), str(tmp_path), use_lib_comm, 0.0, True), nprocs=world, join=True)
+    verdicts = [open(tmp_path / ("verdict_%d.txt" % r)).read() for r in range(world)]
+    told = [("replicas diverged" in v and "training step 2" in v) for v in verdicts]
+    # sum == nranks * own fails on every rank whose checksum differs from the mean: with one odd rank out of four, all of them
+    assert all(told), verdicts
 
 
 def test_shard_covers_everything():
@@ -118,12 +191,15 @@ def test_shard_covers_everything():
         shard([1, 2], 0, 4)
 
 
-def gpu_worker(rank, world, port, outdir, share_device=False, one_call=False):
+def gpu_worker(rank, world, port, outdir, share_device=False, one_call=False, slow_rank0_s=0.0):
     """one rank per GPU: the library's RCCL communicator (clstm_comm_create + clstm_net_set_comm), gloo for the id.
     share_device: every rank on GPU 0 with a communicator WITHOUT RCCL (CLSTM_COMM_NO_RCCL=1: RCCL refuses duplicate GPUs) --
     the exchange is the peer-read path over HIP IPC mappings alone.  one_call: clstm_net_train_step (the fused path)."""
     if share_device:
         os.environ["CLSTM_COMM_NO_RCCL"] = "1"
+    if slow_rank0_s:
+        os.environ["CLSTM_PEER_DEVICE_TIMEOUT_S"] = "5"
+    os.environ["CLSTM_REPLICA_CHECK_EVERY"] = "1"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -157,19 +233,25 @@ def gpu_worker(rank, world, port, outdir, share_device=False, one_call=False):
     comm = Comm(rank, world, exchange, lib=lib)
     tr = Trainer(net, comm=comm)
     import ctypes
+    import time
     for step in range(2):
-        lines, trs = make_data(step)
+        lines, trs = make_data(step, world)
         mine_l, mine_t = shard(lines, rank, world), shard(trs, rank, world)
+        if slow_rank0_s and rank == 0 and step == 1:
+            time.sleep(slow_rank0_s)
         if one_call:
             x = torch.from_numpy(np.ascontiguousarray(np.concatenate(mine_l, 0), np.float32)).to(dev)
             net.train_step([len(l) for l in mine_l], x, mine_t)
         else:
             tr.train(mine_l, mine_t)
-    lib.call("clstm_synchronize")
+    lib.call("clstm_synchronize")         # (also the verdict of the replica checks that followed both updates)
     if one_call:
         cnt = ctypes.c_longlong(0)
         lib.call("clstm_debug_path_count", 7, ctypes.byref(cnt))
         open(os.path.join(outdir, "peer_%d.txt" % rank), "w").write(str(cnt.value))
+    cnt = ctypes.c_longlong(0)
+    lib.call("clstm_debug_path_count", 12, ctypes.byref(cnt))
+    assert cnt.value == 2, "the replica check did not run after every update (%d)" % cnt.value
     np.save(os.path.join(outdir, "params_%d.npy" % rank), params.cpu().numpy())
     np.save(os.path.join(outdir, "derivs_%d.npy" % rank), derivs.cpu().numpy())
     net.set_comm(None)
@@ -186,55 +268,48 @@ def test_two_gpus_library_communicator_matches_single_process(tmp_path, ora32):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (this box has %d)" % torch.cuda.device_count())
     import torch.multiprocessing as mp
-    from common import assert_close
-    from clstm_amd.init import init_params
-    from oracle.oracle import OracleNet
-    port = 31500 + (os.getpid() % 2000)
-    mp.spawn(gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    p = [np.load(tmp_path / ("params_%d.npy" % r)) for r in range(2)]
-    d = [np.load(tmp_path / ("derivs_%d.npy" % r)) for r in range(2)]
-    assert np.array_equal(p[0], p[1]) and np.array_equal(d[0], d[1])
-    ref = OracleNet(ora32, NI, NH, NC, init=False)
-    ref.set_params(init_params(NI, NH, NC, seed=0.222) * 30)
-    ref.set_lr(5e-2, 0.9)
-    for step in range(2):
-        lines, trs = make_data(step)
-        for x, t in zip(lines, trs):
-            ref.set_inputs(x); ref.forward(); ref.ctc_deltas(t); ref.backward()
-        ref.update()
-    assert_close(p[0], ref.get_params(), rtol=2e-5, atol=2e-7, what="params after 2 DP steps on 2 GPUs")
-    assert_close(d[0], ref.get_derivs(), rtol=1e-4, atol=1e-9, scale_atol=2e-4, what="momentum buffer after 2 DP steps on 2 GPUs")
+    mp.spawn(gpu_worker, args=(2, _port(31500), str(tmp_path)), nprocs=2, join=True)
+    _check_replicas_and_oracle(tmp_path, ora32, 2, "2 GPUs")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("one_call", [True, False], ids=["train_step_fused_update", "separate_calls_plain_allreduce"])
-def test_two_processes_on_one_gpu_peer_read_allreduce(tmp_path, ora32, one_call):
-    """VERDICT r3 'Missing 3': the one-shot peer-read all-reduce (each rank maps the others' fresh-gradient buffers through
-    HIP IPC, a flag handshake replaces ncclAllReduce, the sum is formed in rank order inside the update kernel) exercised on
-    ONE GPU: two rank processes share device 0 (a communicator without RCCL, which refuses duplicate GPUs).  Replicas
-    bit-identical, result = the oracle's single-process minibatch; in the one-call form the fused kernel must have run twice."""
+@pytest.mark.parametrize("world", [4, 8])
+def test_all_gpus_one_call_step_matches_single_process(tmp_path, ora32, world):
+    """world ranks on world GPUs through clstm_net_train_step (RCCL communicator + the peer-read exchange where the ranks can
+    map each other): skips unless the box has that many GPUs."""
     import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs (this box has %d)" % (world, torch.cuda.device_count()))
     import torch.multiprocessing as mp
-    from common import assert_close
-    from clstm_amd.init import init_params
-    from oracle.oracle import OracleNet
-    port = 33500 + (os.getpid() % 2000) + int(one_call)
-    mp.spawn(gpu_worker, args=(2, port, str(tmp_path), True, one_call), nprocs=2, join=True)
-    p = [np.load(tmp_path / ("params_%d.npy" % r)) for r in range(2)]
-    d = [np.load(tmp_path / ("derivs_%d.npy" % r)) for r in range(2)]
-    assert np.array_equal(p[0], p[1]) and np.array_equal(d[0], d[1])
+    mp.spawn(gpu_worker, args=(world, _port(30500), str(tmp_path), False, True), nprocs=world, join=True)
+    _check_replicas_and_oracle(tmp_path, ora32, world, "%d GPUs" % world)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,one_call", [(2, True), (2, False), (4, True), (8, True), (8, False)],
+                         ids=["2_train_step_fused_update", "2_separate_calls_plain_allreduce", "4_train_step_fused_update",
+                              "8_train_step_fused_update", "8_separate_calls_plain_allreduce"])
+def test_two_processes_on_one_gpu_peer_read_allreduce(tmp_path, ora32, world, one_call):
+    """VERDICT r3 'Missing 3' / r4 'Missing 2': the one-shot peer-read all-reduce (each rank maps the others' fresh-gradient
+    buffers through HIP IPC, a flag handshake replaces ncclAllReduce, the sum is formed in rank order inside the update kernel)
+    exercised on ONE GPU with 2, 4 and 8 rank processes that share device 0 (a communicator without RCCL, which refuses
+    duplicate GPUs).  Replicas bit-identical, result = the oracle's single-process minibatch; in the one-call form the fused
+    kernel must have run twice; the replica check runs after every update."""
+    import torch.multiprocessing as mp
+    mp.spawn(gpu_worker, args=(world, _port(33500), str(tmp_path), True, one_call), nprocs=world, join=True)
     if one_call:
-        assert [open(tmp_path / ("peer_%d.txt" % r)).read() for r in range(2)] == ["2", "2"]
-    ref = OracleNet(ora32, NI, NH, NC, init=False)
-    ref.set_params(init_params(NI, NH, NC, seed=0.222) * 30)
-    ref.set_lr(5e-2, 0.9)
-    for step in range(2):
-        lines, trs = make_data(step)
-        for x, t in zip(lines, trs):
-            ref.set_inputs(x); ref.forward(); ref.ctc_deltas(t); ref.backward()
-        ref.update()
-    assert_close(p[0], ref.get_params(), rtol=2e-5, atol=2e-7, what="params after 2 DP steps, two processes on one GPU")
-    assert_close(d[0], ref.get_derivs(), rtol=1e-4, atol=1e-9, scale_atol=2e-4, what="momentum buffer after 2 DP steps, two processes on one GPU")
+        assert [open(tmp_path / ("peer_%d.txt" % r)).read() for r in range(world)] == ["2"] * world
+    _check_replicas_and_oracle(tmp_path, ora32, world, "%d processes on one GPU" % world)
+
+
+@pytest.mark.gpu
+def test_rank_30_s_late_on_one_gpu(tmp_path, ora32):
+    """rank 0 sleeps 30 s between the steps (clstmocrtrain's test / save phase) while rank 1 is already
+    at the next exchange; the device-side barrier's time-out is forced down to 5 s.  The hosts' announce handshake keeps rank 1
+    from enqueuing the barrier until rank 0 is there: no time-out, identical replicas, the oracle's result."""
+    import torch.multiprocessing as mp
+    mp.spawn(gpu_worker, args=(2, _port(34500), str(tmp_path), True, True, 30.0), nprocs=2, join=True)
+    _check_replicas_and_oracle(tmp_path, ora32, 2, "rank 0 late by 30 s")
 
 
 # ---- the C++ driver with ngpu=N: rank processes forked by clstmocrtrain itself ---------------------------------------
@@ -260,7 +335,8 @@ def _model_params(tool, path, tmp_path, tag):
     return np.fromfile(out, np.float32)
 
 
-def test_cpp_driver_ngpu2_equals_single_process(tmp_path):
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_cpp_driver_ngpu2_equals_single_process(tmp_path, nranks):
     """clstmocrtrain ngpu=2 batch=2 (the driver forks a second rank, both join the library communicator through
     clstm_comm_unique_id / clstm_comm_create, every rank trains on its half of each minibatch, update() all-reduces the
     gradient) must leave the model of ngpu=1 batch=2 -- same draws, same summed gradient, two summation orders.
@@ -278,19 +354,21 @@ def test_cpp_driver_ngpu2_equals_single_process(tmp_path):
     lst = _driver_fixture(tmp_path)
     tool = os.path.join(root, "clstm_amd", "bin", "clstm_hosttool")
     got = {}
-    for ngpu in (1, 2):
-        env = dict(os.environ, ngpu=str(ngpu), batch="2", ntrain="6", nhidden="6", target_height="12", lrate="1e-2",
-                   report_every="2", save_every="1000", save_name=str(tmp_path / ("m%d" % ngpu)), CLSTM_NGPU_SHARE_DEVICE="1")
+    # (nranks = 4, VERDICT r4 next 3(a): minibatches of four lines, one per rank; the replica check after every update)
+    for ngpu in (1, nranks):
+        env = dict(os.environ, ngpu=str(ngpu), batch=str(nranks), ntrain=str(3 * nranks), nhidden="6", target_height="12", lrate="1e-2",
+                   report_every=str(nranks), save_every="1000", save_name=str(tmp_path / ("m%d" % ngpu)), CLSTM_NGPU_SHARE_DEVICE="1",
+                   CLSTM_REPLICA_CHECK_EVERY="1")
         r = subprocess.run([str(exe), str(lst)], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
-        if ngpu == 2:
-            assert "ranks 2 x 1 lines" in r.stdout
+        if ngpu > 1:
+            assert "ranks %d x 1 lines" % nranks in r.stdout
         assert r.stdout.count("TRU ") == 3, r.stdout          # only rank 0 reports
-        model = tmp_path / ("m%d-4.clstm" % ngpu)
+        model = tmp_path / ("m%d-%d.clstm" % (ngpu, 2 * nranks))
         assert model.exists(), r.stdout[-800:]
         got[ngpu] = _model_params(tool, model, tmp_path, str(ngpu))
-    assert got[1].size == got[2].size and np.abs(got[1]).max() > 0
-    assert np.allclose(got[1], got[2], rtol=1e-5, atol=1e-7), np.abs(got[1] - got[2]).max()
+    assert got[1].size == got[nranks].size and np.abs(got[1]).max() > 0
+    assert np.allclose(got[1], got[nranks], rtol=1e-5, atol=1e-7), np.abs(got[1] - got[nranks]).max()
 
 
 @pytest.mark.gpu
@@ -315,7 +393,8 @@ def test_cpp_driver_ngpu2_on_two_gpus(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_driver_ngpu2_two_rank_processes_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_cpp_driver_ngpu2_two_rank_processes_on_one_gpu(tmp_path, nranks):
     """clstmocrtrain ngpu=2 on a ONE-GPU box: both rank processes bind device 0 (CLSTM_NGPU_SHARE_DEVICE), the communicator
     carries no RCCL (CLSTM_COMM_NO_RCCL=1) and every update goes through the one-shot peer-read all-reduce over HIP IPC
     mappings (clstm_net_train_step_h / clstm_net_update); the model must equal ngpu=1 batch=2 up to the summation order."""
@@ -325,14 +404,14 @@ def test_cpp_driver_ngpu2_two_rank_processes_on_one_gpu(tmp_path):
     tool = os.path.join(root, "clstm_amd", "bin", "clstm_hosttool")
     lst = _driver_fixture(tmp_path)
     got = {}
-    for ngpu in (1, 2):
-        env = dict(os.environ, ngpu=str(ngpu), batch="2", ntrain="40", nhidden="20", lrate="1e-2", report_every="10",
+    for ngpu in (1, nranks):
+        env = dict(os.environ, ngpu=str(ngpu), batch=str(nranks), ntrain=str(20 * nranks), nhidden="20", lrate="1e-2", report_every=str(5 * nranks),
                    save_every="1000", save_name=str(tmp_path / ("s%d" % ngpu)), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   CLSTM_NGPU_SHARE_DEVICE="1", CLSTM_COMM_NO_RCCL="1")
+                   CLSTM_NGPU_SHARE_DEVICE="1", CLSTM_COMM_NO_RCCL="1", CLSTM_REPLICA_CHECK_EVERY="1")
         r = subprocess.run([exe, str(lst)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
-        got[ngpu] = _model_params(tool, tmp_path / ("s%d-38.clstm" % ngpu), tmp_path, "s%d" % ngpu)
-    assert np.abs(got[1]).max() > 0 and np.allclose(got[1], got[2], rtol=1e-4, atol=1e-6), np.abs(got[1] - got[2]).max()
+        got[ngpu] = _model_params(tool, tmp_path / ("s%d-%d.clstm" % (ngpu, 19 * nranks)), tmp_path, "s%d" % ngpu)
+    assert np.abs(got[1]).max() > 0 and np.allclose(got[1], got[nranks], rtol=1e-4, atol=1e-6), np.abs(got[1] - got[nranks]).max()
 
 
 def test_shard_by_length_balances_the_longest_lines():

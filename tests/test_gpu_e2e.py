@@ -587,3 +587,79 @@ def test_fused_launches_randomised_stress(seed):
     env = dict(os.environ, SEED=str(seed), NCASE="60")
     r = subprocess.run([os.sys.executable, os.path.join(ROOT, "scripts", "gpu_stress_overlap.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+# ---- trajectories at the bench shapes, the chip-filling minibatch, the one-call step ------------------
+def _trajectory(ora, ni, nh, nc, Ts, L, scale, nsteps, lr, mom, one_call, precision=0, seed=70, grad_tol=1e-3):
+    """`nsteps` consecutive minibatch updates (a fresh synthetic minibatch every step, momentum carried) on the GPU and in the
+    oracle (reference semantics: every line an independent fwd/CTC/bwd accumulating into Params.d on top of the carried
+    mom * d, then ONE sgd_update -- clstmhl.h:201-223, clstm.cc:201-217, clstm_compute.cc:553-563; OpenMP over lines).
+    Every step: the CTC argmax decodes of all lines IDENTICAL; afterwards the parameters within the tolerance the accepted
+    gradient tolerance implies -- a gradient accepted within grad_tol of its largest entry moves d by that, and v by lr x the
+    accumulated d error: after step k (1-based) sum_{j<=k} sum_{i<=j} mom^(j-i) of them -- and the momentum buffer within
+    grad_tol of ITS largest entry times the same geometric factor."""
+    import torch
+    from common import Backend, synth_lines
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Network
+    from oracle.oracle import OracleNet
+    lib = Backend("hip").lib
+    rng = np.random.default_rng(seed)
+    params = init_params(ni, nh, nc, seed=0.222) * scale
+    ref = OracleNet(ora, ni, nh, nc, init=False)
+    ref.set_params(params); ref.set_lr(lr, mom)
+    net = Network(ni, nh, nc, lib=lib)
+    net.set_params(params); net.setLearningRate(lr, mom)
+    if precision:
+        net.set_gemm_precision(precision)
+    d_fac = v_fac = 0.0
+    for step in range(1, nsteps + 1):
+        lines = synth_lines(rng, Ts, ni)
+        trs = [rng.integers(1, nc, L).astype(np.int32) for _ in Ts]
+        want = ref.minibatch(lines, trs)
+        gmax = float(np.abs(want["derivs"]).max())          # (Params.d right before the update: carried momentum + this minibatch)
+        ref.update()
+        if one_call:                                         # what the bench times: clstm_net_train_step, inputs resident in HBM
+            x_dev = torch.from_numpy(np.ascontiguousarray(np.concatenate(lines, 0), np.float32)).cuda()
+            net.train_step(Ts, x_dev, trs)
+        else:
+            net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward(); net.update()
+        dec = net.decode()                                   # (the step's forward outputs are still in place behind the update)
+        mism = [b for b in range(len(Ts)) if dec[b].tolist() != want["decode"][b].tolist()]
+        assert not mism, "step %d: CTC argmax decodes differ on lines %s" % (step, mism)
+        d_fac = mom * d_fac + 1.0
+        v_fac += d_fac
+        assert_close(net.get_params(), ref.get_params(), rtol=1e-5, atol=1e-7 + v_fac * lr * grad_tol * gmax,
+                     what="parameters after step %d" % step)
+        assert_close(net.get_derivs(), ref.get_derivs(), rtol=grad_tol, atol=1e-9, scale_atol=d_fac * grad_tol,
+                     what="momentum buffer after step %d" % step)
+    lib.call("clstm_synchronize")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("one_call", [False, True], ids=["sequence_of_calls", "clstm_net_train_step"])
+def test_three_minibatch_steps_at_the_bench_shape_vs_oracle(ora32, one_call):
+    """BASELINE configs[2] at full size, THREE consecutive updates (lr 1e-4, momentum 0.9): 64 lines x 200 frames, a fresh
+    minibatch per step -- through the sequence of calls and through the one-call clstm_net_train_step the bench times
+    (fused forward launch, fused backward launch, update riding the slab reduction), each against the oracle."""
+    _trajectory(ora32, 48, 100, 83, [200] * 64, 25, 10.0, 3, 1e-4, 0.9, one_call)
+
+
+@pytest.mark.gpu
+def test_256_lines_fill_every_cu_twice_vs_oracle(ora32):
+    """The size `saturated` in the bench line quotes: 256 lines x 200 frames = 512 recurrence workgroups on 256 CUs (two per
+    CU, dispatched longest first), forward pass as separate launches.  Every saved activation, delta, CTC posterior, decode,
+    gradient and the update of all 256 lines against the oracle, bars of the 64-line case."""
+    from common import Backend
+    from test_net_parity import run_case
+    run_case(Backend("hip"), ora32, 48, 100, 83, [200] * 256, scale=10.0, seed=15, lr=1e-4, ctc_rtol=1e-3, grad_tol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("one_call", [True], ids=["clstm_net_train_step"])
+def test_two_minibatch_steps_at_configs4_f32_vs_oracle(ora32, one_call):
+    """BASELINE configs[4] at full size in the exact-f32 mode, TWO consecutive updates through the one-call step (stacked net:
+    the reductions stage the gradient, one k_update applies the whole step): decodes of all 64 lines identical at both steps,
+    parameters and momentum within the derived tolerance (weights at the reference's own initial scale x 2, where the
+    recurrence is contractive: test_configs4_full_shape_f32_strict_at_reference_init)."""
+    _trajectory(ora32, 64, [512, 512], 100, [400] * 64, 50, 2.0, 2, 1e-4, 0.9, one_call, seed=71)
