@@ -172,6 +172,12 @@ struct StorePartial {  // split-K slabs [z][R][Cn]
     *reinterpret_cast<f32x4*>(out + ((long long)z * R + r) * Cn + c) = v;
   }
 };
+struct StorePartialShift {  // split-K slabs of a product WITHOUT the bias row: operand rows [x | h], row r lands in row r + 1 of [1 | x | h] (R = rows of the slab)
+  float* out; int R, Cn;
+  DEVMFN void operator()(int r, int c, float v, int z) const { out[((long long)z * R + r + 1) * Cn + c] = v; }
+  DEVMFN bool vec4() const { return (Cn & 3) == 0 && ((size_t)out & 15) == 0; }
+  DEVMFN void row4(int r, int c, f32x4 v, int z) const { *reinterpret_cast<f32x4*>(out + ((long long)z * R + r + 1) * Cn + c) = v; }
+};
 struct StorePartialRot {  // split-K slabs whose operand rows were ordered [x | h | 1]: row r lands in row (r + 1) mod R of [1 | x | h]
   float* out; int R, Cn;
   DEVMFN void operator()(int r, int c, float v, int z) const { out[((long long)z * R + (r + 1 == R ? 0 : r + 1)) * Cn + c] = v; }
@@ -1080,6 +1086,7 @@ struct Layer {
   bool h_f32_valid = true;     // the f32 outputs H are current (a persistent bf16 forward pass of a lower layer leaves only Hbf)
   bool sh_valid = true;        // the h_{t-1} columns of S (f32) are current (... only Sbf)
   DevBuf<unsigned short> Dbf;  // per-frame bf16 gate deltas written by the persistent backward kernel (A operand of the x.d GEMM)
+  DevBuf<float> dbias;         // [bs][ndir][no][4] per-line sums of those deltas (the bias row of the weight gradient), same kernel
   DevBuf<unsigned short> Wtb;  // bf16 copy of Wt ([ni][M], k = gate column contiguous): B operand of the bf16-source x.d product
   int lds = 0;
   int wt_slack = 32;          // floats past Wt a vectorised staging load may touch
@@ -1416,6 +1423,7 @@ struct Net {
         // with bf16 GEMMs behind it, nobody reads the f32 deltas of a persistent pass (16 bytes per lane and step, 0.17 ms
         // per configs[4] minibatch); ensure_delta_f32() expands Dbf for a fallback product
         w.skip_d = bf16_gemm;
+        y.dbias.reserve((size_t)bs * ndir * 4 * y.no + 64); w.dbias = y.dbias.p;   // per-line bias-gradient sums (lstm_wide.h: LstmWideArgs::dbias)
       }
       static const bool b16mc_on = !(getenv("CLSTM_GEMM_B16MC") && atoi(getenv("CLSTM_GEMM_B16MC")) == 0);
       if (fwd && b16mc_on && bf16_gemm && (y.ni & 7) == 0 && (y.no & 7) == 0 && wide_kp16_bwd(y.no) == 4 * y.no) {
@@ -1721,6 +1729,17 @@ struct Net {
     return !(e && atoi(e) == 0);
   }
   // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
+  // big tiles of the contraction-major bf16 product (gemm_b16mc: 256 or 192 rows x 256 columns): one workgroup per CU, never a second round
+  int pick_split_mc(int R, int Cn, int nbatch) const {
+    const int th = gemm_mc_tile_rows(R);
+    const long long tiles = (long long)((R + th - 1) / th) * ((Cn + 255) / 256) * nbatch;
+    long long want = device_cu_count() / tiles;
+    const long long maxs = (N + 63) / 64;
+    if (want > maxs) want = maxs;
+    if (want > 64) want = 64;
+    if (want < 1) want = 1;
+    return (int)want;
+  }
   int pick_split(int R, int Cn, int nbatch = 1, int tile = GEMM_BT) const {
     const long long tiles = (long long)((R + tile - 1) / tile) * ((Cn + tile - 1) / tile) * nbatch;
     const long long target = tile == GEMM_BT ? 640 : 480;   // 64 x 64 tiles: 640 measured best (272: slower); 128 x 128 tiles: two workgroups per CU
@@ -1986,14 +2005,17 @@ struct Net {
       if (bwd_persistent) g_path_count[1]++;
       }
       const bool dw_from_bf16 = bf16_gemm && bf16_rec && bwd_persistent && y.sbf_ready && y.Dbf.p && gemm_bf16_big(R, Cn);
+      const bool dw_bias_out = dw_from_bf16 && y.dbias.p && gemm_bf16_big(R - 1, Cn);
       // exact-f32 mode, wide layer: the backward products as f32-grade bf16 x 3 on 128 x 128 tiles (gemm_x3_128_kernel) -- what
       // narrow layers already do inside their fused backward launch; CLSTM_GEMM_X3=0 / clstm_net_set_strict_f32: the f32 MFMA
       const bool x3_big = !bf16_gemm && y.wide && gemm_x3_on && gemm_bf16_big(R, Cn);
       if (bf16_gemm || !overlap_eligible(y))
-        ns = dw_from_bf16 && gemm_tile256(R, Cn) ? pick_split(R, Cn, ndir, 256)
+        ns = dw_bias_out && gemm_tile256(R - 1, Cn) ? pick_split_mc(R - 1, Cn, ndir)
+             : dw_from_bf16 && gemm_tile256(R, Cn) ? pick_split_mc(R, Cn, ndir)
              : (bf16_gemm || x3_big) && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
       if (!dw_from_bf16) { ensure_source(l); ensure_delta_f32(l); }   // the f32-source products below read S and D
       DevBuf<float>& pbuf = partial;
+      bool dx_done = false;   // the input deltas rode the weight-gradient launch (gemm_dw_dx)
       auto do_dw = [&](hipStream_t q) {
         if (bf16_gemm || !overlap_eligible(y)) {
           pbuf.reserve((size_t)ndir * ns * R * Cn);
@@ -2003,9 +2025,30 @@ struct Net {
             // forward pass), transposed by the LDS on the way into the MFMA
             const int ldsb = y.ni + y.no + 8;
             g_path_count[4]++;
+            const GemmOperand16B a2 = y.sbf_x_external ? GemmOperand16B{L[l - 1].Hbf.p, y.ni, (long long)N * y.ni, 0} : GemmOperand16B{nullptr, 0, 0, 0};
+            // ... and, where the layer also owes input deltas from the same bf16 delta array, BOTH products as one launch
+            // (gemm_bf16.h:gemm_dw_dx_kernel: apart, each leaves a quarter of the chip idle)
+            float* const dxp = l > 0 ? L[l - 1].dH.p : nullptr;
+            if (dw_bias_out && dxp && wide_kp16_bwd(y.no) == 4 * y.no && y.Wtb.p &&
+                gemm_dw_dx(q, GemmOperand16B{y.Sbf.p, ldsb, (long long)N * ndir * ldsb, (long long)N * ldsb}, GemmOperand16B{y.Dbf.p, M, (long long)N * M, 4LL * y.no},
+                           StorePartialShift{pbuf.p, R, Cn}, R - 1, Cn, (int)N, ns, ndir, a2, y.sbf_x_external ? y.ni : 0,
+                           GemmOperand16{y.Dbf.p, M, (long long)N * M}, GemmOperand16{y.Wtb.p, M, (long long)y.ni * M}, StorePlain{dxp, y.ni}, (int)N, y.ni, M)) {
+              CLSTM_LAUNCH(k_bias_rows, dim3((unsigned)(((size_t)ndir * Cn + 63) / 64)), dim3(64), 0, q, (const float*)y.dbias.p, pbuf.p, bs, ndir, ns, R, Cn);
+              g_path_count[13]++; g_path_count[3]++; g_path_count[14]++;
+              dx_done = true;
+            } else if (dw_bias_out) {
+              // The bias row W.d[:,0] += sum_b y.d (clstm_compute.cc:301) is not a row of this product: 1 + ni + no rows are one
+              // more than a whole number of row panels at both configs[4] layers (1537 = 6 x 256 + 1: a seventh panel, 14 % of
+              // the product, for one row; 577 = 3 x 192 + 1) -- the persistent backward recurrence sums the deltas of a line while
+              // it produces them (LstmWideArgs::dbias) and k_bias_rows lays the sum over lines into row 0 of the first slab.
+              gemm_b16mc(q, GemmOperand16B{y.Sbf.p, ldsb, (long long)N * ndir * ldsb, (long long)N * ldsb},
+                         GemmOperand16B{y.Dbf.p, M, (long long)N * M, 4LL * y.no}, StorePartialShift{pbuf.p, R, Cn}, R - 1, Cn, (int)N, ns, ndir, a2,
+                         y.sbf_x_external ? y.ni : 0);
+              CLSTM_LAUNCH(k_bias_rows, dim3((unsigned)(((size_t)ndir * Cn + 63) / 64)), dim3(64), 0, q, (const float*)y.dbias.p, pbuf.p, bs, ndir, ns, R, Cn);
+              g_path_count[13]++;
+            } else
             gemm_b16mc(q, GemmOperand16B{y.Sbf.p, ldsb, (long long)N * ndir * ldsb, (long long)N * ldsb},
-                       GemmOperand16B{y.Dbf.p, M, (long long)N * M, 4LL * y.no}, StorePartialRot{pbuf.p, R, Cn}, R, Cn, (int)N, ns, ndir,
-                       y.sbf_x_external ? GemmOperand16B{L[l - 1].Hbf.p, y.ni, (long long)N * y.ni, 0} : GemmOperand16B{nullptr, 0, 0, 0},
+                       GemmOperand16B{y.Dbf.p, M, (long long)N * M, 4LL * y.no}, StorePartialRot{pbuf.p, R, Cn}, R, Cn, (int)N, ns, ndir, a2,
                        y.sbf_x_external ? y.ni : 0);
             if (y.sbf_x_external) g_path_count[8]++;
           } else if (bf16_gemm)
@@ -2040,7 +2083,7 @@ struct Net {
         float* dx = nullptr;
         if (l > 0) dx = L[l - 1].dH.p;
         else if (want_dx0) { dX0.reserve((size_t)N * y.ni); dx = dX0.p; }
-        if (!dx) return;
+        if (!dx || dx_done) return;
         timing.begin("gemm_gates_dx", s);
         if (bf16_gemm && bf16_rec && bwd_persistent && wide_kp16_bwd(y.no) == 4 * y.no && y.Wtb.p && y.Dbf.p)
         {
@@ -3010,6 +3053,14 @@ int clstm_debug_path_count(int which, long long* out_h) {
   *out_h = g_path_count[which];
   ABI_END
 }
+#ifdef CLSTM_GEMM_PROF
+int clstm_debug_gemm_prof(long long* out_h) {   // diagnostics build only (not in the product ABI)
+  ABI_BEGIN
+  HIPCHECK(hipStreamSynchronize(g_stream));
+  HIPCHECK(hipMemcpyFromSymbol(out_h, HIP_SYMBOL(clstm_gemm_prof), 16 * sizeof(long long)));
+  ABI_END
+}
+#endif
 int clstm_debug_lane_ops(float* out) {
   ABI_BEGIN
   CLSTM_LAUNCH(k_debug_lane_ops, dim3(1), dim3(64), 0, g_stream, out);
@@ -3038,15 +3089,18 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* Cm, int R,
     gemm_bf16<GEMM_MC, GEMM_MC>(g_stream, gemm_mc(A, R, K, 0), gemm_mc(B, Cn, K, 0), StorePartial{part->p, R, Cn}, R, Cn, K, nsplit);
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
                  (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0, (UpdateFuse{}));
+  } else if (mode == 34) {   // the kk product with its tiles brought in by LDS-DMA (gemm_b16kk_dma_kernel)
+    gemm_b16kk(g_stream, GemmOperand16{(const unsigned short*)A, K, (long long)R * K}, GemmOperand16{(const unsigned short*)B, K, (long long)Cn * K},
+               StorePlain{Cm, Cn}, R, Cn, K, 2);
   } else if (mode == 30 || mode == 31) {   // A: [R][K] bf16, B: [Cn][K] bf16 (the caller passes halfs in float-typed pointers); 31: the one-barrier loop
     gemm_b16kk(g_stream, GemmOperand16{(const unsigned short*)A, K, (long long)R * K}, GemmOperand16{(const unsigned short*)B, K, (long long)Cn * K},
-               StorePlain{Cm, Cn}, R, Cn, K, mode == 31 ? 0 : 1);
-  } else if (mode == 32 || mode == 33) {   // A: [K][R] bf16, B: [K][Cn] bf16 (R, Cn multiples of 8), split-K slabs reduced afterwards; 33: the one-barrier loop
+               StorePlain{Cm, Cn}, R, Cn, K, mode == 31 ? 0 : 1 | (nsplit > 1 ? nsplit << 4 : 0));   // (diagnostics build: nsplit = leave-out bits)
+  } else if (mode == 32 || mode == 33 || mode == 35) {   // A: [K][R] bf16, B: [K][Cn] bf16 (R, Cn multiples of 8), split-K slabs reduced afterwards; 33: the one-barrier loop
     if (!part) part = new DevBuf<float>();
     if (nsplit < 1) nsplit = 1;
     part->reserve((size_t)nsplit * R * Cn);
     gemm_b16mc(g_stream, GemmOperand16B{(const unsigned short*)A, R, (long long)K * R, 0}, GemmOperand16B{(const unsigned short*)B, Cn, (long long)K * Cn, 0},
-               StorePartial{part->p, R, Cn}, R, Cn, K, nsplit, 1, GemmOperand16B{nullptr, 0, 0, 0}, 0, mode == 33 ? 0 : 1);
+               StorePartial{part->p, R, Cn}, R, Cn, K, nsplit, 1, GemmOperand16B{nullptr, 0, 0, 0}, 0, mode == 33 ? 0 : mode == 35 ? 3 : 1);   // 35: tiles by LDS-DMA
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks((size_t)R * Cn)), dim3(256), 0, g_stream,
                  (ReduceDesc{part->p, nullptr, 0LL, nsplit, 1, R, Cn, Cn}), (ReduceDesc{}), Cm, (int*)nullptr, 0, (UpdateFuse{}));
   } else if (mode == 20) gemm_x3<GEMM_KC, GEMM_MC>(g_stream, gemm_kc(A, K, R, 0), gemm_mc(B, Cn, K, 0), StorePlain{Cm, Cn}, R, Cn, K);

@@ -220,6 +220,17 @@ DEVFN f32x4 buf_load4(BufF32 b, unsigned byte_off) {  // 16 bytes, dword alignme
 DEVFN void buf_store(BufF32 b, unsigned byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.r, byte_off, 0, 0);
 }
+// LDS-DMA (buffer_load_dwordx4 ... lds): 16 bytes per lane straight from memory into LDS -- no VGPR, no ds_write.  The
+// destination is WAVE-UNIFORM base + 16 x lane (a wave instruction fills 1 KB of LDS in lane order; `lds_wave_base` must be
+// the same in every lane), the source offset is per lane: a swizzled LDS image is obtained by permuting the SOURCE chunks.
+// Out-of-range lanes deposit zeros.  Counts in vmcnt like a load; the data is in LDS for the issuing wave once its vmcnt says
+// so, for the other waves behind a barrier after that (wait_vmcnt<N>() + wg_barrier(): __syncthreads() would wait vmcnt(0)).
+DEVFN void lds_dma16(BufF32 b, unsigned byte_off, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_off, 0, 0, 0);
+}
+template <int N> DEVFN void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+DEVFN void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+DEVFN void wg_barrier() { __builtin_amdgcn_s_barrier(); }   // bare s_barrier: no implied waits
 // lane offset (VGPR, bounds-checked) + wave-uniform offset (SGPR, NOT part of the bounds check of a raw
 // buffer): no VALU add per access, and a lane parked at BUF_OOB_BASE stays out of range
 DEVFN float buf_load_s(BufF32 b, unsigned lane_off, unsigned uniform_off) {

@@ -513,7 +513,20 @@ struct GemmOperand16 { const unsigned short* p; int ld; long long elems; };   //
 //   B:                       B [stage t+1 | frags t] B [MFMA t]             B ...
 // Block t+1's buffer is the one block t-1 lived in: its last reader was group B between the two barriers before group A's
 // stage of t+1 (reads are complete at a barrier: __syncthreads waits for lgkmcnt).
-template <class FE, int WI, bool STAG = false>
+#ifdef CLSTM_GEMM_PROF   // diagnostics build (make variant VARIANT=gprof EXTRA=-DCLSTM_GEMM_PROF; scripts/gpu_gemmprof_r5.py)
+// per-segment shader-clock sums of waves 0 and 4 of workgroup 0: [wave group][segment]; LO: parts of the loop left out
+__device__ long long clstm_gemm_prof[2 * 8];
+#define GPROF_DECL long long gp_t = 0, gp_s[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const bool gp_on = blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 255) == 0
+#define GPROF_TOP() do { if (gp_on) gp_t = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define GPROF(i) do { if (gp_on) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); gp_s[i] += t_ - gp_t; gp_t = t_; } } while (0)
+#define GPROF_WRITE() do { if (gp_on) for (int i_ = 0; i_ < 8; i_++) clstm_gemm_prof[(threadIdx.x >> 8) * 8 + i_] = gp_s[i_]; } while (0)
+#else
+#define GPROF_DECL
+#define GPROF_TOP()
+#define GPROF(i)
+#define GPROF_WRITE()
+#endif
+template <class FE, int WI, bool STAG = false, int LO = 0>
 __global__ __launch_bounds__(64 * WI, 2) void gemm_b16kk_kernel(GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K) {
   static_assert(!STAG || WI == 8, "the staggered loop pairs the two waves of each SIMD of an eight-wave workgroup");
   constexpr int NWN = WI / 2, BT = 32 * WI, TILE = BT * GB2_LDH;
@@ -580,21 +593,35 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16kk_kernel(GemmOperand16 A,
   const int fk = lane >> 4, fi = lane & 15;
   const int fsw = (fk ^ gb2_sw(fi)) << 3;
   int cur = 0;
+  GPROF_DECL;
+  u16x8 af[WI], bf[4];
+  if (LO & 8) {   // (diagnostics: fragments read once)
+#pragma unroll
+    for (int i = 0; i < WI; i++) af[i] = *reinterpret_cast<const u16x8*>(&As[(wm * (16 * WI) + i * 16 + fi) * GB2_LDH + fsw]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) bf[j] = *reinterpret_cast<const u16x8*>(&Bs[(wn * 64 + j * 16 + fi) * GB2_LDH + fsw]);
+  }
   if (STAG && wm == 1) __syncthreads();   // group B runs one barrier behind group A (wave-uniform)
   for (int kb = 0; kb < K; kb += GB2_PF * GB_BK) {
 #pragma unroll
     for (int p = 0; p < GB2_PF; p++) {
       const int k0 = kb + p * GB_BK;
       const int pn = p == GB2_PF - 1 ? 0 : p + 1;
-      stage(As + (cur ^ TILE), k0 + GB_BK, ra[pn]);
-      stage(Bs + (cur ^ TILE), k0 + GB_BK, rb[pn]);
-      load_tile(k0 + GB_BK + GB2_PF * GB_BK, ra[pn], rb[pn]);
+      GPROF_TOP();
+      if (!(LO & 4)) {
+        stage(As + (cur ^ TILE), k0 + GB_BK, ra[pn]);
+        stage(Bs + (cur ^ TILE), k0 + GB_BK, rb[pn]);
+      }
+      GPROF(0);   // staged (incl. the wait for the block's loads)
+      if (!(LO & 2)) load_tile(k0 + GB_BK + GB2_PF * GB_BK, ra[pn], rb[pn]);
       SCHED_FENCE();
-      u16x8 af[WI], bf[4];
+      if (!(LO & 8)) {
 #pragma unroll
-      for (int i = 0; i < WI; i++) af[i] = *reinterpret_cast<const u16x8*>(&As[cur + (wm * (16 * WI) + i * 16 + fi) * GB2_LDH + fsw]);
+        for (int i = 0; i < WI; i++) af[i] = *reinterpret_cast<const u16x8*>(&As[cur + (wm * (16 * WI) + i * 16 + fi) * GB2_LDH + fsw]);
 #pragma unroll
-      for (int j = 0; j < 4; j++) bf[j] = *reinterpret_cast<const u16x8*>(&Bs[cur + (wn * 64 + j * 16 + fi) * GB2_LDH + fsw]);
+        for (int j = 0; j < 4; j++) bf[j] = *reinterpret_cast<const u16x8*>(&Bs[cur + (wn * 64 + j * 16 + fi) * GB2_LDH + fsw]);
+      }
+      GPROF(1);   // loads + fragment reads issued
       if (STAG) {                          // ... the other group's MFMAs ran beside the staging and the reads above
         // (the fences pin the MFMAs BETWEEN the two barriers: they touch no memory, so nothing else keeps hipcc from issuing
         //  them in front of the first one as the fragments arrive -- which is the one-barrier loop again)
@@ -602,23 +629,139 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16kk_kernel(GemmOperand16 A,
         __syncthreads();
         SCHED_FENCE();
       }
+      GPROF(2);   // fragments arrived + barrier
+      if (LO & 1) {
+#pragma unroll
+        for (int i = 0; i < WI; i++) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < 4; j++) asm volatile("" ::"v"(bf[j]));
+      } else {
 #pragma unroll
       for (int i = 0; i < WI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
+      }
       if (STAG) SCHED_FENCE();
+      GPROF(3);   // MFMAs issued
       __syncthreads();
       if (STAG) SCHED_FENCE();
+      GPROF(4);   // barrier
       cur ^= TILE;
     }
   }
+  GPROF_WRITE();
   if (STAG && wm == 0) __syncthreads();   // (group A's epilogue stores run beside group B's last MFMAs)
   gb2_store<FE, WI>(fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, 0);
 }
+// ---- the same product with the operand tiles brought in by LDS-DMA (round 5) ----------------------------------------------
+// Phase stamps and leave-out builds of the staggered loop above (scripts/gpu_gemmprof_r5.py, profiles/r05_gemm_phases.txt): of the
+// ~1,950 cycles a 32-k block takes, ~500 are the four ds_write_b128 per thread that stage the next block (the VGPR -> LDS
+// transfer path: ~125 cycles per wave instruction beside the other group's MFMAs) and with them gone the kernel ran 37 % faster
+// (4096^3: 163 -> 103 us) -- more than without global loads (-13 %) or fragment reads (-18 %).  Here nothing is staged through
+// registers: each wave brings 32 rows of both tiles per block with four buffer_load_dwordx4 ... lds (lds_dma16: 1 KB = 16 rows
+// x 64 B per instruction, lane l -> row l >> 2, chunk POSITION l & 3, which holds source chunk (l & 3) ^ gb2_sw(row): the
+// swizzle of the register-staged image, applied to the source address), THREE buffers of A | B (96 KB), block t + 2 requested
+// while block t is consumed.  Fragment reads, MFMA order and epilogue are the staggered loop's: bit-identical results.
+//   group A (waves 0-3):  W b0 [dma t+2 | frags t] b [MFMA t | W] b [dma t+3 | frags t+1] b ...
+//   group B (waves 4-7):  W b0       b [dma t+2 | frags t | W] b [MFMA t] b ...               (W = wait for MY part of block t+1)
+// A block's buffer is reused by the request of block t + 3 -- issued behind a barrier that every wave passes only after its
+// fragment reads of block t have returned.  Every wave waits for its own requests of block t + 1 in front of the barrier that
+// precedes group A's reads of it (vmcnt(4): the four requests of block t + 2 may still be in flight).  K % 32 == 0 (a DMA
+// cannot mask a contraction tail); rows past the operand read zeros (the descriptor ends at the last row).
+constexpr int GKD_SMEM_HALFS = 3 * 2 * 256 * GB2_LDH;   // three buffers of A | B: 96 KB
+// S: ONE LDS array [buffer][A rows | B rows][32 k]; lin, gx, gy: this workgroup's index in the product's gx x gy tile grid
+template <class FE>
+DEVFN void gemm_b16kk_dma_body(unsigned short* const S, GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K,
+                               const unsigned lin, const unsigned gx, const unsigned gy) {
+  constexpr int WI = 8, TILE = 256 * GB2_LDH, BUF = 2 * TILE, NBUF = 3;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int bx, by;
+  {
+    const unsigned total = gx * gy;
+    const unsigned xcd = lin & 7u, idx = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = (int)(v % gx);
+    by = (int)(v / gx);
+  }
+  const int r0 = by * 256, c0 = bx * 256;
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(A.p), (size_t)A.elems * 2);
+  const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(B.p), (size_t)B.elems * 2);
+  // DMA role: rows 32 wave + 16 h + (lane >> 2) of both tiles, position lane & 3 of the row's four 16-byte chunks
+  unsigned aoff[2], boff[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int row = 32 * wave + 16 * h + (lane >> 2);
+    const unsigned c = (unsigned)((lane & 3) ^ gb2_sw(row));
+    aoff[h] = ((unsigned)(r0 + row) * (unsigned)A.ld + 8u * c) * 2u;
+    boff[h] = ((unsigned)(c0 + row) * (unsigned)B.ld + 8u * c) * 2u;
+  }
+  const int nblk = K / GB_BK;
+  auto dma = [&](const int blk, const int buf) {   // block `blk` (clamped: the requests past the end re-read the last block, nobody reads them)
+    const unsigned kc = (unsigned)wave_uniform(blk < nblk ? blk : nblk - 1) * (GB_BK * 2u);
+    unsigned short* const base = S + buf * BUF + (32 * wave) * GB2_LDH;
+#pragma unroll
+    for (int h = 0; h < 2; h++) lds_dma16(abuf, aoff[h] + kc, base + (16 * h) * GB2_LDH);
+#pragma unroll
+    for (int h = 0; h < 2; h++) lds_dma16(bbuf, boff[h] + kc, base + TILE + (16 * h) * GB2_LDH);
+  };
+  f32x4 acc[WI][4];
+#pragma unroll
+  for (int i = 0; i < WI; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+  const int fk = lane >> 4, fi = lane & 15;
+  const int fsw = (fk ^ gb2_sw(fi)) << 3;
+  dma(0, 0);
+  dma(1, 1);
+  wait_vmcnt<4>();
+  wg_barrier();                    // block 0 is in LDS, everybody's part
+  if (wm == 1) wg_barrier();       // group B runs one barrier behind
+  int cur = 0, nxt2 = 2;           // buffers of block t and of block t + 2
+  for (int t = 0; t < nblk; t++) {
+    dma(t + 2, nxt2);
+    SCHED_FENCE();
+    const unsigned short* const As = S + cur * BUF;
+    const unsigned short* const Bs = As + TILE;
+    u16x8 af[WI], bf[4];
+#pragma unroll
+    for (int i = 0; i < WI; i++) af[i] = *reinterpret_cast<const u16x8*>(&As[(wm * 128 + i * 16 + fi) * GB2_LDH + fsw]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) bf[j] = *reinterpret_cast<const u16x8*>(&Bs[(wn * 64 + j * 16 + fi) * GB2_LDH + fsw]);
+    SCHED_FENCE();
+    if (wm == 1) wait_vmcnt<4>();  // my part of block t + 1 (group B: in front of the barrier group A reads it behind)
+    wait_lgkmcnt0();
+    SCHED_FENCE();
+    wg_barrier();
+    SCHED_FENCE();
+#pragma unroll
+    for (int i = 0; i < WI; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);   // transposed: see gb2_store
+    SCHED_FENCE();
+    if (wm == 0) wait_vmcnt<4>();  // (group A: the same wait behind its MFMAs)
+    wg_barrier();
+    SCHED_FENCE();
+    cur = cur == NBUF - 1 ? 0 : cur + 1;
+    nxt2 = nxt2 == NBUF - 1 ? 0 : nxt2 + 1;
+  }
+  if (wm == 0) wg_barrier();
+  wait_vmcnt<0>();                 // (the two requests past the end)
+  gb2_store<FE, WI>(fe, acc, r0 + wm * 128, c0 + wn * 64, lane, R, Cn, 0);
+}
+template <class FE>
+__global__ __launch_bounds__(512, 2) void gemm_b16kk_dma_kernel(GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K) {
+  __shared__ __attribute__((aligned(1024))) unsigned short S[GKD_SMEM_HALFS];
+  gemm_b16kk_dma_body<FE>(S, A, B, fe, R, Cn, K, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y);
+}
 inline bool gemm_tile256(int R, int Cn);
-inline int gemm_stag_default() {   // CLSTM_GEMM_STAG=0: the one-barrier loop on the 256 x 256 tiles (A/B measurements)
-  static const int on = getenv("CLSTM_GEMM_STAG") ? atoi(getenv("CLSTM_GEMM_STAG")) : 1;
-  return on;
+inline int gemm_stag_default() {   // CLSTM_GEMM_STAG: 2 LDS-DMA tiles + staggered wave groups, 1 register-staged + staggered, 0 the one-barrier loop (A/B)
+  const char* e = getenv("CLSTM_GEMM_STAG");   // (read per call: tests compare the variants within one process)
+  return e ? atoi(e) : 2;
 }
 template <class FE>
 inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K, int stag = -1) {
@@ -626,6 +769,22 @@ inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE 
   if (stag < 0) stag = gemm_stag_default();
   if (gemm_tile256(R, Cn)) {
     dim3 grid((Cn + 255) / 256, (R + 255) / 256, 1);
+    if (stag == 2 && K % GB_BK == 0 && K >= 2 * GB_BK && (A.ld & 7) == 0 && (B.ld & 7) == 0) {   // operand tiles by LDS-DMA (16-byte aligned chunks)
+      CLSTM_LAUNCH((gemm_b16kk_dma_kernel<FE>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K);
+      return;
+    }
+#ifdef CLSTM_GEMM_PROF
+    switch (stag >> 4) {   // (diagnostics: stag = 1 | leave-out bits << 4)
+      case 1: CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8, true, 1>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K); return;
+      case 2: CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8, true, 2>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K); return;
+      case 4: CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8, true, 4>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K); return;
+      case 8: CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8, true, 8>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K); return;
+      case 12: CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8, true, 12>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K); return;
+      case 14: CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8, true, 14>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K); return;
+      default: break;
+    }
+    stag &= 1;
+#endif
     if (stag) CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8, true>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K);
     else CLSTM_LAUNCH((gemm_b16kk_kernel<FE, 8, false>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K);
     return;
@@ -650,24 +809,27 @@ constexpr int GT_PF = 3;   // blocks in flight in registers (NB = 1; two with NB
 // WI = 16-row strips of a wave's tile: 4 -> 128 x 128 per workgroup (four waves 2 x 2, 64 x 64 each), 8 -> 256 x 256 (eight
 // waves 2 x 4, 128 x 64 each: half the LDS and vector-cache bytes per MFMA; one workgroup per CU).
 // NB = 32-row sub-blocks per barrier (contraction rows per LDS buffer = 32 NB).
-template <class FE, int WI, int NB, bool STAG = false>   // (STAG: the staggered loop of gemm_b16kk_kernel, WI = 8)
+// Tile: 32 WI rows x 64 NWN columns, waves 2 x NWN (a wave owns 16 WI x 64): WI = 4 -> 128 x 128, four waves; WI = 8 -> 256 x 256,
+// WI = 6 -> 192 x 256 (round 5: 576 = 3 x 192 rows of the first configs[4] layer's weight gradient instead of three 256-row
+// panels for 2.25), eight waves.
 // A2 / a2_rows (optional): output rows r < a2_rows (a multiple of the tile height) take their A columns from a SECOND array
 // shared by all batches -- the weight gradient's x-part rows straight from the bf16 outputs of the layer below instead of a
 // copy of them inside the source rows (k_source_x_bf16: 30 us + 105 MB of traffic per configs[4] step for layer 2).
-__global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K,
-                                                               int ksplit, int nsplit, GemmOperand16B A2, int a2_rows) {
-  constexpr int NWN = WI / 2, BT = 32 * WI, NSTRIP = 2 * WI, STRIP = NB * 512 + 16, TILE = NSTRIP * STRIP, CHUNKS = BT / 8;
+// As, Bs: the two double-buffered LDS images (GmcSmem); lin, gx, gy, gz: this workgroup's index in the gx x gy x gz grid.
+template <class FE, int WI, int NB, bool STAG = false>   // (STAG: the staggered loop of gemm_b16kk_kernel, eight waves)
+DEVFN void gemm_b16mc_body(unsigned short* const As, unsigned short* const Bs, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K,
+                           int ksplit, int nsplit, GemmOperand16B A2, int a2_rows, const unsigned lin, const unsigned gx, const unsigned gy, const unsigned gz) {
+  constexpr int NWN = WI == 4 ? 2 : 4, NT = 128 * NWN, BTM = 32 * WI, BTN = 64 * NWN;
+  constexpr int STRIP = NB * 512 + 16, TILE_A = (BTM / 16) * STRIP, TILE_B = (BTN / 16) * STRIP;
+  constexpr int CH_A = BTM / 8, CH_B = BTN / 8;          // 16-byte chunks of a contraction row of the tile
   constexpr int BKB = 32 * NB, NL = 2 * NB, PF = NB == 1 ? GT_PF : 2;
-  __shared__ __attribute__((aligned(16))) unsigned short As[2 * TILE];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * TILE];
+  static_assert(16 * CH_A <= NT && 16 * CH_B == NT, "one thread per (chunk, contraction row mod 16)");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   int bx, by, z;   // XCD-aware tile order, see gemm_mfma.h
   {
-    const unsigned gx = gridDim.x, gy = gridDim.y;
-    const unsigned total = gx * gy * gridDim.z;
-    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned total = gx * gy * gz;
     const unsigned xcd = lin & 7u, idx = lin >> 3;
     const unsigned q = total >> 3, r = total & 7u;
     const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -675,20 +837,23 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
     by = (int)((v / gx) % gy);
     z = (int)(v / (gx * gy));
   }
-  const int r0 = by * BT, c0 = bx * BT;
+  const int r0 = by * BTM, c0 = bx * BTN;
   const int batch = z / nsplit;
   const int kbeg = (z - batch * nsplit) * ksplit;
   const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
-  const int s_c = tid % CHUNKS, s_k = tid / CHUNKS;   // 16-byte chunk of the row; contraction rows s_k + 16 h of the block
-  const bool use2 = wave_uniform(A2.p != nullptr && r0 < a2_rows ? 1 : 0) != 0;   // (a whole tile: a2_rows is a multiple of BT)
+  // staging role: 16-byte chunk s?_c of contraction rows s?_k + 16 h of the block.  A tile 192 rows high has 24 chunks per row:
+  // threads 384.. (waves 6, 7: wave-uniform) stage no A chunk.
+  const int sa_c = tid % CH_A, sa_k = tid / CH_A, sb_c = tid % CH_B, sb_k = tid / CH_B;
+  const bool a_on = wave_uniform(tid < 16 * CH_A ? 1 : 0) != 0;
+  const bool use2 = wave_uniform(A2.p != nullptr && r0 < a2_rows ? 1 : 0) != 0;   // (a whole tile: a2_rows is a multiple of BTM)
   const unsigned short* const ap = use2 ? A2.p : A.p + batch * A.bstride;
   const long long ael = use2 ? A2.elems : A.elems - batch * A.bstride;
   const unsigned ald = (unsigned)(use2 ? A2.ld : A.ld);
   const BufF32 abuf = make_buf(reinterpret_cast<const float*>(ap), (size_t)ael * 2);
   const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(B.p + batch * B.bstride), (size_t)(B.elems - batch * B.bstride) * 2);
   // columns past R / Cn read whatever follows in the row (or the next row): they only reach outputs that are not stored
-  const unsigned aoff = ((unsigned)s_k * ald + (unsigned)(r0 + s_c * 8)) * 2u, a16 = 32u * ald;
-  const unsigned boff = ((unsigned)s_k * (unsigned)B.ld + (unsigned)(c0 + s_c * 8)) * 2u, b16 = 32u * (unsigned)B.ld;
+  const unsigned aoff = ((unsigned)sa_k * ald + (unsigned)(r0 + sa_c * 8)) * 2u, a16 = 32u * ald;
+  const unsigned boff = ((unsigned)sb_k * (unsigned)B.ld + (unsigned)(c0 + sb_c * 8)) * 2u, b16 = 32u * (unsigned)B.ld;
   const unsigned a_kstep = 2u * ald, b_kstep = 2u * (unsigned)B.ld;
   f32x4 ra[PF][NL], rb[PF][NL];
   // contraction rows past the slab load zeros: their offset is pushed out of the descriptor's range (one select per
@@ -697,19 +862,23 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
     const unsigned kc = (unsigned)wave_uniform(k0);
 #pragma unroll
     for (int h = 0; h < NL; h++) {
-      const bool lv = k0 + s_k + 16 * h < kend;
+      const bool lv = a_on && k0 + sa_k + 16 * h < kend;
       a[h] = buf_load4(abuf, lv ? aoff + kc * a_kstep + (unsigned)h * a16 : BUF_OOB);
     }
 #pragma unroll
     for (int h = 0; h < NL; h++) {
-      const bool lv = k0 + s_k + 16 * h < kend;
+      const bool lv = k0 + sb_k + 16 * h < kend;
       b[h] = buf_load4(bbuf, lv ? boff + kc * b_kstep + (unsigned)h * b16 : BUF_OOB);
     }
   };
-  const int s_at = (s_c >> 1) * STRIP + s_k * 16 + (s_c & 1) * 8;
-  auto stage = [&](unsigned short* S, const f32x4 (&r)[NL]) {
+  const int sa_at = (sa_c >> 1) * STRIP + sa_k * 16 + (sa_c & 1) * 8, sb_at = (sb_c >> 1) * STRIP + sb_k * 16 + (sb_c & 1) * 8;
+  auto stage = [&](unsigned short* Sa, unsigned short* Sb, const f32x4 (&a)[NL], const f32x4 (&b)[NL]) {
+    if (a_on) {
 #pragma unroll
-    for (int h = 0; h < NL; h++) *reinterpret_cast<f32x4*>(&S[s_at + h * 256]) = r[h];
+      for (int h = 0; h < NL; h++) *reinterpret_cast<f32x4*>(&Sa[sa_at + h * 256]) = a[h];
+    }
+#pragma unroll
+    for (int h = 0; h < NL; h++) *reinterpret_cast<f32x4*>(&Sb[sb_at + h * 256]) = b[h];
   };
   f32x4 acc[WI][4];
 #pragma unroll
@@ -719,18 +888,18 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
 #pragma unroll
       for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
   const int f_at = lane * 4;   // lane l of a group points at chunk l of the group's [4 n][16] block: rows 4 (l >> 4) .. + 3
-  auto mfma_sub = [&](const int buf) {   // one 32-row sub-block: fragments by transpose reads, WI x 4 MFMAs
+  auto mfma_sub = [&](const int abuf_at, const int bbuf_at) {   // one 32-row sub-block: fragments by transpose reads, WI x 4 MFMAs
     u16x8 bf[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const unsigned short* bp = &Bs[buf + (wn * 4 + j) * STRIP + f_at];
+      const unsigned short* bp = &Bs[bbuf_at + (wn * 4 + j) * STRIP + f_at];
       bf[j] = join_u16x8(lds_read_tr16(bp), lds_read_tr16(bp + 256));
     }
     if constexpr (STAG) {   // every fragment of the block first, a barrier, then the MFMAs alone (the other group's LDS phase runs beside them)
       u16x8 af[WI];
 #pragma unroll
       for (int i = 0; i < WI; i++) {
-        const unsigned short* ap = &As[buf + (wm * WI + i) * STRIP + f_at];
+        const unsigned short* ap = &As[abuf_at + (wm * WI + i) * STRIP + f_at];
         af[i] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256));
       }
       SCHED_FENCE();   // (pin the MFMAs between the two barriers: see gemm_b16kk_kernel)
@@ -743,16 +912,17 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
       SCHED_FENCE();
       return;
     }
+    constexpr int AG = WI % 4 == 0 ? 4 : 3;   // A strips at a time: 8 AG fragment registers live, not 16 + 4 WI
 #pragma unroll
-    for (int i0 = 0; i0 < WI; i0 += 4) {   // four A strips at a time: 32 fragment registers live, not 16 + 4 WI
-      u16x8 af[4];
+    for (int i0 = 0; i0 < WI; i0 += AG) {
+      u16x8 af[AG];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const unsigned short* ap = &As[buf + (wm * WI + i0 + i) * STRIP + f_at];
+      for (int i = 0; i < AG; i++) {
+        const unsigned short* ap = &As[abuf_at + (wm * WI + i0 + i) * STRIP + f_at];
         af[i] = join_u16x8(lds_read_tr16(ap), lds_read_tr16(ap + 256));
       }
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < AG; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i0 + i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i0 + i][j]);   // transposed: see gb2_store
       if (NB > 1) SCHED_FENCE();
@@ -763,32 +933,182 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16mc_kernel(GemmOperand16B A
     load_tile(kbeg + p * BKB, ra[p], rb[p]);
     SCHED_FENCE();
   }
-  stage(As, ra[0]);
-  stage(Bs, rb[0]);
+  stage(As, Bs, ra[0], rb[0]);
   load_tile(kbeg + PF * BKB, ra[0], rb[0]);
   SCHED_FENCE();
   __syncthreads();
-  static_assert(!STAG || (WI == 8 && NB == 1), "the staggered loop pairs the two waves of each SIMD of an eight-wave workgroup");
-  int cur = 0;
+  static_assert(!STAG || (WI >= 6 && NB == 1), "the staggered loop pairs the two waves of each SIMD of an eight-wave workgroup");
+  int cur = 0;   // 0 / 1: the LDS buffer pair that holds the block the MFMAs are about to consume
   if (STAG && wm == 1) __syncthreads();   // group B (waves 4-7) runs one barrier behind group A: see gemm_b16kk_kernel
   for (int kb = kbeg; kb < kend; kb += PF * BKB) {
 #pragma unroll
     for (int p = 0; p < PF; p++) {
       const int k0 = kb + p * BKB;
       const int pn = p == PF - 1 ? 0 : p + 1;
-      stage(As + (cur ^ TILE), ra[pn]);
-      stage(Bs + (cur ^ TILE), rb[pn]);
+      stage(As + (cur ^ 1) * TILE_A, Bs + (cur ^ 1) * TILE_B, ra[pn], rb[pn]);
       load_tile(k0 + BKB + PF * BKB, ra[pn], rb[pn]);
       SCHED_FENCE();
 #pragma unroll
-      for (int sb = 0; sb < NB; sb++) mfma_sub(cur + sb * 512);
+      for (int sb = 0; sb < NB; sb++) mfma_sub(cur * TILE_A + sb * 512, cur * TILE_B + sb * 512);
       __syncthreads();
-      cur ^= TILE;
+      if (STAG) SCHED_FENCE();
+      cur ^= 1;
     }
   }
   if (STAG && wm == 0) __syncthreads();
   gb2_store<FE, WI>(fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, z);
 }
+template <int WI, int NB> struct GmcSmem {   // halfs of the two double-buffered operand images of gemm_b16mc_body
+  static constexpr int STRIP = NB * 512 + 16, A = 2 * (2 * WI) * STRIP, B = 2 * ((WI == 4 ? 128 : 256) / 16) * STRIP;
+};
+template <class FE, int WI, int NB, bool STAG = false>
+__global__ __launch_bounds__(WI == 4 ? 256 : 512, 2) void gemm_b16mc_kernel(GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K,
+                                                                            int ksplit, int nsplit, GemmOperand16B A2, int a2_rows) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[GmcSmem<WI, NB>::A];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[GmcSmem<WI, NB>::B];
+  gemm_b16mc_body<FE, WI, NB, STAG>(As, Bs, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows,
+                                    blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z);
+}
+// ---- the weight gradient and the input deltas of a wide layer as ONE launch (round 5) --------------------------------------------
+// Both depend on the layer's backward recurrence and on nothing else; apart, each leaves a quarter of the chip idle: the
+// weight-gradient product of the upper configs[4] layer is 96 tiles x 2 slabs = 192 workgroups of 400 blocks on 256 CUs, x.d
+// 400 tiles of 128 blocks = two rounds, the second 56 % full (656 block-times end to end).  One grid -- the long weight-gradient
+// workgroups first, the x.d tiles behind them, taken by whichever CU comes free -- needs ~500 + the tail.  Roles by block index
+// (wave-uniform); ONE LDS array serves both bodies.
+template <class FEW, int WI, class FEX>
+__global__ __launch_bounds__(512, 2) void gemm_dw_dx_kernel(GemmOperand16B A, GemmOperand16B B, FEW few, int R, int Cn, int K, int ksplit, int nsplit,
+                                                            GemmOperand16B A2, int a2_rows, unsigned gxw, unsigned gyw, unsigned gzw,
+                                                            GemmOperand16 XA, GemmOperand16 XB, FEX fex, int XR, int XCn, int XK, unsigned gxx, unsigned gyx) {
+  constexpr int MC_HALFS = GmcSmem<WI, 1>::A + GmcSmem<WI, 1>::B;
+  __shared__ __attribute__((aligned(1024))) unsigned short S[MC_HALFS > GKD_SMEM_HALFS ? MC_HALFS : GKD_SMEM_HALFS];
+  const unsigned nw = gxw * gyw * gzw;
+  if (blockIdx.x < nw) gemm_b16mc_body<FEW, WI, 1, true>(S, S + GmcSmem<WI, 1>::A, A, B, few, R, Cn, K, ksplit, nsplit, A2, a2_rows, blockIdx.x, gxw, gyw, gzw);
+  else gemm_b16kk_dma_body<FEX>(S, XA, XB, fex, XR, XCn, XK, blockIdx.x - nw, gxx, gyx);
+}
+// ---- the contraction-major product with its tiles brought in by LDS-DMA (round 5, third image; see the note below) --------------
+// LDS image of an operand block [32 n][256 columns]: sixteen UNITS of 1 KB, unit (ch, q) = contraction rows 4 q .. 4 q + 3 x columns
+// 128 ch .. 128 ch + 127 as eight [4 n][16 columns] blocks of 128 bytes -- the block a 16-lane group of ds_read_b64_tr_b16 reads
+// (contiguous: one LDS pass per group, like the strips of gemm_b16mc_kernel) -- with block b at position (b + (q & 1)) & 7, so
+// that the two lane groups a read services together (n-quads q, q + 1) fall into different halves of the 256-byte bank window.  A
+// DMA instruction fills one unit: lane l -> position l >> 3, row (l >> 1) & 3, column half l & 1, i.e. four contraction rows x 256
+// contiguous bytes of memory each (the k-contiguous kernel's requests are 64-byte runs).  Two units per wave, operand and block.
+template <class FE, int WI>
+DEVFN void gemm_b16mc_dma_body(unsigned short* const S, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int ksplit, int nsplit,
+                               GemmOperand16B A2, int a2_rows, const unsigned lin, const unsigned gx, const unsigned gy, const unsigned gz) {
+  static_assert(WI == 8 || WI == 6, "256- or 192-row tiles, eight waves");
+  constexpr int BTM = 32 * WI, UNIT = 512, IMG = 16 * UNIT, BUF = 2 * IMG, NBUF = 3;   // halfs: a unit, an operand image, A | B
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int bx, by, z;
+  {
+    const unsigned total = gx * gy * gz;
+    const unsigned xcd = lin & 7u, idx = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bx = (int)(v % gx);
+    by = (int)((v / gx) % gy);
+    z = (int)(v / (gx * gy));
+  }
+  const int r0 = by * BTM, c0 = bx * 256;
+  const int batch = z / nsplit;
+  const int kbeg = (z - batch * nsplit) * ksplit;
+  const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
+  const bool use2 = wave_uniform(A2.p != nullptr && r0 < a2_rows ? 1 : 0) != 0;
+  const unsigned short* const ap = use2 ? A2.p : A.p + batch * A.bstride;
+  const long long ael = use2 ? A2.elems : A.elems - batch * A.bstride;
+  const unsigned ald = (unsigned)(use2 ? A2.ld : A.ld);
+  const BufF32 abuf = make_buf(reinterpret_cast<const float*>(ap), (size_t)ael * 2);
+  const BufF32 bbuf = make_buf(reinterpret_cast<const float*>(B.p + batch * B.bstride), (size_t)(B.elems - batch * B.bstride) * 2);
+  // DMA role: units u = 2 wave + s (s = 0, 1) of each operand: ch = u >> 3, q = u & 7
+  int dn[2];
+  unsigned aoff[2], boff[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; sl++) {
+    const int u = 2 * wave + sl, ch = u >> 3, q = u & 7;
+    const int blk = ((lane >> 3) - (q & 1)) & 7;              // the block this lane's position holds
+    dn[sl] = 4 * q + ((lane >> 1) & 3);
+    const unsigned col = (unsigned)(128 * ch + 16 * blk + 8 * (lane & 1));
+    aoff[sl] = ((unsigned)dn[sl] * ald + (unsigned)r0 + col) * 2u;
+    boff[sl] = ((unsigned)dn[sl] * (unsigned)B.ld + (unsigned)c0 + col) * 2u;
+  }
+  const unsigned a_blk = 64u * ald, b_blk = 64u * (unsigned)B.ld;   // bytes per 32 contraction rows
+  const int nblk = (kend - kbeg + GB_BK - 1) / GB_BK;
+  auto dma = [&](const int blk, const int buf) {   // (requests past the slab read rows >= kend: zeros, nobody reads them)
+    const int k0 = kbeg + wave_uniform(blk) * GB_BK;
+    const unsigned kb = (unsigned)wave_uniform(kbeg / GB_BK + blk);   // kbeg is a multiple of 32 (ksplit is)
+    unsigned short* const ia = S + buf * BUF, * const ib = ia + IMG;
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) lds_dma16(abuf, k0 + dn[sl] < kend ? aoff[sl] + kb * a_blk : BUF_OOB, ia + (2 * wave + sl) * UNIT);
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) lds_dma16(bbuf, k0 + dn[sl] < kend ? boff[sl] + kb * b_blk : BUF_OOB, ib + (2 * wave + sl) * UNIT);
+  };
+  f32x4 acc[WI][4];
+#pragma unroll
+  for (int i = 0; i < WI; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
+  // fragment role: lane group g = lane >> 4 reads n-quad g (first read) / 4 + g (second) of strip j: unit (j >> 3, quad),
+  // position ((j & 7) + (g & 1)) & 7, piece lane & 15
+  const int fg = lane >> 4;
+  const int f_base = fg * UNIT + (lane & 15) * 4;            // halfs; + (j >> 3) * 8 UNIT + position * 64; second read + 4 UNIT
+  auto frag = [&](const unsigned short* img, const int j) -> u16x8 {
+    const unsigned short* p = img + f_base + (j >> 3) * (8 * UNIT) + ((((j & 7) + (fg & 1)) & 7) << 6);
+    return join_u16x8(lds_read_tr16(p), lds_read_tr16(p + 4 * UNIT));
+  };
+  dma(0, 0);
+  dma(1, 1);
+  wait_vmcnt<4>();
+  wg_barrier();
+  if (wm == 1) wg_barrier();
+  int cur = 0, nxt2 = 2;
+  for (int t = 0; t < nblk; t++) {
+    dma(t + 2, nxt2);
+    SCHED_FENCE();
+    const unsigned short* const ia = S + cur * BUF;
+    const unsigned short* const ib = ia + IMG;
+    u16x8 af[WI], bf[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) bf[j] = frag(ib, wn * 4 + j);
+#pragma unroll
+    for (int i = 0; i < WI; i++) af[i] = frag(ia, wm * WI + i);
+    SCHED_FENCE();
+    if (wm == 1) wait_vmcnt<4>();
+    wait_lgkmcnt0();
+    SCHED_FENCE();
+    wg_barrier();
+    SCHED_FENCE();
+#pragma unroll
+    for (int i = 0; i < WI; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);
+    SCHED_FENCE();
+    if (wm == 0) wait_vmcnt<4>();
+    wg_barrier();
+    SCHED_FENCE();
+    cur = cur == NBUF - 1 ? 0 : cur + 1;
+    nxt2 = nxt2 == NBUF - 1 ? 0 : nxt2 + 1;
+  }
+  if (wm == 0) wg_barrier();
+  wait_vmcnt<0>();
+  gb2_store<FE, WI>(fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, z);
+}
+constexpr int GMD_SMEM_HALFS = 3 * 2 * 16 * 512;   // 96 KB
+template <class FE, int WI>
+__global__ __launch_bounds__(512, 2) void gemm_b16mc_dma_kernel(GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K,
+                                                                int ksplit, int nsplit, GemmOperand16B A2, int a2_rows) {
+  __shared__ __attribute__((aligned(1024))) unsigned short S[GMD_SMEM_HALFS];
+  gemm_b16mc_dma_body<FE, WI>(S, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                              gridDim.x, gridDim.y, gridDim.z);
+}
+// (Round 5, measured and not kept: this product with its tiles brought in by LDS-DMA like gemm_b16kk_dma_kernel.  Two LDS images
+// were tried at 1544 x 2048 x 25600, two slabs: the strips of gemm_b16mc_kernel, one DMA instruction per strip -- 32 bytes of each
+// of 32 contraction rows, quarter lines: 522 us against 281 us register-staged; and a row-major [32 n][256] image filled in whole
+// 512-byte rows, chunk c of row n at position c ^ 2 (n & 7), read by ds_read_b64_tr_b16 through per-lane addresses: 481 us -- the
+// transpose read has bank classes of its own that an address swizzle does not cure (guide, T10).  profiles/r05_gemm_variants.txt;
+// the kernels are in the history.  The contraction-major product keeps its register-staged, staggered loop.)
 // 256 x 256 tiles where the problem is large enough and their padding costs at most 25 % more work than 128 x 128 tiles do:
 // the big tile runs ~1.4x faster per flop (1537 rows: 7 x 256 vs 13 x 128, + 8 %; 561 rows: 3 x 256 vs 5 x 128, + 20 %:
 // 98 vs 116 us for one direction of the first layer's weight gradient)
@@ -796,6 +1116,11 @@ inline bool gemm_tile256(int R, int Cn) {
   if (R < 192 || Cn < 192) return false;
   const long long w256 = (long long)((R + 255) / 256) * ((Cn + 255) / 256) * 4, w128 = (long long)((R + 127) / 128) * ((Cn + 127) / 128);
   return 4 * w256 <= 5 * w128;
+}
+// tile height of the big-tile contraction-major product: 256 rows, or 192 where that pads R less (576 = 3 x 192)
+inline int gemm_mc_tile_rows(int R) {
+  const int p256 = (R + 255) / 256 * 256, p192 = (R + 191) / 192 * 192;
+  return p192 < p256 ? 192 : 256;
 }
 template <class FE>
 inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1,
@@ -810,15 +1135,45 @@ inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, F
   const int kq = nsplit > 1 ? GT_PF * GB_BK : GB_BK;   // whole ring rounds per slab
   ksplit = ((ksplit + kq - 1) / kq) * kq;
   if (big) {
-    dim3 grid((Cn + 255) / 256, (R + 255) / 256, nsplit * nbatch);
-    if (a2_rows % 256 != 0) A2.p = nullptr;
-    if (stag) CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 1, true>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
+    const int th = gemm_mc_tile_rows(R);
+    dim3 grid((Cn + 255) / 256, (R + th - 1) / th, nsplit * nbatch);
+    if (a2_rows % th != 0) A2.p = nullptr;
+    const bool dma_ok = stag == 3 && (A.ld & 7) == 0 && (B.ld & 7) == 0 && (A.bstride & 7) == 0 && (B.bstride & 7) == 0 && (!A2.p || (A2.ld & 7) == 0) &&
+                        ksplit >= 2 * GB_BK && ksplit % GB_BK == 0 && (((size_t)A.p | (size_t)B.p | (size_t)A2.p) & 15) == 0;
+    if (dma_ok) {   // operand tiles by LDS-DMA (16-byte aligned chunks, slabs of whole blocks)
+      if (th == 192) CLSTM_LAUNCH((gemm_b16mc_dma_kernel<FE, 6>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
+      else CLSTM_LAUNCH((gemm_b16mc_dma_kernel<FE, 8>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
+      return;
+    }
+    if (th == 192) {
+      if (stag) CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 6, 1, true>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
+      else CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 6, 1, false>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
+    } else if (stag) CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 1, true>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
     else CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 8, 1, false>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
     return;
   }
   dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);
   if (a2_rows % GB2_BT != 0) A2.p = nullptr;
   CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 4, 1>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
+}
+
+// weight gradient (contraction-major, big tiles) + input deltas (k-contiguous, LDS-DMA) as one launch; false: not eligible, nothing launched
+template <class FEW, class FEX>
+inline bool gemm_dw_dx(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FEW few, int R, int Cn, int K, int nsplit, int nbatch, GemmOperand16B A2, int a2_rows,
+                       GemmOperand16 XA, GemmOperand16 XB, FEX fex, int XR, int XCn, int XK) {
+  if (gemm_stag_default() != 2 || !gemm_tile256(R, Cn) || !gemm_tile256(XR, XCn)) return false;
+  if (XK % GB_BK != 0 || XK < 2 * GB_BK || (XA.ld & 7) != 0 || (XB.ld & 7) != 0 || R <= 0 || Cn <= 0 || K <= 0) return false;
+  if (nsplit < 1) nsplit = 1;
+  int ksplit = (K + nsplit - 1) / nsplit;
+  const int kq = nsplit > 1 ? GT_PF * GB_BK : GB_BK;
+  ksplit = ((ksplit + kq - 1) / kq) * kq;
+  const int th = gemm_mc_tile_rows(R);
+  if (a2_rows % th != 0) A2.p = nullptr;
+  const unsigned gxw = (Cn + 255) / 256, gyw = (R + th - 1) / th, gzw = nsplit * nbatch, gxx = (XCn + 255) / 256, gyx = (XR + 255) / 256;
+  const dim3 grid(gxw * gyw * gzw + gxx * gyx);
+  if (th == 192) CLSTM_LAUNCH((gemm_dw_dx_kernel<FEW, 6, FEX>), grid, dim3(512), 0, stream, A, B, few, R, Cn, K, ksplit, nsplit, A2, a2_rows, gxw, gyw, gzw, XA, XB, fex, XR, XCn, XK, gxx, gyx);
+  else CLSTM_LAUNCH((gemm_dw_dx_kernel<FEW, 8, FEX>), grid, dim3(512), 0, stream, A, B, few, R, Cn, K, ksplit, nsplit, A2, a2_rows, gxw, gyw, gzw, XA, XB, fex, XR, XCn, XK, gxx, gyx);
+  return true;
 }
 
 // ---- f32-grade products on the bf16 MFMA: 64 x 64 tile, operands split hi + lo ------------------------------------------

@@ -61,6 +61,9 @@ struct LstmWideArgs {
   unsigned short* Sbf;          // persistent forward kernel: bf16 source rows [x | h_{t-1} | 1] of THIS layer, [dir][N][sbf_ld] (h-part written here), or null
   int sbf_ld, sbf_ofs; long long sbf_dir;
   unsigned short* Dbf;          // persistent backward kernel: per-frame [N][nd][kp16] bf16 deltas (operand of the x.d GEMM), or null
+  float* dbias;                 // persistent bf16 backward kernels: [bs][nd][no][4] -- per line, the sum over its frames of the gate deltas AS STORED
+                                //   IN Dbf (bf16-rounded, summed in f32): the bias row of the weight gradient, W.d[:,0] += sum_b y.d
+                                //   (clstm_compute.cc:301), which then needs no 1537th row in the weight-gradient product (gemm_b16mc); or null
   int kp16;                     // padded contraction length of the bf16 rows, multiple of 32 * WIDE_NW
   float* Rf;                    // persistent f32 kernels: tiled lock-step ring of h (forward) / the gate deltas (backward), ring32_* below
   // persistent bf16 forward kernel with the input projection folded in (lstm_xcd_fwd_bf16_fx): the layer's input frames as
@@ -950,8 +953,10 @@ DEVFN void lstm_xcd_fwd_bf16_body(const LstmWideArgs& a) {
       gx[i] = gx_next[i];
     }
     // publish: every store of this workgroup acknowledged by the L2, then one arrival on the group's counter.  (Storing
-    // the bf16 h first and the other arrays behind the arrival was measured SLOWER, 3.5 vs 3.2 us per step: VMEM
-    // completes in order, so the next step's operand loads then wait behind those stores.)
+    // the bf16 h first and the other arrays behind the arrival was measured SLOWER in round 2, 3.5 vs 3.2 us per step: VMEM
+    // completes in order, so the next step's operand loads then wait behind those stores; measured again in round 5 on
+    // today's 1.65 us step -- both forward kernels, CLSTM_FWD_LATE -- it is a wash: 1.3701 vs 1.3705 ms for the two forward
+    // passes of configs[4], profiles/README.md: the wait behind the arrival grows by what the epilogue in front of it shrinks.)
     XCD_STAMP(5);   // epilogue + stores issued
     drain_vmem();
     XCD_STAMP(6);   // stores acknowledged
@@ -1176,6 +1181,13 @@ inline __host__ __device__ int xcd_bwd_lds_bytes(int mt = 1) {
 
 // MT: 16-line tiles per group, as in the forward kernel (the delta ring block a workgroup reads per step doubles with it:
 // 128 KB at MT = 2 -- sixteen 16-byte loads per lane and line tile, all in flight at once)
+// bias-gradient accumulation of the persistent bf16 backward kernels: the four gate deltas of a frame exactly as Dbf holds them
+DEVFN void bias_acc(f32x4& s, const u32x2 pk) {
+  s[0] += __builtin_bit_cast(float, pk[0] << 16);
+  s[1] += __builtin_bit_cast(float, pk[0] & 0xffff0000u);
+  s[2] += __builtin_bit_cast(float, pk[1] << 16);
+  s[3] += __builtin_bit_cast(float, pk[1] & 0xffff0000u);
+}
 template <int MT>
 DEVFN void lstm_xcd_bwd_bf16_body(const LstmWideArgs& a) {
   constexpr int LDR = 16 + 4;
@@ -1218,8 +1230,9 @@ DEVFN void lstm_xcd_bwd_bf16_body(const LstmWideArgs& a) {
   const unsigned akl = ring_elem(wave * ngrp, lane & 15, 8 * (lane >> 4)) * 2u;
   const unsigned short* wfrag = wl + (lane & 15) * XCD_LDWB + wave * kw + 8 * (lane >> 4);
   float dc_carry[MT];      // dc_{s+1} * gf_{s+1} of this thread's (line, cell)s: carried in registers, not through memory
+  f32x4 bsum[MT];          // sum over the line's frames of the four gate deltas as stored in Dbf (LstmWideArgs::dbias)
 #pragma unroll
-  for (int i = 0; i < MT; i++) dc_carry[i] = 0.0f;
+  for (int i = 0; i < MT; i++) { dc_carry[i] = 0.0f; bsum[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
   __syncthreads();
   u16x8 wreg[16];   // this wave's B fragments (16 rows x its quarter of the contraction) in registers for the whole sequence
 #pragma unroll
@@ -1325,14 +1338,20 @@ DEVFN void lstm_xcd_bwd_bf16_body(const LstmWideArgs& a) {
         const long long n = off[i] + (dir == 0 ? T[i] - 1 - sg : sg);
         if (!a.skip_d) *reinterpret_cast<f32x4*>(a.D + ((n * nd + dir) * no + cell) * 4) = dl[i];
         if (a.Dbf) {   // k-contiguous bf16 copy per frame: the ready-made A operand of the x.d product (gemm_b16kk)
-          *reinterpret_cast<u32x2*>(a.Dbf + (size_t)(n * nd + dir) * a.kp16 + 4 * cell) =
-              u32x2{bf16_pack2(dl[i][0], dl[i][1]), bf16_pack2(dl[i][2], dl[i][3])};
+          const u32x2 pk{bf16_pack2(dl[i][0], dl[i][1]), bf16_pack2(dl[i][2], dl[i][3])};
+          *reinterpret_cast<u32x2*>(a.Dbf + (size_t)(n * nd + dir) * a.kp16 + 4 * cell) = pk;
+          bias_acc(bsum[i], pk);
         }
       }
       c_s[i] = cur[i].c_m1;
       cur[i] = nxt[i];
     }
     XCD_STAMP(8);   // per-frame stores issued
+  }
+  if (a.dbias) {
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+      if (mine[i]) *reinterpret_cast<f32x4*>(a.dbias + (((long long)line[i] * nd + dir) * no + cell) * 4) = bsum[i];
   }
   XCD_PROF_WRITE(xcd, slot, ntile);
 }
@@ -1431,8 +1450,9 @@ DEVFN void lstm_xcd_bwd_bf16_c32_body(const LstmWideArgs& a) {
   const int dblk = dline >> 4;
   const unsigned doff = ring_elem(wave * ngrp + dhalf, dline & 15, 8 * (lane >> 4)) * 2u;
   float dc_carry[EPT];
+  f32x4 bsum[EPT];         // sum over the line's frames of the four gate deltas as stored in Dbf (LstmWideArgs::dbias)
 #pragma unroll
-  for (int e = 0; e < EPT; e++) dc_carry[e] = 0.0f;
+  for (int e = 0; e < EPT; e++) { dc_carry[e] = 0.0f; bsum[e] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
 
   // Byte offsets of a thread's element in the per-frame arrays, advanced by one frame per step instead of recomputed (a 64-bit
   // multiply-add chain per access; the arrays stay below 2 GiB -- host check -- so 32 bits carry them): o4 = ((n nd + dir) no + cell) 4
@@ -1546,6 +1566,7 @@ DEVFN void lstm_xcd_bwd_bf16_c32_body(const LstmWideArgs& a) {
     __syncthreads();
     XCD_STAMP(4);   // barrier
     f32x4 dl[EPT];
+    u32x2 pk[EPT];
     bool live[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
@@ -1572,8 +1593,8 @@ DEVFN void lstm_xcd_bwd_bf16_c32_body(const LstmWideArgs& a) {
         dl[e][3] = (-ci * ci + 1.0f) * d_ci;
       }
       // (one 8-byte store: what the group waits for goes first; a lane without a live element stores out of range)
-      buf_store_u32x2_s(abuf, live[e] ? rofs[e] : BUF_OOB_BASE, (sg & 1) ? ring_parity : 0u,
-                        u32x2{bf16_pack2(dl[e][0], dl[e][1]), bf16_pack2(dl[e][2], dl[e][3])});
+      pk[e] = u32x2{bf16_pack2(dl[e][0], dl[e][1]), bf16_pack2(dl[e][2], dl[e][3])};
+      buf_store_u32x2_s(abuf, live[e] ? rofs[e] : BUF_OOB_BASE, (sg & 1) ? ring_parity : 0u, pk[e]);
     }
     XCD_STAMP(5);   // epilogue + ring store issued
     drain_vmem();
@@ -1585,12 +1606,18 @@ DEVFN void lstm_xcd_bwd_bf16_c32_body(const LstmWideArgs& a) {
     for (int e = 0; e < EPT; e++) {
       if (!a.skip_d) buf_store4(dbuf, live[e] ? os[e] << 2 : BUF_OOB, dl[e]);
       // k-contiguous bf16 copy per frame: the ready-made A operand of the x.d product (gemm_b16kk)
-      buf_store_u32x2_s(dbfbuf, live[e] ? ob[e] : BUF_OOB, 0u, u32x2{bf16_pack2(dl[e][0], dl[e][1]), bf16_pack2(dl[e][2], dl[e][3])});
+      buf_store_u32x2_s(dbfbuf, live[e] ? ob[e] : BUF_OOB, 0u, pk[e]);
+      bias_acc(bsum[e], pk[e]);   // (a dead element's deltas are zeros)
       os[e] += s4; ob[e] += sB;
       c_s[e] = cur[e].c_m1;
       cur[e] = nxt[e];
     }
     XCD_STAMP(8);   // per-frame stores issued
+  }
+  if (a.dbias) {
+#pragma unroll
+    for (int e = 0; e < EPT; e++)
+      if (mine[e]) *reinterpret_cast<f32x4*>(a.dbias + (((long long)line[e] * nd + dir) * no + cell) * 4) = bsum[e];
   }
   XCD_PROF_WRITE(xcd, slot, ntile);
 }

@@ -681,6 +681,29 @@ DEVFN void reduce_scatter_one(const ReduceDesc& d, size_t e, float* g, const Upd
     u.d[o] = di * u.mom;
   }
 }
+// Bias row of a weight gradient whose product left it out (clstm_hip.hip: dw_bias_out): dbias [bs][ndir][Cn] holds, per line, the
+// sum over its frames of the gate deltas (lstm_wide.h: LstmWideArgs::dbias); row 0 of direction d's FIRST slab takes their sum
+// over the lines (in line order), row 0 of its other slabs zeros -- the slab reduction then finds W.d[:,0] += sum_b y.d
+// (clstm_compute.cc:301) where the 1537th row of the product used to put it.
+// (eight lines in flight per thread, eight interleaved sums combined pairwise: the loop is a chain of memory latencies -- one
+// line at a time it took ~30 us per layer at configs[4], 64 lines x 4096 columns on sixteen workgroups)
+__global__ void k_bias_rows(const float* dbias, float* partial, int bs, int ndir, int nsplit, int R, int Cn) {
+  CLSTM_GRID_STRIDE(e, (size_t)ndir * Cn) {
+    const int dir = e / Cn, c = e % Cn;
+    const float* p = dbias + (size_t)dir * Cn + c;
+    const size_t ls = (size_t)ndir * Cn;
+    float s[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int b = 0; b < bs; b += 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) x[u] = b + u < bs ? p[(size_t)(b + u) * ls] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; u++) s[u] += x[u];
+    }
+    const float t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    for (int z = 0; z < nsplit; z++) partial[(((size_t)dir * nsplit + z) * R) * Cn + c] = z == 0 ? t : 0.0f;
+  }
+}
 // up to two slab sets per launch (the softmax layer's weight gradient rides with the top LSTM layer's)
 __global__ void k_reduce_scatter(ReduceDesc d0, ReduceDesc d1, float* g, int* zero, int zero_n, UpdateFuse u) {
   // (house-keeping that rides this launch: the work-queue heads of the fused backward launch return to zero)

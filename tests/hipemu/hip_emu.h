@@ -243,6 +243,14 @@ inline BufF32 make_buf(const float* base, size_t bytes) { return BufF32{const_ca
 inline float buf_load(BufF32 b, unsigned off) { return ((size_t)off + 4 <= b.bytes) ? b.base[off / 4] : 0.0f; }
 inline f32x4 buf_load4(BufF32 b, unsigned off) { f32x4 r; for (int i = 0; i < 4; i++) r[i] = buf_load(b, off + 4 * i); return r; }
 inline void buf_store(BufF32 b, unsigned off, float v) { if ((size_t)off + 4 <= b.bytes) b.base[off / 4] = v; }
+// LDS-DMA: lane l of the wave deposits its 16 bytes (zeros when out of range) at the wave-uniform base + 16 l; synchronous here
+inline void lds_dma16(BufF32 b, unsigned off, void* lds_wave_base) {
+  const f32x4 v = buf_load4(b, off);
+  *reinterpret_cast<f32x4*>(static_cast<char*>(lds_wave_base) + 16 * (threadIdx.x & 63)) = v;
+}
+template <int N> inline void wait_vmcnt() {}
+inline void wait_lgkmcnt0() {}
+inline void wg_barrier() { __syncthreads(); }
 inline float buf_load_s(BufF32 b, unsigned lane_off, unsigned uni) { return ((size_t)lane_off + 4 <= b.bytes) ? b.base[(lane_off + uni) / 4] : 0.0f; }
 inline void buf_store_s(BufF32 b, unsigned lane_off, unsigned uni, float v) { if ((size_t)lane_off + 4 <= b.bytes) b.base[(lane_off + uni) / 4] = v; }
 inline void buf_store4(BufF32 b, unsigned off, f32x4 v) { for (int i = 0; i < 4; i++) buf_store(b, off + 4 * i, v[i]); }

@@ -131,7 +131,8 @@ def _bf16_bits(x):
 
 
 @pytest.mark.parametrize("R,Cn,K", [(128, 128, 32), (256, 256, 64), (97, 200, 30), (300, 130, 1000), (129, 513, 96),
-                                    (500, 512, 96), (250, 760, 70)])   # (256, 256) and the last two: 256 x 256 tiles
+                                    (500, 512, 96), (250, 760, 70),    # (256, 256) and these two: 256 x 256 tiles
+                                    (500, 760, 64), (250, 512, 416), (512, 256, 32)])   # LDS-DMA eligible (K % 32 == 0, K >= 64; the last: not)
 def test_gemm_bf16_sources(backend, R, Cn, K):
     """128 x 128-tile GEMM whose operands are ALREADY bf16 and k-contiguous in memory (gemm_b16kk_128_kernel): exact
     against the float64 product of the same bf16 values (f32 accumulation: 2e-6 of sum |a||b|)."""
@@ -149,10 +150,21 @@ def test_gemm_bf16_sources(backend, R, Cn, K):
     got = backend.down(Cd)
     scale = np.abs(Af) @ np.abs(Bf).T
     assert (np.abs(got - want) <= 2e-6 * scale + 1e-6).all()
+    # mode 31: the one-barrier loop; mode 30 runs the 256 x 256 tiles with the two waves of a SIMD half a block apart (two
+    # barriers per block): same fragments, same MFMA order per accumulator -> bit-identical
+    Ce = backend.zeros((R, Cn))
+    backend.lib.call("clstm_debug_gemm", 31, ptr(Ad), ptr(Bd), ptr(Ce), R, Cn, K, 1)
+    assert np.array_equal(backend.down(Ce), got)
+    # mode 34: the operand tiles brought in by LDS-DMA (three buffers, nothing staged through registers; 256 x 256 tiles and
+    # K % 32 == 0, else it is mode 30 again): same image, same fragments, same order
+    Cf = backend.zeros((R, Cn))
+    backend.lib.call("clstm_debug_gemm", 34, ptr(Ad), ptr(Bd), ptr(Cf), R, Cn, K, 1)
+    assert np.array_equal(backend.down(Cf), got)
 
 
 @pytest.mark.parametrize("R,Cn,K,ns", [(128, 128, 32, 1), (256, 256, 64, 1), (104, 200, 30, 1), (304, 136, 1000, 3), (136, 520, 700, 2),
-                                       (504, 512, 700, 2), (248, 760, 130, 1)])   # (256, 256) and the last two: 256 x 256 tiles
+                                       (504, 512, 700, 2), (248, 760, 130, 1),    # (256, 256) and these two: 256 x 256 tiles
+                                       (576, 520, 130, 1), (380, 256, 230, 2)])   # 192 x 256 tiles (24 chunks per row: waves 6, 7 stage no A)
 def test_gemm_bf16_contraction_major(backend, R, Cn, K, ns):
     """128 x 128-tile GEMM whose bf16 operands lie contraction-major in memory ([K][R], [K][Cn]: the weight-gradient
     product's frame-major deltas and sources), transposed by ds_read_b64_tr_b16 on the way into the MFMA
@@ -172,3 +184,10 @@ def test_gemm_bf16_contraction_major(backend, R, Cn, K, ns):
     got = backend.down(Cd)
     scale = np.abs(Af).T @ np.abs(Bf)
     assert (np.abs(got - want) <= 2e-6 * scale + 1e-6).all()
+    Ce = backend.zeros((R, Cn))          # mode 33: the one-barrier loop (mode 32: staggered wave groups on 256 x 256 tiles)
+    backend.lib.call("clstm_debug_gemm", 33, ptr(Ad), ptr(Bd), ptr(Ce), R, Cn, K, ns)
+    assert np.array_equal(backend.down(Ce), got)
+    Cf = backend.zeros((R, Cn))          # mode 35: the tiles brought in by LDS-DMA (big tiles; contraction tails: zeros from out-of-range requests)
+    backend.lib.call("clstm_debug_gemm", 35, ptr(Ad), ptr(Bd), ptr(Cf), R, Cn, K, ns)
+    assert np.array_equal(backend.down(Cf), got)
+

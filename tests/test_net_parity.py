@@ -689,3 +689,90 @@ def test_tiled_weight_pack_equals_the_single_purpose_kernels(backend, ora32, mon
     assert np.array_equal(res[0][0], res[1][0])
     assert all(np.array_equal(a, b) for a, b in zip(res[0][1], res[1][1]))
     assert np.array_equal(res[0][2], res[1][2]) and np.abs(res[0][2]).max() > 0
+
+
+def test_bias_gradient_outside_the_bf16_weight_gradient_product(backend, ora32, monkeypatch):
+    """Round 5: in bf16 mode the weight-gradient product of a wide layer no longer carries the bias row (1 + ni + no rows are one
+    more than a whole number of row panels at both configs[4] layers: a seventh 256-row panel for ONE row).  The persistent
+    backward recurrence sums the gate deltas of a line while it produces them and k_bias_rows lays the sum over the lines into
+    the slabs' row 0.  W.d[:,0] += sum_b y.d (clstm_compute.cc:301): the bias entries of the gradient must equal the sum over all
+    frames of the stored (bf16) gate deltas, for every layer, direction and gate -- and the path must have run."""
+    from clstm_amd.net import Network
+    monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
+    rng = np.random.default_rng(29)
+    ni, nh, nc, T = 96, [32, 32], 6, [9, 5, 7, 3, 8]      # (96 inputs: both layers' products fill the big tiles)
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 20.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+    net = Network(ni, nh, nc, lib=backend.lib)
+    net.set_params(params)
+    net.set_gemm_precision(2)
+    before = _path_count(backend, 13)
+    net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
+    assert _path_count(backend, 13) - before == len(nh)
+    g = net.get_grads().astype(np.float64)
+    o = 0
+    for l, no in enumerate(nh):
+        nin = ni if l == 0 else 2 * nh[l - 1]
+        blk = no * (1 + nin + no)
+        for d in (0, 1):
+            for name in ("d_ci", "d_gf", "d_gi", "d_go"):          # walk_params: WCI, WGF, WGI, WGO (clstm.cc:59-62)
+                dl = net.state(l, d, name).astype(np.float64)      # [N][no]: the bf16 deltas, expanded exactly
+                want, scale = dl.sum(0), np.abs(dl).sum(0)
+                got = g[o:o + no]                                  # column 0 of the Params block = the bias
+                assert (np.abs(got - want) <= 1e-5 * scale + 1e-9).all(), (l, d, name, np.abs(got - want).max())
+                assert np.abs(want).max() > 0
+                o += blk
+    # ... and the whole gradient still tracks the oracle as before
+    want = oracle_minibatch(ora32, OracleNet, params, ni, nh, nc, lines, trs)
+    assert np.abs(g - want["derivs"]).max() < 8e-2 * np.abs(want["derivs"]).max()
+
+
+def _merged_launch_case(backend, ora32):
+    from clstm_amd.net import Network
+    rng = np.random.default_rng(31)
+    ni, nh, nc, T = 16, [96, 64], 6, [25] * 8          # upper layer: 192 inputs, 256 gate columns per direction, 200 frames
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 10.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, 5).astype(np.int32) for _ in T]
+    res = []
+    for stag in ("2", "1"):
+        os.environ["CLSTM_GEMM_STAG"] = stag
+        net = Network(ni, nh, nc, lib=backend.lib)
+        net.set_params(params)
+        net.set_gemm_precision(2)
+        before = _path_count(backend, 14)
+        net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
+        res.append((net.get_grads(), net.state(0, 0, "d_gi"), _path_count(backend, 14) - before))
+    os.environ.pop("CLSTM_GEMM_STAG", None)
+    assert res[0][2] == 1 and res[1][2] == 0, (res[0][2], res[1][2])       # the upper layer took the merged launch / did not
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1])
+    want = oracle_minibatch(ora32, OracleNet, params, ni, nh, nc, lines, trs)
+    assert np.abs(res[0][0] - want["derivs"]).max() < 8e-2 * np.abs(want["derivs"]).max()
+
+
+def test_weight_gradient_and_input_deltas_as_one_launch(backend, ora32, monkeypatch):
+    """Round 5: a wide layer's weight-gradient product (contraction-major bf16 operands, bias row outside) and its input deltas
+    (k-contiguous bf16 operands, tiles by LDS-DMA) run as ONE launch of two workgroup roles (gemm_dw_dx_kernel) where both fill
+    the big tiles -- apart, each leaves a quarter of the configs[4] chip idle.  Same kernel bodies, same operands: the gradient
+    and the lower layer's deltas must be BIT-identical to the two separate launches (CLSTM_GEMM_STAG=1: register-staged tiles,
+    no merged launch), and the path must have run.  (A 64-cell layer needs 32 persistent workgroups: on the emulator a child
+    process with 48 emulated CUs.)"""
+    monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
+    if backend.kind == "hip":
+        _merged_launch_case(backend, ora32)
+        return
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        from common import Backend
+        from oracle.oracle import Oracle
+        import test_net_parity
+        test_net_parity._merged_launch_case(Backend("emu"), Oracle("f32"))
+        print("IDENTICAL")
+    """ % (ROOT, ROOT))
+    env = dict(os.environ, CLSTM_EMU_CUS="48", CLSTM_FORCE_WIDE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
