@@ -559,7 +559,7 @@ def main():
         ws = Workload(lib, cfg, args.minibatch, args.T, args.ragged, 0, dev, rank, strict_f32=True)
         ms_ = measure(ws, args.steps, 5, 0, min_timed_s=0.5)
         strict = {"value": round(args.minibatch * args.steps / ms_["dt"], 2), "unit": "lines/s", "ms_per_step": round(ms_["dt"] / args.steps * 1e3, 4),
-                  "repeats": len(ms_["blocks"]), "dtype": "f32 (every product on the f32 MFMA: CLSTM_DW_X3=0 CLSTM_GEMM_X3=0)"}
+                  "repeats": len(ms_["blocks"]), "dtype": "f32 (every product on the f32 MFMA: clstm_net_set_strict_f32)"}
         ws.net = ws.trainer = None
         del ws
 

@@ -118,6 +118,7 @@ _SIGS = {
     "clstm_debug_ctc_cycles": [_P],
     "clstm_debug_gemm": [_I, _P, _P, _P, _I, _I, _I, _I],
     "clstm_debug_path_count": [_I, _P],
+    "clstm_debug_set_option": [C.c_char_p, _I],
     "clstm_debug_set_device_error": [_I, _I],
 }
 # functions whose int return value is a result, not a status

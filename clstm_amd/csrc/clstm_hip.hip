@@ -12,6 +12,7 @@
 //   update  : k_update on the flat reference-layout buffers, then re-pack kernel weights.
 // Stacked/Parallel/Reversed never copy: they are pointer hand-offs and index arithmetic.
 #include "../../include/clstm_abi.h"
+#include "dbgopt.h"
 #include "ctc.h"
 #include "devintrin.h"
 #include "gemm_mfma.h"
@@ -296,7 +297,7 @@ static std::vector<char> graph_key(A a) {
 template <class A, class F>
 static void launch_steps(StepGraphCache& cache, int kind, const A& a, int tmax, hipStream_t s, F&& body) {
 #ifndef CLSTM_HIP_EMU
-  static const bool use_graph = !(getenv("CLSTM_WIDE_GRAPH") && atoi(getenv("CLSTM_WIDE_GRAPH")) == 0);
+  const bool use_graph = dbg_opt("wide_graph", 1) != 0;
   if (use_graph && tmax >= 8) {
     const std::vector<char> key = graph_key(a);
     hipGraphExec_t exec = cache.find(kind, key, tmax);
@@ -419,7 +420,7 @@ static void check_device_errors() {
   if (w[7]) throw Error("data-parallel replicas diverged: the parameter checksums of the ranks differ at training step " + std::to_string(w[7]) + " of a net (replica check, "
                         "CLSTM_REPLICA_CHECK_EVERY); every rank applies the identical update to the identical all-reduced gradient, so this is a fault (a skipped update on "
                         "one rank, memory corruption), not drift -- no update was applied since.  The reference re-broadcasts the weights instead (distribute_weights, clstm.cc:718-729)");
-  if (w[6]) throw Error("gradient exchange: " + std::to_string(w[6]) + " wait(s) of the device-side peer barrier timed out (CLSTM_PEER_DEVICE_TIMEOUT_S, default 120 s) although every "
+  if (w[6]) throw Error("gradient exchange: " + std::to_string(w[6]) + " wait(s) of the device-side peer barrier timed out (CLSTM_PEER_TIMEOUT_S, default 120 s) although every "
                         "rank's host had announced the exchange: a peer's GPU never reached it; the minibatches enqueued since then were NOT applied -- CLSTM_PEER_ALLREDUCE=0 "
                         "puts the exchange back on RCCL");
   if (w[3]) throw Error("non-finite value (NaN or Inf) in the softmax logits or the gradient of training step " + std::to_string(w[3]) + " of a net (forward passes counted per net "
@@ -536,7 +537,7 @@ static bool launch_lstm_wide(bool fwd, LstmWideArgs a, int tmax, DevBuf<int>& sy
     if (fits && !bf16 && (size_t)xcd_bwd_f32_lds_bytes(a.kp) <= 160 * 1024 && persistent(lstm_xcd_bwd_f32, (size_t)xcd_bwd_f32_lds_bytes(a.kp))) return true;
     // 32 cells per workgroup, two groups per XCD, groups of 8 / 16 / 32 lines (lstm_wide.h:lstm_xcd_bwd_bf16_c32): half the
     // delta block per step and CU of the 16-cell kernel below, which stays for hidden sizes that are not multiples of 32
-    const bool c32_on = !(getenv("CLSTM_BWD_C32") && atoi(getenv("CLSTM_BWD_C32")) == 0);   // (read per pass: tests compare both kernels in one process)
+    const bool c32_on = dbg_opt("bwd_c32", 1) != 0;   // (read per pass: tests compare both kernels in one process)
     if (fits && bf16 && a.kp16 <= 2048 && c32_on && no % 32 == 0 && a.ndir <= 2) {
       const int per = 16 / a.ndir;   // line groups per launch
       const int ept = a.bs <= 8 * per ? 1 : a.bs <= 16 * per ? 2 : 4;
@@ -732,27 +733,23 @@ static double env_seconds(const char* name, double dflt) {
   return v > 0 ? v : dflt;
 }
 // ticks of wall_clock() (100 MHz) k_peer_barrier waits for a peer whose HOST has already announced the step
-static long long peer_device_timeout_ticks() { return (long long)(env_seconds("CLSTM_PEER_DEVICE_TIMEOUT_S", 120.0) * 1e8); }
+static long long peer_device_timeout_ticks() { return (long long)(env_seconds("CLSTM_PEER_TIMEOUT_S", 120.0) * 1e8); }
 // What the hosts of a communicator share besides the set-up handshake: announced[r] = the last exchange sequence number rank r's
 // host is about to enqueue the device barrier for; left[r] = rank r has destroyed its communicator (or failed).
 struct PeerHostWords { std::atomic<int> announced[PEER_MAX_RANKS], left[PEER_MAX_RANKS]; };
 // Before a rank enqueues k_peer_barrier for sequence number sq it announces sq and waits -- on the HOST, as long as it takes,
 // like ncclAllReduce would -- until every rank's host has announced it too.  A rank whose host is busy elsewhere (clstmocrtrain's
 // rank 0 runs the test set and saves while the others are already at the next step) therefore stalls its peers' hosts, not
-// their GPUs' watchdog: the device barrier only ever waits for queued device work.  CLSTM_PEER_HOST_TIMEOUT_S bounds the
-// wait (default: none); a peer that has left the communicator ends it with an error at once.
+// their GPUs' watchdog: the device barrier only ever waits for queued device work.  The wait is unbounded, like a collective's;
+// a peer that has left the communicator ends it with an error at once.
 static void peer_announce_and_wait(PeerHostWords* w, int rank, int nranks, int sq) {
   if (!w) return;
   w->announced[rank].store(sq);
-  static const double limit = env_seconds("CLSTM_PEER_HOST_TIMEOUT_S", 0.0);
-  const auto t0 = std::chrono::steady_clock::now();
   for (int r = 0; r < nranks; r++) {
     int spins = 0;
     while ((int)((unsigned)sq - (unsigned)w->announced[r].load()) > 0) {   // (wrap-safe: rank r is still behind sq)
       if (w->left[r].load()) throw Error("gradient exchange: rank " + std::to_string(r) + " has left the communicator (exchange " + std::to_string(sq) + " never announced)");
       if (++spins < 2000) sched_yield(); else usleep(100);
-      if (limit > 0 && (spins & 255) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
-        throw Error("gradient exchange: rank " + std::to_string(r) + " did not reach exchange " + std::to_string(sq) + " within CLSTM_PEER_HOST_TIMEOUT_S");
     }
   }
 }
@@ -806,7 +803,7 @@ struct Comm {
       const int sq = -5 + round;
       const PeerArgs pa = p.args(sq, rank, nranks);
       CLSTM_LAUNCH(k_peer_fill, dim3(nblocks(p.cap)), dim3(256), 0, s, p.slot_ptr(sq), p.cap, rank, round);
-      CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, perr, (long long)(env_seconds("CLSTM_PEER_PROBE_TIMEOUT_S", 20.0) * 1e8));
+      CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, perr, (long long)(20.0 * 1e8));
       CLSTM_LAUNCH(k_peer_probe, dim3(nblocks(p.cap)), dim3(256), 0, s, pa, p.cap, round, perr);
       ran = hipGetLastError() == hipSuccess;
     }
@@ -861,7 +858,7 @@ struct Comm {
     if (fd >= 0) close(fd);
     bool good = rv != nullptr;
     if (rv) {
-      const double setup_s = env_seconds("CLSTM_PEER_SETUP_TIMEOUT_S", 60.0);
+      const double setup_s = 60.0;
       rv->h[rank] = mine;
       rv->arrived.fetch_add(1);
       good = wait_for(rv->arrived, nranks, setup_s);
@@ -948,19 +945,15 @@ static double env_seconds(const char* name, double dflt) {
   const double v = atof(e);
   return v > 0 ? v : dflt;
 }
-static long long peer_device_timeout_ticks() { return (long long)(env_seconds("CLSTM_PEER_DEVICE_TIMEOUT_S", 120.0) * 1e8); }
+static long long peer_device_timeout_ticks() { return (long long)(env_seconds("CLSTM_PEER_TIMEOUT_S", 120.0) * 1e8); }
 static void peer_announce_and_wait(PeerHostWords* w, int rank, int nranks, int sq) {
   if (!w) return;
   w->announced[rank].store(sq);
-  static const double limit = env_seconds("CLSTM_PEER_HOST_TIMEOUT_S", 0.0);
-  const auto t0 = std::chrono::steady_clock::now();
   for (int r = 0; r < nranks; r++) {
     int spins = 0;
     while ((int)((unsigned)sq - (unsigned)w->announced[r].load()) > 0) {
       if (w->left[r].load()) throw Error("gradient exchange: rank " + std::to_string(r) + " has left the communicator (exchange " + std::to_string(sq) + " never announced)");
       if (++spins < 2000) sched_yield(); else usleep(100);
-      if (limit > 0 && (spins & 255) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
-        throw Error("gradient exchange: rank " + std::to_string(r) + " did not reach exchange " + std::to_string(sq) + " within CLSTM_PEER_HOST_TIMEOUT_S");
     }
   }
 }
@@ -996,7 +989,7 @@ struct Comm {
       const int sq = -5 + round;
       const PeerArgs pa = p.args(sq, rank, nranks);
       CLSTM_LAUNCH(k_peer_fill, dim3(nblocks(p.cap)), dim3(256), 0, s, p.slot_ptr(sq), p.cap, rank, round);
-      CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, &perr, (long long)(env_seconds("CLSTM_PEER_PROBE_TIMEOUT_S", 60.0) * 1e8));
+      CLSTM_LAUNCH(k_peer_barrier, dim3(1), dim3(64), 0, s, pa, sq, &perr, (long long)(60.0 * 1e8));
       CLSTM_LAUNCH(k_peer_probe, dim3(nblocks(p.cap)), dim3(256), 0, s, pa, p.cap, round, &perr);
     }
     // (the slots keep the last patterns: a peer may still be reading them; every later user assigns what it reads)
@@ -1087,6 +1080,7 @@ struct Layer {
   bool sh_valid = true;        // the h_{t-1} columns of S (f32) are current (... only Sbf)
   DevBuf<unsigned short> Dbf;  // per-frame bf16 gate deltas written by the persistent backward kernel (A operand of the x.d GEMM)
   DevBuf<float> dbias;         // [bs][ndir][no][4] per-line sums of those deltas (the bias row of the weight gradient), same kernel
+  DevBuf<float> partial;       // stacked nets: this layer's own split-K slabs of the weight gradient (reduced behind the LAST recurrence of the pass)
   DevBuf<unsigned short> Wtb;  // bf16 copy of Wt ([ni][M], k = gate column contiguous): B operand of the bf16-source x.d product
   int lds = 0;
   int wt_slack = 32;          // floats past Wt a vectorised staging load may touch
@@ -1281,7 +1275,7 @@ struct Net {
     for (auto& y : L) {
       (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff); (void)hipFree(y.Wk);
       (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release(); y.Rf32.release(); y.R2b.release(); y.D2.release();
-      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false; y.pack_tab.release();
+      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false; y.pack_tab.release(); y.partial.release(); y.dbias.release();
     }
     (void)hipFree(W1k); fw_items.release(); fw_flags.release();
     for (int i = 0; i < 2; i++) { hf.xin[i].release(); if (hf.pin[i]) (void)hipHostFree(hf.pin[i]); if (hf.copied[i]) (void)hipEventDestroy(hf.copied[i]); }
@@ -1303,7 +1297,7 @@ struct Net {
       const int M = ndir * 4 * y.no, KQP = 4 * y.nk4;
       const size_t nr = y.wide ? 0 : (size_t)ndir * 4 * KQP * y.nthreads;
       if (y.wide && bf16_rec && y.no % 128 == 0 && y.ni % 32 == 0 && wide_kp16_fwd(y.no) == y.no && wide_kp16_bwd(y.no) == 4 * y.no &&
-          !(getenv("CLSTM_PACK_TILES") && atoi(getenv("CLSTM_PACK_TILES")) == 0)) {
+          dbg_opt("pack_tiles", 1) != 0) {
         // every bf16-mode copy of the layer in one tiled pass (ops.h:k_pack_wide_tiles)
         const int rf = (y.no + 3) / 4 * 16, kf = wide_kp16_fwd(y.no), rb = (y.no + 15) / 16 * 16, kb = wide_kp16_bwd(y.no);
         y.Wtb.reserve((size_t)y.ni * M + 64);
@@ -1425,7 +1419,7 @@ struct Net {
         w.skip_d = bf16_gemm;
         y.dbias.reserve((size_t)bs * ndir * 4 * y.no + 64); w.dbias = y.dbias.p;   // per-line bias-gradient sums (lstm_wide.h: LstmWideArgs::dbias)
       }
-      static const bool b16mc_on = !(getenv("CLSTM_GEMM_B16MC") && atoi(getenv("CLSTM_GEMM_B16MC")) == 0);
+      const bool b16mc_on = dbg_opt("gemm_b16mc", 1) != 0;
       if (fwd && b16mc_on && bf16_gemm && (y.ni & 7) == 0 && (y.no & 7) == 0 && wide_kp16_bwd(y.no) == 4 * y.no) {
         const int ldsb = y.ni + y.no + 8;
         { const size_t cap0 = y.Sbf.cap; y.Sbf.reserve((size_t)N * ndir * ldsb + 64); if (y.Sbf.cap != cap0) y.sbf_one_key = -1; }
@@ -1535,7 +1529,7 @@ struct Net {
       // one L2 round trip of the poll, not waiting for late tiles -- so the fused work lands on the chain: +400 cycles per step
       // for 64 inputs (67 us per pass against the 121 us of product + bf16 copy it replaces: kept), +2,950 for 1024 inputs
       // (490 us against 321: not kept).  (read per pass: tests switch it inside one process)
-      const int fx_mode = getenv("CLSTM_FUSE_WX") ? atoi(getenv("CLSTM_FUSE_WX")) : 1;
+      const int fx_mode = dbg_opt("fuse_wx", 1);
       if (fx_mode > 0 && (fx_mode > 1 || y.ni <= 128) && y.wide && bf16_gemm && bf16_rec && y.WtbT.p && (y.ni & 31) == 0 && (l == 0 || x_from_hbf)) {
         const int ngx = y.ni <= 128 ? 1 : y.ni <= 512 ? 4 : y.ni <= 1024 ? 8 : 0;
         if (ngx) {
@@ -1714,19 +1708,18 @@ struct Net {
 
   // overlapped weight-gradient GEMM: 1 = bf16 MFMA on hi + lo split operands (three products, f32-grade: gemm_dw.h),
   // 0 = f32 MFMA (CLSTM_DW_X3=0)
-  int dw_x3 = getenv("CLSTM_DW_X3") ? atoi(getenv("CLSTM_DW_X3")) : 1;
+  int dw_x3 = dbg_opt("dw_x3", 1);
   // the softmax layer's backward products W.d / x.d the same way (gemm_x3, gemm_bf16.h); CLSTM_GEMM_X3=0: f32 MFMA.
   // NOT the forward product W_x.x: its ~2^-17 relative error per product shows up in gate pre-activations that cancel to
   // ~0 (a tanh gate at -0.0021 came out 5.6e-6 off where the parity bar allows 2.2e-6), and with K = 49 the split costs
   // more staging than it saves MFMA time (28.5 vs 20.9 us).
-  bool gemm_x3_on = !(getenv("CLSTM_GEMM_X3") && atoi(getenv("CLSTM_GEMM_X3")) == 0);
+  bool gemm_x3_on = dbg_opt("gemm_x3", 1) != 0;
   // exact-f32 mode, wide layers: the persistent BACKWARD recurrence as an f32-grade x3 product on the bf16 MFMA (lstm_wide.h:
   // lstm_xcd_bwd_x3) like the backward GEMMs of this mode; off with them (CLSTM_GEMM_X3=0 / strict f32) or alone (CLSTM_REC_X3=0;
   // read per pass: tests compare both kernels in one process)
   bool rec_x3() const {
     if (bf16_gemm || bf16_rec || !gemm_x3_on) return false;
-    const char* e = getenv("CLSTM_REC_X3");
-    return !(e && atoi(e) == 0);
+    return dbg_opt("rec_x3", 1) != 0;
   }
   // split-K slabs for the weight-gradient GEMMs: enough workgroups to cover the 256 CUs
   // big tiles of the contraction-major bf16 product (gemm_b16mc: 256 or 192 rows x 256 columns): one workgroup per CU, never a second round
@@ -1840,6 +1833,7 @@ struct Net {
     if (prog_base > (1 << 30)) prog_base = 1024;   // (words left from ~5 million launches ago could look complete: harmless in practice, D is rewritten)
     a.prog_off = prog_off;
     a.prog_base = prog_base;
+    DevBuf<float>& partial = layer_partial(y);
     partial.reserve((size_t)ndir * dw_slabs_per_dir * R * Cn);
     GemmDwArgs g{};
     g.S = y.S.p; g.sdir = (long long)N * y.lds; g.lds = y.lds; g.s_elems = (long long)N * ndir * y.lds + 3;
@@ -2014,7 +2008,7 @@ struct Net {
              : dw_from_bf16 && gemm_tile256(R, Cn) ? pick_split_mc(R, Cn, ndir)
              : (bf16_gemm || x3_big) && gemm_bf16_big(R, Cn) ? pick_split(R, Cn, ndir, GB2_BT) : pick_split(R, Cn, ndir);
       if (!dw_from_bf16) { ensure_source(l); ensure_delta_f32(l); }   // the f32-source products below read S and D
-      DevBuf<float>& pbuf = partial;
+      DevBuf<float>& pbuf = layer_partial(y);
       bool dx_done = false;   // the input deltas rode the weight-gradient launch (gemm_dw_dx)
       auto do_dw = [&](hipStream_t q) {
         if (bf16_gemm || !overlap_eligible(y)) {
@@ -2066,15 +2060,13 @@ struct Net {
         const ReduceDesc gates{pbuf.p, y.moff, 0LL, ns, ndir, R, Cn, y.no};
         ReduceDesc extra{};   // empty unless this is the top layer
         if (l == (int)L.size() - 1) extra = sm_red;
-        const size_t work = (size_t)ndir * R * Cn + (size_t)extra.R * extra.Cn * extra.nbatch;
-        UpdateFuse uf{};
-        uf.nanflag = nanflag(); uf.step_no = step_no();
-        if (fuse) {   // (train_step without a communicator) this layer's parameters are updated by the reduction itself
-          uf = UpdateFuse{v, d, lr, mom, gclip, (const int*)dev_err_words(), l == 0 ? update_step_word : nullptr, update_step_id, nanflag(), step_no()};
-          if (l == 0) { update_step_word = nullptr; update_applied = true; }   // (the last reduction of the pass)
+        if (L.size() > 1) {   // stacked net: every reduction behind the last recurrence of the pass (see reduce_layer)
+          pending_red.push_back(PendingReduce{gates, extra, l});
+          timing.end(q);
+          check_launch();
+          return;
         }
-        CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, gdst, (int*)nullptr, 0, uf);
-        if (peer && l == 0) peer_pending = true;
+        reduce_layer(gates, extra, l, true, fuse, peer, gdst, q);
         timing.end(q);
         check_launch();
       };
@@ -2105,6 +2097,35 @@ struct Net {
       do_dw(s);
       do_dx();
     }
+    if (!pending_red.empty()) {
+      timing.begin("reduce_scatter", s);
+      for (size_t i = 0; i < pending_red.size(); i++)
+        reduce_layer(pending_red[i].gates, pending_red[i].extra, pending_red[i].l, i + 1 == pending_red.size(), fuse, peer, gdst, s);
+      pending_red.clear();
+      timing.end(s);
+      check_launch();
+    }
+  }
+  // The slab reduction of one layer (+ the softmax layer's, riding the top layer's).  `last`: the last reduction launch of the
+  // backward pass.  With the update riding the reductions (fuse: train_step without an exchange), ALL of them must see the final
+  // error state of the pass -- a sticky device error raised by a lower layer's recurrence after an upper layer had taken its update
+  // would leave half a step applied -- so a stacked net keeps a slab buffer per layer (Layer::partial) and reduces every layer here,
+  // behind the LAST recurrence; a single layer is reduced where it always was.  (What a reduction itself can still find is a
+  // non-finite gradient ENTRY: skipped entry by entry, ops.h:k_update.)
+  struct PendingReduce { ReduceDesc gates, extra; int l; };
+  std::vector<PendingReduce> pending_red;
+  DevBuf<float>& layer_partial(Layer& y) { return L.size() > 1 ? y.partial : partial; }
+  void reduce_layer(const ReduceDesc& gates, const ReduceDesc& extra, int l, bool last, bool fuse, bool peer, float* gdst, hipStream_t q) {
+    const size_t work = (size_t)gates.nbatch * gates.R * gates.Cn + (size_t)extra.R * extra.Cn * extra.nbatch;
+    UpdateFuse uf{};
+    uf.nanflag = nanflag(); uf.step_no = step_no();
+    if (fuse) {   // (train_step without a communicator) this layer's parameters are updated by the reduction itself
+      uf = UpdateFuse{v, d, lr, mom, gclip, (const int*)dev_err_words(), last ? update_step_word : nullptr, update_step_id, nanflag(), step_no()};
+      if (last) { update_step_word = nullptr; update_applied = true; }
+    }
+    CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, gdst, (int*)nullptr, 0, uf);
+    if (peer && last) peer_pending = true;
+    (void)l;
   }
 
   long long nbackward = 0;           // backward passes of this net so far = the number of the current training step (from 1)
@@ -2124,13 +2145,10 @@ struct Net {
                               //   peer-read all-reduce fused with the update (set by train_step when a communicator of > 1 ranks is attached)
   bool peer_pending = false;  // ... this backward pass did so
   bool fuse_update = false;   // the NEXT backward pass applies the update inside its reductions (set by train_step)
-  // The update rides the slab reductions only where ONE reduction launch covers every parameter (a single LSTM layer: its gate
-  // blocks and the softmax layer's W1 are reduced together, after the last recurrence of the pass).  In a stacked net the
-  // reductions run layer by layer, top down, with the lower layers' recurrences in between: an error word raised by one of
-  // those (a persistent launch that lost its placement, a watchdog) would find the upper layers' parameters already updated
-  // -- half a step.  There the reductions only stage g and k_update applies the whole step behind the last recurrence, or
-  // nothing (35 us of a 4 ms step at configs[4]).
-  bool fuse_eligible() const { return (!comm || comm->nranks == 1) && L.size() == 1; }
+  // The update rides the slab reductions (train_step without an exchange).  All or nothing: every reduction of a pass runs behind
+  // its last recurrence (reduce_layer) -- in a stacked net the layers' reductions used to sit between the recurrences, top down, and
+  // an error word raised by a lower layer found the upper layers' parameters already updated: half a step.
+  bool fuse_eligible() const { return !comm || comm->nranks == 1; }
   bool update_applied = false; // ... and has done so: update() has nothing left to launch
   void update() {
     hipStream_t s = stream();
@@ -2984,8 +3002,8 @@ int clstm_net_set_strict_f32(clstm_net* h, int on) {
   Net& n = h->net;
   if (on) { n.dw_x3 = 0; n.gemm_x3_on = false; }
   else {
-    n.dw_x3 = getenv("CLSTM_DW_X3") ? atoi(getenv("CLSTM_DW_X3")) : 1;
-    n.gemm_x3_on = !(getenv("CLSTM_GEMM_X3") && atoi(getenv("CLSTM_GEMM_X3")) == 0);
+    n.dw_x3 = dbg_opt("dw_x3", 1);
+    n.gemm_x3_on = dbg_opt("gemm_x3", 1) != 0;
   }
   n.packed_dirty = true;   // (the hi | lo weights of the f32-grade backward recurrence are only packed while that mode is on)
   ABI_END
@@ -3045,6 +3063,12 @@ int clstm_debug_set_device_error(int which, int value) {   // tests: what a fail
     return 0;
   }
   HIPCHECK(hipMemcpy(dev_err_words() + which, &value, sizeof(int), hipMemcpyHostToDevice));
+  ABI_END
+}
+int clstm_debug_set_option(const char* name, int value) {   // experiment switches (dbgopt.h); name NULL: forget every option set so far
+  ABI_BEGIN
+  HIPCHECK(hipStreamSynchronize(g_stream));
+  if (!name) dbg_opts().clear(); else dbg_opts()[name] = value;
   ABI_END
 }
 int clstm_debug_path_count(int which, long long* out_h) {

@@ -180,6 +180,20 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 DEVFN u32x2 lds_read_tr16(const unsigned short* p) {
   return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)p));
 }
+// The same read as inline asm, byte address in LDS + immediate offset: beside LDS-DMA in flight hipcc puts s_waitcnt vmcnt(0) in front
+// of the BUILTIN (it cannot tell which LDS bytes the read touches and takes every pending DMA for a producer): the whole
+// request pipeline drained at every block (gemm_b16mc_dma_kernel: 533 vs 284 us, found in the ISA).  An asm statement is
+// invisible to that pass -- the caller orders the read against the DMA itself (wait_vmcnt + wg_barrier) and waits for the result
+// with wait_lgkmcnt0() before it is used.
+typedef unsigned LdsAddr;   // byte address in LDS (the host emulator: a pointer)
+DEVFN LdsAddr lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
+DEVFN LdsAddr lds_addr_add(LdsAddr a, int bytes) { return a + (unsigned)bytes; }
+template <int OFF>
+DEVFN u32x2 lds_read_tr16_raw(LdsAddr addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
 DEVFN u16x8 join_u16x8(u32x2 a, u32x2 b) {
   u32x4 v;
   v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];

@@ -16,6 +16,7 @@
 // One 32-k block costs a wave 4 ds_read_b128 + 4 MFMAs (~70 cycles) instead of 16 ds_read_b32 + 32 f32
 // MFMAs (1024 cycles); the kernel is then bound by the global->LDS staging of its 64x64 tiles.
 #pragma once
+#include "dbgopt.h"
 #include "gemm_mfma.h"
 
 namespace clstm {
@@ -759,9 +760,8 @@ __global__ __launch_bounds__(512, 2) void gemm_b16kk_dma_kernel(GemmOperand16 A,
   gemm_b16kk_dma_body<FE>(S, A, B, fe, R, Cn, K, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y);
 }
 inline bool gemm_tile256(int R, int Cn);
-inline int gemm_stag_default() {   // CLSTM_GEMM_STAG: 2 LDS-DMA tiles + staggered wave groups, 1 register-staged + staggered, 0 the one-barrier loop (A/B)
-  const char* e = getenv("CLSTM_GEMM_STAG");   // (read per call: tests compare the variants within one process)
-  return e ? atoi(e) : 2;
+inline int gemm_stag_default() {   // experiment switch (dbgopt.h): 2 LDS-DMA tiles + staggered wave groups, 1 register-staged + staggered, 0 the one-barrier loop
+  return dbg_opt("gemm_stag", 2);
 }
 template <class FE>
 inline void gemm_b16kk(hipStream_t stream, GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K, int stag = -1) {
@@ -969,22 +969,6 @@ __global__ __launch_bounds__(WI == 4 ? 256 : 512, 2) void gemm_b16mc_kernel(Gemm
   gemm_b16mc_body<FE, WI, NB, STAG>(As, Bs, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows,
                                     blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z);
 }
-// ---- the weight gradient and the input deltas of a wide layer as ONE launch (round 5) --------------------------------------------
-// Both depend on the layer's backward recurrence and on nothing else; apart, each leaves a quarter of the chip idle: the
-// weight-gradient product of the upper configs[4] layer is 96 tiles x 2 slabs = 192 workgroups of 400 blocks on 256 CUs, x.d
-// 400 tiles of 128 blocks = two rounds, the second 56 % full (656 block-times end to end).  One grid -- the long weight-gradient
-// workgroups first, the x.d tiles behind them, taken by whichever CU comes free -- needs ~500 + the tail.  Roles by block index
-// (wave-uniform); ONE LDS array serves both bodies.
-template <class FEW, int WI, class FEX>
-__global__ __launch_bounds__(512, 2) void gemm_dw_dx_kernel(GemmOperand16B A, GemmOperand16B B, FEW few, int R, int Cn, int K, int ksplit, int nsplit,
-                                                            GemmOperand16B A2, int a2_rows, unsigned gxw, unsigned gyw, unsigned gzw,
-                                                            GemmOperand16 XA, GemmOperand16 XB, FEX fex, int XR, int XCn, int XK, unsigned gxx, unsigned gyx) {
-  constexpr int MC_HALFS = GmcSmem<WI, 1>::A + GmcSmem<WI, 1>::B;
-  __shared__ __attribute__((aligned(1024))) unsigned short S[MC_HALFS > GKD_SMEM_HALFS ? MC_HALFS : GKD_SMEM_HALFS];
-  const unsigned nw = gxw * gyw * gzw;
-  if (blockIdx.x < nw) gemm_b16mc_body<FEW, WI, 1, true>(S, S + GmcSmem<WI, 1>::A, A, B, few, R, Cn, K, ksplit, nsplit, A2, a2_rows, blockIdx.x, gxw, gyw, gzw);
-  else gemm_b16kk_dma_body<FEX>(S, XA, XB, fex, XR, XCn, XK, blockIdx.x - nw, gxx, gyx);
-}
 // ---- the contraction-major product with its tiles brought in by LDS-DMA (round 5, third image; see the note below) --------------
 // LDS image of an operand block [32 n][256 columns]: sixteen UNITS of 1 KB, unit (ch, q) = contraction rows 4 q .. 4 q + 3 x columns
 // 128 ch .. 128 ch + 127 as eight [4 n][16 columns] blocks of 128 bytes -- the block a 16-lane group of ds_read_b64_tr_b16 reads
@@ -1052,11 +1036,12 @@ DEVFN void gemm_b16mc_dma_body(unsigned short* const S, GemmOperand16B A, GemmOp
       for (int q = 0; q < 4; q++) acc[i][j][q] = 0.0f;
   // fragment role: lane group g = lane >> 4 reads n-quad g (first read) / 4 + g (second) of strip j: unit (j >> 3, quad),
   // position ((j & 7) + (g & 1)) & 7, piece lane & 15
+  // (ds_read_b64_tr_b16 as inline asm: beside pending DMA the builtin costs an s_waitcnt vmcnt(0) per block, devintrin.h)
   const int fg = lane >> 4;
   const int f_base = fg * UNIT + (lane & 15) * 4;            // halfs; + (j >> 3) * 8 UNIT + position * 64; second read + 4 UNIT
   auto frag = [&](const unsigned short* img, const int j) -> u16x8 {
-    const unsigned short* p = img + f_base + (j >> 3) * (8 * UNIT) + ((((j & 7) + (fg & 1)) & 7) << 6);
-    return join_u16x8(lds_read_tr16(p), lds_read_tr16(p + 4 * UNIT));
+    const LdsAddr p = lds_addr(img + f_base + (j >> 3) * (8 * UNIT) + ((((j & 7) + (fg & 1)) & 7) << 6));
+    return join_u16x8(lds_read_tr16_raw<0>(p), lds_read_tr16_raw<4 * UNIT * 2>(p));
   };
   dma(0, 0);
   dma(1, 1);
@@ -1103,12 +1088,31 @@ __global__ __launch_bounds__(512, 2) void gemm_b16mc_dma_kernel(GemmOperand16B A
   gemm_b16mc_dma_body<FE, WI>(S, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
                               gridDim.x, gridDim.y, gridDim.z);
 }
-// (Round 5, measured and not kept: this product with its tiles brought in by LDS-DMA like gemm_b16kk_dma_kernel.  Two LDS images
-// were tried at 1544 x 2048 x 25600, two slabs: the strips of gemm_b16mc_kernel, one DMA instruction per strip -- 32 bytes of each
-// of 32 contraction rows, quarter lines: 522 us against 281 us register-staged; and a row-major [32 n][256] image filled in whole
-// 512-byte rows, chunk c of row n at position c ^ 2 (n & 7), read by ds_read_b64_tr_b16 through per-lane addresses: 481 us -- the
-// transpose read has bank classes of its own that an address swizzle does not cure (guide, T10).  profiles/r05_gemm_variants.txt;
-// the kernels are in the history.  The contraction-major product keeps its register-staged, staggered loop.)
+// ---- the weight gradient and the input deltas of a wide layer as ONE launch (round 5) --------------------------------------------
+// Both depend on the layer's backward recurrence and on nothing else; apart, each leaves a quarter of the chip idle: the
+// weight-gradient product of the upper configs[4] layer is 96 tiles x 2 slabs = 192 workgroups of 400 blocks on 256 CUs, x.d
+// 400 tiles of 128 blocks = two rounds, the second 56 % full (656 block-times end to end).  One grid -- the long weight-gradient
+// workgroups first, the x.d tiles behind them, taken by whichever CU comes free -- needs ~500 + the tail.  Roles by block index
+// (wave-uniform); ONE LDS array serves both bodies.
+template <class FEW, int WI, class FEX, bool WDMA>   // WDMA: the weight-gradient role's tiles by LDS-DMA too (gemm_b16mc_dma_body)
+__global__ __launch_bounds__(512, 2) void gemm_dw_dx_kernel(GemmOperand16B A, GemmOperand16B B, FEW few, int R, int Cn, int K, int ksplit, int nsplit,
+                                                            GemmOperand16B A2, int a2_rows, unsigned gxw, unsigned gyw, unsigned gzw,
+                                                            GemmOperand16 XA, GemmOperand16 XB, FEX fex, int XR, int XCn, int XK, unsigned gxx, unsigned gyx) {
+  constexpr int MC_HALFS = GmcSmem<WI, 1>::A + GmcSmem<WI, 1>::B;
+  static_assert(GMD_SMEM_HALFS == GKD_SMEM_HALFS, "one 96 KB array serves both DMA bodies");
+  __shared__ __attribute__((aligned(1024))) unsigned short S[MC_HALFS > GKD_SMEM_HALFS ? MC_HALFS : GKD_SMEM_HALFS];
+  const unsigned nw = gxw * gyw * gzw;
+  if (blockIdx.x < nw) {
+    if constexpr (WDMA) gemm_b16mc_dma_body<FEW, WI>(S, A, B, few, R, Cn, K, ksplit, nsplit, A2, a2_rows, blockIdx.x, gxw, gyw, gzw);
+    else gemm_b16mc_body<FEW, WI, 1, true>(S, S + GmcSmem<WI, 1>::A, A, B, few, R, Cn, K, ksplit, nsplit, A2, a2_rows, blockIdx.x, gxw, gyw, gzw);
+  } else gemm_b16kk_dma_body<FEX>(S, XA, XB, fex, XR, XCn, XK, blockIdx.x - nw, gxx, gyx);
+}
+// (Round 5, on the way to gemm_b16mc_dma_kernel: its first three forms -- the strips of gemm_b16mc_kernel filled one DMA instruction
+// per strip, a row-major [32 n][256] image with XOR-permuted chunks, and the unit image above -- all ran 1.9x SLOWER than the
+// register-staged loop (522 / 481 / 533 vs 281 us at 1544 x 2048 x 25600, two slabs), whatever the image: hipcc had put
+// s_waitcnt vmcnt(0) in front of the first ds_read_b64_tr_b16 of every block -- it cannot see which LDS bytes the BUILTIN reads
+// and takes every pending DMA for its producer -- so the request pipeline drained at every block.  With the reads as inline asm
+// (devintrin.h:lds_read_tr16_raw) the unit image runs 240 us.  profiles/r05_gemm_variants.txt.)
 // 256 x 256 tiles where the problem is large enough and their padding costs at most 25 % more work than 128 x 128 tiles do:
 // the big tile runs ~1.4x faster per flop (1537 rows: 7 x 256 vs 13 x 128, + 8 %; 561 rows: 3 x 256 vs 5 x 128, + 20 %:
 // 98 vs 116 us for one direction of the first layer's weight gradient)
@@ -1138,7 +1142,7 @@ inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, F
     const int th = gemm_mc_tile_rows(R);
     dim3 grid((Cn + 255) / 256, (R + th - 1) / th, nsplit * nbatch);
     if (a2_rows % th != 0) A2.p = nullptr;
-    const bool dma_ok = stag == 3 && (A.ld & 7) == 0 && (B.ld & 7) == 0 && (A.bstride & 7) == 0 && (B.bstride & 7) == 0 && (!A2.p || (A2.ld & 7) == 0) &&
+    const bool dma_ok = stag >= 2 && (A.ld & 7) == 0 && (B.ld & 7) == 0 && (A.bstride & 7) == 0 && (B.bstride & 7) == 0 && (!A2.p || (A2.ld & 7) == 0) &&
                         ksplit >= 2 * GB_BK && ksplit % GB_BK == 0 && (((size_t)A.p | (size_t)B.p | (size_t)A2.p) & 15) == 0;
     if (dma_ok) {   // operand tiles by LDS-DMA (16-byte aligned chunks, slabs of whole blocks)
       if (th == 192) CLSTM_LAUNCH((gemm_b16mc_dma_kernel<FE, 6>), grid, dim3(512), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
@@ -1171,8 +1175,13 @@ inline bool gemm_dw_dx(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, F
   if (a2_rows % th != 0) A2.p = nullptr;
   const unsigned gxw = (Cn + 255) / 256, gyw = (R + th - 1) / th, gzw = nsplit * nbatch, gxx = (XCn + 255) / 256, gyx = (XR + 255) / 256;
   const dim3 grid(gxw * gyw * gzw + gxx * gyx);
-  if (th == 192) CLSTM_LAUNCH((gemm_dw_dx_kernel<FEW, 6, FEX>), grid, dim3(512), 0, stream, A, B, few, R, Cn, K, ksplit, nsplit, A2, a2_rows, gxw, gyw, gzw, XA, XB, fex, XR, XCn, XK, gxx, gyx);
-  else CLSTM_LAUNCH((gemm_dw_dx_kernel<FEW, 8, FEX>), grid, dim3(512), 0, stream, A, B, few, R, Cn, K, ksplit, nsplit, A2, a2_rows, gxw, gyw, gzw, XA, XB, fex, XR, XCn, XK, gxx, gyx);
+  const bool wdma = (A.ld & 7) == 0 && (B.ld & 7) == 0 && (A.bstride & 7) == 0 && (B.bstride & 7) == 0 && (!A2.p || (A2.ld & 7) == 0) &&
+                    ksplit >= 2 * GB_BK && ksplit % GB_BK == 0 && (((size_t)A.p | (size_t)B.p | (size_t)A2.p) & 15) == 0;
+#define CLSTM_DWDX(WI_, WD_) CLSTM_LAUNCH((gemm_dw_dx_kernel<FEW, WI_, FEX, WD_>), grid, dim3(512), 0, stream, A, B, few, R, Cn, K, ksplit, nsplit, A2, a2_rows, \
+                                          gxw, gyw, gzw, XA, XB, fex, XR, XCn, XK, gxx, gyx)
+  if (th == 192) { if (wdma) CLSTM_DWDX(6, true); else CLSTM_DWDX(6, false); }
+  else { if (wdma) CLSTM_DWDX(8, true); else CLSTM_DWDX(8, false); }
+#undef CLSTM_DWDX
   return true;
 }
 

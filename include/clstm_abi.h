@@ -306,6 +306,10 @@ int clstm_debug_gemm(int mode, const float* A, const float* B, float* C, int R, 
  * launch (W_x producers + recurrence + softmax consumers, lstm_fwd_fused.h).  Tests use it to make sure the
  * path they mean to cover is the one that ran. */
 int clstm_debug_path_count(int which, long long* out_h);
+/* Experiment switches of the library (clstm_amd/csrc/dbgopt.h: kept kernels against measured losers, e.g. "gemm_stag", "bwd_c32",
+ * "rec_x3", "pack_tiles"): tests compare the two sides bit for bit within one process.  name NULL: forget every option.  Whole
+ * programs: environment CLSTM_DEBUG="name=value,...".  Not product settings. */
+int clstm_debug_set_option(const char* name, int value);
 /* (tests) set a device error word: which = 0 the outcome word of the persistent recurrences, 1 the count of weight-gradient
  * items that gave up waiting.  While either is non-zero clstm_net_update() applies nothing; the next synchronisation
  * point (clstm_synchronize, any *_h read-back) reports the error and clears the words. */

@@ -1,7 +1,7 @@
 #!/bin/bash
 # configs[4] A/B on the GPU: a pytest selection first (parity before speed), then bench.py --config b2 --bf16 under each of the
 # environment settings given as arguments ("-" = none).
-# Usage: gpurun --timeout 900 -- 'bash scripts/gpu_b2ab.sh TAG "pytest -k expr" - CLSTM_FUSE_WX=0 ...'
+# Usage: gpurun --timeout 900 -- 'bash scripts/gpu_b2ab.sh TAG "pytest -k expr" - CLSTM_DEBUG=fuse_wx=0 ...'
 TAG=$1; KEXPR=$2; shift 2
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd "$ROOT"; OUT="$ROOT/gpurun_out/$TAG"; mkdir -p "$OUT"
 python -c "from oracle.oracle import build; build()" > "$OUT/oracle_build.log" 2>&1

@@ -18,10 +18,10 @@ PY
 }
 for MB in 64 256; do
   for C in 0 1; do
-    CLSTM_BWD_C32=$C B --minibatch $MB > "$OUT/b2_mb${MB}_c32_$C.json" 2> "$OUT/b2_mb${MB}_c32_$C.err"; show "$OUT/b2_mb${MB}_c32_$C.json" "mb=$MB CLSTM_BWD_C32=$C"
+    CLSTM_DEBUG=bwd_c32=$C B --minibatch $MB > "$OUT/b2_mb${MB}_c32_$C.json" 2> "$OUT/b2_mb${MB}_c32_$C.err"; show "$OUT/b2_mb${MB}_c32_$C.json" "mb=$MB CLSTM_DEBUG=bwd_c32=$C"
   done
 done
 for C in 0 1; do
-  echo "=== stamps, CLSTM_BWD_C32=$C"
-  CLSTM_BWD_C32=$C CLSTM_HIP_VARIANT=prof timeout 300 python scripts/gpu_xcdprof.py 2>&1 | grep -A 12 -E "^backward|^forward" | tee "$OUT/xcd_phase_cycles_c32_$C.txt"
+  echo "=== stamps, CLSTM_DEBUG=bwd_c32=$C"
+  CLSTM_DEBUG=bwd_c32=$C CLSTM_HIP_VARIANT=prof timeout 300 python scripts/gpu_xcdprof.py 2>&1 | grep -A 12 -E "^backward|^forward" | tee "$OUT/xcd_phase_cycles_c32_$C.txt"
 done

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd "$ROOT"; OUT="$ROOT/gpurun_out/$TAG"; mk
 python -c "from oracle.oracle import build; build()" > "$OUT/oracle_build.log" 2>&1
 timeout 300 python scripts/gpu_gemm_r5.py 5 > "$OUT/gemm_r5.txt" 2>&1; cat "$OUT/gemm_r5.txt" | tail -12
 for st in 0 1; do
-  CLSTM_GEMM_STAG=$st timeout 200 python bench.py --config b2 --bf16 --steps 10 --warmup 3 --profile-steps 3 > "$OUT/bench_b2_bf16_stag$st.json" 2>/dev/null
+  CLSTM_DEBUG=gemm_stag=$st timeout 200 python bench.py --config b2 --bf16 --steps 10 --warmup 3 --profile-steps 3 > "$OUT/bench_b2_bf16_stag$st.json" 2>/dev/null
   python - "$OUT/bench_b2_bf16_stag$st.json" $st <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

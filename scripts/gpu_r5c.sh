@@ -7,7 +7,7 @@ python -c "from oracle.oracle import build; build()" > "$OUT/oracle_build.log" 2
 timeout 300 python scripts/gpu_gemm_r5.py 5 > "$OUT/gemm_r5.txt" 2>&1; tail -12 "$OUT/gemm_r5.txt"
 for cfg in "2 1" "1 1"; do
   set -- $cfg
-  CLSTM_GEMM_STAG=$1 CLSTM_FWD_LATE=$2 timeout 200 python bench.py --config b2 --bf16 --steps 10 --warmup 3 --profile-steps 3 > "$OUT/bench_b2_bf16_stag$1_late$2.json" 2>/dev/null
+  CLSTM_DEBUG=gemm_stag=$1 timeout 200 python bench.py --config b2 --bf16 --steps 10 --warmup 3 --profile-steps 3 > "$OUT/bench_b2_bf16_stag$1_late$2.json" 2>/dev/null
   python - "$OUT/bench_b2_bf16_stag$1_late$2.json" "$cfg" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

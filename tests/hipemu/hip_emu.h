@@ -217,6 +217,10 @@ inline u32x2 lds_read_tr16(const unsigned short* p) {
   memcpy(&out, r, 8);
   return out;
 }
+typedef const char* LdsAddr;
+inline LdsAddr lds_addr(const void* p) { return static_cast<const char*>(p); }
+inline LdsAddr lds_addr_add(LdsAddr a, int bytes) { return a + bytes; }
+template <int OFF> inline u32x2 lds_read_tr16_raw(LdsAddr a) { return lds_read_tr16(reinterpret_cast<const unsigned short*>(a + OFF)); }
 inline u16x8 join_u16x8(u32x2 a, u32x2 b) {
   u16x8 r;
   memcpy(&r.v[0], &a, 8);

@@ -43,7 +43,7 @@ def oracle_after(ora32, nsteps, world):
 
 def worker(rank, world, port, outdir, use_lib_comm, slow_rank0_s=0.0, sabotage=False):
     if slow_rank0_s:
-        os.environ["CLSTM_PEER_DEVICE_TIMEOUT_S"] = "1"      # far below the time rank 0 stays away: the HOST wait must cover it
+        os.environ["CLSTM_PEER_TIMEOUT_S"] = "1"      # far below the time rank 0 stays away: the HOST wait must cover it
     os.environ["CLSTM_REPLICA_CHECK_EVERY"] = "1" if use_lib_comm else "0"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -198,7 +198,7 @@ def gpu_worker(rank, world, port, outdir, share_device=False, one_call=False, sl
     if share_device:
         os.environ["CLSTM_COMM_NO_RCCL"] = "1"
     if slow_rank0_s:
-        os.environ["CLSTM_PEER_DEVICE_TIMEOUT_S"] = "5"
+        os.environ["CLSTM_PEER_TIMEOUT_S"] = "5"
     os.environ["CLSTM_REPLICA_CHECK_EVERY"] = "1"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

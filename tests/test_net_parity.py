@@ -15,6 +15,21 @@ STATES = ("gi", "gf", "go", "ci", "state", "outputs")
 DELTAS = ("d_gi", "d_gf", "d_go", "d_ci")
 
 
+def set_opt(backend, name, value):
+    """experiment switch of the library (clstm_amd/csrc/dbgopt.h), reset after every test by the fixture below"""
+    backend.lib.call("clstm_debug_set_option", name.encode(), int(value))
+
+
+@pytest.fixture(autouse=True)
+def _forget_debug_options(request):
+    yield
+    if "backend" in request.fixturenames:
+        try:
+            request.getfixturevalue("backend").lib.call("clstm_debug_set_option", None, 0)
+        except Exception:     # noqa: BLE001
+            pass
+
+
 def run_case(backend, ora32, ni, nh, nc, T, uni=False, scale=30.0, seed=1, lr=1e-2, check_dx=False,
              ctc_rtol=1e-4, grad_tol=1e-4, overlap=None):
     from clstm_amd.net import Network
@@ -334,7 +349,7 @@ def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatc
     if nh == [32, 32]:
         # sized so that every optional bf16 fast path is eligible even on the emulator's 16 CUs: persistent per-XCD
         # recurrences (two cell tiles per direction), W_x.x from the lower layer's bf16 outputs (since round 4 inside the
-        # persistent forward kernel, path 6; as a product of its own, path 2, with CLSTM_FUSE_WX=0), x.d from the bf16 delta
+        # persistent forward kernel, path 6; as a product of its own, path 2, with fuse_wx = 0 (dbgopt.h)), x.d from the bf16 delta
         # array, and the weight gradient from contraction-major bf16 operands through the LDS transpose reads
         assert all(t > 0 for t in took[:2] + took[3:5]) and took[2] + took[6] > 0, took
 
@@ -343,7 +358,7 @@ def test_bf16_lockstep_recurrence_tracks_the_f32_path(backend, ora32, monkeypatc
                          ids=["eight_line_groups", "three_groups", "sixteen_line_groups", "thirty_two_line_groups"])
 def test_backward_recurrence_with_32_cells_per_workgroup_is_bit_identical(backend, ora32, monkeypatch, nh, nlines):
     """lstm_xcd_bwd_bf16_c32 (round 4: 32 cells per workgroup, two groups per XCD, groups of 8 / 16 / 32 lines -- half the
-    delta block per step and CU) against lstm_xcd_bwd_bf16 (CLSTM_BWD_C32=0): same k split over the waves, same MFMA order,
+    delta block per step and CU) against lstm_xcd_bwd_bf16 (bwd_c32 = 0, dbgopt.h): same k split over the waves, same MFMA order,
     same cross-wave sum -- the gradient and the stored deltas must be IDENTICAL, ragged lines and a half-empty last group
     included."""
     from clstm_amd.net import Network
@@ -356,7 +371,7 @@ def test_backward_recurrence_with_32_cells_per_workgroup_is_bit_identical(backen
     trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("CLSTM_BWD_C32", mode)
+        set_opt(backend, "bwd_c32", mode)
         before = _path_count(backend, 9)
         net = Network(ni, nh, nc, lib=backend.lib)
         net.set_params(params)
@@ -395,7 +410,7 @@ def test_backward_32_cells_dense_eight_line_loads_on_a_larger_emulated_chip(ora3
             trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
             got = {}
             for mode in ("1", "0"):
-                os.environ["CLSTM_BWD_C32"] = mode
+                backend.lib.call("clstm_debug_set_option", b"bwd_c32", int(mode))
                 c0 = count()
                 net = Network(ni, nh, nc, lib=backend.lib); net.set_params(params); net.set_gemm_precision(2)
                 net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
@@ -413,7 +428,7 @@ def test_f32_grade_backward_recurrence_on_the_bf16_mfma(backend, ora32, monkeypa
     """Round 4: in exact-f32 mode the persistent BACKWARD recurrence of a wide layer runs as an f32-grade x3 product on the bf16
     MFMA -- gate deltas and recurrent weights as hi + lo bf16 terms, hi.hi + hi.lo + lo.hi accumulated in f32
     (lstm_wide.h:lstm_xcd_bwd_x3), like the backward GEMMs of this mode.  The forward pass is untouched (bit-identical to
-    CLSTM_REC_X3=0); the gradient: against the oracle at the bar of the other wide-layer tests, against the f32 MFMA kernel
+    rec_x3 = 0 (dbgopt.h)); the gradient: against the oracle at the bar of the other wide-layer tests, against the f32 MFMA kernel
     within the x3 products' 2^-16."""
     from clstm_amd.net import Network
     monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
@@ -426,7 +441,7 @@ def test_f32_grade_backward_recurrence_on_the_bf16_mfma(backend, ora32, monkeypa
     want = oracle_minibatch(ora32, OracleNet, params, ni, nh, nc, lines, trs, states=[], lr=1e-3, mom=0.9)
     res = {}
     for m in ("1", "0"):
-        monkeypatch.setenv("CLSTM_REC_X3", m)
+        set_opt(backend, "rec_x3", m)
         c11 = _path_count(backend, 11)
         net = Network(ni, nh, nc, lib=backend.lib)
         net.set_params(params)
@@ -457,7 +472,7 @@ def test_unidirectional_wide_layer_takes_the_round4_backward_kernels(backend, mo
     params = None
     got = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("CLSTM_BWD_C32", mode); monkeypatch.setenv("CLSTM_REC_X3", mode)
+        set_opt(backend, "bwd_c32", mode); set_opt(backend, "rec_x3", mode)
         which = 9 if precision == 2 else 11
         before = _path_count(backend, which)
         net = Network(ni, nh, nc, unidirectional=True, lib=backend.lib)
@@ -485,7 +500,7 @@ def test_lazy_f32_source_columns_match_the_eager_build(backend):
     """Upper layers whose weight gradient reads the bf16 source rows skip the f32 [1 | x] source columns in the forward pass
     and build them on demand (ensure_source_x).  Forward at precision 2, backward at precision 1 (f32 recurrence, f32-source
     weight-gradient GEMM: needs those columns): the gradient must be bit-identical to a process in which the columns were
-    built eagerly (CLSTM_GEMM_B16MC=0).  The switch is read once per process, hence the subprocesses."""
+    built eagerly (gemm_b16mc = 0, dbgopt.h).  The switch is read once per process, hence the subprocesses."""
     import subprocess, sys, json
     if backend.kind != "emu":
         pytest.skip("host-logic check, run on the emulator")
@@ -493,7 +508,7 @@ def test_lazy_f32_source_columns_match_the_eager_build(backend):
 import os, sys, json, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 os.environ["CLSTM_FORCE_WIDE"] = "1"
-os.environ["CLSTM_FUSE_WX"] = "0"    # (the fused input projection sums in another order than hoisted product + recurrence: not what is compared here)
+os.environ["CLSTM_DEBUG"] = os.environ.get("CLSTM_DEBUG", "") + ",fuse_wx=0"    # (the fused input projection sums in another order than hoisted product + recurrence: not what is compared here)
 import common
 from clstm_amd.net import Network
 lib = common.emu_lib()
@@ -521,7 +536,7 @@ print(json.dumps([float(np.abs(g.astype(np.float64)).sum()), int(g.size)]))
     import tempfile
     arrays = []
     with tempfile.TemporaryDirectory() as tmp:
-        for k, extra in enumerate(({"CLSTM_GEMM_B16MC": "1"}, {"CLSTM_GEMM_B16MC": "0"}, {"CLSTM_XCD_REC": "0"})):
+        for k, extra in enumerate(({"CLSTM_DEBUG": "gemm_b16mc=1"}, {"CLSTM_DEBUG": "gemm_b16mc=0"}, {"CLSTM_XCD_REC": "0"})):
             env = dict(os.environ, **extra)
             out = os.path.join(tmp, "run%d.npy" % k)
             r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests")), out], env=env, capture_output=True, text=True, timeout=600)
@@ -541,7 +556,7 @@ print(json.dumps([float(np.abs(g.astype(np.float64)).sum()), int(g.size)]))
 def test_input_projection_inside_the_persistent_forward_kernel(backend, ora32, monkeypatch, ni, nh, T):
     """Round 4: in bf16 mode the persistent forward recurrence of a wide layer computes W_x.x itself, in the shadow of the
     group hand-off (lstm_wide.h:lstm_xcd_fwd_bf16_fx) -- no hoisted product, no pre-activation array.  Same bf16 products and
-    f32 accumulation as the hoisted form (CLSTM_FUSE_WX=0), only the order of the f32 additions differs: every saved
+    f32 accumulation as the hoisted form (fuse_wx = 0 (dbgopt.h)), only the order of the f32 additions differs: every saved
     activation, the outputs and the gradient agree to 2e-5 relative (+ 2e-6 / 1e-5 of the largest entry), decodes equal; and the
     fused path must really have run."""
     from clstm_amd.net import Network
@@ -553,7 +568,7 @@ def test_input_projection_inside_the_persistent_forward_kernel(backend, ora32, m
     trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
     res = []
     for fuse in ("2", "0"):                       # 2: every eligible layer (the default fuses layers of up to 128 inputs), 0: hoisted product
-        monkeypatch.setenv("CLSTM_FUSE_WX", fuse)
+        set_opt(backend, "fuse_wx", fuse)
         before = _path_count(backend, 6)
         net = Network(ni, nh, nc, lib=backend.lib)
         net.set_params(params)
@@ -584,9 +599,9 @@ def test_persistent_recurrence_placement_fallback(backend, ora32, monkeypatch, p
     from clstm_amd.net import Network
     monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
     monkeypatch.setenv("CLSTM_XCD_REC", "1")
-    f32_mfma = precision == -1      # CLSTM_REC_X3=0: the persistent f32 kernels on the f32 MFMA (same tile and split-K order as the
+    f32_mfma = precision == -1      # rec_x3 = 0 (dbgopt.h): the persistent f32 kernels on the f32 MFMA (same tile and split-K order as the
     if f32_mfma:                    #   per-step launches -> bit-identical); default: the backward recurrence as an f32-grade x3 product on the bf16 MFMA
-        monkeypatch.setenv("CLSTM_REC_X3", "0")
+        set_opt(backend, "rec_x3", 0)
         precision = 0
     rng = np.random.default_rng(41)
     ni, nh, nc, T = 12, [32, 32], 6, [9, 5, 7, 3]
@@ -664,7 +679,7 @@ def test_persistent_recurrence_placement_fallback(backend, ora32, monkeypatch, p
 def test_tiled_weight_pack_equals_the_single_purpose_kernels(backend, ora32, monkeypatch):
     """Round 4: in bf16 mode a wide layer's packed copies (Wt, bias, Wtb, WtbT, Rbf, Rbb) come from ONE tiled pass over its
     parameters (ops.h:k_pack_wide_tiles) instead of five gather kernels.  Same copies, so everything computed from them is
-    BIT-identical to a run on the old kernels (CLSTM_PACK_TILES=0): outputs, saved activations, gradient -- for a first
+    BIT-identical to a run on the old kernels (pack_tiles = 0, dbgopt.h): outputs, saved activations, gradient -- for a first
     layer (32 inputs) and an upper layer (256 inputs), both directions."""
     from clstm_amd.net import Network
     monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
@@ -675,7 +690,7 @@ def test_tiled_weight_pack_equals_the_single_purpose_kernels(backend, ora32, mon
     trs = [rng.integers(1, nc, 1).astype(np.int32) for _ in T]
     res = []
     for tiles in ("1", "0"):
-        monkeypatch.setenv("CLSTM_PACK_TILES", tiles)
+        set_opt(backend, "pack_tiles", tiles)
         net = Network(ni, nh, nc, lib=backend.lib)
         net.set_params(params)
         net.set_gemm_precision(2)
@@ -737,14 +752,14 @@ def _merged_launch_case(backend, ora32):
     trs = [rng.integers(1, nc, 5).astype(np.int32) for _ in T]
     res = []
     for stag in ("2", "1"):
-        os.environ["CLSTM_GEMM_STAG"] = stag
+        backend.lib.call("clstm_debug_set_option", b"gemm_stag", int(stag))
         net = Network(ni, nh, nc, lib=backend.lib)
         net.set_params(params)
         net.set_gemm_precision(2)
         before = _path_count(backend, 14)
         net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
         res.append((net.get_grads(), net.state(0, 0, "d_gi"), _path_count(backend, 14) - before))
-    os.environ.pop("CLSTM_GEMM_STAG", None)
+    backend.lib.call("clstm_debug_set_option", None, 0)
     assert res[0][2] == 1 and res[1][2] == 0, (res[0][2], res[1][2])       # the upper layer took the merged launch / did not
     assert np.array_equal(res[0][0], res[1][0])
     assert np.array_equal(res[0][1], res[1][1])
@@ -756,7 +771,7 @@ def test_weight_gradient_and_input_deltas_as_one_launch(backend, ora32, monkeypa
     """Round 5: a wide layer's weight-gradient product (contraction-major bf16 operands, bias row outside) and its input deltas
     (k-contiguous bf16 operands, tiles by LDS-DMA) run as ONE launch of two workgroup roles (gemm_dw_dx_kernel) where both fill
     the big tiles -- apart, each leaves a quarter of the configs[4] chip idle.  Same kernel bodies, same operands: the gradient
-    and the lower layer's deltas must be BIT-identical to the two separate launches (CLSTM_GEMM_STAG=1: register-staged tiles,
+    and the lower layer's deltas must be BIT-identical to the two separate launches (gemm_stag = 1, dbgopt.h: register-staged tiles,
     no merged launch), and the path must have run.  (A 64-cell layer needs 32 persistent workgroups: on the emulator a child
     process with 48 emulated CUs.)"""
     monkeypatch.setenv("CLSTM_FORCE_WIDE", "1")
