@@ -2,7 +2,7 @@
 TAG=${1:-r5g}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd "$ROOT"; OUT="$ROOT/gpurun_out/$TAG"; mkdir -p "$OUT"
 python -c "from oracle.oracle import build; build()" > "$OUT/oracle_build.log" 2>&1
-for st in 2 1; do
+for st in 2; do
 CLSTM_DEBUG=gemm_stag=$st timeout 200 python bench.py --config b2 --bf16 --steps 10 --warmup 3 --profile-steps 3 > "$OUT/bench_b2_bf16_stag$st.json" 2> "$OUT/bench_b2_bf16.err"
 python - "$OUT/bench_b2_bf16_stag$st.json" $st <<'PY'
 import json, sys
