@@ -245,6 +245,9 @@ DEVFN void lds_dma16(BufF32 b, unsigned byte_off, void* lds_wave_base) {
 template <int N> DEVFN void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 DEVFN void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 DEVFN void wg_barrier() { __builtin_amdgcn_s_barrier(); }   // bare s_barrier: no implied waits
+// lanes of ONE wave exchanging data through LDS: the wave executes in lock-step and its LDS operations complete in order, so the
+// hardware needs nothing but the compiler's own lgkmcnt wait (the host emulator runs lanes as fibers: a real rendezvous there)
+DEVFN void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 // lane offset (VGPR, bounds-checked) + wave-uniform offset (SGPR, NOT part of the bounds check of a raw
 // buffer): no VALU add per access, and a lane parked at BUF_OOB_BASE stays out of range
 DEVFN float buf_load_s(BufF32 b, unsigned lane_off, unsigned uniform_off) {

@@ -669,6 +669,41 @@ __global__ __launch_bounds__(64 * WI, 2) void gemm_b16kk_kernel(GemmOperand16 A,
 // fragment reads of block t have returned.  Every wave waits for its own requests of block t + 1 in front of the barrier that
 // precedes group A's reads of it (vmcnt(4): the four requests of block t + 2 may still be in flight).  K % 32 == 0 (a DMA
 // cannot mask a contraction tail); rows past the operand read zeros (the descriptor ends at the last row).
+// Epilogue of the LDS-DMA kernels (eight waves of 128 x 64, accumulators transposed as in gb2_store) THROUGH LDS: a lane's
+// accumulator registers are four columns of sixteen different rows, so a direct store instruction writes sixteen 64-byte
+// pieces -- half cache lines; 4,096 of them per 256 x 256 tile, and the 419 MB of pre-activations of a configs[4] layer left
+// the chip in half lines (halving the BYTES with bf16 outputs bought 13 us of 281: it is the pieces that cost,
+// profiles/r05_gemm_variants.txt).  Here a wave lays two 16-row strips (32 rows x 64 columns) into its own 8.5 KB of the
+// now idle operand buffers (row stride 68 floats: conflict-free both ways) and reads them back row-wise: a store instruction
+// then writes four rows x 256 contiguous bytes -- whole lines.  No barrier: the region is the wave's own.
+constexpr int GKD_EPI_LD = 68, GKD_EPI_FLOATS = 32 * GKD_EPI_LD;   // per wave
+template <class FE, int WI>
+DEVFN void gb2_store_lds(float* const epi, const FE& fe, const f32x4 (&acc)[WI][4], const int rw, const int cw, const int lane, const int R, const int Cn, const int z) {
+  static_assert(WI % 2 == 0, "two strips per pass");
+#pragma unroll
+  for (int p = 0; p < WI / 2; p++) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4*>(&epi[(ii * 16 + (lane & 15)) * GKD_EPI_LD + j * 16 + (lane >> 4) * 4]) = acc[2 * p + ii][j];
+    wave_lds_fence();   // (the rows this lane reads were written by other lanes of its wave)
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int rl = 4 * q + (lane >> 4), cl = (lane & 15) * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&epi[rl * GKD_EPI_LD + cl]);
+      const int r = rw + p * 32 + rl, c = cw + cl;
+      if (r < R) {
+        if (c + 3 < Cn) fe.row4(r, c, v, z);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (c + e < Cn) fe(r, c + e, v[e], z);
+        }
+      }
+    }
+    wave_lds_fence();   // (... and the next pass overwrites them)
+  }
+}
 constexpr int GKD_SMEM_HALFS = 3 * 2 * 256 * GB2_LDH;   // three buffers of A | B: 96 KB
 // S: ONE LDS array [buffer][A rows | B rows][32 k]; lin, gx, gy: this workgroup's index in the product's gx x gy tile grid
 template <class FE>
@@ -752,7 +787,11 @@ DEVFN void gemm_b16kk_dma_body(unsigned short* const S, GemmOperand16 A, GemmOpe
   }
   if (wm == 0) wg_barrier();
   wait_vmcnt<0>();                 // (the two requests past the end)
-  gb2_store<FE, WI>(fe, acc, r0 + wm * 128, c0 + wn * 64, lane, R, Cn, 0);
+  if (fe.vec4()) {
+    wg_barrier();                  // ... everybody's: the operand buffers are free
+    static_assert(8 * GKD_EPI_FLOATS * 2 <= GKD_SMEM_HALFS, "epilogue regions fit the operand buffers");
+    gb2_store_lds<FE, WI>(reinterpret_cast<float*>(S) + wave * GKD_EPI_FLOATS, fe, acc, r0 + wm * 128, c0 + wn * 64, lane, R, Cn, 0);
+  } else gb2_store<FE, WI>(fe, acc, r0 + wm * 128, c0 + wn * 64, lane, R, Cn, 0);
 }
 template <class FE>
 __global__ __launch_bounds__(512, 2) void gemm_b16kk_dma_kernel(GemmOperand16 A, GemmOperand16 B, FE fe, int R, int Cn, int K) {
@@ -1078,7 +1117,10 @@ DEVFN void gemm_b16mc_dma_body(unsigned short* const S, GemmOperand16B A, GemmOp
   }
   if (wm == 0) wg_barrier();
   wait_vmcnt<0>();
-  gb2_store<FE, WI>(fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, z);
+  if (fe.vec4()) {   // (whole-line stores through LDS: gb2_store_lds)
+    wg_barrier();
+    gb2_store_lds<FE, WI>(reinterpret_cast<float*>(S) + wave * GKD_EPI_FLOATS, fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, z);
+  } else gb2_store<FE, WI>(fe, acc, r0 + wm * (16 * WI), c0 + wn * 64, lane, R, Cn, z);
 }
 constexpr int GMD_SMEM_HALFS = 3 * 2 * 16 * 512;   // 96 KB
 template <class FE, int WI>

@@ -255,6 +255,7 @@ inline void lds_dma16(BufF32 b, unsigned off, void* lds_wave_base) {
 template <int N> inline void wait_vmcnt() {}
 inline void wait_lgkmcnt0() {}
 inline void wg_barrier() { __syncthreads(); }
+inline void wave_lds_fence() { emu_wave_sync(); }
 inline float buf_load_s(BufF32 b, unsigned lane_off, unsigned uni) { return ((size_t)lane_off + 4 <= b.bytes) ? b.base[(lane_off + uni) / 4] : 0.0f; }
 inline void buf_store_s(BufF32 b, unsigned lane_off, unsigned uni, float v) { if ((size_t)lane_off + 4 <= b.bytes) b.base[(lane_off + uni) / 4] = v; }
 inline void buf_store4(BufF32 b, unsigned off, f32x4 v) { for (int i = 0; i < 4; i++) buf_store(b, off + 4 * i, v[i]); }
