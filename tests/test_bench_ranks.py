@@ -38,7 +38,7 @@ def test_bench_rank_body_world2_on_the_emulator(how):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
     assert out["scaling"] == "weak" and out["higher_is_better"] is True
     assert out["config"]["global_minibatch"] == 4 and out["config"]["parallelism"] == "dp2"
-    assert out["value"] > 0 and abs(out["value"] - 4 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-3   # whole-job lines/s
+    assert out["value"] > 0 and abs(out["value"] - 4 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-2   # whole-job lines/s (both figures are rounded in the JSON)
     ar = out["allreduce"]
     assert ar["ranks"] == 2 and ar["bytes"] == 4 * 135883
     assert "peer-read" in ar["impl"]                           # the one-call step ran the fused exchange, not a fallback
