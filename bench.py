@@ -388,7 +388,9 @@ def main():
                     help="frames start in pinned HOST memory every step (clstm_net_train_step_h): the PCIe-inclusive rate, "
                          "not the headline `value` (bench contract: inputs resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[4] leg of the default line")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="the headline workload only: skip the other legs of the default line (strict_f32, saturated, configs[4] in both precisions) -- "
+                         "what the rocprofv3 passes use, so that their per-kernel averages are the headline workload's")
     ap.add_argument("--profile-steps", type=int, default=None,
                     help="extra steps with per-kernel timing (events bound to each launch's dispatch packet); default 50 (b1) / 5 (b2)")
     args = ap.parse_args()
@@ -555,7 +557,7 @@ def main():
     # the same workload with EVERY product on the exact f32 MFMA (clstm_net_set_strict_f32: the default computes the backward
     # weight-gradient / softmax-backward products as f32-grade bf16 x 3 split products); default single-GPU line only
     strict = None
-    if rank == 0 and world == 1 and default_line:
+    if rank == 0 and world == 1 and default_line and not args.no_secondary:
         ws = Workload(lib, cfg, args.minibatch, args.T, args.ragged, 0, dev, rank, strict_f32=True)
         ms_ = measure(ws, args.steps, 5, 0, min_timed_s=0.5)
         strict = {"value": round(args.minibatch * args.steps / ms_["dt"], 2), "unit": "lines/s", "ms_per_step": round(ms_["dt"] / args.steps * 1e3, 4),
@@ -568,7 +570,7 @@ def main():
     # recurrence sits from a bandwidth bound); here the fused gate kernel is VALU-throughput-bound, and its fraction of the
     # HBM roof and of the packed-FMA rate is the "how far from the machine" number for the kernel itself.
     saturated = None
-    if rank == 0 and world == 1 and default_line:
+    if rank == 0 and world == 1 and default_line and not args.no_secondary:
         wsat = Workload(lib, cfg, 256, args.T, False, 0, dev, rank)
         ssat = max(5, min(args.steps, 20))
         msat = measure(wsat, ssat, 3, 20, unfused_pass=True, min_timed_s=0.5)
