@@ -1839,7 +1839,7 @@ struct CtcWorkspace {
   DevBuf<char> meta;
   DevBuf<float> lat;
 };
-// The per-minibatch metadata block [lat_off (bs+1 x i64) | line_off | state_off | states] is staged in a pinned slot;
+// The per-minibatch metadata block [line records | states] is staged in a pinned slot;
 // `defer` (non-null): do not enqueue its copy -- the caller folds it into a kernel it launches anyway before the CTC
 // kernel (the input-ingest launch of a training step) and receives source, destination and size here.
 struct CtcMetaCopy { const int* src = nullptr; int* dst = nullptr; int nwords = 0; };
@@ -1858,33 +1858,33 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
   const int ns = state_off_h[bs];
   for (int i = 0; i < ns; i++) REQUIRE(states_h[i] >= 0 && states_h[i] < nc, "target class out of range");
   w.lat.reserve((size_t)(lo[bs] > 0 ? lo[bs] : 1));
-  // one pinned slot, one device block, one copy: [lat_off (bs+1 x i64) | line_off | state_off | states | order]
-  const size_t nlo = (size_t)(bs + 1) * sizeof(long long), nio = (size_t)(bs + 1) * sizeof(int);
-  const size_t nst = (size_t)(ns > 0 ? ns : 1) * sizeof(int), nord = (size_t)bs * sizeof(int);
-  w.meta.reserve(nlo + 2 * nio + nst + nord);
+  // one pinned slot, one device block, one copy: [line records (bs x 32 bytes, in workgroup order) | states]
+  const size_t nln = (size_t)bs * sizeof(CtcLine), nst = (size_t)(ns > 0 ? ns : 1) * sizeof(int);
+  w.meta.reserve(nln + nst);
   {
-    char* stage = (char*)w.ring.acquire(nlo + 2 * nio + nst + nord);
-    memcpy(stage, lo.data(), nlo);
-    memcpy(stage + nlo, line_off_h, nio);
-    memcpy(stage + nlo + nio, state_off_h, nio);
-    if (ns > 0) memcpy(stage + nlo + 2 * nio, states_h, (size_t)ns * sizeof(int));
+    char* stage = (char*)w.ring.acquire(nln + nst);
     // workgroups take the lines largest lattice first (one workgroup per line; more lines than CUs run in rounds)
     std::vector<int> order(bs);
     for (int b = 0; b < bs; b++) order[b] = b;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return lo[x + 1] - lo[x] > lo[y + 1] - lo[y]; });
-    memcpy(stage + nlo + 2 * nio + nst, order.data(), nord);
+    CtcLine* ln = (CtcLine*)stage;
+    for (int i = 0; i < bs; i++) {
+      const int b = order[i];
+      ln[i] = CtcLine{lo[b], b, line_off_h[b], line_off_h[b + 1] - line_off_h[b], state_off_h[b], state_off_h[b + 1] - state_off_h[b], 0};
+    }
+    if (ns > 0) memcpy(stage + nln, states_h, (size_t)ns * sizeof(int));
     if (defer) {
-      defer->src = (const int*)stage; defer->dst = (int*)w.meta.p; defer->nwords = (int)((nlo + 2 * nio + nst + nord) / sizeof(int));
+      defer->src = (const int*)stage; defer->dst = (int*)w.meta.p; defer->nwords = (int)((nln + nst) / sizeof(int));
     } else {
-      HIPCHECK(hipMemcpyAsync(w.meta.p, stage, nlo + 2 * nio + nst + nord, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipMemcpyAsync(w.meta.p, stage, nln + nst, hipMemcpyHostToDevice, s));
       w.ring.commit(s);
     }
   }
   CtcArgs a{};
-  a.P = probs; a.Dz = deltas; a.aligned = aligned; a.line_off = (const int*)(w.meta.p + nlo);
-  a.states = (const int*)(w.meta.p + nlo + 2 * nio); a.state_off = (const int*)(w.meta.p + nlo + nio);
-  a.lat = w.lat.p; a.lat_off = (const long long*)w.meta.p; a.nc = nc;
-  a.order = (const int*)(w.meta.p + nlo + 2 * nio + nst);
+  a.lines = (const CtcLine*)w.meta.p;
+  a.P = probs; a.Dz = deltas; a.aligned = aligned;
+  a.states = (const int*)(w.meta.p + nln);
+  a.lat = w.lat.p; a.nc = nc;
   w.prof.reserve(16); a.prof = w.prof.p; g_last_ctc_prof = w.prof.p;
   if (!w.tables.p) {
     w.tables.reserve(CTC_TABLE_DOUBLES);

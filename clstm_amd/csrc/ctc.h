@@ -41,17 +41,22 @@ constexpr int CTC_SMAX_LDS = CTC_GROUP * CTC_RMAX;   // the per-state LDS arrays
 constexpr int CTC_MLP = 8;         // independent global loads a thread keeps in flight in the streaming phases
 constexpr int CTC_MLPT = 20;       // ... in the tile staging / write-out loops of the tiled path (a tile's frames of one wave at once)
 constexpr int CTC_MAX_TILE = 256;  // frames per LDS tile (phases A and E)
+#ifndef CLSTM_CTC_PD
+#define CLSTM_CTC_PD 8
+#endif
+constexpr int CTC_PD = CLSTM_CTC_PD;   // frames the one-wave lattice recursions request their match scores ahead
 
+// what a workgroup needs to know about its line, in ONE 32-byte record indexed by the workgroup: the kernel used to walk
+// order[] -> line_off[] / state_off[] / lat_off[] -> states / posteriors, three dependent trips to memory before its first
+// useful load; with the record it is two
+struct CtcLine { long long lat_off; int b, off, T, soff, S, pad; };
 struct CtcArgs {
+  const CtcLine* lines;  // [bs] per workgroup (largest lattice first)
   const float* P;        // [N][nc] softmax outputs
   float* Dz;             // [N][nc] out: aligned - P
   float* aligned;        // [N][nc] out (optional, may be null): alignment posteriors
-  const int* line_off;   // [bs+1]
-  const int* order;      // [bs] line of the b-th workgroup (largest lattice first), or null
-  const int* states;     // packed state classes
-  const int* state_off;  // [bs+1]
-  float* lat;            // lattice workspace: per line 3*T*S floats at lat_off[b]
-  const long long* lat_off;
+  const int* states;     // packed state classes (a line's at lines[].soff)
+  float* lat;            // lattice workspace: per line 3*T*S floats at lines[].lat_off
   const double* tables;  // device copy of ctc_tables.h: exp2_32[32] | invc[64] | logc[64] | softplus[929][4]
   int nc;
   int ncp;               // LDS row stride of the class tile (odd)
@@ -106,14 +111,20 @@ DEVFN float ctc_limexp(float x) {
 }
 
 // Phase B of both paths: alpha into `al`, the reversed-lattice alpha into `be` ([T][S] each).  The match
-// scores are prefetched from HBM two frames ahead (an LDS source was measured 100 cycles per frame slower:
-// its reads share lgkmcnt with the table reads of log_add and end up waited for right where they are issued).
+// scores are prefetched from HBM CTC_PD frames ahead: inside a training step a row this workgroup itself wrote a few
+// microseconds earlier takes ~1 us to come back (two frames ahead -- enough for the kernel on its own -- cost the step
+// 3.5 us; profiles/r05_ctc_tuning.txt).
 // LDS_OUT (S <= 64 only): `al` / `be` are LDS arrays -- the stores of a step then leave the vmcnt queue, whose
 // in-order count otherwise makes the wait for a prefetched match row also a wait for the previous stores'
 // write acknowledgements.
-template <bool LDS_OUT>
+// LDS_SRC (short-line path, S <= 64, where the carve has the room): the match scores never leave LDS -- lml[t][nup] holds
+// them per DISTINCT class, lane j reads column ucol[state]; no rows to HBM in phase A, no store drain in front of the
+// recursion, and the first frames arrive in an LDS latency.  (With the scores requested two frames ahead an LDS source had
+// measured 100 cycles per frame slower than HBM -- its reads share lgkmcnt with the table reads of log_add; CTC_PD frames
+// ahead a score has long arrived when the step that uses it waits for its table entry.)
+template <bool LDS_OUT, bool LDS_SRC = false>
 DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, float* dump, const CrTables tb, const int T,
-                       const int S) {
+                       const int S, const float* lml = nullptr, const int nup = 0, const int* ucol = nullptr) {
   // (= forwardbackward(), ctc.cc:42-55); serial in t, parallel over the label axis
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const size_t latbytes = (size_t)T * S * 4;
@@ -125,39 +136,59 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, float* 
       const bool rev = wave == 1;
       const BufF32 outb = make_buf(rev ? be : al, LDS_OUT ? 0 : latbytes);
       const int j = lane;
-      float* outl = j < S ? (rev ? be : al) + (rev ? S - 1 - j : j) : dump;   // LDS_OUT: this lane's column
-      const int outstride = j < S ? S : 0;
-      // lattice cell of (step i, state j): byte offset = lane part + wave-uniform frame part;
-      // masked lanes (j >= S) sit at BUF_OOB_BASE, prefetches past the end re-read the last frame
+      // lattice cell of (step i, state j): byte offset = lane part + wave-uniform frame part; masked lanes (j >= S) sit at
+      // BUF_OOB_BASE, prefetches past the end re-read the end frame.  The frame parts are carried along (one add and a clamp per
+      // step; the output pointer of a lane one add): a single wave issues an instruction every four cycles or so whatever its
+      // kind, and deriving both from the step number cost a dozen scalar operations and an integer multiply per frame.
       const unsigned lanepart = j < S ? (unsigned)(rev ? S - 1 - j : j) * 4u : BUF_OOB_BASE;
-      const unsigned rowbytes = (unsigned)S * 4u;
-      auto frame = [&](int i) -> unsigned {
-        const int ic = i < T ? i : T - 1;
-        return (unsigned)(rev ? T - 1 - ic : ic) * rowbytes;
-      };
+      const int rowbytes = S * 4, lastb = (T - 1) * rowbytes, stepb = rev ? -rowbytes : rowbytes;
+      auto clampf = [&](int x) -> int { return x < 0 ? 0 : (x > lastb ? lastb : x); };
+      int cf = rev ? lastb : 0;                 // frame of step i
+      const int ostep = j < S ? (rev ? -S : S) : 0;
+      float* op = j < S ? (rev ? be : al) + (rev ? S - 1 - j : j) + (rev ? (T - 1) * S : 0) : dump;   // LDS_OUT: this lane's cell of step i
       float v = -5.0f * (float)j;            // skip * j, exact in float
       float skipi = 0.0f;                    // skip * i, accumulated: exact while 5 T < 2^24
-      float lmA = buf_load_s(lmb, lanepart, frame(0)), lmB = buf_load_s(lmb, lanepart, frame(1));
-      float kaA = 0.0f, kaB = 0.0f;
-      auto step = [&](const int i, float& lmr, float& ka) {
+      float lmq[CTC_PD], kaq[CTC_PD];
+      int pf = cf;                              // frame of the next prefetch (CTC_PD steps ahead once the ring is primed)
+      // LDS_SRC: this lane's column of the score table, at the frame of the next prefetch (never past the line's ends)
+      const float* pp = LDS_SRC ? lml + ucol[j < S ? (rev ? S - 1 - j : j) : 0] + (rev ? (T - 1) * nup : 0) : nullptr;
+      const int pstep = rev ? -nup : nup;
+#pragma unroll
+      for (int q = 0; q < CTC_PD; q++) {
+        if (LDS_SRC) {
+          lmq[q] = 0.0f;
+          if (q < T) { lmq[q] = *pp; pp += pstep; }   // wave-uniform
+        } else {
+          lmq[q] = buf_load_s(lmb, lanepart, (unsigned)pf); pf = clampf(pf + stepb);
+        }
+        kaq[q] = 0.0f;
+      }
+      auto step = [&](float& lmr, float& ka, const bool more) {   // more (LDS_SRC; wave-uniform): the frame CTC_PD ahead exists
         KEEP_ALIVE(ka);
         const float lmv = lmr;
         const float same = v + lmv;
         // next = w + lmatch with w = v[j-1] (lane 0: skip * i), the lane shift folded into the add
         const float next = add_wave_shr1(skipi + lmv, v, lmv);
         skipi -= 5.0f;
-        lmr = buf_load_s(lmb, lanepart, frame(i + 2));  // two frames ahead
+        if (LDS_SRC) {
+          if (more) { lmr = *pp; pp += pstep; }
+        } else {
+          lmr = buf_load_s(lmb, lanepart, (unsigned)pf);  // CTC_PD frames ahead
+          pf = clampf(pf + stepb);
+        }
         v = ctc_log_add(same, next, tb);
-        if (LDS_OUT) outl[(rev ? T - 1 - i : i) * outstride] = v;
-        else buf_store_s(outb, lanepart, frame(i), v);
+        if (LDS_OUT) { *op = v; op += ostep; }
+        else { buf_store_s(outb, lanepart, (unsigned)cf, v); cf += stepb; }
         ka = v;
       };
       int i = 0;
-      for (; i + 1 < T; i += 2) {
-        step(i, lmA, kaA);
-        step(i + 1, lmB, kaB);
+      for (; i + 2 * CTC_PD <= T; i += CTC_PD) {   // rounds whose every step has a frame CTC_PD ahead
+#pragma unroll
+        for (int q = 0; q < CTC_PD; q++) step(lmq[q], kaq[q], true);
       }
-      if (i < T) step(i, lmA, kaA);
+#pragma unroll
+      for (int q = 0; q < 2 * CTC_PD - 1; q++)
+        if (i + q < T) step(lmq[q % CTC_PD], kaq[q % CTC_PD], i + q + CTC_PD < T);
     }
   } else if (S <= 128) {
     // 65..128 states (transcripts of 33..63 labels: configs[4]'s 50 labels = 101 states): still ONE wave per direction and no
@@ -172,37 +203,43 @@ DEVFN void ctc_lattice(const float* lm, float* al, float* be, float* vx, float* 
       const int j0 = 2 * lane, j1 = 2 * lane + 1;
       const unsigned lp0 = j0 < S ? (unsigned)(rev ? S - 1 - j0 : j0) * 4u : BUF_OOB_BASE;
       const unsigned lp1 = j1 < S ? (unsigned)(rev ? S - 1 - j1 : j1) * 4u : BUF_OOB_BASE;
-      const unsigned rowbytes = (unsigned)S * 4u;
-      auto frame = [&](int i) -> unsigned {
-        const int ic = i < T ? i : T - 1;
-        return (unsigned)(rev ? T - 1 - ic : ic) * rowbytes;
-      };
+      const int rowbytes = S * 4, lastb = (T - 1) * rowbytes, stepb = rev ? -rowbytes : rowbytes;   // (frame parts carried along: see above)
+      auto clampf = [&](int x) -> int { return x < 0 ? 0 : (x > lastb ? lastb : x); };
+      int cf = rev ? lastb : 0;
       float v0 = -5.0f * (float)j0, v1 = -5.0f * (float)j1;   // skip * j, exact in float
       float skipi = 0.0f;
-      float a0 = buf_load_s(lmb, lp0, frame(0)), a1 = buf_load_s(lmb, lp1, frame(0));
-      float b0 = buf_load_s(lmb, lp0, frame(1)), b1 = buf_load_s(lmb, lp1, frame(1));
-      float ka0 = 0.0f, ka1 = 0.0f, kb0 = 0.0f, kb1 = 0.0f;
-      auto step = [&](const int i, float& l0, float& l1, float& k0, float& k1) {
+      float l0q[CTC_PD], l1q[CTC_PD], k0q[CTC_PD], k1q[CTC_PD];
+      int pf = cf;
+#pragma unroll
+      for (int q = 0; q < CTC_PD; q++) {
+        l0q[q] = buf_load_s(lmb, lp0, (unsigned)pf); l1q[q] = buf_load_s(lmb, lp1, (unsigned)pf);
+        pf = clampf(pf + stepb); k0q[q] = k1q[q] = 0.0f;
+      }
+      auto step = [&](float& l0, float& l1, float& k0, float& k1) {
         KEEP_ALIVE(k0); KEEP_ALIVE(k1);
         const float m0 = l0, m1 = l1;
         const float same0 = v0 + m0, same1 = v1 + m1;
         const float next1 = v0 + m1;                               // w = v_old[j - 1], the lane's own even state
         const float next0 = add_wave_shr1(skipi + m0, v1, m0);     // ... lane u - 1's odd state (lane 0: skip * i)
         skipi -= 5.0f;
-        l0 = buf_load_s(lmb, lp0, frame(i + 2));                    // two frames ahead
-        l1 = buf_load_s(lmb, lp1, frame(i + 2));
+        l0 = buf_load_s(lmb, lp0, (unsigned)pf);                    // CTC_PD frames ahead
+        l1 = buf_load_s(lmb, lp1, (unsigned)pf);
+        pf = clampf(pf + stepb);
         v0 = ctc_log_add(same0, next0, tb);
         v1 = ctc_log_add(same1, next1, tb);
-        buf_store_s(outb, lp0, frame(i), v0);
-        buf_store_s(outb, lp1, frame(i), v1);
+        buf_store_s(outb, lp0, (unsigned)cf, v0);
+        buf_store_s(outb, lp1, (unsigned)cf, v1);
+        cf += stepb;
         k0 = v0; k1 = v1;
       };
       int i = 0;
-      for (; i + 1 < T; i += 2) {
-        step(i, a0, a1, ka0, ka1);
-        step(i + 1, b0, b1, kb0, kb1);
+      for (; i + CTC_PD <= T; i += CTC_PD) {
+#pragma unroll
+        for (int q = 0; q < CTC_PD; q++) step(l0q[q], l1q[q], k0q[q], k1q[q]);
       }
-      if (i < T) step(i, a0, a1, ka0, ka1);
+#pragma unroll
+      for (int q = 0; q < CTC_PD - 1; q++)
+        if (i + q < T) step(l0q[q], l1q[q], k0q[q], k1q[q]);
     }
   } else {
     const int R = (S + CTC_GROUP - 1) / CTC_GROUP;
@@ -298,6 +335,8 @@ DEVFN void ctc_lattice_huge(const float* lm, float* al, float* be, const CrTable
 #define CTC_STAMP(k) do { if (a.prof && b == 0 && threadIdx.x == 0) a.prof[k] = dev_clock(); } while (0)
 constexpr int CTC_TREG = (CTC_TABLE_DOUBLES + CTC_THREADS - 1) / CTC_THREADS;
 constexpr int CTC_PREG = 34;    // posteriors per thread held in registers across the state classification
+constexpr int CTC_NB = 12;      // items a thread of the short-line path takes per round in the match-score and write-out loops
+constexpr int CTC_CLANE = 32;   // frames per wave of the lane = state form of phases C / D (lines of up to 64 states and 256 frames)
 constexpr int CTC_CCACHE = 26;  // lattice cells per thread kept in registers between the two passes of phase C (26 x 512 = 13312
                                 // cells: lines of up to 261 frames x 51 states -- a ragged OCR minibatch, T ~ U{150..250} -- stay on the short-line path;
                                 // at 24 the 10 % of such lines beyond 240 frames took the tiled path and the launch 107 us instead of 75)
@@ -306,7 +345,7 @@ constexpr int CTC_CCACHE = 26;  // lattice cells per thread kept in registers be
 // Guards are branch-free throughout: reads use a clamped index and a select, masked-off stores go to `dump`,
 // global accesses go through buffer descriptors (out-of-range = no-op).  Loops are written as a batch of
 // independent reads followed by the arithmetic, so the scheduler can interleave the elements of a batch.
-DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const CrTables tb, const int b,
+DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const CrTables tb, const int b, float* lm,
                           const int off, const int T, const int S, const double (&treg)[CTC_TREG],
                           const float (&preg)[CTC_PREG], const bool flat) {
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
@@ -318,7 +357,6 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   //   A: posteriors [T][ncp] | match scores per distinct class [T][nup]      B: alpha [T][S] | reversed alpha [T][S]
   //   C..E: lattice tile [T][sp] | class columns [T][nup]
   float* rowbuf = lds + L.rowbuf;
-  float* lmu = rowbuf + T * ncp;
   float* etile = rowbuf;
   const int cap = L.asum + a.tile - L.rowbuf;
   int* stl = reinterpret_cast<int*>(lds + L.states);
@@ -329,7 +367,6 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   float* red = lds + L.red;
   int* wcnt = reinterpret_cast<int*>(red + 16);
   float* dump = lds + L.dump;
-  float* lm = a.lat + a.lat_off[b];
   float* al = lm + (size_t)T * S;
   float* be = al + (size_t)T * S;
   const int TS = T * S, sp = S | 1;
@@ -381,6 +418,12 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   __syncthreads();
   if (live) ucol[tid] = ccol[sc];
   CTC_STAMP(12);
+  // the match scores per distinct class, [T][nup]: behind the posteriors -- and, where the region has the room, behind the two
+  // LDS lattices of phase B as well, which then reads them where they are (ctc_lattice: LDS_SRC)
+  const bool lds_lat = S <= 64 && 2 * TS <= cap;
+  const int lmu_hi = 2 * TS > T * ncp ? 2 * TS : T * ncp;
+  const bool lm_lds = lds_lat && lmu_hi + T * nup <= cap;   // uniform per workgroup
+  float* lmu = rowbuf + (lm_lds ? lmu_hi : T * ncp);
   {
     double* tabs = reinterpret_cast<double*>(lds + L.tables);
 #pragma unroll
@@ -421,9 +464,19 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   __syncthreads();
   CTC_STAMP(13);
   for (int t = tid; t < T; t += CTC_THREADS) {  // sequential float sum in class order, as asum1() (tensor.h:337-342)
+    // (whole batches carry no guards: with a clamped index and a select per element the loop was 190 instructions per
+    //  sixteen classes, issue-bound on the one wave per SIMD that has frames -- 4.7k cycles at nc = 83)
     const float* r = rowbuf + t * ncp;
     float acc = 0.0f;
-    for (int c0 = 0; c0 < nc; c0 += 16) {
+    int c0 = 0;
+    for (; c0 + 16 <= nc; c0 += 16) {
+      float x[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) x[u] = r[c0 + u];
+#pragma unroll
+      for (int u = 0; u < 16; u++) acc += x[u];
+    }
+    if (c0 < nc) {
       float x[16];
 #pragma unroll
       for (int u = 0; u < 16; u++) x[u] = r[c0 + u < nc ? c0 + u : 0];
@@ -438,11 +491,11 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
     const int n = T * nu;
     const int dq = CTC_THREADS / nu, dr = CTC_THREADS - dq * nu;   // (t, u) of item i, followed incrementally
     int tq = tid / nu, uq = tid - tq * nu;
-    for (int i0 = tid; i0 < n; i0 += 4 * CTC_THREADS) {
-      float q[4];
-      float* w[4];
+    for (int i0 = tid; i0 < n; i0 += CTC_NB * CTC_THREADS) {   // (a line of the bench shape: one round)
+      float q[CTC_NB];
+      float* w[CTC_NB];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < CTC_NB; u++) {
         const bool in = i0 + u * CTC_THREADS < n;
         const int tc = in ? tq : 0, uc = in ? uq : 0;
         q[u] = (float)((double)rowbuf[tc * ncp + ucls[uc]] * part[tc]);
@@ -451,12 +504,12 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
         if (uq >= nu) { uq -= nu; tq++; }
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) *w[u] = cr_logf(q[u], tb);
+      for (int u = 0; u < CTC_NB; u++) *w[u] = cr_logf(q[u], tb);
     }
   }
   __syncthreads();
   CTC_STAMP(15);
-  {  // lmatch rows for the recursion (it prefetches them from HBM two frames ahead: vmcnt, not lgkmcnt)
+  if (!lm_lds) {  // lmatch rows for the recursion (it prefetches them from HBM: vmcnt, not lgkmcnt)
     const BufF32 lmw = make_buf(lm, latbytes);
     for (int s0 = 0; s0 < S; s0 += 64) {   // one wave per frame, lanes over states
       const int st = s0 + lane;
@@ -480,8 +533,8 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   //         depend on the lattice: a class without a target state has aligned = 0, delta = -p.
   float* all = rowbuf;            // alpha / reversed alpha in LDS (row buffer + lattice tile are both free here)
   float* bel = rowbuf + TS;
-  const bool lds_lat = S <= 64 && 2 * TS <= cap;
-  if (lds_lat) ctc_lattice<true>(lm, all, bel, lds + L.vx, dump, tb, T, S);
+  if (lm_lds) ctc_lattice<true, true>(lm, all, bel, lds + L.vx, dump, tb, T, S, lmu, nup, ucol);
+  else if (lds_lat) ctc_lattice<true>(lm, all, bel, lds + L.vx, dump, tb, T, S);
   else ctc_lattice<false>(lm, al, be, lds + L.vx, dump, tb, T, S);
   const BufF32 dzb = make_buf(a.Dz + (size_t)off * nc, (size_t)T * nc * 4);
   const BufF32 agb = make_buf(a.aligned ? a.aligned + (size_t)off * nc : a.Dz, a.aligned ? (size_t)T * nc * 4 : 0);
@@ -510,18 +563,114 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   __syncthreads();
   CTC_STAMP(2);
 
+  // Lines of up to 64 states and 8 x CTC_CLANE frames walk phases C and D with lane = state, wave w on the frames w, w + 8, ..:
+  // no index arithmetic, no per-element guards (frames in wave-uniform groups of four), the cells stay in registers from
+  // the load to the normalised store, and the per-state sums over a wave's frames ARE the time chunks of the generic phase D
+  // (thread q of a state took the frames q, q + 8, ..; Q = 8 for S <= 64), so every sum has the operands and the order it had.
+  // The tile then holds the NORMALISED cells (float)((double)e * 1/total), which phase E otherwise forms on the fly.
+  const bool lanemap = S <= 64 && T <= (CTC_THREADS / 64) * CTC_CLANE;   // uniform per workgroup
+  if (lanemap) {
+    const BufF32 alb = make_buf(al, latbytes), beb = make_buf(be, latbytes);
+    const bool sok = lane < S;
+    const int sl = sok ? lane : 0;
+    float bo[CTC_CLANE];
+    float mx = -3.0e38f;
+    // (the source is chosen by a BRANCH around the whole loop: as a select per element, `lds_lat ? LDS : buffer load`, the
+    //  compiler issued both and every group of cells waited for global loads it did not need -- 7.0k cycles against 1.6k)
+    auto load_cells = [&](auto lds_tag) {
+      constexpr bool LL = decltype(lds_tag)::value;
+#pragma unroll
+      for (int g = 0; g < CTC_CLANE / 4; g++) {
+        if (wave + 32 * g < T) {   // wave-uniform
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int k = 4 * g + u, t = wave + 8 * k;
+            const bool in = sok && t < T;
+            const int ic = (t < T ? t : 0) * S + sl;
+            float x;
+            if constexpr (LL) x = all[ic] + bel[ic];
+            else {
+              const unsigned io = in ? (unsigned)ic * 4u : BUF_OOB;
+              x = buf_load(alb, io) + buf_load(beb, io);
+            }
+            bo[k] = in ? x : -3.0e38f;
+            mx = fmaxf(mx, bo[k]);
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; u++) bo[4 * g + u] = -3.0e38f;
+        }
+      }
+    };
+    if (lds_lat) load_cells(std::true_type{}); else load_cells(std::false_type{});
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();   // (also: every alpha / beta cell is in registers -- the tile may overwrite them)
+    CTC_STAMP(6);
+    mx = red[0];
+#pragma unroll
+    for (int i = 1; i < CTC_THREADS / 64; i++) mx = fmaxf(mx, red[i]);
+    CTC_STAMP(7);
+    double acc = 0.0;
+#pragma unroll
+    for (int g = 0; g < CTC_CLANE / 4; g++) {
+      if (wave + 32 * g < T) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = 4 * g + u, t = wave + 8 * k;
+          const float e = ctc_limexp(bo[k] - mx);
+          bo[k] = e;
+          acc += (t < T) ? (double)e : 0.0;   // increasing t; + 0.0 is exact
+        }
+      }
+    }
+    CTC_STAMP(3);
+    if (sok) part[wave * S + lane] = acc;
+    __syncthreads();
+    CTC_STAMP(8);
+    if (tid < S) {
+      double sum = 0.0;
+      for (int k = 0; k < CTC_THREADS / 64; k++) sum += part[k * S + tid];
+      tot[tid] = 1.0 / fmax(1e-9, sum);
+    }
+    __syncthreads();
+    CTC_STAMP(9);
+    const double it = tot[sl];
+#pragma unroll
+    for (int g = 0; g < CTC_CLANE / 4; g++) {
+      if (wave + 32 * g < T) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = 4 * g + u, t = wave + 8 * k;
+          float* w = (sok && t < T) ? &etile[t * sp + lane] : dump;
+          *w = (float)((double)bo[k] * it);
+        }
+      }
+    }
+    __syncthreads();
+    CTC_STAMP(4);
+  } else {
   // ---- C: epath = limexp(both - amax2(both)) -> etile[t][s]   (ctc.cc:82)
   {
     const BufF32 alb = make_buf(al, latbytes), beb = make_buf(be, latbytes);
     float bo[CTC_CCACHE];
     float mx = -3.0e38f;
+    if (lds_lat) {   // (a branch around the loop, not a select per cell: see load_cells above)
 #pragma unroll
-    for (int k = 0; k < CTC_CCACHE; k++) {
-      const int i = tid + k * CTC_THREADS;
-      const int ic = i < TS ? i : 0;
-      const float x = lds_lat ? all[ic] + bel[ic] : buf_load(alb, (unsigned)i * 4u) + buf_load(beb, (unsigned)i * 4u);
-      bo[k] = i < TS ? x : -3.0e38f;
-      mx = fmaxf(mx, bo[k]);
+      for (int k = 0; k < CTC_CCACHE; k++) {
+        const int i = tid + k * CTC_THREADS;
+        const int ic = i < TS ? i : 0;
+        bo[k] = i < TS ? all[ic] + bel[ic] : -3.0e38f;
+        mx = fmaxf(mx, bo[k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < CTC_CCACHE; k++) {
+        const int i = tid + k * CTC_THREADS;
+        const float x = buf_load(alb, (unsigned)i * 4u) + buf_load(beb, (unsigned)i * 4u);
+        bo[k] = i < TS ? x : -3.0e38f;
+        mx = fmaxf(mx, bo[k]);
+      }
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
@@ -552,7 +701,15 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
     const int q = tid / S, st = tid - q * S;
     const bool act = q < Q;
     double acc = 0.0;
-    for (int t0 = act ? q : T; t0 < T; t0 += 8 * Q) {
+    int t0 = act ? q : T;
+    for (; t0 + 7 * Q < T; t0 += 8 * Q) {   // whole batches: no guards
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) x[u] = etile[(t0 + u * Q) * sp + st];
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc += (double)x[u];
+    }
+    if (t0 < T) {
       float x[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) { const int t = t0 + u * Q; x[u] = etile[(t < T ? t : T - 1) * sp + st]; }
@@ -572,49 +729,78 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
     // (the normalisation itself is applied where phase E consumes the cells: one LDS pass less)
   }
   CTC_STAMP(4);
+  }
 
   // ---- E: project states onto classes (ctc.cc:91-109), compact: one column per class that has a state.
   //         Waves 4-7: lane = one first-occurrence label state, looping over frames (plain stores).
   //         Waves 0-3: lane = one frame, the blank states summed in state order in double (class 0 collects
   //         L+1 states: the reference's double accumulator).
   float* rowc = rowbuf + T * sp;   // [T][nup], behind the lattice tile
-  if (wave >= 4) {
-    for (int f0 = 0; f0 < nf; f0 += 64) {
-      const bool fok = f0 + lane < nf;
-      const int st = lists[nb + (fok ? f0 + lane : 0)];
-      const int col = ucol[st];
-      const double it = tot[st];   // per-state normalisation (phase D), applied on the fly
-      for (int t0 = wave - 4; t0 < T; t0 += 4 * 8) {
-        float x[8];
+  auto project = [&](auto pre_tag) {   // PRE: the tile holds the normalised cells (lane = state form of phases C / D)
+    constexpr bool PRE = decltype(pre_tag)::value;
+    if (wave >= 4) {
+      for (int f0 = 0; f0 < nf; f0 += 64) {
+        const bool fok = f0 + lane < nf;
+        const int st = lists[nb + (fok ? f0 + lane : 0)];
+        const int col = ucol[st];
+        const double it = PRE ? 1.0 : tot[st];   // per-state normalisation (phase D), applied on the fly unless the tile holds it
+        int t0 = wave - 4;
+        for (; t0 + 28 < T; t0 += 4 * 8) {   // whole batches: only the lane guard
+          float x[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int t = t0 + 4 * u; x[u] = etile[(t < T ? t : T - 1) * sp + st]; }
+          for (int u = 0; u < 8; u++) x[u] = etile[(t0 + 4 * u) * sp + st];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int t = t0 + 4 * u;
-          float* w = (fok && t < T) ? &rowc[t * nup + col] : dump;
-          *w = (float)((double)x[u] * it);
+          for (int u = 0; u < 8; u++) {
+            float* w = fok ? &rowc[(t0 + 4 * u) * nup + col] : dump;
+            *w = PRE ? x[u] : (float)((double)x[u] * it);
+          }
+        }
+        if (t0 < T) {
+          float x[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) { const int t = t0 + 4 * u; x[u] = etile[(t < T ? t : T - 1) * sp + st]; }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int t = t0 + 4 * u;
+            float* w = (fok && t < T) ? &rowc[t * nup + col] : dump;
+            *w = PRE ? x[u] : (float)((double)x[u] * it);
+          }
         }
       }
-    }
-  } else {
-    for (int t = tid; t < T; t += 256) {
-      const float* e = etile + t * sp;
-      double blank = 0.0;
-      for (int i0 = 0; i0 < nb; i0 += 8) {
-        float x[8];
-        double it[8];
+    } else {
+      for (int t = tid; t < T; t += 256) {
+        const float* e = etile + t * sp;
+        double blank = 0.0;
+        int i0 = 0;
+        for (; i0 + 8 <= nb; i0 += 8) {   // whole batches: no guards
+          float x[8];
+          double it[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int st = lists[i0 + u < nb ? i0 + u : 0];
-          x[u] = e[st];
-          it[u] = tot[st];
+          for (int u = 0; u < 8; u++) {
+            const int st = lists[i0 + u];
+            x[u] = e[st];
+            it[u] = PRE ? 1.0 : tot[st];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) blank += PRE ? (double)x[u] : (double)(float)((double)x[u] * it[u]);
         }
+        if (i0 < nb) {
+          float x[8];
+          double it[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) blank += (i0 + u < nb) ? (double)(float)((double)x[u] * it[u]) : 0.0;
+          for (int u = 0; u < 8; u++) {
+            const int st = lists[i0 + u < nb ? i0 + u : 0];
+            x[u] = e[st];
+            it[u] = PRE ? 1.0 : tot[st];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) blank += (i0 + u < nb) ? (PRE ? (double)x[u] : (double)(float)((double)x[u] * it[u])) : 0.0;
+        }
+        part[t] = blank;
       }
-      part[t] = blank;
     }
-  }
+  };
+  if (lanemap) project(std::true_type{}); else project(std::false_type{});
   __syncthreads();
   CTC_STAMP(10);
   for (int t = tid; t < T; t += CTC_THREADS) {
@@ -622,11 +808,19 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
     const float* e = etile + t * sp;
     for (int i = 0; i < nr; i++) {   // few; a class may repeat more than once: read-modify-write in state order
       const int st = lists[nb + nf + i];
-      row[ucol[st]] += (float)((double)e[st] * tot[st]);
+      row[ucol[st]] += lanemap ? e[st] : (float)((double)e[st] * tot[st]);
     }
     if (nb > 0) row[ccol[0]] = (float)part[t];
     double total = 0.0;   // columns are in class order: the reference's double sum, minus its exact zeros
-    for (int u0 = 0; u0 < nu; u0 += 8) {
+    int u0 = 0;
+    for (; u0 + 8 <= nu; u0 += 8) {   // whole batches: no guards
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) x[u] = row[u0 + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) total += (double)x[u];
+    }
+    if (u0 < nu) {
       float x[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) x[u] = row[u0 + u < nu ? u0 + u : 0];
@@ -641,11 +835,11 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
     const int n = T * nu;
     const int dq = CTC_THREADS / nu, dr = CTC_THREADS - dq * nu;   // (t, u) of item i, followed incrementally
     int tq = tid / nu, uq = tid - tq * nu;
-    for (int i0 = tid; i0 < n; i0 += 4 * CTC_THREADS) {
-      float p[4], av[4];
-      unsigned ofs[4];
+    for (int i0 = tid; i0 < n; i0 += CTC_NB * CTC_THREADS) {   // (every posterior of the thread requested before the first is used)
+      float p[CTC_NB], av[CTC_NB];
+      unsigned ofs[CTC_NB];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < CTC_NB; u++) {
         const bool in = i0 + u * CTC_THREADS < n;
         const int tc = in ? tq : 0, uc = in ? uq : 0;
         ofs[u] = in ? (unsigned)(tc * nc + ucls[uc]) * 4u : BUF_OOB;
@@ -655,7 +849,7 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
         if (uq >= nu) { uq -= nu; tq++; }
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < CTC_NB; u++) {
         buf_store(agb, ofs[u], av[u]);
         buf_store(dzb, ofs[u], av[u] - p[u]);
       }
@@ -678,14 +872,15 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
   float* red = lds + L.red;
   const CrTables tb{tabs, tabs + 32, tabs + 96, tabs + 160};
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+  const CtcLine ln = a.lines[blockIdx.x];
+  const int b = ln.b;
   const int nc = a.nc, ncp = a.ncp, TT = a.tile;
-  const int off = a.line_off[b], T = a.line_off[b + 1] - off;
-  const int soff = a.state_off[b], S = a.state_off[b + 1] - soff;
+  const int off = ln.off, T = ln.T;
+  const int soff = ln.soff, S = ln.S;
   if (T <= 0 || S <= 0) return;
   const float* P = a.P + (size_t)off * nc;
   float* Dz = a.Dz + (size_t)off * nc;
-  float* lm = a.lat + a.lat_off[b];
+  float* lm = a.lat + ln.lat_off;
   float* al = lm + (size_t)T * S;
   float* be = al + (size_t)T * S;
   CTC_STAMP(0);
@@ -714,7 +909,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_align_kernel(CtcArgs a) {
     if (tid < S) stl[tid] = st0;
     for (int s = tid + CTC_THREADS; s < S; s += CTC_THREADS) stl[s] = a.states[soff + s];
     __syncthreads();
-    ctc_short_line(a, lds, L, tb, b, off, T, S, treg, preg, flat);
+    ctc_short_line(a, lds, L, tb, b, lm, off, T, S, treg, preg, flat);
     return;
   }
   // lines of more than CTC_SMAX_LDS states: the per-state arrays do not fit the LDS carve -- target states are read from
