@@ -424,6 +424,21 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
   const int lmu_hi = 2 * TS > T * ncp ? 2 * TS : T * ncp;
   const bool lm_lds = lds_lat && lmu_hi + T * nup <= cap;   // uniform per workgroup
   float* lmu = rowbuf + (lm_lds ? lmu_hi : T * ncp);
+  // the posteriors the write-out at the very end subtracts (first round of its loop: (frame, present class) items tid,
+  // tid + 512, ..): requested HERE, a whole kernel ahead -- inside a training step such a load is a microsecond on the tail
+  float pw[CTC_NB];
+  {
+    const int n = T * nu;
+    const int dq = CTC_THREADS / nu, dr = CTC_THREADS - dq * nu;
+    int tq = tid / nu, uq = tid - tq * nu;
+#pragma unroll
+    for (int u = 0; u < CTC_NB; u++) {
+      const bool in = tid + u * CTC_THREADS < n;
+      pw[u] = buf_load(pb, in ? (unsigned)(tq * nc + ucls[in ? uq : 0]) * 4u : BUF_OOB);
+      tq += dq; uq += dr;
+      if (uq >= nu) { uq -= nu; tq++; }
+    }
+  }
   {
     double* tabs = reinterpret_cast<double*>(lds + L.tables);
 #pragma unroll
@@ -843,10 +858,16 @@ DEVFN void ctc_short_line(const CtcArgs& a, float* lds, const CtcLds& L, const C
         const bool in = i0 + u * CTC_THREADS < n;
         const int tc = in ? tq : 0, uc = in ? uq : 0;
         ofs[u] = in ? (unsigned)(tc * nc + ucls[uc]) * 4u : BUF_OOB;
-        p[u] = buf_load(pb, ofs[u]);
         av[u] = (float)((double)rowc[tc * nup + uc] * part[tc]);
         tq += dq; uq += dr;
         if (uq >= nu) { uq -= nu; tq++; }
+      }
+      if (i0 == tid) {   // (uniform: every thread is in its first round together)
+#pragma unroll
+        for (int u = 0; u < CTC_NB; u++) p[u] = pw[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < CTC_NB; u++) p[u] = buf_load(pb, ofs[u]);
       }
 #pragma unroll
       for (int u = 0; u < CTC_NB; u++) {
