@@ -342,6 +342,28 @@ def test_ctc_vs_oracle(backend, ora32, T, L, nc):
         assert_close(dz[loff[b]:loff[b + 1]], want - probs[b], rtol=1e-4, atol=2e-6, what="delta line %d" % b)
 
 
+@pytest.mark.parametrize("L,nc", [(1, 5), (25, 83), (31, 40), (25, 60), (40, 30), (63, 70)])
+def test_ctc_recursion_ring_boundaries(backend, ora32, L, nc):
+    """The one-wave lattice recursions request their match scores CTC_PD = 8 frames ahead through a register ring: line lengths
+    around the ring size and its multiples (the loop's rounds, its unrolled tail of up to 15 steps, lines shorter than the ring).
+    (L, nc) pick the source of the scores: 3 / 51 / 63 states with the scores in LDS (ctc_lattice<true, true>), 51 states over
+    60 classes with LDS lattices but the scores from HBM (the carve has no room behind the lattices), 81 / 127 states on two
+    states per lane with everything in HBM."""
+    rng = np.random.default_rng(100 * L + nc)
+    probs, states = [], []
+    for T in (1, 2, 3, 7, 8, 9, 15, 16, 17, 23, 24, 25, 33):
+        p = rng.random((T, nc)).astype(np.float32) ** 3
+        p /= p.sum(1, keepdims=True)
+        tr = rng.integers(1, nc, L)
+        tr[::3] = tr[0]                                   # repeated labels: the read-modify-write columns of phase E
+        probs.append(p.astype(np.float32)); states.append(ora32.mktargets(tr))
+    al, dz, loff = ctc_via_abi(backend, probs, states)
+    for b in range(len(probs)):
+        want = ora32.ctc_align_classes(probs[b], states[b])
+        assert_close(al[loff[b]:loff[b + 1]], want, rtol=1e-4, atol=1e-6, what="aligned, T = %d" % len(probs[b]))
+        assert_close(dz[loff[b]:loff[b + 1]], want - probs[b], rtol=1e-4, atol=2e-6, what="delta, T = %d" % len(probs[b]))
+
+
 @pytest.mark.parametrize("case", ["no_blank", "one_state", "one_frame", "all_same", "many_classes", "huge_classes"])
 def test_ctc_target_shapes(backend, ora32, case):
     """Targets as plain class lists (the Classes overload, ctc.cc:136-146): the short-line path classifies the
