@@ -668,6 +668,8 @@ struct Layer {
   int wk_kp = 0, wk_njp = 0;
   DevBuf<float> dCc;
   DevBuf<int> pack_tab;       // source index of every packed element (k_pack_index), narrow layers in training steps
+  DevBuf<int> pack_inv;       // ... and its inverse, PACK_KD packed elements per parameter (ops.h: PackDst); pack_inv_state: 0 not built, 1 ready, -1 unusable
+  int pack_inv_state = 0;
   // bf16 recurrence of a wide layer (lstm_wide_bf16.h): packed weights and the bf16 copies of h / the deltas
   unsigned short *Rbf = nullptr, *Rbb = nullptr;
   DevBuf<unsigned short> R2b, D2;   // f32-grade backward recurrence on the bf16 MFMA (lstm_xcd_bwd_x3): hi | lo planes of the weights and of the delta ring
@@ -791,13 +793,40 @@ struct Net {
   int* pack_table(Layer& y) {
     if (!y.pack_tab.p) {
       const PackFused pf = pack_fused_desc(y);
-      const size_t n = (size_t)(1 + y.ni) * ndir * 4 * y.no + 2 * ((size_t)ndir * 4 * 4 * y.nk4 * y.nthreads) +
-                       (pf.Wk ? (size_t)ndir * pf.njp * 16 * pf.kp + (size_t)96 * pf.kps : 0);
+      const size_t n = pack_count(y);
       y.pack_tab.reserve(n);
       CLSTM_LAUNCH(k_pack_index, dim3(nblocks(n)), dim3(256), 0, stream(), y.pack_tab.p, y.pd, pf);
       check_launch();
     }
     return y.pack_tab.p;
+  }
+  // the inverse of pack_table(): built once per net on the host (one synchronous read-back of the table)
+  static constexpr int PACK_KD = 4;
+  size_t pack_count(const Layer& y) const {
+    const PackFused pf = pack_fused_desc(y);
+    return (size_t)(1 + y.ni) * ndir * 4 * y.no + 2 * ((size_t)ndir * 4 * 4 * y.nk4 * y.nthreads) +
+           (pf.Wk ? (size_t)ndir * pf.njp * 16 * pf.kp + (size_t)96 * pf.kps : 0);
+  }
+  bool pack_inverse(Layer& y) {
+    if (y.pack_inv_state) return y.pack_inv_state > 0;
+    const int* tab = pack_table(y);
+    const size_t n = pack_count(y);
+    std::vector<int> t(n);
+    HIPCHECK(hipMemcpyAsync(t.data(), tab, n * sizeof(int), hipMemcpyDeviceToHost, stream()));
+    HIPCHECK(hipStreamSynchronize(stream()));
+    std::vector<int> inv((size_t)nparams * PACK_KD, -1), cnt(nparams, 0);
+    y.pack_inv_state = 1;
+    for (size_t e = 0; e < n && y.pack_inv_state > 0; e++) {
+      const int si = t[e];
+      if (si < 0) continue;
+      if (si >= nparams || cnt[si] >= PACK_KD) { y.pack_inv_state = -1; break; }
+      inv[(size_t)si * PACK_KD + cnt[si]++] = (int)e;
+    }
+    if (y.pack_inv_state < 0) return false;
+    y.pack_inv.reserve(inv.size());
+    HIPCHECK(hipMemcpyAsync(y.pack_inv.p, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice, stream()));
+    HIPCHECK(hipStreamSynchronize(stream()));
+    return true;
   }
   PackFused pack_fused_desc(const Layer& y) const {
     PackFused f{};
@@ -884,7 +913,7 @@ struct Net {
     for (auto& y : L) {
       (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff); (void)hipFree(y.Wk);
       (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release(); y.Rf32.release(); y.R2b.release(); y.D2.release();
-      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false; y.pack_tab.release(); y.partial.release(); y.dbias.release();
+      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false; y.pack_tab.release(); y.pack_inv.release(); y.pack_inv_state = 0; y.partial.release(); y.dbias.release();
     }
     (void)hipFree(W1k); fw_items.release(); fw_flags.release();
     for (int i = 0; i < 2; i++) { hf.xin[i].release(); if (hf.pin[i]) (void)hipHostFree(hf.pin[i]); if (hf.copied[i]) (void)hipEventDestroy(hf.copied[i]); }
@@ -1729,8 +1758,18 @@ struct Net {
     UpdateFuse uf{};
     uf.nanflag = nanflag(); uf.step_no = step_no();
     if (fuse) {   // (train_step without a communicator) this layer's parameters are updated by the reduction itself
-      uf = UpdateFuse{v, d, lr, mom, gclip, (const int*)dev_err_words(), last ? update_step_word : nullptr, update_step_id, nanflag(), step_no()};
+      uf = UpdateFuse{v, d, lr, mom, gclip, (const int*)dev_err_words(), last ? update_step_word : nullptr, update_step_id, nanflag(), step_no(), PackDst{}};
       if (last) { update_step_word = nullptr; update_applied = true; }
+      // a single narrow layer whose packed copies are current: the update keeps them current (ops.h: PackDst) and the next
+      // step's ingest launch has nothing to repack
+      packs_follow_update = false;
+      if (L.size() == 1 && !L[0].wide && !packed_dirty && dbg_opt("update_repack", 1) && pack_inverse(L[0])) {
+        Layer& y = L[0];
+        const size_t nr = (size_t)ndir * 4 * 4 * y.nk4 * y.nthreads;
+        uf.pk = PackDst{y.pack_inv.p, PACK_KD, y.Wt, y.bias, y.Rf, y.Rb, y.pd, pack_fused_desc(y), (unsigned)((size_t)(1 + y.ni) * ndir * 4 * y.no), (unsigned)nr};
+        packs_follow_update = true;
+        g_path_count[10]++;
+      }
     }
     CLSTM_LAUNCH(k_reduce_scatter, dim3(nblocks(work)), dim3(256), 0, q, gates, extra, gdst, (int*)nullptr, 0, uf);
     if (peer && last) peer_pending = true;
@@ -1759,12 +1798,14 @@ struct Net {
   // an error word raised by a lower layer found the upper layers' parameters already updated: half a step.
   bool fuse_eligible() const { return !comm || comm->nranks == 1; }
   bool update_applied = false; // ... and has done so: update() has nothing left to launch
+  bool packs_follow_update = false;   // ... and rewrote the packed copies of the parameters it moved
   void update() {
     hipStream_t s = stream();
     RoctxRange range_("clstm:update");
     if (update_applied) {   // done by the reductions of the backward pass just enqueued
       update_applied = false;
-      packed_dirty = true;
+      packed_dirty = !packs_follow_update;
+      packs_follow_update = false;
       return;
     }
     if (peer_pending && comm) {   // one-shot peer-read all-reduce fused into the update (ops.h: k_peer_barrier / k_peer_allreduce_update)

@@ -640,12 +640,29 @@ struct ReduceDesc {
 };
 // The SGD update folded into the reduction (clstm_net_train_step without a communicator: one launch less per step): the
 // thread that produces g[o] also applies k_update's arithmetic to element o -- every parameter is produced exactly once.
+// The packed copies of a narrow layer's parameters (k_ingest_pack / k_pack_layer) kept current BY the fused update: inv[o * kd ..]
+// lists the packed elements that are copies of parameter o (-1 ends the list), addressed as in the table form of k_ingest_pack
+// ([W_x rows + bias | forward recurrence registers | backward ... | fused-launch forms]); the thread that moves v[o] rewrites
+// them, and the next step's ingest launch carries no repack blocks (~2 us of every training step).
+struct PackDst {
+  const int* inv; int kd;   // null inv: the packed copies are not touched
+  float *Wt, *bias, *Rf, *Rb;
+  PackDesc p; PackFused pf;
+  unsigned nwx, nr;
+};
+DEVFN void pack_dst_store(const PackDst& k, unsigned e, float x) {
+  if (e < k.nwx) pack_wx_store(e, x, k.Wt, k.bias, k.p);
+  else if (e < k.nwx + k.nr) k.Rf[e - k.nwx] = x;
+  else if (e < k.nwx + 2 * k.nr) k.Rb[e - k.nwx - k.nr] = x;
+  else pack_fused_store(e - k.nwx - 2 * k.nr, x, k.pf, k.p);
+}
 struct UpdateFuse {
   float* v; float* d;       // null v: reduce only
   float lr, mom, clip;
   const int* err;           // device error words (see k_update)
   int* step_word; int step_id;
   int* nanflag; int step_no; // non-finite gradient entries: see k_update (checked whether or not the update is fused: v may be null)
+  PackDst pk;
 };
 DEVFN void reduce_scatter_one(const ReduceDesc& d, size_t e, float* g, const UpdateFuse& u, const bool apply) {
   const size_t RC = (size_t)d.R * d.Cn;
@@ -677,8 +694,17 @@ DEVFN void reduce_scatter_one(const ReduceDesc& d, size_t e, float* g, const Upd
   if (apply && fin) {
     float di = u.d[o] + gv;
     if (u.clip < 1e6f) di = fmaxf(-u.clip, fminf(u.clip, di));
-    u.v[o] += di * u.lr;
+    const float nv = u.v[o] + di * u.lr;
+    u.v[o] = nv;
     u.d[o] = di * u.mom;
+    if (u.pk.inv) {
+      const int* ip = u.pk.inv + (size_t)o * u.pk.kd;
+      for (int k = 0; k < u.pk.kd; k++) {
+        const int e = ip[k];
+        if (e < 0) break;
+        pack_dst_store(u.pk, (unsigned)e, nv);
+      }
+    }
   }
 }
 // Bias row of a weight gradient whose product left it out (clstm_hip.hip: dw_bias_out): dbias [bs][ndir][Cn] holds, per line, the

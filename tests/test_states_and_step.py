@@ -102,6 +102,13 @@ def test_train_step_is_the_sequence_of_calls(backend, nh):
     for n in (a, b):
         n.set_params(p0)
         n.setLearningRate(1e-2, 0.9)
+
+    def kept_current():   # times the fused update rewrote the packed copies of the parameters it moved (ops.h: PackDst)
+        import ctypes
+        out = ctypes.c_longlong(0)
+        backend.lib.call("clstm_debug_path_count", 10, ctypes.byref(out))
+        return out.value
+    before = kept_current()
     for step in range(3):
         T = [int(t) for t in rng.integers(3, 9, 3)]
         lines = synth_lines(rng, T, ni)
@@ -117,6 +124,9 @@ def test_train_step_is_the_sequence_of_calls(backend, nh):
         assert np.array_equal(a.get_params(), b.get_params()), step
         assert np.array_equal(a.get_derivs(), b.get_derivs()), step
         assert [d.tolist() for d in a.decode()] == [d.tolist() for d in b.decode()]
+    # a single narrow layer: the update of every one-call step also rewrote the layer's packed parameter copies -- the next
+    # step's ingest launch repacked nothing, and the steps above still equal the sequence of calls, which repacks from scratch
+    assert kept_current() - before == (3 if len(nh) == 1 else 0)
 
 
 def test_allreduce_single_rank_is_identity(backend):
