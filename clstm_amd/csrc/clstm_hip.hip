@@ -2195,7 +2195,10 @@ static void net_set_inputs_d(clstm_net* h, const float* x, const CtcMetaCopy* au
     // configs[4] step ~25 us of DMA set-up in front of its first kernel)
     const int M = n.ndir * 4 * y.no, KQP = 4 * y.nk4;
     const size_t nr = (size_t)n.ndir * 4 * KQP * y.nthreads;
-    const int nbi = nblocks((size_t)n.N * (1 + y.ni)), nbp = with_pack ? nblocks((size_t)(1 + y.ni) * M + 2 * nr) : 0;
+    // (the ingest blocks' 16-byte form -- ops.h:k_ingest_pack -- has one item per four input floats: launching a thread per float
+    //  there dispatched 1,800 workgroups that found nothing to do)
+    const bool vec16 = (y.ni & 3) == 0 && (y.lds & 3) == 0 && ((size_t)x & 15) == 0;
+    const int nbi = nblocks(vec16 ? (size_t)n.N * (y.ni / 4 + 1) : (size_t)n.N * (1 + y.ni)), nbp = with_pack ? nblocks((size_t)(1 + y.ni) * M + 2 * nr) : 0;
     const bool lo = n.lo_pending, ax = aux && aux->nwords > 0;
     // optional trailing blocks read small host arrays straight from their pinned slots: the line offsets and -- in a
     // training step -- the CTC metadata (no DMA launches, no event records on the stream's critical path)
