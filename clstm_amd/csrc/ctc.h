@@ -15,8 +15,10 @@
 //      and the fused delta  d = aligned - p                                  (clstmhl.h:211-212)
 // Lines whose lattice fits in LDS (T <= tile, T*S <= 13312: the OCR benchmark shape) take ctc_short_line():
 // the same arithmetic, organised for one CU -- match scores once per DISTINCT class (a blank-interleaved
-// target has L+1 equal blank columns), the lattice tile resident in LDS from C to E, branch-free guards
-// (clamped index + select, masked stores to a dump word) so that independent elements interleave instead
+// target has L+1 equal blank columns) and, where the carve has room, read by the recursion straight from LDS
+// (ctc_lattice: LDS_SRC); up to 64 states and 256 frames: phases C / D with lane = state and the cells in registers;
+// the lattice tile resident in LDS from C to E; guards branch-free (clamped index + select, masked stores to a
+// dump word) in the tails and absent in whole batches, so that independent elements interleave instead
 // of paying the LDS / double-precision latency one element at a time.
 // Targets are given as one class per state (the Classes overload, ctc.cc:136-146; mktargets'
 // blank-interleaved list for OCR lines, ctc.cc:148-157).
