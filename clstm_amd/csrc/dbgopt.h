@@ -9,7 +9,8 @@
 // input projection of layers of <= 128 inputs inside the persistent forward kernel; 0: never; 2: every eligible layer), gemm_b16mc
 // (1; 0: weight gradient of wide layers from f32 source rows), wide_graph (1; 0: per-step launch loops not captured into a
 // hipGraph), dw_x3 / gemm_x3 (1; 0: the f32 MFMA for the fused launch's weight-gradient items / the softmax layer's backward
-// pair -- what clstm_net_set_strict_f32 selects per net).
+// pair -- what clstm_net_set_strict_f32 selects per net), update_repack (1; 0: the fused update of a one-call training step leaves
+// the packed parameter copies of a narrow layer to the next step's ingest launch).
 #pragma once
 #include <cstdlib>
 #include <map>
