@@ -364,6 +364,27 @@ def test_ctc_recursion_ring_boundaries(backend, ora32, L, nc):
         assert_close(dz[loff[b]:loff[b + 1]], want - probs[b], rtol=1e-4, atol=2e-6, what="delta, T = %d" % len(probs[b]))
 
 
+def test_ctc_ragged_ocr_minibatch(backend, ora32):
+    """One launch over lines as a ragged OCR minibatch has them (83 classes): 256 frames -- the longest line whose phases C / D run
+    with lane = state --, 257 and 261 frames (generic phases C / D, match scores still in LDS), lines around the bench length with
+    25 / 31 / 10 labels, short lines, a one-label line; every line against the oracle."""
+    rng = np.random.default_rng(83)
+    nc = 83
+    shapes = [(150, 25), (201, 31), (256, 25), (257, 25), (261, 25), (233, 10), (48, 5), (47, 5), (9, 1)]
+    if backend.kind == "emu":
+        shapes = [(256, 25), (257, 25), (261, 25), (48, 5), (9, 1)]
+    probs, states = [], []
+    for T, L in shapes:
+        p = rng.random((T, nc)).astype(np.float32) ** 4
+        p /= p.sum(1, keepdims=True)
+        probs.append(p.astype(np.float32)); states.append(ora32.mktargets(rng.integers(1, nc, L)))
+    al, dz, loff = ctc_via_abi(backend, probs, states)
+    for b in range(len(probs)):
+        want = ora32.ctc_align_classes(probs[b], states[b])
+        assert_close(al[loff[b]:loff[b + 1]], want, rtol=1e-4, atol=1e-6, what="aligned, line %d (T = %d)" % (b, len(probs[b])))
+        assert_close(dz[loff[b]:loff[b + 1]], want - probs[b], rtol=1e-4, atol=2e-6, what="delta, line %d" % b)
+
+
 @pytest.mark.parametrize("case", ["no_blank", "one_state", "one_frame", "all_same", "many_classes", "huge_classes"])
 def test_ctc_target_shapes(backend, ora32, case):
     """Targets as plain class lists (the Classes overload, ctc.cc:136-146): the short-line path classifies the
