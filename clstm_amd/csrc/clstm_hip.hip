@@ -23,6 +23,7 @@
 #include "softmax_fused.h"
 #include "lstm_seq.h"
 #include "lstm_wide.h"
+#include "lstm_mfma.h"
 #include "ops.h"
 
 #include <algorithm>
@@ -158,7 +159,7 @@ struct StoreBias {  // out[r*ld + c] = val + bias[c]
     *reinterpret_cast<f32x4*>(out + (long long)r * ld + c) = o;
   }
 };
-static long long g_path_count[16];   // clstm_debug_path_count (diagnostics)
+static long long g_path_count[24];   // clstm_debug_path_count (diagnostics)
 struct StorePlain {
   float* out; long long ld;
   DEVMFN void operator()(int r, int c, float v, int) const { out[(long long)r * ld + c] = v; }
@@ -667,6 +668,11 @@ struct Layer {
   float* Wk = nullptr;        // k-contiguous W_x rows for the producer items of the fused forward launch (ops.h:PackFused)
   int wk_kp = 0, wk_njp = 0;
   DevBuf<float> dCc;
+  // minibatches that fill the chip: the recurrence batched over 16 lines on the f16 MFMA (lstm_mfma.h); fragments repacked when
+  // the parameters have moved (Net::params_epoch)
+  DevBuf<unsigned short> Wmf;
+  DevBuf<float> mf_scale;
+  long long mf_epoch = -1;
   DevBuf<int> pack_tab;       // source index of every packed element (k_pack_index), narrow layers in training steps
   DevBuf<int> pack_inv;       // ... and its inverse, PACK_KD packed elements per parameter (ops.h: PackDst); pack_inv_state: 0 not built, 1 ready, -1 unusable
   int pack_inv_state = 0;
@@ -711,6 +717,7 @@ struct Net {
   bool own_v = false, own_d = false, own_g = false;
   float lr = 1e-4f, mom = 0.9f, gclip = 100.0f;
   bool packed_dirty = true;
+  long long params_epoch = 0;   // bumped whenever v may have changed (set_params, params_changed, every update)
   bool bf16_gemm = false;   // hoisted gate GEMMs: bf16 in, f32 accumulate   (clstm_net_set_gemm_precision)
   bool bf16_rec = false;    // wide layers: bf16 MFMA operands in the recurrence
   bool want_dx0 = false;
@@ -913,7 +920,7 @@ struct Net {
     for (auto& y : L) {
       (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff); (void)hipFree(y.Wk);
       (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release(); y.Rf32.release(); y.R2b.release(); y.D2.release();
-      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false; y.pack_tab.release(); y.pack_inv.release(); y.pack_inv_state = 0; y.partial.release(); y.dbias.release();
+      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false; y.pack_tab.release(); y.pack_inv.release(); y.Wmf.release(); y.mf_scale.release(); y.pack_inv_state = 0; y.partial.release(); y.dbias.release();
     }
     (void)hipFree(W1k); fw_items.release(); fw_flags.release();
     for (int i = 0; i < 2; i++) { hf.xin[i].release(); if (hf.pin[i]) (void)hipHostFree(hf.pin[i]); if (hf.copied[i]) (void)hipEventDestroy(hf.copied[i]); }
@@ -1116,13 +1123,65 @@ struct Net {
     y.sx_valid = true;
   }
 
+  // ---- narrow layers, chip-filling minibatches: the recurrence batched over 16 lines per workgroup on the MFMA (lstm_mfma.h) ----
+  // fwd_mfma: 0 never, 1 (default) from 192 lines per GPU on (below that the per-line kernel's one-workgroup-per-line latency
+  // chain is shorter than a 16-line MFMA step), 2 always (tests)
+  bool mfma_eligible(const Layer& y) const {
+#ifdef CLSTM_HIP_EMU
+    return false;
+#else
+    const int mode = dbg_opt("fwd_mfma", 1);
+    if (!mode || y.wide || bf16_gemm) return false;
+    if (!(y.no == 64 || y.no == 100 || y.no == 128)) return false;
+    const double lim = 2147483000.0;   // 32-bit byte offsets inside one descriptor
+    if ((double)N * ndir * 4 * y.no * 4 >= lim || (double)N * y.ldh * 4 >= lim || (double)N * y.lds * 4 >= lim) return false;
+    return mode >= 2 || bs >= 192;
+#endif
+  }
+#ifndef CLSTM_HIP_EMU
+  template <int NO>
+  void launch_mfma_no(Layer& y, bool fwd, hipStream_t s) {
+    using Gm = MfmaGeom<NO>;
+    if (y.mf_epoch != params_epoch) {
+      y.Wmf.reserve((size_t)ndir * Gm::W_HALFS_PER_DIR + 64);
+      y.mf_scale.reserve(8);
+      MfmaPackArgs p{};
+      p.v = v; p.ni = y.ni; p.no = y.no; p.nt = Gm::NT; p.kb = Gm::KB; p.W = y.Wmf.p; p.inv_scale = y.mf_scale.p;
+      for (int d = 0; d < 2; d++) for (int q = 0; q < 4; q++) p.p_off[d][q] = y.pd.p_off[d][q];
+      CLSTM_LAUNCH(k_pack_mfma, dim3(ndir), dim3(1024), 0, s, p);
+      y.mf_epoch = params_epoch;
+    }
+    LstmMfmaArgs a{};
+    a.W = y.Wmf.p; a.inv_scale = y.mf_scale.p; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.S = y.S.p; a.dH = y.dH.p; a.D = y.D.p;
+    a.line_off = line_off.p; a.order = line_off.p + bs + 1; a.bs = bs; a.ndir = ndir; a.ldh = y.ldh; a.hofs = y.hofs;
+    a.lds = y.lds; a.sofs = 1 + y.ni; a.sdir = (long long)N * y.lds; a.N = N;
+#ifdef CLSTM_LSTM_PROF
+    lstm_prof.reserve(128); a.prof = lstm_prof.p;
+#endif
+    static const bool smem_set = (coop_set_smem(lstm_fwd_mfma_kernel<NO>, (size_t)Gm::SMEM), true);
+    (void)smem_set; (void)fwd;
+    CLSTM_LAUNCH(lstm_fwd_mfma_kernel<NO>, dim3((unsigned)((bs + 15) / 16), (unsigned)ndir), dim3(256), (size_t)Gm::SMEM, s, a);
+    g_path_count[16]++;
+  }
+#endif
+  void launch_mfma(Layer& y, bool fwd, hipStream_t s) {
+#ifndef CLSTM_HIP_EMU
+    if (y.no == 64) launch_mfma_no<64>(y, fwd, s);
+    else if (y.no == 100) launch_mfma_no<100>(y, fwd, s);
+    else launch_mfma_no<128>(y, fwd, s);
+    check_launch();
+#else
+    (void)y; (void)fwd; (void)s;
+#endif
+  }
+
   void forward() {
     REQUIRE(N > 0, "set_batch first");
     RoctxRange range_("clstm:forward");
     flush_line_off();
     repack();
     hipStream_t s = stream();
-    if (forward_fused_eligible()) { forward_fused(); return; }
+    if (forward_fused_eligible() && !(L.size() == 1 && mfma_eligible(L[0]))) { forward_fused(); return; }
     for (int l = 0; l < (int)L.size(); l++) {
       Layer& y = L[l];
       const int M = ndir * 4 * y.no;
@@ -1145,7 +1204,8 @@ struct Net {
           if (l > 0 && !from16) ensure_h_f32(l - 1);
           // x columns that fill whole tiles of the weight-gradient GEMM are not copied: the GEMM reads them from Hbf itself
           const int R_ = 1 + y.ni + y.no, Cn_ = 4 * y.no;
-          y.sbf_x_external = from16 && y.ni % (gemm_tile256(R_, Cn_) ? 256 : GB2_BT) == 0;
+          // (for BOTH row counts the backward pass may launch with: R_, and R_ - 1 when the bias row is left out)
+          y.sbf_x_external = from16 && y.ni % gemm_mc_rows_per_tile(R_, Cn_) == 0 && y.ni % gemm_mc_rows_per_tile(R_ - 1, Cn_) == 0;
           if (y.sbf_x_external) {
             if (y.sbf_one_key != (long long)N) {
               CLSTM_LAUNCH(k_source_one_bf16, dim3(nblocks((size_t)N)), dim3(256), 0, s, y.Sbf.p, (size_t)N, y.ni + y.no, w.sbf_ld, ndir, w.sbf_dir);
@@ -1223,7 +1283,9 @@ struct Net {
       if (y.wide) run_wide(wide_args(y, true), 0);
       else {
         timing.begin("lstm_fwd", s);
-        launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s); y.h_f32_valid = y.sh_valid = true;
+        if (mfma_eligible(y)) launch_mfma(y, true, s);
+        else launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
+        y.h_f32_valid = y.sh_valid = true;
         timing.end(s);
       }
       if (!y.sbf_ready) ensure_source_x(l);
@@ -1545,6 +1607,7 @@ struct Net {
     nbackward++;
     RoctxRange range_("clstm:backward");
     update_applied = false;
+    pending_red.clear();   // (entries a throwing pass left behind must not be reduced -- or, with the update fused in, APPLIED -- by this one)
     flush_line_off();
     repack();
     hipStream_t s = stream();
@@ -1802,6 +1865,7 @@ struct Net {
   void update() {
     hipStream_t s = stream();
     RoctxRange range_("clstm:update");
+    params_epoch++;
     if (update_applied) {   // done by the reductions of the backward pass just enqueued
       update_applied = false;
       packed_dirty = !packs_follow_update;
@@ -2165,12 +2229,12 @@ static void copy_d2h(float* dst, const float* src, size_t n) {
   HIPCHECK(hipStreamSynchronize(g_stream));
   check_device_errors();   // whatever is read back was produced by launches whose outcome is known now
 }
-int clstm_net_set_params_h(clstm_net* h, const float* p) { ABI_BEGIN copy_h2d(h->net.v, p, h->net.nparams); h->net.packed_dirty = true; ABI_END }
+int clstm_net_set_params_h(clstm_net* h, const float* p) { ABI_BEGIN copy_h2d(h->net.v, p, h->net.nparams); h->net.packed_dirty = true; h->net.params_epoch++; ABI_END }
 int clstm_net_get_params_h(clstm_net* h, float* p) { ABI_BEGIN copy_d2h(p, h->net.v, h->net.nparams); ABI_END }
 int clstm_net_set_derivs_h(clstm_net* h, const float* p) { ABI_BEGIN copy_h2d(h->net.d, p, h->net.nparams); ABI_END }
 int clstm_net_get_derivs_h(clstm_net* h, float* p) { ABI_BEGIN copy_d2h(p, h->net.d, h->net.nparams); ABI_END }
 int clstm_net_get_grads_h(clstm_net* h, float* p) { ABI_BEGIN copy_d2h(p, h->net.g, h->net.nparams); ABI_END }
-int clstm_net_params_changed(clstm_net* h) { h->net.packed_dirty = true; return 0; }
+int clstm_net_params_changed(clstm_net* h) { h->net.packed_dirty = true; h->net.params_epoch++; return 0; }
 int clstm_net_set_learning_rate(clstm_net* h, float lr, float mom) { h->net.lr = lr; h->net.mom = mom; return 0; }
 int clstm_net_set_gradient_clip(clstm_net* h, float c) {
   ABI_BEGIN REQUIRE(c > 0, "clip must be positive"); h->net.gclip = c; ABI_END
@@ -2726,7 +2790,7 @@ int clstm_debug_set_option(const char* name, int value) {   // experiment switch
 }
 int clstm_debug_path_count(int which, long long* out_h) {
   ABI_BEGIN
-  REQUIRE(which >= 0 && which < 16 && out_h, "bad path index");
+  REQUIRE(which >= 0 && which < 24 && out_h, "bad path index");
   *out_h = g_path_count[which];
   ABI_END
 }

@@ -16,6 +16,7 @@
 // One 32-k block costs a wave 4 ds_read_b128 + 4 MFMAs (~70 cycles) instead of 16 ds_read_b32 + 32 f32
 // MFMAs (1024 cycles); the kernel is then bound by the global->LDS staging of its 64x64 tiles.
 #pragma once
+#include <stdexcept>
 #include "dbgopt.h"
 #include "gemm_mfma.h"
 
@@ -1168,6 +1169,14 @@ inline int gemm_mc_tile_rows(int R) {
   const int p256 = (R + 255) / 256 * 256, p192 = (R + 191) / 192 * 192;
   return p192 < p256 ? 192 : 256;
 }
+// rows of one output tile of gemm_b16mc / gemm_dw_dx for an R x Cn product: an EXTERNAL x block (operand A2: rows that are not
+// copied into the source array but read from the layer below's bf16 outputs) must fill whole tiles.  The forward pass decides
+// "external" with this same function for every R the backward pass may launch with (R, and R - 1 when the bias row is left out),
+// and the launchers REFUSE an A2 that does not fit instead of dropping it (the x rows would then be read from columns nobody wrote).
+inline int gemm_mc_rows_per_tile(int R, int Cn) { return gemm_tile256(R, Cn) ? gemm_mc_tile_rows(R) : 128; }
+inline void gemm_mc_check_a2(const void* a2, int a2_rows, int th) {
+  if (a2 && a2_rows % th != 0) throw std::runtime_error("internal: external x rows of the weight-gradient product do not fill whole row tiles");
+}
 template <class FE>
 inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1,
                        GemmOperand16B A2 = GemmOperand16B{nullptr, 0, 0, 0}, int a2_rows = 0, int stag = -1) {
@@ -1183,7 +1192,7 @@ inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, F
   if (big) {
     const int th = gemm_mc_tile_rows(R);
     dim3 grid((Cn + 255) / 256, (R + th - 1) / th, nsplit * nbatch);
-    if (a2_rows % th != 0) A2.p = nullptr;
+    gemm_mc_check_a2(A2.p, a2_rows, th);
     const bool dma_ok = stag >= 2 && (A.ld & 7) == 0 && (B.ld & 7) == 0 && (A.bstride & 7) == 0 && (B.bstride & 7) == 0 && (!A2.p || (A2.ld & 7) == 0) &&
                         ksplit >= 2 * GB_BK && ksplit % GB_BK == 0 && (((size_t)A.p | (size_t)B.p | (size_t)A2.p) & 15) == 0;
     if (dma_ok) {   // operand tiles by LDS-DMA (16-byte aligned chunks, slabs of whole blocks)
@@ -1199,7 +1208,7 @@ inline void gemm_b16mc(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, F
     return;
   }
   dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);
-  if (a2_rows % GB2_BT != 0) A2.p = nullptr;
+  gemm_mc_check_a2(A2.p, a2_rows, GB2_BT);
   CLSTM_LAUNCH((gemm_b16mc_kernel<FE, 4, 1>), grid, dim3(256), 0, stream, A, B, fe, R, Cn, K, ksplit, nsplit, A2, a2_rows);
 }
 
@@ -1209,12 +1218,13 @@ inline bool gemm_dw_dx(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, F
                        GemmOperand16 XA, GemmOperand16 XB, FEX fex, int XR, int XCn, int XK) {
   if (gemm_stag_default() != 2 || !gemm_tile256(R, Cn) || !gemm_tile256(XR, XCn)) return false;
   if (XK % GB_BK != 0 || XK < 2 * GB_BK || (XA.ld & 7) != 0 || (XB.ld & 7) != 0 || R <= 0 || Cn <= 0 || K <= 0) return false;
+  if ((((size_t)XA.p | (size_t)XB.p) & 15) != 0) return false;   // the x.d role stages by LDS-DMA: 16-byte aligned operands only
   if (nsplit < 1) nsplit = 1;
   int ksplit = (K + nsplit - 1) / nsplit;
   const int kq = nsplit > 1 ? GT_PF * GB_BK : GB_BK;
   ksplit = ((ksplit + kq - 1) / kq) * kq;
   const int th = gemm_mc_tile_rows(R);
-  if (a2_rows % th != 0) A2.p = nullptr;
+  gemm_mc_check_a2(A2.p, a2_rows, th);
   const unsigned gxw = (Cn + 255) / 256, gyw = (R + th - 1) / th, gzw = nsplit * nbatch, gxx = (XCn + 255) / 256, gyx = (XR + 255) / 256;
   const dim3 grid(gxw * gyw * gzw + gxx * gyx);
   const bool wdma = (A.ld & 7) == 0 && (B.ld & 7) == 0 && (A.bstride & 7) == 0 && (B.bstride & 7) == 0 && (!A2.p || (A2.ld & 7) == 0) &&

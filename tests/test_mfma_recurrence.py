@@ -1,0 +1,80 @@
+"""The narrow layer's recurrence batched over 16 lines per workgroup on the f16 MFMA (clstm_amd/csrc/lstm_mfma.h) against the oracle.
+
+-m gpu only: the kernels exist for gfx950 alone (the host emulator keeps the per-line kernels).  The path is forced onto small
+minibatches (experiment switch fwd_mfma=2; the default takes it from 192 lines per GPU on); `run_case` then checks EVERY saved
+activation (gi, gf, go, ci, c, h of both directions, 1e-4 relative: BASELINE.json north_star), the softmax outputs, bit-exact
+decodes, CTC, every gate delta, the minibatch gradient and the update -- and the path counter proves the MFMA kernel really ran.
+Reference semantics: /root/reference/clstm.cc:600-653, clstm_compute.cc:275-320,504-547."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from test_net_parity import run_case, set_opt, _forget_debug_options  # noqa: F401  (autouse fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def backend():
+    from common import Backend
+    return Backend("hip")
+
+
+def _count(backend, which):
+    out = ctypes.c_longlong(0)
+    backend.lib.call("clstm_debug_path_count", which, ctypes.byref(out))
+    return out.value
+
+
+@pytest.mark.parametrize("nh,T", [
+    (100, [40, 23, 1, 70]),                                  # one partial group, a 1-frame line, ragged
+    (100, [31] * 16),                                        # exactly one full group
+    (100, [20, 37, 5, 64, 33, 12, 50, 41, 8, 29, 64, 3, 17, 45, 26, 58, 11, 39, 2, 61, 30, 7, 52, 19, 44,
+           35, 9, 63, 24, 48, 15, 56, 28]),                  # 33 lines: two full groups and one line in a third
+    (64, [25, 40, 13]),                                      # the 64-cell instantiation (no unpaired tile)
+    (128, [18, 33]),                                         # the 128-cell instantiation
+])
+def test_mfma_recurrence_vs_oracle(backend, ora32, nh, T):
+    set_opt(backend, "fwd_mfma", 2)
+    before = _count(backend, 16)
+    run_case(backend, ora32, 48, nh, 83, T, scale=10.0)
+    assert _count(backend, 16) > before, "the MFMA recurrence did not run"
+
+
+def test_mfma_recurrence_large_weights(backend, ora32):
+    """init x 60: saturated gates and |R| of order 1 -- the power-of-two scaling of the f16 split must follow the weights"""
+    set_opt(backend, "fwd_mfma", 2)
+    run_case(backend, ora32, 48, 100, 83, [50, 44, 37, 29, 18], scale=60.0, ctc_rtol=1e-3, grad_tol=1e-3)
+
+
+def test_mfma_second_step_repacks(backend, ora32):
+    """the fragments follow the parameters: two training steps, the second against the oracle's second"""
+    from clstm_amd.net import Network
+    from common import assert_close, oracle_minibatch, synth_lines
+    from oracle.oracle import OracleNet
+    set_opt(backend, "fwd_mfma", 2)
+    rng = np.random.default_rng(5)
+    ni, nh, nc, T = 48, 100, 83, [33, 21, 40, 12, 27]
+    ref = OracleNet(ora32, ni, nh, nc, seed=0.222)
+    params = ref.get_params() * 10.0
+    net = Network(ni, nh, nc, lib=backend.lib)
+    net.set_params(params)
+    net.setLearningRate(1e-2, 0.9)
+    onet = None
+    for step in range(2):
+        lines = synth_lines(rng, T, ni)
+        trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+        want = oracle_minibatch(ora32, OracleNet, params if onet is None else onet.get_params(), ni, nh, nc, lines, trs,
+                                derivs0=None if onet is None else onet.get_derivs(), lr=1e-2, mom=0.9)
+        net.set_inputs(lines)
+        net.forward()
+        got = net.split(net.outputs())
+        for b in range(len(T)):
+            assert_close(got[b], want["outputs"][b], what="step %d outputs line %d" % (step, b))
+        net.ctc(trs)
+        net.backward()
+        net.update()
+        want["net"].update()
+        onet = want["net"]
+    assert_close(net.get_params(), onet.get_params(), rtol=1e-4, atol=1e-6, what="params after two updates")
