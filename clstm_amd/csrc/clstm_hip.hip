@@ -1132,16 +1132,18 @@ struct Net {
 #else
     const int mode = dbg_opt("fwd_mfma", 1);
     if (!mode || y.wide || bf16_gemm) return false;
-    if (!(y.no == 64 || y.no == 100 || y.no == 128)) return false;
+    if (!((y.no == 64 || y.no == 100 || y.no == 128) && y.ni == 48)) return false;   // the instantiated (cells, inputs) geometries
     const double lim = 2147483000.0;   // 32-bit byte offsets inside one descriptor
     if ((double)N * ndir * 4 * y.no * 4 >= lim || (double)N * y.ldh * 4 >= lim || (double)N * y.lds * 4 >= lim) return false;
+    if ((double)N * layer_input_ld((int)(&y - L.data())) * 4 >= lim) return false;
     return mode >= 2 || bs >= 192;
 #endif
   }
 #ifndef CLSTM_HIP_EMU
-  template <int NO>
+  template <int NO, int NI>
   void launch_mfma_no(Layer& y, bool fwd, hipStream_t s) {
-    using Gm = MfmaGeom<NO>;
+    using Gm = MfmaGeom<NO, NI>;
+    const int l = (int)(&y - L.data());
     if (y.mf_epoch != params_epoch) {
       y.Wmf.reserve((size_t)ndir * Gm::W_HALFS_PER_DIR + 64);
       y.mf_scale.reserve(8);
@@ -1155,20 +1157,21 @@ struct Net {
     a.W = y.Wmf.p; a.inv_scale = y.mf_scale.p; a.G = y.G.p; a.C = y.C.p; a.H = y.H.p; a.S = y.S.p; a.dH = y.dH.p; a.D = y.D.p;
     a.line_off = line_off.p; a.order = line_off.p + bs + 1; a.bs = bs; a.ndir = ndir; a.ldh = y.ldh; a.hofs = y.hofs;
     a.lds = y.lds; a.sofs = 1 + y.ni; a.sdir = (long long)N * y.lds; a.N = N;
+    a.X = layer_input(l); a.ldx = layer_input_ld(l); a.store_s = 1; a.dbg = dbg_opt("mfma_dbg", 0);
 #ifdef CLSTM_LSTM_PROF
     lstm_prof.reserve(128); a.prof = lstm_prof.p;
 #endif
-    static const bool smem_set = (coop_set_smem(lstm_fwd_mfma_kernel<NO>, (size_t)Gm::SMEM), true);
+    static const bool smem_set = (coop_set_smem(lstm_fwd_mfma_kernel<NO, NI>, (size_t)Gm::SMEM), true);
     (void)smem_set; (void)fwd;
-    CLSTM_LAUNCH(lstm_fwd_mfma_kernel<NO>, dim3((unsigned)((bs + 15) / 16), (unsigned)ndir), dim3(256), (size_t)Gm::SMEM, s, a);
+    CLSTM_LAUNCH((lstm_fwd_mfma_kernel<NO, NI>), dim3((unsigned)((bs + 15) / 16), (unsigned)ndir), dim3(256), (size_t)Gm::SMEM, s, a);
     g_path_count[16]++;
   }
 #endif
   void launch_mfma(Layer& y, bool fwd, hipStream_t s) {
 #ifndef CLSTM_HIP_EMU
-    if (y.no == 64) launch_mfma_no<64>(y, fwd, s);
-    else if (y.no == 100) launch_mfma_no<100>(y, fwd, s);
-    else launch_mfma_no<128>(y, fwd, s);
+    if (y.no == 64) launch_mfma_no<64, 48>(y, fwd, s);
+    else if (y.no == 100) launch_mfma_no<100, 48>(y, fwd, s);
+    else launch_mfma_no<128, 48>(y, fwd, s);
     check_launch();
 #else
     (void)y; (void)fwd; (void)s;
@@ -1245,6 +1248,17 @@ struct Net {
       }
       if (fx_done) { if (!y.sbf_ready) ensure_source_x(l); continue; }
       if (l > 0 && !x_from_hbf) ensure_h_f32(l - 1);   // the products below read the f32 outputs of the layer underneath
+      if (mfma_eligible(y)) {
+        // chip-filling minibatch of a narrow layer: the input product is part of the batched recurrence (lstm_mfma.h) -- no
+        // hoisted W_x GEMM, no pre-activation array; the [1 | x] columns of the source rows are still the weight gradient's
+        y.sx_valid = l == 0 && src0_ready;
+        ensure_source_x(l);
+        timing.begin("lstm_fwd", s);
+        launch_mfma(y, true, s);
+        y.h_f32_valid = y.sh_valid = true;
+        timing.end(s);
+        continue;
+      }
       timing.begin("gemm_gates_x", s);
       if (x_from_hbf)
       {
@@ -1283,9 +1297,7 @@ struct Net {
       if (y.wide) run_wide(wide_args(y, true), 0);
       else {
         timing.begin("lstm_fwd", s);
-        if (mfma_eligible(y)) launch_mfma(y, true, s);
-        else launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
-        y.h_f32_valid = y.sh_valid = true;
+        launch_lstm(true, y.nk4, y.pd.ku, a, bs, y.nthreads, s); y.h_f32_valid = y.sh_valid = true;
         timing.end(s);
       }
       if (!y.sbf_ready) ensure_source_x(l);

@@ -1,34 +1,40 @@
-// lstm_mfma.h -- the NARROW layer's recurrence batched over lines on the matrix cores (minibatches that fill the chip).
+// lstm_mfma.h -- the NARROW layer's forward recurrence batched over lines on the matrix cores (minibatches that fill the chip).
 //
 // lstm_seq.h walks one line per workgroup: R.h_{t-1} is 100 x 100 x 4 packed f32 FMAs per line and step, the MFMA pipes idle,
 // and once every CU holds two such workgroups (256 lines) the kernel is VALU-bound (27 % of the f32 vector peak).  Here ONE
-// workgroup owns 16 lines x one direction and the per-step product of GenericNPLSTM::forward (clstm.cc:612-620: four
-// forward_full1 = forward_lin1 + forward_nonlin0, clstm_compute.cc:275-314) is a real GEMM
-//     pre[4 no x 16 lines] = R[4 no x no] . h_{t-1}[no x 16 lines]  (+ the hoisted W_x.x_t + b, gemm_mfma.h)
-// on v_mfma_f32_16x16x32_f16 with f32 accumulation.
+// workgroup owns 16 lines x one direction and the WHOLE gate product of GenericNPLSTM::forward (clstm.cc:612-620:
+// forward_stack_delay + four forward_full1 = forward_lin1 + forward_nonlin0, clstm_compute.cc:275-314, 377-397) is a real GEMM
+//     pre[4 no x 16 lines] = [R | W_x | b][4 no x (no + ni + 1)] . [h_{t-1} ; x_t ; 1][(no + ni + 1) x 16 lines]
+// on v_mfma_f32_16x16x32_f16 with f32 accumulation: no hoisted W_x GEMM in front of this kernel, no pre-activation array.
+// (Round 6, v1 read the hoisted product's pre-activations back row by row: 70 KB of global traffic per step on ONE CU, 28 B/clk,
+// 2,500 cycles per step for the memory pipeline alone -- profiles/r06_mfma_v1_phase_cycles_256.txt.  With x_t as 48 more k the
+// input side of a step is 3 KB.)
 //
 // Arithmetic.  Both operands are f32 values split into TWO f16 terms, x = hi + lo with hi = f16(x), lo = f16(x - hi) (the
-// difference is exact), after a power-of-two scaling that keeps lo out of the f16 subnormal range (R by 2^e with max |R| 2^e in
-// [2^13, 2^14), h in [-1, 1] by 2^8; the inverse scale rides the fma that adds the input part).  f16 carries 11 significant
+// difference is exact), after a power-of-two scaling that keeps lo out of the f16 subnormal range ([R | W_x | b] by 2^e with
+// max |.| 2^e in [2^13, 2^14); h in [-1, 1], x and the constant 1 by 2^8: inputs must stay below 255 in magnitude, normalised
+// text lines are in [0, 1]; the inverse scale rides the multiply in front of the gate nonlinearity).  f16 carries 11 significant
 // bits, so hi + lo represents x to 2^-22 |x| or better (f32 itself: 2^-24), each f16 x f16 product is exact in the f32
 // accumulator, and a product is hi.hi + hi.lo + lo.hi: what is dropped (lo.lo) is < 2^-22 |x y|.  That is the f32 MFMA's
 // accuracy class at 5x its rate, NOT the 2^-16 of a bf16 hi + lo split.  Parity: every saved activation within 1e-4 of the
 // oracle (tests/test_mfma_recurrence.py).
 //
-// Geometry (NO cells, NO % 4 == 0, NO <= 128).  M = gate rows in tiles of 16 = 4 cells x 4 gates (row m = 4 cs + q, q = 0 gi,
-// 1 gf, 2 go, 3 ci), N = 16 lines, K = cells in blocks of 32.  In the MFMA's result layout lane l = 16 cs + n then holds the
-// FOUR gates of ONE cell for ONE line (rows 4 (l >> 4) + i, column l & 15): forward_statemem / forward_nonlingate
-// (clstm_compute.cc:504-537) are lane-local.  Tiles come in pairs (2p, 2p + 1) holding cells 8p + 2cs and 8p + 2cs + 1, so that
-// a lane packs the two h values it produces into one dword of the next step's B operand.  Four waves, one per SIMD; wave w keeps
-// the hi and lo A fragments of its pairs (and, for an odd tile count, wave 0 the last tile) in registers for the whole
-// sequence: 25 tiles x 4 k-blocks x 2 x 4 registers = 200 KB of the CU's 512 KB file at NO = 100.
+// Geometry (NO cells, NO % 4 == 0, NO <= 128; NI inputs, NI % 4 == 0, NI <= 64).  M = gate rows in tiles of 16 = 4 cells x 4
+// gates (row m = 4 cs + q, q = 0 gi, 1 gf, 2 go, 3 ci), N = 16 lines, K = [cells | inputs | 1] in blocks of 32.  In the MFMA's
+// result layout lane l = 16 cs + n then holds the FOUR gates of ONE cell for ONE line (rows 4 (l >> 4) + i, column l & 15):
+// forward_statemem / forward_nonlingate (clstm_compute.cc:504-537) are lane-local.  Tiles come in pairs (2p, 2p + 1) holding
+// cells 8p + 2cs and 8p + 2cs + 1, so that a lane packs the two h values it produces into one dword of the next step's B
+// operand, and the two tiles of a pair are two INDEPENDENT accumulator chains that alternate on the matrix pipe (an MFMA behind
+// its own predecessor is forwarded only when nothing sits between them; the epilogue's VALU work is meant to sit there).  Four
+// waves, one per SIMD; wave w keeps the hi and lo A fragments of its pairs (and, for an odd tile count, one wave the last tile)
+// in registers for the whole sequence: 25 tiles x 5 k-blocks x 2 x 4 registers = 250 KB of the CU's 512 KB file at NO = 100.
 //
 // Memory.  The result layout spreads a row of G / C / H over 16-byte pieces of 16 different frames per instruction -- hopeless
 // for the memory pipeline.  Every global access is therefore row-contiguous (wave w moves lines 4w .. 4w + 3) and LDS does the
-// transposition: pre-activations are fetched two steps ahead into registers, written to an LDS row image [line][cell ^ line]
-// (16-byte slots, XOR-swizzled: conflict-free for the row writes, for the per-tile reads of the epilogue and for both sides of
-// the activation image going out), activations / c / h go through the same kind of image and leave at the top of the NEXT step.
-// Two barriers per step: B1 (h_t, the output images and the free input image), B2 (the input image, the free output images).
+// transposition: activations / c / h go through an LDS row image [line][cell ^ line] (16-byte slots, XOR-swizzled:
+// conflict-free for the epilogue's per-tile writes and for the row reads going out) that is double-buffered, and leave -- spread
+// over the NEXT step's MFMA stream, so that the memory pipeline drains beside the matrix pipe instead of in front of it.  One
+// barrier per step.
 #pragma once
 #include "devintrin.h"
 #ifndef CLSTM_HIP_EMU
@@ -36,49 +42,58 @@
 namespace clstm {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int MF_HS = 8;   // h is scaled by 2^MF_HS before the f16 split
+constexpr int MF_HS = 8;   // h, x and the constant 1 are scaled by 2^MF_HS before the f16 split
 
 struct LstmMfmaArgs {
   const unsigned short* W;   // A fragments [dir][tile][k-block][hi | lo][lane][8 halfs]   (k_pack_mfma)
   const float* inv_scale;    // [dir] 2^-(e + MF_HS)
-  float *G, *C, *H, *S;      // as LstmSeqArgs
+  const float* X; int ldx;   // the layer's input frames [N][ldx]
+  float *G, *C, *H, *S;      // as LstmSeqArgs (G: activations out only)
   const float* dH; float* D;
   const int* line_off;
   const int* order;          // [bs] lines, longest first (a group of 16 consecutive entries shares a workgroup), or null
   int bs, ndir, ldh, hofs, lds, sofs;
+  int dbg;                   // experiments (mfma_dbg): 1 no activation-row stores, 2 no c / h / source stores, 4 no input loads
+  int store_s;               // 1: deposit h_t in the next frame's source row (else k_source_h rebuilds those columns from H)
   long long sdir;
   long long N;               // frames in the batch
   long long* prof;           // diagnostics build (-DCLSTM_LSTM_PROF): [4 waves][8] summed phase cycles of workgroup (0, 0)
 };
 
-template <int NO>
+template <int NO, int NI>
 struct MfmaGeom {
-  static_assert(NO % 4 == 0 && NO >= 16 && NO <= 128, "cells");
-  static constexpr int NT = NO / 4, FP = NT / 2, SINGLE = NT & 1, PPW = (FP + 3) / 4, KB = (NO + 31) / 32, NCH = 4 * KB;
+  static_assert(NO % 4 == 0 && NO >= 16 && NO <= 128 && NI % 4 == 0 && NI >= 4 && NI <= 64, "cells / inputs");
+  static constexpr int NT = NO / 4, FP = NT / 2, SINGLE = NT & 1, PPW = (FP + 3) / 4;
+  static constexpr int KT = NO + NI + 1, KB = (KT + 31) / 32, NCH = 4 * KB;   // k = [cells | inputs | 1 | zero pad]
   static constexpr int TPW = 2 * PPW + SINGLE;
   static constexpr int SW = (FP % PPW == 0 && FP / PPW == 4) ? 0 : 3;   // the wave that takes the unpaired tile
   static constexpr int SLOTS = (NO + 15) / 16 * 16;   // 16-byte slots (one per cell) in a staged row of gate values
   static constexpr int RS = SLOTS * 16, RH = (SLOTS + 63) / 64;
-  static constexpr int PART = NCH * 256, HBUF = 2 * PART;   // h image: [buffer][hi | lo][chunk of 8 cells][16 lines][8 halfs]
-  static constexpr int GXS_OFF = 2 * HBUF, ACT_OFF = GXS_OFF + 16 * RS, CS_OFF = ACT_OFF + 16 * RS, HS_OFF = CS_OFF + 16 * NO * 4;
-  static constexpr int SMEM = HS_OFF + 16 * NO * 4;
+  static constexpr int PART = NCH * 256, HBUF = 2 * PART;   // B image: [buffer][hi | lo][chunk of 8 k][16 lines][8 halfs]
+  static constexpr int OUT_OFF = 2 * HBUF, CS_REL = 16 * RS, HS_REL = CS_REL + 16 * NO * 4, OUTSZ = HS_REL + 16 * NO * 4;
+  static constexpr int WS_OFF = OUT_OFF + 2 * OUTSZ;        // the unpaired tile's A fragments [k-block][hi | lo][lane][16 bytes]
+  static constexpr int DUMP_OFF = WS_OFF + SINGLE * KB * 2048;   // where lanes without a datum write
+  static constexpr int SMEM = DUMP_OFF + 64;
   static constexpr long long W_HALFS_PER_DIR = (long long)NT * KB * 2 * 64 * 8;
 };
 
-// ---- packing: one workgroup per direction finds max |R|, picks the scale and writes the fragments -------------------------
-// PackDesc (ops.h) as the other packs: R_q(cell, k) = v[p_off[dir][q] + cell + no (1 + ni + k)]   (tensor.h:263-264)
+// ---- packing: one workgroup per direction finds max |[R | W_x | b]|, picks the scale and writes the fragments -------------
+// PackDesc (ops.h) as the other packs: W_q(cell, col) = v[p_off[dir][q] + cell + no col], col 0 bias, 1 + j input j,
+// 1 + ni + k cell k (tensor.h:263-264); k of the product: [cells | inputs | bias]
 struct MfmaPackArgs { const float* v; long long p_off[2][4]; int ni, no, nt, kb; unsigned short* W; float* inv_scale; };
+DEVFN int mfma_pack_col(int k, int no, int ni) { return k < no ? 1 + ni + k : (k < no + ni ? 1 + (k - no) : (k == no + ni ? 0 : -1)); }
 __global__ __launch_bounds__(1024) void k_pack_mfma(MfmaPackArgs p) {
   __shared__ float red[16];
   __shared__ int e_sh;
   const int dir = blockIdx.x, tid = threadIdx.x;
-  const int no = p.no;
+  const int no = p.no, ncol = 1 + p.ni + no;
   float mx = 0.0f;
-  for (int i = tid; i < 4 * no * no; i += 1024) {
-    const int q = i / (no * no), r = i % (no * no);
-    const float x = fabsf(p.v[p.p_off[dir][q] + (r % no) + (long long)no * (1 + p.ni + r / no)]);
+  for (int i = tid; i < 4 * no * ncol; i += 1024) {
+    const int q = i / (no * ncol), r = i % (no * ncol);
+    const float x = fabsf(p.v[p.p_off[dir][q] + r]);
     mx = x > mx ? x : mx;   // (NaN compares false: a non-finite parameter leaves the scale alone and surfaces in the outputs)
   }
   mx = wave_max(mx);
@@ -102,8 +117,8 @@ __global__ __launch_bounds__(1024) void k_pack_mfma(MfmaPackArgs p) {
     const int m = lane & 15, cs = m >> 2, q = m & 3;
     const int pr = tile >> 1, r = tile & 1;
     const int cell = pr < FP ? 8 * pr + 2 * cs + r : 8 * FP + cs;
-    const int k = kb * 32 + 8 * (lane >> 4) + j;
-    const float x = (cell < no && k < no) ? p.v[p.p_off[dir][q] + cell + (long long)no * (1 + p.ni + k)] * sc : 0.0f;
+    const int col = mfma_pack_col(kb * 32 + 8 * (lane >> 4) + j, no, p.ni);
+    const float x = (cell < no && col >= 0) ? p.v[p.p_off[dir][q] + cell + (long long)no * col] * sc : 0.0f;
     const _Float16 hi = (_Float16)x;
     const _Float16 lo = (_Float16)(x - (float)hi);
     unsigned short* dst = p.W + dir * per_dir + ((long long)(tile * p.kb + kb) * 2) * 512 + lane * 8 + j;
@@ -122,10 +137,13 @@ DEVFN f32x4 buf_load4_s(BufF32 b, unsigned lane_off, unsigned uniform_off) {
 DEVFN void buf_store4_s(BufF32 b, unsigned lane_off, unsigned uniform_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b.r, lane_off, uniform_off, 0);
 }
+// instruction-group hints for the scheduler (IGroupLP): the next `n` instructions of class `mask` in program order
+#define MF_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_W = 0x40, SG_DS_R = 0x100, SG_DS_W = 0x200;
 
-template <int NO>
+template <int NO, int NI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_mfma_kernel(LstmMfmaArgs a) {
-  using Gm = MfmaGeom<NO>;
+  using Gm = MfmaGeom<NO, NI>;
   constexpr int PPW = Gm::PPW, KB = Gm::KB, TPW = Gm::TPW, RH = Gm::RH, RS = Gm::RS;
   char* const smem = dyn_smem<char>();
   const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
@@ -147,35 +165,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int j = 0; j < 4; j++) { offj[j] = __builtin_amdgcn_readlane(off, 4 * w + j); Tj[j] = __builtin_amdgcn_readlane(T, 4 * w + j); }
   if (Tmax <= 0) return;
 
-  // A fragments (hi, lo) of this wave's tiles, resident for the whole sequence
-  f16x8 Wh[TPW][KB], Wl[TPW][KB];
+  // A fragments (hi, lo) of this wave's tiles, resident for the whole sequence (a wave without the unpaired tile: zeros)
+  // (the unpaired tile's fragments stay in LDS and are read every step: with them wave SW would need 7 x 5 x 8 = 280 operand
+  //  registers, more than the 256 of the accumulation half of the file, and hipcc then shuttles EVERY fragment through
+  //  v_accvgpr_read in front of its MFMA -- 4 VALU instructions per MFMA)
+  f16x8 Wh[2 * PPW][KB], Wl[2 * PPW][KB];
 #pragma unroll
-  for (int i = 0; i < TPW; i++) {
+  for (int i = 0; i < 2 * PPW; i++) {
     const int pr = w * PPW + (i >> 1);
-    const bool act = i < 2 * PPW ? pr < Gm::FP : w == Gm::SW;
-    const int tile = i < 2 * PPW ? 2 * pr + (i & 1) : 2 * Gm::FP;
+    const bool act = pr < Gm::FP;
+    const int tile = 2 * pr + (i & 1);
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
-      const unsigned short* wp = a.W + dir * Gm::W_HALFS_PER_DIR + ((long long)(tile * KB + kb) * 2) * 512 + lane * 8;
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      Wh[i][kb] = __builtin_bit_cast(f16x8, act ? *reinterpret_cast<const u32x4*>(wp) : z);
-      Wl[i][kb] = __builtin_bit_cast(f16x8, act ? *reinterpret_cast<const u32x4*>(wp + 512) : z);
+      const unsigned short* wp = a.W + dir * Gm::W_HALFS_PER_DIR + ((long long)((act ? tile : 0) * KB + kb) * 2) * 512 + lane * 8;
+      const u32x4 vh = *reinterpret_cast<const u32x4*>(wp), vl = *reinterpret_cast<const u32x4*>(wp + 512);
+      const unsigned keep = act ? 0xFFFFFFFFu : 0u;
+      Wh[i][kb] = __builtin_bit_cast(f16x8, (u32x4){vh[0] & keep, vh[1] & keep, vh[2] & keep, vh[3] & keep});
+      Wl[i][kb] = __builtin_bit_cast(f16x8, (u32x4){vl[0] & keep, vl[1] & keep, vl[2] & keep, vl[3] & keep});
     }
   }
   const float inv = a.inv_scale[dir];
-  for (int i = tid * 16; i < 2 * Gm::HBUF; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = (u32x4){0u, 0u, 0u, 0u};   // h_{-1} = 0
+  const float sig_k = inv * ACT_SIG_SCALE, tanh_k = inv * ACT_TANH_SCALE;   // (powers of two times a constant: exact products)
+  // B image: h_{-1} = 0, zero padding, and the constant 1 behind the inputs (both buffers)
+  for (int i = tid * 16; i < 2 * Gm::HBUF; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = (u32x4){0u, 0u, 0u, 0u};
+  if (Gm::SINGLE)
+    for (int i = tid; i < KB * 128; i += 256)
+      *reinterpret_cast<u32x4*>(smem + Gm::WS_OFF + i * 16) =
+          *reinterpret_cast<const u32x4*>(a.W + dir * Gm::W_HALFS_PER_DIR + (long long)(2 * Gm::FP) * KB * 1024 + i * 8);
+  __syncthreads();
+  if (tid < 32) {
+    constexpr int kone = NO + NI;
+    const _Float16 one = (_Float16)(float)(1 << MF_HS);
+    *reinterpret_cast<_Float16*>(smem + (tid >> 4) * Gm::HBUF + ((kone >> 3) * 16 + (tid & 15)) * 16 + (kone & 7) * 2) = one;
+  }
 
   // ---- global side: whole rows, wave w owns lines 4w .. 4w+3 ----
   const unsigned gstr = (unsigned)nd * 4 * NO * 4, cstr = (unsigned)nd * NO * 4, hstr = (unsigned)a.ldh * 4, sstr = (unsigned)a.lds * 4;
+  const unsigned xstr = (unsigned)a.ldx * 4;
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * gstr);
   const BufF32 cbuf = make_buf(a.C, (size_t)a.N * cstr);
   const BufF32 hbuf = make_buf(a.H, (size_t)a.N * hstr);
   const BufF32 sbuf = make_buf(a.S + (size_t)dir * a.sdir, (size_t)a.N * sstr);
+  const BufF32 xbuf = make_buf(a.X, (size_t)a.N * xstr);
   unsigned gvo[RH];   // gate rows: lane = cell (16 bytes) within the half row
 #pragma unroll
   for (int hh = 0; hh < RH; hh++) gvo[hh] = 64 * hh + lane < NO ? (unsigned)(64 * hh + lane) * 16u : BUF_OOB_BASE;
   // scalar row state: frame of step t of line j (Reversed = index arithmetic, clstm.cc:458-478)
-  auto row_valid = [&](int j, int t) { return t < Tj[j]; };
+  auto row_valid = [&](int j, int t) { return (unsigned)t < (unsigned)Tj[j]; };   // (t = -1: no)
   auto row_tok = [&](int j, int t) { return offj[j] + (dir == 0 ? t : Tj[j] - 1 - t); };
   auto oob_if = [&](bool ok) -> unsigned { return ok ? 0u : 0x80000000u; };
   // c / h rows leave two lines per instruction (lanes 0-31 / 32-63, 16 bytes = 4 cells per lane)
@@ -188,9 +224,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     Tr[i] = __shfl(T, row, 64);
   }
   const unsigned chl = l5 < NO / 4 ? (unsigned)l5 * 16u : BUF_OOB_BASE;
+  const unsigned s_off_mask = a.store_s ? 0u : 0x80000000u;
+  const unsigned dbg_g = (a.dbg & 1) ? 0x80000000u : 0u, dbg_ch = (a.dbg & 2) ? 0x80000000u : 0u, dbg_x = (a.dbg & 4) ? 0x80000000u : 0u;
+  // input frames: lane = (line 4w + (lane >> 4), float4 lane & 15 of its frame)
+  const int xq = lane & 15, xrow = 4 * w + (lane >> 4);
+  const int offx = __shfl(off, xrow, 64), Tx = __shfl(T, xrow, 64);
+  const unsigned xvl = xq < NI / 4 ? (unsigned)xq * 16u : BUF_OOB_BASE;
+  // (validity as arithmetic, never as control flow: a branch inside a step ends the scheduling region the MFMA stream and the
+  //  work beside it are interleaved in)
+  auto oob_lane = [&](int t, int Tl) -> unsigned { return ~(unsigned)((t - Tl) >> 31) & 0x80000000u; };   // 0 while 0 <= t < Tl ...
+  auto load_x = [&](int t) -> f32x4 {
+    const unsigned tok = (unsigned)(offx + (dir == 0 ? t : Tx - 1 - t));
+    return buf_load4(xbuf, (tok * xstr + xvl) | oob_lane(t, Tx) | dbg_x);
+  };
+  // k = NO + 4 xq .. + 3 of line xrow (lanes without an input: the dump slot)
+  const unsigned xwo_h = xq < NI / 4 ? (unsigned)((((NO + 4 * xq) >> 3) * 16 + xrow) * 16 + ((NO + 4 * xq) & 7) * 2) : 0u;
+  auto put_x = [&](char* img, f32x4 x) {   // two f16 terms of 2^8 x into the B image
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float xs = x[e] * (float)(1 << MF_HS);
+      hi[e] = (_Float16)xs;
+      lo[e] = (_Float16)(xs - (float)hi[e]);
+    }
+    char* const dst = xq < NI / 4 ? img + xwo_h : smem + Gm::DUMP_OFF;
+    *reinterpret_cast<f16x4*>(dst) = hi;
+    *reinterpret_cast<f16x4*>(dst + (xq < NI / 4 ? Gm::PART : 8)) = lo;
+  };
 
   // ---- LDS side ----
-  // epilogue, lane (cl, n), tile i: cell c -> slot (c ^ n) of row n in the gate images
+  // epilogue, lane (cl, n), tile i: cell c -> slot (c ^ n) of row n in the activation image
   unsigned gxo[TPW];
   int cellv[TPW];
 #pragma unroll
@@ -204,81 +267,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const unsigned hwo = (unsigned)(n * 16 + cl * 4);        // pairs: + 256 p (+ PART for lo); the unpaired tile: n * 16 + cl * 2
   const unsigned bfo = (unsigned)(cl * 256 + n * 16);      // B fragments: + 1024 kb (+ PART for lo)
 
-  // input pre-activations: rows of step t + 2 are requested at the top of step t
-  f32x4 gset[2][4 * RH];
-  auto load_gx = [&](int t, f32x4 (&gs)[4 * RH]) {
+  // outputs of a step leave as rows during the next one: activations (G), c, h (H and, shifted by one frame, the source rows S)
+  // (each portion reads its rows from the LDS image right in front of its stores: all twelve reads at the top of the step kept 48
+  //  registers live through the whole MFMA stream and pushed the kernel into scratch)
+  auto store_g = [&](const char* out, const int tp, const int j) {   // the activation row of line 4w + j
+    const int row = 4 * w + j;
+    f32x4 av[RH];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const bool ok = row_valid(j, t);
-      const unsigned so = ok ? (unsigned)row_tok(j, t) * gstr + (unsigned)dir * NO * 16u : 0u;
+    for (int hh = 0; hh < RH; hh++)
+      av[hh] = *reinterpret_cast<const f32x4*>(out + row * RS + (((64 * hh + lane < Gm::SLOTS ? 64 * hh + lane : 0) ^ row) << 4));
+    const bool ok = row_valid(j, tp);
+    const unsigned so = (unsigned)row_tok(j, tp) * gstr + (unsigned)dir * NO * 16u;   // (an invalid row: every lane out of range)
 #pragma unroll
-      for (int hh = 0; hh < RH; hh++) gs[j * RH + hh] = buf_load4_s(gbuf, gvo[hh] | oob_if(ok), so);
-    }
+    for (int hh = 0; hh < RH; hh++) buf_store4_s(gbuf, gvo[hh] | oob_if(ok) | dbg_g, so, av[hh]);
   };
-  auto stage_gx = [&](const f32x4 (&gs)[4 * RH]) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int row = 4 * w + j;
-#pragma unroll
-      for (int hh = 0; hh < RH; hh++)
-        if (64 * hh + lane < Gm::SLOTS)
-          *reinterpret_cast<f32x4*>(smem + Gm::GXS_OFF + row * RS + (((64 * hh + lane) ^ row) << 4)) = gs[j * RH + hh];
-    }
-  };
-  // outputs of step tp leave as rows: activations (G), c, h (H and, shifted by one frame, the source rows S)
-  auto store_rows = [&](int tp) {
-    f32x4 av[4 * RH], cv[2], hv[2];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int row = 4 * w + j;
-#pragma unroll
-      for (int hh = 0; hh < RH; hh++)
-        av[j * RH + hh] = *reinterpret_cast<const f32x4*>(smem + Gm::ACT_OFF + row * RS + (((64 * hh + lane < Gm::SLOTS ? 64 * hh + lane : 0) ^ row) << 4));
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int row = 4 * w + 2 * i + (lane >> 5);
-      const int lo = l5 < NO / 4 ? l5 : 0;
-      cv[i] = *reinterpret_cast<const f32x4*>(smem + Gm::CS_OFF + row * NO * 4 + lo * 16);
-      hv[i] = *reinterpret_cast<const f32x4*>(smem + Gm::HS_OFF + row * NO * 4 + lo * 16);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const bool ok = row_valid(j, tp);
-      const unsigned so = ok ? (unsigned)row_tok(j, tp) * gstr + (unsigned)dir * NO * 16u : 0u;
-#pragma unroll
-      for (int hh = 0; hh < RH; hh++) buf_store4_s(gbuf, gvo[hh] | oob_if(ok), so, av[j * RH + hh]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const bool ok = tp < Tr[i];
-      const unsigned tok = (unsigned)(offr[i] + (dir == 0 ? tp : Tr[i] - 1 - tp));
-      buf_store4(cbuf, ok ? tok * cstr + (unsigned)dir * NO * 4u + chl : BUF_OOB, cv[i]);
-      buf_store4(hbuf, ok ? tok * hstr + (unsigned)(a.hofs + dir * NO) * 4u + chl : BUF_OOB, hv[i]);
-      // h_t is the recurrent part of the NEXT step's source row (forward_stack_delay, clstm_compute.cc:377-397)
-      const bool oks = tp + 1 < Tr[i];
-      const unsigned toks = (unsigned)(offr[i] + (dir == 0 ? tp + 1 : Tr[i] - 2 - tp));
-      buf_store4(sbuf, oks ? toks * sstr + (unsigned)a.sofs * 4u + chl : BUF_OOB, hv[i]);
-    }
+  auto store_ch = [&](const char* out, const int tp, const int i) {  // c, h of lines 4w + 2i, 4w + 2i + 1
+    const int row = 4 * w + 2 * i + (lane >> 5);
+    const int lo = l5 < NO / 4 ? l5 : 0;
+    const f32x4 cv = *reinterpret_cast<const f32x4*>(out + Gm::CS_REL + row * NO * 4 + lo * 16);
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(out + Gm::HS_REL + row * NO * 4 + lo * 16);
+    const unsigned bad = oob_lane(tp, Tr[i]) | (unsigned)(tp >> 31 & 0x80000000) | dbg_ch;
+    const unsigned tok = (unsigned)(offr[i] + (dir == 0 ? tp : Tr[i] - 1 - tp));
+    buf_store4(cbuf, (tok * cstr + (unsigned)dir * NO * 4u + chl) | bad, cv);
+    buf_store4(hbuf, (tok * hstr + (unsigned)(a.hofs + dir * NO) * 4u + chl) | bad, hv);
+    // h_t is the recurrent part of the NEXT step's source row (forward_stack_delay, clstm_compute.cc:377-397)
+    const unsigned bads = oob_lane(tp + 1, Tr[i]) | (unsigned)(tp >> 31 & 0x80000000) | s_off_mask | dbg_ch;
+    const unsigned toks = (unsigned)(offr[i] + (dir == 0 ? tp + 1 : Tr[i] - 2 - tp));
+    buf_store4(sbuf, (toks * sstr + (unsigned)a.sofs * 4u + chl) | bads, hv);
   };
   // h_{-1} = 0 in the first source row of every line (forward_stack_delay with last < 0)
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     const unsigned tok = (unsigned)(offr[i] + (dir == 0 ? 0 : Tr[i] - 1));
-    buf_store4(sbuf, Tr[i] > 0 ? tok * sstr + (unsigned)a.sofs * 4u + chl : BUF_OOB, (f32x4){0.f, 0.f, 0.f, 0.f});
+    buf_store4(sbuf, a.store_s && Tr[i] > 0 ? tok * sstr + (unsigned)a.sofs * 4u + chl : BUF_OOB, (f32x4){0.f, 0.f, 0.f, 0.f});
   }
-  load_gx(0, gset[0]);
-  load_gx(1, gset[1]);
+  // x_0 straight into buffer 0; x_1, x_2 in flight
+  f32x4 xr[2];
+  put_x(smem, load_x(0));
+  xr[1] = load_x(1);
+  xr[0] = load_x(2);
   float cprev[TPW];
 #pragma unroll
   for (int i = 0; i < TPW; i++) cprev[i] = 0.0f;
 
-  // (wave-uniform; constant for the pairs of the instantiated sizes: 4 PPW == FP)
-  auto tile_on = [&](const int i) -> bool {
-    if (i >= 2 * PPW) return w == Gm::SW;
-    if constexpr (Gm::FP == 4 * PPW) return true;
-    return w * PPW + (i >> 1) < Gm::FP;
-  };
 #ifdef CLSTM_LSTM_PROF
   long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long pt = 0;
@@ -291,20 +322,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
   auto step = [&](const int t, auto par_tag) {
     constexpr int PAR = decltype(par_tag)::value;
-    const char* const hr = smem + PAR * Gm::HBUF;          // h_{t-1}
-    char* const hw = smem + (PAR ^ 1) * Gm::HBUF;          // h_t
-    lds_barrier();                                         // B1
+    const char* const hr = smem + PAR * Gm::HBUF;                       // [h_{t-1} ; x_t ; 1]
+    char* const hw = smem + (PAR ^ 1) * Gm::HBUF;                       // [h_t ; x_{t+1} ; 1]
+    char* const outw = smem + Gm::OUT_OFF + PAR * Gm::OUTSZ;            // this step's output rows
+    const char* const outr = smem + Gm::OUT_OFF + (PAR ^ 1) * Gm::OUTSZ;   // the previous step's
+    lds_barrier();
     MF_STAMP(0);
+    // pin the fragments in the accumulation half of the register file (MFMA operands may live there; left alone, hipcc keeps
+    // them in VGPRs, runs out, and shuttles them through v_accvgpr_read in front of every MFMA)
+#pragma unroll
+    for (int i = 0; i < 2 * PPW; i++)
+#pragma unroll
+      for (int kb = 0; kb < KB; kb++) { asm volatile("" : "+a"(Wh[i][kb])); asm volatile("" : "+a"(Wl[i][kb])); }
     f16x8 Bh[KB], Bl[KB];
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
       Bh[kb] = *reinterpret_cast<const f16x8*>(hr + bfo + 1024 * kb);
       Bl[kb] = *reinterpret_cast<const f16x8*>(hr + Gm::PART + bfo + 1024 * kb);
     }
-    // Two tiles = two INDEPENDENT accumulator chains, alternated: an MFMA that follows its own predecessor on the same
-    // accumulator back to back is forwarded, one that follows it behind anything else (the epilogue's VALU work is meant to sit
-    // between the MFMAs) waits ~43 cycles for the write-back (MI355X_MICROARCH.md, per-instruction constants)
-    auto mm2 = [&](const int i0, f32x4& a0, f32x4& a1) {
+    put_x(hw, xr[PAR ^ 1]);                // x_{t+1}, requested two steps ago
+    xr[PAR ^ 1] = load_x(t + 3);
+    auto mm2 = [&](const int i0, f32x4& a0, f32x4& a1) {   // two tiles, two alternating accumulator chains
       a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = a0;
 #pragma unroll
       for (int kb = 0; kb < KB; kb++) {
@@ -313,65 +351,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         a0 = mfma16x16x32_f16(Wh[i0][kb], Bh[kb], a0); a1 = mfma16x16x32_f16(Wh[i0 + 1][kb], Bh[kb], a1);
       }
     };
-    // the unpaired tile: its k-blocks alternate between the two chains, which are summed
-    auto mm1 = [&](const int i, f32x4& a0, f32x4& a1) {
+    // the unpaired tile (every wave runs it, three of them on zero weights: no branch inside the MFMA stream): its k-blocks
+    // alternate between the two chains, which are summed
+    auto mm1 = [&](f32x4& a0, f32x4& a1) {
       a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = a0;
+      f16x8 sh[KB], sl[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; kb++) {
+        sh[kb] = *reinterpret_cast<const f16x8*>(smem + Gm::WS_OFF + kb * 2048 + lane * 16);
+        sl[kb] = *reinterpret_cast<const f16x8*>(smem + Gm::WS_OFF + kb * 2048 + 1024 + lane * 16);
+      }
 #pragma unroll
       for (int kb = 0; kb < KB; kb += 2) {
-        a0 = mfma16x16x32_f16(Wl[i][kb], Bh[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(Wl[i][kb + 1], Bh[kb + 1], a1);
-        a0 = mfma16x16x32_f16(Wh[i][kb], Bl[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(Wh[i][kb + 1], Bl[kb + 1], a1);
-        a0 = mfma16x16x32_f16(Wh[i][kb], Bh[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(Wh[i][kb + 1], Bh[kb + 1], a1);
+        a0 = mfma16x16x32_f16(sl[kb], Bh[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(sl[kb + 1], Bh[kb + 1], a1);
+        a0 = mfma16x16x32_f16(sh[kb], Bl[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(sh[kb + 1], Bl[kb + 1], a1);
+        a0 = mfma16x16x32_f16(sh[kb], Bh[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(sh[kb + 1], Bh[kb + 1], a1);
       }
     };
-    // forward_full1 x 4 (clstm_compute.cc:308-314), forward_statemem (:504-508), forward_nonlingate (:530-537) of one tile
+    // forward_nonlin0 x 4 (clstm_compute.cc:195-229), forward_statemem (:504-508), forward_nonlingate (:530-537) of one tile
     auto epi = [&](const int i, const f32x4 acc) -> float {
-      const f32x4 gx = *reinterpret_cast<const f32x4*>(smem + Gm::GXS_OFF + gxo[i]);
-      const float gi = act_affine(fmaf(acc[0], inv, gx[0]), ACT_SIG_SCALE, 1.0f, 0.0f);
-      const float gf = act_affine(fmaf(acc[1], inv, gx[1]), ACT_SIG_SCALE, 1.0f, 0.0f);
-      const float go = act_affine(fmaf(acc[2], inv, gx[2]), ACT_SIG_SCALE, 1.0f, 0.0f);
-      const float ci = act_affine(fmaf(acc[3], inv, gx[3]), ACT_TANH_SCALE, 2.0f, -1.0f);
+      const float gi = fast_rcp(1.0f + fast_exp2(acc[0] * sig_k));
+      const float gf = fast_rcp(1.0f + fast_exp2(acc[1] * sig_k));
+      const float go = fast_rcp(1.0f + fast_exp2(acc[2] * sig_k));
+      const float ci = fmaf(fast_rcp(1.0f + fast_exp2(acc[3] * tanh_k)), 2.0f, -1.0f);
       const float c = fmaf(gf, cprev[i], ci * gi);
       const float h = go * tanh_fast(c);
       cprev[i] = c;
-      *reinterpret_cast<f32x4*>(smem + Gm::ACT_OFF + gxo[i]) = (f32x4){gi, gf, go, ci};
-      *reinterpret_cast<float*>(smem + Gm::CS_OFF + cho + 4 * cellv[i]) = c;
-      *reinterpret_cast<float*>(smem + Gm::HS_OFF + cho + 4 * cellv[i]) = h;
+      *reinterpret_cast<f32x4*>(outw + gxo[i]) = (f32x4){gi, gf, go, ci};
+      *reinterpret_cast<float*>(outw + Gm::CS_REL + cho + 4 * cellv[i]) = c;
+      *reinterpret_cast<float*>(outw + Gm::HS_REL + cho + 4 * cellv[i]) = h;
       return h * (float)(1 << MF_HS);   // the next step's B operand: two f16 terms of 2^8 h
+    };
+    auto epi_pair = [&](const int u, const f32x4 a0, const f32x4 a1) {
+      const float he = epi(2 * u, a0), ho = epi(2 * u + 1, a1);
+      const int pr = w * PPW + u;
+      f16x2 hi2, lo2;
+      hi2[0] = (_Float16)he; hi2[1] = (_Float16)ho;
+      lo2[0] = (_Float16)(he - (float)hi2[0]); lo2[1] = (_Float16)(ho - (float)hi2[1]);
+      *reinterpret_cast<f16x2*>(hw + hwo + 256 * pr) = hi2;
+      *reinterpret_cast<f16x2*>(hw + Gm::PART + hwo + 256 * pr) = lo2;
+    };
+    // the previous step's rows go out in PPW + 1 portions, one beside each unit's MFMAs
+    auto store_part = [&](const int part) {
+      if (part < PPW) {
+        for (int j = part; j < 4; j += PPW) store_g(outr, t - 1, j);
+      }
+      if (part == (PPW > 1 ? 1 : 0)) store_ch(outr, t - 1, 0);
+      if (part == (PPW > 2 ? 2 : PPW - 1)) store_ch(outr, t - 1, 1);
     };
     f32x4 A0, A1, N0, N1;
     mm2(0, A0, A1);
+    store_part(0);
     MF_STAMP(1);
-    stage_gx(gset[PAR]);
-    MF_STAMP(2);
-    load_gx(t + 2, gset[PAR]);
-    if (t > 0) store_rows(t - 1);
-    MF_STAMP(3);
-    lds_barrier();                                         // B2
-    MF_STAMP(4);
 #pragma unroll
     for (int u = 0; u < PPW; u++) {
       N0 = A0; N1 = A1;
-      if (u + 1 < PPW) { if (tile_on(2 * u + 2)) mm2(2 * u + 2, N0, N1); }
-      else if (Gm::SINGLE && tile_on(2 * PPW)) mm1(2 * PPW, N0, N1);
-      if (tile_on(2 * u)) {
-        const float he = epi(2 * u, A0), ho = epi(2 * u + 1, A1);
-        const int pr = w * PPW + u;
-        f16x2 hi2, lo2;
-        hi2[0] = (_Float16)he; hi2[1] = (_Float16)ho;
-        lo2[0] = (_Float16)(he - (float)hi2[0]); lo2[1] = (_Float16)(ho - (float)hi2[1]);
-        *reinterpret_cast<f16x2*>(hw + hwo + 256 * pr) = hi2;
-        *reinterpret_cast<f16x2*>(hw + Gm::PART + hwo + 256 * pr) = lo2;
+      if (u + 1 < PPW) mm2(2 * u + 2, N0, N1);
+      else if (Gm::SINGLE) mm1(N0, N1);
+      epi_pair(u, A0, A1);
+      store_part(u + 1);
+      // one MFMA, then a share of the epilogue: ~75 VALU instructions beside 6 KB (pair) / 3 KB (unpaired tile) MFMAs
+      if (u + 1 < PPW) {
+#pragma unroll
+        for (int k = 0; k < 6 * KB; k++) { MF_SGB(SG_MFMA, 1); MF_SGB(SG_VALU, 3); }
+      } else if (Gm::SINGLE) {
+#pragma unroll
+        for (int k = 0; k < 3 * KB; k++) { MF_SGB(SG_MFMA, 1); MF_SGB(SG_VALU, 5); }
       }
       A0 = N0; A1 = N1;
+      MF_STAMP(2 + (u < 3 ? u : 3));
     }
-    if (Gm::SINGLE && tile_on(2 * PPW)) {
+    if (Gm::SINGLE && w == Gm::SW) {
       const float hs = epi(2 * PPW, A0 + A1);
       const _Float16 hi1 = (_Float16)hs;
       const _Float16 lo1 = (_Float16)(hs - (float)hi1);
       *reinterpret_cast<_Float16*>(hw + n * 16 + cl * 2 + 256 * Gm::FP) = hi1;
       *reinterpret_cast<_Float16*>(hw + Gm::PART + n * 16 + cl * 2 + 256 * Gm::FP) = lo1;
     }
-    MF_STAMP(5);
+    MF_STAMP(6);
   };
   int t = 0;
   for (; t + 1 < Tmax; t += 2) {
@@ -380,7 +437,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   if (t < Tmax) { step(t, std::integral_constant<int, 0>{}); t++; }
   lds_barrier();
-  store_rows(t - 1);
+  {
+    const char* const out = smem + Gm::OUT_OFF + ((t - 1) & 1) * Gm::OUTSZ;
+#pragma unroll
+    for (int j = 0; j < 4; j++) store_g(out, t - 1, j);
+    store_ch(out, t - 1, 0);
+    store_ch(out, t - 1, 1);
+  }
 #ifdef CLSTM_LSTM_PROF
   if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
     for (int k = 0; k < 8; k++) a.prof[w * 8 + k] = pacc[k];

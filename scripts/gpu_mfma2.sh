@@ -7,7 +7,7 @@ timeout 900 python -m pytest tests/test_mfma_recurrence.py -m gpu -q -x > "$OUT/
 if [ -f clstm_amd/lib/libclstm_hip_prof.so ]; then
   for n in 256 1024; do CLSTM_HIP_VARIANT=prof timeout 300 python scripts/gpu_mfmaprof.py $n 2>&1 | tee "$OUT/prof_$n.txt" | tail -9; done
 fi
-for mb in ${MBS:-256}; do
+for mb in ${MBS:-256 512 1024}; do
   for mode in 1; do
     CLSTM_DEBUG="fwd_mfma=$mode,bwd_mfma=$mode" timeout 600 python bench.py --no-cpu-baseline --no-secondary --minibatch $mb --steps 20 --warmup 5 \
         > "$OUT/bench_mb${mb}_mfma${mode}.json" 2> "$OUT/bench_mb${mb}_mfma${mode}.err"

@@ -23,8 +23,22 @@ fn = lib.dll.clstm_debug_lstm_cycles
 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 fn(net.h, out)
 v = np.array(list(out), dtype=np.float64)[:32].reshape(4, 8) / T
-names = ["B1 wait", "B frags + first MFMAs", "stage gx (vmcnt + ds_write)", "loads + row stores", "B2 wait", "tile loop"]
+names = ["barrier wait", "B frags, x, first pair's MFMAs, rows 0", "pair 0 epilogue | pair 1 MFMAs", "pair 1 epilogue | pair 2 MFMAs",
+         "pair 2 epilogue | last tile MFMAs", "-", "last tile's epilogue"]
 print("lines %d: cycles per step (workgroup 0, waves 0..3; s_memtime ticks = 100 MHz? see total vs wall)" % BS)
 for k, n in enumerate(names):
-    print("  %-30s" % n + "".join("%9.1f" % v[w, k] for w in range(4)))
-print("  %-30s" % "total" + "".join("%9.1f" % v[w, :6].sum() for w in range(4)))
+    print("  %-42s" % n + "".join("%9.1f" % v[w, k] for w in range(4)))
+print("  %-30s" % "total" + "".join("%9.1f" % v[w, :7].sum() for w in range(4)))
+
+# forward launch time by what the memory pipeline is asked to do (mfma_dbg bits: 1 no activation rows, 2 no c / h / source rows, 4 no inputs)
+for dbg in (0, 1, 2, 3, 7):
+    lib.call("clstm_debug_set_option", b"mfma_dbg", dbg)
+    net.forward(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lib.call("clstm_synchronize")
+    import time
+    t0 = time.perf_counter()
+    for _ in range(5):
+        net.forward()
+    lib.call("clstm_synchronize")
+    print("  mfma_dbg %d: forward pass %.1f us (incl. ~%d us of softmax / ingest launches)" % (dbg, (time.perf_counter() - t0) / 5 * 1e6, 0))
