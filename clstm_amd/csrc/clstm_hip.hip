@@ -1124,8 +1124,8 @@ struct Net {
   }
 
   // ---- narrow layers, chip-filling minibatches: the recurrence batched over 16 lines per workgroup on the MFMA (lstm_mfma.h) ----
-  // fwd_mfma: 0 never, 1 (default) from 192 lines per GPU on (below that the per-line kernel's one-workgroup-per-line latency
-  // chain is shorter than a 16-line MFMA step), 2 always (tests)
+  // fwd_mfma: 0 never, 1 (default) from 640 lines per GPU on (measured crossover, profiles/r06_mfma_v3_vs_perline.txt: below
+  // that the launch has fewer 16-line workgroups than the chip has CUs and the per-line kernel wins), 2 always (tests)
   bool mfma_eligible(const Layer& y) const {
 #ifdef CLSTM_HIP_EMU
     return false;
@@ -1136,7 +1136,7 @@ struct Net {
     const double lim = 2147483000.0;   // 32-bit byte offsets inside one descriptor
     if ((double)N * ndir * 4 * y.no * 4 >= lim || (double)N * y.ldh * 4 >= lim || (double)N * y.lds * 4 >= lim) return false;
     if ((double)N * layer_input_ld((int)(&y - L.data())) * 4 >= lim) return false;
-    return mode >= 2 || bs >= 192;
+    return mode >= 2 || bs >= 640;
 #endif
   }
 #ifndef CLSTM_HIP_EMU
@@ -1163,7 +1163,7 @@ struct Net {
 #endif
     static const bool smem_set = (coop_set_smem(lstm_fwd_mfma_kernel<NO, NI>, (size_t)Gm::SMEM), true);
     (void)smem_set; (void)fwd;
-    CLSTM_LAUNCH((lstm_fwd_mfma_kernel<NO, NI>), dim3((unsigned)((bs + 15) / 16), (unsigned)ndir), dim3(256), (size_t)Gm::SMEM, s, a);
+    CLSTM_LAUNCH((lstm_fwd_mfma_kernel<NO, NI>), dim3((unsigned)((bs + 15) / 16), (unsigned)ndir), dim3(512), (size_t)Gm::SMEM, s, a);
     g_path_count[16]++;
   }
 #endif

@@ -65,20 +65,30 @@ struct LstmMfmaArgs {
 
 template <int NO, int NI>
 struct MfmaGeom {
-  static_assert(NO % 4 == 0 && NO >= 16 && NO <= 128 && NI % 4 == 0 && NI >= 4 && NI <= 64, "cells / inputs");
-  static constexpr int NT = NO / 4, FP = NT / 2, SINGLE = NT & 1, PPW = (FP + 3) / 4;
+  static_assert(NO % 4 == 0 && NO >= 32 && NO <= 128 && NI % 4 == 0 && NI >= 4 && NI <= 64, "cells / inputs");
+  static constexpr int NW = 8;                               // waves: two per SIMD -- one wave's epilogue beside the other's MFMAs
+  static constexpr int NT = NO / 4, TW = NT / NW;            // tiles of 4 cells; per wave TW of them in registers ...
+  static constexpr int EXTRA = NT - NW * TW;                 // ... and the last wave EXTRA more, fragments in LDS (0 or 1)
+  static_assert(TW >= 2 && EXTRA <= 1, "geometry not instantiable");
+  static constexpr int NPW = TW / 2, LONE = TW & 1;          // a wave's tiles: NPW pairs, then a lone one
   static constexpr int KT = NO + NI + 1, KB = (KT + 31) / 32, NCH = 4 * KB;   // k = [cells | inputs | 1 | zero pad]
-  static constexpr int TPW = 2 * PPW + SINGLE;
-  static constexpr int SW = (FP % PPW == 0 && FP / PPW == 4) ? 0 : 3;   // the wave that takes the unpaired tile
   static constexpr int SLOTS = (NO + 15) / 16 * 16;   // 16-byte slots (one per cell) in a staged row of gate values
   static constexpr int RS = SLOTS * 16, RH = (SLOTS + 63) / 64;
   static constexpr int PART = NCH * 256, HBUF = 2 * PART;   // B image: [buffer][hi | lo][chunk of 8 k][16 lines][8 halfs]
   static constexpr int OUT_OFF = 2 * HBUF, CS_REL = 16 * RS, HS_REL = CS_REL + 16 * NO * 4, OUTSZ = HS_REL + 16 * NO * 4;
-  static constexpr int WS_OFF = OUT_OFF + 2 * OUTSZ;        // the unpaired tile's A fragments [k-block][hi | lo][lane][16 bytes]
-  static constexpr int DUMP_OFF = WS_OFF + SINGLE * KB * 2048;   // where lanes without a datum write
+  static constexpr int WS_OFF = OUT_OFF + 2 * OUTSZ;        // the extra tile's A fragments [k-block][hi | lo][lane][16 bytes]
+  static constexpr int DUMP_OFF = WS_OFF + EXTRA * KB * 2048;   // where lanes without a datum write
   static constexpr int SMEM = DUMP_OFF + 64;
   static constexpr long long W_HALFS_PER_DIR = (long long)NT * KB * 2 * 64 * 8;
 };
+// cell of (tile, cell slot cs): wave v = tile / TW owns cells 4 TW v .. 4 TW (v + 1) - 1; inside it pairs of tiles interleave
+// (tiles 2p, 2p + 1 of the wave hold cells 8p + 2cs, 8p + 2cs + 1), a lone tile and the extra tile hold 4 consecutive cells
+__host__ __device__ inline int mfma_cell(int nt, int tile, int cs) {
+  const int tw = nt / 8;
+  if (tile >= 8 * tw) return 4 * tile + cs;
+  const int v = tile / tw, i = tile % tw, npw = tw / 2;
+  return 4 * tw * v + (i < 2 * npw ? 8 * (i >> 1) + 2 * cs + (i & 1) : 8 * npw + cs);
+}
 
 // ---- packing: one workgroup per direction finds max |[R | W_x | b]|, picks the scale and writes the fragments -------------
 // PackDesc (ops.h) as the other packs: W_q(cell, col) = v[p_off[dir][q] + cell + no col], col 0 bias, 1 + j input j,
@@ -109,14 +119,12 @@ __global__ __launch_bounds__(1024) void k_pack_mfma(MfmaPackArgs p) {
   }
   __syncthreads();
   const float sc = ldexpf(1.0f, e_sh);
-  const int FP = p.nt / 2;
   const long long per_dir = (long long)p.nt * p.kb * 2 * 64 * 8;
   for (long long i = tid; i < (long long)p.nt * p.kb * 64 * 8; i += 1024) {
     const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
     const int kb = (int)((i >> 9) % p.kb), tile = (int)((i >> 9) / p.kb);
     const int m = lane & 15, cs = m >> 2, q = m & 3;
-    const int pr = tile >> 1, r = tile & 1;
-    const int cell = pr < FP ? 8 * pr + 2 * cs + r : 8 * FP + cs;
+    const int cell = mfma_cell(p.nt, tile, cs);
     const int col = mfma_pack_col(kb * 32 + 8 * (lane >> 4) + j, no, p.ni);
     const float x = (cell < no && col >= 0) ? p.v[p.p_off[dir][q] + cell + (long long)no * col] * sc : 0.0f;
     const _Float16 hi = (_Float16)x;
@@ -134,24 +142,24 @@ DEVFN void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: 
 DEVFN f32x4 buf_load4_s(BufF32 b, unsigned lane_off, unsigned uniform_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, lane_off, uniform_off, 0));
 }
-DEVFN void buf_store4_s(BufF32 b, unsigned lane_off, unsigned uniform_off, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b.r, lane_off, uniform_off, 0);
-}
+// (No store takes an SGPR soffset here.  The ISA manual lists no wait state between a 128-bit buffer store in that form and a
+//  write of its data registers, and LLVM inserts none; with two waves per SIMD the overwrite DID reach memory on MI355X --
+//  activation rows came back holding the next store's offset register.  scripts/dbg/scan_store_hazard.py scans the assembly.)
 // instruction-group hints for the scheduler (IGroupLP): the next `n` instructions of class `mask` in program order
 #define MF_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_W = 0x40, SG_DS_R = 0x100, SG_DS_W = 0x200;
 
 template <int NO, int NI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_fwd_mfma_kernel(LstmMfmaArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_fwd_mfma_kernel(LstmMfmaArgs a) {
   using Gm = MfmaGeom<NO, NI>;
-  constexpr int PPW = Gm::PPW, KB = Gm::KB, TPW = Gm::TPW, RH = Gm::RH, RS = Gm::RS;
+  constexpr int TW = Gm::TW, NPW = Gm::NPW, LONE = Gm::LONE, EXTRA = Gm::EXTRA, KB = Gm::KB, RH = Gm::RH, RS = Gm::RS, NW = Gm::NW;
   char* const smem = dyn_smem<char>();
   const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
   const int n = lane & 15, cl = lane >> 4;
   const int dir = blockIdx.y, grp = blockIdx.x;
   const int nd = a.ndir;
 
-  // this lane's line (column n of the product) and, as scalars, the four lines whose rows this wave moves
+  // this lane's line (column n of the product) and, as scalars, the two lines whose rows this wave moves
   const int gl = grp * 16 + n;
   const int b = gl < a.bs ? (a.order ? a.order[gl] : gl) : -1;
   const int off = b >= 0 ? a.line_off[b] : 0;
@@ -160,38 +168,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int m = 1; m < 16; m <<= 1) { const int o = __shfl_xor(tmx, m, 64); tmx = o > tmx ? o : tmx; }
   const int Tmax = wave_uniform(tmx);
-  int offj[4], Tj[4];
+  int offj[2], Tj[2];
 #pragma unroll
-  for (int j = 0; j < 4; j++) { offj[j] = __builtin_amdgcn_readlane(off, 4 * w + j); Tj[j] = __builtin_amdgcn_readlane(T, 4 * w + j); }
+  for (int j = 0; j < 2; j++) { offj[j] = __builtin_amdgcn_readlane(off, 2 * w + j); Tj[j] = __builtin_amdgcn_readlane(T, 2 * w + j); }
   if (Tmax <= 0) return;
 
-  // A fragments (hi, lo) of this wave's tiles, resident for the whole sequence (a wave without the unpaired tile: zeros)
-  // (the unpaired tile's fragments stay in LDS and are read every step: with them wave SW would need 7 x 5 x 8 = 280 operand
-  //  registers, more than the 256 of the accumulation half of the file, and hipcc then shuttles EVERY fragment through
-  //  v_accvgpr_read in front of its MFMA -- 4 VALU instructions per MFMA)
-  f16x8 Wh[2 * PPW][KB], Wl[2 * PPW][KB];
+  // A fragments (hi, lo) of this wave's TW tiles, resident for the whole sequence.  (The extra tile's stay in LDS and are read
+  // every step by the last wave: with them it would need (TW + 1) x KB x 8 operand registers.)
+  f16x8 Wh[TW][KB], Wl[TW][KB];
 #pragma unroll
-  for (int i = 0; i < 2 * PPW; i++) {
-    const int pr = w * PPW + (i >> 1);
-    const bool act = pr < Gm::FP;
-    const int tile = 2 * pr + (i & 1);
+  for (int i = 0; i < TW; i++)
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) {
-      const unsigned short* wp = a.W + dir * Gm::W_HALFS_PER_DIR + ((long long)((act ? tile : 0) * KB + kb) * 2) * 512 + lane * 8;
-      const u32x4 vh = *reinterpret_cast<const u32x4*>(wp), vl = *reinterpret_cast<const u32x4*>(wp + 512);
-      const unsigned keep = act ? 0xFFFFFFFFu : 0u;
-      Wh[i][kb] = __builtin_bit_cast(f16x8, (u32x4){vh[0] & keep, vh[1] & keep, vh[2] & keep, vh[3] & keep});
-      Wl[i][kb] = __builtin_bit_cast(f16x8, (u32x4){vl[0] & keep, vl[1] & keep, vl[2] & keep, vl[3] & keep});
+      const unsigned short* wp = a.W + dir * Gm::W_HALFS_PER_DIR + ((long long)((w * TW + i) * KB + kb) * 2) * 512 + lane * 8;
+      Wh[i][kb] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wp));
+      Wl[i][kb] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wp + 512));
     }
-  }
   const float inv = a.inv_scale[dir];
   const float sig_k = inv * ACT_SIG_SCALE, tanh_k = inv * ACT_TANH_SCALE;   // (powers of two times a constant: exact products)
   // B image: h_{-1} = 0, zero padding, and the constant 1 behind the inputs (both buffers)
-  for (int i = tid * 16; i < 2 * Gm::HBUF; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = (u32x4){0u, 0u, 0u, 0u};
-  if (Gm::SINGLE)
-    for (int i = tid; i < KB * 128; i += 256)
+  for (int i = tid * 16; i < 2 * Gm::HBUF; i += 512 * 16) *reinterpret_cast<u32x4*>(smem + i) = (u32x4){0u, 0u, 0u, 0u};
+  if (EXTRA)
+    for (int i = tid; i < KB * 128; i += 512)
       *reinterpret_cast<u32x4*>(smem + Gm::WS_OFF + i * 16) =
-          *reinterpret_cast<const u32x4*>(a.W + dir * Gm::W_HALFS_PER_DIR + (long long)(2 * Gm::FP) * KB * 1024 + i * 8);
+          *reinterpret_cast<const u32x4*>(a.W + dir * Gm::W_HALFS_PER_DIR + (long long)(NW * TW) * KB * 1024 + i * 8);
   __syncthreads();
   if (tid < 32) {
     constexpr int kone = NO + NI;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     *reinterpret_cast<_Float16*>(smem + (tid >> 4) * Gm::HBUF + ((kone >> 3) * 16 + (tid & 15)) * 16 + (kone & 7) * 2) = one;
   }
 
-  // ---- global side: whole rows, wave w owns lines 4w .. 4w+3 ----
+  // ---- global side: whole rows, wave w owns lines 2w, 2w + 1 ----
   const unsigned gstr = (unsigned)nd * 4 * NO * 4, cstr = (unsigned)nd * NO * 4, hstr = (unsigned)a.ldh * 4, sstr = (unsigned)a.lds * 4;
   const unsigned xstr = (unsigned)a.ldx * 4;
   const BufF32 gbuf = make_buf(a.G, (size_t)a.N * gstr);
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const BufF32 hbuf = make_buf(a.H, (size_t)a.N * hstr);
   const BufF32 sbuf = make_buf(a.S + (size_t)dir * a.sdir, (size_t)a.N * sstr);
   const BufF32 xbuf = make_buf(a.X, (size_t)a.N * xstr);
+  const unsigned dbg_g = (a.dbg & 1) ? 0x80000000u : 0u, dbg_ch = (a.dbg & 2) ? 0x80000000u : 0u, dbg_x = (a.dbg & 4) ? 0x80000000u : 0u;
   unsigned gvo[RH];   // gate rows: lane = cell (16 bytes) within the half row
 #pragma unroll
   for (int hh = 0; hh < RH; hh++) gvo[hh] = 64 * hh + lane < NO ? (unsigned)(64 * hh + lane) * 16u : BUF_OOB_BASE;
@@ -214,31 +215,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto row_valid = [&](int j, int t) { return (unsigned)t < (unsigned)Tj[j]; };   // (t = -1: no)
   auto row_tok = [&](int j, int t) { return offj[j] + (dir == 0 ? t : Tj[j] - 1 - t); };
   auto oob_if = [&](bool ok) -> unsigned { return ok ? 0u : 0x80000000u; };
-  // c / h rows leave two lines per instruction (lanes 0-31 / 32-63, 16 bytes = 4 cells per lane)
-  const int l5 = lane & 31;
-  int offr[2], Tr[2];
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int row = 4 * w + 2 * i + (lane >> 5);
-    offr[i] = __shfl(off, row, 64);
-    Tr[i] = __shfl(T, row, 64);
-  }
-  const unsigned chl = l5 < NO / 4 ? (unsigned)l5 * 16u : BUF_OOB_BASE;
-  const unsigned s_off_mask = a.store_s ? 0u : 0x80000000u;
-  const unsigned dbg_g = (a.dbg & 1) ? 0x80000000u : 0u, dbg_ch = (a.dbg & 2) ? 0x80000000u : 0u, dbg_x = (a.dbg & 4) ? 0x80000000u : 0u;
-  // input frames: lane = (line 4w + (lane >> 4), float4 lane & 15 of its frame)
-  const int xq = lane & 15, xrow = 4 * w + (lane >> 4);
-  const int offx = __shfl(off, xrow, 64), Tx = __shfl(T, xrow, 64);
-  const unsigned xvl = xq < NI / 4 ? (unsigned)xq * 16u : BUF_OOB_BASE;
   // (validity as arithmetic, never as control flow: a branch inside a step ends the scheduling region the MFMA stream and the
   //  work beside it are interleaved in)
-  auto oob_lane = [&](int t, int Tl) -> unsigned { return ~(unsigned)((t - Tl) >> 31) & 0x80000000u; };   // 0 while 0 <= t < Tl ...
+  auto oob_lane = [&](int t, int Tl) -> unsigned { return ~(unsigned)((t - Tl) >> 31) & 0x80000000u; };   // 0 while t < Tl
+  // c / h rows leave as one instruction for both lines (lanes 0-31 / 32-63, 16 bytes = 4 cells per lane)
+  const int l5 = lane & 31;
+  const int rrow = 2 * w + (lane >> 5);
+  const int offr = __shfl(off, rrow, 64), Tr = __shfl(T, rrow, 64);
+  const unsigned chl = l5 < NO / 4 ? (unsigned)l5 * 16u : BUF_OOB_BASE;
+  const unsigned s_off_mask = a.store_s ? 0u : 0x80000000u;
+  // input frames: lane = (line 2w + (lane >> 4), float4 lane & 15 of its frame), lanes 0-31
+  const int xq = lane & 15, xrow = 2 * w + ((lane >> 4) & 1);
+  const bool xon = lane < 32 && xq < NI / 4;
+  const int offx = __shfl(off, xrow, 64), Tx = __shfl(T, xrow, 64);
+  const unsigned xvl = xon ? (unsigned)xq * 16u : BUF_OOB_BASE;
   auto load_x = [&](int t) -> f32x4 {
     const unsigned tok = (unsigned)(offx + (dir == 0 ? t : Tx - 1 - t));
     return buf_load4(xbuf, (tok * xstr + xvl) | oob_lane(t, Tx) | dbg_x);
   };
   // k = NO + 4 xq .. + 3 of line xrow (lanes without an input: the dump slot)
-  const unsigned xwo_h = xq < NI / 4 ? (unsigned)((((NO + 4 * xq) >> 3) * 16 + xrow) * 16 + ((NO + 4 * xq) & 7) * 2) : 0u;
+  const unsigned xwo_h = (unsigned)((((NO + 4 * xq) >> 3) * 16 + xrow) * 16 + ((NO + 4 * xq) & 7) * 2);
   auto put_x = [&](char* img, f32x4 x) {   // two f16 terms of 2^8 x into the B image
     f16x4 hi, lo;
 #pragma unroll
@@ -247,31 +243,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       hi[e] = (_Float16)xs;
       lo[e] = (_Float16)(xs - (float)hi[e]);
     }
-    char* const dst = xq < NI / 4 ? img + xwo_h : smem + Gm::DUMP_OFF;
+    char* const dst = xon ? img + xwo_h : smem + Gm::DUMP_OFF;
     *reinterpret_cast<f16x4*>(dst) = hi;
-    *reinterpret_cast<f16x4*>(dst + (xq < NI / 4 ? Gm::PART : 8)) = lo;
+    *reinterpret_cast<f16x4*>(dst + (xon ? Gm::PART : 8)) = lo;
   };
 
   // ---- LDS side ----
-  // epilogue, lane (cl, n), tile i: cell c -> slot (c ^ n) of row n in the activation image
-  unsigned gxo[TPW];
-  int cellv[TPW];
+  // epilogue, lane (cl, n), tile i of the wave (TW: the extra tile): cell c -> slot (c ^ n) of row n in the activation image,
+  // k = c in the B image (chunk c >> 3, element c & 7)
+  unsigned gxo[TW + 1], hbo[TW + 1];
+  int cellv[TW + 1];
 #pragma unroll
-  for (int i = 0; i < TPW; i++) {
-    const int pr = w * PPW + (i >> 1);
-    const int c = i < 2 * PPW ? 8 * pr + 2 * cl + (i & 1) : 8 * Gm::FP + cl;
+  for (int i = 0; i <= TW; i++) {
+    const int c = mfma_cell(Gm::NT, i < TW ? w * TW + i : NW * TW, cl);
     cellv[i] = c;
     gxo[i] = (unsigned)(n * RS + ((c ^ n) << 4));
+    hbo[i] = (unsigned)(((c >> 3) * 16 + n) * 16 + (c & 7) * 2);
   }
   const unsigned cho = (unsigned)(n * NO * 4);             // + 4 c
-  const unsigned hwo = (unsigned)(n * 16 + cl * 4);        // pairs: + 256 p (+ PART for lo); the unpaired tile: n * 16 + cl * 2
   const unsigned bfo = (unsigned)(cl * 256 + n * 16);      // B fragments: + 1024 kb (+ PART for lo)
 
-  // outputs of a step leave as rows during the next one: activations (G), c, h (H and, shifted by one frame, the source rows S)
-  // (each portion reads its rows from the LDS image right in front of its stores: all twelve reads at the top of the step kept 48
-  //  registers live through the whole MFMA stream and pushed the kernel into scratch)
-  auto store_g = [&](const char* out, const int tp, const int j) {   // the activation row of line 4w + j
-    const int row = 4 * w + j;
+  // outputs of a step leave as rows during the next one: activations (G), c, h (H and, shifted by one frame, the source rows S);
+  // each portion reads its rows from the LDS image right in front of its stores
+  auto store_g = [&](const char* out, const int tp, const int j) {   // the activation row of line 2w + j
+    const int row = 2 * w + j;
     f32x4 av[RH];
 #pragma unroll
     for (int hh = 0; hh < RH; hh++)
@@ -279,36 +274,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool ok = row_valid(j, tp);
     const unsigned so = (unsigned)row_tok(j, tp) * gstr + (unsigned)dir * NO * 16u;   // (an invalid row: every lane out of range)
 #pragma unroll
-    for (int hh = 0; hh < RH; hh++) buf_store4_s(gbuf, gvo[hh] | oob_if(ok) | dbg_g, so, av[hh]);
+    for (int hh = 0; hh < RH; hh++) buf_store4(gbuf, (gvo[hh] | oob_if(ok) | dbg_g) + so, av[hh]);
   };
-  auto store_ch = [&](const char* out, const int tp, const int i) {  // c, h of lines 4w + 2i, 4w + 2i + 1
-    const int row = 4 * w + 2 * i + (lane >> 5);
+  auto store_ch = [&](const char* out, const int tp) {  // c, h of lines 2w, 2w + 1
     const int lo = l5 < NO / 4 ? l5 : 0;
-    const f32x4 cv = *reinterpret_cast<const f32x4*>(out + Gm::CS_REL + row * NO * 4 + lo * 16);
-    const f32x4 hv = *reinterpret_cast<const f32x4*>(out + Gm::HS_REL + row * NO * 4 + lo * 16);
-    const unsigned bad = oob_lane(tp, Tr[i]) | (unsigned)(tp >> 31 & 0x80000000) | dbg_ch;
-    const unsigned tok = (unsigned)(offr[i] + (dir == 0 ? tp : Tr[i] - 1 - tp));
+    const f32x4 cv = *reinterpret_cast<const f32x4*>(out + Gm::CS_REL + rrow * NO * 4 + lo * 16);
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(out + Gm::HS_REL + rrow * NO * 4 + lo * 16);
+    const unsigned bad = oob_lane(tp, Tr) | (unsigned)(tp >> 31 & 0x80000000) | dbg_ch;
+    const unsigned tok = (unsigned)(offr + (dir == 0 ? tp : Tr - 1 - tp));
     buf_store4(cbuf, (tok * cstr + (unsigned)dir * NO * 4u + chl) | bad, cv);
     buf_store4(hbuf, (tok * hstr + (unsigned)(a.hofs + dir * NO) * 4u + chl) | bad, hv);
     // h_t is the recurrent part of the NEXT step's source row (forward_stack_delay, clstm_compute.cc:377-397)
-    const unsigned bads = oob_lane(tp + 1, Tr[i]) | (unsigned)(tp >> 31 & 0x80000000) | s_off_mask | dbg_ch;
-    const unsigned toks = (unsigned)(offr[i] + (dir == 0 ? tp + 1 : Tr[i] - 2 - tp));
+    const unsigned bads = oob_lane(tp + 1, Tr) | (unsigned)(tp >> 31 & 0x80000000) | s_off_mask | dbg_ch;
+    const unsigned toks = (unsigned)(offr + (dir == 0 ? tp + 1 : Tr - 2 - tp));
     buf_store4(sbuf, (toks * sstr + (unsigned)a.sofs * 4u + chl) | bads, hv);
   };
   // h_{-1} = 0 in the first source row of every line (forward_stack_delay with last < 0)
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const unsigned tok = (unsigned)(offr[i] + (dir == 0 ? 0 : Tr[i] - 1));
-    buf_store4(sbuf, a.store_s && Tr[i] > 0 ? tok * sstr + (unsigned)a.sofs * 4u + chl : BUF_OOB, (f32x4){0.f, 0.f, 0.f, 0.f});
+  {
+    const unsigned tok = (unsigned)(offr + (dir == 0 ? 0 : Tr - 1));
+    buf_store4(sbuf, a.store_s && Tr > 0 ? tok * sstr + (unsigned)a.sofs * 4u + chl : BUF_OOB, (f32x4){0.f, 0.f, 0.f, 0.f});
   }
   // x_0 straight into buffer 0; x_1, x_2 in flight
   f32x4 xr[2];
   put_x(smem, load_x(0));
   xr[1] = load_x(1);
   xr[0] = load_x(2);
-  float cprev[TPW];
+  float cprev[TW + 1];
 #pragma unroll
-  for (int i = 0; i < TPW; i++) cprev[i] = 0.0f;
+  for (int i = 0; i <= TW; i++) cprev[i] = 0.0f;
 
 #ifdef CLSTM_LSTM_PROF
   long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -331,7 +324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // pin the fragments in the accumulation half of the register file (MFMA operands may live there; left alone, hipcc keeps
     // them in VGPRs, runs out, and shuttles them through v_accvgpr_read in front of every MFMA)
 #pragma unroll
-    for (int i = 0; i < 2 * PPW; i++)
+    for (int i = 0; i < TW; i++)
 #pragma unroll
       for (int kb = 0; kb < KB; kb++) { asm volatile("" : "+a"(Wh[i][kb])); asm volatile("" : "+a"(Wl[i][kb])); }
     f16x8 Bh[KB], Bl[KB];
@@ -342,7 +335,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     put_x(hw, xr[PAR ^ 1]);                // x_{t+1}, requested two steps ago
     xr[PAR ^ 1] = load_x(t + 3);
-    auto mm2 = [&](const int i0, f32x4& a0, f32x4& a1) {   // two tiles, two alternating accumulator chains
+    // Two INDEPENDENT accumulator chains alternate on the matrix pipe (a pair of tiles, or the even / odd k-blocks of one): an
+    // MFMA behind its own predecessor is forwarded only back to back, and the epilogue's VALU work is meant to sit between them
+    auto mm2 = [&](const int i0, f32x4& a0, f32x4& a1) {
       a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = a0;
 #pragma unroll
       for (int kb = 0; kb < KB; kb++) {
@@ -351,22 +346,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         a0 = mfma16x16x32_f16(Wh[i0][kb], Bh[kb], a0); a1 = mfma16x16x32_f16(Wh[i0 + 1][kb], Bh[kb], a1);
       }
     };
-    // the unpaired tile (every wave runs it, three of them on zero weights: no branch inside the MFMA stream): its k-blocks
-    // alternate between the two chains, which are summed
-    auto mm1 = [&](f32x4& a0, f32x4& a1) {
-      a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = a0;
-      f16x8 sh[KB], sl[KB];
-#pragma unroll
-      for (int kb = 0; kb < KB; kb++) {
-        sh[kb] = *reinterpret_cast<const f16x8*>(smem + Gm::WS_OFF + kb * 2048 + lane * 16);
-        sl[kb] = *reinterpret_cast<const f16x8*>(smem + Gm::WS_OFF + kb * 2048 + 1024 + lane * 16);
-      }
+    auto mm1 = [&](const f16x8 (&wh)[KB], const f16x8 (&wl)[KB]) -> f32x4 {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
       for (int kb = 0; kb < KB; kb += 2) {
-        a0 = mfma16x16x32_f16(sl[kb], Bh[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(sl[kb + 1], Bh[kb + 1], a1);
-        a0 = mfma16x16x32_f16(sh[kb], Bl[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(sh[kb + 1], Bl[kb + 1], a1);
-        a0 = mfma16x16x32_f16(sh[kb], Bh[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(sh[kb + 1], Bh[kb + 1], a1);
+        a0 = mfma16x16x32_f16(wl[kb], Bh[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(wl[kb + 1], Bh[kb + 1], a1);
+        a0 = mfma16x16x32_f16(wh[kb], Bl[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(wh[kb + 1], Bl[kb + 1], a1);
+        a0 = mfma16x16x32_f16(wh[kb], Bh[kb], a0); if (kb + 1 < KB) a1 = mfma16x16x32_f16(wh[kb + 1], Bh[kb + 1], a1);
       }
+      return a0 + a1;
     };
     // forward_nonlin0 x 4 (clstm_compute.cc:195-229), forward_statemem (:504-508), forward_nonlingate (:530-537) of one tile
     auto epi = [&](const int i, const f32x4 acc) -> float {
@@ -382,53 +370,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       *reinterpret_cast<float*>(outw + Gm::HS_REL + cho + 4 * cellv[i]) = h;
       return h * (float)(1 << MF_HS);   // the next step's B operand: two f16 terms of 2^8 h
     };
-    auto epi_pair = [&](const int u, const f32x4 a0, const f32x4 a1) {
-      const float he = epi(2 * u, a0), ho = epi(2 * u + 1, a1);
-      const int pr = w * PPW + u;
+    auto put_h2 = [&](const int i0, const float he, const float ho) {   // cells c, c + 1 of a pair: one dword per term
       f16x2 hi2, lo2;
       hi2[0] = (_Float16)he; hi2[1] = (_Float16)ho;
       lo2[0] = (_Float16)(he - (float)hi2[0]); lo2[1] = (_Float16)(ho - (float)hi2[1]);
-      *reinterpret_cast<f16x2*>(hw + hwo + 256 * pr) = hi2;
-      *reinterpret_cast<f16x2*>(hw + Gm::PART + hwo + 256 * pr) = lo2;
+      *reinterpret_cast<f16x2*>(hw + hbo[i0]) = hi2;
+      *reinterpret_cast<f16x2*>(hw + Gm::PART + hbo[i0]) = lo2;
     };
-    // the previous step's rows go out in PPW + 1 portions, one beside each unit's MFMAs
-    auto store_part = [&](const int part) {
-      if (part < PPW) {
-        for (int j = part; j < 4; j += PPW) store_g(outr, t - 1, j);
-      }
-      if (part == (PPW > 1 ? 1 : 0)) store_ch(outr, t - 1, 0);
-      if (part == (PPW > 2 ? 2 : PPW - 1)) store_ch(outr, t - 1, 1);
+    auto put_h1 = [&](const int i, const float hs) {
+      const _Float16 hi1 = (_Float16)hs;
+      *reinterpret_cast<_Float16*>(hw + hbo[i]) = hi1;
+      *reinterpret_cast<_Float16*>(hw + Gm::PART + hbo[i]) = (_Float16)(hs - (float)hi1);
     };
-    f32x4 A0, A1, N0, N1;
+    // the previous step's rows go out in two portions beside the later MFMA phases
+    f32x4 A0, A1, N0 = {0.f, 0.f, 0.f, 0.f}, N1 = N0;
     mm2(0, A0, A1);
-    store_part(0);
     MF_STAMP(1);
 #pragma unroll
-    for (int u = 0; u < PPW; u++) {
-      N0 = A0; N1 = A1;
-      if (u + 1 < PPW) mm2(2 * u + 2, N0, N1);
-      else if (Gm::SINGLE) mm1(N0, N1);
-      epi_pair(u, A0, A1);
-      store_part(u + 1);
-      // one MFMA, then a share of the epilogue: ~75 VALU instructions beside 6 KB (pair) / 3 KB (unpaired tile) MFMAs
-      if (u + 1 < PPW) {
+    for (int u = 0; u < NPW; u++) {
+      if (u + 1 < NPW) mm2(2 * u + 2, N0, N1);
+      else if (LONE) N0 = mm1(Wh[TW - 1], Wl[TW - 1]);
+      const float he = epi(2 * u, A0), ho = epi(2 * u + 1, A1);
+      put_h2(2 * u, he, ho);
+      if (u == 0) { store_g(outr, t - 1, 0); if (NPW > 1 || !LONE) store_ch(outr, t - 1); }
+      if (u == NPW - 1 && !LONE) store_g(outr, t - 1, 1);
+      if (u + 1 < NPW) {
 #pragma unroll
         for (int k = 0; k < 6 * KB; k++) { MF_SGB(SG_MFMA, 1); MF_SGB(SG_VALU, 3); }
-      } else if (Gm::SINGLE) {
+      } else if (LONE) {
 #pragma unroll
         for (int k = 0; k < 3 * KB; k++) { MF_SGB(SG_MFMA, 1); MF_SGB(SG_VALU, 5); }
       }
       A0 = N0; A1 = N1;
-      MF_STAMP(2 + (u < 3 ? u : 3));
+      MF_STAMP(2 + (u < 2 ? u : 2));
     }
-    if (Gm::SINGLE && w == Gm::SW) {
-      const float hs = epi(2 * PPW, A0 + A1);
-      const _Float16 hi1 = (_Float16)hs;
-      const _Float16 lo1 = (_Float16)(hs - (float)hi1);
-      *reinterpret_cast<_Float16*>(hw + n * 16 + cl * 2 + 256 * Gm::FP) = hi1;
-      *reinterpret_cast<_Float16*>(hw + Gm::PART + n * 16 + cl * 2 + 256 * Gm::FP) = lo1;
+    if (LONE) {
+      if (NPW == 1) store_ch(outr, t - 1);
+      store_g(outr, t - 1, 1);
+      if (EXTRA && w == NW - 1) {   // the last wave: the extra tile, fragments from LDS
+        f16x8 sh[KB], sl[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) {
+          sh[kb] = *reinterpret_cast<const f16x8*>(smem + Gm::WS_OFF + kb * 2048 + lane * 16);
+          sl[kb] = *reinterpret_cast<const f16x8*>(smem + Gm::WS_OFF + kb * 2048 + 1024 + lane * 16);
+        }
+        const f32x4 X0 = mm1(sh, sl);
+        put_h1(TW - 1, epi(TW - 1, A0));
+#pragma unroll
+        for (int k = 0; k < 3 * KB; k++) { MF_SGB(SG_MFMA, 1); MF_SGB(SG_VALU, 3); }
+        put_h1(TW, epi(TW, X0));
+      } else put_h1(TW - 1, epi(TW - 1, A0));
+    } else if (EXTRA && w == NW - 1) {
+      f16x8 sh[KB], sl[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; kb++) {
+        sh[kb] = *reinterpret_cast<const f16x8*>(smem + Gm::WS_OFF + kb * 2048 + lane * 16);
+        sl[kb] = *reinterpret_cast<const f16x8*>(smem + Gm::WS_OFF + kb * 2048 + 1024 + lane * 16);
+      }
+      put_h1(TW, epi(TW, mm1(sh, sl)));
     }
-    MF_STAMP(6);
+    MF_STAMP(5);
   };
   int t = 0;
   for (; t + 1 < Tmax; t += 2) {
@@ -439,10 +440,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   lds_barrier();
   {
     const char* const out = smem + Gm::OUT_OFF + ((t - 1) & 1) * Gm::OUTSZ;
-#pragma unroll
-    for (int j = 0; j < 4; j++) store_g(out, t - 1, j);
-    store_ch(out, t - 1, 0);
-    store_ch(out, t - 1, 1);
+    store_g(out, t - 1, 0);
+    store_g(out, t - 1, 1);
+    store_ch(out, t - 1);
   }
 #ifdef CLSTM_LSTM_PROF
   if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)

@@ -22,13 +22,12 @@ out = (ctypes.c_longlong * 96)()
 fn = lib.dll.clstm_debug_lstm_cycles
 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 fn(net.h, out)
-v = np.array(list(out), dtype=np.float64)[:32].reshape(4, 8) / T
-names = ["barrier wait", "B frags, x, first pair's MFMAs, rows 0", "pair 0 epilogue | pair 1 MFMAs", "pair 1 epilogue | pair 2 MFMAs",
-         "pair 2 epilogue | last tile MFMAs", "-", "last tile's epilogue"]
+v = np.array(list(out), dtype=np.float64)[:64].reshape(8, 8) / T
+names = ["barrier wait", "B frags, x, the pair's MFMAs", "pair epilogue | lone tile's MFMAs | rows", "-", "-", "lone (+ extra) tile's epilogue | rows"]
 print("lines %d: cycles per step (workgroup 0, waves 0..3; s_memtime ticks = 100 MHz? see total vs wall)" % BS)
 for k, n in enumerate(names):
-    print("  %-42s" % n + "".join("%9.1f" % v[w, k] for w in range(4)))
-print("  %-30s" % "total" + "".join("%9.1f" % v[w, :7].sum() for w in range(4)))
+    print("  %-42s" % n + "".join("%9.1f" % v[w, k] for w in range(8)))
+print("  %-30s" % "total" + "".join("%9.1f" % v[w, :6].sum() for w in range(8)))
 
 # forward launch time by what the memory pipeline is asked to do (mfma_dbg bits: 1 no activation rows, 2 no c / h / source rows, 4 no inputs)
 for dbg in (0, 1, 2, 3, 7):

@@ -1,7 +1,7 @@
 """The narrow layer's recurrence batched over 16 lines per workgroup on the f16 MFMA (clstm_amd/csrc/lstm_mfma.h) against the oracle.
 
 -m gpu only: the kernels exist for gfx950 alone (the host emulator keeps the per-line kernels).  The path is forced onto small
-minibatches (experiment switch fwd_mfma=2; the default takes it from 192 lines per GPU on); `run_case` then checks EVERY saved
+minibatches (experiment switch fwd_mfma=2; the default takes it from 640 lines per GPU on); `run_case` then checks EVERY saved
 activation (gi, gf, go, ci, c, h of both directions, 1e-4 relative: BASELINE.json north_star), the softmax outputs, bit-exact
 decodes, CTC, every gate delta, the minibatch gradient and the update -- and the path counter proves the MFMA kernel really ran.
 Reference semantics: /root/reference/clstm.cc:600-653, clstm_compute.cc:275-320,504-547."""
