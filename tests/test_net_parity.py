@@ -31,21 +31,27 @@ def _forget_debug_options(request):
 
 
 def run_case(backend, ora32, ni, nh, nc, T, uni=False, scale=30.0, seed=1, lr=1e-2, check_dx=False,
-             ctc_rtol=1e-4, grad_tol=1e-4, overlap=None):
+             ctc_rtol=1e-4, grad_tol=1e-4, overlap=None, params=None, lines=None, trs=None, strict_f32=False, act_atol=None, delta_tol=None):
+    """`params` / `lines` / `trs` given: that weight set, those input lines and transcripts instead of init x scale on noise"""
     from clstm_amd.net import Network
     rng = np.random.default_rng(seed)
     nhl = nh if isinstance(nh, list) else [nh]
     dirs = (0,) if uni else (0, 1)
-    ref = OracleNet(ora32, ni, nh, nc, unidirectional=uni, seed=0.222)
-    params = ref.get_params() * scale
-    lines = synth_lines(rng, T, ni)
-    trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+    if params is None:
+        ref = OracleNet(ora32, ni, nh, nc, unidirectional=uni, seed=0.222)
+        params = ref.get_params() * scale
+    if lines is None:
+        lines = synth_lines(rng, T, ni)
+    if trs is None:
+        trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
     skeys = [(l, d, w) for l in range(len(nhl)) for d in dirs for w in STATES + DELTAS]
     want = oracle_minibatch(ora32, OracleNet, params, ni, nh, nc, lines, trs, unidirectional=uni,
                             states=skeys, lr=lr, mom=0.9)
     net = Network(ni, nh, nc, unidirectional=uni, lib=backend.lib)
     net.set_params(params)
     net.setLearningRate(lr, 0.9)
+    if strict_f32:
+        net.set_strict_f32(True)
     if overlap is not None:
         net.set_overlap(overlap)
     if check_dx:
@@ -59,7 +65,7 @@ def run_case(backend, ora32, ni, nh, nc, T, uni=False, scale=30.0, seed=1, lr=1e
         if k[2] in STATES:
             s = net.split(net.state(*k))
             for b in range(len(T)):
-                assert_close(s[b], want["states"][k][b], what="state %s line %d" % (k, b))
+                assert_close(s[b], want["states"][k][b], what="state %s line %d" % (k, b), **({} if act_atol is None else {"atol": act_atol[k] if isinstance(act_atol, dict) else act_atol}))
     dec = net.decode()
     for b in range(len(T)):
         assert dec[b].tolist() == want["decode"][b].tolist()       # bit-exact decode
@@ -71,7 +77,8 @@ def run_case(backend, ora32, ni, nh, nc, T, uni=False, scale=30.0, seed=1, lr=1e
         if k[2] in DELTAS:
             s = net.split(net.state(*k))
             for b in range(len(T)):
-                assert_close(s[b], want["states"][k][b], rtol=grad_tol, atol=1e-9, scale_atol=grad_tol, what="delta %s line %d" % (k, b))
+                dt = grad_tol if delta_tol is None else delta_tol[k]
+                assert_close(s[b], want["states"][k][b], rtol=dt, atol=1e-9, scale_atol=dt, what="delta %s line %d" % (k, b))
     assert_close(net.get_grads(), want["derivs"], rtol=grad_tol, atol=1e-9, scale_atol=grad_tol, what="minibatch gradient")
     net.update()
     want["net"].update()
