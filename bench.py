@@ -85,40 +85,138 @@ def flops_per_line(cfg, T):
     return 48.0 * T * sum(o * (i + o) for i, o in zip(nis, cfg["nh"])) + 6.0 * T * cfg["nc"] * 2 * cfg["nh"][-1]
 
 
+def cpu_topology():
+    """(one logical CPU per physical core, all logical CPUs) among the CPUs this process may run on"""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, phys = set(), []
+    for c in allowed:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+            pkg = open("/sys/devices/system/cpu/cpu%d/topology/physical_package_id" % c).read().strip()
+            key = (pkg, sib)
+        except OSError:
+            key = c
+        if key not in seen:
+            seen.add(key)
+            phys.append(c)
+    return phys, allowed
+
+
+def cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max / v1 cfs quota), or None: threads beyond it are
+    throttled, not run (the GPU box of this pool: 256 hardware threads visible, cpu.max = 16 CPUs -- 128 threads gave the same
+    1.4k lines/s as 16)"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+CPU_TOPOLOGY = cpu_topology()     # at import: once libgomp is loaded (OMP_PROC_BIND above) the main thread is bound to one CPU
+
+
 def cpu_baseline(params, cfg, seconds_target=12.0):
-    """The oracle (CPU restatement of the reference's Eigen path, `kind: port`) timed on this box's host cores on a
-    bounded sample of the same workload: fwd+CTC+bwd of T=200 lines, OpenMP over lines on every hardware thread (the
-    generous 'Eigen/OpenMP' figure; median of three runs) and single-threaded."""
+    """The oracle (CPU restatement of the reference's Eigen path, `kind: port`) timed on this box's host cores on a bounded
+    sample of the same workload: fwd+CTC+bwd of T=200 lines -- single-threaded (what scons + Eigen executes: its tensor
+    contractions on DefaultDevice do not thread) and OpenMP over lines (the generous 'Eigen/OpenMP' figure) with every thread
+    pinned to its own CPU, on its own preallocated net, one untimed line first (oracle/clstm_oracle.c:ora_bench_lines_pinned),
+    once on one thread per PHYSICAL core and once on every hardware thread; the best of the two is `value`."""
     from oracle.oracle import Oracle, OracleNet
     ora = Oracle("f32")
     net = OracleNet(ora, cfg["ni"], cfg["nh"], cfg["nc"], init=False)
     net.set_params(params)
     rng = np.random.default_rng(123)
-    cores = os.cpu_count() or 1
-    nlines = max(8, cores)
+    phys, logical = CPU_TOPOLOGY
+    quota = cpu_quota()
+    cap = len(logical) if quota is None else max(1, int(quota))
+    nlines = 64
     Ts, x, labels = synth_batch(rng, nlines, 200, False, cfg["ni"], cfg["nc"], cfg["L"])
     offs = np.concatenate([[0], np.cumsum(Ts)])
     loffs = np.concatenate([[0], np.cumsum([len(l) for l in labels])])
     lab = np.concatenate(labels)
-    t1 = net.bench_lines(x, offs, lab, loffs, nthreads=1, reps=1)       # also warms the page cache
-    single = nlines / t1
-    reps = max(1, int(seconds_target / 3.0 * single * min(cores, 4) / nlines))
-    runs = sorted(nlines * reps / net.bench_lines(x, offs, lab, loffs, nthreads=cores, reps=reps) for _ in range(3))
-    multi = runs[1]
+    t1 = net.bench_lines(x[:offs[16]], offs[:17], lab[:loffs[16]], loffs[:17], nthreads=1, reps=1, cpus=logical[:1])
+    single = 16 / t1
+    legs = {}
+    for name, cpus in (("physical", phys[:cap]), ("logical", logical[:cap] if len(logical) > len(phys) and cap > len(phys) else None)):
+        if cpus is None:
+            continue
+        n = len(cpus)
+        # calibrate on 2 lines per thread, then two runs of ~seconds_target / 5 each (every thread at least 4 lines)
+        r0 = max(1, int(np.ceil(2.0 * n / nlines)))
+        rate0 = nlines * r0 / net.bench_lines(x, offs, lab, loffs, nthreads=n, reps=r0, cpus=cpus)
+        reps = max(1, int(np.ceil(max(seconds_target / 5.0 * rate0, 4.0 * n) / nlines)))
+        runs = sorted(nlines * reps / net.bench_lines(x, offs, lab, loffs, nthreads=n, reps=reps, cpus=cpus) for _ in range(2))
+        legs[name] = {"threads": n, "lines_per_s": round(runs[-1], 1), "runs": [round(r, 1) for r in runs],
+                      "parallel_efficiency": round(runs[-1] / (single * n), 3), "lines_timed": nlines * reps}
+    best = max(legs, key=lambda k: legs[k]["lines_per_s"])
+    multi = legs[best]["lines_per_s"]
     use_multi = multi >= single
     return {
         "value": round(multi if use_multi else single, 2), "unit": "lines/s",
-        "cores": cores if use_multi else 1, "kind": "port",
-        "sample": "%d lines x %d reps of T=200 fwd+CTC+bwd, OpenMP over lines on %d threads, median of 3 runs "
-                  "(%.1f / %.1f / %.1f lines/s); single thread %.1f lines/s; gcc -O3 -march=native" %
-                  (nlines, reps, cores, runs[0], runs[1], runs[2], single),
+        "cores": legs[best]["threads"] if use_multi else 1, "kind": "port",
+        "single_thread_lines_per_s": round(single, 1),
+        "parallel_efficiency": legs[best]["parallel_efficiency"] if use_multi else 1.0,
+        "physical_cores": len(phys), "hardware_threads": len(logical), "cgroup_cpu_quota": quota, "legs": legs,
+        "sample": "T=200 lines, fwd+CTC+bwd each (the reference's per-line work incl. its memset per Sequence resize): single thread "
+                  "%.1f lines/s over 16 lines; OpenMP over lines on %s, threads pinned one per physical core, per-thread preallocated "
+                  "nets, one untimed line per thread first, best of 2 runs of %d lines: %s; gcc -O3 -march=native" %
+                  (single,
+                   ("%d threads = the container's cgroup CPU quota (%.0f of the host's %d cores / %d hardware threads; threads beyond "
+                    "the quota are throttled, not run)" % (cap, quota, len(phys), len(logical))) if quota is not None and cap < len(logical)
+                   else "every core (%d physical, %d hardware threads)" % (len(phys), len(logical)),
+                   legs[best]["lines_timed"],
+                   "; ".join("%s: %d threads %.1f lines/s (parallel efficiency %.2f)" % (k, v["threads"], v["lines_per_s"], v["parallel_efficiency"])
+                             for k, v in legs.items())),
     }
+
+
+def trained_weights_and_lines(lib, cfg, rng, Ts_list):
+    """SURVEY.md 8(d)'s "trained-like" regime WITHOUT the oracle (bench.py may use oracle/ for cpu_baseline only): the uw3 net is
+    trained by the HIP path itself -- 500 online-SGD steps (CLSTMOCR::train, clstmhl.h:201-223; lr 1e-2) on the reference's OCR
+    fixture line, the recipe tests/trained_weights.py runs on the oracle -- and the minibatches are jittered crops of that
+    normalised line (clstm_amd/fixture.py), each with the transcript the trained net decodes on it.  Returns (parameters,
+    [(Ts, x, labels)], info)."""
+    from clstm_amd.fixture import GT, fixture_frames, fixture_transcript, jittered_crops
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Network
+    assert cfg["ni"] == 48 and len(cfg["nh"]) == 1, "the fixture is a 48-row line for the one-layer uw3 net"
+    x, tr = fixture_frames(), fixture_transcript()
+    net = Network(cfg["ni"], cfg["nh"][0], cfg["nc"], lib=lib)
+    net.set_params(init_params(cfg["ni"], cfg["nh"][0], cfg["nc"], seed=0.222))
+    net.setLearningRate(1e-2, 0.9)
+    for _ in range(500):
+        net.set_inputs([x]); net.forward(); net.ctc([tr]); net.backward(); net.update()
+    net.set_inputs([x]); net.forward()
+    reads = net.decode()[0].tolist() == tr.tolist()
+    params = net.get_params().copy()
+    batches, nlab = [], []
+    for Ts in Ts_list:
+        lines = jittered_crops(rng, Ts)
+        net.set_inputs(lines); net.forward()
+        labels = [np.asarray(d, np.int32) if len(d) and 2 * len(d) + 1 <= t else np.array([1], np.int32) for d, t in zip(net.decode(), Ts)]
+        nlab += [len(l) for l in labels]
+        batches.append((Ts, np.concatenate(lines, 0), labels))
+    out = net.split(net.outputs())
+    info = {"weights": "500 online-SGD steps of this library on tests/golden/textline.bin.png (lr 1e-2, momentum 0.9)",
+            "reads_fixture": bool(reads), "ground_truth": GT, "max_abs_parameter": round(float(np.abs(params).max()), 3),
+            "mean_max_posterior": round(float(np.mean([o.max(1).mean() for o in out])), 4),
+            "labels_per_line_mean": round(float(np.mean(nlab)), 1),
+            "inputs": "jittered crops of the normalised fixture line (clstm_amd/fixture.py), transcripts = the trained net's own decodes"}
+    return params, batches, info
 
 
 class Workload:
     """One network + a small rotating pool of synthetic minibatches resident in HBM."""
 
-    def __init__(self, lib, cfg, minibatch, T, ragged, precision, dev, rank, comm=None, dist=None, host_inputs=False, strict_f32=False):
+    def __init__(self, lib, cfg, minibatch, T, ragged, precision, dev, rank, comm=None, dist=None, host_inputs=False, strict_f32=False,
+                 weights="init"):
         import torch
         from clstm_amd.init import init_params
         from clstm_amd.net import Network
@@ -126,6 +224,12 @@ class Workload:
         self.cfg, self.minibatch, self.T, self.ragged, self.precision = cfg, minibatch, T, ragged, precision
         nh = cfg["nh"][0] if len(cfg["nh"]) == 1 else cfg["nh"]
         self.params_h = init_params(cfg["ni"], nh, cfg["nc"], seed=0.222)
+        rng = np.random.default_rng(1000 + rank)
+        self.weights_info = None
+        batches = None
+        if weights == "trained":
+            Ts_list = [[int(t) for t in (rng.integers(150, 251, minibatch) if ragged else [T] * minibatch)] for _ in range(4)]
+            self.params_h, batches, self.weights_info = trained_weights_and_lines(lib, cfg, rng, Ts_list)
         n = self.params_h.size
         self.params = torch.from_numpy(self.params_h).to(dev)
         self.derivs = torch.zeros(n, device=dev)
@@ -138,10 +242,9 @@ class Workload:
         if strict_f32:
             self.net.set_strict_f32(True)
         self.trainer = Trainer(self.net, grads_tensor=self.grads if (comm is None and dist is not None) else None, comm=comm)
-        rng = np.random.default_rng(1000 + rank)
         self.pool = []
-        for _ in range(4):
-            Ts, x, labels = synth_batch(rng, minibatch, T, ragged, cfg["ni"], cfg["nc"], cfg["L"])
+        for k in range(4):
+            Ts, x, labels = batches[k] if batches else synth_batch(rng, minibatch, T, ragged, cfg["ni"], cfg["nc"], cfg["L"])
             xt = torch.from_numpy(x).pin_memory() if host_inputs else torch.from_numpy(x).to(dev)
             self.pool.append((Ts, xt, labels, Network.prepare_step(Ts, labels)))
         self.host_inputs = host_inputs
@@ -387,6 +490,9 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="frames start in pinned HOST memory every step (clstm_net_train_step_h): the PCIe-inclusive rate, "
                          "not the headline `value` (bench contract: inputs resident in HBM)")
+    ap.add_argument("--weights", choices=["init", "trained"], default="init",
+                    help="trained: the SURVEY 8(d) 'trained-like' regime -- weights after 500 online-SGD steps on the reference's fixture line, "
+                         "inputs = jittered crops of that line (config b1 only); the default line carries it as the `trained_weights` leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="the headline workload only: skip the other legs of the default line (strict_f32, saturated, configs[4] in both precisions) -- "
@@ -421,6 +527,11 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # a hang becomes a stack dump of every thread and a non-zero exit instead of the caller's time-out (multi-rank runs: the
+    # collectives of a step wait for every rank) -- CLSTM_BENCH_WATCHDOG_S, default 20 minutes per rank process
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("CLSTM_BENCH_WATCHDOG_S", "1200")), exit=True)
+
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -429,11 +540,15 @@ def main():
         sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d (launch with torch.distributed.run --nproc-per-node %d, "
                  "or without WORLD_SIZE and let bench.py spawn the ranks)" % (world, args.gpus, args.gpus))
     backend = os.environ.get("CLSTM_BENCH_BACKEND", "nccl")      # ("nccl" IS RCCL on ROCm; gloo: the CPU test of this rank body)
+    # test hook (tests/test_bench_ranks.py, -m gpu): N rank processes SHARE device 0 -- the rank body, the library communicator's
+    # peer-read exchange (CLSTM_COMM_NO_RCCL=1: RCCL refuses duplicate devices) and the JSON line on the real library with one GPU
+    share_dev = os.environ.get("CLSTM_BENCH_SHARE_DEVICE") == "1"
+    dev_index = 0 if share_dev else local_rank
     if not ON_CPU:
-        if torch.cuda.device_count() <= local_rank:
-            sys.exit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local_rank, torch.cuda.device_count()))
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cpu") if ON_CPU else torch.device("cuda", local_rank)
+        if torch.cuda.device_count() <= dev_index:
+            sys.exit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, dev_index, torch.cuda.device_count()))
+        torch.cuda.set_device(dev_index)
+    dev = torch.device("cpu") if ON_CPU else torch.device("cuda", dev_index)
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):   # BENCH_FORCE_DIST=1: exercise the RCCL path on one GPU
         import torch.distributed as dist
@@ -484,7 +599,7 @@ def main():
     def reduce_max(dt):
         if dist is None:
             return dt
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
@@ -499,16 +614,39 @@ def main():
         t_enq = (time.perf_counter() - t1) / 4
         fence()
         kern, fps, kern_unfused = {}, 0, {}
-        if rank == 0 and profile_steps > 0:
+        if profile_steps > 0:
+            # EVERY rank takes these steps (with a communicator a step is a collective: rank 0 stepping alone waited for its
+            # peers forever -- found by tests/test_bench_ranks.py::test_bench_gpus2_on_the_real_library_sharing_one_gpu before
+            # the first multi-GPU run); rank 0's figures are the ones reported
             kern, fps = kernel_times(w, profile_steps, nxt + 4, dt / steps * 1e3)
+            fence()
             if unfused_pass and world == 1:      # the pure kernels: the same steps with the fused launches off
                 w.net.set_overlap(0)
                 kern_unfused, _ = kernel_times(w, profile_steps, nxt + 4 + profile_steps, dt / steps * 1e3)
                 w.net.set_overlap(1)
+            if rank != 0:
+                kern, kern_unfused = {}, {}
         return {"dt": dt, "blocks": blocks, "enqueue": t_enq, "kern": kern, "kern_unfused": kern_unfused, "frames_per_step": fps}
 
     precision = 2 if args.bf16 else 1 if args.bf16_gemm else 0
-    w = Workload(lib, cfg, args.minibatch, args.T, args.ragged, precision, dev, rank, comm=comm, dist=dist, host_inputs=args.host_inputs)
+    w = Workload(lib, cfg, args.minibatch, args.T, args.ragged, precision, dev, rank, comm=comm, dist=dist, host_inputs=args.host_inputs,
+                 weights=args.weights)
+    if share_dev and world > 1:
+        # ranks SHARING a device (test hook only): the fused launches' role workgroups wait for each other inside one launch,
+        # which needs the launch's workgroups co-resident -- true with one process per GPU (the only supported deployment: 128
+        # recurrence workgroups + their helpers on 256 CUs), not with a second process filling the same CUs (measured: two
+        # 64-line ranks on one MI355X stall in the first fused launch).  Separate launches there.
+        w.net.set_overlap(0)
+    if comm is not None:
+        # which exchange this rank's steps use, said on every rank as soon as it is decided (the first training step sets the
+        # peer path up, collectively): it needs every rank to have mapped every other rank's buffers (hipIpcOpenMemHandle) AND
+        # the probe handshakes through the mappings to deliver; otherwise every rank falls back to RCCL
+        w.step(0)
+        device_sync()
+        pa = int(lib.dll.clstm_comm_peer_active(comm.h))
+        sys.stderr.write("bench.py: rank %d / %d on %s: clstm_comm_peer_active = %d (%s)\n" % (
+            rank, world, dev, pa, "peer-read all-reduce over HIP IPC mappings, fused into the update kernel" if pa else
+            "no peer mappings (ranks on different nodes, or hipIpcOpenMemHandle / the probe failed): RCCL ncclAllReduce"))
     m = measure(w, args.steps, args.warmup, args.profile_steps, unfused_pass=max(cfg["nh"]) <= 128)
     dt = m["dt"]
     ms_per_step = dt / args.steps * 1e3
@@ -546,6 +684,7 @@ def main():
             allreduce_impl = ("one-shot peer-read all-reduce fused into the update kernel (HIP IPC mappings of the ranks' gradient buffers over "
                               "xGMI, flag handshake; ops.h:k_peer_allreduce_update) inside clstm_net_train_step; clstm_allreduce_flat = RCCL")
         allreduce = {"impl": allreduce_impl, "ranks": allreduce_ranks, "bytes": int(w.grads.numel()) * 4,
+                     "peer_active": bool(comm is not None and int(lib.dll.clstm_comm_peer_active(comm.h))),
                      "ms_per_call_isolated": None if ar_ms is None else round(ar_ms, 4),
                      "note": "ranks = clstm_comm_size of the communicator the step all-reduces on; the isolated figure is 50 calls back "
                              "to back on the library stream (max over ranks) -- inside a step the call sits between the last reduction and the update"}
@@ -554,8 +693,21 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w.params_h, cfg)
 
-    # the same workload with EVERY product on the exact f32 MFMA (clstm_net_set_strict_f32: the default computes the backward
-    # weight-gradient / softmax-backward products as f32-grade bf16 x 3 split products); default single-GPU line only
+    # the same workload in the TRAINED regime: speed must not depend on the weights -- peaked posteriors and
+    # saturated gates walk the same kernels (default single-GPU line only)
+    trained = None
+    if rank == 0 and world == 1 and default_line and args.weights == "init" and not args.no_secondary:
+        wt = Workload(lib, cfg, args.minibatch, args.T, args.ragged, 0, dev, rank, weights="trained")
+        mt_ = measure(wt, args.steps, 5, 0, min_timed_s=0.5)
+        trained = dict(wt.weights_info, value=round(args.minibatch * args.steps / mt_["dt"], 2), unit="lines/s",
+                       ms_per_step=round(mt_["dt"] / args.steps * 1e3, 4), repeats=len(mt_["blocks"]),
+                       parity="tests/test_gpu_e2e.py::test_full_bench_shape_trained_weights_real_line_crops (same recipe on the oracle)")
+        wt.net = wt.trainer = None
+        del wt
+
+    # the same workload with EVERY product on the f32 MFMA (clstm_net_set_strict_f32: the default computes the backward
+    # weight-gradient / softmax-backward products on the bf16 MFMA from f32 operands split exactly into three bf16 terms);
+    # default single-GPU line only
     strict = None
     if rank == 0 and world == 1 and default_line and not args.no_secondary:
         ws = Workload(lib, cfg, args.minibatch, args.T, args.ragged, 0, dev, rank, strict_f32=True)
@@ -646,8 +798,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 MFMA operands (hoisted gate GEMMs and lock-step recurrence), f32 accumulate / state / softmax / CTC" if args.bf16
                       else "f32 (hoisted gate GEMMs: bf16 in, f32 accumulate)" if args.bf16_gemm
-                      else "f32 (forward, recurrences, CTC, decode: exact f32; backward weight-gradient / softmax-backward products: "
-                           "bf16x3 split, < 2^-16 per product -- `strict_f32` carries the all-f32-MFMA figure)" if b1
+                      else "f32 (operand-exact split): forward, recurrences, CTC, decode in f32 arithmetic; the backward weight-gradient / "
+                           "softmax-backward products take their f32 operands split EXACTLY into three bf16 terms each (x1 + x2 + x3 = x) and "
+                           "sum the six bf16-MFMA products of weight >= 2^-16 in f32 -- what is dropped is < 2^-23 |x||y| per product, the size of "
+                           "an f32 multiply's own rounding; `strict_f32` carries the same step on the f32 MFMA" if b1
                       else "f32 (forward pass incl. its recurrences, CTC, decode: exact f32; BACKWARD products of the wide layers -- weight gradient, "
                            "input deltas and the recurrent delta product inside the backward recurrence: f32-grade bf16x3 split, < 2^-16 per product)"),
             "data": "synthetic" + (" (frames fed from pinned host memory every step: PCIe-inclusive)" if args.host_inputs else ""),
@@ -666,6 +820,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": m["kern"], "kernels_fusions_off": m["kern_unfused"],
             "host_enqueue_ms_per_step": round(m["enqueue"] * 1e3, 4),   # host-side cost of issuing a step
             "allreduce": allreduce,
+            "weights": (w.weights_info or "reference initialisation (rinit negbiased, seed 0.222)"),
+            "trained_weights": trained,
             "strict_f32": strict,
             "saturated": saturated,
             "secondary": secondary,

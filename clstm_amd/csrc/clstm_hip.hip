@@ -235,8 +235,9 @@ static void launch_lstm(bool fwd, int nk4, int ku, LstmSeqArgs a, int bs, int nt
 template <int NK4, int KU>
 static void launch_bwd_dw(const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s) {
   const size_t smem = (2 * 16 * (size_t)lstm_qstride(NK4) + 4) * sizeof(float);
-  if (g.x3) CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU, true>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec);
-  else CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU, false>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec);
+  if (g.x3 && g.terms >= 3) CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU, 3>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec);
+  else if (g.x3) CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU, 2>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec);
+  else CLSTM_LAUNCH((lstm_bwd_dw_kernel<NK4, KU, 0>), dim3(nrec + ngemm), dim3(nthreads), smem, s, a, g, nrec);
 }
 static bool launch_lstm_bwd_dw(int nk4, int ku, const LstmSeqArgs& a, const GemmDwArgs& g, int nrec, unsigned ngemm, int nthreads, hipStream_t s) {
 #define CASE_(N, K) if (nk4 == N && ku == K) { launch_bwd_dw<N, K>(a, g, nrec, ngemm, nthreads, s); check_launch(); return true; }
@@ -1418,9 +1419,12 @@ struct Net {
     }
   }
 
-  // overlapped weight-gradient GEMM: 1 = bf16 MFMA on hi + lo split operands (three products, f32-grade: gemm_dw.h),
-  // 0 = f32 MFMA (CLSTM_DW_X3=0)
+  // overlapped weight-gradient GEMM: 1 = bf16 MFMA on f32 operands split into bf16 terms (gemm_dw.h), 0 = f32 MFMA
+  // (experiment option dw_x3=0)
   int dw_x3 = dbg_opt("dw_x3", 1);
+  // terms per operand of those split products and of the softmax layer's (gemm_x3): 3 = operand-exact (x1 + x2 + x3 is the f32
+  // itself, six products), 2 = hi + lo, three products (< 2^-16 per product; rounds 3-5)
+  int split_terms = dbg_opt("split_terms", 3);
   // the softmax layer's backward products W.d / x.d the same way (gemm_x3, gemm_bf16.h); CLSTM_GEMM_X3=0: f32 MFMA.
   // NOT the forward product W_x.x: its ~2^-17 relative error per product shows up in gate pre-activations that cancel to
   // ~0 (a tanh gate at -0.0021 came out 5.6e-6 off where the parity bar allows 2.2e-6), and with K = 49 the split costs
@@ -1561,6 +1565,7 @@ struct Net {
     g.tcap = tmax + 32;
     g.done = nullptr; g.done_target = 0;
     g.x3 = dw_x3;
+    g.terms = split_terms;
     unsigned nextra = 0;
     if (dwx_active && &y == &L.back()) {
       const int xR = 1 + sm_ni, xCn = desc.nclasses;
@@ -1602,8 +1607,9 @@ struct Net {
     launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
     timing.end(s);
     timing.begin("gemm_gates_dw", s);
-    if (g.x3) CLSTM_LAUNCH(gemm_dw_kernel<true>, dim3(nblk), dim3(256), 0, s, g);
-    else CLSTM_LAUNCH(gemm_dw_kernel<false>, dim3(nblk), dim3(256), 0, s, g);
+    if (g.x3 && g.terms >= 3) CLSTM_LAUNCH(gemm_dw_kernel<3>, dim3(nblk), dim3(256), 0, s, g);
+    else if (g.x3) CLSTM_LAUNCH(gemm_dw_kernel<2>, dim3(nblk), dim3(256), 0, s, g);
+    else CLSTM_LAUNCH(gemm_dw_kernel<0>, dim3(nblk), dim3(256), 0, s, g);
     timing.end(s);
     check_launch();
   }
@@ -1662,7 +1668,8 @@ struct Net {
       // epilogue latency on its own (13.9 + 12.4 us back to back)
       timing.begin("gemm_softmax_dw_dx", s);
       if (dwx_active)
-        gemm_x3<GEMM_KC, GEMM_KC>(s, gemm_kc(Dz.p, nc, N), gemm_kc(W1 + nc, nc, sm_ni, 0), StorePlain{top.dH.p, sm_ni}, (int)N, sm_ni, nc);
+        gemm_x3<GEMM_KC, GEMM_KC>(s, gemm_kc(Dz.p, nc, N), gemm_kc(W1 + nc, nc, sm_ni, 0), StorePlain{top.dH.p, sm_ni}, (int)N, sm_ni, nc,
+                                  1, 1, split_terms);
       else if (sm_big) {
         gemm_x3_big<GEMM_MC, GEMM_MC>(s, gemm_mc(top.srow(), top.ldh, N, 32), gemm_mc(Dz.p, nc, N, 32), StorePartial{partial_sm.p, R, Cn}, R, Cn, (int)N, ns);
         gemm_x3_big<GEMM_KC, GEMM_KC>(s, gemm_kc(Dz.p, nc, N, 32), gemm_kc(W1 + nc, nc, sm_ni, 0), StorePlain{top.dH.p, sm_ni}, (int)N, sm_ni, nc);
@@ -1670,7 +1677,8 @@ struct Net {
         gemm_x3_pair<GEMM_MC, GEMM_MC, StorePartial, GEMM_KC, GEMM_KC, StorePlain>(
             s, gemm_problem(gemm_mc(top.srow(), top.ldh, N), gemm_mc(Dz.p, nc, N), R, Cn, (int)N, ns),
             StorePartial{partial_sm.p, R, Cn},
-            gemm_problem(gemm_kc(Dz.p, nc, N), gemm_kc(W1 + nc, nc, sm_ni, 0), (int)N, sm_ni, nc), StorePlain{top.dH.p, sm_ni});
+            gemm_problem(gemm_kc(Dz.p, nc, N), gemm_kc(W1 + nc, nc, sm_ni, 0), (int)N, sm_ni, nc), StorePlain{top.dH.p, sm_ni},
+            split_terms);
       else
       gemm_f32_pair<GEMM_MC, GEMM_MC, StorePartial, GEMM_KC, GEMM_KC, StorePlain>(
           s, gemm_problem(gemm_mc(top.srow(), top.ldh, N), gemm_mc(Dz.p, nc, N), R, Cn, (int)N, ns),
@@ -2733,6 +2741,7 @@ int clstm_net_set_strict_f32(clstm_net* h, int on) {
   else {
     n.dw_x3 = dbg_opt("dw_x3", 1);
     n.gemm_x3_on = dbg_opt("gemm_x3", 1) != 0;
+    n.split_terms = dbg_opt("split_terms", 3);
   }
   n.packed_dirty = true;   // (the hi | lo weights of the f32-grade backward recurrence are only packed while that mode is on)
   ABI_END

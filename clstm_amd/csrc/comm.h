@@ -72,6 +72,8 @@ struct PeerExchange {
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <signal.h>
+#include <cerrno>
 namespace clstm {
 // seconds from an environment variable (a hang detector's bound, read once per use site)
 static double env_seconds(const char* name, double dflt) {
@@ -84,20 +86,31 @@ static double env_seconds(const char* name, double dflt) {
 static long long peer_device_timeout_ticks() { return (long long)(env_seconds("CLSTM_PEER_TIMEOUT_S", 120.0) * 1e8); }
 // What the hosts of a communicator share besides the set-up handshake: announced[r] = the last exchange sequence number rank r's
 // host is about to enqueue the device barrier for; left[r] = rank r has destroyed its communicator (or failed).
-struct PeerHostWords { std::atomic<int> announced[PEER_MAX_RANKS], left[PEER_MAX_RANKS]; };
+struct PeerHostWords { std::atomic<int> announced[PEER_MAX_RANKS], left[PEER_MAX_RANKS], pid[PEER_MAX_RANKS]; };
 // Before a rank enqueues k_peer_barrier for sequence number sq it announces sq and waits -- on the HOST, as long as it takes,
 // like ncclAllReduce would -- until every rank's host has announced it too.  A rank whose host is busy elsewhere (clstmocrtrain's
 // rank 0 runs the test set and saves while the others are already at the next step) therefore stalls its peers' hosts, not
 // their GPUs' watchdog: the device barrier only ever waits for queued device work.  The wait is unbounded, like a collective's;
 // a peer that has left the communicator ends it with an error at once.
+// A rank that died without running ~Comm (SIGKILL, _exit, a crash) never sets left[r]: about once a second of waiting the
+// waiter asks the kernel whether the process that announced as rank r still exists; the wait itself stays unbounded
+// for a LIVE peer, like a collective's.
+static void peer_liveness(PeerHostWords* w, int r, int sq, int spins) {
+  if (spins < 2000 || (spins - 2000) % 10000 != 0) return;
+  const int pid = w->pid[r].load();
+  if (pid > 0 && kill((pid_t)pid, 0) != 0 && errno == ESRCH)
+    throw Error("gradient exchange: the process of rank " + std::to_string(r) + " (pid " + std::to_string(pid) + ") is gone (exchange " + std::to_string(sq) + " never announced)");
+}
 static void peer_announce_and_wait(PeerHostWords* w, int rank, int nranks, int sq) {
   if (!w) return;
+  w->pid[rank].store((int)getpid());
   w->announced[rank].store(sq);
   for (int r = 0; r < nranks; r++) {
     int spins = 0;
     while ((int)((unsigned)sq - (unsigned)w->announced[r].load()) > 0) {   // (wrap-safe: rank r is still behind sq)
       if (w->left[r].load()) throw Error("gradient exchange: rank " + std::to_string(r) + " has left the communicator (exchange " + std::to_string(sq) + " never announced)");
       if (++spins < 2000) sched_yield(); else usleep(100);
+      peer_liveness(w, r, sq, spins);
     }
   }
 }
@@ -173,7 +186,7 @@ struct Comm {
     HIPCHECK(hipStreamSynchronize(s));
     Handles mine{};
     mine.ok = 1;
-    p.cap = (PEER_MAX_FLOATS < ((n + 63) / 64 * 64) ? PEER_MAX_FLOATS : (n + 63) / 64 * 64);
+    p.cap = PEER_MAX_FLOATS;   // (not the first caller's n: a 4-float replica check may come before the first gradient exchange)
     // Exchange slots AND flags are fine-grained device memory: what a peer reads through its mapping while kernels of the owner
     // are still running must not depend on when the owner's L2 writes a line back, nor on a cache of the reader's side holding
     // the slot's lines of two steps ago -- fine-grained allocations are coherent at system scope by construction (the readers
@@ -263,6 +276,8 @@ struct Comm {
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <signal.h>
+#include <cerrno>
 namespace clstm {
 // Host emulator: the ranks are host PROCESSES and the communicator is a POSIX shared-memory segment (one slot of
 // SLOT floats per rank + a sense-reversing barrier) -- so that the world-size-2 CPU test drives the same entry points
@@ -286,7 +301,7 @@ struct PeerExchange {   // (host emulator: the "mapped" buffers and flags of the
   }
 };
 // (the hosts' announce words: see the GPU build's PeerHostWords / peer_announce_and_wait above -- same protocol)
-struct PeerHostWords { std::atomic<int> announced[PEER_MAX_RANKS], left[PEER_MAX_RANKS]; };
+struct PeerHostWords { std::atomic<int> announced[PEER_MAX_RANKS], left[PEER_MAX_RANKS], pid[PEER_MAX_RANKS]; };
 static double env_seconds(const char* name, double dflt) {
   const char* e = getenv(name);
   if (!e || !*e) return dflt;
@@ -294,14 +309,25 @@ static double env_seconds(const char* name, double dflt) {
   return v > 0 ? v : dflt;
 }
 static long long peer_device_timeout_ticks() { return (long long)(env_seconds("CLSTM_PEER_TIMEOUT_S", 120.0) * 1e8); }
+// A rank that died without running ~Comm (SIGKILL, _exit, a crash) never sets left[r]: about once a second of waiting the
+// waiter asks the kernel whether the process that announced as rank r still exists; the wait itself stays unbounded
+// for a LIVE peer, like a collective's.
+static void peer_liveness(PeerHostWords* w, int r, int sq, int spins) {
+  if (spins < 2000 || (spins - 2000) % 10000 != 0) return;
+  const int pid = w->pid[r].load();
+  if (pid > 0 && kill((pid_t)pid, 0) != 0 && errno == ESRCH)
+    throw Error("gradient exchange: the process of rank " + std::to_string(r) + " (pid " + std::to_string(pid) + ") is gone (exchange " + std::to_string(sq) + " never announced)");
+}
 static void peer_announce_and_wait(PeerHostWords* w, int rank, int nranks, int sq) {
   if (!w) return;
+  w->pid[rank].store((int)getpid());
   w->announced[rank].store(sq);
   for (int r = 0; r < nranks; r++) {
     int spins = 0;
     while ((int)((unsigned)sq - (unsigned)w->announced[r].load()) > 0) {
       if (w->left[r].load()) throw Error("gradient exchange: rank " + std::to_string(r) + " has left the communicator (exchange " + std::to_string(sq) + " never announced)");
       if (++spins < 2000) sched_yield(); else usleep(100);
+      peer_liveness(w, r, sq, spins);
     }
   }
 }
@@ -330,7 +356,7 @@ struct Comm {
       p.px[r] = (float*)(base + (size_t)r * peer_region_bytes());
       p.pf[r] = (int*)(base + (size_t)r * peer_region_bytes() + (size_t)2 * SLOT * sizeof(float));
     }
-    p.cap = (n + 63) / 64 * 64; p.xbuf = p.px[rank]; p.flags = p.pf[rank];
+    p.cap = PEER_MAX_FLOATS; p.xbuf = p.px[rank]; p.flags = p.pf[rank];   // (as the GPU build: never the first caller's n)
     // the set-up probe of the GPU build, same kernels (ops.h:k_peer_fill / k_peer_probe), over the slot length in use
     int perr = 0;
     for (int round = 0; round < 4; round++) {

@@ -1246,11 +1246,13 @@ inline bool gemm_dw_dx(hipStream_t stream, GemmOperand16B A, GemmOperand16B B, F
 // Four swizzled [mn][32 k] images (A hi, A lo, B hi, B lo; gb2_sw) per buffer, two buffers, one barrier per block;
 // every thread stages 8 elements of each operand (KC: 8 consecutive k of a row -> one ds_write_b128 per image;
 // MC: 4 columns x (k, k+1) -> four ds_write_b32 per image); ring of three register-staged blocks.
+// NT = 3: three bf16 terms per operand (x1 + x2 + x3 represents an f32 exactly), six products -- the operand-exact form of
+// gemm_dw.h, the default of the narrow layers' backward products; images [A terms | B terms] per buffer.
 constexpr int GX3_IMG = 64 * 32;                 // halfs per image
-constexpr int GX3_SMEM_FLOATS = 2 * 4 * GX3_IMG / 2;   // 32 KB
-static_assert(GX3_SMEM_FLOATS >= GEMM_BT * GEMM_LDO, "epilogue tile");
+constexpr int gx3_smem_floats(int nt) { return 2 * 2 * nt * GX3_IMG / 2; }   // 32 KB (NT = 2) / 48 KB (NT = 3)
+static_assert(gx3_smem_floats(2) >= GEMM_BT * GEMM_LDO, "epilogue tile");
 
-template <int AMODE, int BMODE, class FE>
+template <int AMODE, int BMODE, class FE, int NT = 2>
 DEVFN void gemm_x3_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int ksplit, int nsplit,
                         const unsigned lin, const unsigned gx, const unsigned gy, const unsigned gz) {
   unsigned short* img = reinterpret_cast<unsigned short*>(smem);
@@ -1295,6 +1297,7 @@ DEVFN void gemm_x3_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R,
     b[1] = buf_load4(bbuf, boff1 + bo);
   };
   // split + store; contraction indices >= kend are zeroed (only the slab's last block and the zero blocks behind it)
+  constexpr int BUFH = 2 * NT * GX3_IMG;   // halfs per buffer
   auto stage = [&](const int MODE, unsigned short* hi, const int mn, const int kk, const int k0, const f32x4 (&r)[2]) {
     const bool whole = wave_uniform(k0 + GB_BK <= kend ? 1 : 0) != 0;
     float x[8];
@@ -1307,23 +1310,28 @@ DEVFN void gemm_x3_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R,
         x[i] = k0 + k < kend ? x[i] : 0.0f;
       }
     }
-    unsigned short* lo = hi + GX3_IMG;
     if (MODE == GEMM_KC) {
-      const u16x8 h = bf16_pack8(x);
-      float e[8];
-#pragma unroll
-      for (int i = 0; i < 8; i++) e[i] = x[i] - __builtin_bit_cast(float, (unsigned)h[i] << 16);
       const int o = mn * 32 + (((kk >> 3) ^ gb2_sw(mn)) << 3);
-      *reinterpret_cast<u16x8*>(hi + o) = h;
-      *reinterpret_cast<u16x8*>(lo + o) = bf16_pack8(e);
+#pragma unroll
+      for (int t = 0; t < NT; t++) {   // term t, then the exact remainder
+        const u16x8 h = bf16_pack8(x);
+        *reinterpret_cast<u16x8*>(hi + t * GX3_IMG + o) = h;
+        if (t + 1 < NT) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) x[i] -= __builtin_bit_cast(float, (unsigned)h[i] << 16);
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 4; i++) {   // column mn + i: the pair (k, k+1)
-        const unsigned h = bf16_pack2(x[i], x[4 + i]);
-        const float e0 = x[i] - __builtin_bit_cast(float, h << 16), e1 = x[4 + i] - __builtin_bit_cast(float, h & 0xffff0000u);
+        float e0 = x[i], e1 = x[4 + i];
         const int o = (mn + i) * 32 + ((((kk >> 3) ^ gb2_sw(mn + i)) << 3) | (kk & 7));
-        *reinterpret_cast<unsigned*>(hi + o) = h;
-        *reinterpret_cast<unsigned*>(lo + o) = bf16_pack2(e0, e1);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const unsigned h = bf16_pack2(e0, e1);
+          *reinterpret_cast<unsigned*>(hi + t * GX3_IMG + o) = h;
+          if (t + 1 < NT) { e0 -= __builtin_bit_cast(float, h << 16); e1 -= __builtin_bit_cast(float, h & 0xffff0000u); }
+        }
       }
     }
   };
@@ -1342,7 +1350,7 @@ DEVFN void gemm_x3_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R,
     SCHED_FENCE();
   }
   stage(AMODE, img, a_mn, a_k, kbeg, ra[0]);
-  stage(BMODE, img + 2 * GX3_IMG, b_mn, b_k, kbeg, rb[0]);
+  stage(BMODE, img + NT * GX3_IMG, b_mn, b_k, kbeg, rb[0]);
   load_tile(kbeg + GB_PF * GB_BK, ra[0], rb[0]);
   SCHED_FENCE();
   __syncthreads();
@@ -1355,28 +1363,29 @@ DEVFN void gemm_x3_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R,
       static_assert(GB_PF == 3, "register ring of three blocks");
       const int k0 = kb + p * GB_BK;
       const int pn = p == 2 ? 0 : p + 1;
-      unsigned short* nb = img + (cur ^ 1) * 4 * GX3_IMG;
+      unsigned short* nb = img + (cur ^ 1) * BUFH;
       stage(AMODE, nb, a_mn, a_k, k0 + GB_BK, ra[pn]);
-      stage(BMODE, nb + 2 * GX3_IMG, b_mn, b_k, k0 + GB_BK, rb[pn]);
+      stage(BMODE, nb + NT * GX3_IMG, b_mn, b_k, k0 + GB_BK, rb[pn]);
       load_tile(k0 + GB_BK + GB_PF * GB_BK, ra[pn], rb[pn]);
       SCHED_FENCE();
-      const unsigned short* b0 = img + cur * 4 * GX3_IMG;
-      u16x8 ah[2], al[2], bh[2], bl[2];
+      const unsigned short* b0 = img + cur * BUFH;
+      u16x8 at[NT][2], bt[NT][2];
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        ah[i] = *reinterpret_cast<const u16x8*>(b0 + (wm * 32 + i * 16) * 32 + fofs);
-        al[i] = *reinterpret_cast<const u16x8*>(b0 + GX3_IMG + (wm * 32 + i * 16) * 32 + fofs);
-        bh[i] = *reinterpret_cast<const u16x8*>(b0 + 2 * GX3_IMG + (wn * 32 + i * 16) * 32 + fofs);
-        bl[i] = *reinterpret_cast<const u16x8*>(b0 + 3 * GX3_IMG + (wn * 32 + i * 16) * 32 + fofs);
-      }
+      for (int t = 0; t < NT; t++)
 #pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          acc[i][j] = mfma16x16x32_bf16(al[i], bh[j], acc[i][j]);
-          acc[i][j] = mfma16x16x32_bf16(ah[i], bl[j], acc[i][j]);
-          acc[i][j] = mfma16x16x32_bf16(ah[i], bh[j], acc[i][j]);
+        for (int i = 0; i < 2; i++) {
+          at[t][i] = *reinterpret_cast<const u16x8*>(b0 + t * GX3_IMG + (wm * 32 + i * 16) * 32 + fofs);
+          bt[t][i] = *reinterpret_cast<const u16x8*>(b0 + (NT + t) * GX3_IMG + (wn * 32 + i * 16) * 32 + fofs);
         }
+      // smallest terms first: ta + tb = NT - 1 .. 0 (NT = 2: lo.hi, hi.lo, hi.hi)
+#pragma unroll
+      for (int w = NT - 1; w >= 0; w--)
+#pragma unroll
+        for (int ta = w; ta >= 0; ta--)
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = mfma16x16x32_bf16(at[ta][i], bt[w - ta][j], acc[i][j]);
       __syncthreads();
       cur ^= 1;
     }
@@ -1416,33 +1425,41 @@ DEVFN void gemm_x3_body(float* smem, GemmOperand A, GemmOperand B, FE fe, int R,
       }
 }
 
-template <int AMODE, int BMODE, class FE>
+template <int AMODE, int BMODE, class FE, int NT = 2>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int ksplit,
                                                       int nsplit) {
-  __shared__ __attribute__((aligned(16))) float smem[GX3_SMEM_FLOATS];
-  gemm_x3_body<AMODE, BMODE, FE>(smem, A, B, fe, R, Cn, K, ksplit, nsplit,
-                                 blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z);
+  __shared__ __attribute__((aligned(16))) float smem[gx3_smem_floats(NT)];
+  gemm_x3_body<AMODE, BMODE, FE, NT>(smem, A, B, fe, R, Cn, K, ksplit, nsplit,
+                                     blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z);
 }
-template <int A1, int B1, class FE1, int A2, int B2, class FE2>
+template <int A1, int B1, class FE1, int A2, int B2, class FE2, int NT = 2>
 __global__ __launch_bounds__(256) void gemm_x3_pair_kernel(GemmProblem p1, FE1 fe1, GemmProblem p2, FE2 fe2, unsigned nb1) {
-  __shared__ __attribute__((aligned(16))) float smem[GX3_SMEM_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[gx3_smem_floats(NT)];
   if (blockIdx.x < nb1)
-    gemm_x3_body<A1, B1, FE1>(smem, p1.A, p1.B, fe1, p1.R, p1.Cn, p1.K, p1.ksplit, p1.nsplit, blockIdx.x, p1.gx, p1.gy, p1.gz);
+    gemm_x3_body<A1, B1, FE1, NT>(smem, p1.A, p1.B, fe1, p1.R, p1.Cn, p1.K, p1.ksplit, p1.nsplit, blockIdx.x, p1.gx, p1.gy, p1.gz);
   else
-    gemm_x3_body<A2, B2, FE2>(smem, p2.A, p2.B, fe2, p2.R, p2.Cn, p2.K, p2.ksplit, p2.nsplit, blockIdx.x - nb1, p2.gx, p2.gy, p2.gz);
+    gemm_x3_body<A2, B2, FE2, NT>(smem, p2.A, p2.B, fe2, p2.R, p2.Cn, p2.K, p2.ksplit, p2.nsplit, blockIdx.x - nb1, p2.gx, p2.gy, p2.gz);
 }
 // launchers with the signatures of gemm_f32 / gemm_f32_pair (KC operands are read 8 floats at a time: same slack rule
 // as gemm_bf16)
+// `terms`: 2 (hi + lo, three products) or 3 (operand-exact, six products)
 template <int AMODE, int BMODE, class FE>
-inline void gemm_x3(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1) {
+inline void gemm_x3(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe, int R, int Cn, int K, int nsplit = 1, int nbatch = 1,
+                    int terms = 2) {
   if (R <= 0 || Cn <= 0) return;
   const GemmProblem p = gemm_problem(A, B, R, Cn, K, nsplit, nbatch);
-  CLSTM_LAUNCH((gemm_x3_kernel<AMODE, BMODE, FE>), dim3(p.gx, p.gy, p.gz), dim3(256), 0, stream, A, B, fe, R, Cn, K, p.ksplit, p.nsplit);
+  if (terms >= 3)
+    CLSTM_LAUNCH((gemm_x3_kernel<AMODE, BMODE, FE, 3>), dim3(p.gx, p.gy, p.gz), dim3(256), 0, stream, A, B, fe, R, Cn, K, p.ksplit, p.nsplit);
+  else
+    CLSTM_LAUNCH((gemm_x3_kernel<AMODE, BMODE, FE, 2>), dim3(p.gx, p.gy, p.gz), dim3(256), 0, stream, A, B, fe, R, Cn, K, p.ksplit, p.nsplit);
 }
 template <int A1, int B1, class FE1, int A2, int B2, class FE2>
-inline void gemm_x3_pair(hipStream_t stream, GemmProblem p1, FE1 fe1, GemmProblem p2, FE2 fe2) {
+inline void gemm_x3_pair(hipStream_t stream, GemmProblem p1, FE1 fe1, GemmProblem p2, FE2 fe2, int terms = 2) {
   const unsigned nb1 = p1.gx * p1.gy * p1.gz, nb2 = p2.gx * p2.gy * p2.gz;
-  CLSTM_LAUNCH((gemm_x3_pair_kernel<A1, B1, FE1, A2, B2, FE2>), dim3(nb1 + nb2), dim3(256), 0, stream, p1, fe1, p2, fe2, nb1);
+  if (terms >= 3)
+    CLSTM_LAUNCH((gemm_x3_pair_kernel<A1, B1, FE1, A2, B2, FE2, 3>), dim3(nb1 + nb2), dim3(256), 0, stream, p1, fe1, p2, fe2, nb1);
+  else
+    CLSTM_LAUNCH((gemm_x3_pair_kernel<A1, B1, FE1, A2, B2, FE2, 2>), dim3(nb1 + nb2), dim3(256), 0, stream, p1, fe1, p2, fe2, nb1);
 }
 
 // shapes that fill 128 x 128 tiles reasonably

@@ -55,14 +55,18 @@ struct GemmDwArgs {
   const float* xD; int xM; long long xd_elems;     // B': [frame][xM]
   const int* xtab; const DwSlab* xslabs; int xnslabs;   // its k-tile table (contiguous frames) and slabs (need_it = 0)
   float* xpartial; int xR, xCn; unsigned xgx, xgy;
-  int x3;                   // 1: products on the bf16 MFMA with both operands split hi + lo (gemm_dw_item_x3), 0: f32 MFMA
+  int x3;                   // 1: products on the bf16 MFMA with both operands split into bf16 terms (gemm_dw_item_x3), 0: f32 MFMA
+  int terms;                // x3: 3 = hi + mid + lo, six products, operand-exact (default); 2 = hi + lo, three products
 };
 
 // blocks of the x3 item in flight in registers (6 and 8 were measured: the fused launch then needs > 168 registers,
 // only one GEMM workgroup fits a CU, 142 / 148 us against 116)
 constexpr int DW_PF = 3;
-constexpr int DW_SMEM_FLOATS = 8192 + 2048;   // + the slab's k-tile table (DW_STAB_MAX entries of 2 ints)
-constexpr int DW_STAB_MAX = 1024;   // 32 KB: two buffers of four 64 x 32 bf16 images (x3 path); the epilogue tile fits too
+// LDS of the GEMM role: two buffers of 2 NT 64 x 32 bf16 images (NT terms per operand; the f32 item: 8192 floats; the epilogue
+// tile fits too) + the slab's k-tile table (DW_STAB_MAX entries of 2 ints)
+constexpr int DW_STAB_MAX = 1024;
+constexpr int dw_img_floats(int nt) { return nt <= 2 ? 8192 : 2 * 2 * nt * 64 * 32 / 2; }
+constexpr int dw_smem_floats(int nt) { return dw_img_floats(nt) + 2 * DW_STAB_MAX; }
 static_assert(8192 >= GEMM_BT * GEMM_LDO, "epilogue tile");
 
 constexpr int DW_WATCHDOG_POLLS = 1 << 16;
@@ -239,21 +243,27 @@ DEVFN void gemm_dw_item(const GemmDwArgs& a, float* smem, const unsigned si, con
     }
   }
 }
-// ---- the same work item on the bf16 MFMA, f32-grade: each f32 operand element x is split into hi = bf16(x) and
-// lo = bf16(x - hi) (the difference is exact in f32), and a product is  hi.hi + hi.lo + lo.hi  -- three
-// v_mfma_f32_16x16x32_bf16 with f32 accumulation.  What is dropped is lo.lo and the rounding of lo: < 2^-16 |x||y| per
-// product, against 2^-24 for an f32 multiply -- the gradient stays within ~1e-5 of its largest entry (measured against
-// the float64 oracle: tests/test_gpu_e2e.py::test_full_shape_gradient_error_vs_float64), well inside the 1e-4 the
-// parity tests grant, while a 32-frame block costs a wave 12 MFMAs of 16 cycles instead of 32 of 32: the product that
-// needed the whole chip for ~45 us (and held the fused backward launch 39 us past the recurrence's end) now keeps
-// pace with the recurrence on the half of the chip the recurrence leaves idle.
+// ---- the same work item on the bf16 MFMA with f32 operands split into bf16 TERMS (the differences are exact in f32):
+//   NT = 3 (default): x = x1 + x2 + x3, x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) -- 3 x 8 significant bits:
+//     the split represents every normal f32 EXACTLY.  A product is the six terms of weight >= 2^-16,
+//     x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1), each exact in the f32 accumulator; what is dropped (x2y3, x3y2, x3y3) is
+//     < 2^-23 |x||y| -- the size of the rounding an f32 multiply makes itself.  "Operand-exact": nothing narrower than the
+//     reference's float enters the gradient.  24 MFMAs of 16 cycles per 32-frame block and wave
+//     against 32 of 32 on the f32 MFMA.
+//   NT = 2 (experiment option split_terms=2; rounds 3-5's default): hi + lo, hi.hi + hi.lo + lo.hi, 12 MFMAs, < 2^-16 |x||y|
+//     per product -- the gradient stayed within ~1e-5 of its largest entry of the float64 oracle's either way
+//     (tests/test_gpu_e2e.py::test_full_shape_gradient_error_vs_float64).
+// The product that needed the whole chip for ~45 us on the f32 MFMA (and held the fused backward launch 39 us past the
+// recurrence's end) keeps pace with the recurrence on the half of the chip the recurrence leaves idle.
 // Staging: waves 0-1 convert the S block, waves 2-3 the D block; lane (m8, kg) loads frames 4 kg .. 4 kg + 3 of the
 // 32-frame block (two 16-frame table entries), 4 columns each, transposes in registers and writes 4 k of one row per
 // ds_write_b64 into swizzled [mn][32 k] images (gemm_bf16.h: conflict-free fragment reads); images are double-buffered,
 // one barrier per block.
+template <int NT>
 DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, const unsigned tile, const bool extra = false) {
   constexpr int IMG = 64 * 32;                 // halfs per image
-  unsigned short* img = reinterpret_cast<unsigned short*>(smem);   // [buffer][A hi | A lo | B hi | B lo][64][32]
+  constexpr int BUFH = 2 * NT * IMG;           // halfs per buffer
+  unsigned short* img = reinterpret_cast<unsigned short*>(smem);   // [buffer][A terms | B terms][64][32]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -267,7 +277,7 @@ DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, 
   // DEPENDENT load in front of every block's operand loads, and VMEM returns in order: waiting for it meant waiting for
   // every operand load still in flight -- one full memory latency per block (measured: 15 us per 16-block item).
   const int* tab = extra ? a.xtab : a.ktab + (size_t)dir * a.ntiles_max * 2;
-  int* stab = reinterpret_cast<int*>(smem + 8192);
+  int* stab = reinterpret_cast<int*>(smem + dw_img_floats(NT));
   for (int i = tid; i < 2 * sl.ntiles && i < 2 * DW_STAB_MAX; i += 256) stab[i] = tab[2 * sl.tile_begin + i];   // (the host keeps slabs <= DW_STAB_MAX entries)
   if (!(a.x3 & 2) && sl.need_it > 0) gemm_dw_wait(a, dir, sl.need_it);
   else __syncthreads();
@@ -302,23 +312,26 @@ DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, 
       else r[j] = buf_load4(abuf, off);
     }
   };
-  unsigned short* const my_img = img + (isB ? 2 * IMG : 0);
+  unsigned short* const my_img = img + (isB ? NT * IMG : 0);
   int wofs[4];                                                     // halfs: row, swizzled chunk, half chunk
 #pragma unroll
   for (int i = 0; i < 4; i++) wofs[i] = (s_mn + i) * 32 + ((((s_kg >> 1) ^ gb2_sw(s_mn + i)) << 3) | ((s_kg & 1) << 2));
   auto stage = [&](int buf, const f32x4 (&r)[4]) {
-    unsigned short* d = my_img + buf * 4 * IMG;
+    unsigned short* d = my_img + buf * BUFH;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      u32x2 h, l;
-      h[0] = bf16_pack2(r[0][i], r[1][i]);
-      h[1] = bf16_pack2(r[2][i], r[3][i]);
-      const float e0 = r[0][i] - __builtin_bit_cast(float, h[0] << 16), e1 = r[1][i] - __builtin_bit_cast(float, h[0] & 0xffff0000u);
-      const float e2 = r[2][i] - __builtin_bit_cast(float, h[1] << 16), e3 = r[3][i] - __builtin_bit_cast(float, h[1] & 0xffff0000u);
-      l[0] = bf16_pack2(e0, e1);
-      l[1] = bf16_pack2(e2, e3);
-      *reinterpret_cast<u32x2*>(d + wofs[i]) = h;
-      *reinterpret_cast<u32x2*>(d + IMG + wofs[i]) = l;
+      float e[4] = {r[0][i], r[1][i], r[2][i], r[3][i]};
+#pragma unroll
+      for (int t = 0; t < NT; t++) {   // term t of the four frames, then the exact remainders
+        u32x2 h;
+        h[0] = bf16_pack2(e[0], e[1]);
+        h[1] = bf16_pack2(e[2], e[3]);
+        *reinterpret_cast<u32x2*>(d + t * IMG + wofs[i]) = h;
+        if (t + 1 < NT) {
+          e[0] -= __builtin_bit_cast(float, h[0] << 16); e[1] -= __builtin_bit_cast(float, h[0] & 0xffff0000u);
+          e[2] -= __builtin_bit_cast(float, h[1] << 16); e[3] -= __builtin_bit_cast(float, h[1] & 0xffff0000u);
+        }
+      }
     }
   };
 
@@ -351,23 +364,24 @@ DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, 
       stage(cur ^ 1, rr[pn]);                                   // block tb/2 + p + 1 into the other buffer
       load_block(role, tb + 2 * (p + 1 + DW_PF), rr[pn]);
       SCHED_FENCE();
-      const unsigned short* b0 = img + cur * 4 * IMG;
-      u16x8 ah[2], al[2], bh[2], bl[2];
+      const unsigned short* b0 = img + cur * BUFH;
+      u16x8 at[NT][2], bt[NT][2];
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        ah[i] = *reinterpret_cast<const u16x8*>(b0 + (wm * 32 + i * 16) * 32 + fofs);
-        al[i] = *reinterpret_cast<const u16x8*>(b0 + IMG + (wm * 32 + i * 16) * 32 + fofs);
-        bh[i] = *reinterpret_cast<const u16x8*>(b0 + 2 * IMG + (wn * 32 + i * 16) * 32 + fofs);
-        bl[i] = *reinterpret_cast<const u16x8*>(b0 + 3 * IMG + (wn * 32 + i * 16) * 32 + fofs);
-      }
+      for (int t = 0; t < NT; t++)
 #pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          acc[i][j] = mfma16x16x32_bf16(al[i], bh[j], acc[i][j]);
-          acc[i][j] = mfma16x16x32_bf16(ah[i], bl[j], acc[i][j]);
-          acc[i][j] = mfma16x16x32_bf16(ah[i], bh[j], acc[i][j]);
+        for (int i = 0; i < 2; i++) {
+          at[t][i] = *reinterpret_cast<const u16x8*>(b0 + t * IMG + (wm * 32 + i * 16) * 32 + fofs);
+          bt[t][i] = *reinterpret_cast<const u16x8*>(b0 + (NT + t) * IMG + (wn * 32 + i * 16) * 32 + fofs);
         }
+      // smallest terms first (term weights 2^-8 apart): ta + tb = 2, then 1, then 0
+#pragma unroll
+      for (int w = NT - 1; w >= 0; w--)
+#pragma unroll
+        for (int ta = 0; ta <= w; ta++)
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = mfma16x16x32_bf16(at[ta][i], bt[w - ta][j], acc[i][j]);
       __syncthreads();
       cur ^= 1;
     }
@@ -406,26 +420,29 @@ DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, 
 // grid mode: workgroup `block` computes one item.  Workgroup b runs on XCD b % 8: XCD x takes slabs x, x+8, ... (all
 // output tiles of a slab pull its frames through ONE L2), and because slabs are listed in readiness order every XCD
 // gets early and late ones alike
-// X3: the item form is a compile-time choice (and so part of the kernel's NAME: a profile of a process that runs both forms --
-// bench.py's strict_f32 leg -- keeps their launch statistics apart); it must agree with a.x3 != 0
-template <bool X3>
+// NT: the item form is a compile-time choice (and so part of the kernel's NAME: a profile of a process that runs several forms --
+// bench.py's strict_f32 leg -- keeps their launch statistics apart): 0 the f32 MFMA (a.x3 == 0), 2 / 3 = a.terms of the split
+template <int NT>
 DEVFN void gemm_dw_body(const GemmDwArgs& a, float* smem, unsigned block) {
+  constexpr bool X3 = NT != 0;
   if (block == 0) { gemm_dw_monitor(a); return; }   // the first workgroup behind the recurrence's watches the lines
   block -= 1;
   const unsigned nextra = X3 ? (unsigned)a.xnslabs * a.xgx * a.xgy : 0u;   // independent items first (see GemmDwArgs)
-  if (X3 && block < nextra) { gemm_dw_item_x3(a, smem, block / (a.xgx * a.xgy), block % (a.xgx * a.xgy), true); return; }
+  if constexpr (X3) {
+    if (block < nextra) { gemm_dw_item_x3<NT>(a, smem, block / (a.xgx * a.xgy), block % (a.xgx * a.xgy), true); return; }
+  }
   block -= nextra;
   const unsigned tiles = a.gx * a.gy;
   const unsigned xcd = block & 7u, idx = block >> 3;
   const unsigned si = (idx / tiles) * 8u + xcd;
   if (si >= (unsigned)a.nslabs) return;
-  if constexpr (X3) gemm_dw_item_x3(a, smem, si, idx % tiles);
+  if constexpr (X3) gemm_dw_item_x3<NT>(a, smem, si, idx % tiles);
   else gemm_dw_item(a, smem, si, idx % tiles);
 }
-template <bool X3>
+template <int NT>
 __global__ __launch_bounds__(256) void gemm_dw_kernel(GemmDwArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[DW_SMEM_FLOATS];
-  gemm_dw_body<X3>(a, smem, blockIdx.x);
+  __shared__ __attribute__((aligned(16))) float smem[dw_smem_floats(NT)];
+  gemm_dw_body<NT>(a, smem, blockIdx.x);
 }
 
 }  // namespace clstm

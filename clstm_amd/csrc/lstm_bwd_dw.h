@@ -14,9 +14,10 @@
 
 namespace clstm {
 
-template <int NK4, int KU, bool X3>
+// NT: the weight-gradient items' arithmetic (gemm_dw_body): 0 f32 MFMA, 2 / 3 bf16 terms per operand
+template <int NK4, int KU, int NT>
 __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_dw_kernel(LstmSeqArgs a, GemmDwArgs g, int nrec) {
-  __shared__ __attribute__((aligned(16))) float gsm[DW_SMEM_FLOATS];
+  __shared__ __attribute__((aligned(16))) float gsm[dw_smem_floats(NT)];
   if ((int)blockIdx.x < nrec) {
 #ifndef CLSTM_HIP_EMU
     __builtin_amdgcn_s_setprio(3);
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_dw
     if (g.trace && threadIdx.x == 0) { g.trace[blockIdx.x * 4] = t0; g.trace[blockIdx.x * 4 + 2] = wall_clock(); }
   } else {
     if (threadIdx.x >= 256) return;   // the GEMM role is four waves; the others retire (a barrier counts live waves only)
-    gemm_dw_body<X3>(g, gsm, blockIdx.x - (unsigned)nrec);   // the monitor, then one item per workgroup in dispatch order
+    gemm_dw_body<NT>(g, gsm, blockIdx.x - (unsigned)nrec);   // the monitor, then one item per workgroup in dispatch order
   }
 }
 

@@ -27,10 +27,14 @@
  * Build: see oracle/Makefile.  Compiled twice: Float=float (liboracle_f32.so) and
  * Float=double with -DORA_DOUBLE (liboracle_f64.so), mirroring tensor.h:62-66.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   /* sched_setaffinity (ora_bench_lines_pinned) */
+#endif
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -1066,36 +1070,85 @@ int ora_net_train_line(OraNet *net, const Float *x, int T, const int *transcript
  * threads (each thread owns a clone of the net; gradients are left in the clones).
  * x: packed [sum T][ni]; offs[nlines+1]; labels packed with loffs[nlines+1].
  * Returns wall seconds.  (OpenMP over lines = the "Eigen/OpenMP" figure of BASELINE.md C2.) */
+/* `cpus` (nthreads entries, or NULL): the logical CPU thread i pins itself to -- bench.py passes one CPU per physical core, or
+ * all of them.  Every thread creates ITS OWN net (allocated and first touched where it runs), trains one untimed line on it --
+ * which sizes every Sequence of the net (seq_resize allocates only when a shape changes; the memset per forward pass is the
+ * reference's, batches.h:127, and stays) -- and only then, behind a barrier, the clock starts: the timed loop is the
+ * reference's per-line work and nothing else. */
+#ifdef _OPENMP
+#include <sched.h>
+#endif
+#ifdef __GLIBC__
+#include <malloc.h>
+#endif
+double ora_bench_lines_pinned(OraNet *net, const Float *x, const int *offs, const int *labels,
+                              const int *loffs, int nlines, int nthreads, int reps, const int *cpus) {
+  if (nthreads < 1) nthreads = 1;
+  double t0 = 0, t1 = 0;
+#ifdef __GLIBC__
+  /* The per-call temporaries of the restated operators (forward/backward_nonlingate's zeroed temps, the CTC matrices: the
+   * reference allocates them per call too) make every thread's malloc arena grow and shrink all the time; glibc gives a
+   * shrinking arena's pages back to the kernel above 128 KB of free top and faults them in again at the next call, under the
+   * PROCESS-wide mmap lock -- measured on the 128-core host of the GPU box: 9 % parallel efficiency.  Keep freed memory in the
+   * arenas for the duration of the baseline (the generous figure the north_star asks for). */
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_MMAP_THRESHOLD, 32 << 20);
+  mallopt(M_TOP_PAD, 16 << 20);
+#endif
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+  {
+    const int tid = omp_get_thread_num();
+#ifdef __linux__
+    if (cpus) {
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      CPU_SET(cpus[tid], &set);
+      sched_setaffinity(0, sizeof set, &set);
+    }
+#endif
+    OraNet *c = ora_net_create(net->nlayers, net->unidirectional, net->ninput, net->nhidden, net->nclasses, 0);
+    ora_net_set_params(c, net->params);
+    {
+      const int i = tid % nlines;
+      ora_net_train_line(c, x + (size_t)offs[i] * net->ninput, offs[i + 1] - offs[i], labels + loffs[i],
+                         loffs[i + 1] - loffs[i], NULL, 0);
+    }
+#pragma omp barrier
+#pragma omp master
+    t0 = omp_get_wtime();
+#pragma omp barrier
+#pragma omp for schedule(dynamic, 1)
+    for (int k = 0; k < nlines * reps; k++) {
+      const int i = k % nlines;
+      ora_net_train_line(c, x + (size_t)offs[i] * net->ninput, offs[i + 1] - offs[i], labels + loffs[i],
+                         loffs[i + 1] - loffs[i], NULL, 0);
+    }
+#pragma omp master
+    t1 = omp_get_wtime();
+    ora_net_free(c);
+  }
+#else
+  (void)cpus;
+  OraNet *c = ora_net_create(net->nlayers, net->unidirectional, net->ninput, net->nhidden, net->nclasses, 0);
+  ora_net_set_params(c, net->params);
+  struct timespec a, b;
+  ora_net_train_line(c, x, offs[1] - offs[0], labels, loffs[1] - loffs[0], NULL, 0);
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  for (int k = 0; k < nlines * reps; k++) {
+    const int i = k % nlines;
+    ora_net_train_line(c, x + (size_t)offs[i] * net->ninput, offs[i + 1] - offs[i], labels + loffs[i],
+                       loffs[i + 1] - loffs[i], NULL, 0);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  t0 = a.tv_sec + 1e-9 * a.tv_nsec; t1 = b.tv_sec + 1e-9 * b.tv_nsec;
+  ora_net_free(c);
+#endif
+  return t1 - t0;
+}
 double ora_bench_lines(OraNet *net, const Float *x, const int *offs, const int *labels,
                        const int *loffs, int nlines, int nthreads, int reps) {
-  if (nthreads < 1) nthreads = 1;
-  OraNet **clones = (OraNet **)malloc(sizeof(OraNet *) * nthreads);
-  for (int i = 0; i < nthreads; i++) {
-    clones[i] = ora_net_create(net->nlayers, net->unidirectional, net->ninput, net->nhidden,
-                               net->nclasses, 0);
-    ora_net_set_params(clones[i], net->params);
-  }
-  double t0 = 0, t1 = 0;
-#ifdef _OPENMP
-  t0 = omp_get_wtime();
-#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
-#endif
-  for (int k = 0; k < nlines * reps; k++) {
-    int i = k % nlines;
-#ifdef _OPENMP
-    OraNet *c = clones[omp_get_thread_num()];
-#else
-    OraNet *c = clones[0];
-#endif
-    ora_net_train_line(c, x + (size_t)offs[i] * net->ninput, offs[i + 1] - offs[i],
-                       labels + loffs[i], loffs[i + 1] - loffs[i], NULL, 0);
-  }
-#ifdef _OPENMP
-  t1 = omp_get_wtime();
-#endif
-  for (int i = 0; i < nthreads; i++) ora_net_free(clones[i]);
-  free(clones);
-  return t1 - t0;
+  return ora_bench_lines_pinned(net, x, offs, labels, loffs, nlines, nthreads, reps, NULL);
 }
 
 /* Parity helper for full-size minibatches: the reference's semantics of a minibatch are nlines

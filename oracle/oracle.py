@@ -114,6 +114,7 @@ class Oracle:
             "ora_net_get_state": (I, [P, I, I, I, I, P]),
             "ora_net_train_line": (I, [P, P, I, P, I, P, I]),
             "ora_bench_lines": (C.c_double, [P, P, P, P, P, I, I, I]),
+            "ora_bench_lines_pinned": (C.c_double, [P, P, P, P, P, I, I, I, P]),
             "ora_minibatch_lines": (None, [P, P, P, P, P, I, I, P, P, P, P, P, I, P]),
             "ora_forward_btswitch": (None, [P, P, I, I, I]),
             "ora_backward_btswitch": (None, [P, P, I, I, I]),
@@ -318,8 +319,14 @@ class OracleNet:
                 "decode": [dec[offs[b]:offs[b] + decn[b]].copy() for b in range(len(lines))],
                 "derivs": self.get_derivs(), "kept": views}
 
-    def bench_lines(self, x, offs, labels, loffs, nthreads=1, reps=1):
+    def bench_lines(self, x, offs, labels, loffs, nthreads=1, reps=1, cpus=None):
+        """seconds for `reps` passes over the lines (fwd + CTC + bwd each) on `nthreads` threads, every thread on its own
+        preallocated net, one untimed line first; `cpus`: the logical CPU each thread pins itself to"""
         x = self.o.arr(x)
         offs, labels, loffs = Oracle.ints(offs), Oracle.ints(labels), Oracle.ints(loffs)
-        return self.o.lib.ora_bench_lines(self.h, Oracle.p(x), Oracle.p(offs), Oracle.p(labels),
-                                          Oracle.p(loffs), len(offs) - 1, nthreads, reps)
+        cp = None
+        if cpus is not None:
+            assert len(cpus) >= nthreads
+            cp = Oracle.ints(list(cpus))
+        return self.o.lib.ora_bench_lines_pinned(self.h, Oracle.p(x), Oracle.p(offs), Oracle.p(labels), Oracle.p(loffs),
+                                                 len(offs) - 1, nthreads, reps, Oracle.p(cp) if cp is not None else None)

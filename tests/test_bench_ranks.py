@@ -23,7 +23,7 @@ def test_bench_rank_body_world2_on_the_emulator(how):
                OMP_NUM_THREADS="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--minibatch", "2", "--T", "6", "--profile-steps", "0", "--no-cpu-baseline"]
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--minibatch", "2", "--T", "6", "--profile-steps", "2", "--no-cpu-baseline"]
     if how == "self_relaunch":      # the plain command: the script becomes the launcher
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:                           # the driver's command line
@@ -43,3 +43,35 @@ def test_bench_rank_body_world2_on_the_emulator(how):
     assert ar["ranks"] == 2 and ar["bytes"] == 4 * 135883
     assert "peer-read" in ar["impl"]                           # the one-call step ran the fused exchange, not a fallback
     assert out["secondary"] is None and out["cpu_baseline"] is None      # single-GPU legs stay out of a multi-rank line
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_on_the_real_library_sharing_one_gpu():
+    """the `--gpus 2` bench body on the REAL library before the driver's first multi-GPU run.  Two rank processes
+    share device 0 (CLSTM_BENCH_SHARE_DEVICE=1; torch.distributed on gloo for the barriers and the max over ranks, because RCCL
+    refuses two ranks on one device; CLSTM_COMM_NO_RCCL=1: the library communicator with the peer path only, as
+    tests/test_distributed.py::test_two_processes_on_one_gpu_peer_read_allreduce).  What runs is what `--gpus 2` runs on two
+    GPUs: the self-relaunch through torch.distributed.run, clstm_comm_create, HIP IPC mappings of the other rank's gradient
+    slots, clstm_net_train_step with the all-reduce fused into the update kernel, the replica check, ONE JSON line -- except that
+    ranks sharing a device run the forward / backward halves as separate launches (bench.py says why).
+    (The first run of this test found a real bug: the per-kernel timing steps ran on rank 0 only, and with a communicator a step
+    is a collective -- `bench.py --gpus N` would have hung in the driver's first multi-GPU run.)"""
+    env = dict(os.environ, CLSTM_BENCH_BACKEND="gloo", CLSTM_BENCH_SHARE_DEVICE="1", CLSTM_COMM_NO_RCCL="1",
+               CLSTM_BENCH_MIN_TIMED_S="0.2", CLSTM_BENCH_MIN_WARMUP_S="0.1", CLSTM_REPLICA_CHECK_EVERY="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CLSTM_BENCH_DEVICE", "CLSTM_BENCH_LIB"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_minibatch"] == 128 and out["config"]["minibatch_per_gpu"] == 64 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["value"] == out["value"] and out["value"] < 1e7          # finite, whole-job lines/s
+    assert abs(out["value"] - 128 * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-2
+    ar = out["allreduce"]
+    assert ar["ranks"] == 2 and ar["bytes"] == 4 * 135883 and ar["peer_active"] is True
+    assert "peer-read" in ar["impl"]
+    assert r.stderr.count("clstm_comm_peer_active = 1") == 2       # every rank says at start-up which exchange it uses
+    assert out["secondary"] is None and out["cpu_baseline"] is None and out["strict_f32"] is None
