@@ -322,30 +322,41 @@ def kernel_times(w, steps, first_step, ms_per_step):
     return kern, frames / steps
 
 
-def pmc_traffic(minibatch, T, ragged):
-    """HBM bytes per launch from the newest committed rocprofv3 PMC passes (same workload only)"""
+def pmc_traffic(minibatch, T, ragged, strict=False):
+    """HBM bytes per launch from the newest committed rocprofv3 PMC passes (same workload only: the default line, its strict_f32
+    form -- `legs.strict` -- and the 256-line form -- `legs.mb256`)"""
     try:
         import glob
         pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*.json")))[-1]
         pmc = json.load(open(pmc_file))
-        if pmc["workload"]["minibatch_per_gpu"] == minibatch and pmc["workload"]["T"] == T and not ragged:
-            src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed -- "
-                   "not re-measured inside this run" % os.path.basename(pmc_file))
-            return {k.split(" ")[0]: v["hbm_bytes"] for k, v in pmc["kernels"].items()}, src
+        if T != pmc["workload"]["T"] or ragged:
+            return {}, None
+        leg = None
+        if minibatch == pmc["workload"]["minibatch_per_gpu"]:
+            leg = pmc.get("legs", {}).get("strict") if strict else pmc
+        elif minibatch == 256 and not strict:
+            leg = pmc.get("legs", {}).get("mb256")
+        if leg:
+            src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command%s, committed -- "
+                   "not re-measured inside this run" % (os.path.basename(pmc_file), " (--strict-f32)" if strict else
+                                                        " (--minibatch 256)" if minibatch == 256 else ""))
+            return {k.split(" ")[0]: v["hbm_bytes"] for k, v in leg["kernels"].items()}, src
     except Exception:
         pass
     return {}, None
 
 
-def rocprof_avg_ms(kernel, minibatch, T, ragged):
+def rocprof_avg_ms(kernel, minibatch, T, ragged, strict=False):
     """average duration (ms) of `kernel` in the newest committed rocprofv3 --kernel-trace --stats summary of this command
-    (default workload only; None otherwise) -- for the reader to hold against avg_launch_ms"""
+    (the default workload, its --strict-f32 form and its --minibatch 256 form; None otherwise) -- for the reader to hold against
+    avg_launch_ms"""
     try:
         import csv
         import glob
-        if minibatch != 64 or T != 200 or ragged:
+        if T != 200 or ragged or (minibatch, strict) not in ((64, False), (64, True), (256, False)):
             return None
-        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))[-1]
+        suffix = "_strict" if strict else "_mb256" if minibatch == 256 else ""
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats%s.csv" % suffix)))[-1]
         for row in csv.DictReader(open(f)):
             if kernel in row["Name"]:
                 return {"ms": round(float(row["AverageNs"]) * 1e-6, 4), "source": "profiles/" + os.path.basename(f),
@@ -382,7 +393,7 @@ def rocprof_b2_avg_ms(dominant):
         return None
 
 
-def roofline_b1(w, kern, kern_unfused, frames_per_step, ms_per_step):
+def roofline_b1(w, kern, kern_unfused, frames_per_step, ms_per_step, strict=False):
     """Fused gate kernels against HBM (north star: 'achieved HBM GB/s for the fused gate kernel'), the batched gate GEMM
     against the f32 MFMA peak ('MFMA utilisation for the batched gate GEMM').  Algorithmic bytes:
     forward recurrence 44 B per cell-step, backward recurrence 56 B per cell-step.  In the default mode both recurrences
@@ -398,7 +409,7 @@ def roofline_b1(w, kern, kern_unfused, frames_per_step, ms_per_step):
     M = ndir * 4 * cfg["nh"][0]
     lds = (1 + ni + no + 15) // 16 * 16
     ldh = (4 + ndir * no + 15) // 16 * 16
-    traffic, traffic_src = pmc_traffic(w.minibatch, w.T, w.ragged)
+    traffic, traffic_src = pmc_traffic(w.minibatch, w.T, w.ragged, strict)
     entries = {}
 
     def hbm_entry(key, label, byts, k):
@@ -442,7 +453,21 @@ def roofline_b1(w, kern, kern_unfused, frames_per_step, ms_per_step):
                      "--kernel-trace --stats average of the same command in the named file under profiles/ (an earlier run)")
     out["rocprof_avg_launch_ms_from_committed_profile"] = rocprof_avg_ms({"lstm_bwd_dw": "lstm_bwd_dw_kernel", "lstm_fwd_fused": "lstm_fwd_fused_kernel",
                                                    "lstm_fwd": "lstm_fwd_kernel", "lstm_bwd": "lstm_bwd_kernel"}.get(dom, dom),
-                                                  w.minibatch, w.T, w.ragged)
+                                                  w.minibatch, w.T, w.ragged, strict)
+    # the whole step against both roofs (3.62 MB + 162.0 MFLOP per line, 2.17 MB per minibatch)
+    step_bytes = 3.62e6 * w.minibatch + 2.17e6
+    step_flops = flops_per_line(cfg, w.T) * w.minibatch if not w.ragged else None
+    sec = ms_per_step * 1e-3
+    step_traffic = sum(v for v in traffic.values()) if traffic else None
+    out["whole_step"] = {
+        "algorithmic_bytes": int(step_bytes), "achieved_GBps": round(step_bytes / sec / 1e9, 1), "hbm_frac": round(step_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+        "algorithmic_flops": None if step_flops is None else int(step_flops),
+        "achieved_TFLOPs": None if step_flops is None else round(step_flops / sec / 1e12, 2),
+        "f32_mfma_frac": None if step_flops is None else round(step_flops / sec / 1e12 / F32_MFMA_PEAK_TFS, 4),
+        "traffic_all_profiled_kernels": step_traffic,
+        "traffic_over_algorithmic": None if not step_traffic else round(step_traffic / step_bytes, 2),
+        "note": "SURVEY.md 8(d): 3.62 MB + 162.0 MFLOP per line (+ 2.17 MB per minibatch); traffic = sum of the per-launch HBM bytes of "
+                "the committed PMC passes over the kernels listed there (one launch each per step)"}
     out["note"] = ("latency-bound recurrence: %d workgroups (lines x directions) on 256 CUs, one dependent step per frame; "
                    "whole step %.1f GB/s of algorithmic bytes (SURVEY 8d: 3.62 MB/line + 2.17 MB/minibatch)"
                    % (2 * w.minibatch, (3.62e6 * w.minibatch + 2.17e6) / (ms_per_step * 1e-3) / 1e9))
@@ -490,6 +515,9 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="frames start in pinned HOST memory every step (clstm_net_train_step_h): the PCIe-inclusive rate, "
                          "not the headline `value` (bench contract: inputs resident in HBM)")
+    ap.add_argument("--strict-f32", action="store_true",
+                    help="every product on the f32 MFMA (clstm_net_set_strict_f32) as the MAIN workload -- what the rocprofv3 passes of "
+                         "the strict leg run; the default line carries the same step as its `strict_f32` leg")
     ap.add_argument("--weights", choices=["init", "trained"], default="init",
                     help="trained: the SURVEY 8(d) 'trained-like' regime -- weights after 500 online-SGD steps on the reference's fixture line, "
                          "inputs = jittered crops of that line (config b1 only); the default line carries it as the `trained_weights` leg")
@@ -506,7 +534,7 @@ def main():
     if args.profile_steps is None:
         args.profile_steps = 50 if args.config == "b1" else 5
     default_line = (args.config == "b1" and not args.bf16 and not args.bf16_gemm and not args.ragged
-                    and args.minibatch == 64 and args.T == 200 and not args.host_inputs)
+                    and args.minibatch == 64 and args.T == 200 and not args.host_inputs and not args.strict_f32)
     if args.config != "b1":
         args.no_cpu_baseline = True     # the bounded CPU sample is defined for the headline workload only
 
@@ -630,7 +658,7 @@ def main():
 
     precision = 2 if args.bf16 else 1 if args.bf16_gemm else 0
     w = Workload(lib, cfg, args.minibatch, args.T, args.ragged, precision, dev, rank, comm=comm, dist=dist, host_inputs=args.host_inputs,
-                 weights=args.weights)
+                 weights=args.weights, strict_f32=args.strict_f32)
     if share_dev and world > 1:
         # ranks SHARING a device (test hook only): the fused launches' role workgroups wait for each other inside one launch,
         # which needs the launch's workgroups co-resident -- true with one process per GPU (the only supported deployment: 128
@@ -654,7 +682,7 @@ def main():
     roofline = None
     if rank == 0 and m["kern"]:
         if max(cfg["nh"]) <= 128:
-            roofline = roofline_b1(w, m["kern"], m["kern_unfused"], m["frames_per_step"], ms_per_step)
+            roofline = roofline_b1(w, m["kern"], m["kern_unfused"], m["frames_per_step"], ms_per_step, strict=args.strict_f32)
         else:
             roofline = roofline_b2(w, m["kern"], m["frames_per_step"], ms_per_step)
 
@@ -711,9 +739,11 @@ def main():
     strict = None
     if rank == 0 and world == 1 and default_line and not args.no_secondary:
         ws = Workload(lib, cfg, args.minibatch, args.T, args.ragged, 0, dev, rank, strict_f32=True)
-        ms_ = measure(ws, args.steps, 5, 0, min_timed_s=0.5)
+        ms_ = measure(ws, args.steps, 5, 20, min_timed_s=0.5)
         strict = {"value": round(args.minibatch * args.steps / ms_["dt"], 2), "unit": "lines/s", "ms_per_step": round(ms_["dt"] / args.steps * 1e3, 4),
-                  "repeats": len(ms_["blocks"]), "dtype": "f32 (every product on the f32 MFMA: clstm_net_set_strict_f32)"}
+                  "repeats": len(ms_["blocks"]), "dtype": "f32 (every product on the f32 MFMA: clstm_net_set_strict_f32)",
+                  "roofline": roofline_b1(ws, ms_["kern"], {}, ms_["frames_per_step"], ms_["dt"] / args.steps * 1e3, strict=True) if ms_["kern"] else None,
+                  "kernels": ms_["kern"]}
         ws.net = ws.trainer = None
         del ws
 
@@ -798,6 +828,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 MFMA operands (hoisted gate GEMMs and lock-step recurrence), f32 accumulate / state / softmax / CTC" if args.bf16
                       else "f32 (hoisted gate GEMMs: bf16 in, f32 accumulate)" if args.bf16_gemm
+                      else "f32 (every product on the f32 MFMA: clstm_net_set_strict_f32)" if args.strict_f32
                       else "f32 (operand-exact split): forward, recurrences, CTC, decode in f32 arithmetic; the backward weight-gradient / "
                            "softmax-backward products take their f32 operands split EXACTLY into three bf16 terms each (x1 + x2 + x3 = x) and "
                            "sum the six bf16-MFMA products of weight >= 2^-16 in f32 -- what is dropped is < 2^-23 |x||y| per product, the size of "

@@ -24,6 +24,7 @@
 #include "lstm_seq.h"
 #include "lstm_wide.h"
 #include "lstm_mfma.h"
+#include "lstm_mfma_bwd.h"
 #include "ops.h"
 
 #include <algorithm>
@@ -674,6 +675,8 @@ struct Layer {
   DevBuf<unsigned short> Wmf;
   DevBuf<float> mf_scale;
   long long mf_epoch = -1;
+  DevBuf<unsigned short> Wmfb;   // R^T fragments of the batched backward recurrence (lstm_mfma_bwd.h)
+  long long mfb_epoch = -1;
   DevBuf<int> pack_tab;       // source index of every packed element (k_pack_index), narrow layers in training steps
   DevBuf<int> pack_inv;       // ... and its inverse, PACK_KD packed elements per parameter (ops.h: PackDst); pack_inv_state: 0 not built, 1 ready, -1 unusable
   int pack_inv_state = 0;
@@ -921,7 +924,7 @@ struct Net {
     for (auto& y : L) {
       (void)hipFree(y.Wt); (void)hipFree(y.bias); (void)hipFree(y.Rf); (void)hipFree(y.Rb); (void)hipFree(y.moff); (void)hipFree(y.Wk);
       (void)hipFree(y.Rwf); (void)hipFree(y.Rwb); (void)hipFree(y.Rbf); (void)hipFree(y.Rbb); y.dCc.release(); y.Hb.release(); y.Db.release(); y.Rf32.release(); y.R2b.release(); y.D2.release();
-      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false; y.pack_tab.release(); y.pack_inv.release(); y.Wmf.release(); y.mf_scale.release(); y.pack_inv_state = 0; y.partial.release(); y.dbias.release();
+      y.G.release(); y.C.release(); y.H.release(); y.D.release(); y.dH.release(); y.S.release(); y.Sbf.release(); y.sbf_ready = false; y.pack_tab.release(); y.pack_inv.release(); y.Wmf.release(); y.mf_scale.release(); y.Wmfb.release(); y.pack_inv_state = 0; y.partial.release(); y.dbias.release();
     }
     (void)hipFree(W1k); fw_items.release(); fw_flags.release();
     for (int i = 0; i < 2; i++) { hf.xin[i].release(); if (hf.pin[i]) (void)hipHostFree(hf.pin[i]); if (hf.copied[i]) (void)hipEventDestroy(hf.copied[i]); }
@@ -1168,6 +1171,55 @@ struct Net {
     g_path_count[16]++;
   }
 #endif
+  // bwd_mfma: the backward twin (lstm_mfma_bwd.h): 0 never, 1 (default) from 1024 lines per GPU on, 2 always (tests).  It gives up
+  // the fused launch (the weight-gradient items then run behind it as a launch of their own, 0.54 ms at 1024 lines): 0.69 + 0.54
+  // against 1.35 ms at 1024 lines, 0.95 + 1.09 against 2.7 at 2048 (profiles/r06_mfma_bwd_leaveout.txt)
+  bool mfma_bwd_eligible(const Layer& y) const {
+#ifdef CLSTM_HIP_EMU
+    return false;
+#else
+    const int mode = dbg_opt("bwd_mfma", 1);
+    if (!mode || y.wide || bf16_gemm) return false;
+    if (!(y.no == 64 || y.no == 100)) return false;   // (128 cells: image + operand staging would need 176 KB of LDS)
+    const double lim = 2147483000.0;   // 32-bit byte offsets inside one descriptor
+    if ((double)N * ndir * 4 * y.no * 4 >= lim) return false;
+    return mode >= 2 || bs >= 1024;
+#endif
+  }
+#ifndef CLSTM_HIP_EMU
+  template <int NO>
+  void launch_mfma_bwd_no(Layer& y, const LstmSeqArgs& sa, hipStream_t s) {
+    constexpr int NT = 2;
+    using Gm = MfmaBwdGeom<NO, NT>;
+    if (y.mfb_epoch != params_epoch) {
+      y.Wmfb.reserve((size_t)ndir * Gm::W_HALFS_PER_DIR + 64);
+      MfmaBwdPackArgs p{};
+      p.v = v; p.ni = y.ni; p.no = y.no; p.ntl = Gm::NTL; p.kb = Gm::KB; p.nt = NT; p.W = y.Wmfb.p;
+      for (int d = 0; d < 2; d++) for (int q = 0; q < 4; q++) p.p_off[d][q] = y.pd.p_off[d][q];
+      CLSTM_LAUNCH(k_pack_mfma_bwd, dim3(16, (unsigned)ndir), dim3(256), 0, s, p);
+      y.mfb_epoch = params_epoch;
+    }
+    LstmMfmaBwdArgs a{};
+    a.W = y.Wmfb.p; a.G = sa.G; a.C = sa.C; a.dH = sa.dH; a.D = sa.D; a.line_off = sa.line_off; a.order = sa.order;
+    a.bs = bs; a.ndir = ndir; a.N = N; a.prog_off = sa.prog_off; a.prog_base = sa.prog_base; a.dbg = dbg_opt("mfma_bwd_dbg", 0);
+    static const bool smem_set = (coop_set_smem(lstm_bwd_mfma_kernel<NO, NT>, (size_t)Gm::SMEM), true);
+    (void)smem_set;
+    CLSTM_LAUNCH((lstm_bwd_mfma_kernel<NO, NT>), dim3((unsigned)((bs + 15) / 16), (unsigned)ndir), dim3(512), (size_t)Gm::SMEM, s, a);
+    g_path_count[17]++;
+  }
+#endif
+  // the narrow layer's backward recurrence: batched over lines on the MFMA where that pays, else one workgroup per line
+  void launch_bwd_narrow(Layer& y, const LstmSeqArgs& a, hipStream_t s) {
+#ifndef CLSTM_HIP_EMU
+    if (mfma_bwd_eligible(y)) {
+      if (y.no == 64) launch_mfma_bwd_no<64>(y, a, s);
+      else launch_mfma_bwd_no<100>(y, a, s);
+      check_launch();
+      return;
+    }
+#endif
+    launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
+  }
   void launch_mfma(Layer& y, bool fwd, hipStream_t s) {
 #ifndef CLSTM_HIP_EMU
     if (y.no == 64) launch_mfma_no<64, 48>(y, fwd, s);
@@ -1581,7 +1633,7 @@ struct Net {
     if (trace_path) { dw_trace.reserve(trace_rows * 4); g.trace = dw_trace.p; g.trace_base = bs * ndir; }
     const unsigned nblk = 1u + nextra + (unsigned)((dw_nslabs + 7) / 8) * 8u * g.gx * g.gy;   // the monitor + the independent items + one per item
 #ifndef CLSTM_HIP_EMU
-    if (y.nthreads >= 256) {   // ONE launch: the recurrence's workgroups first, the GEMM's (one (slab, tile) item each) behind them
+    if (y.nthreads >= 256 && !mfma_bwd_eligible(y)) {   // ONE launch: the recurrence's workgroups first, the GEMM's (one (slab, tile) item each) behind them
       timing.begin("lstm_bwd", s);
       g.done = g.minprog + 2 * PROG_STRIDE;   // own 128-byte line behind the monitor's words; zero-filled once, then only added to
       dw_done_total += (unsigned)(bs * ndir);
@@ -1603,8 +1655,9 @@ struct Net {
 #endif
     // two launches one after the other (host emulator; layers too narrow for the GEMM role's 256 threads when the
     // tests force the path): the items find every progress word complete
+    // (... and minibatches whose backward recurrence runs batched on the MFMA, lstm_mfma_bwd.h: it marks its lines complete)
     timing.begin("lstm_bwd", s);
-    launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
+    launch_bwd_narrow(y, a, s);
     timing.end(s);
     timing.begin("gemm_gates_dw", s);
     if (g.x3 && g.terms >= 3) CLSTM_LAUNCH(gemm_dw_kernel<3>, dim3(nblk), dim3(256), 0, s, g);
@@ -1713,7 +1766,7 @@ struct Net {
         const LstmWideArgs w = wide_args(y, false);
         launch_lstm_wide(false, w, tmax, coop_sync, step_graphs, s, bf16_rec, 0, rec_x3());
         skipped_d = w.skip_d;
-      } else launch_lstm(false, y.nk4, y.pd.ku, a, bs, y.nthreads, s);
+      } else launch_bwd_narrow(y, a, s);
       timing.end(s);
       bwd_persistent = y.wide && g_wide_persistent;
       y.d_f32_valid = !(bwd_persistent && bf16_rec && skipped_d);

@@ -184,6 +184,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       Wh[i][kb] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wp));
       Wl[i][kb] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wp + 512));
     }
+  // (consumed here once, so that the waits for these loads sit in front of the loop and not -- as s_waitcnt vmcnt(N) with a small
+  //  N -- at the top of every step: lstm_mfma_bwd.h)
+#pragma unroll
+  for (int i = 0; i < TW; i++)
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) { asm volatile("" : "+a"(Wh[i][kb])); asm volatile("" : "+a"(Wl[i][kb])); }
   const float inv = a.inv_scale[dir];
   const float sig_k = inv * ACT_SIG_SCALE, tanh_k = inv * ACT_TANH_SCALE;   // (powers of two times a constant: exact products)
   // B image: h_{-1} = 0, zero padding, and the constant 1 behind the inputs (both buffers)

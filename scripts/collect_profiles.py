@@ -10,7 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 pre = "r%s_" % rnd
-for name in ("bench_default.json", "bench_mb1.json", "bench_mb16.json", "bench_mb256.json", "bench_mb1024.json",
+if os.path.exists(os.path.join(src, "bench_kernel_stats_strict.csv")):
+    pass
+for name in ("bench_default.json", "bench_mb1.json", "bench_mb16.json", "bench_mb256.json", "bench_mb1024.json", "bench_mb2048.json", "bench_trained.json",
+             "bench_kernel_stats_strict.csv", "bench_kernel_stats_mb256.csv", "pmc_FETCH_SIZE_strict_summary.txt", "pmc_WRITE_SIZE_strict_summary.txt",
+             "pmc_FETCH_SIZE_mb256_summary.txt", "pmc_WRITE_SIZE_mb256_summary.txt",
              "bench_ragged.json", "bench_b2.json", "bench_b2_bf16gemm.json", "bench_b2_bf16.json", "bench_forcedist.json",
              "bench_overlap0.json", "bench_host_inputs.json", "bench_driver_cmd.json", "fwd_timeline.txt", "lstm_fwd_phase_cycles.txt", "ctc_phase_cycles.txt", "xcd_phase_cycles.txt", "timeline.txt", "host.txt", "pmc_FETCH_SIZE_summary.txt", "pmc_WRITE_SIZE_summary.txt",
              "pmc_SQ_VALU_MFMA_BUSY_CYCLES_summary.txt", "pmc_GRBM_GUI_ACTIVE_summary.txt", "pmc_SQ_summary.txt",
@@ -25,6 +29,8 @@ if os.path.exists(p):
 
 def summary(counter):
     out = {}
+    if not os.path.exists(os.path.join(src, "pmc_%s_summary.txt" % counter)):
+        return out
     for line in open(os.path.join(src, "pmc_%s_summary.txt" % counter)):
         m = re.match(r"(.*?)\s+launches\s+(\d+)\s+avg\s+([\d.]+)", line)
         if m:
@@ -50,10 +56,21 @@ def find(table, prefix):
     return None
 
 
-for k, full in names.items():
-    f, w = find(fe, full), find(wr, full)
-    if f is not None and w is not None:
-        kern[k] = {"fetch_kib": f, "write_kib": w, "hbm_bytes": int(round((2.0 * f + w) * 1024))}
+def leg_kernels(fe, wr):
+    out = {}
+    for k, full in names.items():
+        f, w = find(fe, full), find(wr, full)
+        if f is not None and w is not None:
+            out[k] = {"fetch_kib": f, "write_kib": w, "hbm_bytes": int(round((2.0 * f + w) * 1024))}
+    return out
+
+
+kern = leg_kernels(fe, wr)
+legs = {}
+for leg, what in (("strict", "bench.py --strict-f32"), ("mb256", "bench.py --minibatch 256")):
+    lk = leg_kernels(summary("FETCH_SIZE_" + leg), summary("WRITE_SIZE_" + leg))
+    if lk:
+        legs[leg] = {"command": what, "kernels": lk}
 doc = {
     "_comment": "HBM traffic per launch from rocprofv3 PMC passes (profiles/%spmc_*_summary.txt), bench.py default "
                 "workload (minibatch 64, T=200, BiLSTM(100)). FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE "
@@ -62,6 +79,7 @@ doc = {
                 "2 x 135883 x 4 B = 1,087,064 B." % pre,
     "workload": {"minibatch_per_gpu": 64, "T": 200},
     "kernels": kern,
+    "legs": legs,
 }
 json.dump(doc, open(os.path.join(dst, "pmc_r%s.json" % rnd), "w"), indent=1)
 print(json.dumps(kern, indent=1))

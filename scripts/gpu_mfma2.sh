@@ -3,7 +3,7 @@
 TAG=${1:-mfma2}; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd "$ROOT"; OUT="$ROOT/gpurun_out/$TAG"; mkdir -p "$OUT"
 python -c "from oracle.oracle import build; build()" > "$OUT/oracle_build.log" 2>&1
-timeout 900 python -m pytest tests/test_mfma_recurrence.py -m gpu -q -x > "$OUT/pytest_mfma.log" 2>&1; tail -5 "$OUT/pytest_mfma.log"
+timeout 900 python -m pytest tests/test_mfma_recurrence.py -m gpu -q > "$OUT/pytest_mfma.log" 2>&1; tail -5 "$OUT/pytest_mfma.log"
 if [ -f clstm_amd/lib/libclstm_hip_prof.so ]; then
   for n in 256 1024; do CLSTM_HIP_VARIANT=prof timeout 300 python scripts/gpu_mfmaprof.py $n 2>&1 | tee "$OUT/prof_$n.txt" | tail -9; done
 fi

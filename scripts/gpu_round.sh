@@ -19,7 +19,8 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log
 B() { timeout 600 python bench.py "$@"; }
 echo "=== bench (default = minibatch 64, T=200)"
 B > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; cut -c1-400 "$OUT/bench_default.json"; tail -2 "$OUT/bench_default.err" | grep -v amdgpu
-for MB in 1 16 256 1024; do
+B --weights trained --no-cpu-baseline --no-secondary > "$OUT/bench_trained.json" 2>/dev/null; cut -c1-220 "$OUT/bench_trained.json"
+for MB in 1 16 256 1024 2048; do
   B --minibatch $MB --no-cpu-baseline --no-secondary --steps 50 --warmup 10 > "$OUT/bench_mb$MB.json" 2> "$OUT/bench_mb$MB.err"; cut -c1-220 "$OUT/bench_mb$MB.json"
 done
 B --ragged --no-cpu-baseline --no-secondary > "$OUT/bench_ragged.json" 2>/dev/null; cut -c1-220 "$OUT/bench_ragged.json"
@@ -58,6 +59,19 @@ for CNT in FETCH_SIZE WRITE_SIZE; do
   CLSTM_OVERLAP=0 timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_${CNT}_ov0" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof_${CNT}_ov0.log" 2>&1
   python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_${CNT}_ov0" $CNT > "$OUT/pmc_${CNT}_ov0_summary.txt" 2>&1; head -6 "$OUT/pmc_${CNT}_ov0_summary.txt"
   find "$OUT/pmc_${CNT}_ov0" -name "*.csv" -size +8M -delete
+done
+# the other legs of the default line, each with its own evidence: the strict_f32 step (f32-MFMA weight-gradient
+# items: lstm_bwd_dw_kernel<7, 25, 0>) and the 256-line step -- kernel stats, then FETCH_SIZE / WRITE_SIZE in separate passes
+for LEG in strict mb256; do
+  if [ $LEG = strict ]; then LA="--strict-f32"; else LA="--minibatch 256"; fi
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$LEG" -o bench -- python "$ROOT/bench.py" $LA --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof_$LEG.log" 2>&1
+  find "$OUT/prof_$LEG" -name "*kernel_stats*" | head -1 | while read f; do cp "$f" "$OUT/bench_kernel_stats_$LEG.csv"; head -5 "$f" | cut -c1-160; done
+  find "$OUT/prof_$LEG" -name "*kernel_trace*" -size +20M -delete
+  for CNT in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_${CNT}_$LEG" -o bench -- python "$ROOT/bench.py" $LA --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof_${CNT}_$LEG.log" 2>&1
+    python "$ROOT/scripts/summarize_pmc.py" "$OUT/pmc_${CNT}_$LEG" $CNT > "$OUT/pmc_${CNT}_${LEG}_summary.txt" 2>&1; head -4 "$OUT/pmc_${CNT}_${LEG}_summary.txt"
+    find "$OUT/pmc_${CNT}_$LEG" -name "*.csv" -size +8M -delete
+  done
 done
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_MFMA" -o bench -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > "$OUT/rocprof_MFMA.log" 2>&1
 for CNT in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do

@@ -37,14 +37,28 @@ def _count(backend, which):
 ])
 def test_mfma_recurrence_vs_oracle(backend, ora32, nh, T):
     set_opt(backend, "fwd_mfma", 2)
-    before = _count(backend, 16)
+    set_opt(backend, "bwd_mfma", 2)
+    before, before_b = _count(backend, 16), _count(backend, 17)
     run_case(backend, ora32, 48, nh, 83, T, scale=10.0)
     assert _count(backend, 16) > before, "the MFMA recurrence did not run"
+    assert nh == 128 or _count(backend, 17) > before_b, "the MFMA backward recurrence did not run"   # (128 cells: forward only)
+
+
+@pytest.mark.parametrize("T", [[40, 23, 1, 70], [33] * 17])
+def test_mfma_backward_alone(backend, ora32, T):
+    """the batched backward recurrence (lstm_mfma_bwd.h) behind the per-line forward kernel: its deltas, the weight gradient formed
+    from them by the separate-launch weight-gradient items, the update"""
+    set_opt(backend, "fwd_mfma", 0)
+    set_opt(backend, "bwd_mfma", 2)
+    before = _count(backend, 17)
+    run_case(backend, ora32, 48, 100, 83, T, scale=10.0)
+    assert _count(backend, 17) > before
 
 
 def test_mfma_recurrence_large_weights(backend, ora32):
     """init x 60: saturated gates and |R| of order 1 -- the power-of-two scaling of the f16 split must follow the weights"""
     set_opt(backend, "fwd_mfma", 2)
+    set_opt(backend, "bwd_mfma", 2)
     run_case(backend, ora32, 48, 100, 83, [50, 44, 37, 29, 18], scale=60.0, ctc_rtol=1e-3, grad_tol=1e-3)
 
 
@@ -54,6 +68,7 @@ def test_mfma_second_step_repacks(backend, ora32):
     from common import assert_close, oracle_minibatch, synth_lines
     from oracle.oracle import OracleNet
     set_opt(backend, "fwd_mfma", 2)
+    set_opt(backend, "bwd_mfma", 2)
     rng = np.random.default_rng(5)
     ni, nh, nc, T = 48, 100, 83, [33, 21, 40, 12, 27]
     ref = OracleNet(ora32, ni, nh, nc, seed=0.222)
