@@ -1260,8 +1260,12 @@ struct Net {
           if (l > 0 && !from16) ensure_h_f32(l - 1);
           // x columns that fill whole tiles of the weight-gradient GEMM are not copied: the GEMM reads them from Hbf itself
           const int R_ = 1 + y.ni + y.no, Cn_ = 4 * y.no;
-          // (for BOTH row counts the backward pass may launch with: R_, and R_ - 1 when the bias row is left out)
-          y.sbf_x_external = from16 && y.ni % gemm_mc_rows_per_tile(R_, Cn_) == 0 && y.ni % gemm_mc_rows_per_tile(R_ - 1, Cn_) == 0;
+          // (decided for the row count the backward pass WILL launch with -- R_ - 1 when the bias row is left out, the predicate of
+          //  `dw_bias_out` there -- with the same tile-height function; should the backward pass still come out with another tile
+          //  height, gemm_mc_check_a2 refuses the launch loudly instead of reading x rows nobody wrote.  Requiring BOTH R_ and
+          //  R_ - 1 to fit, the first form of this fix, switched the path off at configs[4]: 1537 rows pick 192-row tiles.)
+          const int R_bwd = wide_kp16_bwd(y.no) == 4 * y.no && gemm_bf16_big(R_ - 1, Cn_) ? R_ - 1 : R_;   // (= the backward's dbias condition)
+          y.sbf_x_external = from16 && y.ni % gemm_mc_rows_per_tile(R_bwd, Cn_) == 0;
           if (y.sbf_x_external) {
             if (y.sbf_one_key != (long long)N) {
               CLSTM_LAUNCH(k_source_one_bf16, dim3(nblocks((size_t)N)), dim3(256), 0, s, y.Sbf.p, (size_t)N, y.ni + y.no, w.sbf_ld, ndir, w.sbf_dir);
