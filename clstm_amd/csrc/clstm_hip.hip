@@ -1282,7 +1282,7 @@ struct Net {
       // bf16 mode, wide layer: no hoisted product at all when the persistent recurrence can take the input projection with it
       // (its operands are the bf16 rows the layer below left, or a bf16 copy of the input frames)
       bool fx_done = false;
-      // CLSTM_FUSE_WX: 0 never, 1 (default) layers of up to 128 inputs, 2 every eligible layer.  Measured at configs[4]
+      // experiment option fuse_wx (CLSTM_DEBUG): 0 never, 1 (default) layers of up to 128 inputs, 2 every eligible layer.  Measured at configs[4]
       // (profiles/r04_xcd_phase_cycles_fused_wx.txt): there is no idle shadow to hide the x-part in -- a step's "group wait" is
       // one L2 round trip of the poll, not waiting for late tiles -- so the fused work lands on the chain: +400 cycles per step
       // for 64 inputs (67 us per pass against the 121 us of product + bf16 copy it replaces: kept), +2,950 for 1024 inputs
@@ -1481,13 +1481,13 @@ struct Net {
   // terms per operand of those split products and of the softmax layer's (gemm_x3): 3 = operand-exact (x1 + x2 + x3 is the f32
   // itself, six products), 2 = hi + lo, three products (< 2^-16 per product; rounds 3-5)
   int split_terms = dbg_opt("split_terms", 3);
-  // the softmax layer's backward products W.d / x.d the same way (gemm_x3, gemm_bf16.h); CLSTM_GEMM_X3=0: f32 MFMA.
+  // the softmax layer's backward products W.d / x.d the same way (gemm_x3, gemm_bf16.h); experiment option gemm_x3=0 (CLSTM_DEBUG): f32 MFMA.
   // NOT the forward product W_x.x: its ~2^-17 relative error per product shows up in gate pre-activations that cancel to
   // ~0 (a tanh gate at -0.0021 came out 5.6e-6 off where the parity bar allows 2.2e-6), and with K = 49 the split costs
   // more staging than it saves MFMA time (28.5 vs 20.9 us).
   bool gemm_x3_on = dbg_opt("gemm_x3", 1) != 0;
   // exact-f32 mode, wide layers: the persistent BACKWARD recurrence as an f32-grade x3 product on the bf16 MFMA (lstm_wide.h:
-  // lstm_xcd_bwd_x3) like the backward GEMMs of this mode; off with them (CLSTM_GEMM_X3=0 / strict f32) or alone (CLSTM_REC_X3=0;
+  // lstm_xcd_bwd_x3) like the backward GEMMs of this mode; off with them (gemm_x3=0 / strict f32) or alone (rec_x3=0, CLSTM_DEBUG options;
   // read per pass: tests compare both kernels in one process)
   bool rec_x3() const {
     if (bf16_gemm || bf16_rec || !gemm_x3_on) return false;
@@ -1779,7 +1779,7 @@ struct Net {
       const bool dw_from_bf16 = bf16_gemm && bf16_rec && bwd_persistent && y.sbf_ready && y.Dbf.p && gemm_bf16_big(R, Cn);
       const bool dw_bias_out = dw_from_bf16 && y.dbias.p && gemm_bf16_big(R - 1, Cn);
       // exact-f32 mode, wide layer: the backward products as f32-grade bf16 x 3 on 128 x 128 tiles (gemm_x3_128_kernel) -- what
-      // narrow layers already do inside their fused backward launch; CLSTM_GEMM_X3=0 / clstm_net_set_strict_f32: the f32 MFMA
+      // narrow layers already do inside their fused backward launch; gemm_x3=0 (CLSTM_DEBUG) / clstm_net_set_strict_f32: the f32 MFMA
       const bool x3_big = !bf16_gemm && y.wide && gemm_x3_on && gemm_bf16_big(R, Cn);
       if (bf16_gemm || !overlap_eligible(y))
         ns = dw_bias_out && gemm_tile256(R - 1, Cn) ? pick_split_mc(R - 1, Cn, ndir)

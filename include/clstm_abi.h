@@ -201,15 +201,15 @@ int clstm_net_get_state_h(clstm_net* net, int layer, int dir, int which, float* 
  * mode 0: off (GEMM after the recurrence); 1 (default): both as two workgroup roles of ONE launch
  * (csrc/lstm_bwd_dw.h) for batches large enough to profit; 2: the same always (tests); 3: two launches on streams
  * with complementary CU masks (measured slower than mode 0, kept for the record).  Results are the same sums in a
- * different slab order; in modes 1-3 the products run on the bf16 MFMA with both f32 operands split hi + lo (three
- * products per term, f32 accumulation: error per product < 2^-16, i.e. the sum is as close to the exact one as an
- * f32 fmaf chain; environment CLSTM_DW_X3=0 selects the f32 MFMA), and the top layer's launch also computes the softmax
- * layer's W.d.  stats: overlapped backward passes so far; slabs that gave up waiting for the recurrence
+ * different slab order; in modes 1-3 the products run on the bf16 MFMA with both f32 operands split EXACTLY into three
+ * bf16 terms (x1 + x2 + x3 = x; the six products of weight >= 2^-16 summed in f32: what is dropped is < 2^-23 |x||y| per
+ * product, the size of an f32 multiply's own rounding; experiment options CLSTM_DEBUG="split_terms=2" -- two terms, three
+ * products, < 2^-16 -- and "dw_x3=0" -- the f32 MFMA), and the top layer's launch also computes the softmax layer's W.d.  stats: overlapped backward passes so far; slabs that gave up waiting for the recurrence
  * (must stay 0). */
 int clstm_net_set_overlap(clstm_net* net, int mode);
-/* on != 0: every product of the training step on the exact f32 MFMA -- the backward products that default to f32-grade
- * bf16 x 3 split products (weight gradients, the softmax layer's W.d / x.d; < 2^-16 |x||y| per product instead of 2^-24)
- * included.  Same as the environment CLSTM_DW_X3=0 CLSTM_GEMM_X3=0, per net (bench.py's `strict_f32` leg). */
+/* on != 0: every product of the training step on the f32 MFMA -- the backward products that default to operand-exact split
+ * products on the bf16 MFMA (weight gradients, the softmax layer's W.d / x.d) included.  Same as
+ * CLSTM_DEBUG="dw_x3=0,gemm_x3=0", per net (bench.py's `strict_f32` leg and --strict-f32). */
 int clstm_net_set_strict_f32(clstm_net* net, int on);
 int clstm_net_overlap_stats(clstm_net* net, long long* launches, int* timeouts);
 int clstm_net_enable_timing(clstm_net* net, int on);

@@ -91,4 +91,9 @@ timeout 300 python scripts/gpu_ctcprof.py > "$OUT/ctc_phase_cycles.txt" 2>&1; ta
 # per-phase stamps of the persistent bf16 recurrences of wide layers (diagnostics build; built here if it is missing)
 make -s -C clstm_amd/csrc ../lib/libclstm_hip_prof.so > /dev/null 2>&1   # (stale or missing: rebuilt here)
 CLSTM_HIP_VARIANT=prof timeout 300 python scripts/gpu_xcdprof.py 2>&1 | grep -v amdgpu.ids > "$OUT/xcd_phase_cycles.txt"; head -11 "$OUT/xcd_phase_cycles.txt"
+# gpurun copies back at most 64 MiB: keep the summaries, drop the raw traces / counter tables / databases
+find "$OUT" -type f \( -name "*.db" -o -name "*.rocpd" -o -name "*.json" -size +2M -o -name "*.csv" -size +2M \) -delete
+find "$OUT" -type f -name "*kernel_trace*.csv" -delete
+find "$OUT" -type f -name "*counter_collection*.csv" -delete
+du -sh "$OUT" | tail -1
 echo "=== done"
