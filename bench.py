@@ -458,7 +458,10 @@ def roofline_b1(w, kern, kern_unfused, frames_per_step, ms_per_step, strict=Fals
     step_bytes = 3.62e6 * w.minibatch + 2.17e6
     step_flops = flops_per_line(cfg, w.T) * w.minibatch if not w.ragged else None
     sec = ms_per_step * 1e-3
-    step_traffic = sum(v for v in traffic.values()) if traffic else None
+    # the launches of THIS step that the PMC passes cover (the fused pair when the step ran fused; never both forms)
+    in_step = [k for k in (("lstm_fwd_fused" if "gemm_gates_x" not in kern else "lstm_fwd"),
+                           ("lstm_bwd_dw" if "gemm_gates_dw" not in kern else "lstm_bwd"), "ctc_align") if k in traffic]
+    step_traffic = sum(traffic[k] for k in in_step) if len(in_step) == 3 else None
     out["whole_step"] = {
         "algorithmic_bytes": int(step_bytes), "achieved_GBps": round(step_bytes / sec / 1e9, 1), "hbm_frac": round(step_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
         "algorithmic_flops": None if step_flops is None else int(step_flops),
@@ -466,8 +469,10 @@ def roofline_b1(w, kern, kern_unfused, frames_per_step, ms_per_step, strict=Fals
         "f32_mfma_frac": None if step_flops is None else round(step_flops / sec / 1e12 / F32_MFMA_PEAK_TFS, 4),
         "traffic_all_profiled_kernels": step_traffic,
         "traffic_over_algorithmic": None if not step_traffic else round(step_traffic / step_bytes, 2),
-        "note": "SURVEY.md 8(d): 3.62 MB + 162.0 MFLOP per line (+ 2.17 MB per minibatch); traffic = sum of the per-launch HBM bytes of "
-                "the committed PMC passes over the kernels listed there (one launch each per step)"}
+        "traffic_kernels": in_step if step_traffic else None,
+        "note": "SURVEY.md 8(d): 3.62 MB + 162.0 MFLOP per line (+ 2.17 MB per minibatch); traffic = per-launch HBM bytes of the "
+                "committed PMC passes summed over the step's forward launch, CTC launch and backward launch (the small x.d / reduce / "
+                "ingest launches are not in those passes' summary)"}
     out["note"] = ("latency-bound recurrence: %d workgroups (lines x directions) on 256 CUs, one dependent step per frame; "
                    "whole step %.1f GB/s of algorithmic bytes (SURVEY 8d: 3.62 MB/line + 2.17 MB/minibatch)"
                    % (2 * w.minibatch, (3.62e6 * w.minibatch + 2.17e6) / (ms_per_step * 1e-3) / 1e9))

@@ -93,9 +93,29 @@ inline __host__ __device__ CtcLds ctc_lds_layout(int tile, int ncp, int smax) {
   return l;
 }
 
+#ifdef CLSTM_CTC_FLOAT_LOGADD
+// EXPERIMENT build (make variant VARIANT=ctcf EXTRA=-DCLSTM_CTC_FLOAT_LOGADD): log(exp(d) + 1) in float on
+// the hardware transcendentals -- exp as in ctc_limexp (<= 2 ulp), the reference's float add of 1, log2 by v_log_f32 (1 ulp)
+// times ln 2 -- 9 float operations instead of ~25 half-rate f64 operations + a table read.  NOT the reference's roundings:
+// parity and time are in profiles/r06_ctc_float_logadd.txt; not the default.
+DEVFN float ctc_softplus_float(float d) {
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
+  const float t = d * L2E_HI;
+  const float r = fmaf(d, L2E_LO, fmaf(d, L2E_HI, -t));
+  const float e2 = fast_exp2(t);
+  const float ef = fmaf(e2 * 0.693147182464599609375f, r, e2);
+  const float sf = ef + 1.0f;
+  return __builtin_amdgcn_logf(sf) * 0.693147182464599609375f;
+}
+#endif
 DEVFN float ctc_log_add(float x, float y, const CrTables tb) {  // tensor.h:86-89
   const float d = x - y;
+#ifdef CLSTM_CTC_FLOAT_LOGADD
+  const float dc = fminf(fmaxf(d, -10.0f), 10.0f);
+  const float lg = ctc_softplus_float(dc) + y;
+#else
   const float lg = cr_softplusf(d, tb) + y;   // log(exp(x-y)+1)+y, every float rounding reproduced (cr_math.h)
+#endif
   return fabsf(d) > 10.0f ? fmaxf(x, y) : lg; // a select (an asm v_max here turns it into an exec-masked branch)
 }
 // limexp (tensor.h:78-82) = exp of the argument clamped to [-30, 30], for phase C.  Phase C is OUTSIDE the recursion: an
