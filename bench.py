@@ -738,6 +738,25 @@ def main():
         wt.net = wt.trainer = None
         del wt
 
+    # the same workload with the CTC recursion's log_add on the float transcendentals (experiment option ctc_float, VERDICT r5 item
+    # 3d: NOT the default -- posteriors then agree with the reference's to 5.6e-5 absolute / 3.2e-4 relative at T = 200 instead of
+    # 7.3e-6 / 1.1e-4; profiles/r06_ctc_float_logadd.txt); default single-GPU line only
+    ctc_float = None
+    if rank == 0 and world == 1 and default_line and args.weights == "init" and not args.no_secondary:
+        lib.call("clstm_debug_set_option", b"ctc_float", 1)
+        try:
+            wc = Workload(lib, cfg, args.minibatch, args.T, args.ragged, 0, dev, rank)
+            mc_ = measure(wc, args.steps, 5, 20, min_timed_s=0.5)
+            ctc_float = {"value": round(args.minibatch * args.steps / mc_["dt"], 2), "unit": "lines/s", "ms_per_step": round(mc_["dt"] / args.steps * 1e3, 4),
+                         "repeats": len(mc_["blocks"]), "ctc_align_ms": mc_["kern"].get("ctc_align", {}).get("ms_per_step"),
+                         "option": "CLSTM_DEBUG=ctc_float=1 (float-only log_add in the CTC lattice recursion; not the default)",
+                         "parity": "reference known answer (test-ctc.cc:76-109) 4.6e-6; vs oracle at T=200, S=51: 5.6e-5 absolute, 3.2e-4 relative "
+                                   "(exact form, the default: 7.3e-6 / 1.1e-4); tests/test_ops_parity.py::test_ctc_float_logadd_option"}
+            wc.net = wc.trainer = None
+            del wc
+        finally:
+            lib.call("clstm_debug_set_option", b"ctc_float", 0)
+
     # the same workload with EVERY product on the f32 MFMA (clstm_net_set_strict_f32: the default computes the backward
     # weight-gradient / softmax-backward products on the bf16 MFMA from f32 operands split exactly into three bf16 terms);
     # default single-GPU line only
@@ -858,6 +877,7 @@ def main():
             "allreduce": allreduce,
             "weights": (w.weights_info or "reference initialisation (rinit negbiased, seed 0.222)"),
             "trained_weights": trained,
+            "ctc_float_logadd": ctc_float,
             "strict_f32": strict,
             "saturated": saturated,
             "secondary": secondary,

@@ -2068,6 +2068,7 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
   a.states = (const int*)(w.meta.p + nln);
   a.lat = w.lat.p; a.nc = nc;
   w.prof.reserve(16); a.prof = w.prof.p; g_last_ctc_prof = w.prof.p;
+  a.float_logadd = dbg_opt("ctc_float", 0) != 0;   // experiment option (ctc.h: ctc_softplus_float); read per alignment
   if (!w.tables.p) {
     w.tables.reserve(CTC_TABLE_DOUBLES);
     std::vector<double> tb(CTC_TABLE_DOUBLES);
@@ -2098,12 +2099,17 @@ static void run_ctc(CtcWorkspace& w, const float* probs, float* deltas, float* a
 #ifndef CLSTM_HIP_EMU
   static size_t smem_set = 0;
   if (smem > smem_set) {
-    HIPCHECK(hipFuncSetAttribute((const void*)ctc_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HIPCHECK(hipFuncSetAttribute((const void*)ctc_align_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HIPCHECK(hipFuncSetAttribute((const void*)ctc_align_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     smem_set = smem;
   }
 #endif
   w.pending = a; w.pending_smem = smem; w.pending_bs = bs;
-  if (launch) { CLSTM_LAUNCH(ctc_align_kernel, dim3(bs), dim3(CTC_THREADS), smem, s, a); check_launch(); }
+  if (launch) {
+    if (a.float_logadd) CLSTM_LAUNCH(ctc_align_kernel<true>, dim3(bs), dim3(CTC_THREADS), smem, s, a);
+    else CLSTM_LAUNCH(ctc_align_kernel<false>, dim3(bs), dim3(CTC_THREADS), smem, s, a);
+    check_launch();
+  }
 }
 struct DecodeWorkspace {
   DevBuf<int> line_off, idx, cls, loc, cnt;
@@ -2402,7 +2408,8 @@ static void net_ctc_launch(clstm_net* h) {
   Net& n = h->net;
   RoctxRange range_("clstm:ctc");
   n.timing.begin("ctc_align", g_stream);
-  CLSTM_LAUNCH(ctc_align_kernel, dim3(h->ctc.pending_bs), dim3(CTC_THREADS), h->ctc.pending_smem, g_stream, h->ctc.pending);
+  if (h->ctc.pending.float_logadd) CLSTM_LAUNCH(ctc_align_kernel<true>, dim3(h->ctc.pending_bs), dim3(CTC_THREADS), h->ctc.pending_smem, g_stream, h->ctc.pending);
+  else CLSTM_LAUNCH(ctc_align_kernel<false>, dim3(h->ctc.pending_bs), dim3(CTC_THREADS), h->ctc.pending_smem, g_stream, h->ctc.pending);
   check_launch();
   n.timing.end(g_stream);
 }

@@ -209,6 +209,7 @@ DEVFN long long wall_clock() { return (long long)__builtin_amdgcn_s_memrealtime(
 DEVFN float fast_exp(float x) { return __expf(x); }
 DEVFN float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 DEVFN float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DEVFN float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
 
 // ---- buffer (SRD) loads/stores: out-of-range offsets are dropped by the bounds check, so masked
 // lanes need no exec-mask branch and hipcc can count the VMEM queue exactly (vmcnt(N), N>0: the

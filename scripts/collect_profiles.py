@@ -45,14 +45,15 @@ if os.path.exists(os.path.join(src, "pmc_FETCH_SIZE_ov0_summary.txt")):   # pure
 names = {"lstm_fwd": "void clstm::lstm_fwd_kernel<", "lstm_bwd": "void clstm::lstm_bwd_kernel<",
          "lstm_fwd_fused (W_x producers + recurrence + softmax consumers, one launch)": "void clstm::lstm_fwd_fused_kernel<",
          "lstm_bwd_dw (recurrence + weight-gradient GEMM, one launch)": "void clstm::lstm_bwd_dw_kernel<",
-         "ctc_align": "clstm::ctc_align_kernel", "sgd_update": "clstm::k_update",
+         "ctc_align": ("void clstm::ctc_align_kernel<false>", "clstm::ctc_align_kernel"), "sgd_update": "clstm::k_update",
          "gemm_dw (all split-K launches, avg)": "void clstm::gemm_f32_kernel<1, 1, clstm::StorePartial>",
          "gemm_gates_x / gemm_softmax (avg)": "void clstm::gemm_f32_kernel<0, 1, clstm::StoreBias>"}
 kern = {}
-def find(table, prefix):
-    for name, v in table.items():
-        if name.startswith(prefix):
-            return v
+def find(table, prefixes):
+    for prefix in (prefixes if isinstance(prefixes, tuple) else (prefixes,)):
+        for name, v in table.items():
+            if name.startswith(prefix):
+                return v
     return None
 
 

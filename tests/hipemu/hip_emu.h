@@ -237,6 +237,7 @@ inline long long wall_clock() {   // 100 MHz ticks, like s_memrealtime
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
+inline float fast_log2(float x) { return log2f(x); }
 #define KEEP_ALIVE(x) (void)(x)
 #define SCHED_FENCE() ((void)0)
 #define OPAQUE(x) ((void)0)

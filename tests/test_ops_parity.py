@@ -342,6 +342,39 @@ def test_ctc_vs_oracle(backend, ora32, T, L, nc):
         assert_close(dz[loff[b]:loff[b + 1]], want - probs[b], rtol=1e-4, atol=2e-6, what="delta line %d" % b)
 
 
+@pytest.mark.parametrize("T,L,nc", [(40, 10, 30), (200, 25, 83), (256, 25, 83), (200, 70, 40), (400, 50, 100)])
+def test_ctc_float_logadd_option(backend, ora32, T, L, nc):
+    """Experiment option ctc_float=1 (NOT the default): log_add of the lattice recursion on the float
+    transcendentals instead of the double evaluation that reproduces glibc's roundings (cr_math.h).  Its stated tolerance on the
+    alignment posteriors: 1e-4 ABSOLUTE -- the bar of the reference's own test (test-ctc.cc:98-104) -- and 1e-3 relative, against
+    1e-4 relative for the default; every lattice path (short line from LDS / HBM, two states per lane, tiled)."""
+    from test_net_parity import set_opt
+    set_opt(backend, "ctc_float", 1)
+    try:
+        rng = np.random.default_rng(T + L)
+        probs, states = [], []
+        for b in range(3):
+            Tb = max(1, T - 3 * b)
+            p = rng.random((Tb, nc)).astype(np.float32) ** 4
+            p /= p.sum(1, keepdims=True)
+            p[0, 1] = 0.0
+            tr = rng.integers(1, nc, max(1, L - b))
+            probs.append(p.astype(np.float32)); states.append(ora32.mktargets(tr))
+        al, dz, loff = ctc_via_abi(backend, probs, states)
+        for b in range(3):
+            want = ora32.ctc_align_classes(probs[b], states[b])
+            assert_close(al[loff[b]:loff[b + 1]], want, rtol=1e-3, atol=1e-4, what="aligned line %d" % b)
+            assert_close(dz[loff[b]:loff[b + 1]], want - probs[b], rtol=1e-3, atol=1e-4, what="delta line %d" % b)
+        # the reference's known answer, at its own tolerance
+        o2 = np.array([[1, .5, 0, 0, 0, 0], [0, .5, .5, 0, 0, 0], [0, 0, .5, .5, 0, 0], [0, 0, 0, .5, .5, 0], [0, 0, 0, 0, .5, 1]], np.float32).T
+        e2 = np.array([[1., 0.12029, 0., 0., 0., 0.], [0., 0.87971, 0.40013, 0., 0., 0.], [0., 0., 0.59987, 0.59987, 0., 0.],
+                       [0., 0., 0., 0.40013, 0.87971, 0.], [0., 0., 0., 0., 0.12029, 1.]], np.float32).T
+        a2, _, _ = ctc_via_abi(backend, [o2], [np.arange(5)])
+        assert np.abs(a2 - e2).max() < 1e-4
+    finally:
+        set_opt(backend, "ctc_float", 0)
+
+
 @pytest.mark.parametrize("L,nc", [(1, 5), (25, 83), (31, 40), (25, 60), (40, 30), (63, 70)])
 def test_ctc_recursion_ring_boundaries(backend, ora32, L, nc):
     """The one-wave lattice recursions request their match scores CTC_PD = 8 frames ahead through a register ring: line lengths
