@@ -798,6 +798,21 @@ def main():
         wsat.net = wsat.trainer = None
         del wsat
 
+    # the same net at 1024 lines per GPU (default single-GPU line only): the narrow recurrences batched over 16 lines per workgroup
+    # on the matrix cores (lstm_mfma.h from 640 lines, lstm_mfma_bwd.h from 1024) -- north_star's "gate GEMMs batched across a
+    # minibatch of text lines with MFMA"; the per-line kernels' ceiling is ~359k lines/s (round 5, profiles/r05_bench_mb1024.json)
+    large = None
+    if rank == 0 and world == 1 and default_line and not args.no_secondary:
+        wl = Workload(lib, cfg, 1024, args.T, False, 0, dev, rank)
+        sl_ = max(5, min(args.steps, 10))
+        ml_ = measure(wl, sl_, 2, 5, min_timed_s=0.3)
+        large = {"value": round(1024 * sl_ / ml_["dt"], 2), "unit": "lines/s", "ms_per_step": round(ml_["dt"] / sl_ * 1e3, 4), "steps": sl_,
+                 "repeats": len(ml_["blocks"]), "config": {"workload": "the headline net at minibatch = 1024 lines per GPU (batched-MFMA recurrences)",
+                                                           "minibatch_per_gpu": 1024},
+                 "kernels": ml_["kern"], "parity": "tests/test_mfma_recurrence.py", "evidence": "profiles/r06_mfma_*.txt, r06_bench_mb1024.json, r06_bench_mb2048.json"}
+        wl.net = wl.trainer = None
+        del wl
+
     # BASELINE.json configs[4] in the same process (default single-GPU line only): 2 x BiLSTM(512), bf16 MFMA
     secondary = None
     if rank == 0 and world == 1 and default_line and not args.no_secondary:
@@ -880,6 +895,7 @@ def main():
             "ctc_float_logadd": ctc_float,
             "strict_f32": strict,
             "saturated": saturated,
+            "large_minibatch": large,
             "secondary": secondary,
             "secondary_f32": secondary_f32,
         }

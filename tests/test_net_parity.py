@@ -750,6 +750,44 @@ def test_bias_gradient_outside_the_bf16_weight_gradient_product(backend, ora32, 
     assert np.abs(g - want["derivs"]).max() < 8e-2 * np.abs(want["derivs"]).max()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nh", [[256, 384], [256, 128], [512, 512]])
+def test_external_x_rows_agree_with_the_weight_gradient_tiles(ora32, nh):
+    """the forward pass decides whether the upper layer's x columns are COPIED into its bf16 source rows or read
+    by the weight-gradient product from the layer below's bf16 outputs (operand A2); the product's row-tile height depends on its
+    row count (192-row tiles where they waste less), and an A2 that does not fill whole tiles used to be dropped silently -- the
+    x rows were then read from columns nobody wrote.  [256 bidir -> 384]: 1 + 512 + 384 rows - the bias row = 896 -> 192-row
+    tiles, 512 % 192 != 0: must take the copy path; [256 -> 128 cells] a narrow upper layer; [512 -> 512] = configs[4]: 1536 rows,
+    256-row tiles, external.  Whatever the path, the W_x block of the upper layer's gradient must track the oracle (bf16
+    tolerance): with unwritten x columns it is garbage or zero.  Both decisions are refused loudly now if they disagree."""
+    from common import Backend
+    from clstm_amd.net import Network
+    backend = Backend("hip")
+    rng = np.random.default_rng(61)
+    ni, nc, T = 16, 7, [24, 17, 24, 9, 20, 24, 13, 24]
+    params = OracleNet(ora32, ni, nh, nc, seed=0.222).get_params() * 4.0
+    lines = synth_lines(rng, T, ni)
+    trs = [rng.integers(1, nc, max(1, t // 4)).astype(np.int32) for t in T]
+    want = oracle_minibatch(ora32, OracleNet, params, ni, nh, nc, lines, trs)["derivs"]
+    for step in range(2):          # (the second pass sees the buffers of the first: the steady-state decision)
+        net = Network(ni, nh, nc, lib=backend.lib) if step == 0 else net
+        if step == 0:
+            net.set_params(params)
+            net.set_gemm_precision(2)
+        net.set_inputs(lines); net.forward(); net.ctc(trs); net.backward()
+        g = net.get_grads()
+        assert np.isfinite(g).all()
+        # the upper layer's parameter blocks: after layer 1's 2 x 4 blocks of nh0 x (1 + ni + nh0)
+        o = 8 * nh[0] * (1 + ni + nh[0])
+        blk = nh[1] * (1 + 2 * nh[0] + nh[1])
+        for k in range(8):
+            gb = g[o + k * blk:o + (k + 1) * blk].reshape(1 + 2 * nh[0] + nh[1], nh[1])      # column-major (no x cols): [col][row]
+            wb = want[o + k * blk:o + (k + 1) * blk].reshape(1 + 2 * nh[0] + nh[1], nh[1])
+            gx, wx = gb[1:1 + 2 * nh[0]], wb[1:1 + 2 * nh[0]]                                  # the W_x columns
+            scale = np.abs(wx).max()
+            assert scale > 0 and np.abs(gx - wx).max() < 8e-2 * scale, (step, k, float(np.abs(gx - wx).max()), float(scale))
+
+
 def _merged_launch_case(backend, ora32):
     from clstm_amd.net import Network
     rng = np.random.default_rng(31)
