@@ -55,6 +55,25 @@ def test_mfma_backward_alone(backend, ora32, T):
     assert _count(backend, 17) > before
 
 
+@pytest.mark.parametrize("seed", [3, 4, 5, 6])
+def test_mfma_randomised_geometries(backend, ora32, seed):
+    """random minibatches through both batched kernels: 1..40 lines of 1..90 frames (groups of 16 with lines that drop out of the
+    lock-step at different steps, groups whose longest line has 1-3 frames: shorter than the kernels' peeled four steps and their
+    operand-request pipeline), 64 or 100 cells -- every activation, every gate delta, the gradient and the update vs the oracle"""
+    rng = np.random.default_rng(seed)
+    for _ in range(4):
+        bs = int(rng.integers(1, 41))
+        T = [int(t) for t in rng.integers(1, 91, bs)]
+        if rng.random() < 0.5:
+            T[:min(bs, 16)] = [int(t) for t in rng.integers(1, 4, min(bs, 16))]     # a whole group of tiny lines (longest first: the LAST group)
+        nh = int(rng.choice([64, 100]))
+        set_opt(backend, "fwd_mfma", 2)
+        set_opt(backend, "bwd_mfma", 2)
+        before = _count(backend, 17)
+        run_case(backend, ora32, 48, nh, 83, T, scale=10.0, seed=int(rng.integers(1 << 30)))
+        assert _count(backend, 17) > before
+
+
 def test_mfma_recurrence_large_weights(backend, ora32):
     """init x 60: saturated gates and |R| of order 1 -- the power-of-two scaling of the f16 split must follow the weights"""
     set_opt(backend, "fwd_mfma", 2)
