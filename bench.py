@@ -798,18 +798,33 @@ def main():
         wsat.net = wsat.trainer = None
         del wsat
 
-    # the same net at 1024 lines per GPU (default single-GPU line only): the narrow recurrences batched over 16 lines per workgroup
+    # the same net at 2048 lines per GPU (default single-GPU line only): the narrow recurrences batched over 16 lines per workgroup
     # on the matrix cores (lstm_mfma.h from 640 lines, lstm_mfma_bwd.h from 1024) -- north_star's "gate GEMMs batched across a
-    # minibatch of text lines with MFMA"; the per-line kernels' ceiling is ~359k lines/s (round 5, profiles/r05_bench_mb1024.json)
+    # minibatch of text lines with MFMA"; 2048 lines = 256 workgroups of 16 lines x direction = one per CU.  The per-line kernels'
+    # ceiling is ~359k lines/s (round 5, profiles/r05_bench_mb1024.json).  Here the recurrences are HBM-bound: their roofline
+    # entries price the bytes the kernels must move (forward: x in, six saved values out = 28 B per cell-step, SURVEY 8(d)'s
+    # "GEMM fused in" figure; backward: activations, c, dH in, four deltas out = 40 B per cell-step -- dc and dh_rec never
+    # leave the chip) against the HBM peak.
     large = None
     if rank == 0 and world == 1 and default_line and not args.no_secondary:
-        wl = Workload(lib, cfg, 1024, args.T, False, 0, dev, rank)
+        LB = 2048
+        wl = Workload(lib, cfg, LB, args.T, False, 0, dev, rank)
         sl_ = max(5, min(args.steps, 10))
         ml_ = measure(wl, sl_, 2, 5, min_timed_s=0.3)
-        large = {"value": round(1024 * sl_ / ml_["dt"], 2), "unit": "lines/s", "ms_per_step": round(ml_["dt"] / sl_ * 1e3, 4), "steps": sl_,
-                 "repeats": len(ml_["blocks"]), "config": {"workload": "the headline net at minibatch = 1024 lines per GPU (batched-MFMA recurrences)",
-                                                           "minibatch_per_gpu": 1024},
-                 "kernels": ml_["kern"], "parity": "tests/test_mfma_recurrence.py", "evidence": "profiles/r06_mfma_*.txt, r06_bench_mb1024.json, r06_bench_mb2048.json"}
+        kl = ml_["kern"]
+        cell_steps = 2.0 * cfg["nh"][0] * ml_["frames_per_step"]
+        rl = {}
+        for name, bpc in (("lstm_fwd", 28.0), ("lstm_bwd", 40.0)):
+            if name in kl:
+                gbs = bpc * cell_steps / (kl[name]["ms_per_step"] * 1e-3) / 1e9
+                rl[name] = {"kernel": "lstm_fwd_mfma_kernel<100, 48>" if name == "lstm_fwd" else "lstm_bwd_mfma_kernel<100, 2>", "bound": "hbm",
+                            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                            "algorithmic_bytes": int(bpc * cell_steps), "bytes_per_cell_step": bpc, "avg_launch_ms": kl[name]["ms_per_step"], "traffic": None}
+        large = {"value": round(LB * sl_ / ml_["dt"], 2), "unit": "lines/s", "ms_per_step": round(ml_["dt"] / sl_ * 1e3, 4), "steps": sl_,
+                 "repeats": len(ml_["blocks"]), "config": {"workload": "the headline net at minibatch = %d lines per GPU (batched-MFMA recurrences, one 16-line workgroup per CU)" % LB,
+                                                           "minibatch_per_gpu": LB},
+                 "roofline": rl, "kernels": kl, "parity": "tests/test_mfma_recurrence.py",
+                 "evidence": "profiles/r06_mfma_*.txt, r06_bench_mb1024.json, r06_bench_mb2048.json"}
         wl.net = wl.trainer = None
         del wl
 

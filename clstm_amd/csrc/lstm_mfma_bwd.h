@@ -192,6 +192,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int kb = 0; kb < KB; kb++)
 #pragma unroll
       for (int t = 0; t < NT; t++) asm volatile("" : "+a"(A[kb][t]));   // fragments live in the accumulation half (see lstm_mfma.h)
+    // this step's operands: requested two (cell states: four / three) steps ago.  Everything that does not depend on this step's
+    // product -- tanh(c), the derivative factors, the second factor of every gate delta -- is computed HERE, in front of the
+    // MFMA stream, so that the scheduler can issue it between the (dependent) MFMAs (the per-line kernel's rule, lstm_seq.h)
+    wait_vmcnt<10>();   // (10, not 11: whatever order the ten operations of a step were issued in, the batch of two steps ago is complete)
+    f32x4 f_gi, f_gf, f_go, f_ci, gthv, gfv, dhv;
+    {
+      const char* const src = in_w + (K & 1) * Gm::IN_SLOT + lane * 16;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(src + i * 1024);
+        const float cci = *reinterpret_cast<const float*>(c_w + K * Gm::C_SLOT + cro + 256 * i);
+        const float cm1 = *reinterpret_cast<const float*>(c_w + ((K + 1) & 3) * Gm::C_SLOT + cro + 256 * i);
+        dhv[i] = *reinterpret_cast<const float*>(in_w + (K & 1) * Gm::IN_SLOT + 4 * 1024 + cro + 256 * i);
+        const float gi = g[0], gf = g[1], go = g[2], ci = g[3];
+        const float th = tanh_fast(cci);                          // backward_nonlingate recomputes tanh(state)
+        gthv[i] = go * fmaf(-th, th, 1.0f);                        // state.d += (1 - t^2) go out.d
+        gfv[i] = gf;
+        f_gi[i] = ci * fmaf(-gi, gi, gi);                          // gi.d = c.d ci, through sigma'
+        f_gf[i] = cm1 * fmaf(-gf, gf, gf);                         // gf.d = c.d c_{s-1}  (c_{-1} = 0: "untouched when last < 0")
+        f_go[i] = th * fmaf(-go, go, go);                          // go.d = tanh(c) out.d
+        f_ci[i] = gi * fmaf(-ci, ci, 1.0f);                        // ci.d = c.d gi, through tanh'
+      }
+    }
     // dh_rec = R^T . delta(s + 1): two accumulator chains alternate over the k-blocks (an MFMA behind its own predecessor is
     // forwarded only back to back); smallest terms first
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -210,34 +233,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     const f32x4 acc = acc0 + acc1;
-    // this step's operands: requested two (cell states: four / three) steps ago
-    wait_vmcnt<10>();   // (10, not 11: whatever order the ten operations of a step were issued in, the batch of two steps ago is complete)
-    struct { f32x4 g[4]; } cur;
-    {
-      const char* const src = in_w + (K & 1) * Gm::IN_SLOT + lane * 16;
-#pragma unroll
-      for (int i = 0; i < 4; i++) cur.g[i] = *reinterpret_cast<const f32x4*>(src + i * 1024);
-    }
-    f32x4 cc, cm1, dhv;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      cc[i] = *reinterpret_cast<const float*>(c_w + K * Gm::C_SLOT + cro + 256 * i);
-      cm1[i] = *reinterpret_cast<const float*>(c_w + ((K + 1) & 3) * Gm::C_SLOT + cro + 256 * i);
-      dhv[i] = *reinterpret_cast<const float*>(in_w + (K & 1) * Gm::IN_SLOT + 4 * 1024 + cro + 256 * i);
-    }
-    // element-wise half of the step for this lane's four cells (lstm_seq.h:lstm_bwd_body, the same expressions)
+    // the dependent tail (lstm_seq.h:lstm_bwd_body, the same expressions)
     f32x4 dl[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const float gi = cur.g[i][0], gf = cur.g[i][1], go = cur.g[i][2], ci = cur.g[i][3];
-      const float th = tanh_fast(cc[i]);                          // backward_nonlingate recomputes tanh(state)
-      const float dh = dhv[i] + acc[i];                        // delta from above + recurrent delta (clstm.cc:626-628, :646)
-      const float dc = fmaf(go * fmaf(-th, th, 1.0f), dh, dcc[i]);   // state.d += (1 - t^2) go out.d
-      dcc[i] = dc * gf;                                           // c_{s-1}.d += c.d gf       (backward_statemem, :509-515)
-      dl[i][0] = dc * ci * fmaf(-gi, gi, gi);                     // gi.d = c.d ci, through sigma'
-      dl[i][1] = dc * cm1[i] * fmaf(-gf, gf, gf);                 // gf.d = c.d c_{s-1}  (c_{-1} = 0: "untouched when last < 0")
-      dl[i][2] = dh * th * fmaf(-go, go, go);                     // go.d = tanh(c) out.d
-      dl[i][3] = dc * gi * fmaf(-ci, ci, 1.0f);                   // ci.d = c.d gi, through tanh'
+      const float dh = dhv[i] + acc[i];                           // delta from above + recurrent delta (clstm.cc:626-628, :646)
+      const float dc = fmaf(gthv[i], dh, dcc[i]);
+      dcc[i] = dc * gfv[i];                                       // c_{s-1}.d += c.d gf       (backward_statemem, :509-515)
+      dl[i][0] = dc * f_gi[i];
+      dl[i][1] = dc * f_gf[i];
+      dl[i][2] = dh * f_go[i];
+      dl[i][3] = dc * f_ci[i];
     }
     {
       const unsigned o = bad(s), tk = tok(s);
