@@ -243,6 +243,10 @@ DEVFN void buf_store(BufF32 b, unsigned byte_off, float v) {
 DEVFN void lds_dma16(BufF32 b, unsigned byte_off, void* lds_wave_base) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_off, 0, 0, 0);
 }
+// dword form: 4 bytes per lane, a wave instruction fills 256 bytes of LDS in lane order (rows that are not a multiple of 16 lanes x 16 B)
+DEVFN void lds_dma4(BufF32 b, unsigned byte_off, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, byte_off, 0, 0, 0);
+}
 template <int N> DEVFN void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 DEVFN void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 DEVFN void wg_barrier() { __builtin_amdgcn_s_barrier(); }   // bare s_barrier: no implied waits

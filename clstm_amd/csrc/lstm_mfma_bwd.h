@@ -298,5 +298,254 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+
+// ---- the same recurrence with every global access a whole ROW (the default; option bwd_mfma_rows=0 selects the kernel above) ----
+// lstm_bwd_mfma_kernel above is bound by the per-CU address pipeline below 2048 lines (64-byte requests: ~1.4 us of a 2.95 us
+// step, profiles/r06_mfma_bwd_leaveout.txt); the forward kernel, whose rows go through LDS and leave 1 KB per instruction, pays
+// almost nothing for 38 KB per step.  Here the operands arrive the same way: wave v requests the rows of lines 2 v, 2 v + 1 by
+// LDS-DMA -- the activation row (1600 B at NO = 100: two 16-byte-per-lane instructions), the c and dH rows (400 B: two dword
+// instructions each) -- into row images padded by 16 bytes per line (conflict-free for the compute lanes' reads), the compute
+// lanes write their deltas into a row image, and wave v stores the delta rows of its two lines during the next step.  LDS: ONE
+// delta image for the MFMA (a second barrier per step separates its readers from its writers) + two slots of activation / dH
+// rows + a ring of three c rows + the delta-row image = 157 KB at NO = 100.  Measured (scripts/dbg/bwd_rows.sh): 256 lines 0.603 ->
+// 0.488 ms, 1024 lines 0.676 -> 0.549, 2048 lines 0.794 -> 0.691 (= 4.75 TB/s, 0.59 of the HBM peak).
+template <int NO, int NT>
+struct MfmaBwdRowsGeom {
+  using G0 = MfmaBwdGeom<NO, NT>;
+  static constexpr int GROW = (4 * NO * 4 + 1023) / 1024 * 1024 + 16;   // activation row: whole 1 KB instructions + pad
+  static constexpr int CROW = (NO * 4 + 255) / 256 * 256 + 16;          // c / dH row: whole 256-byte instructions + pad
+  static constexpr int DROW = 4 * NO * 4 + 16;                          // delta row image
+  static constexpr int NG = GROW / 1024, NC = CROW / 256;               // instructions per row
+  static constexpr int BIMG = G0::BUF;
+  static constexpr int GS_OFF = BIMG, GS_SLOT = 16 * GROW;
+  static constexpr int CR_OFF = GS_OFF + 2 * GS_SLOT, CR_ENT = 16 * CROW;
+  static constexpr int DH_OFF = CR_OFF + 3 * CR_ENT;
+  static constexpr int DI_OFF = DH_OFF + 2 * CR_ENT;
+  static constexpr int DUMP_OFF = DI_OFF + 16 * DROW;
+  static constexpr int SMEM = DUMP_OFF + 64;
+  static_assert(SMEM <= 160 * 1024, "LDS");
+};
+
+template <int NO, int NT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_bwd_mfma_rows_kernel(LstmMfmaBwdArgs a) {
+  using Gm = MfmaBwdGeom<NO, NT>;
+  using Gr = MfmaBwdRowsGeom<NO, NT>;
+  constexpr int KB = Gm::KB, NTL = Gm::NTL, PART = Gm::PART;
+  char* const smem = dyn_smem<char>();
+  const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
+  const int n = lane & 15, cs = lane >> 4;
+  const int dir = blockIdx.y, grp = blockIdx.x;
+  const int nd = a.ndir;
+  const int gl = grp * 16 + n;
+  const int b = gl < a.bs ? (a.order ? a.order[gl] : gl) : -1;
+  const int off = b >= 0 ? a.line_off[b] : 0;
+  const int T = b >= 0 ? a.line_off[b + 1] - off : 0;
+  int tmx = T;
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) { const int o = __shfl_xor(tmx, m, 64); tmx = o > tmx ? o : tmx; }
+  const int Tmax = wave_uniform(tmx);
+  int* const progw = a.prog_off >= 0 && b >= 0 && tid < 16 ? reinterpret_cast<int*>(a.D + a.prog_off) + ((size_t)dir * a.bs + b) * PROG_STRIDE : nullptr;
+  if (Tmax <= 0) {
+    if (progw) store_i32_wt(progw, a.prog_base);
+    return;
+  }
+  // the two lines whose rows this wave moves (scalars)
+  int offj[2], Tj[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) { offj[j] = __builtin_amdgcn_readlane(off, 2 * w + j); Tj[j] = __builtin_amdgcn_readlane(T, 2 * w + j); }
+
+  const bool act = w < NTL;
+  const int c0 = 16 * w + cs;                               // this lane's cells c0 + 4 i (see lstm_bwd_mfma_kernel)
+  u16x8 A[KB][NT];
+#pragma unroll
+  for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const unsigned short* wp = a.W + dir * Gm::W_HALFS_PER_DIR + ((long long)(((act ? w : 0) * KB + kb) * NT + t)) * 512 + lane * 8;
+      A[kb][t] = __builtin_bit_cast(u16x8, *reinterpret_cast<const u32x4*>(wp));
+    }
+#pragma unroll
+  for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+    for (int t = 0; t < NT; t++) asm volatile("" : "+a"(A[kb][t]));
+  for (int i = tid * 16; i < Gr::BIMG; i += 512 * 16) *reinterpret_cast<u32x4*>(smem + i) = (u32x4){0u, 0u, 0u, 0u};
+
+  const unsigned gstr = (unsigned)nd * 4 * NO * 4, cstr = (unsigned)nd * NO * 4;
+  const BufF32 gbuf = make_buf(a.G, (size_t)a.N * gstr);
+  const BufF32 dbuf = make_buf(a.D, (size_t)a.N * gstr);
+  const BufF32 cbuf = make_buf(a.C, (size_t)a.N * cstr);
+  const BufF32 hbuf = make_buf(a.dH, (size_t)a.N * cstr);
+  const unsigned dbg_st = (a.dbg & 4) ? 0x80000000u : 0u, dbg_rq = (a.dbg & 8) ? 0x80000000u : 0u;
+  // row requests / row stores of line 2 w + j at own step s: lane l = bytes 16 l (activations, deltas) / 4 l (c, dH) of a piece
+  auto rtok = [&](int j, int s) -> unsigned { return (unsigned)(offj[j] + (dir == 0 ? s : Tj[j] - 1 - s)); };
+  auto rbad = [&](int j, int s) -> unsigned { return (unsigned)s >= (unsigned)Tj[j] ? 0x80000000u : 0u; };
+  // request_gd: activations + dH of own step sg into slot `slot`; request_c: cell states of own step sc into ring entry `cent`.  c_s is needed at step s
+  // AND, as c_{s-1}, one step EARLIER (step s + 1): it is requested three steps ahead, the rest two -- whatever a step reads was
+  // requested at least two steps before it and waited for (wait_vmcnt below) one barrier before it
+  auto request_gd = [&](int sg, int slot) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int row = 2 * w + j;
+      const unsigned o = rbad(j, sg) | dbg_rq, tk = rtok(j, sg);
+#pragma unroll
+      for (int q = 0; q < Gr::NG; q++) {
+        const unsigned bo = 1024u * q + 16u * lane;
+        lds_dma16(gbuf, bo < 4u * NO * 4 ? (tk * gstr + (unsigned)dir * 4 * NO * 4 + bo) | o : BUF_OOB,
+                  smem + Gr::GS_OFF + slot * Gr::GS_SLOT + row * Gr::GROW + 1024 * q);
+      }
+#pragma unroll
+      for (int q = 0; q < Gr::NC; q++) {
+        const unsigned bo = 256u * q + 4u * lane;
+        lds_dma4(hbuf, bo < 4u * NO ? (tk * cstr + (unsigned)dir * NO * 4 + bo) | o : BUF_OOB,
+                 smem + Gr::DH_OFF + slot * Gr::CR_ENT + row * Gr::CROW + 256 * q);
+      }
+    }
+  };
+  auto request_c = [&](int sc, int cent) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int row = 2 * w + j;
+      const unsigned oc = rbad(j, sc) | dbg_rq, tkc = rtok(j, sc);
+#pragma unroll
+      for (int q = 0; q < Gr::NC; q++) {
+        const unsigned bo = 256u * q + 4u * lane;
+        lds_dma4(cbuf, bo < 4u * NO ? (tkc * cstr + (unsigned)dir * NO * 4 + bo) | oc : BUF_OOB,
+                 smem + Gr::CR_OFF + cent * Gr::CR_ENT + row * Gr::CROW + 256 * q);
+      }
+    }
+  };
+  constexpr int NREQ = 2 * (Gr::NG + 2 * Gr::NC);          // memory operations of one request() per wave
+  constexpr int NST = 2 * Gr::NG;                          // ... of one store_rows()
+  auto store_rows = [&](int s) {                           // the delta rows of own step s (complete in the image)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int row = 2 * w + j;
+      const unsigned o = rbad(j, s) | dbg_st, tk = rtok(j, s);
+#pragma unroll
+      for (int q = 0; q < Gr::NG; q++) {
+        const unsigned bo = 1024u * q + 16u * lane;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(smem + Gr::DI_OFF + row * Gr::DROW + (bo < 4u * NO * 4 ? bo : 0u));
+        buf_store4(dbuf, bo < 4u * NO * 4 ? (tk * gstr + (unsigned)dir * 4 * NO * 4 + bo) | o : BUF_OOB, v);
+      }
+    }
+  };
+  const unsigned bfo = (unsigned)(cs * 256 + n * 16);
+  const unsigned iwo = (unsigned)(((c0 >> 1)) * 256 + n * 16 + (c0 & 1) * 8);   // + 512 i
+  const unsigned gro = (unsigned)(n * Gr::GROW + c0 * 16), cro = (unsigned)(n * Gr::CROW + c0 * 4), dwo = (unsigned)(n * Gr::DROW + c0 * 16);   // + 64 i / 16 i / 64 i
+
+  // prologue: activations / dH of the first two steps, c of the first three
+  request_gd(Tmax - 1, 0);
+  request_gd(Tmax - 2, 1);
+#pragma unroll
+  for (int k = 0; k < 3; k++) request_c(Tmax - 1 - k, k);
+  float dcc[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();   // (waits vmcnt(0))
+
+  // iteration it = Tmax - 1 - s, K = it mod 6: rows in slot K & 1, c_s = ring entry K % 3, c_{s-1} = entry (K + 1) % 3
+  auto step = [&](const int s, auto k_tag) __attribute__((always_inline)) {
+    constexpr int K = decltype(k_tag)::value;
+    lds_barrier();                                          // rows of this step (and its c_{s-1}) have landed; delta(s+1) is in the images
+    if (s + 1 < Tmax) store_rows(s + 1);                    // (wave-uniform; the first step has no predecessor)
+    f32x4 f_gi, f_gf, f_go, f_ci, gthv, gfv, dhv;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    if (act) {
+#pragma unroll
+      for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) asm volatile("" : "+a"(A[kb][t]));
+      const char* const gs = smem + Gr::GS_OFF + (K & 1) * Gr::GS_SLOT + gro;
+      const char* const hs = smem + Gr::DH_OFF + (K & 1) * Gr::CR_ENT + cro;
+      const char* const c0s = smem + Gr::CR_OFF + (K % 3) * Gr::CR_ENT + cro;
+      const char* const c1s = smem + Gr::CR_OFF + ((K + 1) % 3) * Gr::CR_ENT + cro;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const bool ok = c0 + 4 * i < NO;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gs + (ok ? 64 * i : 0));
+        const float cci = *reinterpret_cast<const float*>(c0s + (ok ? 16 * i : 0));
+        const float cm1 = *reinterpret_cast<const float*>(c1s + (ok ? 16 * i : 0));
+        dhv[i] = *reinterpret_cast<const float*>(hs + (ok ? 16 * i : 0));
+        const float gi = g[0], gf = g[1], go = g[2], ci = g[3];
+        const float th = tanh_fast(cci);
+        gthv[i] = go * fmaf(-th, th, 1.0f);
+        gfv[i] = gf;
+        f_gi[i] = ci * fmaf(-gi, gi, gi);
+        f_gf[i] = cm1 * fmaf(-gf, gf, gf);
+        f_go[i] = th * fmaf(-go, go, go);
+        f_ci[i] = gi * fmaf(-ci, ci, 1.0f);
+      }
+      if (!(a.dbg & 1))
+#pragma unroll
+      for (int kb = 0; kb < KB; kb++) {
+        u16x8 B[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) B[t] = *reinterpret_cast<const u16x8*>(smem + t * PART + bfo + 1024 * kb);
+#pragma unroll
+        for (int wt = NT - 1; wt >= 0; wt--)
+#pragma unroll
+          for (int ta = 0; ta <= wt; ta++) {
+            if (kb & 1) acc1 = mfma16x16x32_bf16(A[kb][ta], B[wt - ta], acc1);
+            else acc0 = mfma16x16x32_bf16(A[kb][ta], B[wt - ta], acc0);
+          }
+      }
+    }
+    const f32x4 acc = acc0 + acc1;
+    lds_barrier();                                          // every wave has read delta(s+1), its rows and its operands: all may be overwritten
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const bool ok = c0 + 4 * i < NO;
+        const float dh = dhv[i] + acc[i];
+        const float dc = fmaf(gthv[i], dh, dcc[i]);
+        dcc[i] = dc * gfv[i];
+        float e[4] = {dc * f_gi[i], dc * f_gf[i], dh * f_go[i], dc * f_ci[i]};
+        *reinterpret_cast<f32x4*>(ok ? smem + Gr::DI_OFF + dwo + 64 * i : smem + Gr::DUMP_OFF) = (f32x4){e[0], e[1], e[2], e[3]};
+        const bool oki = ok && !(a.dbg & 2);
+        char* const dst = oki ? smem + iwo + 512 * i : smem + Gr::DUMP_OFF + 16;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          u32x2 h;
+          h[0] = bf16_pack2(e[0], e[1]);
+          h[1] = bf16_pack2(e[2], e[3]);
+          *reinterpret_cast<u32x2*>(dst + (oki ? t * PART : 0)) = h;
+          if (t + 1 < NT) {
+            e[0] -= __builtin_bit_cast(float, h[0] << 16); e[1] -= __builtin_bit_cast(float, h[0] & 0xffff0000u);
+            e[2] -= __builtin_bit_cast(float, h[1] << 16); e[3] -= __builtin_bit_cast(float, h[1] & 0xffff0000u);
+          }
+        }
+      }
+    }
+    // the requests of the previous step (operands of step s - 1) must be in LDS before the next barrier; only this step's row
+    // stores were issued behind them
+    wait_vmcnt<NST>();
+    request_gd(s - 2, K & 1);
+    request_c(s - 3, K % 3);
+  };
+  {
+    int s = Tmax - 1;
+    auto six = [&](const int s0) __attribute__((always_inline)) {
+      step(s0, std::integral_constant<int, 0>{});
+      step(s0 - 1, std::integral_constant<int, 1>{});
+      step(s0 - 2, std::integral_constant<int, 2>{});
+      step(s0 - 3, std::integral_constant<int, 3>{});
+      step(s0 - 4, std::integral_constant<int, 4>{});
+      step(s0 - 5, std::integral_constant<int, 5>{});
+    };
+    for (; s >= 5; s -= 6) six(s);
+    if (s >= 0) step(s, std::integral_constant<int, 0>{});
+    if (s >= 1) step(s - 1, std::integral_constant<int, 1>{});
+    if (s >= 2) step(s - 2, std::integral_constant<int, 2>{});
+    if (s >= 3) step(s - 3, std::integral_constant<int, 3>{});
+    if (s >= 4) step(s - 4, std::integral_constant<int, 4>{});
+  }
+  lds_barrier();
+  store_rows(0);
+  (void)NREQ;
+  if (a.prog_off >= 0) {
+    drain_vmem();
+    __syncthreads();
+    if (progw) store_i32_wt(progw, a.prog_base + T);
+  }
+}
+
 }  // namespace clstm
 #endif  // CLSTM_HIP_EMU

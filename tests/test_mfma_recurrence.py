@@ -44,12 +44,15 @@ def test_mfma_recurrence_vs_oracle(backend, ora32, nh, T):
     assert nh == 128 or _count(backend, 17) > before_b, "the MFMA backward recurrence did not run"   # (128 cells: forward only)
 
 
-@pytest.mark.parametrize("T", [[40, 23, 1, 70], [33] * 17])
-def test_mfma_backward_alone(backend, ora32, T):
+@pytest.mark.parametrize("rows", [1, 0])
+@pytest.mark.parametrize("T", [[40, 23, 1, 70], [33] * 17, [7, 3, 2, 1, 5, 6, 4]])
+def test_mfma_backward_alone(backend, ora32, T, rows):
     """the batched backward recurrence (lstm_mfma_bwd.h) behind the per-line forward kernel: its deltas, the weight gradient formed
-    from them by the separate-launch weight-gradient items, the update"""
+    from them by the separate-launch weight-gradient items, the update -- in both forms of its memory side (rows = 1, the default:
+    whole rows through LDS, lstm_bwd_mfma_rows_kernel; rows = 0: 64-byte pieces per lane group, lstm_bwd_mfma_kernel)"""
     set_opt(backend, "fwd_mfma", 0)
     set_opt(backend, "bwd_mfma", 2)
+    set_opt(backend, "bwd_mfma_rows", rows)
     before = _count(backend, 17)
     run_case(backend, ora32, 48, 100, 83, T, scale=10.0)
     assert _count(backend, 17) > before
