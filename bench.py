@@ -799,7 +799,7 @@ def main():
         del wsat
 
     # the same net at 2048 lines per GPU (default single-GPU line only): the narrow recurrences batched over 16 lines per workgroup
-    # on the matrix cores (lstm_mfma.h from 640 lines, lstm_mfma_bwd.h from 1024) -- north_star's "gate GEMMs batched across a
+    # on the matrix cores (lstm_mfma.h and lstm_mfma_bwd.h, both from 640 lines) -- north_star's "gate GEMMs batched across a
     # minibatch of text lines with MFMA"; 2048 lines = 256 workgroups of 16 lines x direction = one per CU.  The per-line kernels'
     # ceiling is ~359k lines/s (round 5, profiles/r05_bench_mb1024.json).  Here the recurrences are HBM-bound: their roofline
     # entries price the bytes the kernels must move (forward: x in, six saved values out = 28 B per cell-step, SURVEY 8(d)'s
