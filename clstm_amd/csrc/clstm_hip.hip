@@ -25,6 +25,7 @@
 #include "lstm_wide.h"
 #include "lstm_mfma.h"
 #include "lstm_mfma_bwd.h"
+#include "lstm_mfma_bwd_dw.h"
 #include "ops.h"
 
 #include <algorithm>

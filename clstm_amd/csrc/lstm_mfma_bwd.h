@@ -326,15 +326,17 @@ struct MfmaBwdRowsGeom {
   static_assert(SMEM <= 160 * 1024, "LDS");
 };
 
-template <int NO, int NT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_bwd_mfma_rows_kernel(LstmMfmaBwdArgs a) {
+// REPORT: the kernel is one ROLE of a launch whose other workgroups consume the deltas while it runs (lstm_bwd_mfma_dw_kernel
+// below): delta rows are stored write-through, and every wave publishes, per step, how many iterations of its two lines are
+// complete in memory (the progress words gemm_dw.h's monitor reads)
+template <int NO, int NT, bool REPORT>
+DEVFN void lstm_bwd_mfma_rows_body(const LstmMfmaBwdArgs& a, const int grp, const int dir) {
   using Gm = MfmaBwdGeom<NO, NT>;
   using Gr = MfmaBwdRowsGeom<NO, NT>;
   constexpr int KB = Gm::KB, NTL = Gm::NTL, PART = Gm::PART;
   char* const smem = dyn_smem<char>();
   const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
   const int n = lane & 15, cs = lane >> 4;
-  const int dir = blockIdx.y, grp = blockIdx.x;
   const int nd = a.ndir;
   const int gl = grp * 16 + n;
   const int b = gl < a.bs ? (a.order ? a.order[gl] : gl) : -1;
@@ -353,6 +355,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int offj[2], Tj[2];
 #pragma unroll
   for (int j = 0; j < 2; j++) { offj[j] = __builtin_amdgcn_readlane(off, 2 * w + j); Tj[j] = __builtin_amdgcn_readlane(T, 2 * w + j); }
+  // REPORT: lane j < 2 of the wave owns the progress word of line 2 w + j
+  const int rb = __shfl(b, 2 * w + (lane & 1), 64), rT = __shfl(T, 2 * w + (lane & 1), 64);
+  int* const rword = REPORT && a.prog_off >= 0 && lane < 2 && rb >= 0 ? reinterpret_cast<int*>(a.D + a.prog_off) + ((size_t)dir * a.bs + rb) * PROG_STRIDE : nullptr;
 
   const bool act = w < NTL;
   const int c0 = 16 * w + cs;                               // this lane's cells c0 + 4 i (see lstm_bwd_mfma_kernel)
@@ -425,7 +430,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int q = 0; q < Gr::NG; q++) {
         const unsigned bo = 1024u * q + 16u * lane;
         const f32x4 v = *reinterpret_cast<const f32x4*>(smem + Gr::DI_OFF + row * Gr::DROW + (bo < 4u * NO * 4 ? bo : 0u));
-        buf_store4(dbuf, bo < 4u * NO * 4 ? (tk * gstr + (unsigned)dir * 4 * NO * 4 + bo) | o : BUF_OOB, v);
+        const unsigned so = bo < 4u * NO * 4 ? (tk * gstr + (unsigned)dir * 4 * NO * 4 + bo) | o : BUF_OOB;
+        if constexpr (REPORT) buf_store4_wt(dbuf, so, v); else buf_store4(dbuf, so, v);
       }
     }
   };
@@ -517,6 +523,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the requests of the previous step (operands of step s - 1) must be in LDS before the next barrier; only this step's row
     // stores were issued behind them
     wait_vmcnt<NST>();
+    // REPORT: everything this wave issued before this step's row stores has completed -- the delta rows of own steps >= s + 2
+    // of its two lines are in memory: T - (s + 2) iterations (a line not yet started: 0)
+    if constexpr (REPORT) {
+      if (rword) { const int it = rT - (s + 2); store_i32_wt(rword, a.prog_base + (it < 0 ? 0 : it)); }
+    }
     request_gd(s - 2, K & 1);
     request_c(s - 3, K % 3);
   };
@@ -545,6 +556,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     if (progw) store_i32_wt(progw, a.prog_base + T);
   }
+}
+template <int NO, int NT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_bwd_mfma_rows_kernel(LstmMfmaBwdArgs a) {
+  lstm_bwd_mfma_rows_body<NO, NT, false>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 }  // namespace clstm

@@ -77,6 +77,20 @@ def test_mfma_randomised_geometries(backend, ora32, seed):
         assert _count(backend, 17) > before
 
 
+@pytest.mark.parametrize("T", [[40, 23, 1, 70], [33] * 17, [90, 64, 77, 12, 5, 81, 33, 90, 2, 64, 18, 71, 90, 45, 9, 60, 27, 88, 90, 3]])
+def test_mfma_backward_and_weight_gradient_items_as_one_launch(backend, ora32, T):
+    """lstm_mfma_bwd_dw.h: the batched backward recurrence in REPORT mode (write-through delta rows, per-step progress words) and the
+    weight-gradient items of gemm_dw.h as two workgroup roles of ONE launch -- forced onto small minibatches (overlap mode 2):
+    the deltas, the gradient the items form from them WHILE the recurrence runs, the update; no wait ran into its watchdog"""
+    set_opt(backend, "fwd_mfma", 2)
+    set_opt(backend, "bwd_mfma", 2)
+    set_opt(backend, "bwd_mfma_fused", 2)
+    before = _count(backend, 18)
+    net, _ = run_case(backend, ora32, 48, 100, 83, T, scale=10.0, overlap=2)
+    assert _count(backend, 18) > before, "the fused launch did not run"
+    assert net.overlap_stats()[1] == 0
+
+
 def test_mfma_recurrence_large_weights(backend, ora32):
     """init x 60: saturated gates and |R| of order 1 -- the power-of-two scaling of the f16 split must follow the weights"""
     set_opt(backend, "fwd_mfma", 2)
