@@ -91,6 +91,20 @@ def test_mfma_backward_and_weight_gradient_items_as_one_launch(backend, ora32, T
     assert net.overlap_stats()[1] == 0
 
 
+@pytest.mark.parametrize("bs,T", [(640, 24), (1024, 12)])
+def test_mfma_default_rule_at_chip_filling_minibatches(backend, ora32, bs, T):
+    """NO experiment option: what a user's 640- / 1024-line minibatch takes by the library's own rule -- the batched forward
+    recurrence, the batched backward recurrence (640 lines: in ONE launch with the weight-gradient items; 1024: items behind it)
+    -- against the oracle: every activation, gate delta, the gradient, the update.  Lines of 64..T frames so that the overlap
+    rule (N >= 2048 frames, longest line >= 64) holds."""
+    rng = np.random.default_rng(bs)
+    Ts = [64] * 8 + [int(t) for t in rng.integers(1, T + 1, bs - 8)]
+    before_f, before_b, before_1 = _count(backend, 16), _count(backend, 17), _count(backend, 18)
+    run_case(backend, ora32, 48, 100, 83, Ts, scale=10.0, seed=bs)
+    assert _count(backend, 16) > before_f and _count(backend, 17) > before_b
+    assert (_count(backend, 18) > before_1) == (bs < 900)
+
+
 def test_mfma_recurrence_large_weights(backend, ora32):
     """init x 60: saturated gates and |R| of order 1 -- the power-of-two scaling of the f16 split must follow the weights"""
     set_opt(backend, "fwd_mfma", 2)
