@@ -58,7 +58,7 @@ def test_mfma_backward_alone(backend, ora32, T, rows):
     assert _count(backend, 17) > before
 
 
-@pytest.mark.parametrize("seed", [3, 4, 5, 6])
+@pytest.mark.parametrize("seed", [3, 4, 5, 6, 7, 8])
 def test_mfma_randomised_geometries(backend, ora32, seed):
     """random minibatches through both batched kernels: 1..40 lines of 1..90 frames (groups of 16 with lines that drop out of the
     lock-step at different steps, groups whose longest line has 1-3 frames: shorter than the kernels' peeled four steps and their
@@ -70,11 +70,15 @@ def test_mfma_randomised_geometries(backend, ora32, seed):
         if rng.random() < 0.5:
             T[:min(bs, 16)] = [int(t) for t in rng.integers(1, 4, min(bs, 16))]     # a whole group of tiny lines (longest first: the LAST group)
         nh = int(rng.choice([64, 100]))
+        fused = nh == 100 and rng.random() < 0.5     # (the one-launch form needs the in-launch items: 100 cells)
         set_opt(backend, "fwd_mfma", 2)
         set_opt(backend, "bwd_mfma", 2)
-        before = _count(backend, 17)
-        run_case(backend, ora32, 48, nh, 83, T, scale=10.0, seed=int(rng.integers(1 << 30)))
+        set_opt(backend, "bwd_mfma_fused", 2 if fused else 0)
+        before, before_1 = _count(backend, 17), _count(backend, 18)
+        net, _ = run_case(backend, ora32, 48, nh, 83, T, scale=10.0, seed=int(rng.integers(1 << 30)), overlap=2 if fused else None)
         assert _count(backend, 17) > before
+        if fused:
+            assert _count(backend, 18) > before_1 and net.overlap_stats()[1] == 0
 
 
 @pytest.mark.parametrize("T", [[40, 23, 1, 70], [33] * 17, [90, 64, 77, 12, 5, 81, 33, 90, 2, 64, 18, 71, 90, 45, 9, 60, 27, 88, 90, 3]])
