@@ -820,6 +820,16 @@ def main():
                 rl[name] = {"kernel": "lstm_fwd_mfma_kernel<100, 48>" if name == "lstm_fwd" else "lstm_bwd_mfma_kernel<100, 2>", "bound": "hbm",
                             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                             "algorithmic_bytes": int(bpc * cell_steps), "bytes_per_cell_step": bpc, "avg_launch_ms": kl[name]["ms_per_step"], "traffic": None}
+        # ... and their gate products against the matrix peak (north_star: "MFMA utilisation for the batched gate GEMM"): algorithmic
+        # flops = 2 x 4 no x (no + ni + 1) per line, direction and step forward (R.h + W_x.x + b as ONE product), 2 x no x 4 no
+        # backward (R^T.delta); the kernels issue three 16-bit MFMAs per product (split operands), so the pipe is ~3 x as busy
+        # (profiles/r06_mfma_busy_mb2048.txt: SQ_VALU_MFMA_BUSY_CYCLES)
+        no_, ni_ = cfg["nh"][0], cfg["ni"]
+        for name, fl in (("lstm_fwd", 2.0 * 4 * no_ * (no_ + ni_ + 1)), ("lstm_bwd", 2.0 * no_ * 4 * no_)):
+            if name in rl:
+                tf = fl * 2.0 * ml_["frames_per_step"] / (kl[name]["ms_per_step"] * 1e-3) / 1e12
+                rl[name]["recurrent_matvec"] = {"achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tf / BF16_MFMA_PEAK_TFS, 4),
+                                                "note": "algorithmic flops of the step's gate product; x3 MFMA issue (hi/lo split operands)"}
         large = {"value": round(LB * sl_ / ml_["dt"], 2), "unit": "lines/s", "ms_per_step": round(ml_["dt"] / sl_ * 1e3, 4), "steps": sl_,
                  "repeats": len(ml_["blocks"]), "config": {"workload": "the headline net at minibatch = %d lines per GPU (batched-MFMA recurrences, one 16-line workgroup per CU)" % LB,
                                                            "minibatch_per_gpu": LB},

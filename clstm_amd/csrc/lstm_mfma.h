@@ -90,21 +90,25 @@ __host__ __device__ inline int mfma_cell(int nt, int tile, int cs) {
   return 4 * tw * v + (i < 2 * npw ? 8 * (i >> 1) + 2 * cs + (i & 1) : 8 * npw + cs);
 }
 
-// ---- packing: one workgroup per direction finds max |[R | W_x | b]|, picks the scale and writes the fragments -------------
+// ---- packing: find max |[R | W_x | b]| of a direction, pick the scale, write the fragments --------------------------------
 // PackDesc (ops.h) as the other packs: W_q(cell, col) = v[p_off[dir][q] + cell + no col], col 0 bias, 1 + j input j,
 // 1 + ni + k cell k (tensor.h:263-264); k of the product: [cells | inputs | bias]
 struct MfmaPackArgs { const float* v; long long p_off[2][4]; int ni, no, nt, kb; unsigned short* W; float* inv_scale; };
 DEVFN int mfma_pack_col(int k, int no, int ni) { return k < no ? 1 + ni + k : (k < no + ni ? 1 + (k - no) : (k == no + ni ? 0 : -1)); }
+// (grid (blocks, directions): EVERY block finds the direction's max itself -- 60 K floats out of L2 -- and packs its share of the
+//  fragments; as ONE workgroup per direction the kernel took 128 us of every training step, profiles/r06_mfma_busy_mb2048.txt)
 __global__ __launch_bounds__(1024) void k_pack_mfma(MfmaPackArgs p) {
   __shared__ float red[16];
   __shared__ int e_sh;
-  const int dir = blockIdx.x, tid = threadIdx.x;
+  const int dir = blockIdx.y, tid = threadIdx.x;
   const int no = p.no, ncol = 1 + p.ni + no;
   float mx = 0.0f;
-  for (int i = tid; i < 4 * no * ncol; i += 1024) {
-    const int q = i / (no * ncol), r = i % (no * ncol);
-    const float x = fabsf(p.v[p.p_off[dir][q] + r]);
-    mx = x > mx ? x : mx;   // (NaN compares false: a non-finite parameter leaves the scale alone and surfaces in the outputs)
+  for (int q = 0; q < 4; q++) {
+    const float* vq = p.v + p.p_off[dir][q];
+    for (int r = tid; r < no * ncol; r += 1024) {
+      const float x = fabsf(vq[r]);
+      mx = x > mx ? x : mx;   // (NaN compares false: a non-finite parameter leaves the scale alone and surfaces in the outputs)
+    }
   }
   mx = wave_max(mx);
   if ((tid & 63) == 0) red[tid >> 6] = mx;
@@ -115,12 +119,12 @@ __global__ __launch_bounds__(1024) void k_pack_mfma(MfmaPackArgs p) {
     int e = 0;
     if (m > 0.0f && f32_finite(m)) { e = 13 - ilogbf(m); e = e > 40 ? 40 : (e < -40 ? -40 : e); }
     e_sh = e;
-    p.inv_scale[dir] = ldexpf(1.0f, -(e + MF_HS));
+    if (blockIdx.x == 0) p.inv_scale[dir] = ldexpf(1.0f, -(e + MF_HS));
   }
   __syncthreads();
   const float sc = ldexpf(1.0f, e_sh);
   const long long per_dir = (long long)p.nt * p.kb * 2 * 64 * 8;
-  for (long long i = tid; i < (long long)p.nt * p.kb * 64 * 8; i += 1024) {
+  for (long long i = (long long)blockIdx.x * 1024 + tid; i < (long long)p.nt * p.kb * 64 * 8; i += (long long)gridDim.x * 1024) {
     const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
     const int kb = (int)((i >> 9) % p.kb), tile = (int)((i >> 9) / p.kb);
     const int m = lane & 15, cs = m >> 2, q = m & 3;
