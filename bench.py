@@ -817,7 +817,7 @@ def main():
         for name, bpc in (("lstm_fwd", 28.0), ("lstm_bwd", 40.0)):
             if name in kl:
                 gbs = bpc * cell_steps / (kl[name]["ms_per_step"] * 1e-3) / 1e9
-                rl[name] = {"kernel": "lstm_fwd_mfma_kernel<100, 48>" if name == "lstm_fwd" else "lstm_bwd_mfma_kernel<100, 2>", "bound": "hbm",
+                rl[name] = {"kernel": "lstm_fwd_mfma_kernel<100, 48> (+ k_pack_mfma)" if name == "lstm_fwd" else "lstm_bwd_mfma_rows_kernel<100, 2>", "bound": "hbm",
                             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                             "algorithmic_bytes": int(bpc * cell_steps), "bytes_per_cell_step": bpc, "avg_launch_ms": kl[name]["ms_per_step"], "traffic": None}
         # ... and their gate products against the matrix peak (north_star: "MFMA utilisation for the batched gate GEMM"): algorithmic
