@@ -46,7 +46,10 @@ if ROOT not in sys.path:
 
 # b1: BASELINE.json configs[1..3] (uw3 shape); b2: configs[4] (2 x BiLSTM(512), H=64, T~400, 100 classes, 50 labels)
 CONFIGS = {"b1": dict(ni=48, nh=[100], nc=83, T=200, L=25),
-           "b2": dict(ni=64, nh=[512, 512], nc=100, T=400, L=50)}
+           # lr: at the 1e-4 of b1 the f32 trajectory of this net on the synthetic (unlearnable) minibatches reaches a non-finite
+           # gradient at training step 43 (exploding gradient through 2 x 400 steps: |g| 8e19 at step 39, scripts/dbg/b2_divergence.py),
+           # where the reference aborts (clstm.cc:630-649) and the library skips every later update -- Workload.verify refuses that
+           "b2": dict(ni=64, nh=[512, 512], nc=100, T=400, L=50, lr=1e-6)}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 BF16_MFMA_PEAK_TFS = 2500.0    # dense bf16 MFMA
@@ -231,12 +234,14 @@ class Workload:
             Ts_list = [[int(t) for t in (rng.integers(150, 251, minibatch) if ragged else [T] * minibatch)] for _ in range(4)]
             self.params_h, batches, self.weights_info = trained_weights_and_lines(lib, cfg, rng, Ts_list)
         n = self.params_h.size
+        self.params0 = self.params_h.copy()     # (on a CPU device the tensor below aliases params_h)
         self.params = torch.from_numpy(self.params_h).to(dev)
         self.derivs = torch.zeros(n, device=dev)
         self.grads = torch.zeros(n, device=dev)
         self.net = Network(cfg["ni"], nh, cfg["nc"], lib=lib, params=self.params, derivs=self.derivs, grads=self.grads)
         self.net.params_changed()
-        self.net.setLearningRate(1e-4, 0.9)
+        self.lr = cfg.get("lr", 1e-4)
+        self.net.setLearningRate(self.lr, 0.9)
         if precision:
             self.net.set_gemm_precision(precision)
         if strict_f32:
@@ -261,6 +266,17 @@ class Workload:
 
     def frames(self, i):
         return sum(self.pool[i % len(self.pool)][0])
+
+    def verify(self):
+        """The timed steps did their work.  A non-finite logit or gradient, or a fused launch that gave up, makes the library
+        skip that update and every later one (sticky device error words, csrc/runtime.inc:check_device_errors) -- the steps
+        would still be timed, and faster.  Reading the parameters back raises such an error; they must be finite and must
+        have moved."""
+        p = self.net.get_params()
+        moved = float(np.abs(p - self.params0).max())
+        if not np.isfinite(p).all() or not moved > 0.0:
+            raise RuntimeError("bench: the timed steps did not update the parameters (finite: %s, largest change %g)" % (bool(np.isfinite(p).all()), moved))
+        return {"device_errors": "none", "params_finite": True, "max_param_change": moved}
 
 
 def timed_blocks(w, steps, warmup, fence, reduce_max, min_timed_s=None):
@@ -636,7 +652,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    def measure(w, steps, warmup, profile_steps, unfused_pass=False, min_timed_s=None):
+    leg_validity = {}
+
+    def measure(w, steps, warmup, profile_steps, unfused_pass=False, min_timed_s=None, name="main"):
         blocks, nxt = timed_blocks(w, steps, warmup, fence, reduce_max, min_timed_s)
         dt = float(np.median(blocks))
         # host-side cost of issuing a step (diagnostic: is the loop host-bound?): a short burst on an idle stream, few
@@ -659,7 +677,14 @@ def main():
                 w.net.set_overlap(1)
             if rank != 0:
                 kern, kern_unfused = {}, {}
-        return {"dt": dt, "blocks": blocks, "enqueue": t_enq, "kern": kern, "kern_unfused": kern_unfused, "frames_per_step": fps}
+        try:                    # (every leg: a step whose update was skipped is not a step)
+            validity = w.verify()
+        except Exception as e:  # the headline workload fails loudly; a leg reports it and leaves the line standing
+            if name == "main":
+                raise
+            validity = {"error": str(e)[:400]}
+        leg_validity[name] = validity
+        return {"dt": dt, "blocks": blocks, "enqueue": t_enq, "kern": kern, "kern_unfused": kern_unfused, "frames_per_step": fps, "validity": validity}
 
     precision = 2 if args.bf16 else 1 if args.bf16_gemm else 0
     w = Workload(lib, cfg, args.minibatch, args.T, args.ragged, precision, dev, rank, comm=comm, dist=dist, host_inputs=args.host_inputs,
@@ -731,7 +756,7 @@ def main():
     trained = None
     if rank == 0 and world == 1 and default_line and args.weights == "init" and not args.no_secondary:
         wt = Workload(lib, cfg, args.minibatch, args.T, args.ragged, 0, dev, rank, weights="trained")
-        mt_ = measure(wt, args.steps, 5, 0, min_timed_s=0.5)
+        mt_ = measure(wt, args.steps, 5, 0, min_timed_s=0.5, name="trained_weights")
         trained = dict(wt.weights_info, value=round(args.minibatch * args.steps / mt_["dt"], 2), unit="lines/s",
                        ms_per_step=round(mt_["dt"] / args.steps * 1e3, 4), repeats=len(mt_["blocks"]),
                        parity="tests/test_gpu_e2e.py::test_full_bench_shape_trained_weights_real_line_crops (same recipe on the oracle)")
@@ -746,7 +771,7 @@ def main():
         lib.call("clstm_debug_set_option", b"ctc_float", 1)
         try:
             wc = Workload(lib, cfg, args.minibatch, args.T, args.ragged, 0, dev, rank)
-            mc_ = measure(wc, args.steps, 5, 20, min_timed_s=0.5)
+            mc_ = measure(wc, args.steps, 5, 20, min_timed_s=0.5, name="ctc_float_logadd")
             ctc_float = {"value": round(args.minibatch * args.steps / mc_["dt"], 2), "unit": "lines/s", "ms_per_step": round(mc_["dt"] / args.steps * 1e3, 4),
                          "repeats": len(mc_["blocks"]), "ctc_align_ms": mc_["kern"].get("ctc_align", {}).get("ms_per_step"),
                          "option": "CLSTM_DEBUG=ctc_float=1 (float-only log_add in the CTC lattice recursion; not the default)",
@@ -763,7 +788,7 @@ def main():
     strict = None
     if rank == 0 and world == 1 and default_line and not args.no_secondary:
         ws = Workload(lib, cfg, args.minibatch, args.T, args.ragged, 0, dev, rank, strict_f32=True)
-        ms_ = measure(ws, args.steps, 5, 20, min_timed_s=0.5)
+        ms_ = measure(ws, args.steps, 5, 20, min_timed_s=0.5, name="strict_f32")
         strict = {"value": round(args.minibatch * args.steps / ms_["dt"], 2), "unit": "lines/s", "ms_per_step": round(ms_["dt"] / args.steps * 1e3, 4),
                   "repeats": len(ms_["blocks"]), "dtype": "f32 (every product on the f32 MFMA: clstm_net_set_strict_f32)",
                   "roofline": roofline_b1(ws, ms_["kern"], {}, ms_["frames_per_step"], ms_["dt"] / args.steps * 1e3, strict=True) if ms_["kern"] else None,
@@ -779,7 +804,7 @@ def main():
     if rank == 0 and world == 1 and default_line and not args.no_secondary:
         wsat = Workload(lib, cfg, 256, args.T, False, 0, dev, rank)
         ssat = max(5, min(args.steps, 20))
-        msat = measure(wsat, ssat, 3, 20, unfused_pass=True, min_timed_s=0.5)
+        msat = measure(wsat, ssat, 3, 20, unfused_pass=True, min_timed_s=0.5, name="saturated")
         ms_sat = msat["dt"] / ssat * 1e3
         rsat = roofline_b1(wsat, msat["kern"], msat["kern_unfused"], msat["frames_per_step"], ms_sat) if msat["kern"] else None
         if rsat is not None:
@@ -810,7 +835,7 @@ def main():
         LB = 2048
         wl = Workload(lib, cfg, LB, args.T, False, 0, dev, rank)
         sl_ = max(5, min(args.steps, 10))
-        ml_ = measure(wl, sl_, 2, 5, min_timed_s=0.3)
+        ml_ = measure(wl, sl_, 2, 5, min_timed_s=0.3, name="large_minibatch")
         kl = ml_["kern"]
         cell_steps = 2.0 * cfg["nh"][0] * ml_["frames_per_step"]
         rl = {}
@@ -847,14 +872,14 @@ def main():
         w.net = w.trainer = None        # free the first workload's device arrays
         w2 = Workload(lib, c2, 64, c2["T"], False, 2, dev, rank)
         s2 = max(5, min(args.steps, 20))
-        m2 = measure(w2, s2, 3, 2)
+        m2 = measure(w2, s2, 3, 2, name="secondary")
         ms2 = m2["dt"] / s2 * 1e3
         secondary = {
             "metric": "text-line images/sec (fwd+bwd+CTC), 2xBiLSTM(512) H=64 T~400 (bf16 MFMA)",
             "value": round(64 * s2 / m2["dt"], 2), "unit": "lines/s", "n_gpus": 1, "steps": s2, "warmup": 3,
             "repeats": len(m2["blocks"]), "ms_per_step": round(ms2, 4),
             "dtype": "bf16 MFMA operands (hoisted gate GEMMs and lock-step recurrence), f32 accumulate / state / softmax / CTC",
-            "data": "synthetic",
+            "data": "synthetic", "learning_rate": w2.lr,
             "config": {"workload": "stacked 2xBiLSTM(512) H=64 nc=100, T=400, L=50, minibatch=64 lines on 1 GPU "
                                    "(BASELINE.json configs[4] shape), fwd+CTC+bwd+update", "minibatch_per_gpu": 64},
             "roofline": (lambda r: dict(r, rocprof_avg_launch_ms_from_committed_profile=rocprof_b2_avg_ms(r.get("kernel"))))(roofline_b2(w2, m2["kern"], m2["frames_per_step"], ms2)) if m2["kern"] else None,
@@ -868,10 +893,10 @@ def main():
     if rank == 0 and world == 1 and default_line and not args.no_secondary:
         c2 = CONFIGS["b2"]
         w3 = Workload(lib, c2, 64, c2["T"], False, 0, dev, rank)
-        m3 = measure(w3, 10, 2, 0, min_timed_s=0.25)        # 10 steps x >= 3 repeats
+        m3 = measure(w3, 10, 2, 0, min_timed_s=0.25, name="secondary_f32")        # 10 steps x >= 3 repeats
         fl3 = flops_per_line(c2, c2["T"]) * 64 / (m3["dt"] / 10) / 1e12
         secondary_f32 = {"metric": "text-line images/sec (fwd+bwd+CTC), 2xBiLSTM(512) H=64 T~400 (f32)", "value": round(64 * 10 / m3["dt"], 2),
-                         "unit": "lines/s", "steps": 10, "repeats": len(m3["blocks"]), "ms_per_step": round(m3["dt"] / 10 * 1e3, 4),
+                         "unit": "lines/s", "steps": 10, "repeats": len(m3["blocks"]), "ms_per_step": round(m3["dt"] / 10 * 1e3, 4), "learning_rate": w3.lr,
                          "whole_step_tflops": {"achieved": round(fl3, 2), "unit": "TFLOP/s",
                                                "note": "bf16x3-ASSISTED: the backward two thirds of these flops run as three bf16 MFMAs per product "
                                                        "(16x the f32 MFMA's rate), so this figure is NOT a fraction of the 157.3 TFLOP/s f32 MFMA peak"},
@@ -914,6 +939,10 @@ def main():
                        "block_ms_min": round(min(m["blocks"]) * 1e3, 3), "block_ms_max": round(max(m["blocks"]) * 1e3, 3)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": m["kern"], "kernels_fusions_off": m["kern_unfused"],
             "host_enqueue_ms_per_step": round(m["enqueue"] * 1e3, 4),   # host-side cost of issuing a step
+            # after the timed blocks of EVERY workload of this line (Workload.verify: it raises otherwise): no sticky device
+            # error -- the library skips updates after one --, parameters finite and moved by the updates
+            "validity": dict(m["validity"], learning_rate=w.lr,
+                             legs={k: v for k, v in leg_validity.items() if k != "main"}),
             "allreduce": allreduce,
             "weights": (w.weights_info or "reference initialisation (rinit negbiased, seed 0.222)"),
             "trained_weights": trained,

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
                                                                int K, int ksplit, int nsplit) {
   __shared__ __attribute__((aligned(16))) unsigned short As[2 * GB2_TILE];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * GB2_TILE];
+  constexpr bool COAL = false;   // (the row-per-load mapping of gemm_x3_128_kernel is not built for this kernel)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -210,16 +211,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
   const int kbeg = (z - batch * nsplit) * ksplit;
   const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
 
-  const int a_mn = AMODE == GEMM_KC ? (tid >> 1) : wave * 32 + (lane & 7) * 4;
-  const int a_k = AMODE == GEMM_KC ? (tid & 1) * 16 : (lane >> 3) * 4;
-  const int b_mn = BMODE == GEMM_KC ? (tid >> 1) : wave * 32 + (lane & 7) * 4;
-  const int b_k = BMODE == GEMM_KC ? (tid & 1) * 16 : (lane >> 3) * 4;
+  const int a_mn = AMODE == GEMM_KC ? (COAL ? (tid >> 3) : (tid >> 1)) : wave * 32 + (lane & 7) * 4;
+  const int a_k = AMODE == GEMM_KC ? (COAL ? (tid & 7) * 4 : (tid & 1) * 16) : (lane >> 3) * 4;
+  const int b_mn = BMODE == GEMM_KC ? (COAL ? (tid >> 3) : (tid >> 1)) : wave * 32 + (lane & 7) * 4;
+  const int b_k = BMODE == GEMM_KC ? (COAL ? (tid & 7) * 4 : (tid & 1) * 16) : (lane >> 3) * 4;
   const BufF32 abuf = make_buf(A.p + batch * A.bstride, (size_t)(A.elems - batch * A.bstride) * 4);
   const BufF32 bbuf = make_buf(B.p + batch * B.bstride, (size_t)(B.elems - batch * B.bstride) * 4);
   const unsigned a_base = AMODE == GEMM_KC ? (unsigned)(r0 + a_mn) * A.ld + a_k : (unsigned)a_k * A.ld + r0 + a_mn;
   const unsigned b_base = BMODE == GEMM_KC ? (unsigned)(c0 + b_mn) * B.ld + b_k : (unsigned)b_k * B.ld + c0 + b_mn;
   const unsigned a_kstep = AMODE == GEMM_KC ? 1u : (unsigned)A.ld, b_kstep = BMODE == GEMM_KC ? 1u : (unsigned)B.ld;
-  const unsigned a_next = AMODE == GEMM_KC ? 4u : (unsigned)A.ld, b_next = BMODE == GEMM_KC ? 4u : (unsigned)B.ld;
+  const unsigned a_next = AMODE == GEMM_KC ? (COAL ? 32u * (unsigned)A.ld : 4u) : (unsigned)A.ld;   // load j: 32 rows on / 4 k on / 1 k row on
+  const unsigned b_next = BMODE == GEMM_KC ? (COAL ? 32u * (unsigned)B.ld : 4u) : (unsigned)B.ld;
 
   // Block addresses: per-lane byte offsets of the four float4 (fixed) + the block's offset (one add per load, the sum
   // stays inside the descriptor's bounds check).  Blocks past the slab re-read its last block (their products are
@@ -335,7 +337,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
 // Their f32-MFMA form runs near its own roof (96-114 TFLOP/s of 157) and was 6.5 of the 15.2 ms of a configs[4] step; three
 // bf16 MFMAs of 16 cycles replace eight f32 MFMAs of 32.)  Each operand block lives in LDS as a hi and a lo image
 // (4 x 8 KB per buffer, two buffers = 64 KB: one workgroup per CU by LDS... two by registers).
-template <int AMODE, int BMODE, class FE>
+// COAL (k-contiguous operands): a thread's four 16-byte loads of a block are four ROWS, eight neighbouring lanes covering 128
+// contiguous bytes of one row -- the address pipeline takes a 16-byte access of a lane that has no neighbour as a request of its
+// own, and the older form (a thread = 64 contiguous bytes of one row, neighbouring lanes 64 bytes apart) issued 64 per instruction.
+template <int AMODE, int BMODE, class FE, bool COAL = true>
 __global__ __launch_bounds__(256, 2) void gemm_x3_128_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
                                                              int K, int ksplit, int nsplit) {
   unsigned short* const x3_smem = dyn_smem<unsigned short>();   // [A hi | A lo | B hi | B lo] x 2 buffers
@@ -361,16 +366,17 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_128_kernel(GemmOperand A, Gemm
   const int kbeg = (z - batch * nsplit) * ksplit;
   const int kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
 
-  const int a_mn = AMODE == GEMM_KC ? (tid >> 1) : wave * 32 + (lane & 7) * 4;
-  const int a_k = AMODE == GEMM_KC ? (tid & 1) * 16 : (lane >> 3) * 4;
-  const int b_mn = BMODE == GEMM_KC ? (tid >> 1) : wave * 32 + (lane & 7) * 4;
-  const int b_k = BMODE == GEMM_KC ? (tid & 1) * 16 : (lane >> 3) * 4;
+  const int a_mn = AMODE == GEMM_KC ? (COAL ? (tid >> 3) : (tid >> 1)) : wave * 32 + (lane & 7) * 4;
+  const int a_k = AMODE == GEMM_KC ? (COAL ? (tid & 7) * 4 : (tid & 1) * 16) : (lane >> 3) * 4;
+  const int b_mn = BMODE == GEMM_KC ? (COAL ? (tid >> 3) : (tid >> 1)) : wave * 32 + (lane & 7) * 4;
+  const int b_k = BMODE == GEMM_KC ? (COAL ? (tid & 7) * 4 : (tid & 1) * 16) : (lane >> 3) * 4;
   const BufF32 abuf = make_buf(A.p + batch * A.bstride, (size_t)(A.elems - batch * A.bstride) * 4);
   const BufF32 bbuf = make_buf(B.p + batch * B.bstride, (size_t)(B.elems - batch * B.bstride) * 4);
   const unsigned a_base = AMODE == GEMM_KC ? (unsigned)(r0 + a_mn) * A.ld + a_k : (unsigned)a_k * A.ld + r0 + a_mn;
   const unsigned b_base = BMODE == GEMM_KC ? (unsigned)(c0 + b_mn) * B.ld + b_k : (unsigned)b_k * B.ld + c0 + b_mn;
   const unsigned a_kstep = AMODE == GEMM_KC ? 1u : (unsigned)A.ld, b_kstep = BMODE == GEMM_KC ? 1u : (unsigned)B.ld;
-  const unsigned a_next = AMODE == GEMM_KC ? 4u : (unsigned)A.ld, b_next = BMODE == GEMM_KC ? 4u : (unsigned)B.ld;
+  const unsigned a_next = AMODE == GEMM_KC ? (COAL ? 32u * (unsigned)A.ld : 4u) : (unsigned)A.ld;   // load j: 32 rows on / 4 k on / 1 k row on
+  const unsigned b_next = BMODE == GEMM_KC ? (COAL ? 32u * (unsigned)B.ld : 4u) : (unsigned)B.ld;
 
   // Block addresses: per-lane byte offsets of the four float4 (fixed) + the block's offset (one add per load, the sum
   // stays inside the descriptor's bounds check).  Blocks past the slab re-read its last block (their products are
@@ -395,7 +401,25 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_128_kernel(GemmOperand A, Gemm
   // zero blocks behind it) mask contraction indices >= kend per element (one wave-uniform branch per block).
   auto stage = [&](const int MODE, unsigned short* S, const int mn, const int kk, const int k0, const f32x4 (&r)[4]) {
     const bool whole = wave_uniform(k0 + GB_BK <= kend ? 1 : 0) != 0;
-    if (MODE == GEMM_KC) {
+    if (MODE == GEMM_KC && COAL) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {   // row mn + 32 j, contraction indices kk .. kk + 3
+        f32x4 v = r[j];
+        if (!whole) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[i] = (k0 + kk + i < kend) ? v[i] : 0.0f;
+        }
+        u32x2 w2, l2;
+        w2[0] = bf16_pack2(v[0], v[1]);
+        w2[1] = bf16_pack2(v[2], v[3]);
+        l2[0] = bf16_pack2(v[0] - __builtin_bit_cast(float, w2[0] << 16), v[1] - __builtin_bit_cast(float, w2[0] & 0xFFFF0000u));
+        l2[1] = bf16_pack2(v[2] - __builtin_bit_cast(float, w2[1] << 16), v[3] - __builtin_bit_cast(float, w2[1] & 0xFFFF0000u));
+        const int row = mn + 32 * j;
+        const int at = row * GB2_LDH + (((kk >> 3) ^ gb2_sw(row)) << 3) + (kk & 4);
+        *reinterpret_cast<u32x2*>(&S[at]) = w2;
+        *reinterpret_cast<u32x2*>(&S[at + 2 * GB2_TILE]) = l2;
+      }
+    } else if (MODE == GEMM_KC) {
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         float x[8];
@@ -1481,6 +1505,18 @@ inline void gemm_x3_big(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe,
   }
 #endif
   dim3 grid((Cn + GB2_BT - 1) / GB2_BT, (R + GB2_BT - 1) / GB2_BT, nsplit * nbatch);
+  static const bool coal = dbg_opt("x3_coal", 1) != 0;   // (the older k-contiguous load mapping: 0)
+  if ((AMODE == GEMM_KC || BMODE == GEMM_KC) && !coal) {
+#ifndef CLSTM_HIP_EMU
+    static bool attr_set0 = false;
+    if (!attr_set0) {
+      (void)hipFuncSetAttribute((const void*)gemm_x3_128_kernel<AMODE, BMODE, FE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set0 = true;
+    }
+#endif
+    CLSTM_LAUNCH((gemm_x3_128_kernel<AMODE, BMODE, FE, false>), grid, dim3(256), smem, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+    return;
+  }
   CLSTM_LAUNCH((gemm_x3_128_kernel<AMODE, BMODE, FE>), grid, dim3(256), smem, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
 }
 

@@ -43,6 +43,41 @@ def test_bench_rank_body_world2_on_the_emulator(how):
     assert ar["ranks"] == 2 and ar["bytes"] == 4 * 135883
     assert "peer-read" in ar["impl"]                           # the one-call step ran the fused exchange, not a fallback
     assert out["secondary"] is None and out["cpu_baseline"] is None      # single-GPU legs stay out of a multi-rank line
+    v = out["validity"]                                        # the timed steps updated the parameters (Workload.verify)
+    assert v["device_errors"] == "none" and v["params_finite"] is True and v["max_param_change"] > 0 and v["legs"] == {}
+
+
+def test_bench_refuses_steps_whose_updates_were_skipped():
+    """bench.py's Workload.verify: after a sticky device error (a non-finite gradient, a fused launch that gave up) the library
+    skips every later update, and the steps still run -- faster.  Found in round 6: the exact-f32 configs[4] leg reached a
+    non-finite gradient at training step 43 of its synthetic trajectory and timed steps without updates from there on.
+    verify() reads the parameters back (which raises a pending device error) and demands that they are finite and moved."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Net:
+        def __init__(self, p):
+            self.p = p
+
+        def get_params(self):
+            if self.p is None:
+                raise RuntimeError("non-finite value (NaN or Inf) in the softmax logits or the gradient of training step 43")
+            return self.p
+
+    w = bench.Workload.__new__(bench.Workload)
+    w.params0 = np.zeros(8, np.float32)
+    w.net = Net(np.full(8, 0.5, np.float32))
+    assert w.verify() == {"device_errors": "none", "params_finite": True, "max_param_change": 0.5}
+    w.net = Net(np.zeros(8, np.float32))                       # nothing moved
+    with pytest.raises(RuntimeError, match="did not update"):
+        w.verify()
+    w.net = Net(np.array([0.5, np.nan] * 4, np.float32))
+    with pytest.raises(RuntimeError, match="did not update"):
+        w.verify()
+    w.net = Net(None)                                          # the library's own error comes through
+    with pytest.raises(RuntimeError, match="non-finite"):
+        w.verify()
 
 
 @pytest.mark.gpu
