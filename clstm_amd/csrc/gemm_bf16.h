@@ -340,7 +340,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128_kernel(GemmOperand A, Ge
 // COAL (k-contiguous operands): a thread's four 16-byte loads of a block are four ROWS, eight neighbouring lanes covering 128
 // contiguous bytes of one row -- the address pipeline takes a 16-byte access of a lane that has no neighbour as a request of its
 // own, and the older form (a thread = 64 contiguous bytes of one row, neighbouring lanes 64 bytes apart) issued 64 per instruction.
-template <int AMODE, int BMODE, class FE, bool COAL = true>
+// ILV: the conversion of block t + 1 (VALU + LDS writes into the other buffer) and the loads of block t + 4 are issued BETWEEN the 48
+// MFMAs of block t (sched_group_barrier pattern) instead of in front of them: a workgroup is four waves, one per SIMD, and a wave
+// issues in order -- staged first, its ~130 conversion instructions (4 cycles each) and its MFMAs (16 cycles each) ran one after
+// the other.
+#ifdef CLSTM_HIP_EMU
+#define GX3_SGB(mask, n) do {} while (0)
+#else
+#define GX3_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#endif
+template <int AMODE, int BMODE, class FE, bool COAL = true, bool ILV = true>
 __global__ __launch_bounds__(256, 2) void gemm_x3_128_kernel(GemmOperand A, GemmOperand B, FE fe, int R, int Cn,
                                                              int K, int ksplit, int nsplit) {
   unsigned short* const x3_smem = dyn_smem<unsigned short>();   // [A hi | A lo | B hi | B lo] x 2 buffers
@@ -490,28 +499,70 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_128_kernel(GemmOperand A, Gemm
       const int k0 = kb + p * GB_BK;   // block in LDS buffer `cur` (phases past the slab multiply zeros)
       constexpr int pn_of[3] = {1, 2, 0};
       const int pn = pn_of[p];         // register set of block k0 + 32: convert it into the other buffer ...
-      {
+      if (!ILV) {
       stage(AMODE, As + (cur ^ GB2_TILE), a_mn, a_k, k0 + GB_BK, ra[pn]);
       stage(BMODE, Bs + (cur ^ GB2_TILE), b_mn, b_k, k0 + GB_BK, rb[pn]);
-      }
       load_tile(k0 + GB_BK + GB2_PF * GB_BK, ra[pn], rb[pn]);   // ... and re-use the set for the block three ahead
       SCHED_FENCE();
-      u16x8 af[4], bf[4], al[4], bl[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        af[i] = *reinterpret_cast<const u16x8*>(&As[cur + (wm * 64 + i * 16 + fi) * GB2_LDH + fsw]);
-        bf[i] = *reinterpret_cast<const u16x8*>(&Bs[cur + (wn * 64 + i * 16 + fi) * GB2_LDH + fsw]);
-        al[i] = *reinterpret_cast<const u16x8*>(&As[cur + 2 * GB2_TILE + (wm * 64 + i * 16 + fi) * GB2_LDH + fsw]);
-        bl[i] = *reinterpret_cast<const u16x8*>(&Bs[cur + 2 * GB2_TILE + (wn * 64 + i * 16 + fi) * GB2_LDH + fsw]);
       }
+      if (!ILV) {
+        u16x8 af[4], bf[4], al[4], bl[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {   // small terms first (transposed: see gb2_store)
-          acc[i][j] = mfma16x16x32_bf16(bl[j], af[i], acc[i][j]);
-          acc[i][j] = mfma16x16x32_bf16(bf[j], al[i], acc[i][j]);
-          acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);
+        for (int i = 0; i < 4; i++) {
+          af[i] = *reinterpret_cast<const u16x8*>(&As[cur + (wm * 64 + i * 16 + fi) * GB2_LDH + fsw]);
+          bf[i] = *reinterpret_cast<const u16x8*>(&Bs[cur + (wn * 64 + i * 16 + fi) * GB2_LDH + fsw]);
+          al[i] = *reinterpret_cast<const u16x8*>(&As[cur + 2 * GB2_TILE + (wm * 64 + i * 16 + fi) * GB2_LDH + fsw]);
+          bl[i] = *reinterpret_cast<const u16x8*>(&Bs[cur + 2 * GB2_TILE + (wn * 64 + i * 16 + fi) * GB2_LDH + fsw]);
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {   // small terms first (transposed: see gb2_store)
+            acc[i][j] = mfma16x16x32_bf16(bl[j], af[i], acc[i][j]);
+            acc[i][j] = mfma16x16x32_bf16(bf[j], al[i], acc[i][j]);
+            acc[i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[i][j]);
+          }
+      } else {
+        // two halves of 24 MFMAs (A row tiles 0-1, then 2-3: 48 instead of 64 fragment registers live), the A conversion between the
+        // MFMAs of the first, the B conversion and the loads between those of the second
+        u16x8 bf[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          bf[j] = *reinterpret_cast<const u16x8*>(&Bs[cur + (wn * 64 + j * 16 + fi) * GB2_LDH + fsw]);
+          bl[j] = *reinterpret_cast<const u16x8*>(&Bs[cur + 2 * GB2_TILE + (wn * 64 + j * 16 + fi) * GB2_LDH + fsw]);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+          u16x8 af[2], al[2];
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            af[i] = *reinterpret_cast<const u16x8*>(&As[cur + (wm * 64 + (2 * hf + i) * 16 + fi) * GB2_LDH + fsw]);
+            al[i] = *reinterpret_cast<const u16x8*>(&As[cur + 2 * GB2_TILE + (wm * 64 + (2 * hf + i) * 16 + fi) * GB2_LDH + fsw]);
+          }
+          SCHED_FENCE();
+          if (hf == 0) stage(AMODE, As + (cur ^ GB2_TILE), a_mn, a_k, k0 + GB_BK, ra[pn]);
+          else {
+            stage(BMODE, Bs + (cur ^ GB2_TILE), b_mn, b_k, k0 + GB_BK, rb[pn]);
+            load_tile(k0 + GB_BK + GB2_PF * GB_BK, ra[pn], rb[pn]);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              acc[2 * hf + i][j] = mfma16x16x32_bf16(bl[j], af[i], acc[2 * hf + i][j]);
+              acc[2 * hf + i][j] = mfma16x16x32_bf16(bf[j], al[i], acc[2 * hf + i][j]);
+              acc[2 * hf + i][j] = mfma16x16x32_bf16(bf[j], af[i], acc[2 * hf + i][j]);
+            }
+#pragma unroll
+          for (int q = 0; q < 24; q++) {   // one MFMA, three conversion instructions; an LDS write every third, a load every third of the second half
+            GX3_SGB(0x008, 1);
+            GX3_SGB(0x002, 3);
+            if (q % 3 == 0) GX3_SGB(0x200, 1);
+            if (hf == 1 && q % 3 == 1) GX3_SGB(0x020, 1);
+          }
+          SCHED_FENCE();
+        }
+      }
       __syncthreads();
       cur ^= GB2_TILE;
     }
@@ -1515,6 +1566,18 @@ inline void gemm_x3_big(hipStream_t stream, GemmOperand A, GemmOperand B, FE fe,
     }
 #endif
     CLSTM_LAUNCH((gemm_x3_128_kernel<AMODE, BMODE, FE, false>), grid, dim3(256), smem, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
+    return;
+  }
+  static const bool ilv = dbg_opt("x3_ilv", 1) != 0;     // (conversion in front of the MFMAs instead of between them: 0)
+  if (!ilv) {
+#ifndef CLSTM_HIP_EMU
+    static bool attr_set1 = false;
+    if (!attr_set1) {
+      (void)hipFuncSetAttribute((const void*)gemm_x3_128_kernel<AMODE, BMODE, FE, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set1 = true;
+    }
+#endif
+    CLSTM_LAUNCH((gemm_x3_128_kernel<AMODE, BMODE, FE, true, false>), grid, dim3(256), smem, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
     return;
   }
   CLSTM_LAUNCH((gemm_x3_128_kernel<AMODE, BMODE, FE>), grid, dim3(256), smem, stream, A, B, fe, R, Cn, K, ksplit, nsplit);
