@@ -62,9 +62,17 @@ struct GemmDwArgs {
 // blocks of the x3 item in flight in registers (6 and 8 were measured: the fused launch then needs > 168 registers,
 // only one GEMM workgroup fits a CU, 142 / 148 us against 116)
 constexpr int DW_PF = 3;
+#ifdef CLSTM_HIP_EMU
+#define DW_SGB(mask, n) do {} while (0)
+#else
+#define DW_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#endif
 // LDS of the GEMM role: two buffers of 2 NT 64 x 32 bf16 images (NT terms per operand; the f32 item: 8192 floats; the epilogue
 // tile fits too) + the slab's k-tile table (DW_STAB_MAX entries of 2 ints)
-constexpr int DW_STAB_MAX = 1024;
+#ifndef CLSTM_DW_STAB_MAX
+#define CLSTM_DW_STAB_MAX 256   // 2 KB: with three terms the role's LDS is 50 KB -- three workgroups per CU (1024 entries: 56 KB, two)
+#endif
+constexpr int DW_STAB_MAX = CLSTM_DW_STAB_MAX;
 constexpr int dw_img_floats(int nt) { return nt <= 2 ? 8192 : 2 * 2 * nt * 64 * 32 / 2; }
 constexpr int dw_smem_floats(int nt) { return dw_img_floats(nt) + 2 * DW_STAB_MAX; }
 static_assert(8192 >= GEMM_BT * GEMM_LDO, "epilogue tile");
@@ -259,7 +267,8 @@ DEVFN void gemm_dw_item(const GemmDwArgs& a, float* smem, const unsigned si, con
 // 32-frame block (two 16-frame table entries), 4 columns each, transposes in registers and writes 4 k of one row per
 // ds_write_b64 into swizzled [mn][32 k] images (gemm_bf16.h: conflict-free fragment reads); images are double-buffered,
 // one barrier per block.
-template <int NT>
+// ILV: the conversion of block t + 1 issued BETWEEN the MFMAs of block t (sched_group_barrier; as gemm_bf16.h: gemm_x3_128_kernel)
+template <int NT, bool ILV = false>
 DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, const unsigned tile, const bool extra = false) {
   constexpr int IMG = 64 * 32;                 // halfs per image
   constexpr int BUFH = 2 * NT * IMG;           // halfs per buffer
@@ -361,9 +370,11 @@ DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, 
 #pragma unroll
     for (int p = 0; p < DW_PF; p++) {
       const int pn = p + 1 == DW_PF ? 0 : p + 1;
+      if (!ILV) {
       stage(cur ^ 1, rr[pn]);                                   // block tb/2 + p + 1 into the other buffer
       load_block(role, tb + 2 * (p + 1 + DW_PF), rr[pn]);
       SCHED_FENCE();
+      }
       const unsigned short* b0 = img + cur * BUFH;
       u16x8 at[NT][2], bt[NT][2];
 #pragma unroll
@@ -373,6 +384,11 @@ DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, 
           at[t][i] = *reinterpret_cast<const u16x8*>(b0 + t * IMG + (wm * 32 + i * 16) * 32 + fofs);
           bt[t][i] = *reinterpret_cast<const u16x8*>(b0 + (NT + t) * IMG + (wn * 32 + i * 16) * 32 + fofs);
         }
+      if (ILV) {
+        SCHED_FENCE();
+        stage(cur ^ 1, rr[pn]);
+        load_block(role, tb + 2 * (p + 1 + DW_PF), rr[pn]);
+      }
       // smallest terms first (term weights 2^-8 apart): ta + tb = 2, then 1, then 0
 #pragma unroll
       for (int w = NT - 1; w >= 0; w--)
@@ -382,6 +398,17 @@ DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, 
           for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) acc[i][j] = mfma16x16x32_bf16(at[ta][i], bt[w - ta][j], acc[i][j]);
+      if (ILV) {
+        constexpr int NM = 2 * NT * (NT + 1);                    // MFMAs of a block: 12 (two terms) / 24 (three)
+#pragma unroll
+        for (int q = 0; q < NM; q++) {   // one MFMA, four conversion instructions; an LDS write every second, a load every sixth
+          DW_SGB(0x008, 1);
+          DW_SGB(0x002, 4);
+          if (q % 2 == 0) DW_SGB(0x200, 1);
+          if (q % 6 == 0) DW_SGB(0x020, 1);
+        }
+        SCHED_FENCE();
+      }
       __syncthreads();
       cur ^= 1;
     }
@@ -422,27 +449,27 @@ DEVFN void gemm_dw_item_x3(const GemmDwArgs& a, float* smem, const unsigned si, 
 // gets early and late ones alike
 // NT: the item form is a compile-time choice (and so part of the kernel's NAME: a profile of a process that runs several forms --
 // bench.py's strict_f32 leg -- keeps their launch statistics apart): 0 the f32 MFMA (a.x3 == 0), 2 / 3 = a.terms of the split
-template <int NT>
+template <int NT, bool ILV = false>
 DEVFN void gemm_dw_body(const GemmDwArgs& a, float* smem, unsigned block) {
   constexpr bool X3 = NT != 0;
   if (block == 0) { gemm_dw_monitor(a); return; }   // the first workgroup behind the recurrence's watches the lines
   block -= 1;
   const unsigned nextra = X3 ? (unsigned)a.xnslabs * a.xgx * a.xgy : 0u;   // independent items first (see GemmDwArgs)
   if constexpr (X3) {
-    if (block < nextra) { gemm_dw_item_x3<NT>(a, smem, block / (a.xgx * a.xgy), block % (a.xgx * a.xgy), true); return; }
+    if (block < nextra) { gemm_dw_item_x3<NT, ILV>(a, smem, block / (a.xgx * a.xgy), block % (a.xgx * a.xgy), true); return; }
   }
   block -= nextra;
   const unsigned tiles = a.gx * a.gy;
   const unsigned xcd = block & 7u, idx = block >> 3;
   const unsigned si = (idx / tiles) * 8u + xcd;
   if (si >= (unsigned)a.nslabs) return;
-  if constexpr (X3) gemm_dw_item_x3<NT>(a, smem, si, idx % tiles);
+  if constexpr (X3) gemm_dw_item_x3<NT, ILV>(a, smem, si, idx % tiles);
   else gemm_dw_item(a, smem, si, idx % tiles);
 }
-template <int NT>
+template <int NT, bool ILV = false>
 __global__ __launch_bounds__(256) void gemm_dw_kernel(GemmDwArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[dw_smem_floats(NT)];
-  gemm_dw_body<NT>(a, smem, blockIdx.x);
+  gemm_dw_body<NT, ILV>(a, smem, blockIdx.x);
 }
 
 }  // namespace clstm

@@ -17,7 +17,9 @@ namespace clstm {
 // NT: the weight-gradient items' arithmetic (gemm_dw_body): 0 f32 MFMA, 2 / 3 bf16 terms per operand
 template <int NK4, int KU, int NT>
 __global__ __launch_bounds__(64 * NK4) CLSTM_TWO_WAVES_PER_SIMD void lstm_bwd_dw_kernel(LstmSeqArgs a, GemmDwArgs g, int nrec) {
-  __shared__ __attribute__((aligned(16))) float gsm[dw_smem_floats(NT)];
+  // (8 KB more than the items need since their k-tile table shrank to DW_STAB_MAX = 256 entries: with 50 KB a third item workgroup
+  //  fits a CU beside the recurrence's, and the 64-line step measured 0.3 us slower for it -- three interleaved runs, 0.2866 vs 0.2861 ms)
+  __shared__ __attribute__((aligned(16))) float gsm[dw_img_floats(NT) + 2 * 1024];
   if ((int)blockIdx.x < nrec) {
 #ifndef CLSTM_HIP_EMU
     __builtin_amdgcn_s_setprio(3);
