@@ -254,11 +254,17 @@ class Workload:
             self.pool.append((Ts, xt, labels, Network.prepare_step(Ts, labels)))
         self.host_inputs = host_inputs
         self.one_call = self.trainer.dist is None     # single GPU or library communicator: clstm_net_train_step
+        self.declare_next = os.environ.get("CLSTM_BENCH_DECLARE_NEXT", "1") != "0"   # (--no-declare-next)
 
     def step(self, i):
         Ts, xd, labels, prep = self.pool[i % len(self.pool)]
         if self.host_inputs:
             self.net.train_step_host(prep, xd)         # frames in (pinned) host memory: copy stream + double-buffered device input
+        elif self.one_call and self.declare_next:
+            # ... and the loop knows its next minibatch (a loader one batch ahead): clstm_net_train_step_next -- the next
+            # step's ingest rides this step's last launch; every step still ingests exactly one minibatch
+            _, nxd, _, nprep = self.pool[(i + 1) % len(self.pool)]
+            self.net.train_step_prepared(prep, xd, nprep, nxd)
         elif self.one_call:
             self.net.train_step_prepared(prep, xd)     # CLSTMOCR::train for the minibatch: one C-ABI call, no host sync
         else:
@@ -543,12 +549,17 @@ def main():
                     help="trained: the SURVEY 8(d) 'trained-like' regime -- weights after 500 online-SGD steps on the reference's fixture line, "
                          "inputs = jittered crops of that line (config b1 only); the default line carries it as the `trained_weights` leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-declare-next", action="store_true",
+                    help="plain clstm_net_train_step calls: every step starts with an ingest launch of its own (default: the loop "
+                         "declares its next minibatch, clstm_net_train_step_next, and the ingest rides the previous step's last launch)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="the headline workload only: skip the other legs of the default line (strict_f32, saturated, configs[4] in both precisions) -- "
                          "what the rocprofv3 passes use, so that their per-kernel averages are the headline workload's")
     ap.add_argument("--profile-steps", type=int, default=None,
                     help="extra steps with per-kernel timing (events bound to each launch's dispatch packet); default 50 (b1) / 5 (b2)")
     args = ap.parse_args()
+    if args.no_declare_next:
+        os.environ["CLSTM_BENCH_DECLARE_NEXT"] = "0"
     cfg = CONFIGS[args.config]
     if args.T is None:
         args.T = cfg["T"]
@@ -933,6 +944,9 @@ def main():
                                     "(BASELINE.json configs[4] shape), fwd+CTC+bwd+allreduce+update"
                                     % (args.T, args.minibatch, world)),
                        "minibatch_per_gpu": args.minibatch, "global_minibatch": args.minibatch * world,
+                       "step_call": ("clstm_net_train_step_next: the loop declares its next minibatch, whose ingest rides this step's last launch "
+                                     "(one ingest per step, none in front of the forward launch)" if (w.one_call and w.declare_next and not w.host_inputs)
+                                     else "clstm_net_train_step_h" if w.host_inputs else "clstm_net_train_step" if w.one_call else "separate calls + torch.distributed all-reduce"),
                        "parallelism": "dp%d" % world},
             "timing": {"protocol": "median of `repeats` blocks of exactly `steps` steps, each bracketed by barrier + synchronize "
                                    "and max-reduced over ranks; warm-up >= %.1f s" % MIN_WARMUP_S,

@@ -96,6 +96,7 @@ _SIGS = {
     "clstm_net_reset_timing": [_P],
     "clstm_net_train_step": [_P, _P, _I, _P, _P, _P],
     "clstm_net_train_step_h": [_P, _P, _I, _P, _P, _P],
+    "clstm_net_train_step_next": [_P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P],
     "clstm_host_alloc": [_P, C.c_size_t],
     "clstm_host_free": [_P],
     "clstm_net_n_states": [_P, _P],

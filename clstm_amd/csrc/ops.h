@@ -731,16 +731,19 @@ __global__ void k_bias_rows(const float* dbias, float* partial, int bs, int ndir
   }
 }
 // up to two slab sets per launch (the softmax layer's weight gradient rides with the top LSTM layer's)
-__global__ void k_reduce_scatter(ReduceDesc d0, ReduceDesc d1, float* g, int* zero, int zero_n, UpdateFuse u) {
+DEVFN void reduce_scatter_blocks(const ReduceDesc& d0, const ReduceDesc& d1, float* g, int* zero, const int zero_n, const UpdateFuse& u, const unsigned nb) {
   // (house-keeping that rides this launch: the work-queue heads of the fused backward launch return to zero)
   if (zero && blockIdx.x == 0 && (int)threadIdx.x < zero_n) zero[threadIdx.x] = 0;
   if (u.step_word && blockIdx.x == 0 && threadIdx.x == 0) store_i32_wt(u.step_word, u.step_id);
   const bool apply = u.v && !dev_err_set(u.err);   // (a failed launch / a non-finite gradient earlier on: the gradient is not applied)
   const size_t n0 = (size_t)d0.R * d0.Cn * d0.nbatch, n1 = (size_t)d1.R * d1.Cn * d1.nbatch;
-  CLSTM_GRID_STRIDE(e, n0 + n1) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n0 + n1; e += (size_t)nb * blockDim.x) {
     if (e < n0) reduce_scatter_one(d0, e, g, u, apply);
     else reduce_scatter_one(d1, e - n0, g, u, apply);
   }
+}
+__global__ void k_reduce_scatter(ReduceDesc d0, ReduceDesc d1, float* g, int* zero, int zero_n, UpdateFuse u) {
+  reduce_scatter_blocks(d0, d1, g, zero, zero_n, u, gridDim.x);
 }
 // diagnostics: the cross-lane primitives applied to the lane index (tests/test_intrinsics.py)
 __global__ void k_debug_lane_ops(float* out) {
@@ -832,53 +835,58 @@ __global__ void k_transpose_to_bf16(const float* src, unsigned short* dst, int r
 // k_ingest and the first layer's k_pack_layer in ONE launch (a single narrow layer whose parameters changed since
 // the last pack -- every training step): blocks [0, nbi) ingest, the rest repack.  The two jobs are independent
 // and each is far too small to fill the chip, so one launch ramp / tail instead of two.
+// the ingest blocks' job (blocks blk of nbi): frames -> the net's input block X and the first layer's source rows [1 | x] per direction
+DEVFN void ingest_rows(const float* x, float* X, float* S, const size_t N, const int ni, const int lds, const int ndir, const long long sdir,
+                       const unsigned blk, const unsigned nbi) {
+  if ((ni & 3) == 0 && (lds & 3) == 0 && ((size_t)x & 15) == 0) {
+    // 16 bytes per thread: chunk c of a frame = x[4c .. 4c+3] -> X as it is, and -- shifted by the bias column -- floats
+    // 4c .. 4c+3 of the source row [1 | x] = (x[4c-1] or the 1, x[4c], x[4c+1], x[4c+2]); the last chunk holds x[ni-1] alone
+    const size_t nch = (size_t)ni / 4 + 1;
+    for (size_t e = (size_t)blk * blockDim.x + threadIdx.x; e < N * nch; e += (size_t)nbi * blockDim.x) {
+      const size_t n = e / nch;
+      const int c = (int)(e - n * nch);
+      const float prev = c == 0 ? 1.0f : x[n * ni + 4 * c - 1];
+      if (4 * c < ni) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + n * ni + 4 * c);
+        *reinterpret_cast<f32x4*>(X + n * ni + 4 * c) = xv;
+        const f32x4 sv = f32x4{prev, xv[0], xv[1], xv[2]};
+        for (int d = 0; d < ndir; d++) *reinterpret_cast<f32x4*>(S + (size_t)d * sdir + n * lds + 4 * c) = sv;
+      } else {
+        for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + 4 * c] = prev;
+      }
+    }
+  } else {
+    for (size_t e = (size_t)blk * blockDim.x + threadIdx.x; e < N * (size_t)(1 + ni); e += (size_t)nbi * blockDim.x) {
+      const size_t n = e / (1 + ni);
+      const int j = e % (1 + ni);
+      float val = 1.0f;
+      if (j > 0) {
+        val = x[n * ni + (j - 1)];
+        X[n * ni + (j - 1)] = val;
+      }
+      for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = val;
+    }
+  }
+}
+// optional trailing blocks (blk counts from the first of them): small host arrays, straight from their pinned slots
+// (one element per thread: a read of host memory takes microseconds, so they must all be in flight at once)
+DEVFN void ingest_small(int blk, const int* lo_src, int* lo_dst, const int lo_n, const int* aux_src, int* aux_dst, const int aux_n) {
+  if (lo_src) {                       //   the line offsets: first trailing block
+    if (blk == 0) {
+      for (int i = threadIdx.x; i < lo_n; i += blockDim.x) lo_dst[i] = lo_src[i];
+      return;
+    }
+    blk--;
+  }
+  const int i = blk * (int)blockDim.x + (int)threadIdx.x;   //   the CTC metadata of this training step
+  if (i < aux_n) aux_dst[i] = aux_src[i];
+}
 __global__ void k_ingest_pack(const float* x, float* X, float* S, size_t N, int ni, int lds, int ndir, long long sdir,
                               int nbi, int nbp, const float* v, float* Wt, float* bias, float* Rf, float* Rb, PackDesc p, PackFused pf,
                               const int* lo_src, int* lo_dst, int lo_n, const int* aux_src, int* aux_dst, int aux_n, const int* tab) {
-  if ((int)blockIdx.x >= nbi + nbp) {   // optional trailing blocks: small host arrays, straight from their pinned slots
-    // (one element per thread: a read of host memory takes microseconds, so they must all be in flight at once)
-    int blk = (int)blockIdx.x - (nbi + nbp);
-    if (lo_src) {                       //   the line offsets: first trailing block
-      if (blk == 0) {
-        for (int i = threadIdx.x; i < lo_n; i += blockDim.x) lo_dst[i] = lo_src[i];
-        return;
-      }
-      blk--;
-    }
-    const int i = blk * (int)blockDim.x + (int)threadIdx.x;   //   the CTC metadata of this training step
-    if (i < aux_n) aux_dst[i] = aux_src[i];
-    return;
-  }
+  if ((int)blockIdx.x >= nbi + nbp) { ingest_small((int)blockIdx.x - (nbi + nbp), lo_src, lo_dst, lo_n, aux_src, aux_dst, aux_n); return; }
   if ((int)blockIdx.x < nbi) {
-    if ((ni & 3) == 0 && (lds & 3) == 0 && ((size_t)x & 15) == 0) {
-      // 16 bytes per thread: chunk c of a frame = x[4c .. 4c+3] -> X as it is, and -- shifted by the bias column -- floats
-      // 4c .. 4c+3 of the source row [1 | x] = (x[4c-1] or the 1, x[4c], x[4c+1], x[4c+2]); the last chunk holds x[ni-1] alone
-      const size_t nch = (size_t)ni / 4 + 1;
-      for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < N * nch; e += (size_t)nbi * blockDim.x) {
-        const size_t n = e / nch;
-        const int c = (int)(e - n * nch);
-        const float prev = c == 0 ? 1.0f : x[n * ni + 4 * c - 1];
-        if (4 * c < ni) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(x + n * ni + 4 * c);
-          *reinterpret_cast<f32x4*>(X + n * ni + 4 * c) = xv;
-          const f32x4 sv = f32x4{prev, xv[0], xv[1], xv[2]};
-          for (int d = 0; d < ndir; d++) *reinterpret_cast<f32x4*>(S + (size_t)d * sdir + n * lds + 4 * c) = sv;
-        } else {
-          for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + 4 * c] = prev;
-        }
-      }
-    } else {
-      for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < N * (size_t)(1 + ni); e += (size_t)nbi * blockDim.x) {
-        const size_t n = e / (1 + ni);
-        const int j = e % (1 + ni);
-        float val = 1.0f;
-        if (j > 0) {
-          val = x[n * ni + (j - 1)];
-          X[n * ni + (j - 1)] = val;
-        }
-        for (int d = 0; d < ndir; d++) S[(size_t)d * sdir + n * lds + j] = val;
-      }
-    }
+    ingest_rows(x, X, S, N, ni, lds, ndir, sdir, blockIdx.x, (unsigned)nbi);
   } else {
     const size_t nwx = (size_t)(1 + p.ni) * p.ndir * 4 * p.no;
     const size_t nr = (size_t)p.ndir * 4 * 4 * p.nk4 * p.nthreads;
@@ -898,6 +906,22 @@ __global__ void k_ingest_pack(const float* x, float* X, float* S, size_t N, int 
       else pack_fused(e - nwx - 2 * nr, v, pf, p);
     }
   }
+}
+// The NEXT minibatch's ingest riding the last launch of a training step (abi.inc: clstm_net_train_step_next): blocks
+// [0, nb_main) reduce and update, the nbi blocks behind them copy the next frames into the input block and lay down the source
+// rows -- the forward pass of step k read them for the last time a whole backward pass ago --, the blocks behind those fetch the
+// next step's line offsets and CTC metadata from their pinned slots.  One launch less on the step's critical path (k_ingest_pack:
+// 5.7 us in front of the forward launch of a 64 x 200 step).
+struct IngestTail {
+  const float* x; float* X; float* S; unsigned long long N; int ni, lds, ndir; long long sdir;
+  int nb_main, nbi;
+  const int* lo_src; int* lo_dst; int lo_n; const int* aux_src; int* aux_dst; int aux_n;
+};
+__global__ void k_reduce_scatter_ingest(ReduceDesc d0, ReduceDesc d1, float* g, int* zero, int zero_n, UpdateFuse u, IngestTail t) {
+  if ((int)blockIdx.x < t.nb_main) { reduce_scatter_blocks(d0, d1, g, zero, zero_n, u, (unsigned)t.nb_main); return; }
+  const int blk = (int)blockIdx.x - t.nb_main;
+  if (blk < t.nbi) { ingest_rows(t.x, t.X, t.S, (size_t)t.N, t.ni, t.lds, t.ndir, t.sdir, (unsigned)blk, (unsigned)t.nbi); return; }
+  ingest_small(blk - t.nbi, t.lo_src, t.lo_dst, t.lo_n, t.aux_src, t.aux_dst, t.aux_n);
 }
 __global__ void k_fill_col0(float* H, size_t rows, int ld, int col) {
   CLSTM_GRID_STRIDE(e, rows) H[e * ld + col] = 1.0f;

@@ -177,10 +177,17 @@ class Network:
         flat = np.concatenate([i32(tr).reshape(-1) for tr in transcripts]) if len(transcripts) else i32([])
         return Tl, i32(Tl), i32(flat if flat.size else [0]), L
 
-    def train_step_prepared(self, prep, x_dev):
+    def train_step_prepared(self, prep, x_dev, next_prep=None, next_x_dev=None):
+        """clstm_net_train_step; with the NEXT minibatch given (same forms), clstm_net_train_step_next: its ingest rides this
+        step's last launch and the next call -- which must pass that very minibatch -- starts with its forward launch."""
         Tl, t, labels, L = prep
         self.T, self.N = Tl, int(sum(Tl))
-        self.lib.call("clstm_net_train_step", self.h, ptr(t), len(Tl), ptr(x_dev), ptr(labels), ptr(L))
+        if next_prep is None:
+            self.lib.call("clstm_net_train_step", self.h, ptr(t), len(Tl), ptr(x_dev), ptr(labels), ptr(L))
+        else:
+            nTl, nt, nlabels, nL = next_prep
+            self.lib.call("clstm_net_train_step_next", self.h, ptr(t), len(Tl), ptr(x_dev), ptr(labels), ptr(L),
+                          ptr(nt), len(nTl), ptr(next_x_dev), ptr(nlabels), ptr(nL))
 
     def train_step_host(self, prep, x_host):
         """The same step fed from host memory (numpy array or pinned torch tensor [sum T, ninput]): the frames travel on a

@@ -222,6 +222,18 @@ int clstm_net_reset_timing(clstm_net* net);
  * x_d: DEVICE [sum T][ninput].  Decode with clstm_net_decode() afterwards if the caller wants the output. */
 int clstm_net_train_step(clstm_net* net, const int* T_h, int bs, const float* x_d, const int* labels_h,
                          const int* L_h);
+/* clstm_net_train_step for a loop that knows its NEXT minibatch (a data loader one minibatch ahead: what clstmocrtrain's
+ * sample loop, clstmocrtrain.cc:160-172, is once its lines are batched).  Tn_h / bsn / xn_d / labels_n_h / Ln_h describe the
+ * minibatch of the next call in the same form (all NULL / 0: exactly clstm_net_train_step).  The front half of that next step --
+ * batch geometry, the host half of its alignment, the copy of its frames into the net's input block, of its line offsets and CTC
+ * metadata -- is done by THIS call: by extra workgroups of this step's last launch (slab reduction + update), so the next
+ * call starts with its forward launch (one launch less per step: 5.7 us of a 64 x 200 step).  The next call must pass the same
+ * x pointer and the same T / transcripts (compared by content) to profit; anything else -- another minibatch after all, a
+ * communicator of several ranks, clstm_net_set_batch in between -- silently takes the ordinary path.  xn_d must stay unchanged
+ * from this call on.  Until the next step the net has no current minibatch: clstm_net_get_outputs_h / decode / ctc / backward /
+ * get_state_h refuse.  Results are bit-identical to clstm_net_train_step's. */
+int clstm_net_train_step_next(clstm_net* net, const int* T_h, int bs, const float* x_d, const int* labels_h, const int* L_h,
+                              const int* Tn_h, int bsn, const float* xn_d, const int* labels_n_h, const int* Ln_h);
 /* The same step fed from HOST memory (what clstmocrtrain has after read_png + CenterNormalizer, clstmocrtrain.cc:167-172,
  * extras.cc:227-285): x_h: [sum T][ninput].  Asynchronous: the frames go to the device on a copy stream (a DMA from
  * x_h itself if it is pinned -- clstm_host_alloc -- else through a pinned staging buffer of the library) into one of two

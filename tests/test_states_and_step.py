@@ -225,6 +225,55 @@ def test_update_is_skipped_while_a_device_error_is_pending(backend, ora32):
     assert not np.array_equal(net.get_params(), params.astype(np.float32))
 
 
+@pytest.mark.parametrize("nh", [[10], [7, 5]])
+def test_train_step_next_equals_train_step(backend, nh):
+    """clstm_net_train_step_next: the NEXT minibatch's front half -- batch geometry, alignment metadata,
+    the ingest of its frames -- rides this step's last launch (ops.h: k_reduce_scatter_ingest), and the next call starts with its
+    forward launch.  Bit for bit the sequence of plain clstm_net_train_step calls, over minibatches of changing geometry; a
+    call that passes another minibatch than the one declared takes the ordinary path (and is still right); between the two
+    calls the per-batch accessors refuse; the path counters say the tail ran and was used."""
+    import ctypes
+    from clstm_amd.init import init_params
+    from clstm_amd.net import Network
+    ni, nc = 8, 7
+    rng = np.random.default_rng(23)
+    p0 = init_params(ni, nh, nc, seed=0.222) * 20
+    a, b = Network(ni, nh, nc, lib=backend.lib), Network(ni, nh, nc, lib=backend.lib)
+    for n in (a, b):
+        n.set_params(p0)
+        n.setLearningRate(1e-2, 0.9)
+
+    def count(i):
+        out = ctypes.c_longlong(0)
+        backend.lib.call("clstm_debug_path_count", i, ctypes.byref(out))
+        return out.value
+    batches = []
+    for k in range(7):
+        T = [int(t) for t in rng.integers(3, 12, 2 + k % 3)]
+        trs = [rng.integers(1, nc, max(1, t // 3)).astype(np.int32) for t in T]
+        x = backend.up(np.ascontiguousarray(np.concatenate(synth_lines(rng, T, ni), 0), np.float32))
+        batches.append((Network.prepare_step(T, trs), x, T, trs))
+    tails0, used0 = count(19), count(20)
+    for k in range(6):
+        prep, x, T, trs = batches[k]
+        a.train_step_prepared(prep, x)
+        if k == 3:      # declares batch 6, but the next call brings batch 4: the ordinary path, and the declaration is dropped
+            b.train_step_prepared(prep, x, batches[6][0], batches[6][1])
+        elif k < 5:
+            b.train_step_prepared(prep, x, batches[k + 1][0], batches[k + 1][1])
+        else:
+            b.train_step_prepared(prep, x)
+        assert np.array_equal(a.get_params(), b.get_params()), k
+        assert np.array_equal(a.get_derivs(), b.get_derivs()), k
+        if k < 5:       # the net's minibatch is the declared one now: nothing of step k is addressable
+            with pytest.raises(Exception, match="no current minibatch"):
+                b.decode()
+    assert [d.tolist() for d in a.decode()] == [d.tolist() for d in b.decode()]
+    assert np.array_equal(a.outputs(), b.outputs())
+    assert count(19) - tails0 == 5          # five steps carried a next minibatch in their last launch ...
+    assert count(20) - used0 == 4           # ... four of which the next call used (one was declared and not brought)
+
+
 def test_train_step_from_host_memory(backend, ora32):
     """clstm_net_train_step_h: the step fed from host frames (pageable numpy memory here; on the GPU the frames go through
     the library's pinned staging buffer and a copy stream, double-buffered) must equal the device-resident
