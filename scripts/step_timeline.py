@@ -2,7 +2,10 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "clstm::k_ingest" in r["Kernel_Name"]]     # (k_ingest_pack or k_ingest: the first launch of a step)
+# a step ends with its last slab reduction (k_reduce_scatter / k_reduce_scatter_ingest: the update, and -- in a loop that declares its
+# next minibatch, clstm_net_train_step_next -- the next step's ingest): the launch behind it is the first of the next step
+red = lambda r: "clstm::k_reduce_scatter" in r["Kernel_Name"]
+idx = [i for i in range(1, len(rows)) if red(rows[i - 1]) and not red(rows[i])]
 # the step of MEDIAN length (the first step behind every fence of the timed blocks and the host-paced enqueue burst at the end are longer)
 length = lambda j: int(rows[idx[j + 1]]["Start_Timestamp"]) - int(rows[idx[j]]["Start_Timestamp"])
 j = sorted(range(len(idx) - 1), key=length)[(len(idx) - 1) // 2]
