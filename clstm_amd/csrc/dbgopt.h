@@ -11,6 +11,11 @@
 // hipGraph), dw_x3 / gemm_x3 (1; 0: the f32 MFMA for the fused launch's weight-gradient items / the softmax layer's backward
 // pair -- what clstm_net_set_strict_f32 selects per net), update_repack (1; 0: the fused update of a one-call training step leaves
 // the packed parameter copies of a narrow layer to the next step's ingest launch).
+// Round 6: fwd_mfma / bwd_mfma (0 never, 1 from 640 lines, 2 always: the batched-MFMA narrow recurrences), bwd_mfma_rows,
+// bwd_mfma_fused, split_terms (3; 2: two-term split of the backward products), ctc_float (0; 1: float-only log_add),
+// dw_slab_tiles / dw_chunk / dw_tail_parts / dw_tail_chunks (weight-gradient slab geometry), dw_ilv (0; 1: conversion between the
+// MFMAs of the weight-gradient items -- measured slower), x3_coal / x3_ilv (1 / 1: gemm_x3_128_kernel's row-per-load mapping and
+// interleaved conversion; 0: the round-4 forms).
 #pragma once
 #include <cstdlib>
 #include <map>
