@@ -98,6 +98,7 @@ class Network:
 
     # -- data ------------------------------------------------------------------------------
     def set_batch(self, T):
+        self._declared = None
         self.T = [int(t) for t in T]
         self.N = int(sum(self.T))
         t = i32(self.T)
@@ -118,6 +119,9 @@ class Network:
         self.lib.call("clstm_net_set_inputs_d", self.h, ptr(x_dev))
 
     def forward(self):
+        if getattr(self, "_declared", None):      # a minibatch declared by the last train step becomes the current one
+            self.T, self.N = self._declared
+            self._declared = None
         self.lib.call("clstm_net_forward", self.h)
 
     def outputs(self):
@@ -182,10 +186,12 @@ class Network:
         step's last launch and the next call -- which must pass that very minibatch -- starts with its forward launch."""
         Tl, t, labels, L = prep
         self.T, self.N = Tl, int(sum(Tl))
+        self._declared = None
         if next_prep is None:
             self.lib.call("clstm_net_train_step", self.h, ptr(t), len(Tl), ptr(x_dev), ptr(labels), ptr(L))
         else:
             nTl, nt, nlabels, nL = next_prep
+            self._declared = (nTl, int(sum(nTl)))
             self.lib.call("clstm_net_train_step_next", self.h, ptr(t), len(Tl), ptr(x_dev), ptr(labels), ptr(L),
                           ptr(nt), len(nTl), ptr(next_x_dev), ptr(nlabels), ptr(nL))
 

@@ -272,6 +272,18 @@ def test_train_step_next_equals_train_step(backend, nh, precision):
                 b.decode()
     assert [d.tolist() for d in a.decode()] == [d.tolist() for d in b.decode()]
     assert np.array_equal(a.outputs(), b.outputs())
+    # a declared minibatch can also be adopted by an explicit forward pass (its outputs are then addressable), and frames set
+    # by hand replace it: neither may leave a stale declaration behind
+    prep6, x6, T6, trs6 = batches[6]
+    a.train_step_prepared(batches[5][0], batches[5][1])
+    b.train_step_prepared(batches[5][0], batches[5][1], prep6, x6)
+    a.set_batch(T6); a.set_inputs_device(x6); a.forward()
+    b.forward()
+    assert np.array_equal(a.outputs(), b.outputs())
+    a.train_step_prepared(prep6, x6)
+    b.train_step_prepared(prep6, x6)
+    assert np.array_equal(a.get_params(), b.get_params())
+    tails0 += 1                             # (the step above carried batch 6; the explicit forward adopted it, nobody "used" it)
     assert count(19) - tails0 == 5          # five steps carried a next minibatch in their last launch ...
     assert count(20) - used0 == 4           # ... four of which the next call used (one was declared and not brought)
 
