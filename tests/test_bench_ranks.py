@@ -110,3 +110,33 @@ def test_bench_gpus2_on_the_real_library_sharing_one_gpu():
     assert "peer-read" in ar["impl"]
     assert r.stderr.count("clstm_comm_peer_active = 1") == 2       # every rank says at start-up which exchange it uses
     assert out["secondary"] is None and out["cpu_baseline"] is None and out["strict_f32"] is None
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_on_one_gpu():
+    """The driver's command on one GPU (short blocks): ONE JSON line with the contract's fields -- metric / value / unit / n_gpus /
+    steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, the `roofline`
+    and `cpu_baseline` objects, and `validity` (the timed steps updated the parameters); value = lines per step / ms_per_step."""
+    env = dict(os.environ, CLSTM_BENCH_MIN_TIMED_S="0.2", CLSTM_BENCH_MIN_WARMUP_S="0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-secondary"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["metric"].startswith("text-line images/sec") and out["unit"] == "lines/s"
+    assert out["n_gpus"] == 1 and out["steps"] == 5 and out["warmup"] == 2
+    assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["data"] == "synthetic" and out["dtype"].startswith("f32")
+    assert "workload" in out["config"] and out["config"]["minibatch_per_gpu"] == 64
+    assert abs(out["value"] - 64 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-2
+    rf = out["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf and "whole_step" in rf
+    cb = out["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "lines/s" and cb["sample"]
+    v = out["validity"]
+    assert v["device_errors"] == "none" and v["params_finite"] is True and v["max_param_change"] > 0
+    assert "clstm_net_train_step_next" in out["config"]["step_call"]
