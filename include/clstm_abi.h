@@ -223,7 +223,7 @@ int clstm_net_reset_timing(clstm_net* net);
 int clstm_net_train_step(clstm_net* net, const int* T_h, int bs, const float* x_d, const int* labels_h,
                          const int* L_h);
 /* clstm_net_train_step for a loop that knows its NEXT minibatch (a data loader one minibatch ahead: what clstmocrtrain's
- * sample loop, clstmocrtrain.cc:160-172, is once its lines are batched).  Tn_h / bsn / xn_d / labels_n_h / Ln_h describe the
+ * sample loop, clstmocrtrain.cc:167-172, is once its lines are batched).  Tn_h / bsn / xn_d / labels_n_h / Ln_h describe the
  * minibatch of the next call in the same form (all NULL / 0: exactly clstm_net_train_step).  The front half of that next step --
  * batch geometry, the host half of its alignment, the copy of its frames into the net's input block, of its line offsets and CTC
  * metadata -- is done by THIS call: by extra workgroups of this step's last launch (slab reduction + update), so the next
